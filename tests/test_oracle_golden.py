@@ -1,0 +1,85 @@
+"""The CPU oracle against every known-answer the reference holds for the path
+(SURVEY.md section 8c).  CPU only."""
+import numpy as np
+import pytest
+
+from tests import golden
+
+
+def test_keccak_vectors(oracle):
+    for v in golden.keccak_vectors():
+        assert oracle.keccak256(bytes.fromhex(v["msg"])).hex() == v["digest"], v["source"]
+
+
+def test_keccak_with_prefix_equals_concat(oracle):
+    rng = np.random.default_rng(7)
+    for plen, dlen in [(0, 0), (1, 0), (0, 1), (1, 113), (1, 135), (1, 136), (2, 271), (137, 300)]:
+        p = rng.integers(0, 256, plen, dtype=np.uint8).tobytes()
+        d = rng.integers(0, 256, dlen, dtype=np.uint8).tobytes()
+        assert oracle.keccak256_with_prefix(p, d) == oracle.keccak256(p + d)
+
+
+def test_keccak_typed_tx_hash_via_prefix(oracle):
+    # transaction.zig:283-303: the 1559 vector is type byte 0x02 || rlp
+    v = golden.keccak_vectors()[4]
+    msg = bytes.fromhex(v["msg"])
+    assert msg[0] == 0x02
+    assert oracle.keccak256_with_prefix(msg[:1], msg[1:]).hex() == v["digest"]
+
+
+def test_keccak_f1600_zero_state(oracle):
+    # Keccak-f[1600] on the all-zero state, first lane (public KAT of the permutation)
+    st = oracle.keccak_f1600(np.zeros(25, np.uint64))
+    assert int(st[0]) == 0xF1258F7940E1DDE7
+    assert int(st[24]) == 0xEAF1FF7B5CECA249
+
+
+def test_mptize_vectors(oracle):
+    for v in golden.mpt_vectors():
+        keys = [bytes.fromhex(k) for k in v["keys"]]
+        vals = [bytes.fromhex(x) for x in v["values"]]
+        assert oracle.mptize(keys, vals).hex() == v["root"], v["name"]
+
+
+def test_mptize_rejects_unsorted(oracle):
+    with pytest.raises(ValueError):
+        oracle.mptize([b"\x02", b"\x01"], [b"a", b"b"])
+    with pytest.raises(ValueError):
+        oracle.mptize([b"\x01", b"\x01"], [b"a", b"b"])
+
+
+def test_trie_build_matches_mptize(oracle):
+    for v in golden.mpt_vectors():
+        keys = [bytes.fromhex(k) for k in v["keys"]]
+        vals = [bytes.fromhex(x) for x in v["values"]]
+        t = oracle.Trie(keys, vals)
+        assert t.root().hex() == v["root"], v["name"]
+
+
+def test_fixture_tx_and_withdrawal_roots(oracle):
+    fx = golden.fixtures()
+    n_tx = n_wd = 0
+    for c in fx["cases"]:
+        for b in c["blocks"]:
+            items = [bytes.fromhex(x) for x in b["tx_values"]]
+            assert oracle.index_root_rlp(items).hex() == b["transactions_trie"], c["name"]
+            n_tx += 1
+            if "withdrawals_root" in b:
+                items = [bytes.fromhex(x) for x in b["withdrawal_values"]]
+                assert oracle.index_root_rlp(items).hex() == b["withdrawals_root"], c["name"]
+                n_wd += 1
+    assert (n_tx, n_wd) == (87, 87)
+
+
+def test_fixture_state_roots(oracle):
+    fx = golden.fixtures()
+    n_gen = n_post = 0
+    for c in fx["cases"]:
+        acc = golden.accounts_of(c["pre"], fx["codes"])
+        assert oracle.state_root(acc).hex() == c["genesis_state_root"], c["name"]
+        n_gen += 1
+        if "post" in c:
+            acc = golden.accounts_of(c["post"], fx["codes"])
+            assert oracle.state_root(acc).hex() == c["post_state_root"], c["name"]
+            n_post += 1
+    assert (n_gen, n_post) == (84, 73)

@@ -1,0 +1,156 @@
+"""Proof verification in the oracle: derived parity --
+proofs are extracted from tries whose construction is pinned by the
+reference's vectors, must verify, and every mutation must be rejected."""
+import numpy as np
+import pytest
+
+from tests import golden
+from tests.witness_util import random_kv, pack_proofs
+
+
+def test_proofs_from_reference_vectors(oracle):
+    o = oracle
+    for v in golden.mpt_vectors():
+        keys = [bytes.fromhex(k) for k in v["keys"]]
+        vals = [bytes.fromhex(x) for x in v["values"]]
+        if not keys:
+            continue
+        t = o.Trie(keys, vals)
+        root = t.root()
+        assert root.hex() == v["root"]
+        for k, val in zip(keys, vals):
+            proof = t.prove(k)
+            st, got = o.mpt_verify(root, k, proof)
+            assert st == o.PROOF_PRESENT and got == val, (v["name"], k.hex())
+
+
+def test_exclusion_on_reference_vectors(oracle):
+    o = oracle
+    v = golden.mpt_vectors()[6]
+    keys = [bytes.fromhex(k) for k in v["keys"]]
+    vals = [bytes.fromhex(x) for x in v["values"]]
+    t = o.Trie(keys, vals)
+    root = t.root()
+    for k in [b"\x00\x00\x00", b"\x34\x57", b"\x34\x57\x82", b"\x34\x5f\x02\x04", b"\xff\x01\x02", b"\x35",
+              b"\x34\x57\x81\x00", b"\xef\x01\x02\x03\x04"]:
+        assert k not in keys
+        st, got = o.mpt_verify(root, k, t.prove(k))
+        assert st == o.PROOF_ABSENT and got is None, k.hex()
+
+
+@pytest.mark.parametrize("n,key_len,shared", [(1, 32, 0), (2, 32, 0), (17, 32, 0), (300, 32, 0), (300, 32, 6),
+                                                (64, 2, 0), (200, 3, 0), (50, 1, 0)])
+def test_random_tries_inclusion_exclusion(oracle, n, key_len, shared):
+    o = oracle
+    rng = np.random.default_rng(n * 1000 + key_len + shared)
+    keys, vals = random_kv(rng, n, key_len, 1, 70, shared)
+    t = o.Trie(keys, vals)
+    root = t.root()
+    assert root == o.mptize(keys, vals)
+    kset = set(keys)
+    for k, val in zip(keys, vals):
+        st, got = o.mpt_verify(root, k, t.prove(k))
+        assert st == o.PROOF_PRESENT and got == val
+    for _ in range(100):
+        k = bytearray(rng.integers(0, 256, key_len, dtype=np.uint8).tobytes())
+        for i in range(shared // 2):
+            k[i] = 0xAB
+        k = bytes(k)
+        if k in kset:
+            continue
+        st, got = o.mpt_verify(root, k, t.prove(k))
+        assert st == o.PROOF_ABSENT
+
+
+def test_mutations_rejected(oracle):
+    o = oracle
+    rng = np.random.default_rng(99)
+    keys, vals = random_kv(rng, 200, 32, 1, 70)
+    t = o.Trie(keys, vals)
+    root = t.root()
+    for k in keys[:40]:
+        proof = t.prove(k)
+        # any single bit flip in any node breaks a hash link
+        for _ in range(8):
+            i = int(rng.integers(0, len(proof)))
+            nd = bytearray(proof[i])
+            j = int(rng.integers(0, len(nd)))
+            nd[j] ^= 1 << int(rng.integers(0, 8))
+            bad = proof[:i] + [bytes(nd)] + proof[i + 1:]
+            st, _ = o.mpt_verify(root, k, bad)
+            assert st == o.PROOF_BAD_HASH
+        # wrong root
+        st, _ = o.mpt_verify(bytes(32), k, proof)
+        assert st == o.PROOF_BAD_HASH
+        # truncated / extended proofs
+        if len(proof) > 1:
+            st, _ = o.mpt_verify(root, k, proof[:-1])
+            assert st == o.PROOF_MISSING_NODE
+        st, _ = o.mpt_verify(root, k, proof + [proof[-1]])
+        assert st == o.PROOF_EXTRA_NODES
+        st, _ = o.mpt_verify(root, k, [])
+        assert st == o.PROOF_INVALID_EMPTY
+        # truncated node bytes
+        nd = proof[-1][:-1]
+        st, _ = o.mpt_verify(root, k, proof[:-1] + [nd])
+        assert st == o.PROOF_BAD_HASH
+
+
+def test_malformed_nodes_with_matching_hash(oracle):
+    """A root that commits to garbage: hash passes, structure checks fire."""
+    o = oracle
+    key = bytes(32)
+
+    def run(node):
+        return o.mpt_verify(o.keccak256(node), key, [node])[0]
+
+    assert run(b"\x80") == o.PROOF_BAD_NODE                      # a string, not a list
+    assert run(b"\xc0") == o.PROOF_BAD_NODE                      # empty list: 0 items
+    assert run(b"\xc1\x80") == o.PROOF_BAD_NODE                  # 1 item
+    assert run(b"\xc3\x80\x80\x80") == o.PROOF_BAD_NODE          # 3 items
+    assert run(b"\xc2\x80") == o.PROOF_BAD_RLP                   # payload shorter than header says
+    assert run(b"\xc1\x80\x80") == o.PROOF_BAD_RLP               # trailing byte
+    assert run(b"\xc2\x81\x05") == o.PROOF_BAD_RLP               # non-canonical single byte
+    assert run(b"\xf8\x02\x80\x80") == o.PROOF_BAD_RLP           # long form for a short list
+    assert run(b"\xc2\x80\x80") == o.PROOF_BAD_NODE              # 2 items, empty HP path string
+    assert run(b"\xc2\x40\x80") == o.PROOF_BAD_NODE              # HP flag 4
+    assert run(b"\xc2\x21\x80") == o.PROOF_BAD_NODE              # even leaf with non-zero pad nibble
+    assert run(b"\xc2\x00\x80") == o.PROOF_BAD_NODE              # extension with empty path
+    assert run(b"\xc3\x11\x81\x80") == o.PROOF_BAD_NODE          # extension ref of length 1
+    assert run(b"\xc2\x20\x80") == o.PROOF_ABSENT                # leaf, empty path, key has 64 nibbles left
+    assert run(bytes([0xc0 + 18]) + b"\x80" * 18) == o.PROOF_BAD_NODE   # 18 items
+    assert run(bytes([0xc0 + 17]) + b"\x80" * 17) == o.PROOF_ABSENT     # empty branch
+    assert run(bytes([0xc0 + 18]) + b"\x80" * 16 + b"\xc1\x80") == o.PROOF_BAD_NODE  # list in value slot
+    assert run(bytes([0xc0 + 18]) + b"\x81\x80" + b"\x80" * 16) == o.PROOF_BAD_NODE  # 1-byte ref
+
+
+def test_embedded_nodes_and_branch_values(oracle):
+    o = oracle
+    # short keys + short values force embedded (<32 B) children
+    keys = [bytes([a, b]) for a in (0x10, 0x11, 0x20) for b in (0x00, 0x01, 0xF0)]
+    keys = sorted(keys + [b"\x10", b"\x20"])
+    vals = [bytes([i + 1]) * 2 for i in range(len(keys))]
+    t = o.Trie(keys, vals)
+    root = t.root()
+    assert root == o.mptize(keys, vals)
+    for k, v in zip(keys, vals):
+        st, got = o.mpt_verify(root, k, t.prove(k))
+        assert st == o.PROOF_PRESENT and got == v, k.hex()
+    for k in [b"\x10\x02", b"\x30", b"\x11", b"\x10\x00\x00", b"", b"\x20\xf0\x01"]:
+        st, _ = o.mpt_verify(root, k, t.prove(k))
+        assert st == o.PROOF_ABSENT, k.hex()
+
+
+def test_batch_matches_single(oracle):
+    o = oracle
+    rng = np.random.default_rng(5)
+    keys, vals = random_kv(rng, 128, 32, 1, 70)
+    t = o.Trie(keys, vals)
+    root = t.root()
+    proofs = [t.prove(k) for k in keys]
+    nodes, node_off, pfn = pack_proofs(proofs)
+    karr = np.frombuffer(b"".join(keys), np.uint8)
+    st, vo, vl = o.mpt_verify_batch(np.frombuffer(root, np.uint8), None, karr, 32, nodes, node_off, pfn)
+    assert (st == o.PROOF_PRESENT).all()
+    for i, v in enumerate(vals):
+        assert nodes[int(vo[i]):int(vo[i]) + int(vl[i])].tobytes() == v
