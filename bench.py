@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--proofs P] [--workload config3|config2]
+
+A "step" = one pass of the hot path over one batch of synthetic input already
+resident in HBM:
+  config3 (default, the configuration the metric is quoted on): verify
+      P = 100 000 synthetic depth-8 account proofs against one state root
+      (7 full 532-byte branch nodes + one 112-byte account leaf per proof, each
+      proof shipped as its own node list, 0.5 % corrupted + 0.5 % exclusion
+      proofs), reduce to one pass/fail word per root.
+  config2: Keccak-256 of 1 048 576 x 136-byte messages (sponge kernel only).
+
+N > 1: one process per GPU (torchrun), proofs sharded by the top key nibble,
+every rank verifies its own P proofs (weak scaling); the only data-path
+collective is the all-reduce of the per-root failure count (RCCL).  value =
+proofs of ALL ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (HBM; algorithmic bytes per
+launch / average kernel duration measured with HIP events on the launch
+stream) and, at N = 1, `cpu_baseline` (the CPU oracle timed on this host).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline_config3(w, target_seconds):
+    """The CPU oracle (restatement of the reference's scalar path) on a bounded sample of the same
+    workload, 1 core -- phant's MPT code is single-threaded."""
+    import numpy as np
+    from oracle import oracle as O
+
+    b = w.batch
+    n = b.n
+    probe = min(n, 2000)
+
+    def run(cnt):
+        nn = cnt * w.nodes_per_proof
+        nodes = b.nodes[: int(b.node_off[nn].item())].cpu().numpy()
+        node_off = b.node_off[: nn + 1].cpu().numpy().astype(np.uint64)
+        pfn = b.proof_first_node[: cnt + 1].cpu().numpy().astype(np.uint32)
+        keys = b.keys[:cnt].cpu().numpy()
+        roots = b.roots.cpu().numpy()
+        t0 = time.perf_counter()
+        st, _, _ = O.mpt_verify_batch(roots, None, keys, 32, nodes, node_off, pfn)
+        dt = time.perf_counter() - t0
+        return st, dt
+
+    st, dt = run(probe)
+    rate = probe / dt
+    cnt = int(max(probe, min(n, rate * target_seconds)))
+    st, dt = run(cnt)
+    ok = bool((st == w.expected[:cnt].cpu().numpy()).all())
+    return {"value": cnt / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": f"first {cnt} of the {n} config-3 proofs, oracle/verify.c single-threaded, {dt:.1f} s",
+            "host_cpus": os.cpu_count(), "statuses_match_gpu_expected": ok}
+
+
+def cpu_baseline_config2(blob, n, target_seconds):
+    import numpy as np
+    from oracle import oracle as O
+
+    cnt = min(n, 200_000)
+    host = blob[: cnt * 136].cpu().numpy()
+    off = np.arange(cnt + 1, dtype=np.uint64) * 136
+    t0 = time.perf_counter()
+    O.keccak256_batch(host, off)
+    dt = time.perf_counter() - t0
+    reps = max(1, int(target_seconds / max(dt, 1e-3)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.keccak256_batch(host, off)
+    dt = time.perf_counter() - t0
+    return {"value": cnt * reps / dt, "unit": "hashes/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x first {cnt} messages, oracle/keccak.c single-threaded, {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import phant_amd
+    from phant_amd import mpt as M
+    from phant_amd.crypto import hasher as H
+
+    ctx = phant_amd.default_context(local_rank)  # bound to torch's current stream on this device
+
+    if args.workload == "config3":
+        w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
+                                              world=world, ctx=ctx)
+        b = w.batch
+        n_units = b.n
+        alg_bytes = b.algorithmic_bytes()
+        status = torch.empty(n_units, dtype=torch.uint8, device=dev)
+        fails = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def step():
+            M.verify_batch_dev(b, status=status, ctx=ctx)
+            M.verdict_dev(status, None, 1, out=fails, ctx=ctx)
+            if world > 1:
+                dist.all_reduce(fails)  # one pass/fail word per root, over xGMI (RCCL)
+
+        def kernel_only():
+            M.verify_batch_dev(b, status=status, ctx=ctx)
+
+        metric, unit = "mpt_proofs_verified_per_sec_depth%d" % args.depth, "proofs/s"
+        workload = (f"config3: {args.proofs} synthetic depth-{args.depth} account proofs per GPU against one state "
+                    f"root ({w.nodes_per_proof - 1} x 532 B full branches + 112 B leaf, {w.bytes_per_proof} B and "
+                    f"{w.perms_per_proof} Keccak-f per proof, 1% corrupted/exclusion, no cross-proof dedup)")
+    else:
+        n_units = 1 << 20
+        g = torch.Generator(device=dev)
+        g.manual_seed(1 + rank)
+        blob = torch.randint(0, 256, (n_units * 136,), dtype=torch.uint8, device=dev, generator=g)
+        out = torch.empty((n_units, 32), dtype=torch.uint8, device=dev)
+        alg_bytes = n_units * 168
+
+        def step():
+            H.keccak256_fixed_dev(blob, 136, n_units, out=out, ctx=ctx)
+
+        kernel_only = step
+        metric, unit = "keccak256_136B_hashes_per_sec", "hashes/s"
+        workload = "config2: 1048576 x 136-byte Keccak-256 per GPU (2 Keccak-f per message, 168 B per message)"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was timed
+    if args.workload == "config3":
+        assert torch.equal(status, w.expected), "verify statuses differ from the constructed expectation"
+        exp_fail = torch.tensor([w.n_invalid], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(exp_fail)
+        assert int(fails.item()) == int(exp_fail.item()), (int(fails.item()), int(exp_fail.item()))
+
+    # dominant kernel alone, HIP events on the launch stream (phant_timing)
+    ctx.timing(True)
+    kms = []
+    for _ in range(max(5, min(args.steps, 50))):
+        kernel_only()
+        kms.append(ctx.last_kernel_ms())
+    ctx.timing(False)
+    k_avg_ms = sum(kms) / len(kms)
+    achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+
+    value = n_units * world * args.steps / elapsed
+    line = {
+        "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "mpt_verify_fused_kernel" if args.workload == "config3" else "keccak256_fixed_kernel",
+                     "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if args.workload == "config3":
+            line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

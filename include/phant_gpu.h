@@ -1,0 +1,195 @@
+/*
+ * phant_gpu.h -- C-ABI of libphant_gpu: the MI355X (gfx950) implementation of
+ * phant's Keccak-256 / Merkle-Patricia-Trie hot path.
+ *
+ * This is the drop-in boundary.  phant (Zig) has no FFI on this path today:
+ * `mptize` and `keccak256` are plain Zig functions.  A maintainer keeps their
+ * Zig signatures and forwards to the entry points below through `@cImport`
+ * exactly as src/blockchain/vm.zig:1-3 does for evmone and
+ * src/crypto/ecdsa.zig:2,15 for libsecp256k1 (binding shown in
+ * INTEGRATION.md).  Conventions follow those existing C boundaries:
+ *   - plain C, `extern "C"`, pointers + sizes only;
+ *   - every call returns int32_t: 0 = PHANT_OK, < 0 = PHANT_E_*; nothing
+ *     aborts or throws across the boundary.  A malformed *proof* is not an
+ *     error, it is a per-proof status byte;
+ *   - all buffers are caller-owned and only borrowed for the duration of the
+ *     call (for *_dev entry points: until the ctx stream has run the work --
+ *     phant_stream_sync);
+ *   - a ctx is externally synchronised (one thread at a time), independent
+ *     ctxs may be used concurrently (cf. the single shared *Blockchain in
+ *     src/main.zig:143-149);
+ *   - there is NO CPU fallback: without a usable gfx950 device
+ *     phant_ctx_create fails with PHANT_E_NO_DEVICE.
+ *
+ * Two families of entry points:
+ *   host form   `phant_xxx(ctx, host pointers...)`  synchronous; stages H2D,
+ *               runs the kernels, copies results back.  This is what the Zig
+ *               shim calls.
+ *   device form `phant_xxx_dev(ctx, device pointers...)`  asynchronous on the
+ *               ctx stream, inputs and outputs already resident in HBM (what
+ *               bench.py times, and what a caller that keeps witnesses on the
+ *               GPU uses).
+ */
+#ifndef PHANT_GPU_H
+#define PHANT_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define PHANT_API __attribute__((visibility("default")))
+#else
+#define PHANT_API
+#endif
+
+#define PHANT_OK 0
+#define PHANT_E_INVALID_ARG (-1)
+#define PHANT_E_OOM (-2)
+#define PHANT_E_DEVICE (-3)     /* a HIP call failed; see phant_last_error */
+#define PHANT_E_NO_DEVICE (-4)  /* no gfx950 device / device index out of range */
+#define PHANT_E_UNSORTED (-5)   /* mptize precondition, src/mpt/mpt.zig:39 */
+#define PHANT_E_UNSUPPORTED (-6)
+
+/* Per-proof status written by phant_mpt_verify_batch*.  Values < 16 other
+ * than 0 mean "the proof is valid". */
+#define PHANT_PROOF_INVALID_EMPTY 0 /* proof has no nodes */
+#define PHANT_PROOF_PRESENT 1       /* key is in the trie; value_off/len set */
+#define PHANT_PROOF_ABSENT 2        /* proof shows the key is NOT in the trie */
+#define PHANT_PROOF_BAD_HASH 16     /* a node does not hash to its reference */
+#define PHANT_PROOF_BAD_RLP 17      /* a node is not canonical RLP */
+#define PHANT_PROOF_BAD_NODE 18     /* canonical RLP but not an MPT node */
+#define PHANT_PROOF_EXTRA_NODES 19  /* walk finished with nodes left over */
+#define PHANT_PROOF_MISSING_NODE 20 /* walk needs a node the proof lacks */
+#define PHANT_PROOF_BAD_INPUT 21    /* node_off / proof_first_node inconsistent */
+
+typedef struct phant_ctx phant_ctx;
+
+#define PHANT_CTX_OWN_STREAM 1u /* flags: ignore `stream`, create a private non-blocking stream */
+
+typedef struct phant_opts {
+    uint32_t struct_size; /* = sizeof(phant_opts) */
+    int32_t device;       /* HIP device ordinal */
+    void *stream;         /* hipStream_t to run on; NULL = the device's default stream */
+    uint32_t flags;       /* PHANT_CTX_* */
+} phant_opts;
+
+PHANT_API const char *phant_version(void);
+PHANT_API int32_t phant_device_count(void);
+PHANT_API int32_t phant_ctx_create(const phant_opts *opts, phant_ctx **out);
+PHANT_API void phant_ctx_destroy(phant_ctx *ctx);
+/* message for the last failing call on this ctx ("" if none); ctx-owned */
+PHANT_API const char *phant_last_error(const phant_ctx *ctx);
+/* rebind the ctx to another hipStream_t (e.g. torch's current stream; NULL =
+ * the default stream) */
+PHANT_API int32_t phant_set_stream(phant_ctx *ctx, void *stream);
+PHANT_API int32_t phant_stream_sync(phant_ctx *ctx);
+
+/* ------------------------------------------------------------------ Keccak
+ * Replaces src/crypto/hasher.zig:4-8   `keccak256(data: []const u8) Hash32`
+ *      and src/crypto/hasher.zig:10-17 `keccak256WithPrefix(prefix, data)`.
+ * Keccak-256 = Keccak[c=512], pad 0x01..0x80, rate 136 (NOT SHA3-256). */
+PHANT_API int32_t phant_keccak256(phant_ctx *ctx, const uint8_t *data, uint64_t len,
+                                  uint8_t out[32]);
+PHANT_API int32_t phant_keccak256_with_prefix(phant_ctx *ctx, const uint8_t *prefix,
+                                              uint64_t prefix_len, const uint8_t *data,
+                                              uint64_t len, uint8_t out[32]);
+/* n messages; message i = blob[off[i] .. off[i+1]); out = n x 32 bytes.
+ * The batched form of hasher.zig:4-8 (one call per node at mpt.zig:207,245,277
+ * becomes one call per level / per witness). */
+PHANT_API int32_t phant_keccak256_batch(phant_ctx *ctx, const uint8_t *blob, const uint64_t *off,
+                                        uint32_t n, uint8_t *out);
+PHANT_API int32_t phant_keccak256_batch_dev(phant_ctx *ctx, const uint8_t *d_blob,
+                                            const uint64_t *d_off, uint32_t n, uint8_t *d_out);
+/* n messages of msg_len bytes each at d_blob + i*stride (BASELINE config 2:
+ * msg_len = stride = 136). */
+PHANT_API int32_t phant_keccak256_fixed_dev(phant_ctx *ctx, const uint8_t *d_blob,
+                                            uint32_t msg_len, uint64_t stride, uint32_t n,
+                                            uint8_t *d_out);
+
+/* ------------------------------------------------------- proof verification
+ * ABSENT in the reference: this is the call the TODO at
+ * src/engine_api/execution_payload.zig:177-178 asks for (witness field
+ * commented out at :121).  Semantics: DESIGN.md section 3, the inverse of the
+ * node encodings of src/mpt/mpt.zig:187-193,216-231,254-261,285-314.
+ *
+ *   roots            n_roots x 32 bytes
+ *   root_idx         n entries (which root proof i is against) or NULL = all 0
+ *   keys             n x key_len bytes (key_len = 32 for state/storage tries)
+ *   nodes            all proof nodes back to back, nodes_len bytes
+ *   node_off         total_nodes + 1 byte offsets into `nodes`
+ *   proof_first_node n + 1 entries: proof i = nodes
+ *                    [proof_first_node[i], proof_first_node[i+1]), root first
+ *   status           n bytes out (PHANT_PROOF_*)
+ *   value_off/len    n entries out, or NULL: for PRESENT, where in `nodes`
+ *                    the value bytes sit
+ */
+PHANT_API int32_t phant_mpt_verify_batch(phant_ctx *ctx, const uint8_t *roots, uint32_t n_roots,
+                                         const uint32_t *root_idx, const uint8_t *keys,
+                                         uint32_t key_len, const uint8_t *nodes,
+                                         uint64_t nodes_len, const uint64_t *node_off,
+                                         const uint32_t *proof_first_node, uint32_t n,
+                                         uint8_t *status, uint64_t *value_off,
+                                         uint32_t *value_len);
+PHANT_API int32_t phant_mpt_verify_batch_dev(phant_ctx *ctx, const uint8_t *d_roots,
+                                             uint32_t n_roots, const uint32_t *d_root_idx,
+                                             const uint8_t *d_keys, uint32_t key_len,
+                                             const uint8_t *d_nodes, uint64_t nodes_len,
+                                             const uint64_t *d_node_off,
+                                             const uint32_t *d_proof_first_node, uint32_t n,
+                                             uint8_t *d_status, uint64_t *d_value_off,
+                                             uint32_t *d_value_len);
+/* One verdict per root: d_fail_count[r] = number of proofs against root r
+ * whose status is not PRESENT/ABSENT (n_roots x u32, overwritten).  This is
+ * the word each rank all-reduces in the multi-GPU path. */
+PHANT_API int32_t phant_mpt_verdict_dev(phant_ctx *ctx, const uint8_t *d_status,
+                                        const uint32_t *d_root_idx, uint32_t n, uint32_t n_roots,
+                                        uint32_t *d_fail_count);
+
+/* ---------------------------------------------------------------- trie root
+ * Replaces src/mpt/mpt.zig:38 `mptize(arena, list: []const KeyVal) !Hash32`
+ * (KeyVal = mpt.zig:13-34: key bytes expanded to nibbles, value borrowed).
+ *   key i   = keys[key_off[i] .. key_off[i+1])   (bytes, any length <= 255)
+ *   value i = vals[val_off[i] .. val_off[i+1])
+ * Keys must be strictly increasing (mpt.zig:39) else PHANT_E_UNSORTED.
+ * n == 0 gives mpt.zig:10 `empty_mpt_root`. */
+PHANT_API int32_t phant_mpt_root(phant_ctx *ctx, const uint8_t *keys, const uint32_t *key_off,
+                                 const uint8_t *vals, const uint64_t *val_off, uint32_t n,
+                                 uint8_t out[32]);
+
+/* Callers of mptize ("next" rows):
+ * src/blockchain/blockchain.zig:209-235 calculateMPTRoot -- key rlp(index) */
+PHANT_API int32_t phant_index_root_rlp(phant_ctx *ctx, const uint8_t *items,
+                                       const uint64_t *item_off, uint32_t n, uint8_t out[32]);
+/* src/engine_api/execution_payload.zig:125-158 toBlock -- key = 32-byte
+ * big-endian index */
+PHANT_API int32_t phant_index_root_be32(phant_ctx *ctx, const uint8_t *items,
+                                        const uint64_t *item_off, uint32_t n, uint8_t out[32]);
+
+/* State root: the `StateDB.root()` the reference lacks
+ * (src/blockchain/blockchain.zig:83-85).  Inputs are the AccountState fields
+ * of src/state/types.zig:13-20 in struct-of-arrays form:
+ *   addrs n x 20, nonces n, balances n x 32 (big-endian u256),
+ *   code blob + code_off[n+1], storage slots slot_keys/slot_vals m x 32
+ *   (big-endian u256) with account i owning [slot_first[i], slot_first[i+1]).
+ * Zero-valued slots are skipped (src/state/statedb.zig:112-119). */
+PHANT_API int32_t phant_state_root(phant_ctx *ctx, const uint8_t *addrs, const uint64_t *nonces,
+                                   const uint8_t *balances, const uint8_t *code,
+                                   const uint64_t *code_off, const uint8_t *slot_keys,
+                                   const uint8_t *slot_vals, const uint32_t *slot_first,
+                                   uint32_t n, uint8_t out[32]);
+
+/* -------------------------------------------------------------- measurement
+ * Time of the last *_dev kernel sequence on the ctx stream, measured with HIP
+ * events recorded on that stream around the launches (bench.py uses this for
+ * `roofline.achieved`).  Enable with phant_timing(ctx, 1). */
+PHANT_API int32_t phant_timing(phant_ctx *ctx, int32_t enable);
+PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHANT_GPU_H */

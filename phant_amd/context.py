@@ -1,0 +1,80 @@
+"""phant_ctx wrapper: one context per (device, stream)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Owns a phant_ctx.  Externally synchronised, like the C object."""
+
+    def __init__(self, device: int | None = None, use_torch_stream: bool = True):
+        lib = L.lib()
+        if not torch.cuda.is_available():
+            raise L.PhantError(L.E_NO_DEVICE, "no GPU visible (phant_amd has no CPU fallback)")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        # torch's current stream on that device (handle 0 = the default stream), or a private one
+        stream, flags = None, 1  # PHANT_CTX_OWN_STREAM
+        if use_torch_stream:
+            stream, flags = torch.cuda.current_stream(self.device).cuda_stream or None, 0
+        opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
+        h = C.c_void_p()
+        rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))
+        if rc != L.OK:
+            raise L.PhantError(rc, "phant_ctx_create failed (needs a gfx950 device)")
+        self._h = h
+        self._lib = lib
+
+    # -- plumbing --
+    def check(self, rc: int):
+        if rc != L.OK:
+            raise L.PhantError(rc, self._lib.phant_last_error(self._h).decode())
+
+    def sync(self):
+        self.check(self._lib.phant_stream_sync(self._h))
+
+    def timing(self, enable: bool):
+        self.check(self._lib.phant_timing(self._h, 1 if enable else 0))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        self.check(self._lib.phant_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.phant_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+
+_default: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    ctx = _default.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _default[device] = ctx
+    return ctx

@@ -1,0 +1,404 @@
+// capi.hip -- the C-ABI of include/phant_gpu.h: context, device workspace,
+// host-form (staging) and device-form (resident) entry points.
+//
+// No CPU fallback lives here: every entry point ends in a HIP kernel launch;
+// without a gfx950 device phant_ctx_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/phant_gpu.h"
+#include "launch.h"
+#include "trie_build.h"
+
+struct phant_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // bump-allocated device workspace for the host-form calls
+    uint8_t* ws = nullptr;
+    size_t ws_cap = 0, ws_used = 0;
+    // stream-side timing of the last device-form call
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_pending = false;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            changed = hipSetDevice(dev) == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+int32_t fail(phant_ctx* c, int32_t code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(c, call)                                               \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return fail((c), PHANT_E_DEVICE, #call, e_); \
+    } while (0)
+
+constexpr size_t WS_ALIGN = 256;
+
+// Reserve `total` bytes of workspace (drops previous contents).
+int32_t ws_reset(phant_ctx* c, size_t total) {
+    c->ws_used = 0;
+    if (total <= c->ws_cap) return PHANT_OK;
+    if (c->ws) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_cap = 0;
+    }
+    size_t cap = total + total / 4 + (1u << 20);
+    hipError_t e = hipMalloc((void**)&c->ws, cap);
+    if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(workspace)", e);
+    c->ws_cap = cap;
+    return PHANT_OK;
+}
+size_t ws_round(size_t n) { return (n + WS_ALIGN - 1) / WS_ALIGN * WS_ALIGN; }
+template <class T>
+T* ws_take(phant_ctx* c, size_t count) {
+    T* p = reinterpret_cast<T*>(c->ws + c->ws_used);
+    c->ws_used += ws_round(count * sizeof(T));
+    return p;
+}
+
+struct TimedRegion {
+    phant_ctx* c;
+    explicit TimedRegion(phant_ctx* ctx) : c(ctx) {
+        if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~TimedRegion() {
+        if (c->timing) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            c->ev_pending = true;
+        }
+    }
+};
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+const char* phant_version(void) { return "phant_gpu 0.1 (gfx950)"; }
+
+int32_t phant_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
+    if (!out) return PHANT_E_INVALID_ARG;
+    *out = nullptr;
+    int dev = 0;
+    void* stream = nullptr;
+    bool own = false;
+    if (opts) {
+        if (opts->struct_size < sizeof(phant_opts)) return PHANT_E_INVALID_ARG;
+        dev = opts->device;
+        stream = opts->stream;
+        own = (opts->flags & PHANT_CTX_OWN_STREAM) != 0;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || dev < 0 || dev >= n) return PHANT_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return PHANT_E_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PHANT_E_NO_DEVICE;
+    phant_ctx* c = new (std::nothrow) phant_ctx();
+    if (!c) return PHANT_E_OOM;
+    c->device = dev;
+    DeviceGuard g(dev);
+    if (!own) {
+        c->stream = (hipStream_t)stream;  // nullptr = the default stream
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return PHANT_E_DEVICE;
+        }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        phant_ctx_destroy(c);
+        return PHANT_E_DEVICE;
+    }
+    *out = c;
+    return PHANT_OK;
+}
+
+void phant_ctx_destroy(phant_ctx* c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* phant_last_error(const phant_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int32_t phant_set_stream(phant_ctx* c, void* stream) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) {
+        (void)hipStreamDestroy(c->stream);
+        c->own_stream = false;
+    }
+    c->stream = (hipStream_t)stream;  // nullptr = the default stream
+    return PHANT_OK;
+}
+
+int32_t phant_stream_sync(phant_ctx* c) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_timing(phant_ctx* c, int32_t enable) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    c->timing = enable != 0;
+    c->ev_pending = false;
+    return PHANT_OK;
+}
+
+int32_t phant_last_kernel_ms(phant_ctx* c, float* ms) {
+    if (!c || !ms) return PHANT_E_INVALID_ARG;
+    if (!c->ev_pending) return fail(c, PHANT_E_INVALID_ARG, "no timed call pending");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PHANT_OK;
+}
+
+/* ------------------------------------------------------------------ Keccak */
+
+int32_t phant_keccak256_batch_dev(phant_ctx* c, const uint8_t* d_blob, const uint64_t* d_off,
+                                  uint32_t n, uint8_t* d_out) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!d_off || !d_out || !aligned16(d_out)) return fail(c, PHANT_E_INVALID_ARG, "keccak256_batch_dev: null or unaligned pointer");
+    DeviceGuard g(c->device);
+    TimedRegion t(c);
+    HIP_TRY(c, phant::launch_keccak256_var(d_blob, d_off, n, d_out, c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_keccak256_fixed_dev(phant_ctx* c, const uint8_t* d_blob, uint32_t msg_len,
+                                  uint64_t stride, uint32_t n, uint8_t* d_out) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!d_out || !aligned16(d_out) || (!d_blob && msg_len) || (stride < msg_len && n > 1))
+        return fail(c, PHANT_E_INVALID_ARG, "keccak256_fixed_dev: bad argument");
+    DeviceGuard g(c->device);
+    TimedRegion t(c);
+    HIP_TRY(c, phant::launch_keccak256_fixed(d_blob, msg_len, stride, n, d_out, c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_keccak256_batch(phant_ctx* c, const uint8_t* blob, const uint64_t* off, uint32_t n,
+                              uint8_t* out) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!off || !out) return fail(c, PHANT_E_INVALID_ARG, "keccak256_batch: null pointer");
+    for (uint32_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i]) return fail(c, PHANT_E_INVALID_ARG, "keccak256_batch: offsets not monotone");
+    const uint64_t lo = off[0], hi = off[n];
+    const size_t blob_len = (size_t)(hi - lo);
+    if (blob_len && !blob) return fail(c, PHANT_E_INVALID_ARG, "keccak256_batch: null blob");
+    DeviceGuard g(c->device);
+    int32_t rc = ws_reset(c, ws_round(blob_len + 16) + ws_round((size_t)(n + 1) * 8) + ws_round((size_t)n * 32));
+    if (rc) return rc;
+    uint8_t* d_blob = ws_take<uint8_t>(c, blob_len + 16);
+    uint64_t* d_off = ws_take<uint64_t>(c, (size_t)n + 1);
+    uint8_t* d_out = ws_take<uint8_t>(c, (size_t)n * 32);
+    std::vector<uint64_t> rel((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; ++i) rel[i] = off[i] - lo;
+    if (blob_len) HIP_TRY(c, hipMemcpyAsync(d_blob, blob + lo, blob_len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, phant::launch_keccak256_var(d_blob, d_off, n, d_out, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_keccak256(phant_ctx* c, const uint8_t* data, uint64_t len, uint8_t out[32]) {
+    const uint64_t off[2] = {0, len};
+    return phant_keccak256_batch(c, data, off, 1, out);
+}
+
+int32_t phant_keccak256_with_prefix(phant_ctx* c, const uint8_t* prefix, uint64_t prefix_len,
+                                    const uint8_t* data, uint64_t len, uint8_t out[32]) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if ((prefix_len && !prefix) || (len && !data)) return fail(c, PHANT_E_INVALID_ARG, "keccak256_with_prefix: null pointer");
+    // hasher.zig:10-17 streams prefix then data through one sponge: same as
+    // hashing the concatenation
+    uint8_t* cat = (uint8_t*)std::malloc((size_t)(prefix_len + len) + 1);
+    if (!cat) return fail(c, PHANT_E_OOM, "keccak256_with_prefix: host staging");
+    if (prefix_len) std::memcpy(cat, prefix, (size_t)prefix_len);
+    if (len) std::memcpy(cat + prefix_len, data, (size_t)len);
+    const uint64_t off[2] = {0, prefix_len + len};
+    const int32_t rc = phant_keccak256_batch(c, cat, off, 1, out);
+    std::free(cat);
+    return rc;
+}
+
+/* ------------------------------------------------------- proof verification */
+
+int32_t phant_mpt_verify_batch_dev(phant_ctx* c, const uint8_t* d_roots, uint32_t n_roots,
+                                   const uint32_t* d_root_idx, const uint8_t* d_keys,
+                                   uint32_t key_len, const uint8_t* d_nodes, uint64_t nodes_len,
+                                   const uint64_t* d_node_off, const uint32_t* d_proof_first_node,
+                                   uint32_t n, uint8_t* d_status, uint64_t* d_value_off,
+                                   uint32_t* d_value_len) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!d_roots || n_roots == 0 || !d_node_off || !d_proof_first_node || !d_status || (key_len && !d_keys) ||
+        key_len > 0x3fffffffu)
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_batch_dev: bad argument");
+    phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len,
+                        d_node_off, d_proof_first_node, n, d_status, d_value_off, d_value_len};
+    DeviceGuard g(c->device);
+    TimedRegion t(c);
+    HIP_TRY(c, phant::launch_mpt_verify_fused(a, c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_mpt_verdict_dev(phant_ctx* c, const uint8_t* d_status, const uint32_t* d_root_idx,
+                              uint32_t n, uint32_t n_roots, uint32_t* d_fail_count) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n_roots == 0 || !d_fail_count || (n && !d_status))
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verdict_dev: bad argument");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, phant::launch_mpt_verdict(d_status, d_root_idx, n, n_roots, d_fail_count, c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_mpt_verify_batch(phant_ctx* c, const uint8_t* roots, uint32_t n_roots,
+                               const uint32_t* root_idx, const uint8_t* keys, uint32_t key_len,
+                               const uint8_t* nodes, uint64_t nodes_len, const uint64_t* node_off,
+                               const uint32_t* proof_first_node, uint32_t n, uint8_t* status,
+                               uint64_t* value_off, uint32_t* value_len) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!roots || n_roots == 0 || !node_off || !proof_first_node || !status || (key_len && !keys) ||
+        (nodes_len && !nodes))
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_batch: null pointer");
+    // the number of node offsets the caller must have provided
+    uint32_t total_nodes = 0;
+    for (uint32_t i = 0; i <= n; ++i)
+        if (proof_first_node[i] > total_nodes) total_nodes = proof_first_node[i];
+    DeviceGuard g(c->device);
+    const size_t need = ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) +
+                        ws_round((size_t)n * key_len + 4) + ws_round((size_t)nodes_len + 16) +
+                        ws_round(((size_t)total_nodes + 1) * 8) + ws_round(((size_t)n + 1) * 4) +
+                        ws_round(n) + ws_round((size_t)n * 8) + ws_round((size_t)n * 4);
+    int32_t rc = ws_reset(c, need);
+    if (rc) return rc;
+    uint8_t* d_roots = ws_take<uint8_t>(c, (size_t)n_roots * 32);
+    uint32_t* d_ridx = ws_take<uint32_t>(c, n);
+    uint8_t* d_keys = ws_take<uint8_t>(c, (size_t)n * key_len + 4);
+    uint8_t* d_nodes = ws_take<uint8_t>(c, (size_t)nodes_len + 16);
+    uint64_t* d_noff = ws_take<uint64_t>(c, (size_t)total_nodes + 1);
+    uint32_t* d_pfn = ws_take<uint32_t>(c, (size_t)n + 1);
+    uint8_t* d_status = ws_take<uint8_t>(c, n);
+    uint64_t* d_voff = ws_take<uint64_t>(c, n);
+    uint32_t* d_vlen = ws_take<uint32_t>(c, n);
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 32, hipMemcpyHostToDevice, s));
+    if (root_idx) HIP_TRY(c, hipMemcpyAsync(d_ridx, root_idx, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
+    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nodes_len, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_noff, node_off, ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_pfn, proof_first_node, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+    phant::VerifyArgs a{d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
+                        d_noff, d_pfn, n, d_status, d_voff, d_vlen};
+    HIP_TRY(c, phant::launch_mpt_verify_fused(a, s));
+    HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
+    if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (value_len) HIP_TRY(c, hipMemcpyAsync(value_len, d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return PHANT_OK;
+}
+
+/* ---------------------------------------------------------------- trie root */
+
+int32_t phant_mpt_root(phant_ctx* c, const uint8_t* keys, const uint32_t* key_off,
+                       const uint8_t* vals, const uint64_t* val_off, uint32_t n, uint8_t out[32]) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    if (n && (!key_off || !val_off)) return fail(c, PHANT_E_INVALID_ARG, "mpt_root: null pointer");
+    DeviceGuard g(c->device);
+    std::string err;
+    int32_t rc = phant::trie_root_host(c->stream, keys, key_off, vals, val_off, n, out, err);
+    if (rc) return fail(c, rc, err.c_str());
+    return PHANT_OK;
+}
+
+int32_t phant_index_root_rlp(phant_ctx* c, const uint8_t* items, const uint64_t* item_off,
+                             uint32_t n, uint8_t out[32]) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    if (n && (!items || !item_off)) return fail(c, PHANT_E_INVALID_ARG, "index_root_rlp: null pointer");
+    DeviceGuard g(c->device);
+    std::string err;
+    int32_t rc = phant::index_root_host(c->stream, items, item_off, n, /*be32=*/false, out, err);
+    if (rc) return fail(c, rc, err.c_str());
+    return PHANT_OK;
+}
+
+int32_t phant_index_root_be32(phant_ctx* c, const uint8_t* items, const uint64_t* item_off,
+                              uint32_t n, uint8_t out[32]) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    if (n && (!items || !item_off)) return fail(c, PHANT_E_INVALID_ARG, "index_root_be32: null pointer");
+    DeviceGuard g(c->device);
+    std::string err;
+    int32_t rc = phant::index_root_host(c->stream, items, item_off, n, /*be32=*/true, out, err);
+    if (rc) return fail(c, rc, err.c_str());
+    return PHANT_OK;
+}
+
+int32_t phant_state_root(phant_ctx* c, const uint8_t* addrs, const uint64_t* nonces,
+                         const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
+                         const uint8_t* slot_keys, const uint8_t* slot_vals,
+                         const uint32_t* slot_first, uint32_t n, uint8_t out[32]) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    if (n && (!addrs || !nonces || !balances || !code_off || !slot_first))
+        return fail(c, PHANT_E_INVALID_ARG, "state_root: null pointer");
+    DeviceGuard g(c->device);
+    std::string err;
+    int32_t rc = phant::state_root_host(c->stream, addrs, nonces, balances, code, code_off, slot_keys,
+                                        slot_vals, slot_first, n, out, err);
+    if (rc) return fail(c, rc, err.c_str());
+    return PHANT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,33 @@
+// launch.h -- host-callable launchers of the HIP kernels (internal; the public
+// surface is include/phant_gpu.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phant {
+
+hipError_t launch_keccak256_var(const uint8_t* d_blob, const uint64_t* d_off, uint32_t n,
+                                uint8_t* d_out, hipStream_t st);
+hipError_t launch_keccak256_fixed(const uint8_t* d_blob, uint32_t msg_len, uint64_t stride,
+                                  uint32_t n, uint8_t* d_out, hipStream_t st);
+
+struct VerifyArgs {
+    const uint8_t* roots;
+    uint32_t n_roots;
+    const uint32_t* root_idx;  // may be null
+    const uint8_t* keys;
+    uint32_t key_len;
+    const uint8_t* nodes;
+    uint64_t nodes_len;
+    const uint64_t* node_off;
+    const uint32_t* proof_first_node;
+    uint32_t n;
+    uint8_t* status;
+    uint64_t* value_off;  // may be null
+    uint32_t* value_len;  // may be null
+};
+hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
+hipError_t launch_mpt_verdict(const uint8_t* d_status, const uint32_t* d_root_idx, uint32_t n,
+                              uint32_t n_roots, uint32_t* d_fail_count, hipStream_t st);
+
+}  // namespace phant

@@ -1,0 +1,201 @@
+// state_root.hip -- the `StateDB.root()` the reference leaves as a TODO
+// (src/blockchain/blockchain.zig:83-85), over the AccountState fields of
+// src/state/types.zig:13-20.
+//
+// Secure trie: account key keccak256(addr), value
+// rlp([nonce, balance, storageRoot, keccak256(code)]); storage key
+// keccak256(be32(slot)), value rlp(minimal-BE(value)); zero-valued slots do not
+// exist (src/state/statedb.zig:112-119).  All Keccak work (addresses, slots,
+// code, every trie node) runs on the GPU; one forest pass hashes every
+// account's storage trie at once, a second pass the account trie.  The host
+// only orders keys and packs the <= 110-byte account records.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../include/phant_gpu.h"
+#include "launch.h"
+#include "trie_build.h"
+
+namespace phant {
+namespace {
+
+struct DBuf {
+    void* p = nullptr;
+    ~DBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+#define SR_TRY(call)                                                          \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                               \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);          \
+            return e_ == hipErrorOutOfMemory ? PHANT_E_OOM : PHANT_E_DEVICE;  \
+        }                                                                     \
+    } while (0)
+
+// keccak256 of n fixed-size records on the GPU, digests back to the host
+int32_t hash_fixed(hipStream_t st, const uint8_t* host, uint32_t rec_len, uint32_t n,
+                   std::vector<uint8_t>& out, std::string& err) {
+    out.resize((size_t)n * 32);
+    if (!n) return PHANT_OK;
+    DBuf d_in, d_out;
+    SR_TRY(d_in.alloc((size_t)n * rec_len + 16));
+    SR_TRY(d_out.alloc((size_t)n * 32));
+    SR_TRY(hipMemcpyAsync(d_in.p, host, (size_t)n * rec_len, hipMemcpyHostToDevice, st));
+    SR_TRY(launch_keccak256_fixed((const uint8_t*)d_in.p, rec_len, rec_len, n, (uint8_t*)d_out.p, st));
+    SR_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size(), hipMemcpyDeviceToHost, st));
+    SR_TRY(hipStreamSynchronize(st));
+    return PHANT_OK;
+}
+
+int32_t hash_var(hipStream_t st, const uint8_t* blob, const uint64_t* off, uint32_t n,
+                 std::vector<uint8_t>& out, std::string& err) {
+    out.resize((size_t)n * 32);
+    if (!n) return PHANT_OK;
+    const uint64_t lo = off[0], len = off[n] - off[0];
+    std::vector<uint64_t> rel((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; ++i) {
+        if (i && off[i] < off[i - 1]) {
+            err = "code_off not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+        rel[i] = off[i] - lo;
+    }
+    DBuf d_in, d_off, d_out;
+    SR_TRY(d_in.alloc((size_t)len + 16));
+    SR_TRY(d_off.alloc(rel.size() * 8));
+    SR_TRY(d_out.alloc((size_t)n * 32));
+    if (len) SR_TRY(hipMemcpyAsync(d_in.p, blob + lo, (size_t)len, hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, st));
+    SR_TRY(launch_keccak256_var((const uint8_t*)d_in.p, (const uint64_t*)d_off.p, n, (uint8_t*)d_out.p, st));
+    SR_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size(), hipMemcpyDeviceToHost, st));
+    SR_TRY(hipStreamSynchronize(st));
+    return PHANT_OK;
+}
+
+// canonical RLP of a byte string (row a10)
+void put_rlp_str(std::vector<uint8_t>& o, const uint8_t* s, size_t len) {
+    if (len == 1 && s[0] < 0x80) {
+        o.push_back(s[0]);
+        return;
+    }
+    if (len <= 55) {
+        o.push_back((uint8_t)(0x80 + len));
+    } else {
+        uint8_t be[8];
+        size_t n = 0;
+        for (size_t v = len; v; v >>= 8) be[n++] = (uint8_t)v;
+        o.push_back((uint8_t)(0xb7 + n));
+        for (size_t i = 0; i < n; ++i) o.push_back(be[n - 1 - i]);
+    }
+    o.insert(o.end(), s, s + len);
+}
+
+size_t strip32(const uint8_t* v, const uint8_t** out) {
+    size_t z = 0;
+    while (z < 32 && v[z] == 0) ++z;
+    *out = v + z;
+    return 32 - z;
+}
+
+}  // namespace
+
+int32_t state_root_host(hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
+                        const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
+                        const uint8_t* slot_keys, const uint8_t* slot_vals,
+                        const uint32_t* slot_first, uint32_t n, uint8_t out[32], std::string& err) {
+    if (n == 0) return trie_root_host(st, nullptr, nullptr, nullptr, nullptr, 0, out, err);
+    for (uint32_t a = 0; a < n; ++a)
+        if (slot_first[a + 1] < slot_first[a]) {
+            err = "slot_first not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+    // ---- storage: live (non-zero) slots, hashed keys, per-account order ----
+    std::vector<uint32_t> live;       // slot indices with non-zero value
+    std::vector<uint32_t> acc_first(n + 1, 0);
+    for (uint32_t a = 0; a < n; ++a) {
+        for (uint32_t s = slot_first[a]; s < slot_first[a + 1]; ++s) {
+            const uint8_t* v;
+            if (strip32(slot_vals + 32ull * s, &v)) live.push_back(s);
+        }
+        acc_first[a + 1] = (uint32_t)live.size();
+    }
+    const uint32_t m = (uint32_t)live.size();
+    std::vector<uint8_t> live_keys((size_t)m * 32), hk;
+    for (uint32_t j = 0; j < m; ++j) std::memcpy(&live_keys[(size_t)j * 32], slot_keys + 32ull * live[j], 32);
+    int32_t rc = hash_fixed(st, live_keys.data(), 32, m, hk, err);
+    if (rc) return rc;
+    std::vector<uint32_t> perm(m);
+    std::iota(perm.begin(), perm.end(), 0u);
+    for (uint32_t a = 0; a < n; ++a)
+        std::sort(perm.begin() + acc_first[a], perm.begin() + acc_first[a + 1], [&](uint32_t x, uint32_t y) {
+            return std::memcmp(&hk[(size_t)x * 32], &hk[(size_t)y * 32], 32) < 0;
+        });
+    std::vector<uint8_t> skeys((size_t)m * 32), svals;
+    std::vector<uint32_t> skoff(m + 1, 0);
+    std::vector<uint64_t> svoff(m + 1, 0);
+    svals.reserve((size_t)m * 33);
+    for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t src = perm[j];
+        std::memcpy(&skeys[(size_t)j * 32], &hk[(size_t)src * 32], 32);
+        const uint8_t* v;
+        const size_t vl = strip32(slot_vals + 32ull * live[src], &v);
+        put_rlp_str(svals, v, vl);
+        skoff[j + 1] = 32 * (j + 1);
+        svoff[j + 1] = svals.size();
+    }
+    std::vector<uint8_t> sroots((size_t)n * 32);
+    rc = trie_forest_host(st, skeys.data(), skoff.data(), svals.data(), svoff.data(), m, acc_first.data(), n,
+                          sroots.data(), err);
+    if (rc) return rc;
+
+    // ---- accounts ----
+    std::vector<uint8_t> ha, hc;
+    rc = hash_fixed(st, addrs, 20, n, ha, err);
+    if (rc) return rc;
+    rc = hash_var(st, code, code_off, n, hc, err);
+    if (rc) return rc;
+    std::vector<uint32_t> ord(n);
+    std::iota(ord.begin(), ord.end(), 0u);
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+        return std::memcmp(&ha[(size_t)x * 32], &ha[(size_t)y * 32], 32) < 0;
+    });
+    std::vector<uint8_t> akeys((size_t)n * 32), avals, payload;
+    std::vector<uint32_t> akoff(n + 1, 0);
+    std::vector<uint64_t> avoff(n + 1, 0);
+    avals.reserve((size_t)n * 112);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t a = ord[i];
+        std::memcpy(&akeys[(size_t)i * 32], &ha[(size_t)a * 32], 32);
+        payload.clear();
+        uint8_t nb[8];
+        size_t nn = 0;
+        for (int s = 56; s >= 0; s -= 8) {
+            const uint8_t b = (uint8_t)(nonces[a] >> s);
+            if (nn || b) nb[nn++] = b;
+        }
+        put_rlp_str(payload, nb, nn);
+        const uint8_t* bv;
+        const size_t bl = strip32(balances + 32ull * a, &bv);
+        put_rlp_str(payload, bv, bl);
+        put_rlp_str(payload, &sroots[(size_t)a * 32], 32);
+        put_rlp_str(payload, &hc[(size_t)a * 32], 32);
+        if (payload.size() <= 55) {
+            avals.push_back((uint8_t)(0xc0 + payload.size()));
+        } else {
+            avals.push_back(0xf8);  // payload <= 110 bytes
+            avals.push_back((uint8_t)payload.size());
+        }
+        avals.insert(avals.end(), payload.begin(), payload.end());
+        akoff[i + 1] = 32 * (i + 1);
+        avoff[i + 1] = avals.size();
+    }
+    return trie_root_host(st, akeys.data(), akoff.data(), avals.data(), avoff.data(), n, out, err);
+}
+
+}  // namespace phant

@@ -1,0 +1,730 @@
+// trie_build.hip -- Merkle-Patricia trie root(s) on the GPU.
+//
+// Replaces src/mpt/mpt.zig:38-119 (`mptize` -> recursive `insertNode`) with a
+// data-parallel construction over the SORTED key list:
+//
+//   1. lcp[i] = common nibble prefix of key i-1 and key i (-1 at trie starts).
+//   2. Every branch node insertNode would create is exactly one LCP-interval:
+//      a maximal run of keys [l..r] whose pairwise lcp >= d, with d = the
+//      minimum inside.  Its id is the leftmost boundary i in (l..r] with
+//      lcp[i] == d.  "Nearest smaller lcp to the left/right" queries against a
+//      min-tree give l, r, the parent interval and the slot nibble in
+//      O(log n) per element, with no recursion (mpt.zig:62-116 scans groups;
+//      mpt.zig:83-99 is the longest-common-prefix scan => the extension).
+//   3. Leaves (one lane per key), then branch nodes level by level from the
+//      deepest nibble depth up: each lane RLP-encodes its node into a scratch
+//      blob (wave prefix-sum + one atomic bump per wave to place the
+//      variable-length encodings), hashes it with its sponge in registers and
+//      drops the <= 32-byte reference into its parent's slot table
+//      (embed-if-shorter-than-32 rule mpt.zig:104,112; root always hashed :42).
+//
+// A forest of tries (one per account's storage) goes through the same passes
+// at once: trie starts are just lcp = -1 boundaries.
+#include "trie_build.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/phant_gpu.h"
+#include "absorb.hip.h"
+#include "launch.h"
+
+namespace phant {
+namespace {
+
+constexpr uint32_t NONE = 0xffffffffu;
+constexpr uint32_t BRANCH_VALUE = 0xfffffffeu;  // leaf_ps marker: key is a branch's value
+constexpr int MAX_DEPTH_BINS = 512;             // nibble depth <= 2*255
+constexpr int INF_LCP = 0x7fffffff;
+
+struct TrieDev {
+    const uint8_t* keys;
+    const uint32_t* key_off;
+    const uint8_t* vals;
+    const uint64_t* val_off;
+    uint32_t n;
+    const uint32_t* seg_first;
+    uint32_t n_tries;
+    uint8_t* first_flag;  // n+1: key i starts a trie
+    int32_t* lcp;         // n+1
+    int32_t* tree;        // 2*M min-tree over lcp
+    uint32_t M;
+    // per boundary index (n+1)
+    uint32_t* dense;      // dense node id of a representative boundary, else NONE
+    uint32_t* nd_l;       // first key of the interval
+    int32_t* nd_pd;       // parent depth (-1: root)
+    uint32_t* nd_parent;  // parent's representative boundary, NONE: root
+    uint32_t* value_key;  // key whose value sits in this branch's value slot, or NONE
+    // per key (n)
+    uint32_t* leaf_parent;
+    uint32_t* leaf_ps;    // first nibble of the leaf path, or BRANCH_VALUE
+    // per dense node
+    uint8_t* slot_bytes;  // n_rep x 16 x 32
+    uint8_t* slot_len;    // n_rep x 16
+    // scratch blob for encodings
+    uint8_t* scratch;
+    unsigned long long* cursor;
+    // counters[0] = n_rep, [1] = error flags, [2] = scratch overflow, hist at [8..8+512)
+    uint32_t* counters;
+    uint32_t* order;      // rep boundaries grouped by depth
+    uint32_t* depth_cursor;  // 512
+    uint8_t* roots;       // n_tries x 32
+    unsigned long long scratch_cap;
+};
+
+enum : uint32_t { ERR_UNSORTED = 1u };
+
+PHANT_DEV uint32_t nib_len(const TrieDev& t, uint32_t i) { return 2u * (t.key_off[i + 1] - t.key_off[i]); }
+PHANT_DEV uint32_t nib_at(const TrieDev& t, uint32_t i, uint32_t j) {
+    const uint32_t b = t.keys[t.key_off[i] + (j >> 1)];
+    return (j & 1u) ? (b & 0x0fu) : (b >> 4);
+}
+
+__global__ void __launch_bounds__(256) first_flag_kernel(TrieDev t) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s < t.n_tries) {
+        const uint32_t f = t.seg_first[s];
+        if (f <= t.n) t.first_flag[f] = 1;
+    }
+}
+
+// lcp + strict-order check (mpt.zig:39 asserts sorted; distinct keys assumed)
+__global__ void __launch_bounds__(256) lcp_kernel(TrieDev t) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i > t.n) return;
+    int32_t v = -1;
+    if (i > 0 && i < t.n && !t.first_flag[i]) {
+        const uint32_t la = t.key_off[i] - t.key_off[i - 1], lb = t.key_off[i + 1] - t.key_off[i];
+        const uint8_t* a = t.keys + t.key_off[i - 1];
+        const uint8_t* b = t.keys + t.key_off[i];
+        const uint32_t m = la < lb ? la : lb;
+        uint32_t k = 0;
+        while (k < m && a[k] == b[k]) ++k;
+        bool ok;
+        if (k == m) {
+            v = 2 * (int32_t)m;
+            ok = la < lb;  // a is a proper prefix of b
+        } else {
+            const uint32_t x = a[k], y = b[k];
+            v = 2 * (int32_t)k + (((x ^ y) & 0xf0u) ? 0 : 1);
+            ok = x < y;
+        }
+        if (!ok) atomicOr(&t.counters[1], ERR_UNSORTED);
+    }
+    t.lcp[i] = v;
+    t.tree[t.M + i] = v;
+}
+
+__global__ void __launch_bounds__(256) tree_pad_kernel(TrieDev t) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x + t.n + 1;
+    if (i < t.M) t.tree[t.M + i] = INF_LCP;
+}
+
+__global__ void __launch_bounds__(256) tree_level_kernel(int32_t* tree, uint32_t w) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < w) {
+        const uint32_t v = w + k;
+        const int32_t a = tree[2 * v], b = tree[2 * v + 1];
+        tree[v] = a < b ? a : b;
+    }
+}
+
+// largest j < i with lcp[j] < thr (exists: lcp[0] = -1 and thr >= 0)
+PHANT_DEV uint32_t prev_less(const TrieDev& t, uint32_t i, int32_t thr) {
+    uint32_t v = t.M + i;
+    while (v > 1) {
+        if ((v & 1u) && t.tree[v - 1] < thr) {
+            v = v - 1;
+            while (v < t.M) v = (t.tree[2 * v + 1] < thr) ? 2 * v + 1 : 2 * v;
+            return v - t.M;
+        }
+        v >>= 1;
+    }
+    return 0;
+}
+// smallest j > i with lcp[j] < thr (exists: lcp[n] = -1)
+PHANT_DEV uint32_t next_less(const TrieDev& t, uint32_t i, int32_t thr) {
+    uint32_t v = t.M + i;
+    while (v > 1) {
+        if (!(v & 1u) && t.tree[v + 1] < thr) {
+            v = v + 1;
+            while (v < t.M) v = (t.tree[2 * v] < thr) ? 2 * v : 2 * v + 1;
+            return v - t.M;
+        }
+        v >>= 1;
+    }
+    return t.n;
+}
+
+// representative boundary of the interval at depth pd that contains key x,
+// given lcp[x] <= pd
+PHANT_DEV uint32_t rep_of(const TrieDev& t, uint32_t x, int32_t lcp_x, int32_t pd) {
+    const uint32_t PL = (lcp_x < pd) ? x : prev_less(t, x, pd);
+    return next_less(t, PL, pd + 1);
+}
+
+__global__ void __launch_bounds__(256) identify_kernel(TrieDev t) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= t.n) return;
+    // --- key i as a leaf (or a branch value) ---
+    {
+        const int32_t dl = t.lcp[i], dr = t.lcp[i + 1];
+        const int32_t di = dl > dr ? dl : dr;
+        if (di < 0) {
+            t.leaf_parent[i] = NONE;  // single-key trie: the leaf is the root
+            t.leaf_ps[i] = 0;
+        } else {
+            const uint32_t rep = rep_of(t, i, dl, di);
+            t.leaf_parent[i] = rep;
+            if (nib_len(t, i) == (uint32_t)di) {
+                t.value_key[rep] = i;  // mpt.zig:65-69
+                t.leaf_ps[i] = BRANCH_VALUE;
+            } else {
+                t.leaf_ps[i] = (uint32_t)di + 1u;
+            }
+        }
+    }
+    // --- boundary i as a branch node ---
+    uint32_t dn = NONE;
+    const int32_t d = t.lcp[i];
+    if (i >= 1 && d >= 0) {
+        const uint32_t p = prev_less(t, i, d + 1);
+        if (t.lcp[p] < d) {  // leftmost boundary of value d in its interval
+            const uint32_t l = p;
+            const uint32_t r1 = next_less(t, i, d);  // r + 1
+            const int32_t pl = t.lcp[l], pr = t.lcp[r1];
+            const int32_t pd = pl > pr ? pl : pr;
+            t.nd_l[i] = l;
+            t.nd_pd[i] = pd;
+            t.nd_parent[i] = pd < 0 ? NONE : rep_of(t, l, pl, pd);
+            dn = atomicAdd(&t.counters[0], 1u);
+            atomicAdd(&t.counters[8 + d], 1u);
+        }
+    }
+    t.dense[i] = dn;
+}
+
+__global__ void __launch_bounds__(256) order_kernel(TrieDev t, const uint32_t* depth_begin) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= t.n || i == 0) return;
+    if (t.dense[i] == NONE) return;
+    const int32_t d = t.lcp[i];
+    const uint32_t pos = atomicAdd(&t.depth_cursor[d], 1u);
+    t.order[depth_begin[d] + pos] = i;
+}
+
+// ---- RLP helpers (row a10: canonical subset used at mpt.zig:127,198,236,268) ----
+PHANT_DEV uint32_t be_len_bytes(uint64_t v) {
+    uint32_t n = 0;
+    while (v) {
+        ++n;
+        v >>= 8;
+    }
+    return n;
+}
+// encoded size of a byte string of `len` bytes whose first byte is b0
+PHANT_DEV uint64_t rlp_str_size(uint64_t len, uint32_t b0) {
+    if (len == 1 && b0 < 0x80u) return 1;
+    if (len <= 55) return 1 + len;
+    return 1 + be_len_bytes(len) + len;
+}
+PHANT_DEV uint32_t rlp_list_hdr_size(uint64_t payload) {
+    return payload <= 55 ? 1u : 1u + be_len_bytes(payload);
+}
+PHANT_DEV uint8_t* put_hdr(uint8_t* w, uint64_t len, uint32_t short_base, uint32_t long_base) {
+    if (len <= 55) {
+        *w++ = (uint8_t)(short_base + len);
+        return w;
+    }
+    const uint32_t ll = be_len_bytes(len);
+    *w++ = (uint8_t)(long_base + ll);
+    for (int s = 8 * ((int)ll - 1); s >= 0; s -= 8) *w++ = (uint8_t)(len >> s);
+    return w;
+}
+PHANT_DEV uint8_t* put_str(uint8_t* w, const uint8_t* s, uint64_t len) {
+    if (!(len == 1 && s[0] < 0x80u)) w = put_hdr(w, len, 0x80u, 0xb7u);
+    for (uint64_t k = 0; k < len; ++k) w[k] = s[k];
+    return w + len;
+}
+
+// Wave-aggregated bump allocation of `size` bytes (0 for idle lanes): exclusive
+// prefix sum across the 64 lanes, one atomic per wave.  Every lane of the wave
+// must call it.
+PHANT_DEV unsigned long long wave_alloc(unsigned long long* cursor, uint32_t size) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = size;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += up;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(cursor, (unsigned long long)total);
+    base = __shfl(base, 0, 64);
+    return base + (incl - size);
+}
+
+PHANT_DEV uint32_t trie_of(const TrieDev& t, uint32_t key) {
+    // largest s with seg_first[s] <= key
+    uint32_t lo = 0, hi = t.n_tries;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (t.seg_first[mid] <= key)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// hex-prefix of nibbles [ps, pe) of key k (mpt.zig:285-314), as an RLP string
+PHANT_DEV uint64_t hp_rlp_size(uint32_t plen) {
+    const uint32_t hp = plen / 2u + 1u;
+    return hp == 1 ? 1 : rlp_str_size(hp, 0xffu);  // a 1-byte HP is 0x00..0x3f: encodes as itself
+}
+PHANT_DEV uint8_t* put_hp(uint8_t* w, const TrieDev& t, uint32_t k, uint32_t ps, uint32_t pe,
+                          bool is_leaf) {
+    const uint32_t plen = pe - ps;
+    const uint32_t hp = plen / 2u + 1u;
+    const bool odd = plen & 1u;
+    const uint32_t b0 = ((is_leaf ? 2u : 0u) + (odd ? 1u : 0u)) << 4 | (odd ? nib_at(t, k, ps) : 0u);
+    if (hp > 1) w = put_hdr(w, hp, 0x80u, 0xb7u);
+    *w++ = (uint8_t)b0;
+    for (uint32_t j = ps + (odd ? 1u : 0u); j < pe; j += 2)
+        *w++ = (uint8_t)((nib_at(t, k, j) << 4) | nib_at(t, k, j + 1));
+    return w;
+}
+
+// Deliver a finished node's reference (<= 32 bytes) to its parent slot, or to
+// the trie's root output.
+PHANT_DEV void deliver(const TrieDev& t, uint32_t parent, uint32_t nib, uint32_t first_key,
+                       const uint8_t* enc, uint32_t enc_len, const Sponge& s, bool hashed) {
+    if (parent == NONE) {
+        store_digest(s, t.roots + 32ull * trie_of(t, first_key));
+        return;
+    }
+    const uint64_t slot = (uint64_t)t.dense[parent] * 16u + nib;
+    uint8_t* dst = t.slot_bytes + slot * 32u;
+    if (hashed) {
+        store_digest(s, dst);
+        t.slot_len[slot] = 32;
+    } else {
+        for (uint32_t k = 0; k < enc_len; ++k) dst[k] = enc[k];
+        t.slot_len[slot] = (uint8_t)enc_len;
+    }
+}
+
+// LeafNode, mpt.zig:54-56 / :254-261
+__global__ void __launch_bounds__(256) leaf_kernel(TrieDev t) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool live = i < t.n && t.leaf_ps[i] != BRANCH_VALUE;
+    uint32_t ps = 0, nl = 0, total = 0;
+    uint64_t vlen = 0, payload = 0;
+    const uint8_t* v = nullptr;
+    if (live) {
+        ps = t.leaf_ps[i];
+        nl = nib_len(t, i);
+        v = t.vals + t.val_off[i];
+        vlen = t.val_off[i + 1] - t.val_off[i];
+        payload = hp_rlp_size(nl - ps) + rlp_str_size(vlen, vlen ? v[0] : 0u);
+        total = (uint32_t)(rlp_list_hdr_size(payload) + payload);
+    }
+    const unsigned long long at = wave_alloc(t.cursor, (total + 3u) & ~3u);
+    if (!live) return;
+    if (at + total > t.scratch_cap) {
+        atomicOr(&t.counters[2], 1u);
+        return;
+    }
+    uint8_t* enc = t.scratch + at;
+    uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
+    w = put_hp(w, t, i, ps, nl, true);
+    w = put_str(w, v, vlen);
+    const uint32_t parent = t.leaf_parent[i];
+    const bool hashed = total >= 32u || parent == NONE;
+    Sponge s;
+    if (hashed) keccak256_global(s, enc, total);
+    deliver(t, parent, ps ? nib_at(t, i, ps - 1) : 0u, i, enc, total, s, hashed);
+}
+
+// BranchNode (mpt.zig:216-231) at nibble depth d, plus the ExtensionNode above
+// it when the parent is more than one nibble up (mpt.zig:83-106, :187-193).
+__global__ void __launch_bounds__(256) branch_kernel(TrieDev t, uint32_t begin, uint32_t count) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const bool live = q < count;
+    uint32_t i = 0, dn = 0, total = 0, vk = NONE;
+    uint64_t payload = 0, vlen = 0;
+    const uint8_t* v = nullptr;
+    if (live) {
+        i = t.order[begin + q];
+        dn = t.dense[i];
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t sl = t.slot_len[(uint64_t)dn * 16u + k];
+            payload += sl == 0 ? 1u : (sl == 32u ? 33u : sl);
+        }
+        vk = t.value_key[i];
+        if (vk != NONE) {
+            v = t.vals + t.val_off[vk];
+            vlen = t.val_off[vk + 1] - t.val_off[vk];
+        }
+        payload += rlp_str_size(vlen, vlen ? v[0] : 0u);
+        total = (uint32_t)(rlp_list_hdr_size(payload) + payload);
+    }
+    const int32_t d = live ? t.lcp[i] : 0;
+    const int32_t pd = live ? t.nd_pd[i] : 0;
+    const uint32_t ext_len = live ? (uint32_t)(d - (pd + 1)) : 0u;
+    const uint32_t l = live ? t.nd_l[i] : 0u;
+    // extension size bound: list hdr (<=3) + HP string (<= 2 + ext_len/2 + 1) + ref (<= 33)
+    const uint32_t ext_cap = (live && ext_len) ? (40u + ext_len / 2u + 4u) : 0u;
+    const unsigned long long at = wave_alloc(t.cursor, ((total + 3u) & ~3u) + ((ext_cap + 3u) & ~3u));
+    if (!live) return;
+    if (at + total + ext_cap + 8 > t.scratch_cap) {
+        atomicOr(&t.counters[2], 1u);
+        return;
+    }
+    uint8_t* enc = t.scratch + at;
+    uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
+    for (uint32_t k = 0; k < 16; ++k) {
+        const uint64_t slot = (uint64_t)dn * 16u + k;
+        const uint32_t sl = t.slot_len[slot];
+        const uint8_t* src = t.slot_bytes + slot * 32u;
+        if (sl == 0) {
+            *w++ = 0x80;
+        } else {
+            if (sl == 32u) *w++ = 0xa0;
+            for (uint32_t b = 0; b < sl; ++b) w[b] = src[b];
+            w += sl;
+        }
+    }
+    if (vlen)
+        w = put_str(w, v, vlen);
+    else
+        *w++ = 0x80;
+
+    const uint32_t parent = t.nd_parent[i];
+    const bool is_root = parent == NONE;
+    bool hashed = total >= 32u || (is_root && ext_len == 0);
+    Sponge s;
+    if (hashed) keccak256_global(s, enc, total);
+    uint32_t out_len = total;
+    if (ext_len) {
+        // ExtensionNode [HP(path), ref]; path = key l, nibbles [pd+1, d)
+        uint8_t* xenc = enc + ((total + 3u) & ~3u);
+        const uint32_t ref_size = hashed ? 33u : total;
+        const uint64_t xpayload = hp_rlp_size(ext_len) + ref_size;
+        uint8_t* x = put_hdr(xenc, xpayload, 0xc0u, 0xf7u);
+        x = put_hp(x, t, l, (uint32_t)(pd + 1), (uint32_t)d, false);
+        if (hashed) {
+            *x++ = 0xa0;
+            // digest bytes, little-endian lanes
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t lo = s.lo[k], hi = s.hi[k];
+                for (int b = 0; b < 4; ++b) x[8 * k + b] = (uint8_t)(lo >> (8 * b));
+                for (int b = 0; b < 4; ++b) x[8 * k + 4 + b] = (uint8_t)(hi >> (8 * b));
+            }
+            x += 32;
+        } else {
+            for (uint32_t b = 0; b < total; ++b) x[b] = enc[b];
+            x += total;
+        }
+        out_len = (uint32_t)(x - xenc);
+        enc = xenc;
+        hashed = out_len >= 32u || is_root;
+        if (hashed) keccak256_global(s, enc, out_len);
+    }
+    deliver(t, parent, is_root ? 0u : nib_at(t, l, (uint32_t)pd), l, enc, out_len, s, hashed);
+}
+
+__global__ void __launch_bounds__(256) fill_empty_roots_kernel(uint8_t* roots, uint32_t n_tries) {
+    // mpt.zig:10 empty_mpt_root = keccak256(0x80)
+    const uint8_t E[32] = {0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 0xff, 0x83, 0x45,
+                           0xe6, 0x92, 0xc0, 0xf8, 0x6e, 0x5b, 0x48, 0xe0, 0x1b, 0x99, 0x6c,
+                           0xad, 0xc0, 0x01, 0x62, 0x2f, 0xb5, 0xe3, 0x63, 0xb4, 0x21};
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_tries)
+        for (int k = 0; k < 32; ++k) roots[32ull * i + k] = E[k];
+}
+
+// ---- host driver ----
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+#define TB_TRY(call)                                    \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) {                         \
+            err = std::string(#call) + ": " + hipGetErrorString(e_); \
+            return e_ == hipErrorOutOfMemory ? PHANT_E_OOM : PHANT_E_DEVICE; \
+        }                                               \
+    } while (0)
+
+inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
+
+}  // namespace
+
+// Device-side forest build; all pointers device memory, except roots_host.
+static int32_t forest_device(hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off,
+                             const uint8_t* d_vals, const uint64_t* d_val_off, uint32_t n,
+                             uint64_t total_key_bytes, uint64_t total_val_bytes,
+                             const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_roots,
+                             std::string& err) {
+    TrieDev t{};
+    t.keys = d_keys;
+    t.key_off = d_key_off;
+    t.vals = d_vals;
+    t.val_off = d_val_off;
+    t.n = n;
+    t.seg_first = d_seg_first;
+    t.n_tries = n_tries;
+    t.roots = d_roots;
+    hipLaunchKernelGGL(fill_empty_roots_kernel, dim3(blocks(n_tries)), dim3(256), 0, st, d_roots, n_tries);
+    TB_TRY(hipGetLastError());
+    if (n == 0) return PHANT_OK;
+
+    uint32_t M = 1;
+    while (M < n + 1) M <<= 1;
+    t.M = M;
+    DevBuf b_flag, b_lcp, b_tree, b_dense, b_l, b_pd, b_parent, b_vk, b_lp, b_ps, b_cnt, b_order, b_dc, b_db,
+        b_cursor;
+    TB_TRY(b_flag.alloc((size_t)n + 1));
+    TB_TRY(b_lcp.alloc(((size_t)n + 1) * 4));
+    TB_TRY(b_tree.alloc((size_t)2 * M * 4));
+    TB_TRY(b_dense.alloc(((size_t)n + 1) * 4));
+    TB_TRY(b_l.alloc(((size_t)n + 1) * 4));
+    TB_TRY(b_pd.alloc(((size_t)n + 1) * 4));
+    TB_TRY(b_parent.alloc(((size_t)n + 1) * 4));
+    TB_TRY(b_vk.alloc(((size_t)n + 1) * 4));
+    TB_TRY(b_lp.alloc((size_t)n * 4));
+    TB_TRY(b_ps.alloc((size_t)n * 4));
+    TB_TRY(b_cnt.alloc((8 + MAX_DEPTH_BINS) * 4));
+    TB_TRY(b_order.alloc((size_t)n * 4));
+    TB_TRY(b_dc.alloc(MAX_DEPTH_BINS * 4));
+    TB_TRY(b_db.alloc(MAX_DEPTH_BINS * 4));
+    TB_TRY(b_cursor.alloc(8));
+    t.first_flag = b_flag.as<uint8_t>();
+    t.lcp = b_lcp.as<int32_t>();
+    t.tree = b_tree.as<int32_t>();
+    t.dense = b_dense.as<uint32_t>();
+    t.nd_l = b_l.as<uint32_t>();
+    t.nd_pd = b_pd.as<int32_t>();
+    t.nd_parent = b_parent.as<uint32_t>();
+    t.value_key = b_vk.as<uint32_t>();
+    t.leaf_parent = b_lp.as<uint32_t>();
+    t.leaf_ps = b_ps.as<uint32_t>();
+    t.counters = b_cnt.as<uint32_t>();
+    t.order = b_order.as<uint32_t>();
+    t.depth_cursor = b_dc.as<uint32_t>();
+    t.cursor = b_cursor.as<unsigned long long>();
+
+    TB_TRY(hipMemsetAsync(t.first_flag, 0, (size_t)n + 1, st));
+    TB_TRY(hipMemsetAsync(t.counters, 0, (8 + MAX_DEPTH_BINS) * 4, st));
+    TB_TRY(hipMemsetAsync(t.depth_cursor, 0, MAX_DEPTH_BINS * 4, st));
+    TB_TRY(hipMemsetAsync(t.value_key, 0xff, ((size_t)n + 1) * 4, st));
+    TB_TRY(hipMemsetAsync(t.dense, 0xff, ((size_t)n + 1) * 4, st));
+    TB_TRY(hipMemsetAsync(t.cursor, 0, 8, st));
+
+    hipLaunchKernelGGL(first_flag_kernel, dim3(blocks(n_tries)), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(lcp_kernel, dim3(blocks((uint64_t)n + 1)), dim3(256), 0, st, t);
+    if (M > n + 1) hipLaunchKernelGGL(tree_pad_kernel, dim3(blocks(M - n - 1)), dim3(256), 0, st, t);
+    for (uint32_t w = M / 2; w >= 1; w >>= 1)
+        hipLaunchKernelGGL(tree_level_kernel, dim3(blocks(w)), dim3(256), 0, st, t.tree, w);
+    hipLaunchKernelGGL(identify_kernel, dim3(blocks(n)), dim3(256), 0, st, t);
+    TB_TRY(hipGetLastError());
+
+    std::vector<uint32_t> cnt(8 + MAX_DEPTH_BINS);
+    TB_TRY(hipMemcpyAsync(cnt.data(), t.counters, cnt.size() * 4, hipMemcpyDeviceToHost, st));
+    TB_TRY(hipStreamSynchronize(st));
+    if (cnt[1] & ERR_UNSORTED) {
+        err = "keys are not strictly increasing (mpt.zig:39)";
+        return PHANT_E_UNSORTED;
+    }
+    const uint32_t n_rep = cnt[0];
+    std::vector<uint32_t> depth_begin(MAX_DEPTH_BINS);
+    uint32_t acc = 0;
+    for (int d = 0; d < MAX_DEPTH_BINS; ++d) {
+        depth_begin[d] = acc;
+        acc += cnt[8 + d];
+    }
+    TB_TRY(hipMemcpyAsync(b_db.p, depth_begin.data(), MAX_DEPTH_BINS * 4, hipMemcpyHostToDevice, st));
+
+    DevBuf b_sb, b_sl, b_scratch;
+    TB_TRY(b_sb.alloc((size_t)n_rep * 16 * 32));
+    TB_TRY(b_sl.alloc((size_t)n_rep * 16));
+    // leaves: list hdr (<=9) + HP (<= 3 + key bytes + 1) + value (<= 9 + len), 4-byte rounded;
+    // branches: <= 3 + 16*33 + value; extensions <= 48 + key bytes / 2
+    const uint64_t max_key = 255;
+    const uint64_t cap = total_val_bytes + total_key_bytes + (uint64_t)n * 32 +
+                         (uint64_t)n_rep * (3 + 16 * 33 + 16 + 48 + max_key / 2 + 16) + 4096;
+    TB_TRY(b_scratch.alloc(cap));
+    t.slot_bytes = b_sb.as<uint8_t>();
+    t.slot_len = b_sl.as<uint8_t>();
+    t.scratch = b_scratch.as<uint8_t>();
+    t.scratch_cap = cap;
+    TB_TRY(hipMemsetAsync(t.slot_len, 0, (size_t)n_rep * 16, st));
+
+    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3(blocks(n)), dim3(256), 0, st, t, b_db.as<uint32_t>());
+    hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t);
+    for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
+        const uint32_t c = cnt[8 + d];
+        if (!c) continue;
+        hipLaunchKernelGGL(branch_kernel, dim3(blocks(c)), dim3(256), 0, st, t, depth_begin[d], c);
+    }
+    TB_TRY(hipGetLastError());
+    uint32_t flags[3];
+    TB_TRY(hipMemcpyAsync(flags, t.counters, sizeof flags, hipMemcpyDeviceToHost, st));
+    TB_TRY(hipStreamSynchronize(st));
+    if (flags[2]) {
+        err = "trie scratch overflow (internal bound too small)";
+        return PHANT_E_DEVICE;
+    }
+    return PHANT_OK;
+}
+
+int32_t trie_forest_host(hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
+                         const uint8_t* vals, const uint64_t* val_off, uint32_t n,
+                         const uint32_t* seg_first, uint32_t n_tries, uint8_t* roots_out,
+                         std::string& err) {
+    if (n_tries == 0) return PHANT_OK;
+    const uint64_t kb = n ? key_off[n] - key_off[0] : 0;
+    const uint64_t vb = n ? val_off[n] - val_off[0] : 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (key_off[i + 1] < key_off[i] || val_off[i + 1] < val_off[i]) {
+            err = "offsets not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+        if (key_off[i + 1] - key_off[i] > 255) {
+            err = "key longer than 255 bytes";
+            return PHANT_E_UNSUPPORTED;
+        }
+    }
+    for (uint32_t s = 0; s < n_tries; ++s)
+        if (seg_first[s] > seg_first[s + 1] || seg_first[s + 1] > n) {
+            err = "seg_first not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+    if (seg_first[0] != 0 || seg_first[n_tries] != n) {
+        err = "seg_first must span [0, n]";
+        return PHANT_E_INVALID_ARG;
+    }
+    DevBuf d_keys, d_koff, d_vals, d_voff, d_seg, d_roots;
+    TB_TRY(d_keys.alloc(kb + 16));
+    TB_TRY(d_koff.alloc(((size_t)n + 1) * 4));
+    TB_TRY(d_vals.alloc(vb + 16));
+    TB_TRY(d_voff.alloc(((size_t)n + 1) * 8));
+    TB_TRY(d_seg.alloc(((size_t)n_tries + 1) * 4));
+    TB_TRY(d_roots.alloc((size_t)n_tries * 32));
+    std::vector<uint32_t> ko((size_t)n + 1, 0);
+    std::vector<uint64_t> vo((size_t)n + 1, 0);
+    for (uint32_t i = 0; i <= n && n; ++i) {
+        ko[i] = key_off[i] - key_off[0];
+        vo[i] = val_off[i] - val_off[0];
+    }
+    if (kb) TB_TRY(hipMemcpyAsync(d_keys.p, keys + key_off[0], kb, hipMemcpyHostToDevice, st));
+    if (vb) TB_TRY(hipMemcpyAsync(d_vals.p, vals + val_off[0], vb, hipMemcpyHostToDevice, st));
+    TB_TRY(hipMemcpyAsync(d_koff.p, ko.data(), ko.size() * 4, hipMemcpyHostToDevice, st));
+    TB_TRY(hipMemcpyAsync(d_voff.p, vo.data(), vo.size() * 8, hipMemcpyHostToDevice, st));
+    TB_TRY(hipMemcpyAsync(d_seg.p, seg_first, ((size_t)n_tries + 1) * 4, hipMemcpyHostToDevice, st));
+    int32_t rc = forest_device(st, d_keys.as<uint8_t>(), d_koff.as<uint32_t>(), d_vals.as<uint8_t>(),
+                               d_voff.as<uint64_t>(), n, kb, vb, d_seg.as<uint32_t>(), n_tries,
+                               d_roots.as<uint8_t>(), err);
+    if (rc) {
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
+    TB_TRY(hipMemcpyAsync(roots_out, d_roots.p, (size_t)n_tries * 32, hipMemcpyDeviceToHost, st));
+    TB_TRY(hipStreamSynchronize(st));
+    return PHANT_OK;
+}
+
+int32_t trie_root_host(hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
+                       const uint8_t* vals, const uint64_t* val_off, uint32_t n, uint8_t out[32],
+                       std::string& err) {
+    const uint32_t seg[2] = {0, n};
+    const uint32_t zero32[1] = {0};
+    const uint64_t zero64[1] = {0};
+    return trie_forest_host(st, keys, n ? key_off : zero32, vals, n ? val_off : zero64, n, seg, 1, out, err);
+}
+
+// rlp.serialize(usize, i) as used at blockchain.zig:226-229
+static size_t rlp_index_key(uint64_t v, uint8_t* out) {
+    if (v == 0) {
+        out[0] = 0x80;
+        return 1;
+    }
+    uint8_t be[8];
+    size_t n = 0;
+    for (int s = 56; s >= 0; s -= 8) {
+        const uint8_t b = (uint8_t)(v >> s);
+        if (n || b) be[n++] = b;
+    }
+    if (n == 1 && be[0] < 0x80) {
+        out[0] = be[0];
+        return 1;
+    }
+    out[0] = (uint8_t)(0x80 + n);
+    std::memcpy(out + 1, be, n);
+    return 1 + n;
+}
+
+int32_t index_root_host(hipStream_t st, const uint8_t* items, const uint64_t* item_off, uint32_t n,
+                        bool be32, uint8_t out[32], std::string& err) {
+    std::vector<uint8_t> keys;
+    std::vector<uint32_t> key_off((size_t)n + 1, 0);
+    std::vector<uint64_t> val_off((size_t)n + 1, 0);
+    std::vector<uint8_t> vals;
+    if (be32) {
+        // execution_payload.zig:127-139: 32-byte key, index big-endian in the tail;
+        // ascending index is ascending key, values stay in place
+        keys.assign((size_t)n * 32, 0);
+        for (uint32_t i = 0; i < n; ++i) {
+            for (int b = 0; b < 8; ++b) keys[(size_t)i * 32 + 31 - b] = (uint8_t)((uint64_t)i >> (8 * b));
+            key_off[i + 1] = 32 * (i + 1);
+        }
+        for (uint32_t i = 0; i <= n && n; ++i) val_off[i] = item_off[i] - item_off[0];
+        return trie_root_host(st, keys.data(), key_off.data(), n ? items + item_off[0] : nullptr,
+                              val_off.data(), n, out, err);
+    }
+    // blockchain.zig:213-232: items 1..0x7f, then item 0 (key 0x80), then 0x80.. --
+    // that insertion order is ascending key order
+    keys.reserve((size_t)n * 4);
+    vals.reserve(n ? (size_t)(item_off[n] - item_off[0]) : 0);
+    uint32_t k = 0;
+    auto push = [&](uint32_t idx, const uint8_t* key, size_t klen) {
+        keys.insert(keys.end(), key, key + klen);
+        vals.insert(vals.end(), items + item_off[idx], items + item_off[idx + 1]);
+        ++k;
+        key_off[k] = (uint32_t)keys.size();
+        val_off[k] = vals.size();
+    };
+    uint32_t i = 0;
+    while (i + 1 < n && i + 1 != 0x80) {
+        const uint8_t kb = (uint8_t)(i + 1);
+        push(i + 1, &kb, 1);
+        ++i;
+    }
+    if (n > 0) {
+        const uint8_t kb = 0x80;
+        push(0, &kb, 1);
+        ++i;
+    }
+    while (i < n) {
+        uint8_t kb[9];
+        const size_t kl = rlp_index_key(i, kb);
+        push(i, kb, kl);
+        ++i;
+    }
+    return trie_root_host(st, keys.data(), key_off.data(), vals.data(), val_off.data(), n, out, err);
+}
+
+}  // namespace phant

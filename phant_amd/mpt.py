@@ -1,0 +1,200 @@
+"""Mirror of phant's src/mpt/mpt.zig over the C-ABI, plus the batched proof
+verifier the reference only has as a TODO
+(src/engine_api/execution_payload.zig:177-178).
+
+    KeyVal.init(key, value)            mpt.zig:13-34
+    mptize(list[KeyVal]) -> Hash32     mpt.zig:38-45   (list must be sorted)
+    empty_mpt_root                     mpt.zig:10
+    index_root_rlp / index_root_be32   blockchain.zig:209-235 /
+                                       execution_payload.zig:125-158
+    verify_batch / verify_batch_dev    DESIGN.md section 3
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .context import Context, default_context, _np_ptr
+
+empty_mpt_root = bytes.fromhex("56e81f171bcc55a6ff8345e692c0f86e5b48e01b996cadc001622fb5e363b421")
+
+PROOF_INVALID_EMPTY = L.PROOF_INVALID_EMPTY
+PROOF_PRESENT = L.PROOF_PRESENT
+PROOF_ABSENT = L.PROOF_ABSENT
+PROOF_BAD_HASH = L.PROOF_BAD_HASH
+PROOF_BAD_RLP = L.PROOF_BAD_RLP
+PROOF_BAD_NODE = L.PROOF_BAD_NODE
+PROOF_EXTRA_NODES = L.PROOF_EXTRA_NODES
+PROOF_MISSING_NODE = L.PROOF_MISSING_NODE
+PROOF_BAD_INPUT = L.PROOF_BAD_INPUT
+
+
+class UnsortedError(ValueError):
+    """mptize precondition (mpt.zig:39): keys strictly increasing."""
+
+
+@dataclass(frozen=True)
+class KeyVal:
+    """mpt.zig:13-34.  `nibbles` is what KeyVal.init derives from the key bytes."""
+    key: bytes
+    value: bytes
+
+    @staticmethod
+    def init(key: bytes, value: bytes) -> "KeyVal":
+        return KeyVal(bytes(key), bytes(value))
+
+    @property
+    def nibbles(self) -> bytes:
+        out = bytearray()
+        for b in self.key:
+            out.append(b >> 4)
+            out.append(b & 0x0F)
+        return bytes(out)
+
+    @staticmethod
+    def less_than(a: "KeyVal", b: "KeyVal") -> bool:
+        return a.nibbles < b.nibbles
+
+
+def _pack(items, off_dtype):
+    off = np.zeros(len(items) + 1, off_dtype)
+    if items:
+        off[1:] = np.cumsum([len(x) for x in items])
+    blob = np.frombuffer(b"".join(items), np.uint8).copy() if items else np.zeros(0, np.uint8)
+    if blob.size == 0:
+        blob = np.zeros(1, np.uint8)
+    return blob, off
+
+
+def mptize_packed(keys: np.ndarray, key_off: np.ndarray, vals: np.ndarray, val_off: np.ndarray,
+                  ctx: Context | None = None) -> bytes:
+    ctx = ctx or default_context()
+    keys = np.ascontiguousarray(keys, np.uint8)
+    key_off = np.ascontiguousarray(key_off, np.uint32)
+    vals = np.ascontiguousarray(vals, np.uint8)
+    val_off = np.ascontiguousarray(val_off, np.uint64)
+    n = len(key_off) - 1
+    out = np.zeros(32, np.uint8)
+    rc = ctx._lib.phant_mpt_root(ctx.handle, _np_ptr(keys), _np_ptr(key_off), _np_ptr(vals), _np_ptr(val_off), n,
+                                 _np_ptr(out))
+    if rc == L.E_UNSORTED:
+        raise UnsortedError("mptize: keys must be strictly increasing")
+    ctx.check(rc)
+    return out.tobytes()
+
+
+def mptize(keyvals, ctx: Context | None = None) -> bytes:
+    """Root hash of the MPT holding exactly `keyvals` (sorted by key)."""
+    kb, ko = _pack([kv.key for kv in keyvals], np.uint32)
+    vb, vo = _pack([kv.value for kv in keyvals], np.uint64)
+    return mptize_packed(kb, ko, vb, vo, ctx)
+
+
+def index_root_rlp(items, ctx: Context | None = None) -> bytes:
+    """calculateMPTRoot (blockchain.zig:209-235): item i under key rlp(i)."""
+    ctx = ctx or default_context()
+    blob, off = _pack([bytes(x) for x in items], np.uint64)
+    out = np.zeros(32, np.uint8)
+    ctx.check(ctx._lib.phant_index_root_rlp(ctx.handle, _np_ptr(blob), _np_ptr(off), len(items), _np_ptr(out)))
+    return out.tobytes()
+
+
+def index_root_be32(items, ctx: Context | None = None) -> bytes:
+    """ExecutionPayload.toBlock (execution_payload.zig:125-158): 32-byte BE index keys."""
+    ctx = ctx or default_context()
+    blob, off = _pack([bytes(x) for x in items], np.uint64)
+    out = np.zeros(32, np.uint8)
+    ctx.check(ctx._lib.phant_index_root_be32(ctx.handle, _np_ptr(blob), _np_ptr(off), len(items), _np_ptr(out)))
+    return out.tobytes()
+
+
+def verify_batch(roots, root_idx, keys, key_len, nodes, node_off, proof_first_node, ctx: Context | None = None):
+    """Host form.  numpy in -> (status u8[n], value_off u64[n], value_len u32[n])."""
+    ctx = ctx or default_context()
+    roots = np.ascontiguousarray(roots, np.uint8).reshape(-1)
+    n_roots = roots.size // 32
+    keys = np.ascontiguousarray(keys, np.uint8).reshape(-1)
+    nodes = np.ascontiguousarray(nodes, np.uint8).reshape(-1)
+    nodes_len = nodes.size
+    if nodes.size == 0:
+        nodes = np.zeros(1, np.uint8)
+    if keys.size == 0:
+        keys = np.zeros(1, np.uint8)
+    node_off = np.ascontiguousarray(node_off, np.uint64)
+    pfn = np.ascontiguousarray(proof_first_node, np.uint32)
+    n = len(pfn) - 1
+    ri = None if root_idx is None else np.ascontiguousarray(root_idx, np.uint32)
+    status = np.zeros(max(n, 1), np.uint8)
+    voff = np.zeros(max(n, 1), np.uint64)
+    vlen = np.zeros(max(n, 1), np.uint32)
+    ctx.check(ctx._lib.phant_mpt_verify_batch(
+        ctx.handle, _np_ptr(roots), n_roots, None if ri is None else _np_ptr(ri), _np_ptr(keys), key_len,
+        _np_ptr(nodes), nodes_len, _np_ptr(node_off), _np_ptr(pfn), n, _np_ptr(status), _np_ptr(voff),
+        _np_ptr(vlen)))
+    return status[:n], voff[:n], vlen[:n]
+
+
+@dataclass
+class ProofBatch:
+    """A witness resident in HBM (all tensors on one device).
+
+    roots (n_roots, 32) u8 | root_idx (n,) i32 or None | keys (n, key_len) u8 |
+    nodes (nodes_len,) u8 | node_off (total_nodes+1,) i64 | proof_first_node (n+1,) i32
+    """
+    roots: torch.Tensor
+    root_idx: torch.Tensor | None
+    keys: torch.Tensor
+    nodes: torch.Tensor
+    node_off: torch.Tensor
+    proof_first_node: torch.Tensor
+
+    @property
+    def n(self) -> int:
+        return self.proof_first_node.numel() - 1
+
+    @property
+    def key_len(self) -> int:
+        return self.keys.shape[1] if self.keys.dim() == 2 else 0
+
+    @property
+    def n_roots(self) -> int:
+        return self.roots.numel() // 32
+
+    def algorithmic_bytes(self) -> int:
+        """node bytes + key bytes read, 1 status byte written per proof."""
+        return int(self.nodes.numel() + self.keys.numel() + self.n)
+
+
+def verify_batch_dev(b: ProofBatch, status: torch.Tensor | None = None, value_off: torch.Tensor | None = None,
+                     value_len: torch.Tensor | None = None, ctx: Context | None = None) -> torch.Tensor:
+    """Device form, asynchronous on the ctx stream.  Returns the status tensor."""
+    ctx = ctx or default_context(b.nodes.device.index)
+    n = b.n
+    dev = b.nodes.device
+    assert b.nodes.dtype == torch.uint8 and b.node_off.dtype == torch.int64
+    assert b.proof_first_node.dtype == torch.int32 and b.keys.dtype == torch.uint8 and b.roots.dtype == torch.uint8
+    if b.root_idx is not None:
+        assert b.root_idx.dtype == torch.int32
+    if status is None:
+        status = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx.check(ctx._lib.phant_mpt_verify_batch_dev(
+        ctx.handle, b.roots.data_ptr(), b.n_roots, None if b.root_idx is None else b.root_idx.data_ptr(),
+        b.keys.data_ptr(), b.key_len, b.nodes.data_ptr(), b.nodes.numel(), b.node_off.data_ptr(),
+        b.proof_first_node.data_ptr(), n, status.data_ptr(),
+        None if value_off is None else value_off.data_ptr(), None if value_len is None else value_len.data_ptr()))
+    return status
+
+
+def verdict_dev(status: torch.Tensor, root_idx: torch.Tensor | None, n_roots: int,
+                out: torch.Tensor | None = None, ctx: Context | None = None) -> torch.Tensor:
+    """fail_count[r] = number of proofs against root r that are not PRESENT/ABSENT (int32, device)."""
+    ctx = ctx or default_context(status.device.index)
+    if out is None:
+        out = torch.empty(n_roots, dtype=torch.int32, device=status.device)
+    ctx.check(ctx._lib.phant_mpt_verdict_dev(ctx.handle, status.data_ptr(),
+                                             None if root_idx is None else root_idx.data_ptr(), status.numel(),
+                                             n_roots, out.data_ptr()))
+    return out

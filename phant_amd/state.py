@@ -1,0 +1,53 @@
+"""The state-root surface src/state lacks (`StateDB.root()`, TODO at
+src/blockchain/blockchain.zig:83-85) over the AccountState fields of
+src/state/types.zig:13-20."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib as L
+from .context import Context, default_context, _np_ptr
+
+
+@dataclass
+class AccountState:
+    """src/state/types.zig:13-20 (allocator dropped)."""
+    addr: bytes
+    nonce: int = 0
+    balance: int = 0
+    code: bytes = b""
+    storage: dict = field(default_factory=dict)  # u256 slot -> u256 value
+
+
+def state_root(accounts, ctx: Context | None = None) -> bytes:
+    """accounts: iterable of AccountState (or dicts with the same keys)."""
+    ctx = ctx or default_context()
+    acc = [a if isinstance(a, AccountState) else AccountState(**a) for a in accounts]
+    n = len(acc)
+    addrs = np.zeros((max(n, 1), 20), np.uint8)
+    nonces = np.zeros(max(n, 1), np.uint64)
+    bal = np.zeros((max(n, 1), 32), np.uint8)
+    codes, sk, sv, first = [], [], [], [0]
+    for i, a in enumerate(acc):
+        addrs[i] = np.frombuffer(a.addr, np.uint8)
+        nonces[i] = a.nonce
+        bal[i] = np.frombuffer(int(a.balance).to_bytes(32, "big"), np.uint8)
+        codes.append(bytes(a.code))
+        for s, v in a.storage.items():
+            sk.append(int(s).to_bytes(32, "big"))
+            sv.append(int(v).to_bytes(32, "big"))
+        first.append(len(sk))
+    code_off = np.zeros(n + 1, np.uint64)
+    if n:
+        code_off[1:] = np.cumsum([len(c) for c in codes])
+    code = np.frombuffer(b"".join(codes), np.uint8).copy() if code_off[-1] else np.zeros(1, np.uint8)
+    skb = np.frombuffer(b"".join(sk), np.uint8).copy() if sk else np.zeros(32, np.uint8)
+    svb = np.frombuffer(b"".join(sv), np.uint8).copy() if sv else np.zeros(32, np.uint8)
+    fi = np.array(first, np.uint32)
+    out = np.zeros(32, np.uint8)
+    ctx.check(ctx._lib.phant_state_root(ctx.handle, _np_ptr(addrs), _np_ptr(nonces), _np_ptr(bal), _np_ptr(code),
+                                        _np_ptr(code_off), _np_ptr(skb), _np_ptr(svb), _np_ptr(fi), n,
+                                        _np_ptr(out)))
+    return out.tobytes()

@@ -1,0 +1,181 @@
+"""Synthetic witnesses for BASELINE.json's configs, built ON the GPU with the
+product's own batched Keccak (nothing here touches oracle/).
+
+`account_witness(n, depth=8)` is config 3: n account proofs against ONE state
+root, every proof = (depth-1) full 17-item branch nodes (532 B, all 16 slots
+hashed) + one 112-byte account leaf, shipped as its own node list (no
+cross-proof dedup): 3 836 B of nodes + 32 B key per proof at depth 8, 29
+Keccak-f permutations.  Slots that are on no proof path hold random 32-byte
+hashes (opaque subtrees: verification never opens siblings).  Node hashes are
+computed bottom-up so all proofs share the root.
+
+Sharding (multi-GPU): proofs shard by the top key nibble.  Rank r of W owns
+the top nibbles {x : x % W == r}; it builds its own subtrees, the 16 level-1
+hashes are summed across ranks with one all_reduce, and every rank forms the
+same 532-byte root branch.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from .crypto.hasher import keccak256_fixed_dev
+from .mpt import ProofBatch, PROOF_PRESENT, PROOF_ABSENT, PROOF_BAD_HASH
+
+EMPTY_ROOT = bytes.fromhex("56e81f171bcc55a6ff8345e692c0f86e5b48e01b996cadc001622fb5e363b421")
+EMPTY_CODE_HASH = bytes.fromhex("c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470")
+BRANCH_LEN = 532  # f9 02 11 + 16 x (a0 + 32) + 80
+
+
+def _account_rlp(nonce: int = 1, balance: int = 10 ** 18) -> bytes:
+    """rlp([nonce, balance, storageRoot=empty_mpt_root, codeHash=keccak("")]) -- 78 bytes for the defaults."""
+    def s(b: bytes) -> bytes:
+        if len(b) == 1 and b[0] < 0x80:
+            return b
+        assert len(b) <= 55
+        return bytes([0x80 + len(b)]) + b
+
+    def i(v: int) -> bytes:
+        return s(v.to_bytes((v.bit_length() + 7) // 8, "big"))
+
+    payload = i(nonce) + i(balance) + s(EMPTY_ROOT) + s(EMPTY_CODE_HASH)
+    assert 55 < len(payload) < 256
+    return bytes([0xF8, len(payload)]) + payload
+
+
+@dataclass
+class Witness:
+    batch: ProofBatch
+    expected: torch.Tensor  # (n,) uint8 status every proof must get
+    n_invalid: int          # proofs whose expected status is not PRESENT/ABSENT
+    nodes_per_proof: int
+    bytes_per_proof: int    # node bytes + key bytes
+    perms_per_proof: int
+    seed: int
+
+
+def _rand_u8(shape, gen, device):
+    return torch.randint(0, 256, shape, dtype=torch.uint8, device=device, generator=gen)
+
+
+def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_frac: float = 0.01,
+                    rank: int = 0, world: int = 1, group=None, ctx=None) -> Witness:
+    assert 2 <= depth <= 9, "depth counts nodes per proof: (depth-1) branches + 1 leaf"
+    assert world in (1, 2, 4, 8, 16)
+    device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    L = depth - 1  # branch levels; prefix of L nibbles identifies the leaf slot
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed * 1000003 + rank)
+
+    # ---- keys: distinct L-nibble prefixes, top nibble owned by this rank ----
+    owned = torch.tensor([x for x in range(16) if x % world == rank], device=device, dtype=torch.int64)
+    rest_bits = 4 * (L - 1)
+    need = n
+    pref = torch.empty(0, dtype=torch.int64, device=device)
+    while pref.numel() < n:
+        m = int(need * 1.2) + 64
+        top = owned[torch.randint(0, owned.numel(), (m,), device=device, generator=gen)]
+        rest = torch.randint(0, 1 << rest_bits, (m,), device=device, generator=gen) if rest_bits else \
+            torch.zeros(m, dtype=torch.int64, device=device)
+        pref = torch.unique(torch.cat([pref, (top << rest_bits) | rest]))
+        need = n - pref.numel()
+    pref = pref[torch.randperm(pref.numel(), device=device, generator=gen)[:n]]
+    keys = _rand_u8((n, 32), gen, device)
+    # write the L prefix nibbles into the key
+    for j in range(L):
+        nib = ((pref >> (4 * (L - 1 - j))) & 0xF).to(torch.uint8)
+        b = keys[:, j // 2]
+        keys[:, j // 2] = (b & 0x0F) | (nib << 4) if j % 2 == 0 else (b & 0xF0) | nib
+
+    # ---- leaves ----
+    acct = _account_rlp()
+    path_nibbles = 64 - L
+    if path_nibbles % 2:  # odd: flag 3, first nibble in the low half of byte 0
+        hp = torch.cat([(0x30 | (keys[:, L // 2] & 0x0F)).unsqueeze(1), keys[:, L // 2 + 1:]], dim=1)
+    else:
+        hp = torch.cat([torch.full((n, 1), 0x20, dtype=torch.uint8, device=device), keys[:, L // 2:]], dim=1)
+    hp_len = hp.shape[1]
+    assert 1 < hp_len <= 55 and len(acct) > 55
+    payload_len = 1 + hp_len + 2 + len(acct)
+    assert 55 < payload_len < 256
+    head = torch.tensor([0xF8, payload_len, 0x80 + hp_len], dtype=torch.uint8, device=device).expand(n, 3)
+    tail = torch.tensor(list(bytes([0xB8, len(acct)]) + acct), dtype=torch.uint8, device=device).expand(n, -1)
+    leaves = torch.cat([head, hp, tail], dim=1).contiguous()
+    leaf_len = leaves.shape[1]
+    child_hash = keccak256_fixed_dev(leaves.reshape(-1), leaf_len, n, ctx=ctx)
+
+    # ---- branch levels, bottom-up ----
+    level_nodes = [None] * L   # (U_l, 532) encodings
+    level_index = [None] * L   # (n,) which node of level l proof p passes through
+    child_prefix = pref        # identifies the child entities (starts as the leaves)
+    child_of_proof = torch.arange(n, device=device)
+    for l in range(L - 1, -1, -1):
+        nib = (child_prefix & 0xF)
+        parent_prefix = child_prefix >> 4
+        if l == 0 and world > 1:
+            # the root is shared by all ranks: gather the 16 level-1 hashes
+            import torch.distributed as dist
+            contrib = torch.zeros((16, 33), dtype=torch.int32, device=device)
+            contrib[nib, :32] = child_hash.to(torch.int32)
+            contrib[nib, 32] = 1
+            dist.all_reduce(contrib, group=group)
+            g0 = torch.Generator(device=device)
+            g0.manual_seed(seed * 7919 + 17)  # same filler on every rank
+            slots = _rand_u8((1, 16, 32), g0, device)
+            have = contrib[:, 32] > 0
+            slots[0, have] = contrib[have, :32].to(torch.uint8)
+            uniq_inv = torch.zeros(child_prefix.numel(), dtype=torch.int64, device=device)
+            U = 1
+        else:
+            uniq, uniq_inv = torch.unique(parent_prefix, return_inverse=True)
+            U = uniq.numel()
+            slots = _rand_u8((U, 16, 32), gen, device)
+            slots[uniq_inv, nib] = child_hash
+            child_prefix_next = uniq
+        enc = torch.empty((U, BRANCH_LEN), dtype=torch.uint8, device=device)
+        enc[:, 0] = 0xF9
+        enc[:, 1] = 0x02
+        enc[:, 2] = 0x11
+        body = enc[:, 3:3 + 16 * 33].view(U, 16, 33)
+        body[:, :, 0] = 0xA0
+        body[:, :, 1:] = slots
+        enc[:, BRANCH_LEN - 1] = 0x80
+        level_nodes[l] = enc
+        level_index[l] = uniq_inv[child_of_proof]
+        child_hash = keccak256_fixed_dev(enc.reshape(-1), BRANCH_LEN, U, ctx=ctx)
+        if not (l == 0 and world > 1):
+            child_prefix = child_prefix_next
+        child_of_proof = level_index[l]
+    root = child_hash.reshape(-1, 32)[:1].contiguous()
+
+    # ---- ship every proof as its own node list ----
+    proof_bytes = L * BRANCH_LEN + leaf_len
+    nodes = torch.empty((n, proof_bytes), dtype=torch.uint8, device=device)
+    for l in range(L):
+        nodes[:, l * BRANCH_LEN:(l + 1) * BRANCH_LEN] = level_nodes[l][level_index[l]]
+    nodes[:, L * BRANCH_LEN:] = leaves
+    sizes = torch.tensor([BRANCH_LEN] * L + [leaf_len], dtype=torch.int64, device=device)
+    within = torch.cumsum(sizes, 0) - sizes
+    node_off = (torch.arange(n, device=device, dtype=torch.int64).unsqueeze(1) * proof_bytes + within).reshape(-1)
+    node_off = torch.cat([node_off, torch.tensor([n * proof_bytes], dtype=torch.int64, device=device)])
+    pfn = (torch.arange(n + 1, device=device, dtype=torch.int64) * depth).to(torch.int32)
+
+    # ---- 1 % slice: corrupted nodes (-> BAD_HASH) and exclusion proofs (-> ABSENT) ----
+    expected = torch.full((n,), PROOF_PRESENT, dtype=torch.uint8, device=device)
+    n_bad = int(n * corrupt_frac / 2)
+    n_invalid = 0
+    if n_bad:
+        pick = torch.randperm(n, device=device, generator=gen)[:2 * n_bad]
+        bad, excl = pick[:n_bad], pick[n_bad:]
+        pos = torch.randint(0, proof_bytes, (n_bad,), device=device, generator=gen)
+        nodes[bad, pos] ^= 0x01
+        expected[bad] = PROOF_BAD_HASH
+        keys[excl, 31] ^= 0x01  # same path down to the leaf, different tail: proven absent
+        expected[excl] = PROOF_ABSENT
+        n_invalid = n_bad
+    batch = ProofBatch(roots=root, root_idx=None, keys=keys.contiguous(), nodes=nodes.reshape(-1),
+                       node_off=node_off.contiguous(), proof_first_node=pfn.contiguous())
+    perms = L * ((BRANCH_LEN + 1 + 135) // 136) + (leaf_len + 1 + 135) // 136
+    return Witness(batch=batch, expected=expected, n_invalid=n_invalid, nodes_per_proof=depth,
+                   bytes_per_proof=proof_bytes + 32, perms_per_proof=perms, seed=seed)

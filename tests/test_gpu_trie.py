@@ -1,0 +1,105 @@
+"""GPU trie hasher (mptize / index roots / state root) vs the reference's
+vectors, the fixture roots and the oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+from tests import golden
+from tests.witness_util import random_kv
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import phant_amd
+    return phant_amd
+
+
+def test_mptize_reference_vectors(P):
+    assert P.mpt.mptize([]) == P.mpt.empty_mpt_root
+    for v in golden.mpt_vectors():
+        kvs = [P.mpt.KeyVal.init(bytes.fromhex(k), bytes.fromhex(x)) for k, x in zip(v["keys"], v["values"])]
+        assert P.mpt.mptize(kvs).hex() == v["root"], v["name"]
+
+
+def test_mptize_rejects_unsorted(P):
+    KV = P.mpt.KeyVal.init
+    with pytest.raises(P.mpt.UnsortedError):
+        P.mpt.mptize([KV(b"\x02", b"a"), KV(b"\x01", b"b")])
+    with pytest.raises(P.mpt.UnsortedError):
+        P.mpt.mptize([KV(b"\x01", b"a"), KV(b"\x01", b"b")])
+    with pytest.raises(P.mpt.UnsortedError):
+        P.mpt.mptize([KV(b"\x01\x00", b"a"), KV(b"\x01", b"b")])
+
+
+@pytest.mark.parametrize("n,key_len,shared,vmax", [(1, 32, 0, 40), (2, 32, 0, 40), (3, 1, 0, 5), (16, 1, 0, 3),
+                                                     (256, 1, 0, 40), (1000, 32, 0, 120), (1000, 32, 10, 40),
+                                                     (5000, 3, 0, 10), (2000, 32, 62, 33), (300, 4, 0, 700),
+                                                     (20000, 32, 0, 90)])
+def test_mptize_random_vs_oracle(P, oracle, n, key_len, shared, vmax):
+    rng = np.random.default_rng(n + key_len * 31 + shared)
+    n = min(n, 256 ** key_len)
+    keys, vals = random_kv(rng, n, key_len, 1, vmax, shared)
+    kvs = [P.mpt.KeyVal.init(k, v) for k, v in zip(keys, vals)]
+    assert P.mpt.mptize(kvs) == oracle.mptize(keys, vals)
+
+
+def test_mptize_variable_length_keys_and_branch_values(P, oracle):
+    rng = np.random.default_rng(77)
+    keys = set()
+    while len(keys) < 600:
+        ln = int(rng.integers(0, 5))
+        keys.add(bytes(rng.integers(0, 4, ln, dtype=np.uint8) * 0x11))  # many prefix relations
+    keys = sorted(keys)
+    vals = [rng.integers(0, 256, int(rng.integers(1, 60)), dtype=np.uint8).tobytes() for _ in keys]
+    kvs = [P.mpt.KeyVal.init(k, v) for k, v in zip(keys, vals)]
+    assert P.mpt.mptize(kvs) == oracle.mptize(keys, vals)
+
+
+def test_fixture_tx_and_withdrawal_roots(P):
+    fx = golden.fixtures()
+    n = 0
+    for c in fx["cases"]:
+        for b in c["blocks"]:
+            assert P.mpt.index_root_rlp([bytes.fromhex(x) for x in b["tx_values"]]).hex() == b["transactions_trie"]
+            if "withdrawals_root" in b:
+                items = [bytes.fromhex(x) for x in b["withdrawal_values"]]
+                assert P.mpt.index_root_rlp(items).hex() == b["withdrawals_root"], c["name"]
+            n += 1
+    assert n == 87
+
+
+def test_index_root_be32_vs_oracle(P, oracle):
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 17, 129, 400):
+        items = [rng.integers(0, 256, int(rng.integers(1, 200)), dtype=np.uint8).tobytes() for _ in range(n)]
+        assert P.mpt.index_root_be32(items) == oracle.index_root_be32(items)
+        assert P.mpt.index_root_rlp(items) == oracle.index_root_rlp(items)
+
+
+def test_fixture_state_roots(P):
+    fx = golden.fixtures()
+    n = 0
+    for c in fx["cases"]:
+        acc = golden.accounts_of(c["pre"], fx["codes"])
+        assert P.state.state_root(acc).hex() == c["genesis_state_root"], c["name"]
+        if "post" in c:
+            acc = golden.accounts_of(c["post"], fx["codes"])
+            assert P.state.state_root(acc).hex() == c["post_state_root"], c["name"]
+        n += 1
+    assert n == 84
+
+
+def test_state_root_random_vs_oracle(P, oracle):
+    rng = np.random.default_rng(9)
+    acc = []
+    for i in range(3000):
+        st = {}
+        for _ in range(int(rng.integers(0, 6))):
+            st[int(rng.integers(0, 2 ** 62))] = int(rng.integers(0, 3)) * int(rng.integers(1, 2 ** 62))
+        acc.append(dict(addr=rng.integers(0, 256, 20, dtype=np.uint8).tobytes(), nonce=int(rng.integers(0, 1000)),
+                        balance=int(rng.integers(0, 2 ** 62)) ** 2,
+                        code=rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes(),
+                        storage=st))
+    assert P.state.state_root(acc) == oracle.state_root(acc)
+    assert P.state.state_root([]) == P.mpt.empty_mpt_root

@@ -1,0 +1,214 @@
+"""Batched MPT proof verification (HIP) vs the oracle, through the C-ABI.
+Status bytes and value locations must match exactly."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden
+from tests.witness_util import random_kv, pack_proofs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    import phant_amd
+    return phant_amd.mpt
+
+
+def _both(M, oracle, roots, root_idx, keys, key_len, proofs):
+    nodes, node_off, pfn = pack_proofs(proofs)
+    karr = np.frombuffer(b"".join(keys), np.uint8) if key_len else np.zeros(0, np.uint8)
+    r = np.frombuffer(b"".join(roots), np.uint8)
+    got = M.verify_batch(r, root_idx, karr, key_len, nodes, node_off, pfn)
+    want = oracle.mpt_verify_batch(r, root_idx, karr if karr.size else np.zeros(1, np.uint8), key_len,
+                                   nodes if nodes.size else np.zeros(1, np.uint8), node_off, pfn)
+    return got, want
+
+
+def _assert_same(got, want):
+    assert np.array_equal(got[0], want[0]), (got[0][:20], want[0][:20])
+    assert np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2], want[2])
+
+
+def test_reference_vector_tries(M, oracle):
+    for v in golden.mpt_vectors():
+        keys = [bytes.fromhex(k) for k in v["keys"]]
+        vals = [bytes.fromhex(x) for x in v["values"]]
+        if not keys:
+            continue
+        klen = len(keys[0])
+        if any(len(k) != klen for k in keys):
+            # batch API has one key_len: verify key-length groups separately
+            groups = {}
+            for k in keys:
+                groups.setdefault(len(k), []).append(k)
+        else:
+            groups = {klen: keys}
+        t = oracle.Trie(keys, vals)
+        for kl, ks in groups.items():
+            proofs = [t.prove(k) for k in ks]
+            got, want = _both(M, oracle, [t.root()], None, ks, kl, proofs)
+            _assert_same(got, want)
+            assert (got[0] == M.PROOF_PRESENT).all()
+
+
+@pytest.mark.parametrize("n,key_len,shared", [(1, 32, 0), (2, 32, 0), (17, 32, 0), (400, 32, 0), (300, 32, 6),
+                                                (64, 2, 0), (200, 3, 0), (50, 1, 0), (300, 20, 2)])
+def test_random_tries(M, oracle, n, key_len, shared):
+    rng = np.random.default_rng(n * 1000 + key_len + shared)
+    keys, vals = random_kv(rng, n, key_len, 1, 90, shared)
+    t = oracle.Trie(keys, vals)
+    q = list(keys)
+    for _ in range(200):  # exclusion proofs
+        k = bytearray(rng.integers(0, 256, key_len, dtype=np.uint8).tobytes())
+        for i in range(shared // 2):
+            k[i] = 0xAB
+        q.append(bytes(k))
+    proofs = [t.prove(k) for k in q]
+    got, want = _both(M, oracle, [t.root()], None, q, key_len, proofs)
+    _assert_same(got, want)
+    assert (got[0][:n] == M.PROOF_PRESENT).all()
+    nodes, _, _ = pack_proofs(proofs)
+    for i in range(n):
+        assert nodes[int(got[1][i]):int(got[1][i]) + int(got[2][i])].tobytes() == vals[i]
+
+
+def test_embedded_nodes_and_branch_values(M, oracle):
+    keys = [bytes([a, b]) for a in (0x10, 0x11, 0x20) for b in (0x00, 0x01, 0xF0)]
+    vals = [bytes([i + 1]) * 2 for i in range(len(keys))]
+    t = oracle.Trie(keys, vals)
+    q = keys + [b"\x10\x02", b"\x30\x00", b"\x11\x02", b"\x20\xf1"]
+    got, want = _both(M, oracle, [t.root()], None, q, 2, [t.prove(k) for k in q])
+    _assert_same(got, want)
+    # variable key lengths incl. keys that end on a branch (value slot)
+    keys2 = sorted(keys + [b"\x10", b"\x20"])
+    vals2 = [bytes([i + 1]) * 3 for i in range(len(keys2))]
+    t2 = oracle.Trie(keys2, vals2)
+    for kl in (1, 2, 3, 0):
+        q = [k for k in keys2 if len(k) == kl] + [bytes([0x10, 0x00, 0x05][:kl]), bytes([0x77] * kl)]
+        got, want = _both(M, oracle, [t2.root()], None, q, kl, [t2.prove(k) for k in q])
+        _assert_same(got, want)
+
+
+def test_mutation_fuzz_matches_oracle(M, oracle):
+    """Random structural damage: whatever the oracle says, the GPU says."""
+    rng = np.random.default_rng(2024)
+    keys, vals = random_kv(rng, 300, 32, 1, 70)
+    t = oracle.Trie(keys, vals)
+    root = t.root()
+    q, proofs, roots, ridx = [], [], [root, bytes(32), oracle.keccak256(b"x")], []
+    for it in range(3000):
+        k = keys[int(rng.integers(0, len(keys)))]
+        p = t.prove(k)
+        kind = int(rng.integers(0, 12))
+        r = 0
+        if kind == 0:
+            i = int(rng.integers(0, len(p)))
+            nd = bytearray(p[i])
+            nd[int(rng.integers(0, len(nd)))] ^= 1 << int(rng.integers(0, 8))
+            p = p[:i] + [bytes(nd)] + p[i + 1:]
+        elif kind == 1:
+            p = p[:-1]
+        elif kind == 2:
+            p = p + [p[int(rng.integers(0, len(p)))]]
+        elif kind == 3:
+            p = []
+        elif kind == 4:
+            r = int(rng.integers(1, 3))
+        elif kind == 5 and len(p) > 1:
+            i = int(rng.integers(0, len(p) - 1))
+            p = p[:i] + [p[i + 1], p[i]] + p[i + 2:]
+        elif kind == 6:
+            i = int(rng.integers(0, len(p)))
+            p = p[:i] + [p[i][:int(rng.integers(0, len(p[i]) + 1))]] + p[i + 1:]
+        elif kind == 7:
+            k = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+        elif kind == 8:
+            i = int(rng.integers(0, len(p)))
+            p = p[:i] + [p[i] + b"\x00"] + p[i + 1:]
+        elif kind == 9:
+            p = [rng.integers(0, 256, int(rng.integers(0, 80)), dtype=np.uint8).tobytes()] + p[1:]
+        q.append(k)
+        proofs.append(p)
+        ridx.append(r)
+    got, want = _both(M, oracle, roots, np.array(ridx, np.uint32), q, 32, proofs)
+    _assert_same(got, want)
+    assert len(set(got[0].tolist())) >= 5  # the fuzz reaches many distinct outcomes
+
+
+def test_garbage_committed_roots(M, oracle):
+    """Nodes that hash correctly but are not MPT nodes: structure checks, same code as the oracle."""
+    key = bytes(32)
+    cases = [b"\x80", b"\xc0", b"\xc1\x80", b"\xc3\x80\x80\x80", b"\xc2\x80", b"\xc1\x80\x80", b"\xc2\x81\x05",
+             b"\xf8\x02\x80\x80", b"\xc2\x80\x80", b"\xc2\x40\x80", b"\xc2\x21\x80", b"\xc2\x00\x80",
+             b"\xc3\x11\x81\x80", b"\xc2\x20\x80", bytes([0xc0 + 18]) + b"\x80" * 18,
+             bytes([0xc0 + 17]) + b"\x80" * 17, bytes([0xc0 + 18]) + b"\x80" * 16 + b"\xc1\x80",
+             bytes([0xc0 + 18]) + b"\x81\x80" + b"\x80" * 16, b"", b"\xb8", b"\xf9\x02", b"\xf9\x00\x40" + b"\x00" * 64,
+             b"\xbf" + b"\xff" * 8, b"\xff" + b"\xff" * 8, b"\xc2\x30\x80", b"\xc4\x20\xc2\x80\x80",
+             # extension with an embedded branch-less child, leaf inside an embedded node
+             b"\xc7\x11\xc5\x30\x83abc", b"\xc6\x00\xc4\x20\x82hi"]
+    roots = [oracle.keccak256(c) for c in cases]
+    got, want = _both(M, oracle, roots, np.arange(len(cases), dtype=np.uint32), [key] * len(cases), 32,
+                      [[c] for c in cases])
+    _assert_same(got, want)
+
+
+def test_bad_offsets_are_flagged(M):
+    root = np.zeros(32, np.uint8)
+    keys = np.zeros(64, np.uint8)
+    nodes = np.zeros(100, np.uint8)
+    node_off = np.array([0, 50, 40, 1000], np.uint64)   # decreasing, then past the end
+    pfn = np.array([0, 1, 3], np.uint32)
+    st, _, _ = M.verify_batch(root, None, keys, 32, nodes, node_off, pfn)
+    assert st[0] == M.PROOF_BAD_HASH and st[1] == M.PROOF_BAD_INPUT
+
+
+def test_synthetic_depth8_small_vs_oracle(M, oracle):
+    import phant_amd
+    w = phant_amd.witness.account_witness(3000, depth=8, seed=2, corrupt_frac=0.05)
+    st = M.verify_batch_dev(w.batch)
+    torch.cuda.synchronize()
+    assert torch.equal(st, w.expected)
+    b = w.batch
+    want = oracle.mpt_verify_batch(b.roots.cpu().numpy(), None, b.keys.cpu().numpy(), 32, b.nodes.cpu().numpy(),
+                                   b.node_off.cpu().numpy().astype(np.uint64),
+                                   b.proof_first_node.cpu().numpy().astype(np.uint32))
+    assert np.array_equal(st.cpu().numpy(), want[0])
+    assert w.bytes_per_proof == 3868 and w.perms_per_proof == 29 and w.nodes_per_proof == 8
+    fails = M.verdict_dev(st, None, 1)
+    assert int(fails.item()) == w.n_invalid == 75
+
+
+@pytest.mark.parametrize("depth", [2, 3, 5, 9])
+def test_synthetic_other_depths(M, oracle, depth):
+    import phant_amd
+    w = phant_amd.witness.account_witness(500, depth=depth, seed=5, corrupt_frac=0.1)
+    st = M.verify_batch_dev(w.batch)
+    assert torch.equal(st, w.expected)
+    b = w.batch
+    want = oracle.mpt_verify_batch(b.roots.cpu().numpy(), None, b.keys.cpu().numpy(), 32, b.nodes.cpu().numpy(),
+                                   b.node_off.cpu().numpy().astype(np.uint64),
+                                   b.proof_first_node.cpu().numpy().astype(np.uint32))
+    assert np.array_equal(st.cpu().numpy(), want[0])
+
+
+def test_config3_full_size_properties(M):
+    """BASELINE config 3 at full size (100 k depth-8 proofs, one root): every status is the one the
+    construction forces, the per-root verdict counts exactly the corrupted proofs, and verifying is
+    idempotent."""
+    import phant_amd
+    w = phant_amd.witness.account_witness(100_000, depth=8, seed=2)
+    vo = torch.empty(w.batch.n, dtype=torch.int64, device="cuda")
+    vl = torch.empty(w.batch.n, dtype=torch.int32, device="cuda")
+    st = M.verify_batch_dev(w.batch, value_off=vo, value_len=vl)
+    assert torch.equal(st, w.expected)
+    assert int(M.verdict_dev(st, None, 1).item()) == w.n_invalid == 500
+    st2 = M.verify_batch_dev(w.batch)
+    assert torch.equal(st, st2)
+    present = st == M.PROOF_PRESENT
+    assert (vl[present] == 78).all() and (vl[~present] == 0).all()
+    # the value of proof i is the last 78 bytes of its leaf
+    i = torch.nonzero(present)[:5, 0]
+    assert torch.equal(vo[i], (i + 1) * 3836 - 78)
