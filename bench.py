@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--verify-mode", default="flat", choices=["flat", "fused"],
+                    help="flat = node-parallel pipeline (default); fused = one lane per proof (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -123,7 +125,8 @@ def main():
     from phant_amd import mpt as M
     from phant_amd.crypto import hasher as H
 
-    ctx = phant_amd.default_context(local_rank)  # bound to torch's current stream on this device
+    # bound to torch's current stream on this device
+    ctx = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"))
 
     if args.workload == "config3":
         w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
@@ -203,10 +206,12 @@ def main():
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}"},
+        "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}",
+                   "verify_mode": args.verify_mode if args.workload == "config3" else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "mpt_verify_fused_kernel" if args.workload == "config3" else "keccak256_fixed_kernel",
+                     "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
+                                "hash_nodes_kernel" if args.verify_mode == "flat" else "mpt_verify_fused_kernel"),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

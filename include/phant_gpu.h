@@ -68,7 +68,9 @@ extern "C" {
 
 typedef struct phant_ctx phant_ctx;
 
-#define PHANT_CTX_OWN_STREAM 1u /* flags: ignore `stream`, create a private non-blocking stream */
+#define PHANT_CTX_OWN_STREAM 1u   /* flags: ignore `stream`, create a private non-blocking stream */
+#define PHANT_CTX_VERIFY_FUSED 2u /* flags: verify with the one-lane-per-proof kernel instead of the
+                                     node-parallel pipeline (A/B and debugging) */
 
 typedef struct phant_opts {
     uint32_t struct_size; /* = sizeof(phant_opts) */
@@ -126,6 +128,7 @@ PHANT_API int32_t phant_keccak256_fixed_dev(phant_ctx *ctx, const uint8_t *d_blo
  *   status           n bytes out (PHANT_PROOF_*)
  *   value_off/len    n entries out, or NULL: for PRESENT, where in `nodes`
  *                    the value bytes sit
+ * The device form also takes total_nodes (= entries of node_off minus one).
  */
 PHANT_API int32_t phant_mpt_verify_batch(phant_ctx *ctx, const uint8_t *roots, uint32_t n_roots,
                                          const uint32_t *root_idx, const uint8_t *keys,
@@ -138,7 +141,7 @@ PHANT_API int32_t phant_mpt_verify_batch_dev(phant_ctx *ctx, const uint8_t *d_ro
                                              uint32_t n_roots, const uint32_t *d_root_idx,
                                              const uint8_t *d_keys, uint32_t key_len,
                                              const uint8_t *d_nodes, uint64_t nodes_len,
-                                             const uint64_t *d_node_off,
+                                             const uint64_t *d_node_off, uint32_t total_nodes,
                                              const uint32_t *d_proof_first_node, uint32_t n,
                                              uint8_t *d_status, uint64_t *d_value_off,
                                              uint32_t *d_value_len);
@@ -183,8 +186,9 @@ PHANT_API int32_t phant_state_root(phant_ctx *ctx, const uint8_t *addrs, const u
                                    uint32_t n, uint8_t out[32]);
 
 /* -------------------------------------------------------------- measurement
- * Time of the last *_dev kernel sequence on the ctx stream, measured with HIP
- * events recorded on that stream around the launches (bench.py uses this for
+ * Duration of the DOMINANT kernel of the last *_dev call (the node-hashing
+ * kernel for verify, the sponge kernel for keccak), measured with HIP events
+ * recorded on the ctx stream around that launch (bench.py uses this for
  * `roofline.achieved`).  Enable with phant_timing(ctx, 1). */
 PHANT_API int32_t phant_timing(phant_ctx *ctx, int32_t enable);
 PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);

@@ -50,8 +50,8 @@ SYMBOLS = {
     "phant_keccak256_batch_dev": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "phant_keccak256_fixed_dev": (_i32, [_vp, _vp, _u32, _u64, _u32, _vp]),
     "phant_mpt_verify_batch": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp]),
-    "phant_mpt_verify_batch_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u32, _vp, _vp,
-                                          _vp]),
+    "phant_mpt_verify_batch_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp,
+                                          _vp, _vp]),
     "phant_mpt_verdict_dev": (_i32, [_vp, _vp, _vp, _u32, _u32, _vp]),
     "phant_mpt_root": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "phant_index_root_rlp": (_i32, [_vp, _vp, _vp, _u32, _vp]),

@@ -16,7 +16,7 @@ def _np_ptr(a: np.ndarray):
 class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
-    def __init__(self, device: int | None = None, use_torch_stream: bool = True):
+    def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False):
         lib = L.lib()
         if not torch.cuda.is_available():
             raise L.PhantError(L.E_NO_DEVICE, "no GPU visible (phant_amd has no CPU fallback)")
@@ -27,6 +27,8 @@ class Context:
         stream, flags = None, 1  # PHANT_CTX_OWN_STREAM
         if use_torch_stream:
             stream, flags = torch.cuda.current_stream(self.device).cuda_stream or None, 0
+        if verify_fused:
+            flags |= 2  # PHANT_CTX_VERIFY_FUSED
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
         h = C.c_void_p()
         rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))

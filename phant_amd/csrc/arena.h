@@ -1,0 +1,58 @@
+// arena.h -- grow-only device arenas owned by a phant_ctx, so that host-form
+// calls do not pay hipMalloc/hipFree (which synchronise the device) per call.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace phant {
+
+struct DevArena {
+    uint8_t* base = nullptr;
+    size_t cap = 0, used = 0;
+
+    static size_t round(size_t n) { return (n + 255) / 256 * 256; }
+
+    // Make room for `total` bytes and start allocating from the beginning.
+    // Contents are dropped; the caller guarantees no kernel still uses them.
+    hipError_t reset(size_t total) {
+        used = 0;
+        if (total <= cap) return hipSuccess;
+        if (base) {
+            hipError_t e = hipFree(base);  // implies a device synchronise
+            base = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        const size_t want = total + total / 4 + (1u << 20);
+        hipError_t e = hipMalloc((void**)&base, want);
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    template <class T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(base + used);
+        used += round(count * sizeof(T));
+        return p;
+    }
+    void release() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = used = 0;
+    }
+};
+
+// The arenas a ctx lends to the host-form entry points.
+struct Workspaces {
+    DevArena io;  // staged inputs / outputs of the current call
+    DevArena t1;  // trie builder: per-key / per-boundary arrays
+    DevArena t2;  // trie builder: slot tables + encoding scratch
+    void release() {
+        io.release();
+        t1.release();
+        t2.release();
+    }
+};
+
+}  // namespace phant

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/phant_gpu.h"
+#include "arena.h"
 #include "launch.h"
 #include "trie_build.h"
 
@@ -21,9 +22,10 @@ struct phant_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
-    // bump-allocated device workspace for the host-form calls
-    uint8_t* ws = nullptr;
-    size_t ws_cap = 0, ws_used = 0;
+    // grow-only device arenas for the host-form calls
+    phant::Workspaces ws;
+    phant::DevArena dv;  // workspace of the device-form verify pipeline
+    bool verify_fused = false;
     // stream-side timing of the last device-form call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -62,30 +64,20 @@ int32_t fail(phant_ctx* c, int32_t code, const char* what, hipError_t e = hipSuc
         if (e_ != hipSuccess) return fail((c), PHANT_E_DEVICE, #call, e_); \
     } while (0)
 
-constexpr size_t WS_ALIGN = 256;
-
-// Reserve `total` bytes of workspace (drops previous contents).
+// Reserve `total` bytes of staging workspace (drops previous contents).
 int32_t ws_reset(phant_ctx* c, size_t total) {
-    c->ws_used = 0;
-    if (total <= c->ws_cap) return PHANT_OK;
-    if (c->ws) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipFree(c->ws));
-        c->ws = nullptr;
-        c->ws_cap = 0;
+    if (total > c->ws.io.cap) {
+        hipError_t s = hipStreamSynchronize(c->stream);
+        if (s != hipSuccess) return fail(c, PHANT_E_DEVICE, "hipStreamSynchronize", s);
     }
-    size_t cap = total + total / 4 + (1u << 20);
-    hipError_t e = hipMalloc((void**)&c->ws, cap);
+    hipError_t e = c->ws.io.reset(total);
     if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(workspace)", e);
-    c->ws_cap = cap;
     return PHANT_OK;
 }
-size_t ws_round(size_t n) { return (n + WS_ALIGN - 1) / WS_ALIGN * WS_ALIGN; }
+size_t ws_round(size_t n) { return phant::DevArena::round(n); }
 template <class T>
 T* ws_take(phant_ctx* c, size_t count) {
-    T* p = reinterpret_cast<T*>(c->ws + c->ws_used);
-    c->ws_used += ws_round(count * sizeof(T));
-    return p;
+    return c->ws.io.take<T>(count);
 }
 
 struct TimedRegion {
@@ -127,6 +119,8 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         stream = opts->stream;
         own = (opts->flags & PHANT_CTX_OWN_STREAM) != 0;
     }
+    bool fused = opts && (opts->flags & PHANT_CTX_VERIFY_FUSED);
+    if (const char* m = std::getenv("PHANT_VERIFY_MODE")) fused = std::strcmp(m, "fused") == 0;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || dev < 0 || dev >= n) return PHANT_E_NO_DEVICE;
     hipDeviceProp_t prop;
@@ -135,6 +129,7 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     phant_ctx* c = new (std::nothrow) phant_ctx();
     if (!c) return PHANT_E_OOM;
     c->device = dev;
+    c->verify_fused = fused;
     DeviceGuard g(dev);
     if (!own) {
         c->stream = (hipStream_t)stream;  // nullptr = the default stream
@@ -157,7 +152,8 @@ void phant_ctx_destroy(phant_ctx* c) {
     if (!c) return;
     DeviceGuard g(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->ws) (void)hipFree(c->ws);
+    c->ws.release();
+    c->dv.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -275,12 +271,31 @@ int32_t phant_keccak256_with_prefix(phant_ctx* c, const uint8_t* prefix, uint64_
 
 /* ------------------------------------------------------- proof verification */
 
+// Runs the verify pipeline on device-resident arguments (shared by both forms).
+static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes) {
+    if (c->verify_fused) {
+        TimedRegion t(c);
+        HIP_TRY(c, phant::launch_mpt_verify_fused(a, c->stream));
+        return PHANT_OK;
+    }
+    const size_t need = phant::verify_flat_workspace_bytes(total_nodes);
+    if (need > c->dv.cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipError_t e = c->dv.reset(need);
+        if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(verify workspace)", e);
+    }
+    HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, c->dv.base, c->stream, c->timing ? c->ev0 : nullptr,
+                                             c->timing ? c->ev1 : nullptr));
+    if (c->timing) c->ev_pending = true;
+    return PHANT_OK;
+}
+
 int32_t phant_mpt_verify_batch_dev(phant_ctx* c, const uint8_t* d_roots, uint32_t n_roots,
                                    const uint32_t* d_root_idx, const uint8_t* d_keys,
                                    uint32_t key_len, const uint8_t* d_nodes, uint64_t nodes_len,
-                                   const uint64_t* d_node_off, const uint32_t* d_proof_first_node,
-                                   uint32_t n, uint8_t* d_status, uint64_t* d_value_off,
-                                   uint32_t* d_value_len) {
+                                   const uint64_t* d_node_off, uint32_t total_nodes,
+                                   const uint32_t* d_proof_first_node, uint32_t n, uint8_t* d_status,
+                                   uint64_t* d_value_off, uint32_t* d_value_len) {
     if (!c) return PHANT_E_INVALID_ARG;
     if (n == 0) return PHANT_OK;
     if (!d_roots || n_roots == 0 || !d_node_off || !d_proof_first_node || !d_status || (key_len && !d_keys) ||
@@ -289,9 +304,7 @@ int32_t phant_mpt_verify_batch_dev(phant_ctx* c, const uint8_t* d_roots, uint32_
     phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len,
                         d_node_off, d_proof_first_node, n, d_status, d_value_off, d_value_len};
     DeviceGuard g(c->device);
-    TimedRegion t(c);
-    HIP_TRY(c, phant::launch_mpt_verify_fused(a, c->stream));
-    return PHANT_OK;
+    return verify_resident(c, a, total_nodes);
 }
 
 int32_t phant_mpt_verdict_dev(phant_ctx* c, const uint8_t* d_status, const uint32_t* d_root_idx,
@@ -343,7 +356,10 @@ int32_t phant_mpt_verify_batch(phant_ctx* c, const uint8_t* roots, uint32_t n_ro
     HIP_TRY(c, hipMemcpyAsync(d_pfn, proof_first_node, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
     phant::VerifyArgs a{d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
                         d_noff, d_pfn, n, d_status, d_voff, d_vlen};
-    HIP_TRY(c, phant::launch_mpt_verify_fused(a, s));
+    {
+        const int32_t vrc = verify_resident(c, a, total_nodes);
+        if (vrc) return vrc;
+    }
     HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
     if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     if (value_len) HIP_TRY(c, hipMemcpyAsync(value_len, d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -359,7 +375,7 @@ int32_t phant_mpt_root(phant_ctx* c, const uint8_t* keys, const uint32_t* key_of
     if (n && (!key_off || !val_off)) return fail(c, PHANT_E_INVALID_ARG, "mpt_root: null pointer");
     DeviceGuard g(c->device);
     std::string err;
-    int32_t rc = phant::trie_root_host(c->stream, keys, key_off, vals, val_off, n, out, err);
+    int32_t rc = phant::trie_root_host(c->ws, c->stream, keys, key_off, vals, val_off, n, out, err);
     if (rc) return fail(c, rc, err.c_str());
     return PHANT_OK;
 }
@@ -370,7 +386,7 @@ int32_t phant_index_root_rlp(phant_ctx* c, const uint8_t* items, const uint64_t*
     if (n && (!items || !item_off)) return fail(c, PHANT_E_INVALID_ARG, "index_root_rlp: null pointer");
     DeviceGuard g(c->device);
     std::string err;
-    int32_t rc = phant::index_root_host(c->stream, items, item_off, n, /*be32=*/false, out, err);
+    int32_t rc = phant::index_root_host(c->ws, c->stream, items, item_off, n, /*be32=*/false, out, err);
     if (rc) return fail(c, rc, err.c_str());
     return PHANT_OK;
 }
@@ -381,7 +397,7 @@ int32_t phant_index_root_be32(phant_ctx* c, const uint8_t* items, const uint64_t
     if (n && (!items || !item_off)) return fail(c, PHANT_E_INVALID_ARG, "index_root_be32: null pointer");
     DeviceGuard g(c->device);
     std::string err;
-    int32_t rc = phant::index_root_host(c->stream, items, item_off, n, /*be32=*/true, out, err);
+    int32_t rc = phant::index_root_host(c->ws, c->stream, items, item_off, n, /*be32=*/true, out, err);
     if (rc) return fail(c, rc, err.c_str());
     return PHANT_OK;
 }
@@ -395,7 +411,7 @@ int32_t phant_state_root(phant_ctx* c, const uint8_t* addrs, const uint64_t* non
         return fail(c, PHANT_E_INVALID_ARG, "state_root: null pointer");
     DeviceGuard g(c->device);
     std::string err;
-    int32_t rc = phant::state_root_host(c->stream, addrs, nonces, balances, code, code_off, slot_keys,
+    int32_t rc = phant::state_root_host(c->ws, c->stream, addrs, nonces, balances, code, code_off, slot_keys,
                                         slot_vals, slot_first, n, out, err);
     if (rc) return fail(c, rc, err.c_str());
     return PHANT_OK;

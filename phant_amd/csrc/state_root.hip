@@ -21,14 +21,6 @@
 namespace phant {
 namespace {
 
-struct DBuf {
-    void* p = nullptr;
-    ~DBuf() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-};
-
 #define SR_TRY(call)                                                          \
     do {                                                                      \
         hipError_t e_ = (call);                                               \
@@ -39,21 +31,21 @@ struct DBuf {
     } while (0)
 
 // keccak256 of n fixed-size records on the GPU, digests back to the host
-int32_t hash_fixed(hipStream_t st, const uint8_t* host, uint32_t rec_len, uint32_t n,
+int32_t hash_fixed(Workspaces& ws, hipStream_t st, const uint8_t* host, uint32_t rec_len, uint32_t n,
                    std::vector<uint8_t>& out, std::string& err) {
     out.resize((size_t)n * 32);
     if (!n) return PHANT_OK;
-    DBuf d_in, d_out;
-    SR_TRY(d_in.alloc((size_t)n * rec_len + 16));
-    SR_TRY(d_out.alloc((size_t)n * 32));
-    SR_TRY(hipMemcpyAsync(d_in.p, host, (size_t)n * rec_len, hipMemcpyHostToDevice, st));
-    SR_TRY(launch_keccak256_fixed((const uint8_t*)d_in.p, rec_len, rec_len, n, (uint8_t*)d_out.p, st));
-    SR_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size(), hipMemcpyDeviceToHost, st));
+    SR_TRY(ws.io.reset(DevArena::round((size_t)n * rec_len + 16) + DevArena::round((size_t)n * 32) + 512));
+    uint8_t* d_in = ws.io.take<uint8_t>((size_t)n * rec_len + 16);
+    uint8_t* d_out = ws.io.take<uint8_t>((size_t)n * 32);
+    SR_TRY(hipMemcpyAsync(d_in, host, (size_t)n * rec_len, hipMemcpyHostToDevice, st));
+    SR_TRY(launch_keccak256_fixed(d_in, rec_len, rec_len, n, d_out, st));
+    SR_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));
     SR_TRY(hipStreamSynchronize(st));
     return PHANT_OK;
 }
 
-int32_t hash_var(hipStream_t st, const uint8_t* blob, const uint64_t* off, uint32_t n,
+int32_t hash_var(Workspaces& ws, hipStream_t st, const uint8_t* blob, const uint64_t* off, uint32_t n,
                  std::vector<uint8_t>& out, std::string& err) {
     out.resize((size_t)n * 32);
     if (!n) return PHANT_OK;
@@ -66,14 +58,15 @@ int32_t hash_var(hipStream_t st, const uint8_t* blob, const uint64_t* off, uint3
         }
         rel[i] = off[i] - lo;
     }
-    DBuf d_in, d_off, d_out;
-    SR_TRY(d_in.alloc((size_t)len + 16));
-    SR_TRY(d_off.alloc(rel.size() * 8));
-    SR_TRY(d_out.alloc((size_t)n * 32));
-    if (len) SR_TRY(hipMemcpyAsync(d_in.p, blob + lo, (size_t)len, hipMemcpyHostToDevice, st));
-    SR_TRY(hipMemcpyAsync(d_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, st));
-    SR_TRY(launch_keccak256_var((const uint8_t*)d_in.p, (const uint64_t*)d_off.p, n, (uint8_t*)d_out.p, st));
-    SR_TRY(hipMemcpyAsync(out.data(), d_out.p, out.size(), hipMemcpyDeviceToHost, st));
+    SR_TRY(ws.io.reset(DevArena::round((size_t)len + 16) + DevArena::round(rel.size() * 8) +
+                       DevArena::round((size_t)n * 32) + 1024));
+    uint8_t* d_in = ws.io.take<uint8_t>((size_t)len + 16);
+    uint64_t* d_off = ws.io.take<uint64_t>(rel.size());
+    uint8_t* d_out = ws.io.take<uint8_t>((size_t)n * 32);
+    if (len) SR_TRY(hipMemcpyAsync(d_in, blob + lo, (size_t)len, hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, st));
+    SR_TRY(launch_keccak256_var(d_in, d_off, n, d_out, st));
+    SR_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));
     SR_TRY(hipStreamSynchronize(st));
     return PHANT_OK;
 }
@@ -105,11 +98,11 @@ size_t strip32(const uint8_t* v, const uint8_t** out) {
 
 }  // namespace
 
-int32_t state_root_host(hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
+int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
                         const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
                         const uint8_t* slot_keys, const uint8_t* slot_vals,
                         const uint32_t* slot_first, uint32_t n, uint8_t out[32], std::string& err) {
-    if (n == 0) return trie_root_host(st, nullptr, nullptr, nullptr, nullptr, 0, out, err);
+    if (n == 0) return trie_root_host(ws, st, nullptr, nullptr, nullptr, nullptr, 0, out, err);
     for (uint32_t a = 0; a < n; ++a)
         if (slot_first[a + 1] < slot_first[a]) {
             err = "slot_first not monotone";
@@ -128,7 +121,7 @@ int32_t state_root_host(hipStream_t st, const uint8_t* addrs, const uint64_t* no
     const uint32_t m = (uint32_t)live.size();
     std::vector<uint8_t> live_keys((size_t)m * 32), hk;
     for (uint32_t j = 0; j < m; ++j) std::memcpy(&live_keys[(size_t)j * 32], slot_keys + 32ull * live[j], 32);
-    int32_t rc = hash_fixed(st, live_keys.data(), 32, m, hk, err);
+    int32_t rc = hash_fixed(ws, st, live_keys.data(), 32, m, hk, err);
     if (rc) return rc;
     std::vector<uint32_t> perm(m);
     std::iota(perm.begin(), perm.end(), 0u);
@@ -150,15 +143,15 @@ int32_t state_root_host(hipStream_t st, const uint8_t* addrs, const uint64_t* no
         svoff[j + 1] = svals.size();
     }
     std::vector<uint8_t> sroots((size_t)n * 32);
-    rc = trie_forest_host(st, skeys.data(), skoff.data(), svals.data(), svoff.data(), m, acc_first.data(), n,
+    rc = trie_forest_host(ws, st, skeys.data(), skoff.data(), svals.data(), svoff.data(), m, acc_first.data(), n,
                           sroots.data(), err);
     if (rc) return rc;
 
     // ---- accounts ----
     std::vector<uint8_t> ha, hc;
-    rc = hash_fixed(st, addrs, 20, n, ha, err);
+    rc = hash_fixed(ws, st, addrs, 20, n, ha, err);
     if (rc) return rc;
-    rc = hash_var(st, code, code_off, n, hc, err);
+    rc = hash_var(ws, st, code, code_off, n, hc, err);
     if (rc) return rc;
     std::vector<uint32_t> ord(n);
     std::iota(ord.begin(), ord.end(), 0u);
@@ -195,7 +188,7 @@ int32_t state_root_host(hipStream_t st, const uint8_t* addrs, const uint64_t* no
         akoff[i + 1] = 32 * (i + 1);
         avoff[i + 1] = avals.size();
     }
-    return trie_root_host(st, akeys.data(), akoff.data(), avals.data(), avoff.data(), n, out, err);
+    return trie_root_host(ws, st, akeys.data(), akoff.data(), avals.data(), avoff.data(), n, out, err);
 }
 
 }  // namespace phant

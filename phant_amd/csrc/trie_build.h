@@ -5,17 +5,19 @@
 
 #include <string>
 
+#include "arena.h"
+
 namespace phant {
 
 // mptize (src/mpt/mpt.zig:38-45) over host buffers: H2D, build + hash on the
 // GPU, root back.  Returns PHANT_OK / PHANT_E_*; err gets a message.
-int32_t trie_root_host(hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
+int32_t trie_root_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
                        const uint8_t* vals, const uint64_t* val_off, uint32_t n, uint8_t out[32],
                        std::string& err);
 
 // A forest of independent tries in one pass: trie t owns keys
 // [seg_first[t], seg_first[t+1]); roots_out = n_tries x 32 bytes.
-int32_t trie_forest_host(hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
+int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
                          const uint8_t* vals, const uint64_t* val_off, uint32_t n,
                          const uint32_t* seg_first, uint32_t n_tries, uint8_t* roots_out,
                          std::string& err);
@@ -23,11 +25,11 @@ int32_t trie_forest_host(hipStream_t st, const uint8_t* keys, const uint32_t* ke
 // calculateMPTRoot (src/blockchain/blockchain.zig:209-235) when !be32,
 // ExecutionPayload.toBlock keys (src/engine_api/execution_payload.zig:127-139)
 // when be32.
-int32_t index_root_host(hipStream_t st, const uint8_t* items, const uint64_t* item_off, uint32_t n,
+int32_t index_root_host(Workspaces& ws, hipStream_t st, const uint8_t* items, const uint64_t* item_off, uint32_t n,
                         bool be32, uint8_t out[32], std::string& err);
 
 // secure-trie state root over AccountState fields (src/state/types.zig:13-20)
-int32_t state_root_host(hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
+int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
                         const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
                         const uint8_t* slot_keys, const uint8_t* slot_vals,
                         const uint32_t* slot_first, uint32_t n, uint8_t out[32], std::string& err);

@@ -448,18 +448,6 @@ __global__ void __launch_bounds__(256) fill_empty_roots_kernel(uint8_t* roots, u
 }
 
 // ---- host driver ----
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <class T>
-    T* as() const {
-        return reinterpret_cast<T*>(p);
-    }
-};
-
 #define TB_TRY(call)                                    \
     do {                                                \
         hipError_t e_ = (call);                         \
@@ -474,7 +462,7 @@ inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
 }  // namespace
 
 // Device-side forest build; all pointers device memory, except roots_host.
-static int32_t forest_device(hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off,
+static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off,
                              const uint8_t* d_vals, const uint64_t* d_val_off, uint32_t n,
                              uint64_t total_key_bytes, uint64_t total_val_bytes,
                              const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_roots,
@@ -495,37 +483,28 @@ static int32_t forest_device(hipStream_t st, const uint8_t* d_keys, const uint32
     uint32_t M = 1;
     while (M < n + 1) M <<= 1;
     t.M = M;
-    DevBuf b_flag, b_lcp, b_tree, b_dense, b_l, b_pd, b_parent, b_vk, b_lp, b_ps, b_cnt, b_order, b_dc, b_db,
-        b_cursor;
-    TB_TRY(b_flag.alloc((size_t)n + 1));
-    TB_TRY(b_lcp.alloc(((size_t)n + 1) * 4));
-    TB_TRY(b_tree.alloc((size_t)2 * M * 4));
-    TB_TRY(b_dense.alloc(((size_t)n + 1) * 4));
-    TB_TRY(b_l.alloc(((size_t)n + 1) * 4));
-    TB_TRY(b_pd.alloc(((size_t)n + 1) * 4));
-    TB_TRY(b_parent.alloc(((size_t)n + 1) * 4));
-    TB_TRY(b_vk.alloc(((size_t)n + 1) * 4));
-    TB_TRY(b_lp.alloc((size_t)n * 4));
-    TB_TRY(b_ps.alloc((size_t)n * 4));
-    TB_TRY(b_cnt.alloc((8 + MAX_DEPTH_BINS) * 4));
-    TB_TRY(b_order.alloc((size_t)n * 4));
-    TB_TRY(b_dc.alloc(MAX_DEPTH_BINS * 4));
-    TB_TRY(b_db.alloc(MAX_DEPTH_BINS * 4));
-    TB_TRY(b_cursor.alloc(8));
-    t.first_flag = b_flag.as<uint8_t>();
-    t.lcp = b_lcp.as<int32_t>();
-    t.tree = b_tree.as<int32_t>();
-    t.dense = b_dense.as<uint32_t>();
-    t.nd_l = b_l.as<uint32_t>();
-    t.nd_pd = b_pd.as<int32_t>();
-    t.nd_parent = b_parent.as<uint32_t>();
-    t.value_key = b_vk.as<uint32_t>();
-    t.leaf_parent = b_lp.as<uint32_t>();
-    t.leaf_ps = b_ps.as<uint32_t>();
-    t.counters = b_cnt.as<uint32_t>();
-    t.order = b_order.as<uint32_t>();
-    t.depth_cursor = b_dc.as<uint32_t>();
-    t.cursor = b_cursor.as<unsigned long long>();
+    {
+        const size_t n1 = (size_t)n + 1;
+        const size_t total = DevArena::round(n1) + DevArena::round(n1 * 4) * 6 + DevArena::round((size_t)2 * M * 4) +
+                             DevArena::round((size_t)n * 4) * 3 + DevArena::round((8 + MAX_DEPTH_BINS) * 4) +
+                             DevArena::round(MAX_DEPTH_BINS * 4) * 2 + 256 + 4096;
+        TB_TRY(ws.t1.reset(total));
+        t.first_flag = ws.t1.take<uint8_t>(n1);
+        t.lcp = ws.t1.take<int32_t>(n1);
+        t.tree = ws.t1.take<int32_t>((size_t)2 * M);
+        t.dense = ws.t1.take<uint32_t>(n1);
+        t.nd_l = ws.t1.take<uint32_t>(n1);
+        t.nd_pd = ws.t1.take<int32_t>(n1);
+        t.nd_parent = ws.t1.take<uint32_t>(n1);
+        t.value_key = ws.t1.take<uint32_t>(n1);
+        t.leaf_parent = ws.t1.take<uint32_t>(n);
+        t.leaf_ps = ws.t1.take<uint32_t>(n);
+        t.order = ws.t1.take<uint32_t>(n);
+        t.counters = ws.t1.take<uint32_t>(8 + MAX_DEPTH_BINS);
+        t.depth_cursor = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
+        t.cursor = ws.t1.take<unsigned long long>(1);
+    }
+    uint32_t* d_depth_begin = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
 
     TB_TRY(hipMemsetAsync(t.first_flag, 0, (size_t)n + 1, st));
     TB_TRY(hipMemsetAsync(t.counters, 0, (8 + MAX_DEPTH_BINS) * 4, st));
@@ -556,24 +535,22 @@ static int32_t forest_device(hipStream_t st, const uint8_t* d_keys, const uint32
         depth_begin[d] = acc;
         acc += cnt[8 + d];
     }
-    TB_TRY(hipMemcpyAsync(b_db.p, depth_begin.data(), MAX_DEPTH_BINS * 4, hipMemcpyHostToDevice, st));
+    TB_TRY(hipMemcpyAsync(d_depth_begin, depth_begin.data(), MAX_DEPTH_BINS * 4, hipMemcpyHostToDevice, st));
 
-    DevBuf b_sb, b_sl, b_scratch;
-    TB_TRY(b_sb.alloc((size_t)n_rep * 16 * 32));
-    TB_TRY(b_sl.alloc((size_t)n_rep * 16));
     // leaves: list hdr (<=9) + HP (<= 3 + key bytes + 1) + value (<= 9 + len), 4-byte rounded;
     // branches: <= 3 + 16*33 + value; extensions <= 48 + key bytes / 2
     const uint64_t max_key = 255;
     const uint64_t cap = total_val_bytes + total_key_bytes + (uint64_t)n * 32 +
                          (uint64_t)n_rep * (3 + 16 * 33 + 16 + 48 + max_key / 2 + 16) + 4096;
-    TB_TRY(b_scratch.alloc(cap));
-    t.slot_bytes = b_sb.as<uint8_t>();
-    t.slot_len = b_sl.as<uint8_t>();
-    t.scratch = b_scratch.as<uint8_t>();
+    TB_TRY(ws.t2.reset(DevArena::round((size_t)n_rep * 16 * 32) + DevArena::round((size_t)n_rep * 16) +
+                       DevArena::round(cap) + 1024));
+    t.slot_bytes = ws.t2.take<uint8_t>((size_t)n_rep * 16 * 32);
+    t.slot_len = ws.t2.take<uint8_t>((size_t)n_rep * 16);
+    t.scratch = ws.t2.take<uint8_t>(cap);
     t.scratch_cap = cap;
     TB_TRY(hipMemsetAsync(t.slot_len, 0, (size_t)n_rep * 16, st));
 
-    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3(blocks(n)), dim3(256), 0, st, t, b_db.as<uint32_t>());
+    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3(blocks(n)), dim3(256), 0, st, t, d_depth_begin);
     hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t);
     for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
         const uint32_t c = cnt[8 + d];
@@ -591,7 +568,7 @@ static int32_t forest_device(hipStream_t st, const uint8_t* d_keys, const uint32
     return PHANT_OK;
 }
 
-int32_t trie_forest_host(hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
+int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
                          const uint8_t* vals, const uint64_t* val_off, uint32_t n,
                          const uint32_t* seg_first, uint32_t n_tries, uint8_t* roots_out,
                          std::string& err) {
@@ -617,43 +594,43 @@ int32_t trie_forest_host(hipStream_t st, const uint8_t* keys, const uint32_t* ke
         err = "seg_first must span [0, n]";
         return PHANT_E_INVALID_ARG;
     }
-    DevBuf d_keys, d_koff, d_vals, d_voff, d_seg, d_roots;
-    TB_TRY(d_keys.alloc(kb + 16));
-    TB_TRY(d_koff.alloc(((size_t)n + 1) * 4));
-    TB_TRY(d_vals.alloc(vb + 16));
-    TB_TRY(d_voff.alloc(((size_t)n + 1) * 8));
-    TB_TRY(d_seg.alloc(((size_t)n_tries + 1) * 4));
-    TB_TRY(d_roots.alloc((size_t)n_tries * 32));
+    TB_TRY(ws.io.reset(DevArena::round(kb + 16) + DevArena::round(((size_t)n + 1) * 4) + DevArena::round(vb + 16) +
+                       DevArena::round(((size_t)n + 1) * 8) + DevArena::round(((size_t)n_tries + 1) * 4) +
+                       DevArena::round((size_t)n_tries * 32) + 1024));
+    uint8_t* d_keys = ws.io.take<uint8_t>(kb + 16);
+    uint32_t* d_koff = ws.io.take<uint32_t>((size_t)n + 1);
+    uint8_t* d_vals = ws.io.take<uint8_t>(vb + 16);
+    uint64_t* d_voff = ws.io.take<uint64_t>((size_t)n + 1);
+    uint32_t* d_seg = ws.io.take<uint32_t>((size_t)n_tries + 1);
+    uint8_t* d_roots = ws.io.take<uint8_t>((size_t)n_tries * 32);
     std::vector<uint32_t> ko((size_t)n + 1, 0);
     std::vector<uint64_t> vo((size_t)n + 1, 0);
     for (uint32_t i = 0; i <= n && n; ++i) {
         ko[i] = key_off[i] - key_off[0];
         vo[i] = val_off[i] - val_off[0];
     }
-    if (kb) TB_TRY(hipMemcpyAsync(d_keys.p, keys + key_off[0], kb, hipMemcpyHostToDevice, st));
-    if (vb) TB_TRY(hipMemcpyAsync(d_vals.p, vals + val_off[0], vb, hipMemcpyHostToDevice, st));
-    TB_TRY(hipMemcpyAsync(d_koff.p, ko.data(), ko.size() * 4, hipMemcpyHostToDevice, st));
-    TB_TRY(hipMemcpyAsync(d_voff.p, vo.data(), vo.size() * 8, hipMemcpyHostToDevice, st));
-    TB_TRY(hipMemcpyAsync(d_seg.p, seg_first, ((size_t)n_tries + 1) * 4, hipMemcpyHostToDevice, st));
-    int32_t rc = forest_device(st, d_keys.as<uint8_t>(), d_koff.as<uint32_t>(), d_vals.as<uint8_t>(),
-                               d_voff.as<uint64_t>(), n, kb, vb, d_seg.as<uint32_t>(), n_tries,
-                               d_roots.as<uint8_t>(), err);
+    if (kb) TB_TRY(hipMemcpyAsync(d_keys, keys + key_off[0], kb, hipMemcpyHostToDevice, st));
+    if (vb) TB_TRY(hipMemcpyAsync(d_vals, vals + val_off[0], vb, hipMemcpyHostToDevice, st));
+    TB_TRY(hipMemcpyAsync(d_koff, ko.data(), ko.size() * 4, hipMemcpyHostToDevice, st));
+    TB_TRY(hipMemcpyAsync(d_voff, vo.data(), vo.size() * 8, hipMemcpyHostToDevice, st));
+    TB_TRY(hipMemcpyAsync(d_seg, seg_first, ((size_t)n_tries + 1) * 4, hipMemcpyHostToDevice, st));
+    int32_t rc = forest_device(ws, st, d_keys, d_koff, d_vals, d_voff, n, kb, vb, d_seg, n_tries, d_roots, err);
     if (rc) {
         (void)hipStreamSynchronize(st);
         return rc;
     }
-    TB_TRY(hipMemcpyAsync(roots_out, d_roots.p, (size_t)n_tries * 32, hipMemcpyDeviceToHost, st));
+    TB_TRY(hipMemcpyAsync(roots_out, d_roots, (size_t)n_tries * 32, hipMemcpyDeviceToHost, st));
     TB_TRY(hipStreamSynchronize(st));
     return PHANT_OK;
 }
 
-int32_t trie_root_host(hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
+int32_t trie_root_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
                        const uint8_t* vals, const uint64_t* val_off, uint32_t n, uint8_t out[32],
                        std::string& err) {
     const uint32_t seg[2] = {0, n};
     const uint32_t zero32[1] = {0};
     const uint64_t zero64[1] = {0};
-    return trie_forest_host(st, keys, n ? key_off : zero32, vals, n ? val_off : zero64, n, seg, 1, out, err);
+    return trie_forest_host(ws, st, keys, n ? key_off : zero32, vals, n ? val_off : zero64, n, seg, 1, out, err);
 }
 
 // rlp.serialize(usize, i) as used at blockchain.zig:226-229
@@ -677,7 +654,7 @@ static size_t rlp_index_key(uint64_t v, uint8_t* out) {
     return 1 + n;
 }
 
-int32_t index_root_host(hipStream_t st, const uint8_t* items, const uint64_t* item_off, uint32_t n,
+int32_t index_root_host(Workspaces& ws, hipStream_t st, const uint8_t* items, const uint64_t* item_off, uint32_t n,
                         bool be32, uint8_t out[32], std::string& err) {
     std::vector<uint8_t> keys;
     std::vector<uint32_t> key_off((size_t)n + 1, 0);
@@ -692,7 +669,7 @@ int32_t index_root_host(hipStream_t st, const uint8_t* items, const uint64_t* it
             key_off[i + 1] = 32 * (i + 1);
         }
         for (uint32_t i = 0; i <= n && n; ++i) val_off[i] = item_off[i] - item_off[0];
-        return trie_root_host(st, keys.data(), key_off.data(), n ? items + item_off[0] : nullptr,
+        return trie_root_host(ws, st, keys.data(), key_off.data(), n ? items + item_off[0] : nullptr,
                               val_off.data(), n, out, err);
     }
     // blockchain.zig:213-232: items 1..0x7f, then item 0 (key 0x80), then 0x80.. --
@@ -724,7 +701,7 @@ int32_t index_root_host(hipStream_t st, const uint8_t* items, const uint64_t* it
         push(i, kb, kl);
         ++i;
     }
-    return trie_root_host(st, keys.data(), key_off.data(), vals.data(), val_off.data(), n, out, err);
+    return trie_root_host(ws, st, keys.data(), key_off.data(), vals.data(), val_off.data(), n, out, err);
 }
 
 }  // namespace phant

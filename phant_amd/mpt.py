@@ -183,7 +183,7 @@ def verify_batch_dev(b: ProofBatch, status: torch.Tensor | None = None, value_of
     ctx.check(ctx._lib.phant_mpt_verify_batch_dev(
         ctx.handle, b.roots.data_ptr(), b.n_roots, None if b.root_idx is None else b.root_idx.data_ptr(),
         b.keys.data_ptr(), b.key_len, b.nodes.data_ptr(), b.nodes.numel(), b.node_off.data_ptr(),
-        b.proof_first_node.data_ptr(), n, status.data_ptr(),
+        b.node_off.numel() - 1, b.proof_first_node.data_ptr(), n, status.data_ptr(),
         None if value_off is None else value_off.data_ptr(), None if value_len is None else value_len.data_ptr()))
     return status
 

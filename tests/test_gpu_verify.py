@@ -10,10 +10,28 @@ from tests.witness_util import random_kv, pack_proofs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def M():
+class _Mode:
+    """phant_amd.mpt with every verify call bound to one ctx (flat pipeline or fused kernel)."""
+
+    def __init__(self, mod, ctx):
+        self._mod, self._ctx = mod, ctx
+
+    def __getattr__(self, name):
+        return getattr(self._mod, name)
+
+    def verify_batch(self, *a, **k):
+        return self._mod.verify_batch(*a, ctx=self._ctx, **k)
+
+    def verify_batch_dev(self, *a, **k):
+        return self._mod.verify_batch_dev(*a, ctx=self._ctx, **k)
+
+
+@pytest.fixture(scope="module", params=["flat", "fused"])
+def M(request):
     import phant_amd
-    return phant_amd.mpt
+    ctx = phant_amd.Context(verify_fused=(request.param == "fused"))
+    yield _Mode(phant_amd.mpt, ctx)
+    ctx.close()
 
 
 def _both(M, oracle, roots, root_idx, keys, key_len, proofs):
