@@ -1,0 +1,135 @@
+"""Multi-rank path on CPU: world_size 2 over gloo.
+
+The product's sharding + verdict reduction (phant_amd/shard.py) with the ORACLE
+plugged in as the per-rank verifier (tests may do that; the product default is
+the GPU C-ABI).  Checks that the partition is a disjoint cover, that every
+rank's sub-witness verifies to the statuses the unsharded batch gets, and that
+the all-reduced per-root failure count equals the single-process count.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _two_root_witness(oracle, seed=5, n_a=120, n_b=60):
+    """Proofs against two roots (inclusion, exclusion, and a few damaged), as a HostBatch."""
+    from phant_amd.shard import HostBatch
+    from tests.witness_util import random_kv, pack_proofs
+
+    rng = np.random.default_rng(seed)
+    proofs, keys, ridx, roots = [], [], [], []
+    for r, n in enumerate((n_a, n_b)):
+        ks, vs = random_kv(rng, n, 32, 1, 70)
+        t = oracle.Trie(ks, vs)
+        roots.append(t.root())
+        for k in ks:
+            proofs.append(t.prove(k))
+            keys.append(k)
+            ridx.append(r)
+        for _ in range(n // 4):  # exclusion proofs
+            k = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+            if k in ks:
+                continue
+            proofs.append(t.prove(k))
+            keys.append(k)
+            ridx.append(r)
+    # damage every 9th proof: flip one bit of its last node
+    for i in range(0, len(proofs), 9):
+        nd = bytearray(proofs[i][-1])
+        nd[len(nd) // 2] ^= 0x10
+        proofs[i] = proofs[i][:-1] + [bytes(nd)]
+    nodes, node_off, pfn = pack_proofs(proofs)
+    return HostBatch(roots=np.frombuffer(b"".join(roots), np.uint8).reshape(-1, 32).copy(),
+                     root_idx=np.asarray(ridx, np.uint32), keys=np.frombuffer(b"".join(keys), np.uint8)
+                     .reshape(-1, 32).copy(), nodes=nodes, node_off=node_off, proof_first_node=pfn)
+
+
+def _oracle_verify(oracle):
+    def f(b):
+        st, _, _ = oracle.mpt_verify_batch(b.roots, b.root_idx, b.keys, 32, b.nodes, b.node_off, b.proof_first_node)
+        return st
+    return f
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from phant_amd import shard
+
+    O.build()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = _two_root_witness(O)
+        mine, status, fc = shard.verify_sharded(b, rank, world, verify=_oracle_verify(O))
+        q.put((rank, mine.tolist(), status.tolist(), fc.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partition_is_a_disjoint_cover(oracle):
+    from phant_amd import shard
+
+    b = _two_root_witness(oracle)
+    for world in (1, 2, 4, 8):
+        parts = shard.partition(b, world)
+        allidx = np.concatenate(parts)
+        assert sorted(allidx.tolist()) == list(range(b.n))
+        for r, p in enumerate(parts):
+            assert ((b.keys[p, 0] >> 4) % world == r).all()
+
+
+def test_take_proofs_roundtrip(oracle):
+    from phant_amd import shard
+
+    b = _two_root_witness(oracle)
+    full = _oracle_verify(oracle)(b)
+    idx = np.arange(b.n)[::-3]  # reversed, strided: order must be honoured
+    sub = shard.take_proofs(b, idx)
+    assert sub.n == len(idx) and int(sub.node_off[-1]) == sub.nodes.size
+    assert np.array_equal(_oracle_verify(oracle)(sub), full[idx])
+    empty = shard.take_proofs(b, np.zeros(0, np.int64))
+    assert empty.n == 0 and empty.nodes.size == 0
+
+
+def test_world2_gloo_matches_single_process(oracle):
+    import torch.multiprocessing as mp
+
+    from phant_amd import shard
+
+    b = _two_root_witness(oracle)
+    full = _oracle_verify(oracle)(b)
+    want_fc = shard.fail_counts(full, b.root_idx, b.n_roots)
+    assert want_fc.sum() > 0 and (full == oracle.PROOF_ABSENT).any() and (full == oracle.PROOF_PRESENT).any()
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seen = np.full(b.n, 255, np.uint8)
+    for rank, mine, status, fc in got:
+        assert fc == want_fc.tolist(), (rank, fc, want_fc)   # same global verdict on every rank
+        seen[np.asarray(mine, np.int64)] = np.asarray(status, np.uint8)
+    assert np.array_equal(seen, full)                         # disjoint cover, identical statuses
