@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
-    ap.add_argument("--verify-mode", default="flat", choices=["flat", "fused"],
-                    help="flat = node-parallel pipeline (default); fused = one lane per proof (A/B)")
+    ap.add_argument("--verify-mode", default="flat", choices=["flat", "nodedup", "fused"],
+                    help="flat = node-parallel pipeline with in-batch node dedup (default); nodedup = same pipeline "
+                         "hashing every shipped node (A/B); fused = one lane per proof (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -126,7 +127,8 @@ def main():
     from phant_amd.crypto import hasher as H
 
     # bound to torch's current stream on this device
-    ctx = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"))
+    ctx = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"),
+                            verify_nodedup=(args.verify_mode == "nodedup"))
 
     if args.workload == "config3":
         w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
@@ -191,7 +193,8 @@ def main():
             dist.all_reduce(exp_fail)
         assert int(fails.item()) == int(exp_fail.item()), (int(fails.item()), int(exp_fail.item()))
 
-    # dominant kernel alone, HIP events on the launch stream (phant_timing)
+    # device time of one launch of the path (all kernels of the verify pipeline / the sponge kernel),
+    # HIP events on the launch stream (phant_timing)
     ctx.timing(True)
     kms = []
     for _ in range(max(5, min(args.steps, 50))):
@@ -200,6 +203,13 @@ def main():
     ctx.timing(False)
     k_avg_ms = sum(kms) / len(kms)
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+    extra = {}
+    if args.workload == "config3" and args.verify_mode != "fused":
+        hashed = ctx.verify_stats()
+        shipped = int(b.node_off.numel() - 1)
+        extra = {"nodes_shipped": shipped, "nodes_hashed": int(sum(hashed)),
+                 "keccak_f_run": int(sum((c + 1) * h for c, h in enumerate(hashed))),
+                 "keccak_f_if_every_node_hashed": int(w.perms_per_proof * n_units)}
 
     value = n_units * world * args.steps / elapsed
     line = {
@@ -211,8 +221,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
-                                "hash_nodes_kernel" if args.verify_mode == "flat" else "mpt_verify_fused_kernel"),
-                     "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                                "mpt_verify_fused_kernel" if args.verify_mode == "fused" else
+                                "verify pipeline = plan_kernel + dedup_kernel + hash_list_kernel + "
+                                "walk_proofs_kernel + mpt_verify_fixup_kernel (sum of the launch)"),
+                     "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.workload == "config3":

@@ -71,6 +71,8 @@ typedef struct phant_ctx phant_ctx;
 #define PHANT_CTX_OWN_STREAM 1u   /* flags: ignore `stream`, create a private non-blocking stream */
 #define PHANT_CTX_VERIFY_FUSED 2u /* flags: verify with the one-lane-per-proof kernel instead of the
                                      node-parallel pipeline (A/B and debugging) */
+#define PHANT_CTX_VERIFY_NODEDUP 4u /* flags: node-parallel pipeline, but hash every shipped node even
+                                       when the batch carries byte-identical copies (A/B) */
 
 typedef struct phant_opts {
     uint32_t struct_size; /* = sizeof(phant_opts) */
@@ -186,11 +188,15 @@ PHANT_API int32_t phant_state_root(phant_ctx *ctx, const uint8_t *addrs, const u
                                    uint32_t n, uint8_t out[32]);
 
 /* -------------------------------------------------------------- measurement
- * Duration of the DOMINANT kernel of the last *_dev call (the node-hashing
- * kernel for verify, the sponge kernel for keccak), measured with HIP events
- * recorded on the ctx stream around that launch (bench.py uses this for
- * `roofline.achieved`).  Enable with phant_timing(ctx, 1). */
+ * Device time of the last *_dev call -- every kernel it launched, first to
+ * last -- measured with HIP events recorded on the ctx stream around the
+ * launches (bench.py uses this for `roofline.achieved`).  Enable with
+ * phant_timing(ctx, 1). */
 PHANT_API int32_t phant_timing(phant_ctx *ctx, int32_t enable);
+/* After a node-parallel verify call on this ctx: hashed[c] = number of nodes
+ * of (c+1) rate blocks (c = 7: 8 or more) that were actually hashed, i.e.
+ * distinct nodes; synchronises the ctx stream.  All zero after a fused call. */
+PHANT_API int32_t phant_verify_stats(phant_ctx *ctx, uint32_t hashed[8]);
 PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
 
 #ifdef __cplusplus

@@ -59,6 +59,7 @@ SYMBOLS = {
     "phant_state_root": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "phant_timing": (_i32, [_vp, _i32]),
     "phant_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
+    "phant_verify_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 8)]),
 }
 
 

@@ -16,7 +16,8 @@ def _np_ptr(a: np.ndarray):
 class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
-    def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False):
+    def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
+                 verify_nodedup: bool = False):
         lib = L.lib()
         if not torch.cuda.is_available():
             raise L.PhantError(L.E_NO_DEVICE, "no GPU visible (phant_amd has no CPU fallback)")
@@ -29,6 +30,8 @@ class Context:
             stream, flags = torch.cuda.current_stream(self.device).cuda_stream or None, 0
         if verify_fused:
             flags |= 2  # PHANT_CTX_VERIFY_FUSED
+        if verify_nodedup:
+            flags |= 4  # PHANT_CTX_VERIFY_NODEDUP
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
         h = C.c_void_p()
         rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))
@@ -52,6 +55,12 @@ class Context:
         ms = C.c_float(0)
         self.check(self._lib.phant_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def verify_stats(self) -> list[int]:
+        """Nodes hashed by the last node-parallel verify call, per rate-block class."""
+        out = (C.c_uint32 * 8)()
+        self.check(self._lib.phant_verify_stats(self._h, C.byref(out)))
+        return list(out)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -72,9 +72,87 @@ PHANT_DEV void absorb_final_block(Sponge& s, const uint32_t* __restrict__ w, uin
     }
 }
 
+// ---- wide form: unaligned 16-byte loads straight from the message ----
+// gfx950 global loads take any byte address, so a lane can fetch its rate block as 8 x dwordx4 +
+// 1 x dwordx2 (9 vector-memory instructions instead of 35 dword loads + 34 v_alignbyte).  With one
+// node per lane every load touches 64 different cache lines, so the instruction count is what loads
+// the CU's address/L1 pipeline: 35 loads per block kept it ~65 % busy next to the VALU-bound
+// permutation, 9 do not.
+struct __attribute__((packed, aligned(1))) PackedU32x4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) PackedU32x2 { uint32_t x, y; };
+
+PHANT_DEV void load_block_wide(uint32_t (&d)[RATE_DWORDS], const uint8_t* __restrict__ p) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const PackedU32x4 v = *reinterpret_cast<const PackedU32x4*>(p + 16 * c);
+        d[4 * c] = v.x;
+        d[4 * c + 1] = v.y;
+        d[4 * c + 2] = v.z;
+        d[4 * c + 3] = v.w;
+    }
+    const PackedU32x2 t = *reinterpret_cast<const PackedU32x2*>(p + 128);
+    d[32] = t.x;
+    d[33] = t.y;
+}
+
+// One full 136-byte block at byte pointer p (any alignment).
+PHANT_DEV void absorb_full_block_wide(Sponge& s, const uint8_t* __restrict__ p) {
+    uint32_t d[RATE_DWORDS];
+    load_block_wide(d, p);
+    xor_block(s, d);
+}
+
+// Final block whose 136-byte window is already in d: keep the first r (< 136) bytes, add the pad
+// 0x01 .. 0x80 (src/crypto/hasher.zig -> Zig std Keccak256) and absorb.
+PHANT_DEV void absorb_loaded_final(Sponge& s, const uint32_t (&d)[RATE_DWORDS], uint32_t r) {
+#pragma unroll
+    for (int i = 0; i < (int)RATE_DWORDS; ++i) {
+        const int m = (int)r - 4 * i;  // message bytes inside this dword
+        const uint32_t t = 1u << ((m & 3) * 8);
+        const uint32_t keep = m >= 4 ? 0xffffffffu : (m <= 0 ? 0u : t - 1u);
+        const uint32_t pad = (m >= 0 && m < 4) ? t : 0u;
+        uint32_t v = (d[i] & keep) ^ pad;
+        if (i == (int)RATE_DWORDS - 1) v ^= 0x80000000u;
+        if (i & 1)
+            s.hi[i >> 1] ^= v;
+        else
+            s.lo[i >> 1] ^= v;
+    }
+}
+
+// Final block: r (< 136) message bytes at p, then the pad.  Reads the whole 136-byte window when it
+// lies inside the caller's buffer (p + 136 <= safe_end) and masks what is beyond r; otherwise (the
+// last few messages of a buffer) falls back to the aligned-dword form that never leaves the message.
+PHANT_DEV void absorb_final_block_wide(Sponge& s, const uint8_t* __restrict__ p, uint32_t r,
+                                       const uint8_t* __restrict__ safe_end) {
+    if (p + RATE <= safe_end) {
+        uint32_t d[RATE_DWORDS];
+        load_block_wide(d, p);
+        absorb_loaded_final(s, d, r);
+    } else {
+        const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+        absorb_final_block(s, reinterpret_cast<const uint32_t*>(p - sh), sh, r);
+    }
+}
+
 // Hash a whole message sitting in global memory.  Digest = s.lo[0..3], s.hi[0..3].
-PHANT_DEV void keccak256_global(Sponge& s, const uint8_t* __restrict__ p, uint64_t len) {
+// safe_end: one past the last byte of the buffer the message lives in (reads may run past the message
+// up to there), or nullptr to touch nothing but the aligned dwords that hold message bytes.
+PHANT_DEV void keccak256_global(Sponge& s, const uint8_t* __restrict__ p, uint64_t len,
+                                const uint8_t* __restrict__ safe_end = nullptr) {
     sponge_zero(s);
+    if (safe_end) {
+        uint64_t left = len;
+        while (left >= RATE) {
+            absorb_full_block_wide(s, p);
+            keccak_f1600(s);
+            p += RATE;
+            left -= RATE;
+        }
+        absorb_final_block_wide(s, p, (uint32_t)left, safe_end);
+        keccak_f1600(s);
+        return;
+    }
     const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
     const uint32_t* w = reinterpret_cast<const uint32_t*>(p - sh);
     uint64_t left = len;

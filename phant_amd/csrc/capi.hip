@@ -26,6 +26,7 @@ struct phant_ctx {
     phant::Workspaces ws;
     phant::DevArena dv;  // workspace of the device-form verify pipeline
     bool verify_fused = false;
+    bool verify_nodedup = false;
     // stream-side timing of the last device-form call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -130,6 +131,8 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     if (!c) return PHANT_E_OOM;
     c->device = dev;
     c->verify_fused = fused;
+    c->verify_nodedup = opts && (opts->flags & PHANT_CTX_VERIFY_NODEDUP);
+    if (const char* m = std::getenv("PHANT_VERIFY_MODE")) c->verify_nodedup = std::strcmp(m, "nodedup") == 0;
     DeviceGuard g(dev);
     if (!own) {
         c->stream = (hipStream_t)stream;  // nullptr = the default stream
@@ -185,6 +188,17 @@ int32_t phant_timing(phant_ctx* c, int32_t enable) {
     if (!c) return PHANT_E_INVALID_ARG;
     c->timing = enable != 0;
     c->ev_pending = false;
+    return PHANT_OK;
+}
+
+int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
+    if (!c || !hashed) return PHANT_E_INVALID_ARG;
+    for (int i = 0; i < 8; ++i) hashed[i] = 0;
+    if (c->verify_fused || !c->dv.base) return PHANT_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the class cursors are the first 8 words of the verify workspace (mpt_verify_flat.hip)
+    HIP_TRY(c, hipMemcpy(hashed, c->dv.base, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return PHANT_OK;
 }
 
@@ -284,9 +298,8 @@ static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_
         hipError_t e = c->dv.reset(need);
         if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(verify workspace)", e);
     }
-    HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, c->dv.base, c->stream, c->timing ? c->ev0 : nullptr,
-                                             c->timing ? c->ev1 : nullptr));
-    if (c->timing) c->ev_pending = true;
+    TimedRegion t(c);
+    HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, c->dv.base, !c->verify_nodedup, c->stream));
     return PHANT_OK;
 }
 

@@ -20,35 +20,33 @@ keccak256_var_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restric
     if (i >= n) return;
     const uint64_t b = off[i], e = off[i + 1];
     Sponge s;
-    keccak256_global(s, blob + b, e >= b ? e - b : 0);
+    keccak256_global(s, blob + b, e >= b ? e - b : 0, blob + off[n]);
     store_digest(s, out + 32ull * i);
 }
 
 // ---- fixed length: message i = blob[i*stride .. i*stride + msg_len) ----
-// msg_len is wave-uniform, so the block loop and the tail shape are scalar
-// control flow; only the byte shift (i*stride & 3) is per lane.
+// msg_len is wave-uniform, so the block loop and the tail shape are scalar control flow.
 __global__ void __launch_bounds__(256)
 keccak256_fixed_kernel(const uint8_t* __restrict__ blob, uint32_t msg_len, uint64_t stride,
                        uint32_t n, uint8_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint8_t* p = blob + stride * i;
+    const uint8_t* safe_end = blob + stride * (n - 1u) + msg_len;
     Sponge s;
     sponge_zero(s);
-    const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(p - sh);
     const uint32_t nfull = msg_len / RATE;
     for (uint32_t k = 0; k < nfull; ++k) {
-        absorb_full_block(s, w, sh);
+        absorb_full_block_wide(s, p);
         keccak_f1600(s);
-        w += RATE_DWORDS;
+        p += RATE;
     }
     const uint32_t r = msg_len - nfull * RATE;
     if (r == 0) {  // the whole last block is padding: 0x01 at byte 0, 0x80 at byte 135
         s.lo[0] ^= 0x00000001u;
         s.hi[16] ^= 0x80000000u;
     } else {
-        absorb_final_block(s, w, sh, r);
+        absorb_final_block_wide(s, p, r, safe_end);
     }
     keccak_f1600(s);
     store_digest(s, out + 32ull * i);

@@ -27,11 +27,13 @@ struct VerifyArgs {
     uint32_t* value_len;  // may be null
 };
 hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
-// flat pipeline (plan -> class-sorted node hashing -> walk); ws = verify_flat_workspace_bytes().
-// ev_hash0/1 (optional) bracket the dominant kernel, hash_nodes_kernel.
+// re-verifies, one lane per proof, the proofs whose status byte is 0xff (the flat pipeline's
+// "could not settle from the tables" marker)
+hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, hipStream_t st);
+// flat pipeline (plan -> dedup/compare -> class-sorted hashing of distinct nodes -> walk -> fixup);
+// ws = verify_flat_workspace_bytes().  dedup = false hashes every shipped node (A/B).
 size_t verify_flat_workspace_bytes(uint32_t total_nodes);
-hipError_t launch_mpt_verify_flat(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, hipStream_t st,
-                                  hipEvent_t ev_hash0, hipEvent_t ev_hash1);
+hipError_t launch_mpt_verify_flat(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, bool dedup, hipStream_t st);
 hipError_t launch_mpt_verdict(const uint8_t* d_status, const uint32_t* d_root_idx, uint32_t n,
                               uint32_t n_roots, uint32_t* d_fail_count, hipStream_t st);
 

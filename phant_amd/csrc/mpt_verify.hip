@@ -55,7 +55,7 @@ PHANT_DEV uint32_t verify_one(const VerifyArgs& a, uint32_t i, uint64_t& voff, u
             cur_len = (uint32_t)(e - b);
             ++used;
             Sponge s;
-            keccak256_global(s, cur, cur_len);
+            keccak256_global(s, cur, cur_len, a.nodes + a.nodes_len);
             uint32_t diff = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -98,6 +98,19 @@ __global__ void __launch_bounds__(256) mpt_verify_fused_kernel(const VerifyArgs 
     if (a.value_len) a.value_len[i] = vlen;
 }
 
+// Second opinion for the flat pipeline: proofs it marked 0xff ("a representative was not
+// self-represented", see mpt_verify_flat.hip) are verified from scratch by one lane each.
+__global__ void __launch_bounds__(256) mpt_verify_fixup_kernel(const VerifyArgs a) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n || a.status[i] != 0xffu) return;
+    uint64_t voff;
+    uint32_t vlen;
+    const uint32_t st = verify_one(a, i, voff, vlen);
+    a.status[i] = (uint8_t)st;
+    if (a.value_off) a.value_off[i] = voff;
+    if (a.value_len) a.value_len[i] = vlen;
+}
+
 // fail_count[r] += #proofs against root r that are not PRESENT/ABSENT.
 // Per-wave ballot first, then one atomic per (wave, root) -- with a single
 // root that is one atomic per wave.
@@ -121,6 +134,13 @@ hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st) {
     if (a.n == 0) return hipSuccess;
     const uint32_t grid = (a.n + 255u) / 256u;
     hipLaunchKernelGGL(mpt_verify_fused_kernel, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, hipStream_t st) {
+    if (a.n == 0) return hipSuccess;
+    const uint32_t grid = (a.n + 255u) / 256u;
+    hipLaunchKernelGGL(mpt_verify_fixup_kernel, dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -1,25 +1,40 @@
-// mpt_verify_flat.hip -- batched proof verification, "flat" pipeline.
+// mpt_verify_flat.hip -- batched proof verification, node-parallel pipeline with
+// in-batch node deduplication.
 //
-// The fused kernel (mpt_verify.hip) gives one lane a whole proof: at
-// BASELINE's 100 k proofs that is only 1.5 waves per SIMD and every lane drags
-// a 1-block leaf behind seven 4-block branches.  Here the unit of hashing is
-// the NODE:
+// A witness ships every proof as its own node list, so the upper trie levels
+// arrive many times over (BASELINE config 3: 800 k shipped nodes, ~350 k
+// distinct).  Keccak-f is integer-VALU-bound on gfx950 (DESIGN.md section 9:
+// v_alignbit is half rate), while COMPARING two nodes is a pure HBM stream.  So
+// every shipped byte is still read exactly once, coalesced, but only the first
+// copy of a node is hashed:
 //
-//   plan_count / plan_scatter   one lane per proof walks its node offsets and
-//        files every node under its class = number of 136-byte rate blocks
-//        (wave ballot per class + one atomic per wave, so the variable-length
-//        nodes come out compacted into per-class lists);
-//   hash_nodes   one lane per node, workgroups cover ONE class each, so every
-//        wave runs the same number of Keccak-f permutations (no lane idles on a
-//        short leaf while its neighbours finish a 532-byte branch).  For the
-//        canonical full branch (532 B: f9 02 11, 16 x (a0 + 32 B), 80) the node
-//        bytes are validated and the child reference for the proof's key
-//        nibble is captured FROM THE REGISTERS the sponge absorbs -- nothing is
-//        read twice;
-//   walk_proofs  one lane per proof links digest -> expected reference ->
-//        next digest (DESIGN.md section 3 order of checks) and only re-opens
-//        node bytes for the nodes the fast path did not cover (leaves,
-//        extensions, sparse branches, anything malformed).
+//   plan_kernel     one lane per proof: stamps node -> proof, and for every
+//        multi-block node proposes itself as the representative of its
+//        (root, depth, key-prefix) group in a 2-choice table (plain 8-byte
+//        stores, last writer wins -- no atomics, correctness never depends on
+//        who wins).
+//   dedup_kernel    a wave reads one node at a time, 16 bytes per lane
+//        (coalesced): validates the canonical 532-byte full branch and captures
+//        the child reference for the proof's key nibble straight from the
+//        loaded bytes, then compares the node byte-for-byte with the group's
+//        representative.  Equal  => rep[j] = representative (no hashing);
+//        different / no representative => the node is hashed itself.  Nodes to
+//        hash are compacted per rate-block class with wave ballots + one
+//        block-level reservation per class (the variable-length nodes come out
+//        as dense per-class lists, so every hashing wave runs the same number
+//        of Keccak-f permutations).
+//   hash_list_kernel  one lane per listed node, sponge in registers.
+//   walk_proofs_kernel  one lane per proof links digest[rep[node]] -> expected
+//        reference -> next node (DESIGN.md section 3 order of checks); only
+//        nodes outside the full-branch fast path are re-opened and decoded.
+//   fixup_kernel    proofs the walk could not settle from the tables (never
+//        in practice: a representative that is not self-represented) go
+//        through the one-lane-per-proof verifier.
+//
+// Soundness: rep[j] = r only if bytes(j) == bytes(r) (so keccak(j) ==
+// digest[r]) and the walk only trusts digest[r] when rep[r] == r (r was
+// hashed); a captured reference is only used by a proof whose key nibble at
+// that depth equals the nibble it was captured for.
 //
 // What it computes: the verifier missing at
 // src/engine_api/execution_payload.zig:177-178, over the node encodings of
@@ -29,256 +44,438 @@
 
 namespace phant {
 
-constexpr uint32_t N_CLASS = 8;          // class c = (c+1) rate blocks; last class = 8 or more
-constexpr uint32_t META_FAST = 1u;       // full branch validated, ref captured for nibble index = meta >> 8
-constexpr uint32_t META_HASHED = 2u;     // digest valid
+constexpr uint32_t N_CLASS = 8;        // class c = (c+1) rate blocks; last class = 8 or more
+constexpr uint32_t CLASS_NONE = 0xffu;
+constexpr uint32_t META_FAST = 1u;     // canonical full branch; ref[] holds slot (meta>>4)&15, depth meta>>8
+constexpr uint32_t DEDUP_MAX_DEPTH = 16;  // key prefix of <= 16 nibbles fits the 64-bit group key
+constexpr uint32_t STATUS_NEEDS_SLOW = 0xffu;
+constexpr uint32_t BRANCH_LEN = 532u;  // f9 02 11 | 16 x (a0 + 32 bytes) | 80
 
-PHANT_DEV uint32_t node_class(uint64_t len) {
-    const uint64_t nb = len / RATE + 1;
-    return (uint32_t)(nb > N_CLASS ? N_CLASS : nb) - 1u;
+PHANT_DEV uint32_t node_class(uint32_t len) {
+    const uint32_t nb = len / RATE + 1u;
+    return (nb > N_CLASS ? N_CLASS : nb) - 1u;
 }
 
+struct __attribute__((packed, aligned(1))) U32x4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U32x1 { uint32_t x; };
+PHANT_DEV uint4 load16u(const uint8_t* p) {  // unaligned 16-byte global load
+    const U32x4 v = *reinterpret_cast<const U32x4*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+PHANT_DEV uint32_t load4u(const uint8_t* p) { return reinterpret_cast<const U32x1*>(p)->x; }
+
+// first 8 key bytes, big-endian (zero padded): the nibble prefix of depth d is its top 4d bits
+PHANT_DEV uint64_t key_prefix64(const uint8_t* __restrict__ key, uint32_t key_len) {
+    uint64_t kb = 0;
+    const uint32_t take = key_len < 8u ? key_len : 8u;
+    for (uint32_t t = 0; t < take; ++t) kb |= (uint64_t)key[t] << (56u - 8u * t);
+    return kb;
+}
+// 64-bit group key of (root, depth, first `d` key nibbles); murmur3 finaliser.
+PHANT_DEV uint64_t group_key(uint64_t kb, uint32_t root, uint32_t d) {
+    const uint64_t pre = d ? (kb >> (64u - 4u * d)) : 0ull;
+    uint64_t h = pre ^ ((uint64_t)(d + 1u) << 58) ^ ((uint64_t)root * 0x9E3779B97F4A7C15ull);
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    return h;
+}
+PHANT_DEV uint32_t gk_fp(uint64_t h) { return (uint32_t)(h >> 32) | 1u; }
+PHANT_DEV uint32_t gk_slot_a(uint64_t h, uint32_t mask) { return (uint32_t)h & mask; }
+PHANT_DEV uint32_t gk_slot_b(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 20) & mask; }
+
+struct FlatArgs {
+    VerifyArgs v;
+    uint32_t total_nodes;
+    uint32_t dedup;          // 0: hash every node (A/B)
+    uint64_t* table;         // tmask + 1 entries {fp:32 | node:32}, zeroed per call
+    uint32_t tmask;
+    uint32_t* rep;           // total_nodes
+    uint32_t* meta;          // total_nodes
+    uint32_t* ent;           // N_CLASS x total_nodes
+    uint32_t* cursors;       // N_CLASS class counts + [N_CLASS] = work-queue head of the hash kernel; zeroed per call
+    uint32_t* digest;        // total_nodes x 8
+    uint32_t* ref;           // total_nodes x 8
+};
+
 // ---------------------------------------------------------------- plan
-// counts[c] += nodes of class c.  One lane per proof, loop over its nodes;
-// per iteration one ballot per class present and one atomic per wave.
-template <bool SCATTER>
-__global__ void __launch_bounds__(256)
-plan_kernel(const uint64_t* __restrict__ node_off, const uint32_t* __restrict__ pfn, uint32_t n,
-            uint32_t total_nodes, uint64_t nodes_len, uint32_t* __restrict__ counts /*[N_CLASS]*/,
-            uint32_t* __restrict__ cursors /*[N_CLASS], SCATTER*/, uint32_t* __restrict__ ent_node,
-            uint32_t* __restrict__ ent_proof) {
-    __shared__ uint32_t s_count[N_CLASS];
-    __shared__ uint32_t s_base[N_CLASS];
+// One lane per proof: every multi-block node proposes itself as the representative of its
+// (root, depth, key prefix) group.  Plain stores: the last writer of a slot wins.
+__global__ void __launch_bounds__(256) plan_kernel(const FlatArgs a) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (threadIdx.x < N_CLASS) s_count[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t first = 0, last = 0;
-    if (p < n) {
-        first = pfn[p];
-        last = pfn[p + 1];
-        if (last < first || last > total_nodes) last = first;  // BAD_INPUT: walk reports it
-    }
-    uint32_t class_begin[N_CLASS];
-    if (SCATTER) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (uint32_t c = 0; c < N_CLASS; ++c) {
-            class_begin[c] = acc;
-            acc += counts[c];
+    if (p >= a.v.n) return;
+    const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
+    if (last < first || last > a.total_nodes) return;  // BAD_INPUT: the walk reports it
+    const uint32_t root = a.v.root_idx ? a.v.root_idx[p] : 0u;
+    const uint64_t kb = key_prefix64(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len);
+    uint32_t dmax = 2u * a.v.key_len;
+    dmax = dmax < DEDUP_MAX_DEPTH ? dmax : DEDUP_MAX_DEPTH;
+    uint32_t end = last - first;
+    end = end <= dmax ? end : dmax + 1u;
+    uint64_t b = end ? a.v.node_off[first] : 0ull;
+    for (uint32_t d = 0; d < end; ++d) {
+        const uint32_t j = first + d;
+        const uint64_t e = a.v.node_off[j + 1];
+        if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull && e - b >= RATE) {
+            const uint64_t h = group_key(kb, root, d);
+            const uint64_t entry = ((uint64_t)gk_fp(h) << 32) | j;
+            a.table[gk_slot_a(h, a.tmask)] = entry;
+            a.table[gk_slot_b(h, a.tmask)] = entry;
         }
+        b = e;
     }
-    // longest proof in the wave bounds the loop
-    uint32_t m = last - first;
-    uint32_t wave_max = m;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t other = __shfl_xor(wave_max, o, 64);
-        wave_max = other > wave_max ? other : wave_max;
+}
+
+// ---------------------------------------------------------------- dedup
+// all 64 lanes: are the `len` bytes at x and y equal?  16 bytes per lane per step.
+PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len, uint32_t lane) {
+    uint32_t diff = 0;
+    const uint32_t full = len & ~15u;
+    for (uint32_t o = 16u * lane; o < full; o += 1024u) {
+        const uint4 p = load16u(x + o), q = load16u(y + o);
+        diff |= (p.x ^ q.x) | (p.y ^ q.y) | (p.z ^ q.z) | (p.w ^ q.w);
     }
-    for (uint32_t k = 0; k < wave_max; ++k) {
-        uint32_t cls = 0xffffffffu;
-        const uint32_t j = first + k;
-        if (k < m) {
-            const uint64_t b = node_off[j], e = node_off[j + 1];
-            if (e >= b && e <= nodes_len && e - b <= 0x7fffffffull) cls = node_class(e - b);
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < N_CLASS; ++c) {
-            const unsigned long long mask = __ballot(cls == c);
-            if (mask == 0) continue;
-            const uint32_t cnt = (uint32_t)__popcll(mask);
-            if (!SCATTER) {
-                if (lane == 0) atomicAdd(&s_count[c], cnt);
-            } else {
-                uint32_t base = 0;
-                if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(&cursors[c], cnt);
-                base = __shfl(base, __builtin_ctzll(mask), 64);
-                if (cls == c) {
-                    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    const uint32_t at = class_begin[c] + base + rank;
-                    ent_node[at] = j;
-                    ent_proof[at] = p;
+    if (lane < (len & 15u)) diff |= (uint32_t)(x[full + lane] ^ y[full + lane]);
+    return __ballot(diff != 0) == 0ull;
+}
+
+// proof owning node j: pfn[p] <= j < pfn[p+1].  Equal-length proofs are hit by the first guess.
+PHANT_DEV uint32_t find_proof(const uint32_t* __restrict__ pfn, uint32_t n, uint32_t total_nodes, uint32_t j) {
+    uint32_t g = (uint32_t)(((uint64_t)j * n) / total_nodes);
+    g = g < n ? g : n - 1u;
+    if (pfn[g] <= j && j < pfn[g + 1]) return g;
+    uint32_t lo = 0, hi = n;  // invariant (for monotone pfn): pfn[lo] <= j < pfn[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (pfn[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte path
+
+__global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
+    __shared__ uint32_t s_cnt[4][N_CLASS];
+    __shared__ uint32_t s_base[N_CLASS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t j = blockIdx.x * 256u + tid;
+    const uint32_t N = a.total_nodes;
+
+    // ---- lane-per-node metadata (coalesced) ----
+    bool valid = false;
+    uint64_t b = 0, cb = 0;
+    uint32_t len = 0, cand = j, nib = 0xffu, dpos = 0xffffffffu;
+    if (j < N) {
+        const uint64_t e = a.v.node_off[j + 1];
+        b = a.v.node_off[j];
+        if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
+            valid = true;
+            len = (uint32_t)(e - b);
+            if (len >= RATE) {
+                const uint32_t p = find_proof(a.v.proof_first_node, a.v.n, N, j);
+                const uint32_t first = a.v.proof_first_node[p];
+                const uint32_t nn = 2u * a.v.key_len;
+                if (first <= j && j - first <= nn) {
+                    dpos = j - first;
+                    const uint8_t* key = a.v.keys + (uint64_t)a.v.key_len * p;
+                    if (dpos < nn) {
+                        const uint32_t kbyte = key[dpos >> 1];
+                        nib = (dpos & 1u) ? (kbyte & 0x0fu) : (kbyte >> 4);
+                    }
+                    if (a.dedup && dpos <= DEDUP_MAX_DEPTH) {
+                        const uint32_t root = a.v.root_idx ? a.v.root_idx[p] : 0u;
+                        const uint64_t h = group_key(key_prefix64(key, a.v.key_len), root, dpos);
+                        const uint32_t fp = gk_fp(h);
+                        uint64_t en = a.table[gk_slot_a(h, a.tmask)];
+                        if ((uint32_t)(en >> 32) != fp) en = a.table[gk_slot_b(h, a.tmask)];
+                        if ((uint32_t)(en >> 32) == fp && (uint32_t)en < N && (uint32_t)en != j) {
+                            // a representative is only usable if it is a well-formed node of the same length
+                            const uint32_t c = (uint32_t)en;
+                            const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
+                            if (c1 >= c0 && c1 <= a.v.nodes_len && c1 - c0 == len) {
+                                cand = c;
+                                cb = c0;
+                            }
+                        }
+                    }
                 }
             }
         }
     }
-    if (!SCATTER) {
-        __syncthreads();
-        if (threadIdx.x < N_CLASS && s_count[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_count[threadIdx.x]);
+
+    // ---- this lane's share of a 532-byte node: bytes [16 lane, 16 lane + 16) for lane < 33; the lanes
+    // above all take the last 16 bytes [516, 532) (redundant cover: no lane is ever masked off, so
+    // every load below is unconditional and the loads of several nodes overlap) ----
+    const uint32_t coff = lane < 33u ? 16u * lane : BRANCH_LEN - 16u;
+    // what those 16 bytes must look like in the canonical full branch f9 02 11 | 16 x (a0 + hash) | 80
+    uint32_t cm[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
+    for (uint32_t t = 0; t < 16u; ++t) {
+        const uint32_t q = coff + t;
+        uint32_t want = 0x100u;
+        if (q == 0) want = 0xf9u;
+        else if (q == 1) want = 0x02u;
+        else if (q == 2) want = 0x11u;
+        else if (q == 531u) want = 0x80u;
+        else if ((q - 3u) % 33u == 0u) want = 0xa0u;
+        if (want != 0x100u) {
+            cm[t >> 2] |= 0xffu << (8u * (t & 3u));
+            cv[t >> 2] |= want << (8u * (t & 3u));
+        }
     }
-    (void)s_base;
+
+    uint32_t my_rep = j, my_meta = 0;
+
+    // ---- 532-byte nodes: DEDUP_UNROLL nodes per trip, all their loads issued before any is used.
+    // A short last trip repeats its last node (idempotent) so that the body has no conditionals. ----
+    unsigned long long todo = __ballot(valid && len == BRANCH_LEN);
+    while (todo) {
+        uint32_t ii[DEDUP_UNROLL], nb[DEDUP_UNROLL], cj[DEDUP_UNROLL], rf[DEDUP_UNROLL];
+        uint4 x[DEDUP_UNROLL], y[DEDUP_UNROLL];
+        uint32_t i = 0;
+#pragma unroll
+        for (int u = 0; u < DEDUP_UNROLL; ++u) {
+            if (todo) {
+                i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+            }
+            ii[u] = i;
+            const uint8_t* own = a.v.nodes + (((uint64_t)__builtin_amdgcn_readlane((uint32_t)(b >> 32), i) << 32) |
+                                              __builtin_amdgcn_readlane((uint32_t)b, i));
+            nb[u] = __builtin_amdgcn_readlane(nib, i);
+            cj[u] = __builtin_amdgcn_readlane(cand, i);
+            // no representative: compare the node with itself (L1 hits) and ignore the outcome
+            const uint8_t* oth = own;
+            if (cj[u] != (j - lane) + i)
+                oth = a.v.nodes + (((uint64_t)__builtin_amdgcn_readlane((uint32_t)(cb >> 32), i) << 32) |
+                                   __builtin_amdgcn_readlane((uint32_t)cb, i));
+            x[u] = load16u(own + coff);
+            y[u] = load16u(oth + coff);
+            // slot nb's 32 hash bytes sit at [4 + 33 nb, 36 + 33 nb): lanes 0..7 fetch one dword each
+            rf[u] = load4u(own + 4u + 33u * (nb[u] & 15u) + 4u * (lane & 7u));
+        }
+#pragma unroll
+        for (int u = 0; u < DEDUP_UNROLL; ++u) {
+            const uint32_t jj = (j - lane) + ii[u];
+            uint32_t r_rep = jj, r_meta = 0;
+            const uint32_t bad = ((x[u].x ^ cv[0]) & cm[0]) | ((x[u].y ^ cv[1]) & cm[1]) |
+                                 ((x[u].z ^ cv[2]) & cm[2]) | ((x[u].w ^ cv[3]) & cm[3]);
+            if (__ballot(bad != 0) == 0ull && nb[u] < 16u) {
+                if (lane < 8u) a.ref[8ull * jj + lane] = rf[u];
+                r_meta = META_FAST | (nb[u] << 4) | (__builtin_amdgcn_readlane(dpos, ii[u]) << 8);
+            }
+            const uint32_t diff = (x[u].x ^ y[u].x) | (x[u].y ^ y[u].y) | (x[u].z ^ y[u].z) | (x[u].w ^ y[u].w);
+            if (__ballot(diff != 0) == 0ull) r_rep = cj[u];  // cj == jj when there is no representative
+            if (lane == ii[u]) {
+                my_rep = r_rep;
+                my_meta = r_meta;
+            }
+        }
+    }
+
+    // ---- other multi-block nodes (sparse branches >= 136 bytes): generic compare, one at a time ----
+    todo = __ballot(valid && len >= RATE && len != BRANCH_LEN && cand != j);
+    while (todo) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t ll = __builtin_amdgcn_readlane(len, i);
+        const uint8_t* o = a.v.nodes + (((uint64_t)__builtin_amdgcn_readlane((uint32_t)(b >> 32), i) << 32) |
+                                        __builtin_amdgcn_readlane((uint32_t)b, i));
+        const uint8_t* c = a.v.nodes + (((uint64_t)__builtin_amdgcn_readlane((uint32_t)(cb >> 32), i) << 32) |
+                                        __builtin_amdgcn_readlane((uint32_t)cb, i));
+        const bool eq = wave_bytes_equal(o, c, ll, lane);
+        if (lane == i && eq) my_rep = cand;
+    }
+
+    // ---- results + per-class compaction of the nodes that must be hashed ----
+    const bool need = valid && my_rep == j;
+    const uint32_t cls = valid ? node_class(len) : CLASS_NONE;
+    if (j < N) {
+        a.rep[j] = my_rep;
+        a.meta[j] = my_meta;
+    }
+    uint32_t my_rank = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < N_CLASS; ++c) {
+        const unsigned long long m = __ballot(need && cls == c);
+        if (lane == 0) s_cnt[wave][c] = (uint32_t)__popcll(m);
+        if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (tid < N_CLASS) {
+        const uint32_t tot = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
+        s_base[tid] = tot ? atomicAdd(&a.cursors[tid], tot) : 0u;
+    }
+    __syncthreads();
+    if (need) {
+        uint32_t at = s_base[cls] + my_rank;
+        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
+        a.ent[(uint64_t)cls * N + at] = j;
+    }
 }
 
 // ---------------------------------------------------------------- hash
-struct HashArgs {
-    const uint8_t* nodes;
-    const uint64_t* node_off;
-    const uint32_t* pfn;
-    const uint8_t* keys;
-    uint32_t key_len;
-    const uint32_t* counts;     // [N_CLASS]
-    const uint32_t* ent_node;
-    const uint32_t* ent_proof;
-    uint32_t* digest;           // total_nodes x 8
-    uint32_t* ref;              // total_nodes x 8
-    uint32_t* meta;             // total_nodes
-};
+// Persistent waves are dealt 64-node chunks round-robin, the classes with the most rate blocks first, so
+// that every SIMD stays busy until the short single-block nodes fill the tail (a static grid left
+// some CUs with 5 four-permutation workgroups and others with 4: +25 % on the makespan).
+//
+// One node per lane means every rate block comes from 64 scattered places; a wave that loads, waits,
+// then permutes spent 44 % of its time parked on s_waitcnt, and since the waves of a SIMD run the
+// same program in step, all of them at once.  So the loads run one block ahead of the permutation:
+// while Keccak-f chews block k the next block of the node (or block 0 of the NEXT chunk's node) is in
+// flight, and the chunk bookkeeping runs ahead of that -- node id two chunks ahead, node offsets one
+// ahead.
+// hipcc sinks a load next to its first use; left alone it turns "xor block k; load block k+1;
+// permute" back into "permute; load; wait; xor".  These empty asm statements are compiler-only
+// fences: the loads written before PIN_LOADS_BEFORE are issued before it (memory clobber), the
+// permutation consumes the state it redefines and so stays after it, and whatever follows PIN_AFTER
+// (the wait + xor of the prefetched block) stays behind the permutation.
+#define PIN_LOADS_BEFORE(s) asm volatile("" : "+v"((s).lo[0]), "+v"((s).hi[0]) : : "memory")
+#define PIN_AFTER(s) asm volatile("" : "+v"((s).lo[0]), "+v"((s).hi[0]) : : "memory")
 
-// The canonical full branch: f9 02 11 | 16 x (a0 + 32 bytes) | 80  = 532 bytes,
-// 4 rate blocks (3 full + 124 bytes).  `g` = node-relative dword index.
-// Slot k's prefix byte sits at byte 3 + 33k, its 32 hash bytes at [4 + 33k, 36 + 33k).
-struct BranchProbe {
-    uint32_t bad;      // accumulates (byte ^ expected) of every structural byte
-    uint32_t cap[9];   // the 9 aligned dwords covering the selected slot's hash
-};
-
-template <int BLOCK>
-PHANT_DEV void probe_block(BranchProbe& pr, const uint32_t (&d)[RATE_DWORDS], uint32_t nib) {
-    constexpr int G0 = BLOCK * (int)RATE_DWORDS;  // first node dword of this block
-    constexpr int NDW = BLOCK == 3 ? 31 : (int)RATE_DWORDS;  // 532 = 3*136 + 124 -> 31 dwords
-    if constexpr (BLOCK == 0) pr.bad |= d[0] ^ 0xa01102f9u;  // f9 02 11 a0
-#pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        const int byte_pos = 3 + 33 * k;
-        const int g = byte_pos >> 2, sh = (byte_pos & 3) * 8;
-        if (g >= G0 && g < G0 + NDW) pr.bad |= ((d[g - G0] >> sh) & 0xffu) ^ 0xa0u;
-    }
-    if constexpr (BLOCK == 3) pr.bad |= (d[132 - G0] >> 24) ^ 0x80u;  // byte 531: empty value slot
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int dk = (4 + 33 * k) >> 2;  // first aligned dword of slot k's hash
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int g = dk + t;
-            if (g >= G0 && g < G0 + NDW && g <= 132) pr.cap[t] = (nib == (uint32_t)k) ? d[g - G0] : pr.cap[t];
-        }
-    }
-}
-
-// Load block BLOCK (34 dwords, or the 31 + pad of the last one) of a 532-byte
-// node, absorb, probe.
-template <int BLOCK>
-PHANT_DEV void branch532_block(Sponge& s, BranchProbe& pr, const uint32_t* __restrict__ w, uint32_t sh,
-                               uint32_t nib) {
-    // keep this block's loads below the previous permutation: hipcc otherwise hoists all four
-    // blocks' loads to the top (214 VGPRs, 2 waves/SIMD)
-    asm volatile("" ::: "memory");
-    uint32_t d[RATE_DWORDS];
-    if constexpr (BLOCK < 3) {
-        uint32_t v[RATE_DWORDS + 1];
-#pragma unroll
-        for (int j = 0; j < (int)RATE_DWORDS; ++j) v[j] = w[BLOCK * RATE_DWORDS + j];
-        v[RATE_DWORDS] = sh ? w[BLOCK * RATE_DWORDS + RATE_DWORDS] : 0u;
-#pragma unroll
-        for (int i = 0; i < (int)RATE_DWORDS; ++i) d[i] = alignbyte(v[i + 1], v[i], sh);
-    } else {
-        // 124 message bytes = 31 dwords, then pad 0x01, zeros, 0x80 in byte 135
-        uint32_t v[32];
-#pragma unroll
-        for (int j = 0; j < 31; ++j) v[j] = w[3 * RATE_DWORDS + j];
-        v[31] = sh ? w[3 * RATE_DWORDS + 31] : 0u;
-#pragma unroll
-        for (int i = 0; i < 31; ++i) d[i] = alignbyte(v[i + 1], v[i], sh);
-        d[31] = 0x00000001u;
-        d[32] = 0u;
-        d[33] = 0x80000000u;
-    }
-    probe_block<BLOCK>(pr, d, nib);
-    // pin the probe results here: otherwise hipcc sinks the select chains to the end of the kernel
-    // and keeps all 144 candidate dwords alive across the permutations (214 VGPRs)
-    asm volatile("" : "+v"(pr.bad));
-#pragma unroll
-    for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(pr.cap[t]));
-    xor_block(s, d);
-    keccak_f1600(s);
-}
-
-__global__ void __launch_bounds__(256) hash_nodes_kernel(const HashArgs a) {
-    // which class does this workgroup serve?
-    uint32_t cnt[N_CLASS];
-#pragma unroll
-    for (uint32_t c = 0; c < N_CLASS; ++c) cnt[c] = a.counts[c];
-    uint32_t wg = blockIdx.x, cls = N_CLASS, begin = 0, acc = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < N_CLASS; ++c) {
-        const uint32_t wgs = (cnt[c] + 255u) / 256u;
-        if (cls == N_CLASS) {
-            if (wg < wgs) {
-                cls = c;
-                begin = acc;
-            } else {
-                wg -= wgs;
-            }
-        }
-        acc += cnt[c];
-    }
-    if (cls == N_CLASS) return;
-    const uint32_t idx = wg * 256u + threadIdx.x;
-    if (idx >= cnt[cls]) return;
-    const uint32_t j = a.ent_node[begin + idx];
-    const uint32_t p = a.ent_proof[begin + idx];
-    const uint64_t b = a.node_off[j];
-    const uint32_t len = (uint32_t)(a.node_off[j + 1] - b);
-    const uint8_t* ptr = a.nodes + b;
-    const uint32_t sh = (uint32_t)((uintptr_t)ptr & 3u);
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(ptr - sh);
+PHANT_DEV void hash_one_node(const FlatArgs& a, uint32_t j) {
+    const uint64_t b = a.v.node_off[j];
+    uint32_t left = (uint32_t)(a.v.node_off[j + 1] - b);
+    const uint8_t* ptr = a.v.nodes + b;
     Sponge s;
     sponge_zero(s);
-    uint32_t meta = META_HASHED;
-    if (cls == 3 && len == 532u) {
-        // speculative position: the d-th node of a proof follows key nibble d
-        // (true whenever every node above it is a plain branch)
-        const uint32_t dpos = j - a.pfn[p];
-        uint32_t nib = 0xffu;
-        if (dpos < 2u * a.key_len) {
-            const uint32_t kb = a.keys[(uint64_t)a.key_len * p + (dpos >> 1)];
-            nib = (dpos & 1u) ? (kb & 0x0fu) : (kb >> 4);
-        }
-        BranchProbe pr;
-        pr.bad = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) pr.cap[t] = 0;
-        branch532_block<0>(s, pr, w, sh, nib);
-        branch532_block<1>(s, pr, w, sh, nib);
-        branch532_block<2>(s, pr, w, sh, nib);
-        branch532_block<3>(s, pr, w, sh, nib);
-        if (pr.bad == 0 && nib < 16u) {
-            const uint32_t rs = (4u + 33u * nib) & 3u;
-            uint4* r = reinterpret_cast<uint4*>(a.ref + 8ull * j);
-            r[0] = make_uint4(alignbyte(pr.cap[1], pr.cap[0], rs), alignbyte(pr.cap[2], pr.cap[1], rs),
-                              alignbyte(pr.cap[3], pr.cap[2], rs), alignbyte(pr.cap[4], pr.cap[3], rs));
-            r[1] = make_uint4(alignbyte(pr.cap[5], pr.cap[4], rs), alignbyte(pr.cap[6], pr.cap[5], rs),
-                              alignbyte(pr.cap[7], pr.cap[6], rs), alignbyte(pr.cap[8], pr.cap[7], rs));
-            meta |= META_FAST | (dpos << 8);
-        }
-    } else {
-        uint32_t left = len;
-        while (left >= RATE) {
-            absorb_full_block(s, w, sh);
-            keccak_f1600(s);
-            w += RATE_DWORDS;
-            left -= RATE;
-        }
-        absorb_final_block(s, w, sh, left);
+    while (left >= RATE) {
+        absorb_full_block_wide(s, ptr);
         keccak_f1600(s);
+        ptr += RATE;
+        left -= RATE;
     }
+    absorb_final_block_wide(s, ptr, left, a.v.nodes + a.v.nodes_len);
+    keccak_f1600(s);
     uint4* o = reinterpret_cast<uint4*>(a.digest + 8ull * j);
     o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
     o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
-    a.meta[j] = meta;
+}
+
+__global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t N = a.total_nodes;
+    uint32_t cnt[N_CLASS];
+#pragma unroll
+    for (uint32_t c = 0; c < N_CLASS; ++c) cnt[c] = a.cursors[c];
+    const uint8_t* const nodes = a.v.nodes;
+    const uint8_t* const safe_end = nodes + a.v.nodes_len;
+    const bool tiny = a.v.nodes_len < RATE;  // no 136-byte window fits the blob: simple path only
+    const uint8_t* const last_window = tiny ? nodes : safe_end - RATE;
+
+    // queue position -> class (N_CLASS = past the end) and this lane's slot in ent[]; a short last
+    // chunk repeats its last node (same digest stored twice) so that no lane is ever idle-masked
+    auto locate = [&](uint32_t q, uint32_t& cls) -> uint64_t {
+        cls = N_CLASS;
+        uint32_t first = 0;
+#pragma unroll
+        for (int c = (int)N_CLASS - 1; c >= 0; --c) {
+            const uint32_t chunks = (cnt[c] + 63u) / 64u;
+            if (cls == N_CLASS) {
+                if (q < chunks) {
+                    cls = (uint32_t)c;
+                    first = q * 64u;
+                } else {
+                    q -= chunks;
+                }
+            }
+        }
+        if (cls == N_CLASS) return 0;
+        uint32_t idx = first + lane;
+        idx = idx < cnt[cls] ? idx : cnt[cls] - 1u;
+        return (uint64_t)cls * N + idx;
+    };
+    auto window = [&](const uint8_t* p) -> const uint8_t* { return p < last_window ? p : last_window; };
+
+    // ---- prologue: fill the pipeline ----
+    // chunk q belongs to wave (q mod W): a fixed round-robin deal.  (A shared queue balances no better
+    // here -- the long chunks come first and a wave rarely gets more than two of them -- and with a
+    // run-ahead of three chunks per wave it would hand ALL chunks to the first waves to arrive.)
+    const uint32_t W = gridDim.x * 4u;
+    uint32_t cls0, cls1, cls2, j0 = 0, j1 = 0, j2 = 0;
+    const uint32_t q0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t q1 = q0 + W;
+    uint32_t q2 = q1 + W;
+    {
+        const uint64_t e0 = locate(q0, cls0), e1 = locate(q1, cls1);
+        if (cls0 == N_CLASS) return;
+        j0 = a.ent[e0];
+        if (cls1 != N_CLASS) j1 = a.ent[e1];
+    }
+    const uint8_t* ptr0;
+    uint32_t len0;
+    uint32_t d[RATE_DWORDS];
+    {
+        const uint64_t b = a.v.node_off[j0];
+        len0 = (uint32_t)(a.v.node_off[j0 + 1] - b);
+        ptr0 = nodes + b;
+        if (!tiny) load_block_wide(d, window(ptr0));
+    }
+
+    for (;;) {
+        // ---- run ahead: node id of chunk +2, node offsets of chunk +1 ----
+        {
+            const uint64_t e2 = locate(q2, cls2);
+            if (cls2 != N_CLASS) j2 = a.ent[e2];
+        }
+        uint64_t b1 = 0, e1 = 0;
+        if (cls1 != N_CLASS) {
+            b1 = a.v.node_off[j1];
+            e1 = a.v.node_off[j1 + 1];
+        }
+        const uint8_t* ptr1 = nodes + b1;
+
+        // ---- chunk 0 ----
+        if (tiny || cls0 + 1u == N_CLASS) {
+            // 8 or more rate blocks (trip count differs per lane), or a blob smaller than one window
+            hash_one_node(a, j0);
+            if (!tiny && cls1 != N_CLASS) load_block_wide(d, window(ptr1));
+        } else {
+            Sponge s;
+            sponge_zero(s);
+            const uint8_t* p = ptr0;
+            uint32_t left = len0;
+            // every node of class c has exactly c full rate blocks: wave-uniform trip count
+            for (uint32_t k = 0; k < cls0; ++k) {
+                xor_block(s, d);
+                p += RATE;
+                left -= RATE;
+                load_block_wide(d, window(p));  // next block of this node, in flight during the permutation
+                PIN_LOADS_BEFORE(s);
+                keccak_f1600(s);
+                PIN_AFTER(s);
+            }
+            if (p <= last_window) {
+                absorb_loaded_final(s, d, left);
+            } else {  // the window was clamped (last node of the blob): re-read with the narrow loads
+                const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+                absorb_final_block(s, reinterpret_cast<const uint32_t*>(p - sh), sh, left);
+            }
+            if (cls1 != N_CLASS) load_block_wide(d, window(ptr1));  // block 0 of the next chunk's node
+            PIN_LOADS_BEFORE(s);
+            keccak_f1600(s);
+            PIN_AFTER(s);
+            uint4* o = reinterpret_cast<uint4*>(a.digest + 8ull * j0);
+            o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+            o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+        }
+
+        // ---- rotate ----
+        if (cls1 == N_CLASS) return;
+        cls0 = cls1;
+        j0 = j1;
+        ptr0 = ptr1;
+        len0 = (uint32_t)(e1 - b1);
+        cls1 = cls2;
+        j1 = j2;
+        q2 += W;
+    }
 }
 
 // ---------------------------------------------------------------- walk
-struct WalkArgs {
-    VerifyArgs v;
-    uint32_t total_nodes;
-    const uint32_t* digest;
-    const uint32_t* ref;
-    const uint32_t* meta;
-};
-
-__global__ void __launch_bounds__(256) walk_proofs_kernel(const WalkArgs a) {
+__global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= a.v.n) return;
     uint64_t voff = 0;
@@ -324,7 +521,14 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const WalkArgs a) {
                 cur = a.v.nodes + b;
                 cur_len = (uint32_t)(e - b);
                 ++used;
-                const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * j);
+                // digest of this node = digest of its representative (identical bytes), which must
+                // itself have been hashed
+                const uint32_t rj = a.rep[j];
+                if (rj != j && (rj >= a.total_nodes || a.rep[rj] != rj)) {
+                    status = STATUS_NEEDS_SLOW;
+                    break;
+                }
+                const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
                 const uint4 d0 = dg[0], d1 = dg[1];
                 const uint32_t diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
                                       (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
@@ -333,8 +537,9 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const WalkArgs a) {
                     break;
                 }
                 const uint32_t m = a.meta[j];
-                // the captured ref is for key nibble (m >> 8); usable iff that is where the walk stands
-                if ((m & META_FAST) && (m >> 8) == w.pos && w.pos < nn) {
+                // the captured ref is slot (m>>4)&15 of a validated full branch, captured at depth m>>8:
+                // usable iff the walk stands at that depth and the key's nibble there is that slot
+                if ((m & META_FAST) && (m >> 8) == w.pos && w.pos < nn && ((m >> 4) & 0xfu) == key_nibble(key, w.pos)) {
                     const uint4* rf = reinterpret_cast<const uint4*>(a.ref + 8ull * j);
                     const uint4 r0 = rf[0], r1 = rf[1];
                     want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
@@ -374,42 +579,68 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const WalkArgs a) {
     if (a.v.value_len) a.v.value_len[i] = vlen;
 }
 
-size_t verify_flat_workspace_bytes(uint32_t total_nodes) {
-    const size_t tn = total_nodes;
-    return 256 /*counters*/ + ((tn * 4 + 255) / 256 * 256) * 3 /*ent_node, ent_proof, meta*/ +
-           ((tn * 32 + 255) / 256 * 256) * 2 /*digest, ref*/ + 1024;
+// ---------------------------------------------------------------- host side
+static size_t rnd256(size_t x) { return (x + 255) / 256 * 256; }
+
+// CUs of the current device (256 on MI355X)
+static uint32_t compute_units() {
+    static int cached[64] = {0};
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256u;
+    if (cached[dev]) return (uint32_t)cached[dev];
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev] = cus;
+    return (uint32_t)cus;
 }
 
-hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, hipStream_t st,
-                                  hipEvent_t ev_hash0, hipEvent_t ev_hash1) {
+static uint32_t table_entries(uint32_t total_nodes) {
+    uint32_t t = 1024;
+    while (t < total_nodes && t < (1u << 26)) t <<= 1;
+    return t;
+}
+
+size_t verify_flat_workspace_bytes(uint32_t total_nodes) {
+    const size_t tn = total_nodes;
+    return 256 /*cursors*/ + rnd256((size_t)table_entries(total_nodes) * 8) + rnd256(tn * 4) * 2 /*rep, meta*/ +
+           rnd256(tn * 4 * N_CLASS) /*ent*/ + rnd256(tn * 32) * 2 /*digest, ref*/ + 1024;
+}
+
+hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, bool dedup, hipStream_t st) {
     if (v.n == 0) return hipSuccess;
     const size_t tn = total_nodes;
-    auto rnd = [](size_t x) { return (x + 255) / 256 * 256; };
-    uint32_t* counts = reinterpret_cast<uint32_t*>(ws);           // [0..8) counts, [8..16) cursors
-    uint32_t* cursors = counts + N_CLASS;
-    uint8_t* p = ws + 256;
-    uint32_t* ent_node = reinterpret_cast<uint32_t*>(p);  p += rnd(tn * 4);
-    uint32_t* ent_proof = reinterpret_cast<uint32_t*>(p); p += rnd(tn * 4);
-    uint32_t* meta = reinterpret_cast<uint32_t*>(p);      p += rnd(tn * 4);
-    uint32_t* digest = reinterpret_cast<uint32_t*>(p);    p += rnd(tn * 32);
-    uint32_t* ref = reinterpret_cast<uint32_t*>(p);
-    hipError_t e = hipMemsetAsync(counts, 0, 2 * N_CLASS * sizeof(uint32_t), st);
+    FlatArgs a;
+    a.v = v;
+    a.total_nodes = total_nodes;
+    a.dedup = dedup ? 1u : 0u;
+    const uint32_t te = table_entries(total_nodes);
+    uint8_t* p = ws;
+    a.cursors = reinterpret_cast<uint32_t*>(p);    p += 256;
+    a.table = reinterpret_cast<uint64_t*>(p);      p += rnd256((size_t)te * 8);
+    a.tmask = te - 1u;
+    a.rep = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4);
+    a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);
+    a.ent = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4 * N_CLASS);
+    a.digest = reinterpret_cast<uint32_t*>(p);     p += rnd256(tn * 32);
+    a.ref = reinterpret_cast<uint32_t*>(p);
+    // cursors and (when deduplicating) the table are contiguous: one memset
+    hipError_t e = hipMemsetAsync(ws, 0, dedup ? 256 + (size_t)te * 8 : 256, st);
     if (e != hipSuccess) return e;
     const uint32_t pg = (v.n + 255u) / 256u;
     if (total_nodes) {
-        hipLaunchKernelGGL(plan_kernel<false>, dim3(pg), dim3(256), 0, st, v.node_off, v.proof_first_node, v.n,
-                           total_nodes, v.nodes_len, counts, cursors, ent_node, ent_proof);
-        hipLaunchKernelGGL(plan_kernel<true>, dim3(pg), dim3(256), 0, st, v.node_off, v.proof_first_node, v.n,
-                           total_nodes, v.nodes_len, counts, cursors, ent_node, ent_proof);
-        HashArgs h{v.nodes, v.node_off, v.proof_first_node, v.keys, v.key_len, counts, ent_node, ent_proof,
-                   digest, ref, meta};
-        const uint32_t hg = (total_nodes + 255u) / 256u + N_CLASS;
-        if (ev_hash0) (void)hipEventRecord(ev_hash0, st);
-        hipLaunchKernelGGL(hash_nodes_kernel, dim3(hg), dim3(256), 0, st, h);
-        if (ev_hash1) (void)hipEventRecord(ev_hash1, st);
+        const uint32_t ng = (total_nodes + 255u) / 256u;
+        hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(dedup_kernel, dim3(ng), dim3(256), 0, st, a);
+        // persistent: 3 workgroups (= 3 waves per SIMD, what ~155 VGPRs admit) per CU, never more than
+        // there are chunks
+        const uint32_t slots = 3u * compute_units();
+        const uint32_t hg = ng + N_CLASS < slots ? ng + N_CLASS : slots;
+        hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, st, a);
     }
-    WalkArgs wa{v, total_nodes, digest, ref, meta};
-    hipLaunchKernelGGL(walk_proofs_kernel, dim3(pg), dim3(256), 0, st, wa);
+    hipLaunchKernelGGL(walk_proofs_kernel, dim3(pg), dim3(256), 0, st, a);
+    if (dedup) {
+        e = launch_mpt_verify_fixup(v, st);
+        if (e != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 

@@ -65,6 +65,8 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
     assert world in (1, 2, 4, 8, 16)
     device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
     L = depth - 1  # branch levels; prefix of L nibbles identifies the leaf slot
+    owned_slots = (16 // world if world <= 16 else 0) * 16 ** (L - 1)
+    assert n <= owned_slots, f"depth {depth} has only {owned_slots} leaf slots per rank (asked for {n} proofs)"
     gen = torch.Generator(device=device)
     gen.manual_seed(seed * 1000003 + rank)
 

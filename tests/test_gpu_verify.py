@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 class _Mode:
-    """phant_amd.mpt with every verify call bound to one ctx (flat pipeline or fused kernel)."""
+    """phant_amd.mpt with every verify call bound to one ctx (flat pipeline with / without in-batch node dedup, or the fused kernel)."""
 
     def __init__(self, mod, ctx):
         self._mod, self._ctx = mod, ctx
@@ -26,10 +26,10 @@ class _Mode:
         return self._mod.verify_batch_dev(*a, ctx=self._ctx, **k)
 
 
-@pytest.fixture(scope="module", params=["flat", "fused"])
+@pytest.fixture(scope="module", params=["flat", "nodedup", "fused"])
 def M(request):
     import phant_amd
-    ctx = phant_amd.Context(verify_fused=(request.param == "fused"))
+    ctx = phant_amd.Context(verify_fused=(request.param == "fused"), verify_nodedup=(request.param == "nodedup"))
     yield _Mode(phant_amd.mpt, ctx)
     ctx.close()
 
@@ -202,7 +202,9 @@ def test_synthetic_depth8_small_vs_oracle(M, oracle):
 @pytest.mark.parametrize("depth", [2, 3, 5, 9])
 def test_synthetic_other_depths(M, oracle, depth):
     import phant_amd
-    w = phant_amd.witness.account_witness(500, depth=depth, seed=5, corrupt_frac=0.1)
+    # (depth-1) branch levels give 16^(depth-1) distinct leaf slots: keep n below that
+    n = min(500, 16 ** (depth - 1) * 3 // 4)
+    w = phant_amd.witness.account_witness(n, depth=depth, seed=5, corrupt_frac=0.2)
     st = M.verify_batch_dev(w.batch)
     assert torch.equal(st, w.expected)
     b = w.batch
