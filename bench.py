@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
-    ap.add_argument("--verify-mode", default="flat", choices=["flat", "nodedup", "fused"],
-                    help="flat = node-parallel pipeline with in-batch node dedup (default); nodedup = same pipeline "
+    ap.add_argument("--verify-mode", default="flat", choices=["flat", "overlap", "nodedup", "fused"],
+                    help="flat = node-parallel pipeline with in-batch node dedup (default); overlap = the same with "
+                         "the byte comparison on a helper stream next to the hashing; nodedup = same pipeline "
                          "hashing every shipped node (A/B); fused = one lane per proof (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -128,7 +129,8 @@ def main():
 
     # bound to torch's current stream on this device
     ctx = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"),
-                            verify_nodedup=(args.verify_mode == "nodedup"))
+                            verify_nodedup=(args.verify_mode == "nodedup"),
+                            verify_overlap=(args.verify_mode == "overlap"))
 
     if args.workload == "config3":
         w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,

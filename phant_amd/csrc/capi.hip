@@ -26,7 +26,9 @@ struct phant_ctx {
     phant::Workspaces ws;
     phant::DevArena dv;  // workspace of the device-form verify pipeline
     bool verify_fused = false;
-    bool verify_nodedup = false;
+    phant::FlatMode flat_mode = phant::FLAT_SERIAL;
+    // helper stream of the overlap pipeline (created on first use)
+    phant::FlatSide side{nullptr, nullptr, nullptr};
     // stream-side timing of the last device-form call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -121,7 +123,15 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         own = (opts->flags & PHANT_CTX_OWN_STREAM) != 0;
     }
     bool fused = opts && (opts->flags & PHANT_CTX_VERIFY_FUSED);
-    if (const char* m = std::getenv("PHANT_VERIFY_MODE")) fused = std::strcmp(m, "fused") == 0;
+    phant::FlatMode flat = phant::FLAT_SERIAL;
+    if (opts && (opts->flags & PHANT_CTX_VERIFY_NODEDUP)) flat = phant::FLAT_NODEDUP;
+    if (opts && (opts->flags & PHANT_CTX_VERIFY_OVERLAP)) flat = phant::FLAT_OVERLAP;
+    if (const char* m = std::getenv("PHANT_VERIFY_MODE")) {  // overrides the flags (A/B without touching callers)
+        fused = std::strcmp(m, "fused") == 0;
+        flat = std::strcmp(m, "nodedup") == 0   ? phant::FLAT_NODEDUP
+               : std::strcmp(m, "overlap") == 0 ? phant::FLAT_OVERLAP
+                                                : phant::FLAT_SERIAL;
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || dev < 0 || dev >= n) return PHANT_E_NO_DEVICE;
     hipDeviceProp_t prop;
@@ -131,8 +141,7 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     if (!c) return PHANT_E_OOM;
     c->device = dev;
     c->verify_fused = fused;
-    c->verify_nodedup = opts && (opts->flags & PHANT_CTX_VERIFY_NODEDUP);
-    if (const char* m = std::getenv("PHANT_VERIFY_MODE")) c->verify_nodedup = std::strcmp(m, "nodedup") == 0;
+    c->flat_mode = flat;
     DeviceGuard g(dev);
     if (!own) {
         c->stream = (hipStream_t)stream;  // nullptr = the default stream
@@ -159,6 +168,10 @@ void phant_ctx_destroy(phant_ctx* c) {
     c->dv.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->side.stream) (void)hipStreamSynchronize(c->side.stream);
+    if (c->side.fork) (void)hipEventDestroy(c->side.fork);
+    if (c->side.join) (void)hipEventDestroy(c->side.join);
+    if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -197,8 +210,11 @@ int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
     if (c->verify_fused || !c->dv.base) return PHANT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // the class cursors are the first 8 words of the verify workspace (mpt_verify_flat.hip)
-    HIP_TRY(c, hipMemcpy(hashed, c->dv.base, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // the class cursors are words 0..7 of the verify workspace, the late-hash cursors of the overlap
+    // pipeline words 16..23 (mpt_verify_flat.hip)
+    uint32_t hdr[24];
+    HIP_TRY(c, hipMemcpy(hdr, c->dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) hashed[i] = hdr[i] + hdr[16 + i];
     return PHANT_OK;
 }
 
@@ -298,8 +314,13 @@ static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_
         hipError_t e = c->dv.reset(need);
         if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(verify workspace)", e);
     }
+    if (c->flat_mode == phant::FLAT_OVERLAP && !c->side.stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
+    }
     TimedRegion t(c);
-    HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, c->dv.base, !c->verify_nodedup, c->stream));
+    HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, c->dv.base, c->flat_mode, c->stream, &c->side));
     return PHANT_OK;
 }
 

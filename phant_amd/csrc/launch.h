@@ -31,9 +31,19 @@ hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
 // "could not settle from the tables" marker)
 hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, hipStream_t st);
 // flat pipeline (plan -> dedup/compare -> class-sorted hashing of distinct nodes -> walk -> fixup);
-// ws = verify_flat_workspace_bytes().  dedup = false hashes every shipped node (A/B).
+// ws = verify_flat_workspace_bytes().
+//   FLAT_SERIAL   compare, then hash, on one stream
+//   FLAT_NODEDUP  hash every shipped node (A/B)
+//   FLAT_OVERLAP  the byte comparison (an HBM stream) runs on `side->stream` NEXT TO the hashing of the
+//                 groups' representatives (integer-VALU-bound) instead of in front of it
+enum FlatMode : int { FLAT_SERIAL = 0, FLAT_NODEDUP = 1, FLAT_OVERLAP = 2 };
+struct FlatSide {
+    hipStream_t stream;      // non-blocking helper stream owned by the ctx
+    hipEvent_t fork, join;   // timing-disabled events
+};
 size_t verify_flat_workspace_bytes(uint32_t total_nodes);
-hipError_t launch_mpt_verify_flat(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, bool dedup, hipStream_t st);
+hipError_t launch_mpt_verify_flat(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, FlatMode mode,
+                                  hipStream_t st, const FlatSide* side);
 hipError_t launch_mpt_verdict(const uint8_t* d_status, const uint32_t* d_root_idx, uint32_t n,
                               uint32_t n_roots, uint32_t* d_fail_count, hipStream_t st);
 

@@ -39,6 +39,8 @@
 // What it computes: the verifier missing at
 // src/engine_api/execution_payload.zig:177-178, over the node encodings of
 // src/mpt/mpt.zig:187-193,216-231,254-261,285-314.
+#include <cstdlib>
+
 #include "launch.h"
 #include "mpt_walk.hip.h"
 
@@ -98,7 +100,19 @@ struct FlatArgs {
     uint32_t* cursors;       // N_CLASS class counts + [N_CLASS] = work-queue head of the hash kernel; zeroed per call
     uint32_t* digest;        // total_nodes x 8
     uint32_t* ref;           // total_nodes x 8
+    // overlap mode only: nodes whose bytes turned out to differ from their group's representative
+    uint32_t* late_ent;      // N_CLASS x total_nodes
+    uint32_t* late_cursors;  // N_CLASS class counts; zeroed per call
 };
+
+// dedup_kernel flavours.  SERIAL: classify + compare + compact in one kernel, the hash kernel runs
+// after it.  CLASSIFY / COMPARE: the overlap pipeline -- CLASSIFY only consults the plan table and
+// lists every node that is its group's representative (or has none) for hashing; COMPARE, which
+// runs NEXT TO the hash kernel on a second stream, streams the bytes, validates / captures the
+// full-branch references and lists the rare node that differs from its representative for a late
+// hashing pass.
+enum : int { DEDUP_SERIAL = 0, DEDUP_CLASSIFY = 1, DEDUP_COMPARE = 2 };
+constexpr uint32_t PRE_NIB = 2u;  // CLASSIFY -> COMPARE hand-over in meta[]: PRE_NIB | nibble << 4 | depth << 8
 
 // ---------------------------------------------------------------- plan
 // One lane per proof: every multi-block node proposes itself as the representative of its
@@ -157,6 +171,7 @@ PHANT_DEV uint32_t find_proof(const uint32_t* __restrict__ pfn, uint32_t n, uint
 
 constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte path
 
+template <int MODE>
 __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
     __shared__ uint32_t s_cnt[4][N_CLASS];
     __shared__ uint32_t s_base[N_CLASS];
@@ -174,7 +189,19 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
         if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
             valid = true;
             len = (uint32_t)(e - b);
-            if (len >= RATE) {
+            if (MODE == DEDUP_COMPARE) {
+                if (len >= RATE) {
+                    // CLASSIFY left the representative in rep[] (already checked: in range, well formed,
+                    // same length) and the proof's key nibble / depth in meta[]
+                    const uint32_t pm = a.meta[j], c = a.rep[j];
+                    if (pm & PRE_NIB) nib = (pm >> 4) & 15u;
+                    dpos = pm >> 8;
+                    if (c != j && c < N) {
+                        cand = c;
+                        cb = a.v.node_off[c];
+                    }
+                }
+            } else if (len >= RATE) {
                 const uint32_t p = find_proof(a.v.proof_first_node, a.v.n, N, j);
                 const uint32_t first = a.v.proof_first_node[p];
                 const uint32_t nn = 2u * a.v.key_len;
@@ -206,6 +233,12 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
         }
     }
 
+    uint32_t my_rep = j, my_meta = 0;
+    if constexpr (MODE == DEDUP_CLASSIFY) {
+        // no bytes are read here: trust the table, COMPARE checks it
+        my_rep = cand;
+        if (valid && len >= RATE) my_meta = (nib < 16u ? (PRE_NIB | (nib << 4)) : 0u) | ((dpos & 0xffffffu) << 8);
+    } else {
     // ---- this lane's share of a 532-byte node: bytes [16 lane, 16 lane + 16) for lane < 33; the lanes
     // above all take the last 16 bytes [516, 532) (redundant cover: no lane is ever masked off, so
     // every load below is unconditional and the loads of several nodes overlap) ----
@@ -225,8 +258,6 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
             cv[t >> 2] |= want << (8u * (t & 3u));
         }
     }
-
-    uint32_t my_rep = j, my_meta = 0;
 
     // ---- 532-byte nodes: DEDUP_UNROLL nodes per trip, all their loads issued before any is used.
     // A short last trip repeats its last node (idempotent) so that the body has no conditionals. ----
@@ -289,8 +320,15 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
         if (lane == i && eq) my_rep = cand;
     }
 
+    }  // MODE != DEDUP_CLASSIFY
+
     // ---- results + per-class compaction of the nodes that must be hashed ----
-    const bool need = valid && my_rep == j;
+    // SERIAL: every node that represents itself.  CLASSIFY: the same, before any byte was compared.
+    // COMPARE: only the nodes that had a representative and turned out to differ from it.
+    const bool need = MODE == DEDUP_COMPARE ? (valid && len >= RATE && cand != j && my_rep == j)
+                                            : (valid && my_rep == j);
+    uint32_t* const cursors = MODE == DEDUP_COMPARE ? a.late_cursors : a.cursors;
+    uint32_t* const ent = MODE == DEDUP_COMPARE ? a.late_ent : a.ent;
     const uint32_t cls = valid ? node_class(len) : CLASS_NONE;
     if (j < N) {
         a.rep[j] = my_rep;
@@ -306,13 +344,13 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
     __syncthreads();
     if (tid < N_CLASS) {
         const uint32_t tot = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
-        s_base[tid] = tot ? atomicAdd(&a.cursors[tid], tot) : 0u;
+        s_base[tid] = tot ? atomicAdd(&cursors[tid], tot) : 0u;
     }
     __syncthreads();
     if (need) {
         uint32_t at = s_base[cls] + my_rank;
         for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
-        a.ent[(uint64_t)cls * N + at] = j;
+        ent[(uint64_t)cls * N + at] = j;
     }
 }
 
@@ -475,6 +513,14 @@ __global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
 }
 
 // ---------------------------------------------------------------- walk
+// PF: the leading run of validated full branches of a proof is checked WALK_PF nodes at a time with
+// all table reads of those nodes in flight together (the expected reference of node k+1 is the
+// captured reference of node k, so nothing but the verdict is sequential); the generic loop below
+// then continues from the first node that is not on the fast path -- for BASELINE's depth-8 proofs
+// the leaf.  Without PF every node costs two dependent trips to HBM, 16 in a row per proof.
+constexpr int WALK_PF = 8;
+
+template <bool PF>
 __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= a.v.n) return;
@@ -505,7 +551,59 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
         const uint8_t* cur = nullptr;
         uint32_t cur_len = 0;
         status = 0xffffffffu;
+        if constexpr (PF) {
+            bool stop = false;
+            while (!stop && used < last) {
+                const uint32_t c = last - used < (uint32_t)WALK_PF ? last - used : (uint32_t)WALK_PF;
+                uint32_t jn[WALK_PF], rp[WALK_PF], mt[WALK_PF], rr[WALK_PF];
+                uint4 d0[WALK_PF], d1[WALK_PF], f0[WALK_PF], f1[WALK_PF];
+#pragma unroll
+                for (int u = 0; u < WALK_PF; ++u) {  // a short run repeats its last node (cache hits)
+                    jn[u] = used + ((uint32_t)u < c ? (uint32_t)u : c - 1u);
+                    rp[u] = a.rep[jn[u]];
+                    mt[u] = a.meta[jn[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < WALK_PF; ++u) {
+                    rr[u] = 0;
+                    d0[u] = d1[u] = f0[u] = f1[u] = make_uint4(0, 0, 0, 0);
+                    if ((mt[u] & META_FAST) && rp[u] < a.total_nodes) {
+                        rr[u] = a.rep[rp[u]];
+                        const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rp[u]);
+                        d0[u] = dg[0];
+                        d1[u] = dg[1];
+                        const uint4* rf = reinterpret_cast<const uint4*>(a.ref + 8ull * jn[u]);
+                        f0[u] = rf[0];
+                        f1[u] = rf[1];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < WALK_PF; ++u) {
+                    if (stop || (uint32_t)u >= c) continue;
+                    const uint32_t m = mt[u];
+                    // same conditions, in the same order, as the generic loop below applies to a node
+                    // reached through a 32-byte reference
+                    if (!(m & META_FAST) || w.pos >= nn || (m >> 8) != w.pos ||
+                        ((m >> 4) & 0xfu) != key_nibble(key, w.pos)) {
+                        stop = true;  // not a fast step: the generic loop takes this node
+                    } else if (rp[u] != jn[u] && (rp[u] >= a.total_nodes || rr[u] != rp[u])) {
+                        status = STATUS_NEEDS_SLOW;
+                        stop = true;
+                    } else if ((d0[u].x ^ want[0]) | (d0[u].y ^ want[1]) | (d0[u].z ^ want[2]) | (d0[u].w ^ want[3]) |
+                               (d1[u].x ^ want[4]) | (d1[u].y ^ want[5]) | (d1[u].z ^ want[6]) | (d1[u].w ^ want[7])) {
+                        status = PHANT_PROOF_BAD_HASH;
+                        stop = true;
+                    } else {
+                        want[0] = f0[u].x; want[1] = f0[u].y; want[2] = f0[u].z; want[3] = f0[u].w;
+                        want[4] = f1[u].x; want[5] = f1[u].y; want[6] = f1[u].z; want[7] = f1[u].w;
+                        w.pos += 1;
+                        ++used;
+                    }
+                }
+            }
+        }
         for (;;) {
+            if (status != 0xffffffffu) break;  // settled on the prefetched fast path
             bool fast = false;
             if (by_hash) {
                 if (used == last) {
@@ -601,12 +699,26 @@ static uint32_t table_entries(uint32_t total_nodes) {
 
 size_t verify_flat_workspace_bytes(uint32_t total_nodes) {
     const size_t tn = total_nodes;
-    return 256 /*cursors*/ + rnd256((size_t)table_entries(total_nodes) * 8) + rnd256(tn * 4) * 2 /*rep, meta*/ +
-           rnd256(tn * 4 * N_CLASS) /*ent*/ + rnd256(tn * 32) * 2 /*digest, ref*/ + 1024;
+    return 256 /*cursors + late cursors*/ + rnd256((size_t)table_entries(total_nodes) * 8) + rnd256(tn * 4) * 2 /*rep, meta*/ +
+           rnd256(tn * 4 * N_CLASS) * 2 /*ent, late_ent*/ + rnd256(tn * 32) * 2 /*digest, ref*/ + 1024;
 }
 
-hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, bool dedup, hipStream_t st) {
+// tuning knobs read from the environment at every launch (A/B sweeps on the GPU box inside one
+// process, tools/sweep_verify.py; the defaults are what DESIGN.md section 9 measured best)
+static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+    const char* s = std::getenv(name);
+    if (!s || !*s) return dflt;
+    const long v = std::strtol(s, nullptr, 10);
+    if (v < (long)lo) return lo;
+    if (v > (long)hi) return hi;
+    return (uint32_t)v;
+}
+
+hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, FlatMode mode,
+                                  hipStream_t st, const FlatSide* side) {
     if (v.n == 0) return hipSuccess;
+    const bool dedup = mode != FLAT_NODEDUP;
+    const bool overlap = mode == FLAT_OVERLAP && side && side->stream && side->fork && side->join;
     const size_t tn = total_nodes;
     FlatArgs a;
     a.v = v;
@@ -614,12 +726,15 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
     a.dedup = dedup ? 1u : 0u;
     const uint32_t te = table_entries(total_nodes);
     uint8_t* p = ws;
-    a.cursors = reinterpret_cast<uint32_t*>(p);    p += 256;
+    a.cursors = reinterpret_cast<uint32_t*>(p);
+    a.late_cursors = reinterpret_cast<uint32_t*>(p) + 16;  // same zeroed 256-byte header
+    p += 256;
     a.table = reinterpret_cast<uint64_t*>(p);      p += rnd256((size_t)te * 8);
     a.tmask = te - 1u;
     a.rep = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4);
     a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);
     a.ent = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4 * N_CLASS);
+    a.late_ent = reinterpret_cast<uint32_t*>(p);   p += rnd256(tn * 4 * N_CLASS);
     a.digest = reinterpret_cast<uint32_t*>(p);     p += rnd256(tn * 32);
     a.ref = reinterpret_cast<uint32_t*>(p);
     // cursors and (when deduplicating) the table are contiguous: one memset
@@ -628,15 +743,36 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
     const uint32_t pg = (v.n + 255u) / 256u;
     if (total_nodes) {
         const uint32_t ng = (total_nodes + 255u) / 256u;
-        hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(dedup_kernel, dim3(ng), dim3(256), 0, st, a);
-        // persistent: 3 workgroups (= 3 waves per SIMD, what ~155 VGPRs admit) per CU, never more than
-        // there are chunks
-        const uint32_t slots = 3u * compute_units();
+        // persistent hash grid: `wps` workgroups per CU = waves per SIMD.  ~155 VGPRs admit 3; the overlap
+        // pipeline takes 2 so that COMPARE waves (40 VGPRs) always find room on the same SIMDs.
+        const uint32_t wps_serial = env_u32("PHANT_HASH_WPS", 3u, 1u, 3u);
+        const uint32_t wps_overlap = env_u32("PHANT_HASH_WPS", 2u, 1u, 3u);
+        const uint32_t slots = (overlap ? wps_overlap : wps_serial) * compute_units();
         const uint32_t hg = ng + N_CLASS < slots ? ng + N_CLASS : slots;
-        hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
+        if (!overlap) {
+            hipLaunchKernelGGL(dedup_kernel<DEDUP_SERIAL>, dim3(ng), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, st, a);
+        } else {
+            // COMPARE is capped at (160 KiB / lds) workgroups per CU by an otherwise unused dynamic LDS
+            // allocation, so it can never crowd the hash waves out of the wave slots
+            const uint32_t cmp_lds = env_u32("PHANT_CMP_LDS_KB", 60u, 0u, 63u) * 1024u;
+            hipLaunchKernelGGL(dedup_kernel<DEDUP_CLASSIFY>, dim3(ng), dim3(256), 0, st, a);
+            if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
+            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(dedup_kernel<DEDUP_COMPARE>, dim3(ng), dim3(256), cmp_lds, side->stream, a);
+            FlatArgs late = a;  // same kernel over the (normally empty) list of nodes that differed
+            late.ent = a.late_ent;
+            late.cursors = a.late_cursors;
+            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, side->stream, late);
+            if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
+        }
     }
-    hipLaunchKernelGGL(walk_proofs_kernel, dim3(pg), dim3(256), 0, st, a);
+    const uint32_t walk_pf = env_u32("PHANT_WALK_PF", 1u, 0u, 1u);
+    if (walk_pf) hipLaunchKernelGGL(walk_proofs_kernel<true>, dim3(pg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(walk_proofs_kernel<false>, dim3(pg), dim3(256), 0, st, a);
     if (dedup) {
         e = launch_mpt_verify_fixup(v, st);
         if (e != hipSuccess) return e;

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 class _Mode:
-    """phant_amd.mpt with every verify call bound to one ctx (flat pipeline with / without in-batch node dedup, or the fused kernel)."""
+    """phant_amd.mpt with every verify call bound to one ctx (flat pipeline serial / overlapped / without in-batch node dedup, or the fused kernel)."""
 
     def __init__(self, mod, ctx):
         self._mod, self._ctx = mod, ctx
@@ -26,10 +26,11 @@ class _Mode:
         return self._mod.verify_batch_dev(*a, ctx=self._ctx, **k)
 
 
-@pytest.fixture(scope="module", params=["flat", "nodedup", "fused"])
+@pytest.fixture(scope="module", params=["flat", "overlap", "nodedup", "fused"])
 def M(request):
     import phant_amd
-    ctx = phant_amd.Context(verify_fused=(request.param == "fused"), verify_nodedup=(request.param == "nodedup"))
+    ctx = phant_amd.Context(verify_fused=(request.param == "fused"), verify_nodedup=(request.param == "nodedup"),
+                            verify_overlap=(request.param == "overlap"))
     yield _Mode(phant_amd.mpt, ctx)
     ctx.close()
 

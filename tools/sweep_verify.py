@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""A/B sweep of the verify pipeline's modes and tuning knobs on one GPU, one process, one witness.
+
+    python tools/sweep_verify.py [--proofs 100000] [--steps 20] [--out gpurun_out/sweep.jsonl]
+
+Every combination is checked against the constructed expectation before it is timed.  Prints one
+JSON line per combination: wall ms/step (sync-bracketed), HIP-event ms of the launch, nodes hashed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+COMBOS = [
+    ("flat", {}),
+    ("flat", {"PHANT_WALK_PF": "0"}),
+    ("flat", {"PHANT_HASH_WPS": "2"}),
+    ("overlap", {}),
+    ("overlap", {"PHANT_WALK_PF": "0"}),
+    ("overlap", {"PHANT_CMP_LDS_KB": "0"}),
+    ("overlap", {"PHANT_CMP_LDS_KB": "40"}),
+    ("overlap", {"PHANT_CMP_LDS_KB": "0", "PHANT_HASH_WPS": "3"}),
+    ("overlap", {"PHANT_CMP_LDS_KB": "30"}),
+    ("nodedup", {}),
+    ("nodedup", {"PHANT_HASH_WPS": "2"}),
+    ("fused", {}),
+]
+KNOBS = ("PHANT_WALK_PF", "PHANT_HASH_WPS", "PHANT_CMP_LDS_KB")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--proofs", type=int, default=100_000)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    import torch
+    import phant_amd
+    from phant_amd import mpt as M
+
+    dev = torch.device("cuda", 0)
+    w = phant_amd.witness.account_witness(args.proofs, depth=8, seed=2, device=dev)
+    b = w.batch
+    status = torch.empty(b.n, dtype=torch.uint8, device=dev)
+    lines = []
+    for mode, env in COMBOS:
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        ctx = phant_amd.Context(0, verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"),
+                                verify_overlap=(mode == "overlap"))
+        status.fill_(0x77)
+        for _ in range(3):
+            M.verify_batch_dev(b, status=status, ctx=ctx)
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(status, w.expected))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            M.verify_batch_dev(b, status=status, ctx=ctx)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / args.steps * 1e3
+        ctx.timing(True)
+        kms = []
+        for _ in range(10):
+            M.verify_batch_dev(b, status=status, ctx=ctx)
+            kms.append(ctx.last_kernel_ms())
+        ctx.timing(False)
+        hashed = ctx.verify_stats() if mode != "fused" else []
+        line = {"mode": mode, "env": env, "ok": ok, "wall_ms": round(wall, 4), "event_ms": round(sum(kms) / len(kms), 4),
+                "event_min_ms": round(min(kms), 4), "proofs_per_s": round(b.n / (wall * 1e-3)),
+                "nodes_hashed": int(sum(hashed)), "keccak_f": int(sum((c + 1) * h for c, h in enumerate(hashed)))}
+        print(json.dumps(line), flush=True)
+        lines.append(line)
+        ctx.close()
+    if args.out:
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        with open(args.out, "w") as f:
+            for l in lines:
+                f.write(json.dumps(l) + "\n")
+
+
+if __name__ == "__main__":
+    main()
