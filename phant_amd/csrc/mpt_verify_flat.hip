@@ -65,6 +65,12 @@ PHANT_DEV uint4 load16u(const uint8_t* p) {  // unaligned 16-byte global load
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 PHANT_DEV uint32_t load4u(const uint8_t* p) { return reinterpret_cast<const U32x1*>(p)->x; }
+// value of `v` in lane `i` (wave-uniform i).  The builtin returns int: without the cast a 64-bit
+// offset assembled from two halves gets its low half sign-extended (wrong for blobs > 2 GiB).
+PHANT_DEV uint32_t lane_u32(uint32_t v, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane(v, i); }
+PHANT_DEV uint64_t lane_u64(uint32_t lo, uint32_t hi, uint32_t i) {
+    return ((uint64_t)lane_u32(hi, i) << 32) | (uint64_t)lane_u32(lo, i);
+}
 
 // first 8 key bytes, big-endian (zero padded): the nibble prefix of depth d is its top 4d bits
 PHANT_DEV uint64_t key_prefix64(const uint8_t* __restrict__ key, uint32_t key_len) {
@@ -92,15 +98,17 @@ struct FlatArgs {
     VerifyArgs v;
     uint32_t total_nodes;
     uint32_t dedup;          // 0: hash every node (A/B)
+    uint32_t cmp_prio;       // overlap mode: s_setprio level of the COMPARE waves (they share SIMDs with hash waves)
     uint64_t* table;         // tmask + 1 entries {fp:32 | node:32}, zeroed per call
     uint32_t tmask;
     uint32_t* rep;           // total_nodes
     uint32_t* meta;          // total_nodes
-    uint32_t* ent;           // N_CLASS x total_nodes
+    uint32_t* ent;           // N_CLASS x total_nodes: node ids to hash, per rate-block class
     uint32_t* cursors;       // N_CLASS class counts + [N_CLASS] = work-queue head of the hash kernel; zeroed per call
     uint32_t* digest;        // total_nodes x 8
     uint32_t* ref;           // total_nodes x 8
     // overlap mode only: nodes whose bytes turned out to differ from their group's representative
+    uint64_t* gkey;          // total_nodes: group key of the node, where meta[] says PRE_GROUP
     uint32_t* late_ent;      // N_CLASS x total_nodes
     uint32_t* late_cursors;  // N_CLASS class counts; zeroed per call
 };
@@ -112,33 +120,70 @@ struct FlatArgs {
 // full-branch references and lists the rare node that differs from its representative for a late
 // hashing pass.
 enum : int { DEDUP_SERIAL = 0, DEDUP_CLASSIFY = 1, DEDUP_COMPARE = 2 };
-constexpr uint32_t PRE_NIB = 2u;  // CLASSIFY -> COMPARE hand-over in meta[]: PRE_NIB | nibble << 4 | depth << 8
+// plan_kernel -> dedup_kernel hand-over in meta[] (zeroed per call, so an unstamped node reads 0):
+// PRE_STAMP | PRE_NIB (nibble valid) | PRE_GROUP (gkey[] valid) | nibble << 4 | depth << 8
+constexpr uint32_t PRE_NIB = 2u, PRE_GROUP = 4u, PRE_STAMP = 8u;
 
 // ---------------------------------------------------------------- plan
-// One lane per proof: every multi-block node proposes itself as the representative of its
-// (root, depth, key prefix) group.  Plain stores: the last writer of a slot wins.
+// One lane per proof.  Stamps every node of the proof (up to the deepest position a walk can reach)
+// with what the node-parallel kernels need to know about its owner -- depth, the key nibble at that
+// depth, and the 64-bit key of its (root, depth, key prefix) group -- so that they never search for
+// the owning proof or touch the keys again.  Every multi-block node also proposes itself as the
+// representative of its group.  Plain stores: the last writer of a table slot wins.
+constexpr uint32_t PLAN_BATCH = 8;  // even: a batch starts on a key byte
+
 __global__ void __launch_bounds__(256) plan_kernel(const FlatArgs a) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= a.v.n) return;
     const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
     if (last < first || last > a.total_nodes) return;  // BAD_INPUT: the walk reports it
     const uint32_t root = a.v.root_idx ? a.v.root_idx[p] : 0u;
-    const uint64_t kb = key_prefix64(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len);
-    uint32_t dmax = 2u * a.v.key_len;
-    dmax = dmax < DEDUP_MAX_DEPTH ? dmax : DEDUP_MAX_DEPTH;
+    const uint8_t* key = a.v.keys + (uint64_t)a.v.key_len * p;
+    const uint64_t kb = key_prefix64(key, a.v.key_len);
+    const uint32_t nn = 2u * a.v.key_len;
+    uint32_t dmax = nn < DEDUP_MAX_DEPTH ? nn : DEDUP_MAX_DEPTH;
     uint32_t end = last - first;
-    end = end <= dmax ? end : dmax + 1u;
+    end = end <= nn ? end : nn + 1u;  // a walk consumes at least one nibble per hashed node
+    // PLAN_BATCH nodes at a time: their offsets are all requested before the first store (the compiler
+    // may not move a load across the table / stamp stores itself -- they could alias -- and one HBM
+    // round trip per node is what this kernel's time is made of)
     uint64_t b = end ? a.v.node_off[first] : 0ull;
-    for (uint32_t d = 0; d < end; ++d) {
-        const uint32_t j = first + d;
-        const uint64_t e = a.v.node_off[j + 1];
-        if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull && e - b >= RATE) {
-            const uint64_t h = group_key(kb, root, d);
-            const uint64_t entry = ((uint64_t)gk_fp(h) << 32) | j;
-            a.table[gk_slot_a(h, a.tmask)] = entry;
-            a.table[gk_slot_b(h, a.tmask)] = entry;
+    for (uint32_t d0 = 0; d0 < end; d0 += PLAN_BATCH) {
+        uint64_t offs[PLAN_BATCH];
+        uint32_t kb4 = 0;  // key bytes d0/2 .. d0/2 + 3 (PLAN_BATCH = 8 nibbles)
+#pragma unroll
+        for (uint32_t u = 0; u < PLAN_BATCH; ++u) {
+            const uint32_t d = d0 + u < end ? d0 + u : end - 1u;
+            offs[u] = a.v.node_off[first + d + 1u];
         }
-        b = e;
+#pragma unroll
+        for (uint32_t u = 0; u < PLAN_BATCH / 2u; ++u)
+            if (d0 / 2u + u < a.v.key_len) kb4 |= (uint32_t)key[d0 / 2u + u] << (8u * u);
+#pragma unroll
+        for (uint32_t u = 0; u < PLAN_BATCH; ++u) {
+            const uint32_t d = d0 + u;
+            if (d < end) {
+                const uint32_t j = first + d;
+                const uint64_t e = offs[u];
+                uint32_t pm = PRE_STAMP | (d << 8);
+                if (d < nn) {
+                    const uint32_t kbyte = (kb4 >> (8u * (u >> 1))) & 0xffu;
+                    pm |= PRE_NIB | (((u & 1u) ? (kbyte & 0x0fu) : (kbyte >> 4)) << 4);
+                }
+                if (a.dedup && d <= dmax) {
+                    const uint64_t h = group_key(kb, root, d);
+                    a.gkey[j] = h;
+                    pm |= PRE_GROUP;
+                    if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull && e - b >= RATE) {
+                        const uint64_t entry = ((uint64_t)gk_fp(h) << 32) | j;
+                        a.table[gk_slot_a(h, a.tmask)] = entry;
+                        a.table[gk_slot_b(h, a.tmask)] = entry;
+                    }
+                }
+                a.meta[j] = pm;
+                b = e;
+            }
+        }
     }
 }
 
@@ -155,20 +200,6 @@ PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len
     return __ballot(diff != 0) == 0ull;
 }
 
-// proof owning node j: pfn[p] <= j < pfn[p+1].  Equal-length proofs are hit by the first guess.
-PHANT_DEV uint32_t find_proof(const uint32_t* __restrict__ pfn, uint32_t n, uint32_t total_nodes, uint32_t j) {
-    uint32_t g = (uint32_t)(((uint64_t)j * n) / total_nodes);
-    g = g < n ? g : n - 1u;
-    if (pfn[g] <= j && j < pfn[g + 1]) return g;
-    uint32_t lo = 0, hi = n;  // invariant (for monotone pfn): pfn[lo] <= j < pfn[hi]
-    while (hi - lo > 1u) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (pfn[mid] <= j) lo = mid;
-        else hi = mid;
-    }
-    return lo;
-}
-
 constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte path
 
 template <int MODE>
@@ -178,54 +209,46 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t j = blockIdx.x * 256u + tid;
     const uint32_t N = a.total_nodes;
+    if constexpr (MODE == DEDUP_COMPARE) {
+        // these waves issue a few instructions and then wait for memory; next to the hash waves (which
+        // never stop issuing) they would otherwise only get the leftover issue slots
+        if (a.cmp_prio == 1u) __builtin_amdgcn_s_setprio(1);
+        else if (a.cmp_prio == 2u) __builtin_amdgcn_s_setprio(2);
+        else if (a.cmp_prio >= 3u) __builtin_amdgcn_s_setprio(3);
+    }
 
     // ---- lane-per-node metadata (coalesced) ----
     bool valid = false;
     uint64_t b = 0, cb = 0;
-    uint32_t len = 0, cand = j, nib = 0xffu, dpos = 0xffffffffu;
+    uint32_t len = 0, cand = j, stamp = 0;  // stamp: plan_kernel's PRE_* word (0: no walk reaches the node)
     if (j < N) {
         const uint64_t e = a.v.node_off[j + 1];
         b = a.v.node_off[j];
         if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
             valid = true;
             len = (uint32_t)(e - b);
-            if (MODE == DEDUP_COMPARE) {
-                if (len >= RATE) {
+            if (len >= RATE) {
+                stamp = a.meta[j];
+                if (MODE == DEDUP_COMPARE) {
                     // CLASSIFY left the representative in rep[] (already checked: in range, well formed,
-                    // same length) and the proof's key nibble / depth in meta[]
-                    const uint32_t pm = a.meta[j], c = a.rep[j];
-                    if (pm & PRE_NIB) nib = (pm >> 4) & 15u;
-                    dpos = pm >> 8;
+                    // same length)
+                    const uint32_t c = a.rep[j];
                     if (c != j && c < N) {
                         cand = c;
                         cb = a.v.node_off[c];
                     }
-                }
-            } else if (len >= RATE) {
-                const uint32_t p = find_proof(a.v.proof_first_node, a.v.n, N, j);
-                const uint32_t first = a.v.proof_first_node[p];
-                const uint32_t nn = 2u * a.v.key_len;
-                if (first <= j && j - first <= nn) {
-                    dpos = j - first;
-                    const uint8_t* key = a.v.keys + (uint64_t)a.v.key_len * p;
-                    if (dpos < nn) {
-                        const uint32_t kbyte = key[dpos >> 1];
-                        nib = (dpos & 1u) ? (kbyte & 0x0fu) : (kbyte >> 4);
-                    }
-                    if (a.dedup && dpos <= DEDUP_MAX_DEPTH) {
-                        const uint32_t root = a.v.root_idx ? a.v.root_idx[p] : 0u;
-                        const uint64_t h = group_key(key_prefix64(key, a.v.key_len), root, dpos);
-                        const uint32_t fp = gk_fp(h);
-                        uint64_t en = a.table[gk_slot_a(h, a.tmask)];
-                        if ((uint32_t)(en >> 32) != fp) en = a.table[gk_slot_b(h, a.tmask)];
-                        if ((uint32_t)(en >> 32) == fp && (uint32_t)en < N && (uint32_t)en != j) {
-                            // a representative is only usable if it is a well-formed node of the same length
-                            const uint32_t c = (uint32_t)en;
-                            const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
-                            if (c1 >= c0 && c1 <= a.v.nodes_len && c1 - c0 == len) {
-                                cand = c;
-                                cb = c0;
-                            }
+                } else if (stamp & PRE_GROUP) {
+                    const uint64_t h = a.gkey[j];
+                    const uint32_t fp = gk_fp(h);
+                    uint64_t en = a.table[gk_slot_a(h, a.tmask)];
+                    if ((uint32_t)(en >> 32) != fp) en = a.table[gk_slot_b(h, a.tmask)];
+                    if ((uint32_t)(en >> 32) == fp && (uint32_t)en < N && (uint32_t)en != j) {
+                        // a representative is only usable if it is a well-formed node of the same length
+                        const uint32_t c = (uint32_t)en;
+                        const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
+                        if (c1 >= c0 && c1 <= a.v.nodes_len && c1 - c0 == len) {
+                            cand = c;
+                            cb = c0;
                         }
                     }
                 }
@@ -237,33 +260,45 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
     if constexpr (MODE == DEDUP_CLASSIFY) {
         // no bytes are read here: trust the table, COMPARE checks it
         my_rep = cand;
-        if (valid && len >= RATE) my_meta = (nib < 16u ? (PRE_NIB | (nib << 4)) : 0u) | ((dpos & 0xffffffu) << 8);
+        if (valid && len >= RATE) my_meta = stamp;  // keep the stamp for COMPARE
     } else {
     // ---- this lane's share of a 532-byte node: bytes [16 lane, 16 lane + 16) for lane < 33; the lanes
     // above all take the last 16 bytes [516, 532) (redundant cover: no lane is ever masked off, so
     // every load below is unconditional and the loads of several nodes overlap) ----
     const uint32_t coff = lane < 33u ? 16u * lane : BRANCH_LEN - 16u;
-    // what those 16 bytes must look like in the canonical full branch f9 02 11 | 16 x (a0 + hash) | 80
-    uint32_t cm[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0};
-    for (uint32_t t = 0; t < 16u; ++t) {
-        const uint32_t q = coff + t;
-        uint32_t want = 0x100u;
-        if (q == 0) want = 0xf9u;
-        else if (q == 1) want = 0x02u;
-        else if (q == 2) want = 0x11u;
-        else if (q == 531u) want = 0x80u;
-        else if ((q - 3u) % 33u == 0u) want = 0xa0u;
-        if (want != 0x100u) {
-            cm[t >> 2] |= 0xffu << (8u * (t & 3u));
-            cv[t >> 2] |= want << (8u * (t & 3u));
+    // what those 16 bytes must look like in the canonical full branch f9 02 11 | 16 x (a0 + hash) | 80:
+    // a 16-byte window holds at most one of the a0 markers at 3 + 33 k (k < 16), lane 0 also the list
+    // header, the last window the empty value
+    uint64_t m64[2] = {0, 0}, v64[2] = {0, 0};
+    {
+        const uint32_t k0 = coff <= 3u ? 0u : (coff + 29u) / 33u;  // first k with 3 + 33 k >= coff
+        const uint32_t q0 = 3u + 33u * k0;
+        if (k0 < 16u && q0 < coff + 16u) {
+            const uint32_t t = q0 - coff;
+            m64[t >> 3] |= 0xffull << (8u * (t & 7u));
+            v64[t >> 3] |= 0xa0ull << (8u * (t & 7u));
+        }
+        if (coff == 0u) {
+            m64[0] |= 0xffffffull;
+            v64[0] |= 0x1102f9ull;
+        }
+        if (coff == BRANCH_LEN - 16u) {
+            m64[1] |= 0xffull << 56;
+            v64[1] |= 0x80ull << 56;
         }
     }
+    const uint32_t cm[4] = {(uint32_t)m64[0], (uint32_t)(m64[0] >> 32), (uint32_t)m64[1], (uint32_t)(m64[1] >> 32)};
+    const uint32_t cv[4] = {(uint32_t)v64[0], (uint32_t)(v64[0] >> 32), (uint32_t)v64[1], (uint32_t)(v64[1] >> 32)};
+
+    // everything that selects a node below is wave-uniform: say so, or the compiler predicates per lane
+    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(j - lane);
+    const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32), cb_lo = (uint32_t)cb, cb_hi = (uint32_t)(cb >> 32);
 
     // ---- 532-byte nodes: DEDUP_UNROLL nodes per trip, all their loads issued before any is used.
     // A short last trip repeats its last node (idempotent) so that the body has no conditionals. ----
     unsigned long long todo = __ballot(valid && len == BRANCH_LEN);
     while (todo) {
-        uint32_t ii[DEDUP_UNROLL], nb[DEDUP_UNROLL], cj[DEDUP_UNROLL], rf[DEDUP_UNROLL];
+        uint32_t ii[DEDUP_UNROLL], nb[DEDUP_UNROLL], dp[DEDUP_UNROLL], cj[DEDUP_UNROLL], rf[DEDUP_UNROLL];
         uint4 x[DEDUP_UNROLL], y[DEDUP_UNROLL];
         uint32_t i = 0;
 #pragma unroll
@@ -273,31 +308,43 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
                 todo &= todo - 1ull;
             }
             ii[u] = i;
-            const uint8_t* own = a.v.nodes + (((uint64_t)__builtin_amdgcn_readlane((uint32_t)(b >> 32), i) << 32) |
-                                              __builtin_amdgcn_readlane((uint32_t)b, i));
-            nb[u] = __builtin_amdgcn_readlane(nib, i);
-            cj[u] = __builtin_amdgcn_readlane(cand, i);
-            // no representative: compare the node with itself (L1 hits) and ignore the outcome
-            const uint8_t* oth = own;
-            if (cj[u] != (j - lane) + i)
-                oth = a.v.nodes + (((uint64_t)__builtin_amdgcn_readlane((uint32_t)(cb >> 32), i) << 32) |
-                                   __builtin_amdgcn_readlane((uint32_t)cb, i));
+            const uint64_t ob = lane_u64(b_lo, b_hi, i);
+            const uint32_t st = lane_u32(stamp, i);
+            nb[u] = (st & PRE_NIB) ? ((st >> 4) & 15u) : 0xffu;
+            dp[u] = st >> 8;
+            cj[u] = lane_u32(cand, i);
+            // no representative: compare the node with itself (cache hits) and ignore the outcome.  (Skipping
+            // that second load for the 45 % of nodes without one makes the trip's loads conditional and the
+            // kernel 22 % slower.)
+            uint64_t cbo = ob;
+            if (cj[u] != wbase + i)
+                cbo = lane_u64(cb_lo, cb_hi, i);
+            const uint8_t* own = a.v.nodes + ob;
+            const uint8_t* oth = a.v.nodes + cbo;
             x[u] = load16u(own + coff);
             y[u] = load16u(oth + coff);
             // slot nb's 32 hash bytes sit at [4 + 33 nb, 36 + 33 nb): lanes 0..7 fetch one dword each
-            rf[u] = load4u(own + 4u + 33u * (nb[u] & 15u) + 4u * (lane & 7u));
+            rf[u] = load4u(own + (4u + 33u * (nb[u] & 15u)) + 4u * (lane & 7u));
         }
 #pragma unroll
         for (int u = 0; u < DEDUP_UNROLL; ++u) {
-            const uint32_t jj = (j - lane) + ii[u];
+            const uint32_t jj = wbase + ii[u];
             uint32_t r_rep = jj, r_meta = 0;
-            const uint32_t bad = ((x[u].x ^ cv[0]) & cm[0]) | ((x[u].y ^ cv[1]) & cm[1]) |
-                                 ((x[u].z ^ cv[2]) & cm[2]) | ((x[u].w ^ cv[3]) & cm[3]);
+            // ((x ^ cv) & cm) for the four dwords, OR-ed
+            const uint32_t bad = __builtin_amdgcn_bitop3_b32(x[u].x, cv[0], cm[0], 0x28) |
+                                 __builtin_amdgcn_bitop3_b32(x[u].y, cv[1], cm[1], 0x28) |
+                                 __builtin_amdgcn_bitop3_b32(x[u].z, cv[2], cm[2], 0x28) |
+                                 __builtin_amdgcn_bitop3_b32(x[u].w, cv[3], cm[3], 0x28);
             if (__ballot(bad != 0) == 0ull && nb[u] < 16u) {
-                if (lane < 8u) a.ref[8ull * jj + lane] = rf[u];
-                r_meta = META_FAST | (nb[u] << 4) | (__builtin_amdgcn_readlane(dpos, ii[u]) << 8);
+                uint32_t* const rbase = a.ref + 8ull * jj;
+                if (lane < 8u) rbase[lane] = rf[u];
+                r_meta = META_FAST | (nb[u] << 4) | (dp[u] << 8);
             }
-            const uint32_t diff = (x[u].x ^ y[u].x) | (x[u].y ^ y[u].y) | (x[u].z ^ y[u].z) | (x[u].w ^ y[u].w);
+            // acc | (x ^ y), dword by dword
+            uint32_t diff = x[u].x ^ y[u].x;
+            diff = __builtin_amdgcn_bitop3_b32(x[u].y, y[u].y, diff, 0xBE);
+            diff = __builtin_amdgcn_bitop3_b32(x[u].z, y[u].z, diff, 0xBE);
+            diff = __builtin_amdgcn_bitop3_b32(x[u].w, y[u].w, diff, 0xBE);
             if (__ballot(diff != 0) == 0ull) r_rep = cj[u];  // cj == jj when there is no representative
             if (lane == ii[u]) {
                 my_rep = r_rep;
@@ -311,11 +358,9 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
     while (todo) {
         const uint32_t i = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
-        const uint32_t ll = __builtin_amdgcn_readlane(len, i);
-        const uint8_t* o = a.v.nodes + (((uint64_t)__builtin_amdgcn_readlane((uint32_t)(b >> 32), i) << 32) |
-                                        __builtin_amdgcn_readlane((uint32_t)b, i));
-        const uint8_t* c = a.v.nodes + (((uint64_t)__builtin_amdgcn_readlane((uint32_t)(cb >> 32), i) << 32) |
-                                        __builtin_amdgcn_readlane((uint32_t)cb, i));
+        const uint32_t ll = lane_u32(len, i);
+        const uint8_t* o = a.v.nodes + lane_u64(b_lo, b_hi, i);
+        const uint8_t* c = a.v.nodes + lane_u64(cb_lo, cb_hi, i);
         const bool eq = wave_bytes_equal(o, c, ll, lane);
         if (lane == i && eq) my_rep = cand;
     }
@@ -428,12 +473,16 @@ __global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
     auto window = [&](const uint8_t* p) -> const uint8_t* { return p < last_window ? p : last_window; };
 
     // ---- prologue: fill the pipeline ----
-    // chunk q belongs to wave (q mod W): a fixed round-robin deal.  (A shared queue balances no better
-    // here -- the long chunks come first and a wave rarely gets more than two of them -- and with a
-    // run-ahead of three chunks per wave it would hand ALL chunks to the first waves to arrive.)
+    // chunk q belongs to wave (q mod W): a fixed, even round-robin deal.  Measured alternatives, all
+    // slower on BASELINE config 3 (166 us): a shared queue with tickets drawn at prefetch depth (hands
+    // every chunk out in the first microsecond), a two-ended queue with tickets drawn during the last
+    // permutation (214 us: a slow wave that draws a long chunk late holds it after the fast ones ran
+    // dry), and a deal weighted by the oldest-first VALU arbitration measured in
+    // tools/ubench/hash_sched.hip (187 us: with real loads in the loop the oldest wave is latency-bound,
+    // not issue-bound).  DESIGN.md section 9.
     const uint32_t W = gridDim.x * 4u;
     uint32_t cls0, cls1, cls2, j0 = 0, j1 = 0, j2 = 0;
-    const uint32_t q0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t q1 = q0 + W;
     uint32_t q2 = q1 + W;
     {
@@ -520,10 +569,22 @@ __global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
 // the leaf.  Without PF every node costs two dependent trips to HBM, 16 in a row per proof.
 constexpr int WALK_PF = 8;
 
+// Nodes the generic decoder opens (for BASELINE's proofs: the 112-byte account leaf) are first copied
+// into a per-lane LDS slot with 16-byte loads, together with the key: the RLP decoder and the path
+// comparison read single bytes one after the other, and from HBM/L2 every one of those ~100 dependent
+// reads cost a full cache round trip (the per-CU L1 does not hold 256 lanes' nodes).
+constexpr uint32_t WALK_STAGE_BYTES = 192;  // nodes up to this size are staged; longer ones are read in place
+constexpr uint32_t WALK_KEY_BYTES = 32;
+constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  // odd stride: no bank pile-up
+
 template <bool PF>
 __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
+    __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= a.v.n) return;
+    uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
+    const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
+    const uint8_t* const nodes_end = a.v.nodes + a.v.nodes_len;
     uint64_t voff = 0;
     uint32_t vlen = 0, status;
     const uint32_t first = a.v.proof_first_node[i], last = a.v.proof_first_node[i + 1];
@@ -533,8 +594,18 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
     } else if (last == first) {
         status = PHANT_PROOF_INVALID_EMPTY;
     } else {
-        const uint8_t* key = a.v.keys + (uint64_t)a.v.key_len * i;
+        const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * i;
         const uint32_t nn = 2u * a.v.key_len;
+        // Two pointers, never merged into one variable: the compiler only emits ds_read for the LDS copies
+        // if each access site sees where its pointer comes from (a pointer that may be either turns every
+        // byte access into a flat load, which goes through the vector-memory path even when it hits LDS).
+        const uint8_t* const slot_key = reinterpret_cast<const uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+        const bool key_in_lds = a.v.key_len <= WALK_KEY_BYTES;  // the lane's own slot: no barrier needed
+        if (key_in_lds) {
+            uint8_t* kdst = reinterpret_cast<uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+            for (uint32_t t = 0; t < a.v.key_len; ++t) kdst[t] = key[t];
+        }
+        const uint8_t* staged_from = nullptr;  // global address of the node currently in the slot
         uint32_t want[8];
         {
             const uint8_t* rp = a.v.roots + 32ull * r;
@@ -584,7 +655,7 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
                     // same conditions, in the same order, as the generic loop below applies to a node
                     // reached through a 32-byte reference
                     if (!(m & META_FAST) || w.pos >= nn || (m >> 8) != w.pos ||
-                        ((m >> 4) & 0xfu) != key_nibble(key, w.pos)) {
+                        ((m >> 4) & 0xfu) != (key_in_lds ? key_nibble(slot_key, w.pos) : key_nibble(key, w.pos))) {
                         stop = true;  // not a fast step: the generic loop takes this node
                     } else if (rp[u] != jn[u] && (rp[u] >= a.total_nodes || rr[u] != rp[u])) {
                         status = STATUS_NEEDS_SLOW;
@@ -637,7 +708,8 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
                 const uint32_t m = a.meta[j];
                 // the captured ref is slot (m>>4)&15 of a validated full branch, captured at depth m>>8:
                 // usable iff the walk stands at that depth and the key's nibble there is that slot
-                if ((m & META_FAST) && (m >> 8) == w.pos && w.pos < nn && ((m >> 4) & 0xfu) == key_nibble(key, w.pos)) {
+                if ((m & META_FAST) && (m >> 8) == w.pos && w.pos < nn &&
+                    ((m >> 4) & 0xfu) == (key_in_lds ? key_nibble(slot_key, w.pos) : key_nibble(key, w.pos))) {
                     const uint4* rf = reinterpret_cast<const uint4*>(a.ref + 8ull * j);
                     const uint4 r0 = rf[0], r1 = rf[1];
                     want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
@@ -647,12 +719,38 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
                 }
             }
             if (fast) continue;
-            GlobalBytes nd{cur};
-            const uint32_t step = walk_node(nd, cur_len, key, nn, w);
+            if (by_hash) {
+                // a node reached through a hash and not settled from the tables: stage it (embedded
+                // children are decoded inside their parent's copy)
+                staged_from = nullptr;
+                const uint32_t padded = (cur_len + 15u) & ~15u;
+                if (cur_len <= WALK_STAGE_BYTES && cur + padded <= nodes_end) {
+                    for (uint32_t o = 0; o < padded; o += 16u) {
+                        const uint4 q = load16u(cur + o);
+                        slot[o / 4u] = q.x;
+                        slot[o / 4u + 1u] = q.y;
+                        slot[o / 4u + 2u] = q.z;
+                        slot[o / 4u + 3u] = q.w;
+                    }
+                    staged_from = cur;
+                }
+            }
+            // decode + one step of the walk, with the node and the key each read from where they are
+            auto step_from = [&](const uint8_t* nb, const uint8_t* kp) __attribute__((always_inline)) -> uint32_t {
+                GlobalBytes nd{nb};
+                const uint32_t st = walk_node(nd, cur_len, kp, nn, w);
+                if (st == STEP_HASH) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) want[k] = nd.u32(w.ref_pay + 4 * k);
+                }
+                return st;
+            };
+            uint32_t step;
+            if (!key_in_lds) step = step_from(cur, key);
+            else if (staged_from) step = step_from(slot_node + (cur - staged_from), slot_key);
+            else step = step_from(cur, slot_key);
             if (step == STEP_DONE) break;
             if (step == STEP_HASH) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) want[k] = nd.u32(w.ref_pay + 4 * k);
                 by_hash = true;
             } else {
                 cur = cur + w.ref_pay;
@@ -700,7 +798,7 @@ static uint32_t table_entries(uint32_t total_nodes) {
 size_t verify_flat_workspace_bytes(uint32_t total_nodes) {
     const size_t tn = total_nodes;
     return 256 /*cursors + late cursors*/ + rnd256((size_t)table_entries(total_nodes) * 8) + rnd256(tn * 4) * 2 /*rep, meta*/ +
-           rnd256(tn * 4 * N_CLASS) * 2 /*ent, late_ent*/ + rnd256(tn * 32) * 2 /*digest, ref*/ + 1024;
+           rnd256(tn * 4 * N_CLASS) * 2 /*ent, late_ent*/ + rnd256(tn * 32) * 2 /*digest, ref*/ + rnd256(tn * 8) /*gkey*/ + 1024;
 }
 
 // tuning knobs read from the environment at every launch (A/B sweeps on the GPU box inside one
@@ -724,6 +822,7 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
     a.v = v;
     a.total_nodes = total_nodes;
     a.dedup = dedup ? 1u : 0u;
+    a.cmp_prio = env_u32("PHANT_CMP_PRIO", 3u, 0u, 3u);
     const uint32_t te = table_entries(total_nodes);
     uint8_t* p = ws;
     a.cursors = reinterpret_cast<uint32_t*>(p);
@@ -731,14 +830,15 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
     p += 256;
     a.table = reinterpret_cast<uint64_t*>(p);      p += rnd256((size_t)te * 8);
     a.tmask = te - 1u;
+    a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);  // zeroed with the header
     a.rep = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4);
-    a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);
     a.ent = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4 * N_CLASS);
     a.late_ent = reinterpret_cast<uint32_t*>(p);   p += rnd256(tn * 4 * N_CLASS);
     a.digest = reinterpret_cast<uint32_t*>(p);     p += rnd256(tn * 32);
-    a.ref = reinterpret_cast<uint32_t*>(p);
-    // cursors and (when deduplicating) the table are contiguous: one memset
-    hipError_t e = hipMemsetAsync(ws, 0, dedup ? 256 + (size_t)te * 8 : 256, st);
+    a.ref = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 32);
+    a.gkey = reinterpret_cast<uint64_t*>(p);
+    // cursors, the table and the stamps are contiguous: one memset
+    hipError_t e = hipMemsetAsync(ws, 0, 256 + rnd256((size_t)te * 8) + tn * 4, st);
     if (e != hipSuccess) return e;
     const uint32_t pg = (v.n + 255u) / 256u;
     if (total_nodes) {
@@ -747,25 +847,29 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
         // pipeline takes 2 so that COMPARE waves (40 VGPRs) always find room on the same SIMDs.
         const uint32_t wps_serial = env_u32("PHANT_HASH_WPS", 3u, 1u, 3u);
         const uint32_t wps_overlap = env_u32("PHANT_HASH_WPS", 2u, 1u, 3u);
-        const uint32_t slots = (overlap ? wps_overlap : wps_serial) * compute_units();
+        const uint32_t wps = overlap ? wps_overlap : wps_serial;
+        const uint32_t slots = wps * compute_units();
         const uint32_t hg = ng + N_CLASS < slots ? ng + N_CLASS : slots;
+        auto launch_hash = [&](const FlatArgs& fa, hipStream_t s) {
+            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, s, fa);
+        };
         hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
         if (!overlap) {
             hipLaunchKernelGGL(dedup_kernel<DEDUP_SERIAL>, dim3(ng), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, st, a);
+            launch_hash(a, st);
         } else {
             // COMPARE is capped at (160 KiB / lds) workgroups per CU by an otherwise unused dynamic LDS
             // allocation, so it can never crowd the hash waves out of the wave slots
-            const uint32_t cmp_lds = env_u32("PHANT_CMP_LDS_KB", 60u, 0u, 63u) * 1024u;
+            const uint32_t cmp_lds = env_u32("PHANT_CMP_LDS_KB", 0u, 0u, 63u) * 1024u;
             hipLaunchKernelGGL(dedup_kernel<DEDUP_CLASSIFY>, dim3(ng), dim3(256), 0, st, a);
             if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
-            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, st, a);
+            launch_hash(a, st);
             hipLaunchKernelGGL(dedup_kernel<DEDUP_COMPARE>, dim3(ng), dim3(256), cmp_lds, side->stream, a);
             FlatArgs late = a;  // same kernel over the (normally empty) list of nodes that differed
             late.ent = a.late_ent;
             late.cursors = a.late_cursors;
-            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, side->stream, late);
+            launch_hash(late, side->stream);
             if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
         }

@@ -233,3 +233,24 @@ def test_config3_full_size_properties(M):
     # the value of proof i is the last 78 bytes of its leaf
     i = torch.nonzero(present)[:5, 0]
     assert torch.equal(vo[i], (i + 1) * 3836 - 78)
+
+
+def test_nodes_beyond_2gib_offsets(M):
+    """64-bit node offsets: the same proofs verified with their nodes parked behind 2.2 GiB of
+    filler (offsets with bit 31 set, and above 2^32 for the last ones)."""
+    import phant_amd
+    from phant_amd.mpt import ProofBatch
+    w = phant_amd.witness.account_witness(600, depth=8, seed=11, corrupt_frac=0.1)
+    b = w.batch
+    st0 = M.verify_batch_dev(b).clone()
+    assert torch.equal(st0, w.expected)
+    for pad in (2_362_232_013, 4_300_000_003):  # odd paddings: unaligned nodes
+        nodes = torch.zeros(pad + b.nodes.numel(), dtype=torch.uint8, device=b.nodes.device)
+        nodes[pad:] = b.nodes
+        shifted = ProofBatch(b.roots, b.root_idx, b.keys, nodes, b.node_off + pad, b.proof_first_node)
+        vo = torch.empty(b.n, dtype=torch.int64, device=nodes.device)
+        st = M.verify_batch_dev(shifted, value_off=vo)
+        assert torch.equal(st, w.expected)
+        present = st == M.PROOF_PRESENT
+        assert (vo[present] >= pad).all()
+        del nodes, shifted

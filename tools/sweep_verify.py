@@ -20,16 +20,11 @@ COMBOS = [
     ("flat", {"PHANT_WALK_PF": "0"}),
     ("flat", {"PHANT_HASH_WPS": "2"}),
     ("overlap", {}),
-    ("overlap", {"PHANT_WALK_PF": "0"}),
-    ("overlap", {"PHANT_CMP_LDS_KB": "0"}),
-    ("overlap", {"PHANT_CMP_LDS_KB": "40"}),
-    ("overlap", {"PHANT_CMP_LDS_KB": "0", "PHANT_HASH_WPS": "3"}),
-    ("overlap", {"PHANT_CMP_LDS_KB": "30"}),
+    ("overlap", {"PHANT_CMP_PRIO": "0"}),
     ("nodedup", {}),
-    ("nodedup", {"PHANT_HASH_WPS": "2"}),
     ("fused", {}),
 ]
-KNOBS = ("PHANT_WALK_PF", "PHANT_HASH_WPS", "PHANT_CMP_LDS_KB")
+KNOBS = ("PHANT_WALK_PF", "PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO")
 
 
 def main():
