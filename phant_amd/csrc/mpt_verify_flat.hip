@@ -1,40 +1,45 @@
 // mpt_verify_flat.hip -- batched proof verification, node-parallel pipeline with
-// in-batch node deduplication.
+// in-batch node deduplication.  Every shipped byte is read from HBM once.
 //
 // A witness ships every proof as its own node list, so the upper trie levels
-// arrive many times over (BASELINE config 3: 800 k shipped nodes, ~350 k
+// arrive many times over (BASELINE config 3: 800 k shipped nodes, ~354 k
 // distinct).  Keccak-f is integer-VALU-bound on gfx950 (DESIGN.md section 9:
-// v_alignbit is half rate), while COMPARING two nodes is a pure HBM stream.  So
-// every shipped byte is still read exactly once, coalesced, but only the first
-// copy of a node is hashed:
+// rotates are half rate), while COMPARING two nodes is a pure memory stream.
+// So only the first copy of a node is hashed, every other copy is compared
+// with it byte for byte:
 //
-//   plan_kernel     one lane per proof: stamps node -> proof, and for every
-//        multi-block node proposes itself as the representative of its
-//        (root, depth, key-prefix) group in a 2-choice table (plain 8-byte
-//        stores, last writer wins -- no atomics, correctness never depends on
-//        who wins).
-//   dedup_kernel    a wave reads one node at a time, 16 bytes per lane
-//        (coalesced): validates the canonical 532-byte full branch and captures
-//        the child reference for the proof's key nibble straight from the
-//        loaded bytes, then compares the node byte-for-byte with the group's
-//        representative.  Equal  => rep[j] = representative (no hashing);
-//        different / no representative => the node is hashed itself.  Nodes to
-//        hash are compacted per rate-block class with wave ballots + one
-//        block-level reservation per class (the variable-length nodes come out
-//        as dense per-class lists, so every hashing wave runs the same number
-//        of Keccak-f permutations).
-//   hash_list_kernel  one lane per listed node, sponge in registers.
-//   walk_proofs_kernel  one lane per proof links digest[rep[node]] -> expected
-//        reference -> next node (DESIGN.md section 3 order of checks); only
-//        nodes outside the full-branch fast path are re-opened and decoded.
+//   plan_kernel     one lane per proof: stamps every node with its depth in
+//        the proof, the key nibble at that depth and the 64-bit key of its
+//        (root, depth, key-prefix) group; every multi-block node proposes
+//        itself as the representative of its group in a 2-choice table (plain
+//        8-byte stores, last writer wins -- no atomics, correctness never
+//        depends on who wins).
+//   dedup_kernel    one lane per node looks its group up; a wave then reads the
+//        nodes that HAVE a representative, 16 bytes per lane (coalesced), next
+//        to the representative's bytes (L2 / Infinity-Cache hits).  Equal =>
+//        rep[j] = representative (no hashing); different, or no
+//        representative => the node is listed for hashing, compacted per
+//        rate-block class with wave ballots + one block-level reservation per
+//        class (so every hashing wave runs the same number of permutations).
+//        Nodes without a representative are not opened here at all.
+//   hash_list_kernel  one lane per listed node, sponge in registers; while a
+//        532-byte node streams through the lane's registers its form is
+//        checked against the canonical full branch (canon[]).
+//   link_kernel     one lane per node: does digest[rep[j]] equal the reference
+//        its parent (node j - 1 of the proof, a canonical full branch) holds
+//        for this key's nibble?  One status byte per node.
+//   walk_proofs_kernel  one lane per proof steps over the run of nodes
+//        link_kernel settled and decodes the rest (DESIGN.md section 3 order of
+//        checks) from an LDS copy -- for BASELINE's proofs just the leaf.
 //   fixup_kernel    proofs the walk could not settle from the tables (never
 //        in practice: a representative that is not self-represented) go
 //        through the one-lane-per-proof verifier.
 //
 // Soundness: rep[j] = r only if bytes(j) == bytes(r) (so keccak(j) ==
-// digest[r]) and the walk only trusts digest[r] when rep[r] == r (r was
-// hashed); a captured reference is only used by a proof whose key nibble at
-// that depth equals the nibble it was captured for.
+// digest[r]) and digest[r] is only trusted when rep[r] == r (r was hashed);
+// canon[r] is only set by the wave that hashed r; a stamp is only used by the
+// proof that wrote it (node ranges of proofs are disjoint when
+// proof_first_node is monotone -- otherwise the walk ignores stamps).
 //
 // What it computes: the verifier missing at
 // src/engine_api/execution_payload.zig:177-178, over the node encodings of
@@ -48,7 +53,6 @@ namespace phant {
 
 constexpr uint32_t N_CLASS = 8;        // class c = (c+1) rate blocks; last class = 8 or more
 constexpr uint32_t CLASS_NONE = 0xffu;
-constexpr uint32_t META_FAST = 1u;     // canonical full branch; ref[] holds slot (meta>>4)&15, depth meta>>8
 constexpr uint32_t DEDUP_MAX_DEPTH = 16;  // key prefix of <= 16 nibbles fits the 64-bit group key
 constexpr uint32_t STATUS_NEEDS_SLOW = 0xffu;
 constexpr uint32_t BRANCH_LEN = 532u;  // f9 02 11 | 16 x (a0 + 32 bytes) | 80
@@ -104,9 +108,10 @@ struct FlatArgs {
     uint32_t* rep;           // total_nodes
     uint32_t* meta;          // total_nodes
     uint32_t* ent;           // N_CLASS x total_nodes: node ids to hash, per rate-block class
-    uint32_t* cursors;       // N_CLASS class counts + [N_CLASS] = work-queue head of the hash kernel; zeroed per call
+    uint32_t* cursors;       // N_CLASS class counts, [CURSOR_PFN_BROKEN] flag; zeroed per call
     uint32_t* digest;        // total_nodes x 8
-    uint32_t* ref;           // total_nodes x 8
+    uint8_t* link;           // total_nodes (+ 16 readable): LINK_* code of link_kernel
+    uint8_t* canon;          // total_nodes: 1 = hashed AND a canonical full branch (written by the hash kernel; zeroed per call)
     // overlap mode only: nodes whose bytes turned out to differ from their group's representative
     uint64_t* gkey;          // total_nodes: group key of the node, where meta[] says PRE_GROUP
     uint32_t* late_ent;      // N_CLASS x total_nodes
@@ -130,13 +135,20 @@ constexpr uint32_t PRE_NIB = 2u, PRE_GROUP = 4u, PRE_STAMP = 8u;
 // depth, and the 64-bit key of its (root, depth, key prefix) group -- so that they never search for
 // the owning proof or touch the keys again.  Every multi-block node also proposes itself as the
 // representative of its group.  Plain stores: the last writer of a table slot wins.
+constexpr uint32_t CURSOR_PFN_BROKEN = 9;  // word of the zeroed header: some proof has last < first
 constexpr uint32_t PLAN_BATCH = 8;  // even: a batch starts on a key byte
 
 __global__ void __launch_bounds__(256) plan_kernel(const FlatArgs a) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= a.v.n) return;
     const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
-    if (last < first || last > a.total_nodes) return;  // BAD_INPUT: the walk reports it
+    if (last < first) {
+        // proof_first_node is not monotone: node ranges of OTHER proofs may then overlap, and a node stamped
+        // by one proof would be read by another.  Tell the walk not to trust anything derived from stamps.
+        a.cursors[CURSOR_PFN_BROKEN] = 1u;
+        return;  // BAD_INPUT: the walk reports it
+    }
+    if (last > a.total_nodes) return;  // BAD_INPUT: the walk reports it
     const uint32_t root = a.v.root_idx ? a.v.root_idx[p] : 0u;
     const uint8_t* key = a.v.keys + (uint64_t)a.v.key_len * p;
     const uint64_t kb = key_prefix64(key, a.v.key_len);
@@ -256,49 +268,25 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
         }
     }
 
-    uint32_t my_rep = j, my_meta = 0;
+    uint32_t my_rep = j;
     if constexpr (MODE == DEDUP_CLASSIFY) {
         // no bytes are read here: trust the table, COMPARE checks it
         my_rep = cand;
-        if (valid && len >= RATE) my_meta = stamp;  // keep the stamp for COMPARE
     } else {
     // ---- this lane's share of a 532-byte node: bytes [16 lane, 16 lane + 16) for lane < 33; the lanes
     // above all take the last 16 bytes [516, 532) (redundant cover: no lane is ever masked off, so
     // every load below is unconditional and the loads of several nodes overlap) ----
     const uint32_t coff = lane < 33u ? 16u * lane : BRANCH_LEN - 16u;
-    // what those 16 bytes must look like in the canonical full branch f9 02 11 | 16 x (a0 + hash) | 80:
-    // a 16-byte window holds at most one of the a0 markers at 3 + 33 k (k < 16), lane 0 also the list
-    // header, the last window the empty value
-    uint64_t m64[2] = {0, 0}, v64[2] = {0, 0};
-    {
-        const uint32_t k0 = coff <= 3u ? 0u : (coff + 29u) / 33u;  // first k with 3 + 33 k >= coff
-        const uint32_t q0 = 3u + 33u * k0;
-        if (k0 < 16u && q0 < coff + 16u) {
-            const uint32_t t = q0 - coff;
-            m64[t >> 3] |= 0xffull << (8u * (t & 7u));
-            v64[t >> 3] |= 0xa0ull << (8u * (t & 7u));
-        }
-        if (coff == 0u) {
-            m64[0] |= 0xffffffull;
-            v64[0] |= 0x1102f9ull;
-        }
-        if (coff == BRANCH_LEN - 16u) {
-            m64[1] |= 0xffull << 56;
-            v64[1] |= 0x80ull << 56;
-        }
-    }
-    const uint32_t cm[4] = {(uint32_t)m64[0], (uint32_t)(m64[0] >> 32), (uint32_t)m64[1], (uint32_t)(m64[1] >> 32)};
-    const uint32_t cv[4] = {(uint32_t)v64[0], (uint32_t)(v64[0] >> 32), (uint32_t)v64[1], (uint32_t)(v64[1] >> 32)};
-
     // everything that selects a node below is wave-uniform: say so, or the compiler predicates per lane
-    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(j - lane);
     const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32), cb_lo = (uint32_t)cb, cb_hi = (uint32_t)(cb >> 32);
 
-    // ---- 532-byte nodes: DEDUP_UNROLL nodes per trip, all their loads issued before any is used.
-    // A short last trip repeats its last node (idempotent) so that the body has no conditionals. ----
-    unsigned long long todo = __ballot(valid && len == BRANCH_LEN);
+    // ---- 532-byte nodes that have a representative: DEDUP_UNROLL nodes per trip, all their loads issued
+    // before any is used.  A short last trip repeats its last node (idempotent) so that the body has no
+    // conditionals.  Nodes WITHOUT a representative are not opened here at all: the hash kernel reads
+    // them (once), and checks their form while it has them in registers. ----
+    unsigned long long todo = __ballot(valid && len == BRANCH_LEN && cand != j);
     while (todo) {
-        uint32_t ii[DEDUP_UNROLL], nb[DEDUP_UNROLL], dp[DEDUP_UNROLL], cj[DEDUP_UNROLL], rf[DEDUP_UNROLL];
+        uint32_t ii[DEDUP_UNROLL], cj[DEDUP_UNROLL];
         uint4 x[DEDUP_UNROLL], y[DEDUP_UNROLL];
         uint32_t i = 0;
 #pragma unroll
@@ -308,48 +296,21 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
                 todo &= todo - 1ull;
             }
             ii[u] = i;
-            const uint64_t ob = lane_u64(b_lo, b_hi, i);
-            const uint32_t st = lane_u32(stamp, i);
-            nb[u] = (st & PRE_NIB) ? ((st >> 4) & 15u) : 0xffu;
-            dp[u] = st >> 8;
             cj[u] = lane_u32(cand, i);
-            // no representative: compare the node with itself (cache hits) and ignore the outcome.  (Skipping
-            // that second load for the 45 % of nodes without one makes the trip's loads conditional and the
-            // kernel 22 % slower.)
-            uint64_t cbo = ob;
-            if (cj[u] != wbase + i)
-                cbo = lane_u64(cb_lo, cb_hi, i);
-            const uint8_t* own = a.v.nodes + ob;
-            const uint8_t* oth = a.v.nodes + cbo;
+            const uint8_t* own = a.v.nodes + lane_u64(b_lo, b_hi, i);
+            const uint8_t* oth = a.v.nodes + lane_u64(cb_lo, cb_hi, i);
             x[u] = load16u(own + coff);
             y[u] = load16u(oth + coff);
-            // slot nb's 32 hash bytes sit at [4 + 33 nb, 36 + 33 nb): lanes 0..7 fetch one dword each
-            rf[u] = load4u(own + (4u + 33u * (nb[u] & 15u)) + 4u * (lane & 7u));
         }
 #pragma unroll
         for (int u = 0; u < DEDUP_UNROLL; ++u) {
-            const uint32_t jj = wbase + ii[u];
-            uint32_t r_rep = jj, r_meta = 0;
-            // ((x ^ cv) & cm) for the four dwords, OR-ed
-            const uint32_t bad = __builtin_amdgcn_bitop3_b32(x[u].x, cv[0], cm[0], 0x28) |
-                                 __builtin_amdgcn_bitop3_b32(x[u].y, cv[1], cm[1], 0x28) |
-                                 __builtin_amdgcn_bitop3_b32(x[u].z, cv[2], cm[2], 0x28) |
-                                 __builtin_amdgcn_bitop3_b32(x[u].w, cv[3], cm[3], 0x28);
-            if (__ballot(bad != 0) == 0ull && nb[u] < 16u) {
-                uint32_t* const rbase = a.ref + 8ull * jj;
-                if (lane < 8u) rbase[lane] = rf[u];
-                r_meta = META_FAST | (nb[u] << 4) | (dp[u] << 8);
-            }
             // acc | (x ^ y), dword by dword
             uint32_t diff = x[u].x ^ y[u].x;
             diff = __builtin_amdgcn_bitop3_b32(x[u].y, y[u].y, diff, 0xBE);
             diff = __builtin_amdgcn_bitop3_b32(x[u].z, y[u].z, diff, 0xBE);
             diff = __builtin_amdgcn_bitop3_b32(x[u].w, y[u].w, diff, 0xBE);
-            if (__ballot(diff != 0) == 0ull) r_rep = cj[u];  // cj == jj when there is no representative
-            if (lane == ii[u]) {
-                my_rep = r_rep;
-                my_meta = r_meta;
-            }
+            const bool same = __ballot(diff != 0) == 0ull;
+            if (same && lane == ii[u]) my_rep = cj[u];
         }
     }
 
@@ -375,10 +336,7 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
     uint32_t* const cursors = MODE == DEDUP_COMPARE ? a.late_cursors : a.cursors;
     uint32_t* const ent = MODE == DEDUP_COMPARE ? a.late_ent : a.ent;
     const uint32_t cls = valid ? node_class(len) : CLASS_NONE;
-    if (j < N) {
-        a.rep[j] = my_rep;
-        a.meta[j] = my_meta;
-    }
+    if (j < N) a.rep[j] = my_rep;  // meta[] keeps plan_kernel's stamp: depth and key nibble, for the walk
     uint32_t my_rank = 0;
 #pragma unroll
     for (uint32_t c = 0; c < N_CLASS; ++c) {
@@ -396,6 +354,53 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
         uint32_t at = s_base[cls] + my_rank;
         for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
         ent[(uint64_t)cls * N + at] = j;
+    }
+}
+
+// ---------------------------------------------------------------- canonical full branch, per rate block
+// f9 02 11 | 16 x (a0 + 32 bytes) | 80 = 532 bytes: what the marker bytes of rate block K (bytes
+// [136 K, 136 K + 136) of the node, as 34 little-endian dwords) must be.  The hash kernel holds exactly
+// these dwords in registers when it absorbs the block, so checking the form of a node there costs ~10
+// VALU operations per block and no memory traffic.
+struct BranchMask {
+    uint32_t m[4][RATE_DWORDS];
+    uint32_t v[4][RATE_DWORDS];
+};
+constexpr BranchMask make_branch_mask() {
+    BranchMask r{};
+    for (uint32_t q = 0; q < BRANCH_LEN; ++q) {
+        int want = -1;
+        if (q == 0) want = 0xf9;
+        else if (q == 1) want = 0x02;
+        else if (q == 2) want = 0x11;
+        else if (q == BRANCH_LEN - 1u) want = 0x80;
+        else if ((q - 3u) % 33u == 0u) want = 0xa0;
+        if (want >= 0) {
+            const uint32_t k = q / RATE, i = (q % RATE) / 4u, sh = 8u * (q % 4u);
+            r.m[k][i] |= 0xffu << sh;
+            r.v[k][i] |= (uint32_t)want << sh;
+        }
+    }
+    return r;
+}
+constexpr BranchMask BRANCH_MASK = make_branch_mask();
+
+template <int K>
+PHANT_DEV uint32_t branch_block_bad_k(const uint32_t (&d)[RATE_DWORDS]) {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int i = 0; i < (int)RATE_DWORDS; ++i) {
+        if (BRANCH_MASK.m[K][i] != 0u) bad |= (d[i] ^ BRANCH_MASK.v[K][i]) & BRANCH_MASK.m[K][i];
+    }
+    return bad;
+}
+// nonzero iff the dwords of rate block k (wave-uniform k < 4) contradict the canonical full branch
+PHANT_DEV uint32_t branch_block_bad(uint32_t k, const uint32_t (&d)[RATE_DWORDS]) {
+    switch (k) {
+        case 0: return branch_block_bad_k<0>(d);
+        case 1: return branch_block_bad_k<1>(d);
+        case 2: return branch_block_bad_k<2>(d);
+        default: return branch_block_bad_k<3>(d);
     }
 }
 
@@ -524,8 +529,12 @@ __global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
             sponge_zero(s);
             const uint8_t* p = ptr0;
             uint32_t left = len0;
+            // 4-block chunks are where the 532-byte full branches are: check their form on the way through
+            const bool check = cls0 == BRANCH_LEN / RATE;
+            uint32_t bad = len0 != BRANCH_LEN;
             // every node of class c has exactly c full rate blocks: wave-uniform trip count
             for (uint32_t k = 0; k < cls0; ++k) {
+                if (check) bad |= branch_block_bad(k, d);
                 xor_block(s, d);
                 p += RATE;
                 left -= RATE;
@@ -535,11 +544,14 @@ __global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
                 PIN_AFTER(s);
             }
             if (p <= last_window) {
+                if (check) bad |= branch_block_bad(cls0, d);
                 absorb_loaded_final(s, d, left);
             } else {  // the window was clamped (last node of the blob): re-read with the narrow loads
                 const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
                 absorb_final_block(s, reinterpret_cast<const uint32_t*>(p - sh), sh, left);
+                bad = 1u;  // not checked here: the walk decodes this one node the long way
             }
+            if (check && bad == 0u) a.canon[j0] = 1;
             if (cls1 != N_CLASS) load_block_wide(d, window(ptr1));  // block 0 of the next chunk's node
             PIN_LOADS_BEFORE(s);
             keccak_f1600(s);
@@ -561,14 +573,86 @@ __global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- walk
-// PF: the leading run of validated full branches of a proof is checked WALK_PF nodes at a time with
-// all table reads of those nodes in flight together (the expected reference of node k+1 is the
-// captured reference of node k, so nothing but the verdict is sequential); the generic loop below
-// then continues from the first node that is not on the fast path -- for BASELINE's depth-8 proofs
-// the leaf.  Without PF every node costs two dependent trips to HBM, 16 in a row per proof.
-constexpr int WALK_PF = 8;
+// ---------------------------------------------------------------- link
+// One lane per node: is this node the one its parent commits to?  The parent of node j inside a proof is
+// node j - 1; if that is a canonical full branch, the reference it holds for this proof's key nibble
+// sits at a fixed place in its bytes, and the digest of node j is digest[rep[j]].  Everything a lane
+// needs is indexed by j (coalesced) or one gather away, 800 k lanes hide the latency of those gathers, and
+// the per-proof walk -- 100 k lanes, each a chain of dependent reads -- is left with one byte per node:
+//   LINK_FAST     hash matches, node is a canonical full branch stamped with this key's nibble: step over
+//   LINK_HASH_OK  hash matches, node must be decoded (BASELINE: the account leaf)
+//   LINK_BAD_HASH / LINK_SLOW   settle the proof (DESIGN.md section 3 order: they come after BAD_INPUT)
+//   LINK_GENERIC  nothing established (parent not canonical, offsets bad, ...): the walk does it all
+// A code is only ever consulted by a walk that stepped over the parent with LINK_FAST.
+enum : uint32_t { LINK_GENERIC = 0, LINK_FAST = 1, LINK_HASH_OK = 2, LINK_BAD_HASH = 3, LINK_SLOW = 4 };
 
+// proof owning node j: pfn[p] <= j < pfn[p+1] (only root nodes of multi-root batches ask)
+PHANT_DEV uint32_t find_proof(const uint32_t* __restrict__ pfn, uint32_t n, uint32_t j) {
+    uint32_t lo = 0, hi = n;  // invariant (for monotone pfn): pfn[lo] <= j < pfn[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (pfn[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) link_kernel(const FlatArgs a) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= a.total_nodes) return;
+    uint32_t code = LINK_GENERIC;
+    const uint32_t m = a.meta[j];
+    const uint64_t b = a.v.node_off[j], e = a.v.node_off[j + 1];
+    const bool valid = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull;
+    if ((m & PRE_STAMP) && valid) {
+        const uint32_t d = m >> 8;
+        uint32_t want[8];
+        bool have = false;
+        if (d == 0u) {
+            uint32_t r = 0;
+            if (a.v.root_idx) {
+                const uint32_t p = find_proof(a.v.proof_first_node, a.v.n, j);
+                r = a.v.root_idx[p];
+            }
+            if (r < a.v.n_roots) {
+                GlobalBytes rb{a.v.roots + 32ull * r};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
+                have = true;
+            }
+        } else {
+            // node j - 1 is this proof's node at depth d - 1 (plan_kernel stamps a proof's nodes in order)
+            const uint32_t mp = a.meta[j - 1u];
+            const uint32_t rpp = a.rep[j - 1u];
+            if ((mp & PRE_NIB) && (mp >> 8) == d - 1u && rpp < a.total_nodes && a.canon[rpp]) {
+                const uint64_t bp = a.v.node_off[j - 1u];
+                if (bp <= a.v.nodes_len && a.v.nodes_len - bp >= BRANCH_LEN) {  // implied by canon[]; cheap
+                    const uint8_t* rb = a.v.nodes + bp + (4u + 33u * ((mp >> 4) & 15u));
+                    const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
+                    want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
+                    want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
+                    have = true;
+                }
+            }
+        }
+        if (have) {
+            const uint32_t rj = a.rep[j];
+            if (rj != j && (rj >= a.total_nodes || a.rep[rj] != rj)) {
+                code = LINK_SLOW;
+            } else {
+                const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
+                const uint4 d0 = dg[0], d1 = dg[1];
+                const uint32_t diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
+                                      (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
+                if (diff) code = LINK_BAD_HASH;
+                else code = ((m & PRE_NIB) && a.canon[rj]) ? LINK_FAST : LINK_HASH_OK;
+            }
+        }
+    }
+    a.link[j] = (uint8_t)code;
+}
+
+// ---------------------------------------------------------------- walk
 // Nodes the generic decoder opens (for BASELINE's proofs: the 112-byte account leaf) are first copied
 // into a per-lane LDS slot with 16-byte loads, together with the key: the RLP decoder and the path
 // comparison read single bytes one after the other, and from HBM/L2 every one of those ~100 dependent
@@ -577,7 +661,6 @@ constexpr uint32_t WALK_STAGE_BYTES = 192;  // nodes up to this size are staged;
 constexpr uint32_t WALK_KEY_BYTES = 32;
 constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  // odd stride: no bank pile-up
 
-template <bool PF>
 __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
     __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -605,77 +688,58 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
             uint8_t* kdst = reinterpret_cast<uint8_t*>(slot + WALK_STAGE_BYTES / 4);
             for (uint32_t t = 0; t < a.v.key_len; ++t) kdst[t] = key[t];
         }
-        const uint8_t* staged_from = nullptr;  // global address of the node currently in the slot
-        uint32_t want[8];
-        {
-            const uint8_t* rp = a.v.roots + 32ull * r;
-            GlobalBytes rb{rp};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
-        }
         WalkState w;
         w.pos = 0;
         w.status = PHANT_PROOF_BAD_INPUT;
         w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
         uint32_t used = first;
-        bool by_hash = true;
-        const uint8_t* cur = nullptr;
-        uint32_t cur_len = 0;
         status = 0xffffffffu;
-        if constexpr (PF) {
-            bool stop = false;
-            while (!stop && used < last) {
-                const uint32_t c = last - used < (uint32_t)WALK_PF ? last - used : (uint32_t)WALK_PF;
-                uint32_t jn[WALK_PF], rp[WALK_PF], mt[WALK_PF], rr[WALK_PF];
-                uint4 d0[WALK_PF], d1[WALK_PF], f0[WALK_PF], f1[WALK_PF];
+
+        // ---- the run of nodes link_kernel settled: one byte each, eight at a time ----
+        bool hash_known = false;  // the node at `used` is already known to hash to its reference
+        // (with a monotone proof_first_node the node ranges are disjoint, so every stamp a code was derived
+        // from is this proof's own)
+        for (bool run = a.cursors[CURSOR_PFN_BROKEN] == 0u; run && used < last;) {
+            const uint8_t* lp = a.link + used;  // link[] is padded: 8 bytes past the last node are readable
+            const uint32_t c0 = load4u(lp), c1 = load4u(lp + 4);
 #pragma unroll
-                for (int u = 0; u < WALK_PF; ++u) {  // a short run repeats its last node (cache hits)
-                    jn[u] = used + ((uint32_t)u < c ? (uint32_t)u : c - 1u);
-                    rp[u] = a.rep[jn[u]];
-                    mt[u] = a.meta[jn[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < WALK_PF; ++u) {
-                    rr[u] = 0;
-                    d0[u] = d1[u] = f0[u] = f1[u] = make_uint4(0, 0, 0, 0);
-                    if ((mt[u] & META_FAST) && rp[u] < a.total_nodes) {
-                        rr[u] = a.rep[rp[u]];
-                        const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rp[u]);
-                        d0[u] = dg[0];
-                        d1[u] = dg[1];
-                        const uint4* rf = reinterpret_cast<const uint4*>(a.ref + 8ull * jn[u]);
-                        f0[u] = rf[0];
-                        f1[u] = rf[1];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < WALK_PF; ++u) {
-                    if (stop || (uint32_t)u >= c) continue;
-                    const uint32_t m = mt[u];
-                    // same conditions, in the same order, as the generic loop below applies to a node
-                    // reached through a 32-byte reference
-                    if (!(m & META_FAST) || w.pos >= nn || (m >> 8) != w.pos ||
-                        ((m >> 4) & 0xfu) != (key_in_lds ? key_nibble(slot_key, w.pos) : key_nibble(key, w.pos))) {
-                        stop = true;  // not a fast step: the generic loop takes this node
-                    } else if (rp[u] != jn[u] && (rp[u] >= a.total_nodes || rr[u] != rp[u])) {
-                        status = STATUS_NEEDS_SLOW;
-                        stop = true;
-                    } else if ((d0[u].x ^ want[0]) | (d0[u].y ^ want[1]) | (d0[u].z ^ want[2]) | (d0[u].w ^ want[3]) |
-                               (d1[u].x ^ want[4]) | (d1[u].y ^ want[5]) | (d1[u].z ^ want[6]) | (d1[u].w ^ want[7])) {
-                        status = PHANT_PROOF_BAD_HASH;
-                        stop = true;
-                    } else {
-                        want[0] = f0[u].x; want[1] = f0[u].y; want[2] = f0[u].z; want[3] = f0[u].w;
-                        want[4] = f1[u].x; want[5] = f1[u].y; want[6] = f1[u].z; want[7] = f1[u].w;
-                        w.pos += 1;
-                        ++used;
-                    }
+            for (int u = 0; u < 8; ++u) {
+                if (!run || used >= last) continue;
+                const uint32_t c = ((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 0xffu;
+                if (c == LINK_FAST) {  // depth == pos and nibble == key nibble by construction of the stamp
+                    ++used;
+                    w.pos += 1;
+                } else {
+                    run = false;
+                    if (c == LINK_BAD_HASH) status = PHANT_PROOF_BAD_HASH;
+                    else if (c == LINK_SLOW) status = STATUS_NEEDS_SLOW;
+                    else hash_known = c == LINK_HASH_OK;
                 }
             }
         }
+
+        // ---- everything else: the reference the next node must hash to, then node by node ----
+        uint32_t want[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (status == 0xffffffffu && !hash_known) {
+            if (used == first) {
+                GlobalBytes rb{a.v.roots + 32ull * r};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
+            } else {
+                // stepped over node used - 1 (a canonical full branch): its slot for this key's nibble
+                const uint32_t mp = a.meta[used - 1u];
+                const uint8_t* rb = a.v.nodes + a.v.node_off[used - 1u] + (4u + 33u * ((mp >> 4) & 15u));
+                const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
+                want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
+                want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
+            }
+        }
+        bool by_hash = true;
+        const uint8_t* cur = nullptr;
+        uint32_t cur_len = 0;
+        const uint8_t* staged_from = nullptr;  // global address of the node currently in the slot
         for (;;) {
-            if (status != 0xffffffffu) break;  // settled on the prefetched fast path
-            bool fast = false;
+            if (status != 0xffffffffu) break;  // settled from the link codes
             if (by_hash) {
                 if (used == last) {
                     status = PHANT_PROOF_MISSING_NODE;
@@ -690,38 +754,27 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
                 cur = a.v.nodes + b;
                 cur_len = (uint32_t)(e - b);
                 ++used;
-                // digest of this node = digest of its representative (identical bytes), which must
-                // itself have been hashed
-                const uint32_t rj = a.rep[j];
-                if (rj != j && (rj >= a.total_nodes || a.rep[rj] != rj)) {
-                    status = STATUS_NEEDS_SLOW;
-                    break;
+                if (hash_known) {
+                    hash_known = false;  // link_kernel compared digest[rep[j]] with the parent's reference
+                } else {
+                    // digest of this node = digest of its representative (identical bytes), which must
+                    // itself have been hashed
+                    const uint32_t rj = a.rep[j];
+                    if (rj != j && (rj >= a.total_nodes || a.rep[rj] != rj)) {
+                        status = STATUS_NEEDS_SLOW;
+                        break;
+                    }
+                    const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
+                    const uint4 d0 = dg[0], d1 = dg[1];
+                    const uint32_t diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
+                                          (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
+                    if (diff) {
+                        status = PHANT_PROOF_BAD_HASH;
+                        break;
+                    }
                 }
-                const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
-                const uint4 d0 = dg[0], d1 = dg[1];
-                const uint32_t diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
-                                      (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
-                if (diff) {
-                    status = PHANT_PROOF_BAD_HASH;
-                    break;
-                }
-                const uint32_t m = a.meta[j];
-                // the captured ref is slot (m>>4)&15 of a validated full branch, captured at depth m>>8:
-                // usable iff the walk stands at that depth and the key's nibble there is that slot
-                if ((m & META_FAST) && (m >> 8) == w.pos && w.pos < nn &&
-                    ((m >> 4) & 0xfu) == (key_in_lds ? key_nibble(slot_key, w.pos) : key_nibble(key, w.pos))) {
-                    const uint4* rf = reinterpret_cast<const uint4*>(a.ref + 8ull * j);
-                    const uint4 r0 = rf[0], r1 = rf[1];
-                    want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
-                    want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
-                    w.pos += 1;
-                    fast = true;
-                }
-            }
-            if (fast) continue;
-            if (by_hash) {
-                // a node reached through a hash and not settled from the tables: stage it (embedded
-                // children are decoded inside their parent's copy)
+                // a node reached through a hash: stage it (embedded children are decoded inside their
+                // parent's copy)
                 staged_from = nullptr;
                 const uint32_t padded = (cur_len + 15u) & ~15u;
                 if (cur_len <= WALK_STAGE_BYTES && cur + padded <= nodes_end) {
@@ -798,7 +851,7 @@ static uint32_t table_entries(uint32_t total_nodes) {
 size_t verify_flat_workspace_bytes(uint32_t total_nodes) {
     const size_t tn = total_nodes;
     return 256 /*cursors + late cursors*/ + rnd256((size_t)table_entries(total_nodes) * 8) + rnd256(tn * 4) * 2 /*rep, meta*/ +
-           rnd256(tn * 4 * N_CLASS) * 2 /*ent, late_ent*/ + rnd256(tn * 32) * 2 /*digest, ref*/ + rnd256(tn * 8) /*gkey*/ + 1024;
+           rnd256(tn * 4 * N_CLASS) * 2 /*ent, late_ent*/ + rnd256(tn * 32) /*digest*/ + rnd256(tn * 8) /*gkey*/ + rnd256(tn) /*canon*/ + rnd256(tn + 16) /*link*/ + 1024;
 }
 
 // tuning knobs read from the environment at every launch (A/B sweeps on the GPU box inside one
@@ -831,20 +884,23 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
     a.table = reinterpret_cast<uint64_t*>(p);      p += rnd256((size_t)te * 8);
     a.tmask = te - 1u;
     a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);  // zeroed with the header
+    a.canon = p;                                   p += rnd256(tn);      // zeroed with the header
     a.rep = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4);
     a.ent = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4 * N_CLASS);
     a.late_ent = reinterpret_cast<uint32_t*>(p);   p += rnd256(tn * 4 * N_CLASS);
     a.digest = reinterpret_cast<uint32_t*>(p);     p += rnd256(tn * 32);
-    a.ref = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 32);
-    a.gkey = reinterpret_cast<uint64_t*>(p);
-    // cursors, the table and the stamps are contiguous: one memset
-    hipError_t e = hipMemsetAsync(ws, 0, 256 + rnd256((size_t)te * 8) + tn * 4, st);
+    a.gkey = reinterpret_cast<uint64_t*>(p);       p += rnd256(tn * 8);
+    a.link = p;
+    // cursors, the table, the stamps and the canonical-form flags are contiguous: one memset
+    hipError_t e = hipMemsetAsync(ws, 0, 256 + rnd256((size_t)te * 8) + rnd256(tn * 4) + tn, st);
     if (e != hipSuccess) return e;
     const uint32_t pg = (v.n + 255u) / 256u;
     if (total_nodes) {
         const uint32_t ng = (total_nodes + 255u) / 256u;
-        // persistent hash grid: `wps` workgroups per CU = waves per SIMD.  ~155 VGPRs admit 3; the overlap
-        // pipeline takes 2 so that COMPARE waves (40 VGPRs) always find room on the same SIMDs.
+        // persistent hash grid: `wps` workgroups per CU = waves per SIMD; ~155 VGPRs admit 3.  (VALU issue is
+        // arbitrated oldest-first, so the third wave only adds ~12 % -- tools/ubench/hash_sched.hip -- but on
+        // BASELINE config 3 it is still worth 3 %: 0.289 ms against 0.298 ms for the pipeline.)  The overlap
+        // pipeline takes 2 so that COMPARE waves find room on the same SIMDs.
         const uint32_t wps_serial = env_u32("PHANT_HASH_WPS", 3u, 1u, 3u);
         const uint32_t wps_overlap = env_u32("PHANT_HASH_WPS", 2u, 1u, 3u);
         const uint32_t wps = overlap ? wps_overlap : wps_serial;
@@ -874,9 +930,8 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
             if ((e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
         }
     }
-    const uint32_t walk_pf = env_u32("PHANT_WALK_PF", 1u, 0u, 1u);
-    if (walk_pf) hipLaunchKernelGGL(walk_proofs_kernel<true>, dim3(pg), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(walk_proofs_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+    if (total_nodes) hipLaunchKernelGGL(link_kernel, dim3((total_nodes + 255u) / 256u), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(walk_proofs_kernel, dim3(pg), dim3(256), 0, st, a);
     if (dedup) {
         e = launch_mpt_verify_fixup(v, st);
         if (e != hipSuccess) return e;

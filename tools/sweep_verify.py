@@ -16,12 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 COMBOS = [
-    ("flat", {}),
-    ("flat", {"PHANT_WALK_PF": "0"}),
     ("flat", {"PHANT_HASH_WPS": "2"}),
+    ("flat", {"PHANT_HASH_WPS": "3"}),
+    ("flat", {"PHANT_HASH_WPS": "2"}),
+    ("flat", {"PHANT_HASH_WPS": "3"}),
+    ("flat", {"PHANT_HASH_WPS": "2"}),
+    ("flat", {"PHANT_HASH_WPS": "3"}),
     ("overlap", {}),
-    ("overlap", {"PHANT_CMP_PRIO": "0"}),
-    ("nodedup", {}),
+    ("overlap", {"PHANT_HASH_WPS": "3"}),
+    ("nodedup", {"PHANT_HASH_WPS": "2"}),
+    ("nodedup", {"PHANT_HASH_WPS": "3"}),
     ("fused", {}),
 ]
 KNOBS = ("PHANT_WALK_PF", "PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO")
