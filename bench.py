@@ -36,6 +36,24 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(mode, proofs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    their own runs and corrected as tools/pmc_traffic.py documents), or None.  The counters cannot be read
+    from inside this process; the newest profiles/*/pmc_traffic.json measured on this pipeline is quoted."""
+    import glob
+    if proofs != 100_000:
+        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if mode in t:
+            return {"bytes": t[mode]["total"], "read": t[mode]["read"], "write": t[mode]["write"],
+                    "source": os.path.relpath(f, ROOT)}
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,9 +98,45 @@ def cpu_baseline_config3(w, target_seconds):
     cnt = int(max(probe, min(n, rate * target_seconds)))
     st, dt = run(cnt)
     ok = bool((st == w.expected[:cnt].cpu().numpy()).all())
-    return {"value": cnt / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": f"first {cnt} of the {n} config-3 proofs, oracle/verify.c single-threaded, {dt:.1f} s",
-            "host_cpus": os.cpu_count(), "statuses_match_gpu_expected": ok}
+    out = {"value": cnt / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+           "sample": f"first {cnt} of the {n} config-3 proofs, oracle/verify.c single-threaded, {dt:.1f} s",
+           "host_cpus": os.cpu_count(), "statuses_match_gpu_expected": ok}
+    # the same scalar code on all host cores, one slice of proofs per thread (ctypes releases the GIL);
+    # phant itself is single-threaded, so this is the generous reading of "the CPU path"
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        threads = max(1, min(os.cpu_count() or 1, 128))
+        npp = w.nodes_per_proof
+        nodes_h = b.nodes.cpu().numpy()
+        off_h = b.node_off.cpu().numpy().astype(np.uint64)
+        pfn_h = b.proof_first_node.cpu().numpy().astype(np.uint32)
+        keys_h = b.keys.cpu().numpy()
+        roots_h = b.roots.cpu().numpy()
+        bounds = [n * t // threads for t in range(threads + 1)]
+        budget = max(2.0, target_seconds / 2.0)  # wall seconds, whatever the host's scaling turns out to be
+
+        def work(t):
+            lo, hi = bounds[t], bounds[t + 1]
+            if hi <= lo:
+                return 0
+            off_t = off_h[lo * npp: hi * npp + 1]
+            pfn_t = pfn_h[lo: hi + 1] - pfn_h[lo]
+            done = 0
+            while time.perf_counter() < deadline:
+                O.mpt_verify_batch(roots_h, None, keys_h[lo:hi], 32, nodes_h, off_t, pfn_t)
+                done += hi - lo
+            return done
+
+        with ThreadPoolExecutor(threads) as ex:
+            t0 = time.perf_counter()
+            deadline = t0 + budget
+            done = sum(ex.map(work, range(threads)))
+            dta = time.perf_counter() - t0
+        out["all_cores"] = {"value": done / dta, "unit": "proofs/s", "cores": threads,
+                            "sample": f"{done} proofs (slices of the {n}, repeated), {threads} threads, {dta:.1f} s"}
+    except Exception as exc:  # the 1-core figure above is the baseline; this one is a courtesy
+        out["all_cores"] = {"error": repr(exc)}
+    return out
 
 
 def cpu_baseline_config2(blob, n, target_seconds):
@@ -209,9 +263,16 @@ def main():
     if args.workload == "config3" and args.verify_mode != "fused":
         hashed = ctx.verify_stats()
         shipped = int(b.node_off.numel() - 1)
-        extra = {"nodes_shipped": shipped, "nodes_hashed": int(sum(hashed)),
-                 "keccak_f_run": int(sum((c + 1) * h for c, h in enumerate(hashed))),
-                 "keccak_f_if_every_node_hashed": int(w.perms_per_proof * n_units)}
+        kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
+        # the second roofline of this path: Keccak-f is integer-VALU-bound.  Peak = what the product's round
+        # function sustains with nothing but permutations on the chip (tools/ubench/keccak_rate.hip,
+        # profiles/r1i/keccak_rate_ubench.txt: 10.3 G perm/s at 6 waves/SIMD, 9.7 G at the 3 this kernel fits)
+        extra = {"nodes_shipped": shipped, "nodes_hashed": int(sum(hashed)), "keccak_f_run": kf,
+                 "keccak_f_if_every_node_hashed": int(w.perms_per_proof * n_units),
+                 "valu": {"bound": "valu", "achieved": kf / (k_avg_ms * 1e-3) / 1e9, "peak": 10.3,
+                          "unit": "G Keccak-f/s", "frac": kf / (k_avg_ms * 1e-3) / 1e9 / 10.3,
+                          "note": "permutations actually run / whole-pipeline time; the hash kernel alone "
+                                  "runs them in ~55 % of that time"}}
 
     value = n_units * world * args.steps / elapsed
     line = {
@@ -221,11 +282,16 @@ def main():
         "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}",
                    "verify_mode": args.verify_mode if args.workload == "config3" else None},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (tr["bytes"] if (tr := (pmc_traffic(args.verify_mode, args.proofs)
+                                                        if args.workload == "config3" else None)) else None),
+                     "traffic_detail": tr,
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
                                 "mpt_verify_fused_kernel" if args.verify_mode == "fused" else
-                                "verify pipeline = plan_kernel + dedup_kernel + hash_list_kernel + "
-                                "walk_proofs_kernel + mpt_verify_fixup_kernel (sum of the launch)"),
+                                "verify pipeline = plan_kernel + dedup_kernel + hash_list_kernel + link_kernel + "
+                                "walk_proofs_kernel + mpt_verify_fixup_kernel (one launch of the path, first "
+                                "kernel start to last kernel end; hash_list_kernel is ~55 % of it and is "
+                                "integer-VALU-bound, see roofline.valu)"),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

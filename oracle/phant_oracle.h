@@ -98,6 +98,7 @@ enum {
     ORACLE_PROOF_BAD_NODE = 18,     /* well-formed RLP, not a valid MPT node */
     ORACLE_PROOF_EXTRA_NODES = 19,  /* walk ended with nodes left over */
     ORACLE_PROOF_MISSING_NODE = 20, /* walk needs a node the proof lacks */
+    ORACLE_PROOF_BAD_INPUT = 21,    /* proof_first_node goes backwards (batch form only) */
 };
 
 /* Verify one proof.  value_off is relative to `nodes`. */

@@ -255,6 +255,14 @@ void oracle_mpt_verify_batch(const uint8_t *roots, const uint32_t *root_idx, con
         const uint8_t *root = roots + 32 * (size_t)(root_idx ? root_idx[i] : 0);
         uint64_t vo = 0;
         uint32_t vl = 0;
+        if (l < f) { /* inconsistent proof_first_node -> BAD_INPUT */
+            status[i] = ORACLE_PROOF_BAD_INPUT;
+            if (value_off)
+                value_off[i] = 0;
+            if (value_len)
+                value_len[i] = 0;
+            continue;
+        }
         /* node_off is global; oracle_mpt_verify indexes node_off[0..] relative
          * to `nodes`, so pass the sub-array and keep offsets absolute */
         status[i] = oracle_mpt_verify(root, keys + (size_t)key_len * i, key_len, nodes,

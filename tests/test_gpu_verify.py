@@ -254,3 +254,25 @@ def test_nodes_beyond_2gib_offsets(M):
         present = st == M.PROOF_PRESENT
         assert (vo[present] >= pad).all()
         del nodes, shifted
+
+
+def test_non_monotone_proof_first_node_matches_oracle(M, oracle):
+    """proof_first_node that goes backwards: one proof is BAD_INPUT and the node ranges of its
+    neighbours overlap, so nodes are shared between proofs with different keys.  Whatever the oracle
+    says for each proof on its own, the GPU says."""
+    import phant_amd
+    w = phant_amd.witness.account_witness(64, depth=8, seed=21, corrupt_frac=0.0)
+    b = w.batch
+    roots = b.roots.cpu().numpy()
+    keys = b.keys.cpu().numpy()
+    nodes = b.nodes.cpu().numpy()
+    node_off = b.node_off.cpu().numpy().astype(np.uint64)
+    pfn = b.proof_first_node.cpu().numpy().astype(np.uint32).copy()
+    pfn[2] = 4        # proof 1 = [8, 4): BAD_INPUT; proof 2 = [4, 24) overlaps proof 0's nodes 4..7
+    pfn[10] = 72      # proof 9 = [72, 72): empty; proof 10 starts inside proof 8... = [72, 88)
+    pfn[40] = 300     # proof 39 = [312, 300): BAD_INPUT; proof 40 = [300, 328) overlaps 37..38
+    got = M.verify_batch(roots, None, keys, 32, nodes, node_off, pfn)
+    want = oracle.mpt_verify_batch(roots, None, keys, 32, nodes, node_off, pfn)
+    assert np.array_equal(got[0], want[0]), (got[0].tolist(), want[0].tolist())
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    assert got[0][0] == M.PROOF_PRESENT and got[0][1] == M.PROOF_BAD_INPUT

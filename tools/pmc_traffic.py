@@ -41,7 +41,7 @@ nd_f = mean_by_kernel(os.path.join(d, "nodedup_FETCH_SIZE.csv"))
 # nodedup: 100000 proofs x (7 x 532 + 112) node bytes, + 8-byte offsets (2 per node) + 4-byte list entry,
 # + the 136-byte window of the last rate block reaching past the node (12 B per branch, 24 B per leaf)
 n = 100000
-known_hash = n * 3836 + 800000 * (16 + 4) + 700000 * 12 + 100000 * 24
+known_hash = n * 3836 + 800000 * (16 + 4) + 700000 * 12 + 100000 * 24 + 700000 * 1
 f_hash = known_hash / nd_f["phant::hash_list_kernel"]
 
 out = {"unit": "bytes per launch (100000 depth-8 proofs)", "factors": {
