@@ -11,6 +11,9 @@ resident in HBM:
       proof shipped as its own node list, 0.5 % corrupted + 0.5 % exclusion
       proofs), reduce to one pass/fail word per root.
   config2: Keccak-256 of 1 048 576 x 136-byte messages (sponge kernel only).
+  config5: consecutive block witnesses streamed from pinned host memory through
+      phant_mpt_verify_submit / phant_wait (copy-in of witness k+1 overlaps the kernels of witness k);
+      a step = one witness of --stream-proofs depth-8 proofs; PCIe-bound by construction.
 
 N > 1: one process per GPU (torchrun), proofs sharded by the top key nibble,
 every rank verifies its own P proofs (weak scaling); the only data-path
@@ -61,7 +64,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"])
+    ap.add_argument("--stream-proofs", type=int, default=20_000, help="proofs per streamed witness (config5)")
+    ap.add_argument("--stream-slots", type=int, default=3, help="witnesses in flight (config5)")
     ap.add_argument("--verify-mode", default="flat", choices=["flat", "overlap", "nodedup", "fused"],
                     help="flat = node-parallel pipeline with in-batch node dedup (default); overlap = the same with "
                          "the byte comparison on a helper stream next to the hashing; nodedup = same pipeline "
@@ -208,6 +213,35 @@ def main():
         workload = (f"config3: {args.proofs} synthetic depth-{args.depth} account proofs per GPU against one state "
                     f"root ({w.nodes_per_proof - 1} x 532 B full branches + 112 B leaf, {w.bytes_per_proof} B and "
                     f"{w.perms_per_proof} Keccak-f per proof, 1% corrupted/exclusion, no cross-proof dedup)")
+    elif args.workload == "config5":
+        # 4 distinct witnesses in pinned host memory, submitted round-robin; results land in pinned buffers
+        from phant_amd import mpt as MM
+        wl = [phant_amd.witness.account_witness(args.stream_proofs, depth=args.depth, seed=40 + k, device=dev,
+                                                rank=rank, world=world, ctx=ctx) for k in range(4)]
+        hosts = [MM.to_host(x.batch) for x in wl]
+        w = wl[0]
+        b = w.batch
+        n_units = args.stream_proofs
+        alg_bytes = wl[0].batch.algorithmic_bytes()
+        slots = max(1, min(args.stream_slots, 4))
+        state = {"k": 0, "pending": []}
+
+        def step():
+            k = state["k"]
+            if len(state["pending"]) == slots:
+                MM.wait(state["pending"].pop(0), ctx)
+            MM.verify_submit(hosts[k % 4], k % slots, ctx)
+            state["pending"].append(k % slots)
+            state["k"] = k + 1
+
+        def drain():
+            while state["pending"]:
+                MM.wait(state["pending"].pop(0), ctx)
+
+        kernel_only = None
+        metric, unit = "mpt_proofs_verified_per_sec_depth%d_streamed" % args.depth, "proofs/s"
+        workload = (f"config5: consecutive witnesses of {args.stream_proofs} depth-{args.depth} proofs streamed from "
+                    f"pinned host memory, {slots} in flight per GPU (H2D {hosts[0].h2d_bytes()} B per witness)")
     else:
         n_units = 1 << 20
         g = torch.Generator(device=dev)
@@ -228,12 +262,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    streamed = args.workload == "config5"
     for _ in range(args.warmup):
         step()
+    if streamed:
+        drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if streamed:
+        drain()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -249,6 +288,16 @@ def main():
             dist.all_reduce(exp_fail)
         assert int(fails.item()) == int(exp_fail.item()), (int(fails.item()), int(exp_fail.item()))
 
+    if streamed:
+        for x, h in zip(wl, hosts):
+            assert torch.equal(h.status, x.expected.cpu()), "streamed statuses differ from the expectation"
+        # the kernels of one witness, device-resident, for the roofline object (the streamed rate itself is
+        # bounded by PCIe: see the pcie object)
+        dstatus = torch.empty(n_units, dtype=torch.uint8, device=dev)
+
+        def kernel_only():
+            M.verify_batch_dev(wl[0].batch, status=dstatus, ctx=ctx)
+
     # device time of one launch of the path (all kernels of the verify pipeline / the sponge kernel),
     # HIP events on the launch stream (phant_timing)
     ctx.timing(True)
@@ -260,7 +309,7 @@ def main():
     k_avg_ms = sum(kms) / len(kms)
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
     extra = {}
-    if args.workload == "config3" and args.verify_mode != "fused":
+    if args.workload in ("config3", "config5") and args.verify_mode != "fused":
         hashed = ctx.verify_stats()
         shipped = int(b.node_off.numel() - 1)
         kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
@@ -294,8 +343,14 @@ def main():
                                 "integer-VALU-bound, see roofline.valu)"),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
+    if streamed:
+        h2d = hosts[0].h2d_bytes() * world * args.steps / elapsed / 1e9
+        line["pcie"] = {"h2d_GBps_all_gpus": h2d, "h2d_GBps_per_gpu": h2d / world, "peak_per_gpu": 63.0,
+                        "frac": h2d / world / 63.0, "slots": slots,
+                        "note": "PCIe Gen5 x16 spec; the streamed rate is H2D-bound, the kernels of one witness "
+                                "take roofline.kernel_avg_ms"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.workload == "config3":
+        if args.workload in ("config3", "config5"):
             line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds)
         else:
             line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)

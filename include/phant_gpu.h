@@ -156,6 +156,25 @@ PHANT_API int32_t phant_mpt_verdict_dev(phant_ctx *ctx, const uint8_t *d_status,
                                         const uint32_t *d_root_idx, uint32_t n, uint32_t n_roots,
                                         uint32_t *d_fail_count);
 
+/* ------------------------------------------------------------------ streaming
+ * BASELINE config 5 (consecutive block witnesses, H2D overlapped with verification): up to
+ * PHANT_MAX_SLOTS host-form verifications in flight on one ctx, each on its own stream with its own
+ * staging and workspace.  phant_mpt_verify_submit queues copy-in, kernels and copy-out and returns;
+ * every buffer of the call (inputs AND status / value outputs) stays borrowed until phant_wait(slot)
+ * returns.  Copies only overlap with other slots' kernels when the buffers are pinned: allocate them with
+ * phant_host_alloc (hipHostMalloc) or register them; pageable memory works but serialises.
+ * The async pair SURVEY.md section 8(b) lists for this path. */
+#define PHANT_MAX_SLOTS 4
+PHANT_API int32_t phant_host_alloc(phant_ctx *ctx, size_t bytes, void **out);
+PHANT_API int32_t phant_host_free(phant_ctx *ctx, void *p);
+PHANT_API int32_t phant_mpt_verify_submit(phant_ctx *ctx, uint32_t slot, const uint8_t *roots,
+                                          uint32_t n_roots, const uint32_t *root_idx,
+                                          const uint8_t *keys, uint32_t key_len, const uint8_t *nodes,
+                                          uint64_t nodes_len, const uint64_t *node_off,
+                                          const uint32_t *proof_first_node, uint32_t n,
+                                          uint8_t *status, uint64_t *value_off, uint32_t *value_len);
+PHANT_API int32_t phant_wait(phant_ctx *ctx, uint32_t slot);
+
 /* ---------------------------------------------------------------- trie root
  * Replaces src/mpt/mpt.zig:38 `mptize(arena, list: []const KeyVal) !Hash32`
  * (KeyVal = mpt.zig:13-34: key bytes expanded to nibbles, value borrowed).

@@ -29,6 +29,12 @@ struct phant_ctx {
     phant::FlatMode flat_mode = phant::FLAT_SERIAL;
     // helper stream of the overlap pipeline (created on first use)
     phant::FlatSide side{nullptr, nullptr, nullptr};
+    // streaming slots (phant_mpt_verify_submit / phant_wait): own stream, staging and workspace each
+    struct Slot {
+        hipStream_t stream = nullptr;
+        phant::DevArena io, dv;
+        bool busy = false;
+    } slots[PHANT_MAX_SLOTS];
     // stream-side timing of the last device-form call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -168,6 +174,14 @@ void phant_ctx_destroy(phant_ctx* c) {
     c->dv.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto& sl : c->slots) {
+        if (sl.stream) {
+            (void)hipStreamSynchronize(sl.stream);
+            (void)hipStreamDestroy(sl.stream);
+        }
+        sl.io.release();
+        sl.dv.release();
+    }
     if (c->side.stream) (void)hipStreamSynchronize(c->side.stream);
     if (c->side.fork) (void)hipEventDestroy(c->side.fork);
     if (c->side.join) (void)hipEventDestroy(c->side.join);
@@ -301,26 +315,85 @@ int32_t phant_keccak256_with_prefix(phant_ctx* c, const uint8_t* prefix, uint64_
 
 /* ------------------------------------------------------- proof verification */
 
-// Runs the verify pipeline on device-resident arguments (shared by both forms).
-static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes) {
+// Runs the verify pipeline on device-resident arguments (shared by all forms) on stream `st` with the
+// workspace arena `dv`; `side` = helper stream of the overlap pipeline or nullptr (then it runs serially).
+static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes, hipStream_t st,
+                                  phant::DevArena& dv, const phant::FlatSide* side, bool timed) {
     if (c->verify_fused) {
-        TimedRegion t(c);
-        HIP_TRY(c, phant::launch_mpt_verify_fused(a, c->stream));
+        if (timed) {
+            TimedRegion t(c);
+            HIP_TRY(c, phant::launch_mpt_verify_fused(a, st));
+        } else {
+            HIP_TRY(c, phant::launch_mpt_verify_fused(a, st));
+        }
         return PHANT_OK;
     }
     const size_t need = phant::verify_flat_workspace_bytes(total_nodes);
-    if (need > c->dv.cap) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        hipError_t e = c->dv.reset(need);
+    if (need > dv.cap) {
+        HIP_TRY(c, hipStreamSynchronize(st));
+        hipError_t e = dv.reset(need);
         if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(verify workspace)", e);
     }
-    if (c->flat_mode == phant::FLAT_OVERLAP && !c->side.stream) {
+    if (timed) {
+        TimedRegion t(c);
+        HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, dv.base, c->flat_mode, st, side));
+    } else {
+        HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, dv.base, c->flat_mode, st, side));
+    }
+    return PHANT_OK;
+}
+
+static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes) {
+    if (!c->verify_fused && c->flat_mode == phant::FLAT_OVERLAP && !c->side.stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
     }
-    TimedRegion t(c);
-    HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, c->dv.base, c->flat_mode, c->stream, &c->side));
+    return verify_resident_on(c, a, total_nodes, c->stream, c->dv, &c->side, true);
+}
+
+// Stage a host witness into `io` on stream `s`, run the pipeline there and queue the copies of the results
+// back into the caller's buffers.  Does NOT wait.
+static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& io, phant::DevArena& dv,
+                                 const phant::FlatSide* side, bool timed, const uint8_t* roots, uint32_t n_roots,
+                                 const uint32_t* root_idx, const uint8_t* keys, uint32_t key_len, const uint8_t* nodes,
+                                 uint64_t nodes_len, const uint64_t* node_off, const uint32_t* proof_first_node,
+                                 uint32_t n, uint8_t* status, uint64_t* value_off, uint32_t* value_len) {
+    // the number of node offsets the caller must have provided
+    uint32_t total_nodes = 0;
+    for (uint32_t i = 0; i <= n; ++i)
+        if (proof_first_node[i] > total_nodes) total_nodes = proof_first_node[i];
+    const size_t need = ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) +
+                        ws_round((size_t)n * key_len + 4) + ws_round((size_t)nodes_len + 16) +
+                        ws_round(((size_t)total_nodes + 1) * 8) + ws_round(((size_t)n + 1) * 4) +
+                        ws_round(n) + ws_round((size_t)n * 8) + ws_round((size_t)n * 4);
+    if (need > io.cap) HIP_TRY(c, hipStreamSynchronize(s));
+    {
+        hipError_t e = io.reset(need);
+        if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(workspace)", e);
+    }
+    uint8_t* d_roots = io.take<uint8_t>((size_t)n_roots * 32);
+    uint32_t* d_ridx = io.take<uint32_t>(n);
+    uint8_t* d_keys = io.take<uint8_t>((size_t)n * key_len + 4);
+    uint8_t* d_nodes = io.take<uint8_t>((size_t)nodes_len + 16);
+    uint64_t* d_noff = io.take<uint64_t>((size_t)total_nodes + 1);
+    uint32_t* d_pfn = io.take<uint32_t>((size_t)n + 1);
+    uint8_t* d_status = io.take<uint8_t>(n);
+    uint64_t* d_voff = io.take<uint64_t>(n);
+    uint32_t* d_vlen = io.take<uint32_t>(n);
+    HIP_TRY(c, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 32, hipMemcpyHostToDevice, s));
+    if (root_idx) HIP_TRY(c, hipMemcpyAsync(d_ridx, root_idx, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
+    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nodes_len, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_noff, node_off, ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_pfn, proof_first_node, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+    phant::VerifyArgs a{d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
+                        d_noff, d_pfn, n, d_status, d_voff, d_vlen};
+    const int32_t vrc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
+    if (vrc) return vrc;
+    HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
+    if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (value_len) HIP_TRY(c, hipMemcpyAsync(value_len, d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     return PHANT_OK;
 }
 
@@ -361,43 +434,71 @@ int32_t phant_mpt_verify_batch(phant_ctx* c, const uint8_t* roots, uint32_t n_ro
     if (!roots || n_roots == 0 || !node_off || !proof_first_node || !status || (key_len && !keys) ||
         (nodes_len && !nodes))
         return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_batch: null pointer");
-    // the number of node offsets the caller must have provided
-    uint32_t total_nodes = 0;
-    for (uint32_t i = 0; i <= n; ++i)
-        if (proof_first_node[i] > total_nodes) total_nodes = proof_first_node[i];
     DeviceGuard g(c->device);
-    const size_t need = ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) +
-                        ws_round((size_t)n * key_len + 4) + ws_round((size_t)nodes_len + 16) +
-                        ws_round(((size_t)total_nodes + 1) * 8) + ws_round(((size_t)n + 1) * 4) +
-                        ws_round(n) + ws_round((size_t)n * 8) + ws_round((size_t)n * 4);
-    int32_t rc = ws_reset(c, need);
-    if (rc) return rc;
-    uint8_t* d_roots = ws_take<uint8_t>(c, (size_t)n_roots * 32);
-    uint32_t* d_ridx = ws_take<uint32_t>(c, n);
-    uint8_t* d_keys = ws_take<uint8_t>(c, (size_t)n * key_len + 4);
-    uint8_t* d_nodes = ws_take<uint8_t>(c, (size_t)nodes_len + 16);
-    uint64_t* d_noff = ws_take<uint64_t>(c, (size_t)total_nodes + 1);
-    uint32_t* d_pfn = ws_take<uint32_t>(c, (size_t)n + 1);
-    uint8_t* d_status = ws_take<uint8_t>(c, n);
-    uint64_t* d_voff = ws_take<uint64_t>(c, n);
-    uint32_t* d_vlen = ws_take<uint32_t>(c, n);
-    hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 32, hipMemcpyHostToDevice, s));
-    if (root_idx) HIP_TRY(c, hipMemcpyAsync(d_ridx, root_idx, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
-    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nodes_len, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d_noff, node_off, ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d_pfn, proof_first_node, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
-    phant::VerifyArgs a{d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
-                        d_noff, d_pfn, n, d_status, d_voff, d_vlen};
-    {
-        const int32_t vrc = verify_resident(c, a, total_nodes);
-        if (vrc) return vrc;
+    if (!c->verify_fused && c->flat_mode == phant::FLAT_OVERLAP && !c->side.stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
     }
-    HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
-    if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    if (value_len) HIP_TRY(c, hipMemcpyAsync(value_len, d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    const int32_t rc = verify_host_async(c, c->stream, c->ws.io, c->dv, &c->side, true, roots, n_roots, root_idx, keys,
+                                         key_len, nodes, nodes_len, node_off, proof_first_node, n, status, value_off,
+                                         value_len);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PHANT_OK;
+}
+
+/* ------------------------------------------------------------------ streaming */
+
+int32_t phant_host_alloc(phant_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    *out = nullptr;
+    DeviceGuard g(c->device);
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipHostMalloc", e);
+    return PHANT_OK;
+}
+
+int32_t phant_host_free(phant_ctx* c, void* p) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (!p) return PHANT_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipHostFree(p));
+    return PHANT_OK;
+}
+
+int32_t phant_mpt_verify_submit(phant_ctx* c, uint32_t slot, const uint8_t* roots, uint32_t n_roots,
+                                const uint32_t* root_idx, const uint8_t* keys, uint32_t key_len,
+                                const uint8_t* nodes, uint64_t nodes_len, const uint64_t* node_off,
+                                const uint32_t* proof_first_node, uint32_t n, uint8_t* status,
+                                uint64_t* value_off, uint32_t* value_len) {
+    if (!c || slot >= PHANT_MAX_SLOTS) return PHANT_E_INVALID_ARG;
+    phant_ctx::Slot& sl = c->slots[slot];
+    if (sl.busy) return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_submit: slot still in flight (phant_wait it first)");
+    if (n == 0) return PHANT_OK;
+    if (!roots || n_roots == 0 || !node_off || !proof_first_node || !status || (key_len && !keys) ||
+        (nodes_len && !nodes) || key_len > 0x3fffffffu)
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_submit: bad argument");
+    DeviceGuard g(c->device);
+    if (!sl.stream) HIP_TRY(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    const int32_t rc = verify_host_async(c, sl.stream, sl.io, sl.dv, nullptr, false, roots, n_roots, root_idx, keys,
+                                         key_len, nodes, nodes_len, node_off, proof_first_node, n, status, value_off,
+                                         value_len);
+    if (rc) {
+        (void)hipStreamSynchronize(sl.stream);  // nothing of a failed submission stays in flight
+        return rc;
+    }
+    sl.busy = true;
+    return PHANT_OK;
+}
+
+int32_t phant_wait(phant_ctx* c, uint32_t slot) {
+    if (!c || slot >= PHANT_MAX_SLOTS) return PHANT_E_INVALID_ARG;
+    phant_ctx::Slot& sl = c->slots[slot];
+    if (!sl.busy) return PHANT_OK;
+    DeviceGuard g(c->device);
+    sl.busy = false;
+    HIP_TRY(c, hipStreamSynchronize(sl.stream));
     return PHANT_OK;
 }
 

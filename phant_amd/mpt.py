@@ -198,3 +198,61 @@ def verdict_dev(status: torch.Tensor, root_idx: torch.Tensor | None, n_roots: in
                                              None if root_idx is None else root_idx.data_ptr(), status.numel(),
                                              n_roots, out.data_ptr()))
     return out
+
+
+# ---------------------------------------------------------------------------- streaming (BASELINE config 5)
+@dataclass
+class HostWitness:
+    """A witness in pinned host memory (what a block-processing loop holds after parsing the wire format),
+    plus pinned result buffers.  All tensors are CPU tensors with pin_memory=True."""
+    roots: torch.Tensor
+    root_idx: torch.Tensor | None
+    keys: torch.Tensor
+    nodes: torch.Tensor
+    node_off: torch.Tensor
+    proof_first_node: torch.Tensor
+    status: torch.Tensor
+    value_off: torch.Tensor
+    value_len: torch.Tensor
+
+    @property
+    def n(self) -> int:
+        return self.proof_first_node.numel() - 1
+
+    def h2d_bytes(self) -> int:
+        t = [self.roots, self.keys, self.nodes, self.node_off, self.proof_first_node]
+        if self.root_idx is not None:
+            t.append(self.root_idx)
+        return int(sum(x.numel() * x.element_size() for x in t))
+
+
+def to_host(b: ProofBatch) -> HostWitness:
+    """Copy a device-resident ProofBatch into pinned host buffers."""
+    def pin(t):
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t)
+        return h
+
+    n = b.n
+    return HostWitness(pin(b.roots), None if b.root_idx is None else pin(b.root_idx), pin(b.keys), pin(b.nodes),
+                       pin(b.node_off), pin(b.proof_first_node),
+                       torch.empty(n, dtype=torch.uint8, pin_memory=True),
+                       torch.empty(n, dtype=torch.int64, pin_memory=True),
+                       torch.empty(n, dtype=torch.int32, pin_memory=True))
+
+
+def verify_submit(hw: HostWitness, slot: int, ctx: Context | None = None) -> None:
+    """phant_mpt_verify_submit: queue copy-in, verification and copy-out of `hw` on slot `slot`; returns at
+    once.  hw.status / value_off / value_len are valid after wait(slot)."""
+    ctx = ctx or default_context()
+    key_len = hw.keys.shape[1] if hw.keys.dim() == 2 else 0
+    ctx.check(ctx._lib.phant_mpt_verify_submit(
+        ctx.handle, slot, hw.roots.data_ptr(), hw.roots.numel() // 32,
+        None if hw.root_idx is None else hw.root_idx.data_ptr(), hw.keys.data_ptr(), key_len, hw.nodes.data_ptr(),
+        hw.nodes.numel(), hw.node_off.data_ptr(), hw.proof_first_node.data_ptr(), hw.n, hw.status.data_ptr(),
+        hw.value_off.data_ptr(), hw.value_len.data_ptr()))
+
+
+def wait(slot: int, ctx: Context | None = None) -> None:
+    ctx = ctx or default_context()
+    ctx.check(ctx._lib.phant_wait(ctx.handle, slot))

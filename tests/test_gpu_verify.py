@@ -276,3 +276,36 @@ def test_non_monotone_proof_first_node_matches_oracle(M, oracle):
     assert np.array_equal(got[0], want[0]), (got[0].tolist(), want[0].tolist())
     assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
     assert got[0][0] == M.PROOF_PRESENT and got[0][1] == M.PROOF_BAD_INPUT
+
+
+def test_streaming_submit_wait(M):
+    """phant_mpt_verify_submit / phant_wait: several witnesses in flight on one ctx, pinned host buffers,
+    results identical to the device-form call."""
+    import phant_amd
+    from phant_amd import mpt
+    ctx = M._ctx
+    ws = [phant_amd.witness.account_witness(n, depth=8, seed=30 + k, corrupt_frac=0.1)
+          for k, n in enumerate((700, 1300, 64, 2000, 900))]
+    hosts = [mpt.to_host(w.batch) for w in ws]
+    for round_ in range(2):  # second round reuses the slots' arenas
+        for h in hosts:
+            h.status.fill_(0x55)
+        pending = []
+        for k, h in enumerate(hosts):
+            slot = k % 3
+            if len(pending) == 3:
+                mpt.wait(pending.pop(0), ctx)
+            mpt.verify_submit(h, slot, ctx)
+            pending.append(slot)
+        for s in pending:
+            mpt.wait(s, ctx)
+        for w, h in zip(ws, hosts):
+            assert torch.equal(h.status, w.expected.cpu())
+            present = h.status == M.PROOF_PRESENT
+            assert (h.value_len[present] == 78).all()
+    # a slot cannot be reused while in flight
+    mpt.verify_submit(hosts[0], 0, ctx)
+    with pytest.raises(Exception):
+        mpt.verify_submit(hosts[1], 0, ctx)
+    mpt.wait(0, ctx)
+    assert torch.equal(hosts[0].status, ws[0].expected.cpu())
