@@ -65,6 +65,10 @@ extern "C" {
 #define PHANT_PROOF_EXTRA_NODES 19  /* walk finished with nodes left over */
 #define PHANT_PROOF_MISSING_NODE 20 /* walk needs a node the proof lacks */
 #define PHANT_PROOF_BAD_INPUT 21    /* node_off / proof_first_node inconsistent */
+#define PHANT_PROOF_MISMATCH 22     /* phant_witness_verify only: the proof is valid, but what it proves
+                                       contradicts what the witness declares (storageHash, codeHash, nonce,
+                                       balance, slot value), or its root is not anchored because the
+                                       account proof above it failed */
 
 typedef struct phant_ctx phant_ctx;
 
@@ -174,6 +178,42 @@ PHANT_API int32_t phant_mpt_verify_submit(phant_ctx *ctx, uint32_t slot, const u
                                           const uint32_t *proof_first_node, uint32_t n,
                                           uint8_t *status, uint64_t *value_off, uint32_t *value_len);
 PHANT_API int32_t phant_wait(phant_ctx *ctx, uint32_t slot);
+
+/* ------------------------------------------------------------ block witness
+ * The step before the kernel: the engine-API witness as JSON, parsed into
+ * the packed arrays above and verified in one call.  phant has no witness type yet
+ * (src/engine_api/execution_payload.zig:121 commented out, TODO at :175-178); the wire format taken is
+ * the JSON-RPC encoding of MPT proofs, EIP-1186 eth_getProof result objects under a state root:
+ *   { "stateRoot": "0x<32>", "accounts": [ { "address", "accountProof": [..], "storageHash", "codeHash",
+ *     "nonce", "balance", "storageProof": [ { "key", "value", "proof": [..] } ] } ] }
+ * with phant's hex conventions (src/common/hexutils.zig:22-37).  Parsing is host-only code (works
+ * without a GPU); phant_witness_verify hashes the 20-byte addresses / 32-byte slots into trie keys on
+ * the GPU (batched Keccak), verifies account proofs against stateRoot and storage proofs against each
+ * account's storageHash in ONE batch, then checks on the host that every proven account leaf
+ * rlp([nonce, balance, storageRoot, codeHash]) (src/state/types.zig:13-20) agrees with what the
+ * witness declares.  status[i] per proof in document order (account proof, then its storage proofs). */
+typedef struct phant_witness phant_witness;
+typedef struct phant_witness_info {
+    uint32_t struct_size; /* = sizeof(phant_witness_info) */
+    uint32_t n_proofs, n_roots, n_accounts, n_slots, total_nodes;
+    uint64_t nodes_len;
+    const uint8_t *roots;             /* n_roots x 32: stateRoot, then every account's storageHash */
+    const uint32_t *root_idx;         /* n_proofs */
+    const uint32_t *account_of;       /* n_proofs: which account the proof belongs to */
+    const uint8_t *preimages;         /* 20-byte addresses / 32-byte slots, back to back */
+    const uint32_t *preimage_off;     /* n_proofs + 1 */
+    const uint8_t *nodes;
+    const uint64_t *node_off;         /* total_nodes + 1 */
+    const uint32_t *proof_first_node; /* n_proofs + 1 */
+} phant_witness_info;
+/* err (optional, err_cap bytes) receives a message with the byte offset on PHANT_E_INVALID_ARG */
+PHANT_API int32_t phant_witness_parse_json(const char *json, uint64_t len, phant_witness **out,
+                                           char *err, uint32_t err_cap);
+PHANT_API void phant_witness_free(phant_witness *w);
+/* pointers stay valid until phant_witness_free */
+PHANT_API int32_t phant_witness_get(const phant_witness *w, phant_witness_info *info);
+PHANT_API int32_t phant_witness_verify(phant_ctx *ctx, const phant_witness *w, uint8_t *status,
+                                       uint32_t *n_failed);
 
 /* ---------------------------------------------------------------- trie root
  * Replaces src/mpt/mpt.zig:38 `mptize(arena, list: []const KeyVal) !Hash32`

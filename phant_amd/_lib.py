@@ -33,6 +33,7 @@ PROOF_BAD_NODE = 18
 PROOF_EXTRA_NODES = 19
 PROOF_MISSING_NODE = 20
 PROOF_BAD_INPUT = 21
+PROOF_MISMATCH = 22
 
 # every symbol include/phant_gpu.h declares: (name, restype, argtypes)
 _vp, _u32, _u64, _i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
@@ -57,6 +58,10 @@ SYMBOLS = {
     "phant_host_free": (_i32, [_vp, _vp]),
     "phant_mpt_verify_submit": (_i32, [_vp, _u32, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp]),
     "phant_wait": (_i32, [_vp, _u32]),
+    "phant_witness_parse_json": (_i32, [C.c_char_p, _u64, C.POINTER(_vp), C.c_char_p, _u32]),
+    "phant_witness_free": (None, [_vp]),
+    "phant_witness_get": (_i32, [_vp, _vp]),
+    "phant_witness_verify": (_i32, [_vp, _vp, _vp, C.POINTER(_u32)]),
     "phant_mpt_root": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "phant_index_root_rlp": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "phant_index_root_be32": (_i32, [_vp, _vp, _vp, _u32, _vp]),

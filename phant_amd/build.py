@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libphant_gpu.so")
-SOURCES = ["keccak_batch.hip", "mpt_verify.hip", "mpt_verify_flat.hip", "trie_build.hip", "state_root.hip", "capi.hip"]
+SOURCES = ["keccak_batch.hip", "mpt_verify.hip", "mpt_verify_flat.hip", "trie_build.hip", "state_root.hip", "capi.hip",
+           "witness_json.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-exceptions",
          "-Wall", "-Wno-unused-function"]
 
@@ -46,7 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(obj_dir, exist_ok=True)
     procs = []
     for s in SOURCES:
-        o = os.path.join(obj_dir, s.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, s.replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(o)
         cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:

@@ -16,6 +16,11 @@
 #include "arena.h"
 #include "launch.h"
 #include "trie_build.h"
+#include "witness.h"
+
+struct phant_witness {
+    phant::Witness w;
+};
 
 struct phant_ctx {
     int device = 0;
@@ -499,6 +504,227 @@ int32_t phant_wait(phant_ctx* c, uint32_t slot) {
     DeviceGuard g(c->device);
     sl.busy = false;
     HIP_TRY(c, hipStreamSynchronize(sl.stream));
+    return PHANT_OK;
+}
+
+/* ------------------------------------------------------------------ block witness */
+
+namespace {
+
+// one canonical RLP item of `avail` bytes at p: payload offset / length, or false
+bool host_rlp_item(const uint8_t* p, size_t avail, size_t& pay, size_t& len, size_t& total, bool& is_list) {
+    if (avail == 0) return false;
+    const uint8_t b = p[0];
+    if (b < 0x80) {
+        pay = 0, len = 1, total = 1, is_list = false;
+        return true;
+    }
+    if (b <= 0xb7 || (b >= 0xc0 && b <= 0xf7)) {
+        is_list = b >= 0xc0;
+        len = b - (is_list ? 0xc0 : 0x80);
+        pay = 1, total = 1 + len;
+        if (total > avail) return false;
+        if (!is_list && len == 1 && p[1] < 0x80) return false;
+        return true;
+    }
+    is_list = b >= 0xf8;
+    const size_t ll = b - (is_list ? 0xf7 : 0xb7);
+    if (1 + ll > avail || p[1] == 0) return false;
+    size_t l = 0;
+    for (size_t i = 0; i < ll; ++i) l = l << 8 | p[1 + i];
+    if (l <= 55 || l > avail - 1 - ll) return false;
+    pay = 1 + ll, len = l, total = 1 + ll + l;
+    return true;
+}
+
+// big-endian minimal integer string == the 32-byte padded declaration?
+bool be_equals_padded(const uint8_t* v, size_t len, const uint8_t padded[32]) {
+    if (len > 32 || (len && v[0] == 0)) return false;
+    for (size_t i = 0; i < 32 - len; ++i)
+        if (padded[i]) return false;
+    return std::memcmp(padded + 32 - len, v, len) == 0;
+}
+
+const uint8_t EMPTY_ROOT[32] = {0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 0xff, 0x83, 0x45, 0xe6, 0x92, 0xc0, 0xf8, 0x6e,
+                                0x5b, 0x48, 0xe0, 0x1b, 0x99, 0x6c, 0xad, 0xc0, 0x01, 0x62, 0x2f, 0xb5, 0xe3, 0x63, 0xb4, 0x21};
+const uint8_t EMPTY_CODE[32] = {0xc5, 0xd2, 0x46, 0x01, 0x86, 0xf7, 0x23, 0x3c, 0x92, 0x7e, 0x7d, 0xb2, 0xdc, 0xc7, 0x03, 0xc0,
+                                0xe5, 0x00, 0xb6, 0x53, 0xca, 0x82, 0x27, 0x3b, 0x7b, 0xfa, 0xd8, 0x04, 0x5d, 0x85, 0xa4, 0x70};
+
+// Does the proven account leaf agree with the declaration?  value = rlp([nonce, balance, storageRoot, codeHash])
+bool account_consistent(const phant::WitnessAccount& a, const uint8_t* value, size_t vlen) {
+    size_t pay, len, total;
+    bool is_list;
+    if (!host_rlp_item(value, vlen, pay, len, total, is_list) || !is_list || total != vlen) return false;
+    const uint8_t* p = value + pay;
+    size_t left = len;
+    const uint8_t* item[4];
+    size_t ilen[4];
+    for (int k = 0; k < 4; ++k) {
+        size_t ip, il, it;
+        bool il_list;
+        if (!host_rlp_item(p, left, ip, il, it, il_list) || il_list) return false;
+        item[k] = p + ip;
+        ilen[k] = il;
+        p += it;
+        left -= it;
+    }
+    if (left) return false;
+    if (ilen[2] != 32 || std::memcmp(item[2], a.storage_hash, 32) != 0) return false;
+    if (a.has_code_hash && (ilen[3] != 32 || std::memcmp(item[3], a.code_hash, 32) != 0)) return false;
+    if (a.has_balance && !be_equals_padded(item[1], ilen[1], a.balance)) return false;
+    if (a.has_nonce) {
+        uint8_t n32[32] = {0};
+        for (int i = 0; i < 8; ++i) n32[31 - i] = (uint8_t)(a.nonce >> (8 * i));
+        if (!be_equals_padded(item[0], ilen[0], n32)) return false;
+    }
+    return true;
+}
+
+bool account_absent_consistent(const phant::WitnessAccount& a) {
+    static const uint8_t zero[32] = {0};
+    if (std::memcmp(a.storage_hash, EMPTY_ROOT, 32) != 0) return false;
+    if (a.has_code_hash && std::memcmp(a.code_hash, EMPTY_CODE, 32) != 0) return false;
+    if (a.has_balance && std::memcmp(a.balance, zero, 32) != 0) return false;
+    if (a.has_nonce && a.nonce != 0) return false;
+    return true;
+}
+
+}  // namespace
+
+int32_t phant_witness_parse_json(const char* json, uint64_t len, phant_witness** out, char* err, uint32_t err_cap) {
+    if (err && err_cap) err[0] = 0;
+    if (!out || (!json && len)) return PHANT_E_INVALID_ARG;
+    *out = nullptr;
+    phant_witness* w = new (std::nothrow) phant_witness();
+    if (!w) return PHANT_E_OOM;
+    std::string msg;
+    if (!phant::witness_parse_json(json, (size_t)len, w->w, msg)) {
+        if (err && err_cap) {
+            std::strncpy(err, msg.c_str(), err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        delete w;
+        return PHANT_E_INVALID_ARG;
+    }
+    *out = w;
+    return PHANT_OK;
+}
+
+void phant_witness_free(phant_witness* w) { delete w; }
+
+int32_t phant_witness_get(const phant_witness* pw, phant_witness_info* info) {
+    if (!pw || !info || info->struct_size < sizeof(phant_witness_info)) return PHANT_E_INVALID_ARG;
+    const phant::Witness& w = pw->w;
+    info->n_proofs = (uint32_t)w.root_idx.size();
+    info->n_roots = (uint32_t)(w.roots.size() / 32);
+    info->n_accounts = (uint32_t)w.accounts.size();
+    info->n_slots = (uint32_t)w.slots.size();
+    info->total_nodes = (uint32_t)(w.node_off.size() - 1);
+    info->nodes_len = (uint64_t)w.nodes.size();
+    info->roots = w.roots.data();
+    info->root_idx = w.root_idx.data();
+    info->account_of = w.account_of.data();
+    info->preimages = w.preimages.data();
+    info->preimage_off = w.preimage_off.data();
+    info->nodes = w.nodes.data();
+    info->node_off = w.node_off.data();
+    info->proof_first_node = w.proof_first_node.data();
+    return PHANT_OK;
+}
+
+int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* status, uint32_t* n_failed) {
+    if (!c || !pw) return PHANT_E_INVALID_ARG;
+    const phant::Witness& w = pw->w;
+    const uint32_t n = (uint32_t)w.root_idx.size();
+    if (n_failed) *n_failed = 0;
+    if (n == 0) return PHANT_OK;
+    if (!status) return fail(c, PHANT_E_INVALID_ARG, "witness_verify: null status");
+    const uint32_t n_roots = (uint32_t)(w.roots.size() / 32);
+    const uint32_t total_nodes = (uint32_t)(w.node_off.size() - 1);
+    const size_t nodes_len = w.nodes.size(), pre_len = w.preimages.size();
+    DeviceGuard g(c->device);
+    hipStream_t s = c->stream;
+    const size_t need = ws_round(pre_len + 16) + ws_round(((size_t)n + 1) * 8) + ws_round((size_t)n * 32) +
+                        ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) + ws_round(nodes_len + 16) +
+                        ws_round(((size_t)total_nodes + 1) * 8) + ws_round(((size_t)n + 1) * 4) + ws_round(n) +
+                        ws_round((size_t)n * 8) + ws_round((size_t)n * 4);
+    int32_t rc = ws_reset(c, need);
+    if (rc) return rc;
+    uint8_t* d_pre = ws_take<uint8_t>(c, pre_len + 16);
+    uint64_t* d_poff = ws_take<uint64_t>(c, (size_t)n + 1);
+    uint8_t* d_keys = ws_take<uint8_t>(c, (size_t)n * 32);
+    uint8_t* d_roots = ws_take<uint8_t>(c, (size_t)n_roots * 32);
+    uint32_t* d_ridx = ws_take<uint32_t>(c, n);
+    uint8_t* d_nodes = ws_take<uint8_t>(c, nodes_len + 16);
+    uint64_t* d_noff = ws_take<uint64_t>(c, (size_t)total_nodes + 1);
+    uint32_t* d_pfn = ws_take<uint32_t>(c, (size_t)n + 1);
+    uint8_t* d_status = ws_take<uint8_t>(c, n);
+    uint64_t* d_voff = ws_take<uint64_t>(c, n);
+    uint32_t* d_vlen = ws_take<uint32_t>(c, n);
+    std::vector<uint64_t> poff64(w.preimage_off.begin(), w.preimage_off.end());
+    HIP_TRY(c, hipMemcpyAsync(d_pre, w.preimages.data(), pre_len, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_poff, poff64.data(), poff64.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_roots, w.roots.data(), w.roots.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_ridx, w.root_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, w.nodes.data(), nodes_len, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_noff, w.node_off.data(), ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_pfn, w.proof_first_node.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+    // secure-trie keys: keccak256(address) / keccak256(slot), one batched launch
+    HIP_TRY(c, phant::launch_keccak256_var(d_pre, d_poff, n, d_keys, s));
+    phant::VerifyArgs a{d_roots, n_roots, d_ridx, d_keys, 32, d_nodes, nodes_len, d_noff, d_pfn, n, d_status, d_voff, d_vlen};
+    if (!c->verify_fused && c->flat_mode == phant::FLAT_OVERLAP && !c->side.stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
+    }
+    rc = verify_resident_on(c, a, total_nodes, s, c->dv, &c->side, true);
+    if (rc) return rc;
+    std::vector<uint64_t> voff(n);
+    std::vector<uint32_t> vlen(n);
+    HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(voff.data(), d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(vlen.data(), d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+
+    // ---- host: does what was proven agree with what the witness declares? ----
+    std::vector<uint8_t> anchored(w.accounts.size(), 0);
+    for (size_t ai = 0; ai < w.accounts.size(); ++ai) {
+        const phant::WitnessAccount& acc = w.accounts[ai];
+        uint8_t& st = status[acc.proof];
+        if (st == PHANT_PROOF_PRESENT) {
+            if (account_consistent(acc, w.nodes.data() + voff[acc.proof], vlen[acc.proof])) anchored[ai] = 1;
+            else st = PHANT_PROOF_MISMATCH;
+        } else if (st == PHANT_PROOF_ABSENT) {
+            if (account_absent_consistent(acc)) anchored[ai] = 1;
+            else st = PHANT_PROOF_MISMATCH;
+        }
+    }
+    for (const phant::WitnessSlot& sl : w.slots) {
+        uint8_t& st = status[sl.proof];
+        if (st != PHANT_PROOF_PRESENT && st != PHANT_PROOF_ABSENT) continue;
+        if (!anchored[sl.account]) {
+            st = PHANT_PROOF_MISMATCH;  // verified against a storage root nothing commits to
+            continue;
+        }
+        if (!sl.has_value) continue;
+        static const uint8_t zero[32] = {0};
+        if (st == PHANT_PROOF_ABSENT) {
+            if (std::memcmp(sl.value, zero, 32) != 0) st = PHANT_PROOF_MISMATCH;
+        } else {
+            // slot value = rlp(minimal big-endian integer)
+            size_t pay, len, total;
+            bool is_list;
+            const uint8_t* v = w.nodes.data() + voff[sl.proof];
+            if (!host_rlp_item(v, vlen[sl.proof], pay, len, total, is_list) || is_list || total != vlen[sl.proof] ||
+                !be_equals_padded(v + pay, len, sl.value))
+                st = PHANT_PROOF_MISMATCH;
+        }
+    }
+    if (n_failed) {
+        uint32_t bad = 0;
+        for (uint32_t i = 0; i < n; ++i) bad += !(status[i] == PHANT_PROOF_PRESENT || status[i] == PHANT_PROOF_ABSENT);
+        *n_failed = bad;
+    }
     return PHANT_OK;
 }
 

@@ -1,0 +1,42 @@
+// witness.h -- a parsed block witness (witness_json.cpp) in the packed layout of phant_mpt_verify_batch.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace phant {
+
+struct WitnessAccount {
+    uint8_t address[20];
+    uint8_t storage_hash[32];  // declared storage root (empty_mpt_root when the member is absent)
+    uint8_t code_hash[32];
+    uint8_t balance[32];       // big-endian u256
+    uint64_t nonce;
+    uint32_t proof;            // index of its account proof
+    uint8_t has_storage_hash, has_code_hash, has_balance, has_nonce;
+};
+
+struct WitnessSlot {
+    uint8_t value[32];  // declared value, big-endian u256
+    uint32_t proof;     // index of its storage proof
+    uint32_t account;
+    uint8_t has_value;
+};
+
+struct Witness {
+    std::vector<uint8_t> roots;             // (1 + accounts) x 32: stateRoot, then every account's storageHash
+    std::vector<uint32_t> root_idx;         // per proof
+    std::vector<uint32_t> account_of;       // per proof: index into accounts
+    std::vector<uint8_t> preimages;         // 20-byte addresses / 32-byte slots, back to back
+    std::vector<uint32_t> preimage_off;     // proofs + 1
+    std::vector<uint8_t> nodes;
+    std::vector<uint64_t> node_off;         // total_nodes + 1
+    std::vector<uint32_t> proof_first_node; // proofs + 1
+    std::vector<WitnessAccount> accounts;
+    std::vector<WitnessSlot> slots;
+};
+
+bool witness_parse_json(const char* json, size_t len, Witness& out, std::string& err);
+
+}  // namespace phant

@@ -1,0 +1,105 @@
+"""Mirror of the hook phant leaves open in src/engine_api/execution_payload.zig:175-178
+("TODO reconstruct the proof from the (currently undefined) execution witness and verify it"):
+the block witness as JSON -> packed arrays -> one batched verification on the GPU.
+
+Wire format: EIP-1186 `eth_getProof` result objects under a state root (include/phant_gpu.h, block
+witness section), hex per src/common/hexutils.zig:22-37.
+
+    w = ExecutionWitness.parse_json(text)       # host-only (no GPU needed)
+    status, n_failed = w.verify(ctx)            # PHANT_PROOF_* per proof, document order
+    ok = new_payload_witness_ok(text, ctx)      # what newPayloadV2Handler would ask before runBlock
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .context import Context, default_context
+
+
+class WitnessInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_proofs", C.c_uint32), ("n_roots", C.c_uint32),
+                ("n_accounts", C.c_uint32), ("n_slots", C.c_uint32), ("total_nodes", C.c_uint32),
+                ("nodes_len", C.c_uint64), ("roots", C.c_void_p), ("root_idx", C.c_void_p),
+                ("account_of", C.c_void_p), ("preimages", C.c_void_p), ("preimage_off", C.c_void_p),
+                ("nodes", C.c_void_p), ("node_off", C.c_void_p), ("proof_first_node", C.c_void_p)]
+
+
+class WitnessFormatError(ValueError):
+    pass
+
+
+def _view(ptr, count, dtype):
+    if not count:
+        return np.zeros(0, dtype)
+    n = count * np.dtype(dtype).itemsize
+    buf = (C.c_uint8 * n).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class ExecutionWitness:
+    def __init__(self, handle):
+        self._h = handle
+        self._lib = L.lib()
+
+    @staticmethod
+    def parse_json(text: str | bytes) -> "ExecutionWitness":
+        lib = L.lib()
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = lib.phant_witness_parse_json(data, len(data), C.byref(h), err, 256)
+        if rc != L.OK:
+            raise WitnessFormatError(err.value.decode() or f"phant_witness_parse_json rc={rc}")
+        return ExecutionWitness(h)
+
+    def info(self) -> dict:
+        """numpy views (valid while this object lives) of the packed arrays + counts."""
+        wi = WitnessInfo()
+        wi.struct_size = C.sizeof(WitnessInfo)
+        rc = self._lib.phant_witness_get(self._h, C.byref(wi))
+        if rc != L.OK:
+            raise L.PhantError(rc, "phant_witness_get")
+        n = wi.n_proofs
+        pre_off = _view(wi.preimage_off, n + 1, np.uint32)
+        return {"n_proofs": n, "n_roots": wi.n_roots, "n_accounts": wi.n_accounts, "n_slots": wi.n_slots,
+                "total_nodes": wi.total_nodes, "nodes_len": wi.nodes_len,
+                "roots": _view(wi.roots, wi.n_roots * 32, np.uint8).reshape(-1, 32),
+                "root_idx": _view(wi.root_idx, n, np.uint32), "account_of": _view(wi.account_of, n, np.uint32),
+                "preimages": _view(wi.preimages, int(pre_off[-1]) if n else 0, np.uint8), "preimage_off": pre_off,
+                "nodes": _view(wi.nodes, wi.nodes_len, np.uint8),
+                "node_off": _view(wi.node_off, wi.total_nodes + 1, np.uint64),
+                "proof_first_node": _view(wi.proof_first_node, n + 1, np.uint32)}
+
+    def verify(self, ctx: Context | None = None):
+        """-> (status u8[n_proofs], n_failed).  Needs a GPU (no CPU fallback)."""
+        ctx = ctx or default_context()
+        n = self.info()["n_proofs"]
+        status = np.zeros(max(n, 1), np.uint8)
+        bad = C.c_uint32(0)
+        ctx.check(self._lib.phant_witness_verify(ctx.handle, self._h, status.ctypes.data_as(C.c_void_p), C.byref(bad)))
+        return status[:n], int(bad.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.phant_witness_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def new_payload_witness_ok(witness_json: str | bytes, ctx: Context | None = None) -> bool:
+    """The check newPayloadV2Handler (execution_payload.zig:175-181) would make before
+    `blockchain.runBlock(block)`: every proof of the witness valid and consistent."""
+    w = ExecutionWitness.parse_json(witness_json)
+    try:
+        _, bad = w.verify(ctx)
+        return bad == 0
+    finally:
+        w.close()

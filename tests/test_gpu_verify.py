@@ -309,3 +309,22 @@ def test_streaming_submit_wait(M):
         mpt.verify_submit(hosts[1], 0, ctx)
     mpt.wait(0, ctx)
     assert torch.equal(hosts[0].status, ws[0].expected.cpu())
+
+
+def test_block_witness_accounts_and_storage(M, oracle):
+    """BASELINE config 4 in miniature: account proofs against the state root and storage proofs against
+    41 per-account roots in ONE batch (root_idx), real trie shapes (extensions, sparse branches, short
+    leaves), exclusion proofs, damaged nodes, wrong roots.  Status / value location per proof and the
+    per-root verdict must equal the oracle's."""
+    from tests.witness_util import block_witness
+    rng = np.random.default_rng(404)
+    roots, ridx, keys, proofs = block_witness(oracle, rng)
+    got, want = _both(M, oracle, roots, ridx, keys, 32, proofs)
+    _assert_same(got, want)
+    kinds = set(got[0].tolist())
+    assert {M.PROOF_PRESENT, M.PROOF_ABSENT, M.PROOF_BAD_HASH} <= kinds
+    st = torch.from_numpy(got[0].copy()).cuda()
+    fails = M.verdict_dev(st, torch.from_numpy(ridx.astype(np.int32)).cuda(), len(roots)).cpu().numpy()
+    bad = ~np.isin(want[0], (M.PROOF_PRESENT, M.PROOF_ABSENT))
+    assert np.array_equal(fails, np.bincount(ridx[bad], minlength=len(roots)))
+    assert fails.sum() > 0 and (fails == 0).any()

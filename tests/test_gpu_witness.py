@@ -1,0 +1,129 @@
+"""phant_witness_verify: JSON block witness -> GPU (batched Keccak of addresses / slots into trie keys,
+one multi-root proof batch) -> host consistency check, through the C-ABI."""
+import copy
+import json
+
+import numpy as np
+import pytest
+
+from tests.witness_util import block_witness_json
+
+pytestmark = pytest.mark.gpu
+
+PRESENT, ABSENT, BAD_HASH, MISMATCH = 1, 2, 16, 22
+
+
+@pytest.fixture(scope="module")
+def EA():
+    from phant_amd import engine_api
+    return engine_api
+
+
+@pytest.fixture(scope="module")
+def built(oracle):
+    return block_witness_json(oracle, np.random.default_rng(99))
+
+
+def _run(EA, doc):
+    w = EA.ExecutionWitness.parse_json(json.dumps(doc))
+    st, bad = w.verify()
+    info = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in w.info().items()}
+    w.close()
+    return st, bad, info
+
+
+def test_clean_witness(EA, built):
+    doc, expected, _ = built
+    st, bad, _ = _run(EA, doc)
+    assert st.tolist() == expected and bad == 0
+    assert EA.new_payload_witness_ok(json.dumps(doc))
+    assert PRESENT in expected and ABSENT in expected
+
+
+def _first_contract(doc):
+    return next(i for i, a in enumerate(doc["accounts"]) if len(a["storageProof"]) >= 2)
+
+
+def _proof_index(doc, account, slot=None):
+    i = 0
+    for ai, a in enumerate(doc["accounts"]):
+        if ai == account:
+            return i if slot is None else i + 1 + slot
+        i += 1 + len(a["storageProof"])
+    raise IndexError
+
+
+def test_declared_fields_must_match_the_proven_leaf(EA, built):
+    doc0, expected, _ = built
+    c = _first_contract(doc0)
+    for field, bump in (("nonce", lambda v: hex(int(v, 16) + 1)), ("balance", lambda v: hex(int(v, 16) ^ 1)),
+                        ("codeHash", lambda v: "0x" + "77" * 32)):
+        doc = copy.deepcopy(doc0)
+        doc["accounts"][c][field] = bump(doc["accounts"][c][field])
+        st, bad, _ = _run(EA, doc)
+        want = list(expected)
+        ia = _proof_index(doc, c)
+        want[ia] = MISMATCH
+        for s in range(len(doc["accounts"][c]["storageProof"])):  # their root is no longer anchored
+            want[ia + 1 + s] = MISMATCH
+        assert st.tolist() == want, field
+        assert bad == 1 + len(doc["accounts"][c]["storageProof"])
+        assert not EA.new_payload_witness_ok(json.dumps(doc))
+
+
+def test_wrong_storage_hash_and_slot_value(EA, built):
+    doc0, expected, _ = built
+    c = _first_contract(doc0)
+    ia = _proof_index(doc0, c)
+    # declared storageHash differs from the one in the proven leaf: account MISMATCH, and its storage
+    # proofs no longer hash to the root they are checked against
+    doc = copy.deepcopy(doc0)
+    doc["accounts"][c]["storageHash"] = "0x" + "42" * 32
+    st, _, _ = _run(EA, doc)
+    assert st[ia] == MISMATCH
+    assert all(s == BAD_HASH for s in st[ia + 1: ia + 1 + len(doc["accounts"][c]["storageProof"])])
+    assert st.tolist()[:ia] == expected[:ia]
+    # one slot declares a different value than its leaf holds
+    doc = copy.deepcopy(doc0)
+    sp = doc["accounts"][c]["storageProof"]
+    k = next(i for i, s in enumerate(sp) if int(s["value"], 16) != 0)
+    sp[k]["value"] = hex(int(sp[k]["value"], 16) + 1)
+    st, bad, _ = _run(EA, doc)
+    want = list(expected)
+    want[ia + 1 + k] = MISMATCH
+    assert st.tolist() == want and bad == 1
+    # an absent slot that claims a value
+    k0 = next((i for i, s in enumerate(sp) if int(doc0["accounts"][c]["storageProof"][i]["value"], 16) == 0), None)
+    if k0 is not None:
+        doc = copy.deepcopy(doc0)
+        doc["accounts"][c]["storageProof"][k0]["value"] = "0x5"
+        st, bad, _ = _run(EA, doc)
+        assert st[ia + 1 + k0] == MISMATCH and bad == 1
+
+
+def test_damaged_account_proof_unanchors_its_slots(EA, built):
+    doc0, expected, _ = built
+    c = _first_contract(doc0)
+    ia = _proof_index(doc0, c)
+    doc = copy.deepcopy(doc0)
+    nd = bytearray(bytes.fromhex(doc["accounts"][c]["accountProof"][-1][2:]))
+    nd[len(nd) // 2] ^= 0x04
+    doc["accounts"][c]["accountProof"][-1] = "0x" + nd.hex()
+    st, bad, _ = _run(EA, doc)
+    n_s = len(doc["accounts"][c]["storageProof"])
+    assert st[ia] == BAD_HASH and all(s == MISMATCH for s in st[ia + 1: ia + 1 + n_s])
+    want = list(expected)
+    want[ia: ia + 1 + n_s] = [BAD_HASH] + [MISMATCH] * n_s
+    assert st.tolist() == want and bad == 1 + n_s
+
+
+def test_keys_are_the_keccak_of_the_preimages(EA, built, oracle):
+    """The trie keys phant_witness_verify derives on the GPU are keccak256(address) / keccak256(slot):
+    verifying the packed arrays with oracle-hashed keys gives the same statuses."""
+    doc, expected, keys = built
+    st, _, info = _run(EA, doc)
+    pre = [info["preimages"][info["preimage_off"][i]: info["preimage_off"][i + 1]].tobytes() for i in range(info["n_proofs"])]
+    assert [oracle.keccak256(p) for p in pre] == keys
+    want, _, _ = oracle.mpt_verify_batch(info["roots"].reshape(-1), info["root_idx"], np.frombuffer(b"".join(keys), np.uint8), 32,
+                                         info["nodes"], info["node_off"], info["proof_first_node"])
+    assert st.tolist() == want.tolist()

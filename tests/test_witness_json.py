@@ -1,0 +1,95 @@
+"""Block-witness wire format (EIP-1186 objects under a state root): the host-side parser of
+phant_amd/csrc/witness_json.cpp through the C-ABI.  No GPU needed: parsing is host code."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.witness_util import block_witness_json
+
+
+@pytest.fixture(scope="module")
+def EA():
+    from phant_amd import engine_api
+    return engine_api
+
+
+def test_parse_matches_document(EA, oracle):
+    rng = np.random.default_rng(7)
+    doc, expected, keys = block_witness_json(oracle, rng)
+    w = EA.ExecutionWitness.parse_json(json.dumps(doc))
+    info = w.info()
+    n_acc = len(doc["accounts"])
+    n_slots = sum(len(a["storageProof"]) for a in doc["accounts"])
+    assert info["n_accounts"] == n_acc and info["n_slots"] == n_slots
+    assert info["n_proofs"] == n_acc + n_slots == len(expected)
+    assert info["n_roots"] == 1 + n_acc
+    assert info["roots"][0].tobytes().hex() == doc["stateRoot"][2:]
+    i = 0
+    for ai, a in enumerate(doc["accounts"]):
+        assert info["roots"][1 + ai].tobytes().hex() == a["storageHash"][2:]
+        proofs = [(0, bytes.fromhex(a["address"][2:]), a["accountProof"])]
+        for sp in a["storageProof"]:
+            proofs.append((1 + ai, int(sp["key"], 16).to_bytes(32, "big"), sp["proof"]))
+        for root, pre, nodes in proofs:
+            assert info["root_idx"][i] == root and info["account_of"][i] == ai
+            lo, hi = info["preimage_off"][i], info["preimage_off"][i + 1]
+            assert info["preimages"][lo:hi].tobytes() == pre
+            assert oracle.keccak256(pre) == keys[i]
+            f, l = info["proof_first_node"][i], info["proof_first_node"][i + 1]
+            assert l - f == len(nodes)
+            for j, nd in enumerate(nodes):
+                b, e = int(info["node_off"][f + j]), int(info["node_off"][f + j + 1])
+                assert info["nodes"][b:e].tobytes().hex() == nd[2:]
+            i += 1
+    assert i == info["n_proofs"]
+    w.close()
+
+
+def test_parsed_witness_verifies_on_the_oracle(EA, oracle):
+    """The packed arrays are what phant_mpt_verify_batch takes: feed them (with oracle-hashed keys) to the
+    CPU oracle and get the statuses the construction forces."""
+    rng = np.random.default_rng(8)
+    doc, expected, keys = block_witness_json(oracle, rng)
+    w = EA.ExecutionWitness.parse_json(json.dumps(doc, indent=1))  # whitespace everywhere
+    info = w.info()
+    st, _, _ = oracle.mpt_verify_batch(info["roots"].reshape(-1), info["root_idx"], np.frombuffer(b"".join(keys), np.uint8),
+                                       32, info["nodes"], info["node_off"], info["proof_first_node"])
+    assert st.tolist() == expected
+    w.close()
+
+
+def test_hex_conventions_and_unknown_members(EA):
+    root = "11" * 32
+    doc = {"stateRoot": root,  # no 0x prefix: hexutils.zig accepts both
+           "futureField": {"nested": [1, 2.5e3, True, None, "x\"y"]},
+           "accounts": [{"address": "0X" + "ab" * 20, "accountProof": ["0xc0", "0x0", ""], "nonce": "0x1",
+                         "storageProof": [{"key": "0x5", "proof": ["0x80"], "extra": []}], "x": None}]}
+    w = EA.ExecutionWitness.parse_json(json.dumps(doc))
+    info = w.info()
+    assert info["n_proofs"] == 2 and info["total_nodes"] == 4
+    assert np.diff(info["node_off"].astype(np.int64)).tolist() == [1, 0, 0, 1]   # "0x0" and "" are empty
+    assert info["preimages"][20:52].tobytes() == (5).to_bytes(32, "big")
+    # storageHash absent -> the empty trie root
+    assert info["roots"][1].tobytes().hex() == "56e81f171bcc55a6ff8345e692c0f86e5b48e01b996cadc001622fb5e363b421"
+    w.close()
+    assert EA.ExecutionWitness.parse_json('{"stateRoot":"0x' + root + '"}').info()["n_proofs"] == 0
+
+
+@pytest.mark.parametrize("text,needle", [
+    ('{"accounts": []}', "stateRoot"),
+    ('{"stateRoot": "0x1234", "accounts": []}', "stateRoot"),
+    ('{"stateRoot": "0x' + "00" * 32 + '", "accounts": [{"accountProof": []}]}', "address"),
+    ('{"stateRoot": "0x' + "00" * 32 + '", "accounts": [{"address": "0x' + "00" * 20 + '", "accountProof": ["0x123"]}]}', "hex"),
+    ('{"stateRoot": "0x' + "00" * 32 + '", "accounts": [{"address": "0x' + "00" * 20 + '", "accountProof": ["0xzz"]}]}', "hex"),
+    ('{"stateRoot": "0x' + "00" * 32 + '", "accounts": [{"address": "0x' + "00" * 20 + '", "accountProof": [], '
+     '"storageProof": [{"proof": []}]}]}', "key"),
+    ('{"stateRoot": "0x' + "00" * 32 + '", "accounts": [', "unexpected"),
+    ('{"stateRoot": "0x' + "00" * 32 + '"} trailing', "trailing"),
+    ('[]', "unexpected"),
+    ('', "unexpected"),
+])
+def test_malformed_documents_are_rejected(EA, text, needle):
+    with pytest.raises(EA.WitnessFormatError) as ei:
+        EA.ExecutionWitness.parse_json(text)
+    assert needle in str(ei.value), str(ei.value)
