@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"])
     ap.add_argument("--stream-proofs", type=int, default=20_000, help="proofs per streamed witness (config5)")
     ap.add_argument("--stream-slots", type=int, default=3, help="witnesses in flight (config5)")
-    ap.add_argument("--verify-mode", default="flat", choices=["flat", "overlap", "nodedup", "fused"],
+    ap.add_argument("--verify-mode", default="flat", choices=["flat", "pipelined", "overlap", "nodedup", "fused"],
                     help="flat = node-parallel pipeline with in-batch node dedup (default); overlap = the same with "
                          "the byte comparison on a helper stream next to the hashing; nodedup = same pipeline "
                          "hashing every shipped node (A/B); fused = one lane per proof (A/B)")
@@ -189,7 +189,8 @@ def main():
     # bound to torch's current stream on this device
     ctx = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"),
                             verify_nodedup=(args.verify_mode == "nodedup"),
-                            verify_overlap=(args.verify_mode == "overlap"))
+                            verify_overlap=(args.verify_mode == "overlap"),
+                            verify_pipelined=(args.verify_mode == "pipelined"))
 
     if args.workload == "config3":
         w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,

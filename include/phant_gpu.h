@@ -77,6 +77,8 @@ typedef struct phant_ctx phant_ctx;
                                      node-parallel pipeline (A/B and debugging) */
 #define PHANT_CTX_VERIFY_NODEDUP 4u /* flags: node-parallel pipeline, but hash every shipped node even
                                        when the batch carries byte-identical copies (A/B) */
+#define PHANT_CTX_VERIFY_PIPELINED 16u /* flags: node-parallel pipeline over two half batches, the second a
+                                          phase behind the first on a ctx-owned helper stream */
 #define PHANT_CTX_VERIFY_OVERLAP 8u /* flags: node-parallel pipeline with the byte comparison running on a
                                        ctx-owned helper stream next to the hashing instead of before it */
 

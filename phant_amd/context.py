@@ -17,7 +17,7 @@ class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
     def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
-                 verify_nodedup: bool = False, verify_overlap: bool = False):
+                 verify_nodedup: bool = False, verify_overlap: bool = False, verify_pipelined: bool = False):
         lib = L.lib()
         if not torch.cuda.is_available():
             raise L.PhantError(L.E_NO_DEVICE, "no GPU visible (phant_amd has no CPU fallback)")
@@ -34,6 +34,8 @@ class Context:
             flags |= 4  # PHANT_CTX_VERIFY_NODEDUP
         if verify_overlap:
             flags |= 8  # PHANT_CTX_VERIFY_OVERLAP
+        if verify_pipelined:
+            flags |= 16  # PHANT_CTX_VERIFY_PIPELINED
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
         h = C.c_void_p()
         rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))

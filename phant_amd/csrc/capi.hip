@@ -33,7 +33,7 @@ struct phant_ctx {
     bool verify_fused = false;
     phant::FlatMode flat_mode = phant::FLAT_SERIAL;
     // helper stream of the overlap pipeline (created on first use)
-    phant::FlatSide side{nullptr, nullptr, nullptr};
+    phant::FlatSide side{nullptr, nullptr, nullptr, nullptr};
     // streaming slots (phant_mpt_verify_submit / phant_wait): own stream, staging and workspace each
     struct Slot {
         hipStream_t stream = nullptr;
@@ -137,11 +137,13 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     phant::FlatMode flat = phant::FLAT_SERIAL;
     if (opts && (opts->flags & PHANT_CTX_VERIFY_NODEDUP)) flat = phant::FLAT_NODEDUP;
     if (opts && (opts->flags & PHANT_CTX_VERIFY_OVERLAP)) flat = phant::FLAT_OVERLAP;
+    if (opts && (opts->flags & PHANT_CTX_VERIFY_PIPELINED)) flat = phant::FLAT_PIPELINED;
     if (const char* m = std::getenv("PHANT_VERIFY_MODE")) {  // overrides the flags (A/B without touching callers)
         fused = std::strcmp(m, "fused") == 0;
         flat = std::strcmp(m, "nodedup") == 0   ? phant::FLAT_NODEDUP
-               : std::strcmp(m, "overlap") == 0 ? phant::FLAT_OVERLAP
-                                                : phant::FLAT_SERIAL;
+               : std::strcmp(m, "overlap") == 0   ? phant::FLAT_OVERLAP
+               : std::strcmp(m, "pipelined") == 0 ? phant::FLAT_PIPELINED
+                                                  : phant::FLAT_SERIAL;
     }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || dev < 0 || dev >= n) return PHANT_E_NO_DEVICE;
@@ -190,6 +192,7 @@ void phant_ctx_destroy(phant_ctx* c) {
     if (c->side.stream) (void)hipStreamSynchronize(c->side.stream);
     if (c->side.fork) (void)hipEventDestroy(c->side.fork);
     if (c->side.join) (void)hipEventDestroy(c->side.join);
+    if (c->side.mid) (void)hipEventDestroy(c->side.mid);
     if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -230,10 +233,11 @@ int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // the class cursors are words 0..7 of the verify workspace, the late-hash cursors of the overlap
-    // pipeline words 16..23 (mpt_verify_flat.hip)
-    uint32_t hdr[24];
+    // pipeline words 16..23, the second half's cursors of the pipelined mode words 64..71
+    // (mpt_verify_flat.hip)
+    uint32_t hdr[72];
     HIP_TRY(c, hipMemcpy(hdr, c->dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i) hashed[i] = hdr[i] + hdr[16 + i];
+    for (int i = 0; i < 8; ++i) hashed[i] = hdr[i] + hdr[16 + i] + hdr[64 + i];
     return PHANT_OK;
 }
 
@@ -320,6 +324,17 @@ int32_t phant_keccak256_with_prefix(phant_ctx* c, const uint8_t* prefix, uint64_
 
 /* ------------------------------------------------------- proof verification */
 
+// helper stream + events of the overlap / pipelined modes (created on first use)
+static int32_t ensure_side(phant_ctx* c) {
+    const bool need = !c->verify_fused && (c->flat_mode == phant::FLAT_OVERLAP || c->flat_mode == phant::FLAT_PIPELINED);
+    if (!need || c->side.stream) return PHANT_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->side.mid, hipEventDisableTiming));
+    return PHANT_OK;
+}
+
 // Runs the verify pipeline on device-resident arguments (shared by all forms) on stream `st` with the
 // workspace arena `dv`; `side` = helper stream of the overlap pipeline or nullptr (then it runs serially).
 static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes, hipStream_t st,
@@ -349,10 +364,9 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a, uint
 }
 
 static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes) {
-    if (!c->verify_fused && c->flat_mode == phant::FLAT_OVERLAP && !c->side.stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
+    {
+        const int32_t src = ensure_side(c);
+        if (src) return src;
     }
     return verify_resident_on(c, a, total_nodes, c->stream, c->dv, &c->side, true);
 }
@@ -440,10 +454,9 @@ int32_t phant_mpt_verify_batch(phant_ctx* c, const uint8_t* roots, uint32_t n_ro
         (nodes_len && !nodes))
         return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_batch: null pointer");
     DeviceGuard g(c->device);
-    if (!c->verify_fused && c->flat_mode == phant::FLAT_OVERLAP && !c->side.stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
+    {
+        const int32_t src = ensure_side(c);
+        if (src) return src;
     }
     const int32_t rc = verify_host_async(c, c->stream, c->ws.io, c->dv, &c->side, true, roots, n_roots, root_idx, keys,
                                          key_len, nodes, nodes_len, node_off, proof_first_node, n, status, value_off,
@@ -672,10 +685,9 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* sta
     // secure-trie keys: keccak256(address) / keccak256(slot), one batched launch
     HIP_TRY(c, phant::launch_keccak256_var(d_pre, d_poff, n, d_keys, s));
     phant::VerifyArgs a{d_roots, n_roots, d_ridx, d_keys, 32, d_nodes, nodes_len, d_noff, d_pfn, n, d_status, d_voff, d_vlen};
-    if (!c->verify_fused && c->flat_mode == phant::FLAT_OVERLAP && !c->side.stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
+    {
+        const int32_t src = ensure_side(c);
+        if (src) return src;
     }
     rc = verify_resident_on(c, a, total_nodes, s, c->dv, &c->side, true);
     if (rc) return rc;

@@ -28,18 +28,23 @@ struct VerifyArgs {
 };
 hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
 // re-verifies, one lane per proof, the proofs whose status byte is 0xff (the flat pipeline's
-// "could not settle from the tables" marker)
-hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, hipStream_t st);
+// "could not settle from the tables" marker) -- or every proof when one of the two device flags (may be
+// null) is set: a pipelined launch found proof_first_node going backwards, so a proof of one half may
+// have read nodes the other half had not finished
+hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, const uint32_t* all_flag_a, const uint32_t* all_flag_b,
+                                   hipStream_t st);
 // flat pipeline (plan -> dedup/compare -> class-sorted hashing of distinct nodes -> walk -> fixup);
 // ws = verify_flat_workspace_bytes().
 //   FLAT_SERIAL   compare, then hash, on one stream
 //   FLAT_NODEDUP  hash every shipped node (A/B)
 //   FLAT_OVERLAP  the byte comparison (an HBM stream) runs on `side->stream` NEXT TO the hashing of the
 //                 groups' representatives (integer-VALU-bound) instead of in front of it
-enum FlatMode : int { FLAT_SERIAL = 0, FLAT_NODEDUP = 1, FLAT_OVERLAP = 2 };
+//   FLAT_PIPELINED  two half batches, the second one a phase behind the first on `side->stream`: the
+//                 memory-bound kernels of one half run next to the VALU-bound hash of the other
+enum FlatMode : int { FLAT_SERIAL = 0, FLAT_NODEDUP = 1, FLAT_OVERLAP = 2, FLAT_PIPELINED = 3 };
 struct FlatSide {
-    hipStream_t stream;      // non-blocking helper stream owned by the ctx
-    hipEvent_t fork, join;   // timing-disabled events
+    hipStream_t stream;           // non-blocking helper stream owned by the ctx
+    hipEvent_t fork, join, mid;   // timing-disabled events
 };
 size_t verify_flat_workspace_bytes(uint32_t total_nodes);
 hipError_t launch_mpt_verify_flat(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, FlatMode mode,

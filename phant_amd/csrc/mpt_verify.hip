@@ -100,9 +100,12 @@ __global__ void __launch_bounds__(256) mpt_verify_fused_kernel(const VerifyArgs 
 
 // Second opinion for the flat pipeline: proofs it marked 0xff ("a representative was not
 // self-represented", see mpt_verify_flat.hip) are verified from scratch by one lane each.
-__global__ void __launch_bounds__(256) mpt_verify_fixup_kernel(const VerifyArgs a) {
+__global__ void __launch_bounds__(256) mpt_verify_fixup_kernel(const VerifyArgs a, const uint32_t* all_a,
+                                                               const uint32_t* all_b) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.n || a.status[i] != 0xffu) return;
+    if (i >= a.n) return;
+    const bool all = (all_a && *all_a) || (all_b && *all_b);
+    if (!all && a.status[i] != 0xffu) return;
     uint64_t voff;
     uint32_t vlen;
     const uint32_t st = verify_one(a, i, voff, vlen);
@@ -137,10 +140,11 @@ hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, hipStream_t st) {
+hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, const uint32_t* all_flag_a, const uint32_t* all_flag_b,
+                                   hipStream_t st) {
     if (a.n == 0) return hipSuccess;
     const uint32_t grid = (a.n + 255u) / 256u;
-    hipLaunchKernelGGL(mpt_verify_fixup_kernel, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mpt_verify_fixup_kernel, dim3(grid), dim3(256), 0, st, a, all_flag_a, all_flag_b);
     return hipGetLastError();
 }
 

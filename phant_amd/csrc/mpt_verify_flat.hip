@@ -102,6 +102,8 @@ struct FlatArgs {
     VerifyArgs v;
     uint32_t total_nodes;
     uint32_t dedup;          // 0: hash every node (A/B)
+    uint32_t half;           // 0: the whole batch; 1 / 2: first / second half of a pipelined launch
+    uint32_t p_mid;          // pipelined: first proof of the second half
     uint32_t cmp_prio;       // overlap mode: s_setprio level of the COMPARE waves (they share SIMDs with hash waves)
     uint64_t* table;         // tmask + 1 entries {fp:32 | node:32}, zeroed per call
     uint32_t tmask;
@@ -117,6 +119,24 @@ struct FlatArgs {
     uint32_t* late_ent;      // N_CLASS x total_nodes
     uint32_t* late_cursors;  // N_CLASS class counts; zeroed per call
 };
+
+// Pipelined launches cut the batch at proof p_mid: a half owns the proofs on its side and the NODES on its
+// side of proof_first_node[p_mid] (clamped), so that every node of the batch belongs to exactly one half
+// whatever proof_first_node looks like.
+PHANT_DEV void proof_range(const FlatArgs& a, uint32_t& lo, uint32_t& hi) {
+    lo = a.half == 2u ? a.p_mid : 0u;
+    hi = a.half == 1u ? a.p_mid : a.v.n;
+}
+PHANT_DEV void node_range(const FlatArgs& a, uint32_t& lo, uint32_t& hi) {
+    lo = 0u;
+    hi = a.total_nodes;
+    if (a.half) {
+        uint32_t mid = a.v.proof_first_node[a.p_mid];
+        mid = mid < a.total_nodes ? mid : a.total_nodes;
+        if (a.half == 1u) hi = mid;
+        else lo = mid;
+    }
+}
 
 // dedup_kernel flavours.  SERIAL: classify + compare + compact in one kernel, the hash kernel runs
 // after it.  CLASSIFY / COMPARE: the overlap pipeline -- CLASSIFY only consults the plan table and
@@ -139,8 +159,10 @@ constexpr uint32_t CURSOR_PFN_BROKEN = 9;  // word of the zeroed header: some pr
 constexpr uint32_t PLAN_BATCH = 8;  // even: a batch starts on a key byte
 
 __global__ void __launch_bounds__(256) plan_kernel(const FlatArgs a) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= a.v.n) return;
+    uint32_t p_lo, p_hi;
+    proof_range(a, p_lo, p_hi);
+    const uint32_t p = p_lo + blockIdx.x * 256u + threadIdx.x;
+    if (p >= p_hi) return;
     const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
     if (last < first) {
         // proof_first_node is not monotone: node ranges of OTHER proofs may then overlap, and a node stamped
@@ -214,20 +236,29 @@ PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len
 
 constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte path
 
+// Workgroups of 1 024 lanes: every workgroup ends with one returning atomicAdd per non-empty class on the
+// SAME few list cursors, and same-address atomics are served one at a time (~11.6 ns each,
+// tools/ubench/atomic_rate.hip): with 256-lane workgroups the 2 x 3 125 reservations of BASELINE config 3
+// alone took 36 us.
+constexpr uint32_t DEDUP_BLOCK = 1024;
+constexpr uint32_t DEDUP_WAVES = DEDUP_BLOCK / 64;
+
 template <int MODE>
-__global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
-    __shared__ uint32_t s_cnt[4][N_CLASS];
+__global__ void __launch_bounds__(DEDUP_BLOCK) dedup_kernel(const FlatArgs a) {
+    __shared__ uint32_t s_cnt[DEDUP_WAVES][N_CLASS];
     __shared__ uint32_t s_base[N_CLASS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t j = blockIdx.x * 256u + tid;
-    const uint32_t N = a.total_nodes;
-    if constexpr (MODE == DEDUP_COMPARE) {
-        // these waves issue a few instructions and then wait for memory; next to the hash waves (which
-        // never stop issuing) they would otherwise only get the leftover issue slots
-        if (a.cmp_prio == 1u) __builtin_amdgcn_s_setprio(1);
-        else if (a.cmp_prio == 2u) __builtin_amdgcn_s_setprio(2);
-        else if (a.cmp_prio >= 3u) __builtin_amdgcn_s_setprio(3);
-    }
+    uint32_t n_lo, n_hi;
+    node_range(a, n_lo, n_hi);
+    if (n_lo + blockIdx.x * DEDUP_BLOCK >= n_hi) return;  // (whole workgroup: the grid covers total_nodes)
+    const uint32_t j = n_lo + blockIdx.x * DEDUP_BLOCK + tid;
+    const uint32_t N = n_hi;        // nodes this launch owns end here ...
+    const uint32_t NT = a.total_nodes;  // ... ids and list strides are global
+    // next to hash waves (which never stop issuing) these waves -- a few instructions, then a wait for
+    // memory -- would otherwise only get the leftover issue slots
+    if (a.cmp_prio == 1u) __builtin_amdgcn_s_setprio(1);
+    else if (a.cmp_prio == 2u) __builtin_amdgcn_s_setprio(2);
+    else if (a.cmp_prio >= 3u) __builtin_amdgcn_s_setprio(3);
 
     // ---- lane-per-node metadata (coalesced) ----
     bool valid = false;
@@ -245,7 +276,7 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
                     // CLASSIFY left the representative in rep[] (already checked: in range, well formed,
                     // same length)
                     const uint32_t c = a.rep[j];
-                    if (c != j && c < N) {
+                    if (c != j && c < NT) {
                         cand = c;
                         cb = a.v.node_off[c];
                     }
@@ -254,7 +285,7 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
                     const uint32_t fp = gk_fp(h);
                     uint64_t en = a.table[gk_slot_a(h, a.tmask)];
                     if ((uint32_t)(en >> 32) != fp) en = a.table[gk_slot_b(h, a.tmask)];
-                    if ((uint32_t)(en >> 32) == fp && (uint32_t)en < N && (uint32_t)en != j) {
+                    if ((uint32_t)(en >> 32) == fp && (uint32_t)en < NT && (uint32_t)en != j) {
                         // a representative is only usable if it is a well-formed node of the same length
                         const uint32_t c = (uint32_t)en;
                         const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
@@ -346,14 +377,15 @@ __global__ void __launch_bounds__(256) dedup_kernel(const FlatArgs a) {
     }
     __syncthreads();
     if (tid < N_CLASS) {
-        const uint32_t tot = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < DEDUP_WAVES; ++w) tot += s_cnt[w][tid];
         s_base[tid] = tot ? atomicAdd(&cursors[tid], tot) : 0u;
     }
     __syncthreads();
     if (need) {
         uint32_t at = s_base[cls] + my_rank;
         for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
-        ent[(uint64_t)cls * N + at] = j;
+        ent[(uint64_t)cls * NT + at] = j;
     }
 }
 
@@ -598,8 +630,10 @@ PHANT_DEV uint32_t find_proof(const uint32_t* __restrict__ pfn, uint32_t n, uint
 }
 
 __global__ void __launch_bounds__(256) link_kernel(const FlatArgs a) {
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= a.total_nodes) return;
+    uint32_t n_lo, n_hi;
+    node_range(a, n_lo, n_hi);
+    const uint32_t j = n_lo + blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_hi) return;
     uint32_t code = LINK_GENERIC;
     const uint32_t m = a.meta[j];
     const uint64_t b = a.v.node_off[j], e = a.v.node_off[j + 1];
@@ -663,8 +697,10 @@ constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  
 
 __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
     __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.v.n) return;
+    uint32_t p_lo, p_hi;
+    proof_range(a, p_lo, p_hi);
+    const uint32_t i = p_lo + blockIdx.x * 256u + threadIdx.x;
+    if (i >= p_hi) return;
     uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
     const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
     const uint8_t* const nodes_end = a.v.nodes + a.v.nodes_len;
@@ -848,9 +884,11 @@ static uint32_t table_entries(uint32_t total_nodes) {
     return t;
 }
 
+constexpr size_t FLAT_HEADER_BYTES = 512;  // cursors (words 0..), late cursors (16..), second half's cursors (64..)
+
 size_t verify_flat_workspace_bytes(uint32_t total_nodes) {
     const size_t tn = total_nodes;
-    return 256 /*cursors + late cursors*/ + rnd256((size_t)table_entries(total_nodes) * 8) + rnd256(tn * 4) * 2 /*rep, meta*/ +
+    return FLAT_HEADER_BYTES + 2 * rnd256((size_t)table_entries(total_nodes) * 8) + rnd256(tn * 4) * 2 /*rep, meta*/ +
            rnd256(tn * 4 * N_CLASS) * 2 /*ent, late_ent*/ + rnd256(tn * 32) /*digest*/ + rnd256(tn * 8) /*gkey*/ + rnd256(tn) /*canon*/ + rnd256(tn + 16) /*link*/ + 1024;
 }
 
@@ -869,59 +907,100 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
                                   hipStream_t st, const FlatSide* side) {
     if (v.n == 0) return hipSuccess;
     const bool dedup = mode != FLAT_NODEDUP;
-    const bool overlap = mode == FLAT_OVERLAP && side && side->stream && side->fork && side->join;
+    const bool have_side = side && side->stream && side->fork && side->join;
+    const bool overlap = mode == FLAT_OVERLAP && have_side;
+    // two half batches, the second one a phase behind the first on the helper stream: worth it once a half
+    // still fills the chip
+    const bool pipelined = mode == FLAT_PIPELINED && have_side && side->mid && v.n >= env_u32("PHANT_PIPE_MIN_PROOFS", 16384u, 2u, 0xffffffffu);
     const size_t tn = total_nodes;
     FlatArgs a;
     a.v = v;
     a.total_nodes = total_nodes;
     a.dedup = dedup ? 1u : 0u;
+    a.half = 0;
+    a.p_mid = v.n / 2u;
     a.cmp_prio = env_u32("PHANT_CMP_PRIO", 3u, 0u, 3u);
     const uint32_t te = table_entries(total_nodes);
     uint8_t* p = ws;
     a.cursors = reinterpret_cast<uint32_t*>(p);
-    a.late_cursors = reinterpret_cast<uint32_t*>(p) + 16;  // same zeroed 256-byte header
-    p += 256;
+    a.late_cursors = reinterpret_cast<uint32_t*>(p) + 16;  // same zeroed header
+    uint32_t* const cursors_b = reinterpret_cast<uint32_t*>(p) + 64;  // second half of a pipelined launch
+    p += FLAT_HEADER_BYTES;
     a.table = reinterpret_cast<uint64_t*>(p);      p += rnd256((size_t)te * 8);
+    uint64_t* const table_b = reinterpret_cast<uint64_t*>(p); p += rnd256((size_t)te * 8);
     a.tmask = te - 1u;
     a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);  // zeroed with the header
     a.canon = p;                                   p += rnd256(tn);      // zeroed with the header
     a.rep = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4);
     a.ent = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4 * N_CLASS);
-    a.late_ent = reinterpret_cast<uint32_t*>(p);   p += rnd256(tn * 4 * N_CLASS);
+    a.late_ent = reinterpret_cast<uint32_t*>(p);   p += rnd256(tn * 4 * N_CLASS);  // overlap: late list; pipelined: second half
     a.digest = reinterpret_cast<uint32_t*>(p);     p += rnd256(tn * 32);
     a.gkey = reinterpret_cast<uint64_t*>(p);       p += rnd256(tn * 8);
     a.link = p;
-    // cursors, the table, the stamps and the canonical-form flags are contiguous: one memset
-    hipError_t e = hipMemsetAsync(ws, 0, 256 + rnd256((size_t)te * 8) + rnd256(tn * 4) + tn, st);
+    // header, both tables, the stamps and the canonical-form flags are contiguous: one memset
+    hipError_t e = hipMemsetAsync(ws, 0, FLAT_HEADER_BYTES + 2 * rnd256((size_t)te * 8) + rnd256(tn * 4) + tn, st);
     if (e != hipSuccess) return e;
     const uint32_t pg = (v.n + 255u) / 256u;
+    const uint32_t cus = compute_units();
+    const uint32_t ng = (total_nodes + 255u) / 256u;  // hash grid bound (64-node chunks, 4 waves) and link grid
+    const uint32_t dg = (total_nodes + DEDUP_BLOCK - 1u) / DEDUP_BLOCK;
+    // persistent hash grid: `wps` workgroups per CU = waves per SIMD; ~155 VGPRs admit 3.  (VALU issue is
+    // arbitrated oldest-first, so the third wave only adds ~12 % -- tools/ubench/hash_sched.hip -- but on
+    // BASELINE config 3 it is still worth 3 %: 0.289 ms against 0.298 ms for the serial pipeline.)  Whenever
+    // other kernels are meant to run NEXT TO the hash kernel it takes 2, which leaves them registers.
+    const uint32_t wps = env_u32("PHANT_HASH_WPS", (overlap || pipelined) ? 2u : 3u, 1u, 3u);
+    const uint32_t slots = wps * cus;
+    const uint32_t hg = ng + N_CLASS < slots ? ng + N_CLASS : slots;
+    auto launch_hash = [&](const FlatArgs& fa, hipStream_t s) {
+        hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, s, fa);
+    };
+    if (pipelined && total_nodes) {
+        // st   : plan A, dedup A,            hash A,  link A, walk A,           [join] fixup
+        // side :                 plan B, dedup B,     hash B,         link B, walk B
+        // B starts when A's dedup is done, so B's memory-bound kernels run next to A's VALU-bound hash, and
+        // A's latency-bound link / walk next to B's hash.
+        FlatArgs ha = a, hb = a;
+        ha.half = 1;
+        hb.half = 2;
+        hb.cursors = cursors_b;
+        hb.table = table_b;
+        hb.ent = a.late_ent;
+        const uint32_t pga = (a.p_mid + 255u) / 256u, pgb = (v.n - a.p_mid + 255u) / 256u;
+        hipLaunchKernelGGL(plan_kernel, dim3(pga), dim3(256), 0, st, ha);
+        hipLaunchKernelGGL(dedup_kernel<DEDUP_SERIAL>, dim3(dg), dim3(DEDUP_BLOCK), 0, st, ha);
+        if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
+        launch_hash(ha, st);
+        hipLaunchKernelGGL(plan_kernel, dim3(pgb), dim3(256), 0, side->stream, hb);
+        hipLaunchKernelGGL(dedup_kernel<DEDUP_SERIAL>, dim3(dg), dim3(DEDUP_BLOCK), 0, side->stream, hb);
+        // B's hash must not squeeze in before A's (A's link / walk are what should fill B's hash phase)
+        if ((e = hipEventRecord(side->mid, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side->stream, side->mid, 0)) != hipSuccess) return e;
+        launch_hash(hb, side->stream);
+        hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, ha);
+        hipLaunchKernelGGL(walk_proofs_kernel, dim3(pga), dim3(256), 0, st, ha);
+        hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, side->stream, hb);
+        hipLaunchKernelGGL(walk_proofs_kernel, dim3(pgb), dim3(256), 0, side->stream, hb);
+        if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
+        e = launch_mpt_verify_fixup(v, a.cursors + CURSOR_PFN_BROKEN, cursors_b + CURSOR_PFN_BROKEN, st);
+        if (e != hipSuccess) return e;
+        return hipGetLastError();
+    }
     if (total_nodes) {
-        const uint32_t ng = (total_nodes + 255u) / 256u;
-        // persistent hash grid: `wps` workgroups per CU = waves per SIMD; ~155 VGPRs admit 3.  (VALU issue is
-        // arbitrated oldest-first, so the third wave only adds ~12 % -- tools/ubench/hash_sched.hip -- but on
-        // BASELINE config 3 it is still worth 3 %: 0.289 ms against 0.298 ms for the pipeline.)  The overlap
-        // pipeline takes 2 so that COMPARE waves find room on the same SIMDs.
-        const uint32_t wps_serial = env_u32("PHANT_HASH_WPS", 3u, 1u, 3u);
-        const uint32_t wps_overlap = env_u32("PHANT_HASH_WPS", 2u, 1u, 3u);
-        const uint32_t wps = overlap ? wps_overlap : wps_serial;
-        const uint32_t slots = wps * compute_units();
-        const uint32_t hg = ng + N_CLASS < slots ? ng + N_CLASS : slots;
-        auto launch_hash = [&](const FlatArgs& fa, hipStream_t s) {
-            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, s, fa);
-        };
         hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
         if (!overlap) {
-            hipLaunchKernelGGL(dedup_kernel<DEDUP_SERIAL>, dim3(ng), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(dedup_kernel<DEDUP_SERIAL>, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);
             launch_hash(a, st);
         } else {
-            // COMPARE is capped at (160 KiB / lds) workgroups per CU by an otherwise unused dynamic LDS
-            // allocation, so it can never crowd the hash waves out of the wave slots
+            // COMPARE can be capped at (160 KiB / lds) workgroups per CU by an otherwise unused dynamic LDS
+            // allocation (0 = no cap; the s_setprio of its waves is what matters)
             const uint32_t cmp_lds = env_u32("PHANT_CMP_LDS_KB", 0u, 0u, 63u) * 1024u;
-            hipLaunchKernelGGL(dedup_kernel<DEDUP_CLASSIFY>, dim3(ng), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(dedup_kernel<DEDUP_CLASSIFY>, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);
             if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
             launch_hash(a, st);
-            hipLaunchKernelGGL(dedup_kernel<DEDUP_COMPARE>, dim3(ng), dim3(256), cmp_lds, side->stream, a);
+            hipLaunchKernelGGL(dedup_kernel<DEDUP_COMPARE>, dim3(dg), dim3(DEDUP_BLOCK), cmp_lds, side->stream, a);
             FlatArgs late = a;  // same kernel over the (normally empty) list of nodes that differed
             late.ent = a.late_ent;
             late.cursors = a.late_cursors;
@@ -929,11 +1008,11 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
             if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
         }
+        hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
     }
-    if (total_nodes) hipLaunchKernelGGL(link_kernel, dim3((total_nodes + 255u) / 256u), dim3(256), 0, st, a);
     hipLaunchKernelGGL(walk_proofs_kernel, dim3(pg), dim3(256), 0, st, a);
     if (dedup) {
-        e = launch_mpt_verify_fixup(v, st);
+        e = launch_mpt_verify_fixup(v, nullptr, nullptr, st);
         if (e != hipSuccess) return e;
     }
     return hipGetLastError();

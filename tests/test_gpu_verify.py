@@ -26,11 +26,12 @@ class _Mode:
         return self._mod.verify_batch_dev(*a, ctx=self._ctx, **k)
 
 
-@pytest.fixture(scope="module", params=["flat", "overlap", "nodedup", "fused"])
+@pytest.fixture(scope="module", params=["flat", "pipelined", "overlap", "nodedup", "fused"])
 def M(request):
     import phant_amd
     ctx = phant_amd.Context(verify_fused=(request.param == "fused"), verify_nodedup=(request.param == "nodedup"),
-                            verify_overlap=(request.param == "overlap"))
+                            verify_overlap=(request.param == "overlap"),
+                            verify_pipelined=(request.param == "pipelined"))
     yield _Mode(phant_amd.mpt, ctx)
     ctx.close()
 

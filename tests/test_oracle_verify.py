@@ -154,3 +154,23 @@ def test_batch_matches_single(oracle):
     assert (st == o.PROOF_PRESENT).all()
     for i, v in enumerate(vals):
         assert nodes[int(vo[i]):int(vo[i]) + int(vl[i])].tobytes() == v
+
+
+def test_batch_form_flags_backwards_proof_first_node(oracle):
+    """proof_first_node going backwards is BAD_INPUT for that proof, and the
+    proofs around it are judged on their own node ranges."""
+    import numpy as np
+    from tests.witness_util import random_kv, pack_proofs
+    rng = np.random.default_rng(3)
+    keys, vals = random_kv(rng, 40, 32, 1, 60)
+    t = oracle.Trie(keys, vals)
+    proofs = [t.prove(k) for k in keys[:6]]
+    nodes, node_off, pfn = pack_proofs(proofs)
+    good, _, _ = oracle.mpt_verify_batch(np.frombuffer(t.root(), np.uint8), None, np.frombuffer(b"".join(keys[:6]), np.uint8),
+                                         32, nodes, node_off, pfn)
+    assert (good == 1).all()
+    bad = pfn.copy()
+    bad[3] = bad[2] - 1  # proof 2 = [pfn2, pfn2 - 1): backwards
+    st, _, _ = oracle.mpt_verify_batch(np.frombuffer(t.root(), np.uint8), None, np.frombuffer(b"".join(keys[:6]), np.uint8),
+                                       32, nodes, node_off, bad)
+    assert st[2] == 21 and st[0] == 1 and st[1] == 1 and st[4] == 1 and st[5] == 1

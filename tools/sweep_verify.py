@@ -16,16 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 COMBOS = [
-    ("flat", {"PHANT_HASH_WPS": "2"}),
-    ("flat", {"PHANT_HASH_WPS": "3"}),
-    ("flat", {"PHANT_HASH_WPS": "2"}),
-    ("flat", {"PHANT_HASH_WPS": "3"}),
-    ("flat", {"PHANT_HASH_WPS": "2"}),
-    ("flat", {"PHANT_HASH_WPS": "3"}),
+    ("flat", {}),
+    ("pipelined", {}),
+    ("pipelined", {"PHANT_CMP_PRIO": "0"}),
+    ("pipelined", {"PHANT_HASH_WPS": "3"}),
+    ("flat", {}),
+    ("pipelined", {}),
     ("overlap", {}),
-    ("overlap", {"PHANT_HASH_WPS": "3"}),
-    ("nodedup", {"PHANT_HASH_WPS": "2"}),
-    ("nodedup", {"PHANT_HASH_WPS": "3"}),
+    ("nodedup", {}),
     ("fused", {}),
 ]
 KNOBS = ("PHANT_WALK_PF", "PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO")
@@ -51,7 +49,7 @@ def main():
             os.environ.pop(k, None)
         os.environ.update(env)
         ctx = phant_amd.Context(0, verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"),
-                                verify_overlap=(mode == "overlap"))
+                                verify_overlap=(mode == "overlap"), verify_pipelined=(mode == "pipelined"))
         status.fill_(0x77)
         for _ in range(3):
             M.verify_batch_dev(b, status=status, ctx=ctx)
