@@ -605,6 +605,74 @@ __global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- hash, one chunk per wave
+// The serial pipelines' hash kernel: wave q hashes chunk q (64 nodes of one rate-block class, long classes
+// first) and exits; the grid covers the worst case and the dispatcher keeps every SIMD full until the list
+// runs out (see launch_mpt_verify_flat).  No register prefetch of the next rate block: without the 34-dword
+// buffer the kernel fits 4 waves per SIMD (<= 128 VGPRs) instead of 3, and four waves hide a block's load
+// latency as well as the buffer did.
+__global__ void __launch_bounds__(256, 4) hash_chunk_kernel(const FlatArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t N = a.total_nodes;
+    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    // queue position -> class and this lane's slot in ent[]; a short last chunk repeats its last node (same
+    // digest stored twice) so that no lane is ever idle-masked
+    uint32_t cls = N_CLASS, idx = 0;
+#pragma unroll
+    for (int c = (int)N_CLASS - 1; c >= 0; --c) {
+        const uint32_t cnt = a.cursors[c];
+        const uint32_t chunks = (cnt + 63u) / 64u;
+        if (cls == N_CLASS) {
+            if (q < chunks) {
+                cls = (uint32_t)c;
+                idx = q * 64u + lane;
+                idx = idx < cnt ? idx : cnt - 1u;
+            } else {
+                q -= chunks;
+            }
+        }
+    }
+    if (cls == N_CLASS) return;
+    const uint32_t j = a.ent[(uint64_t)cls * N + idx];
+    const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
+    if (cls + 1u == N_CLASS || a.v.nodes_len < RATE) {
+        hash_one_node(a, j);  // 8 or more rate blocks (trip count differs per lane), or a tiny blob
+        return;
+    }
+    const uint64_t b = a.v.node_off[j];
+    uint32_t left = (uint32_t)(a.v.node_off[j + 1] - b);
+    const uint8_t* p = a.v.nodes + b;
+    const bool check = cls == BRANCH_LEN / RATE;  // 4-block chunks are where the 532-byte full branches are
+    uint32_t bad = left != BRANCH_LEN;
+    Sponge s;
+    sponge_zero(s);
+    // every node of class c has exactly c full rate blocks: wave-uniform trip count
+    for (uint32_t k = 0; k < cls; ++k) {
+        uint32_t d[RATE_DWORDS];
+        load_block_wide(d, p);
+        if (check) bad |= branch_block_bad(k, d);
+        xor_block(s, d);
+        keccak_f1600(s);
+        p += RATE;
+        left -= RATE;
+    }
+    if (p + RATE <= safe_end) {
+        uint32_t d[RATE_DWORDS];
+        load_block_wide(d, p);  // the whole window; bytes past the node are masked off
+        if (check) bad |= branch_block_bad(cls, d);
+        absorb_loaded_final(s, d, left);
+    } else {  // last node of the blob: narrow loads that never leave the message
+        const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+        absorb_final_block(s, reinterpret_cast<const uint32_t*>(p - sh), sh, left);
+        bad = 1u;  // not checked here: the walk decodes this one node the long way
+    }
+    keccak_f1600(s);
+    if (check && bad == 0u) a.canon[j] = 1;
+    uint4* o = reinterpret_cast<uint4*>(a.digest + 8ull * j);
+    o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+    o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+}
+
 // ---------------------------------------------------------------- link
 // One lane per node: is this node the one its parent commits to?  The parent of node j inside a proof is
 // node j - 1; if that is a canonical full branch, the reference it holds for this proof's key nibble
@@ -950,9 +1018,19 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
     // other kernels are meant to run NEXT TO the hash kernel it takes 2, which leaves them registers.
     const uint32_t wps = env_u32("PHANT_HASH_WPS", (overlap || pipelined) ? 2u : 3u, 1u, 3u);
     const uint32_t slots = wps * cus;
-    const uint32_t hg = ng + N_CLASS < slots ? ng + N_CLASS : slots;
+    // Serial pipelines: ONE chunk per wave, the grid covers the worst case (every node hashed; surplus
+    // workgroups exit at once) and the hardware dispatcher hands workgroups out as slots free up, long
+    // chunks first.  That beats any fixed deal over a persistent grid -- 126 vs 140 us for BASELINE config 3's
+    // permutations alone (tools/ubench/hash_dispatch.hip), 10 % at every scale: waves of one SIMD finish at
+    // very different times (oldest-first issue), and only the dispatcher refills a SIMD the moment a wave
+    // leaves.  When other kernels must share the SIMDs with the hash (overlap / pipelined) the grid stays
+    // persistent at `wps` workgroups per CU so that they find registers.
+    const bool persistent = env_u32("PHANT_HASH_PERSISTENT", (overlap || pipelined) ? 1u : 0u, 0u, 1u) != 0u;
+    const uint32_t hg = (!persistent || ng + N_CLASS < slots) ? ng + N_CLASS : slots;
+    const bool chunk_kernel = !persistent && env_u32("PHANT_HASH_CHUNK", 1u, 0u, 1u) != 0u;
     auto launch_hash = [&](const FlatArgs& fa, hipStream_t s) {
-        hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, s, fa);
+        if (chunk_kernel) hipLaunchKernelGGL(hash_chunk_kernel, dim3(hg), dim3(256), 0, s, fa);
+        else hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, s, fa);
     };
     if (pipelined && total_nodes) {
         // st   : plan A, dedup A,            hash A,  link A, walk A,           [join] fixup

@@ -17,16 +17,14 @@ sys.path.insert(0, ROOT)
 
 COMBOS = [
     ("flat", {}),
-    ("pipelined", {}),
-    ("pipelined", {"PHANT_CMP_PRIO": "0"}),
-    ("pipelined", {"PHANT_HASH_WPS": "3"}),
-    ("flat", {}),
+    ("flat", {"PHANT_HASH_CHUNK": "0"}),
+    ("flat", {"PHANT_HASH_PERSISTENT": "1"}),
     ("pipelined", {}),
     ("overlap", {}),
     ("nodedup", {}),
     ("fused", {}),
 ]
-KNOBS = ("PHANT_WALK_PF", "PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO")
+KNOBS = ("PHANT_WALK_PF", "PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO", "PHANT_HASH_PERSISTENT", "PHANT_HASH_CHUNK")
 
 
 def main():
