@@ -42,11 +42,12 @@ nd_f = mean_by_kernel(os.path.join(d, "nodedup_FETCH_SIZE.csv"))
 # + the 136-byte window of the last rate block reaching past the node (12 B per branch, 24 B per leaf)
 n = 100000
 known_hash = n * 3836 + 800000 * (16 + 4) + 700000 * 12 + 100000 * 24 + 700000 * 1
-f_hash = known_hash / nd_f["phant::hash_list_kernel"]
+hk = "phant::hash_chunk_kernel" if "phant::hash_chunk_kernel" in nd_f else "phant::hash_list_kernel"
+f_hash = known_hash / nd_f[hk]
 
 out = {"unit": "bytes per launch (100000 depth-8 proofs)", "factors": {
     "stream_read_uint4": round(f_stream, 3), "node_read_16B_per_lane": round(f_node, 3),
-    "hash_list_kernel (from nodedup known bytes)": round(f_hash, 3), "write": round(f_write, 3)}}
+    "hash kernel (from nodedup known bytes)": round(f_hash, 3), "write": round(f_write, 3)}}
 for mode in ("flat", "nodedup"):
     fr = mean_by_kernel(os.path.join(d, f"{mode}_FETCH_SIZE.csv"))
     wr = mean_by_kernel(os.path.join(d, f"{mode}_WRITE_SIZE.csv"))
@@ -55,11 +56,11 @@ for mode in ("flat", "nodedup"):
     for k in fr:
         if not k.startswith("phant::") or "keccak256_fixed" in k or "verdict" in k:
             continue
-        fac = f_node if "dedup_kernel" in k else f_hash if "hash_list" in k else 1.0
+        fac = f_node if "dedup_kernel" in k else f_hash if "hash_" in k else 1.0
         r = fr[k] * fac
         w = wr.get(k, 0.0) * f_write
         per[k] = {"read": round(r), "write": round(w), "read_factor": round(fac, 3),
-                  "calibrated": "dedup_kernel" in k or "hash_list" in k}
+                  "calibrated": "dedup_kernel" in k or "hash_" in k}
         tot_r += r
         tot_w += w
     out[mode] = {"read": round(tot_r), "write": round(tot_w), "total": round(tot_r + tot_w), "kernels": per}
