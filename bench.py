@@ -11,6 +11,8 @@ resident in HBM:
       proof shipped as its own node list, 0.5 % corrupted + 0.5 % exclusion
       proofs), reduce to one pass/fail word per root.
   config2: Keccak-256 of 1 048 576 x 136-byte messages (sponge kernel only).
+  nodeset: config 3's proofs as a node SET (every distinct node shipped once, references resolved by
+      hash; phant_mpt_verify_nodeset_dev).
   config5: consecutive block witnesses streamed from pinned host memory through
       phant_mpt_verify_submit / phant_wait (copy-in of witness k+1 overlaps the kernels of witness k);
       a step = one witness of --stream-proofs depth-8 proofs; PCIe-bound by construction.
@@ -64,7 +66,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5", "nodeset"])
     ap.add_argument("--stream-proofs", type=int, default=20_000, help="proofs per streamed witness (config5)")
     ap.add_argument("--stream-slots", type=int, default=3, help="witnesses in flight (config5)")
     ap.add_argument("--verify-mode", default="flat", choices=["flat", "pipelined", "overlap", "nodedup", "fused"],
@@ -214,6 +216,28 @@ def main():
         workload = (f"config3: {args.proofs} synthetic depth-{args.depth} account proofs per GPU against one state "
                     f"root ({w.nodes_per_proof - 1} x 532 B full branches + 112 B leaf, {w.bytes_per_proof} B and "
                     f"{w.perms_per_proof} Keccak-f per proof, 1% corrupted/exclusion, no cross-proof dedup)")
+    elif args.workload == "nodeset":
+        w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
+                                              world=world, ctx=ctx, corrupt_frac=0.0)
+        b = w.batch
+        set_nodes, set_off = phant_amd.witness.as_node_set(b, ctx=ctx)
+        n_units = b.n
+        alg_bytes = int(set_nodes.numel() + b.keys.numel() + n_units)
+        status = torch.empty(n_units, dtype=torch.uint8, device=dev)
+        fails = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def kernel_only():
+            M.verify_nodeset_dev(b.roots, None, b.keys, set_nodes, set_off, status=status, ctx=ctx)
+
+        def step():
+            kernel_only()
+            M.verdict_dev(status, None, 1, out=fails, ctx=ctx)
+            if world > 1:
+                dist.all_reduce(fails)
+
+        metric, unit = "mpt_keys_verified_per_sec_depth%d_nodeset" % args.depth, "proofs/s"
+        workload = (f"nodeset: {args.proofs} depth-{args.depth} keys per GPU against one state root, witness = the "
+                    f"{set_off.numel() - 1} distinct nodes shipped once ({set_nodes.numel()} B)")
     elif args.workload == "config5":
         # 4 distinct witnesses in pinned host memory, submitted round-robin; results land in pinned buffers
         from phant_amd import mpt as MM
@@ -282,6 +306,8 @@ def main():
         elapsed = float(t.item())
 
     # correctness of what was timed
+    if args.workload == "nodeset":
+        assert bool((status == 1).all()) and int(fails.item()) == 0, "node-set statuses differ from the expectation"
     if args.workload == "config3":
         assert torch.equal(status, w.expected), "verify statuses differ from the constructed expectation"
         exp_fail = torch.tensor([w.n_invalid], dtype=torch.int32, device=dev)
@@ -337,6 +363,8 @@ def main():
                                                         if args.workload == "config3" else None)) else None),
                      "traffic_detail": tr,
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
+                                "node-set pipeline = dedup_kernel (class lists) + hash_chunk_kernel + "
+                                "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
                                 "mpt_verify_fused_kernel" if args.verify_mode == "fused" else
                                 "verify pipeline = plan_kernel + dedup_kernel + hash_list_kernel + link_kernel + "
                                 "walk_proofs_kernel + mpt_verify_fixup_kernel (one launch of the path, first "
@@ -351,7 +379,7 @@ def main():
                         "note": "PCIe Gen5 x16 spec; the streamed rate is H2D-bound, the kernels of one witness "
                                 "take roofline.kernel_avg_ms"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.workload in ("config3", "config5"):
+        if args.workload in ("config3", "config5", "nodeset"):
             line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds)
         else:
             line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)

@@ -162,6 +162,24 @@ PHANT_API int32_t phant_mpt_verdict_dev(phant_ctx *ctx, const uint8_t *d_status,
                                         const uint32_t *d_root_idx, uint32_t n, uint32_t n_roots,
                                         uint32_t *d_fail_count);
 
+/* -------------------------------------------------------------- node-set witnesses
+ * The same verification for a witness that ships every trie node ONCE, in any order (SURVEY.md section
+ * 8f row 3, "dedup'd node-set verification"): `nodes` / `node_off` hold a SET of total_nodes nodes, there
+ * is no proof_first_node; every key is walked from its root and the node a 32-byte reference points to is
+ * the node of the set with that Keccak-256 digest.  Statuses as above, except that a reference nothing in
+ * the set hashes to gives MISSING_NODE, and BAD_HASH / EXTRA_NODES / INVALID_EMPTY cannot occur. */
+PHANT_API int32_t phant_mpt_verify_nodeset(phant_ctx *ctx, const uint8_t *roots, uint32_t n_roots,
+                                           const uint32_t *root_idx, const uint8_t *keys,
+                                           uint32_t key_len, const uint8_t *nodes, uint64_t nodes_len,
+                                           const uint64_t *node_off, uint32_t total_nodes, uint32_t n,
+                                           uint8_t *status, uint64_t *value_off, uint32_t *value_len);
+PHANT_API int32_t phant_mpt_verify_nodeset_dev(phant_ctx *ctx, const uint8_t *d_roots, uint32_t n_roots,
+                                               const uint32_t *d_root_idx, const uint8_t *d_keys,
+                                               uint32_t key_len, const uint8_t *d_nodes,
+                                               uint64_t nodes_len, const uint64_t *d_node_off,
+                                               uint32_t total_nodes, uint32_t n, uint8_t *d_status,
+                                               uint64_t *d_value_off, uint32_t *d_value_len);
+
 /* ------------------------------------------------------------------ streaming
  * BASELINE config 5 (consecutive block witnesses, H2D overlapped with verification): up to
  * PHANT_MAX_SLOTS host-form verifications in flight on one ctx, each on its own stream with its own

@@ -78,6 +78,10 @@ def lib():
                                                  C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                                  C.c_void_p]
         _lib.oracle_mpt_verify_batch.restype = None
+        _lib.oracle_mpt_verify_nodeset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                   C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p]
+        _lib.oracle_mpt_verify_nodeset.restype = C.c_int
         _lib.oracle_index_root_rlp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.oracle_index_root_rlp.restype = C.c_int
         _lib.oracle_index_root_be32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -220,6 +224,28 @@ def mpt_verify_batch(roots, root_idx, keys, key_len, nodes, node_off, proof_firs
     vlen = np.zeros(n, np.uint32)
     lib().oracle_mpt_verify_batch(_p(roots), None if ri is None else _p(ri), _p(keys), key_len, _p(nodes),
                                   _p(node_off), _p(pfn), n, _p(status), _p(voff), _p(vlen))
+    return status, voff, vlen
+
+
+def mpt_verify_nodeset(roots, root_idx, keys, key_len, nodes, node_off):
+    """Node-set form: `nodes`/`node_off` hold an unordered set of m nodes; every key is walked from its
+    root, children are looked up by hash."""
+    roots = np.ascontiguousarray(roots, np.uint8)
+    keys = np.ascontiguousarray(keys, np.uint8)
+    nodes = np.ascontiguousarray(nodes, np.uint8)
+    node_off = np.ascontiguousarray(node_off, np.uint64)
+    m = len(node_off) - 1
+    n = keys.size // key_len if key_len else 0
+    ri = None if root_idx is None else np.ascontiguousarray(root_idx, np.uint32)
+    if ri is not None:
+        n = len(ri)
+    status = np.zeros(n, np.uint8)
+    voff = np.zeros(n, np.uint64)
+    vlen = np.zeros(n, np.uint32)
+    rc = lib().oracle_mpt_verify_nodeset(_p(roots), None if ri is None else _p(ri), _p(keys), key_len, _p(nodes),
+                                         _p(node_off), m, n, _p(status), _p(voff), _p(vlen))
+    if rc:
+        raise MemoryError("oracle_mpt_verify_nodeset")
     return status, voff, vlen
 
 

@@ -102,6 +102,13 @@ enum {
 };
 
 /* Verify one proof.  value_off is relative to `nodes`. */
+/* Node-SET witnesses: the m nodes are an unordered set, every reference is resolved by hash
+ * (MISSING_NODE when no node of the set hashes to it; BAD_HASH / EXTRA_NODES / INVALID_EMPTY do not
+ * occur).  0 = ok, -1 = out of memory. */
+int oracle_mpt_verify_nodeset(const uint8_t *roots, const uint32_t *root_idx, const uint8_t *keys,
+                              uint32_t key_len, const uint8_t *nodes, const uint64_t *node_off,
+                              uint32_t m, uint32_t n, uint8_t *status, uint64_t *value_off,
+                              uint32_t *value_len);
 uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key,
                           uint32_t key_len, const uint8_t *nodes,
                           const uint64_t *node_off, uint32_t n_nodes,

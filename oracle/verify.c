@@ -30,6 +30,7 @@
  */
 #include "phant_oracle.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 typedef struct {
@@ -99,14 +100,40 @@ static int ref_kind(const rlp_item *it) {
     return REF_BAD;
 }
 
-uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key, uint32_t key_len,
-                          const uint8_t *nodes, const uint64_t *node_off, uint32_t n_nodes,
-                          uint64_t *value_off, uint32_t *value_len) {
+/* A node SET (witness that ships every node once, in any order): nodes are found by their hash.
+ * digests = n_nodes x 32, order = node indices sorted by digest (memcmp order). */
+typedef struct {
+    const uint8_t *digests;
+    const uint32_t *order;
+    uint32_t m;
+} nodeset;
+
+static int64_t nodeset_find(const nodeset *s, const uint8_t want[32]) {
+    uint32_t lo = 0, hi = s->m;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        int c = memcmp(s->digests + 32 * (size_t)s->order[mid], want, 32);
+        if (c == 0)
+            return (int64_t)s->order[mid];
+        if (c < 0)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return -1;
+}
+
+/* set == NULL: ordered proof.  set != NULL: the same walk, except that the node a
+ * 32-byte reference points to is looked up by hash -- absent => MISSING_NODE; there is no BAD_HASH, no
+ * EXTRA_NODES and no INVALID_EMPTY in that form. */
+static uint8_t verify_core(const uint8_t root[32], const uint8_t *key, uint32_t key_len,
+                           const uint8_t *nodes, const uint64_t *node_off, uint32_t n_nodes,
+                           const nodeset *set, uint64_t *value_off, uint32_t *value_len) {
     if (value_off)
         *value_off = 0;
     if (value_len)
         *value_len = 0;
-    if (n_nodes == 0)
+    if (n_nodes == 0 && !set)
         return ORACLE_PROOF_INVALID_EMPTY;
 
     const uint32_t nn = 2 * key_len;
@@ -122,7 +149,13 @@ uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key, uint32_t k
     size_t vlen = 0;
 
     for (;;) {
-        if (by_hash) {
+        if (by_hash && set) {
+            int64_t i = nodeset_find(set, want);
+            if (i < 0)
+                return ORACLE_PROOF_MISSING_NODE;
+            cur = nodes + node_off[i];
+            cur_len = (size_t)(node_off[i + 1] - node_off[i]);
+        } else if (by_hash) {
             if (used == n_nodes)
                 return ORACLE_PROOF_MISSING_NODE;
             cur = nodes + node_off[used];
@@ -235,7 +268,7 @@ uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key, uint32_t k
             by_hash = 0;
         }
     }
-    if (used != n_nodes)
+    if (!set && used != n_nodes)
         return ORACLE_PROOF_EXTRA_NODES;
     if (result == ORACLE_PROOF_PRESENT) {
         if (value_off)
@@ -244,6 +277,51 @@ uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key, uint32_t k
             *value_len = (uint32_t)vlen;
     }
     return result;
+}
+
+uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key, uint32_t key_len,
+                          const uint8_t *nodes, const uint64_t *node_off, uint32_t n_nodes,
+                          uint64_t *value_off, uint32_t *value_len) {
+    return verify_core(root, key, key_len, nodes, node_off, n_nodes, NULL, value_off, value_len);
+}
+
+static const uint8_t *g_sort_digests; /* qsort has no context argument; the oracle is single-threaded here */
+static int cmp_digest_idx(const void *a, const void *b) {
+    return memcmp(g_sort_digests + 32 * (size_t)*(const uint32_t *)a,
+                  g_sort_digests + 32 * (size_t)*(const uint32_t *)b, 32);
+}
+
+int oracle_mpt_verify_nodeset(const uint8_t *roots, const uint32_t *root_idx, const uint8_t *keys,
+                              uint32_t key_len, const uint8_t *nodes, const uint64_t *node_off,
+                              uint32_t m, uint32_t n, uint8_t *status, uint64_t *value_off,
+                              uint32_t *value_len) {
+    uint8_t *dig = (uint8_t *)malloc(32 * (size_t)(m ? m : 1));
+    uint32_t *order = (uint32_t *)malloc(4 * (size_t)(m ? m : 1));
+    if (!dig || !order) {
+        free(dig);
+        free(order);
+        return -1;
+    }
+    for (uint32_t i = 0; i < m; ++i) {
+        oracle_keccak256(nodes + node_off[i], (size_t)(node_off[i + 1] - node_off[i]), dig + 32 * (size_t)i);
+        order[i] = i;
+    }
+    g_sort_digests = dig;
+    qsort(order, m, sizeof(uint32_t), cmp_digest_idx);
+    nodeset set = {dig, order, m};
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t *root = roots + 32 * (size_t)(root_idx ? root_idx[i] : 0);
+        uint64_t vo = 0;
+        uint32_t vl = 0;
+        status[i] = verify_core(root, keys + (size_t)key_len * i, key_len, nodes, node_off, m, &set, &vo, &vl);
+        if (value_off)
+            value_off[i] = vo;
+        if (value_len)
+            value_len[i] = vl;
+    }
+    free(dig);
+    free(order);
+    return 0;
 }
 
 void oracle_mpt_verify_batch(const uint8_t *roots, const uint32_t *root_idx, const uint8_t *keys,

@@ -466,6 +466,68 @@ int32_t phant_mpt_verify_batch(phant_ctx* c, const uint8_t* roots, uint32_t n_ro
     return PHANT_OK;
 }
 
+/* -------------------------------------------------------------- node-set witnesses */
+
+int32_t phant_mpt_verify_nodeset_dev(phant_ctx* c, const uint8_t* d_roots, uint32_t n_roots, const uint32_t* d_root_idx,
+                                     const uint8_t* d_keys, uint32_t key_len, const uint8_t* d_nodes, uint64_t nodes_len,
+                                     const uint64_t* d_node_off, uint32_t total_nodes, uint32_t n, uint8_t* d_status,
+                                     uint64_t* d_value_off, uint32_t* d_value_len) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!d_roots || n_roots == 0 || !d_node_off || !d_status || (key_len && !d_keys) || key_len > 0x3fffffffu)
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset_dev: bad argument");
+    DeviceGuard g(c->device);
+    const size_t need = phant::verify_nodeset_workspace_bytes(total_nodes);
+    if (need > c->dv.cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipError_t e = c->dv.reset(need);
+        if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(verify workspace)", e);
+    }
+    phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len, d_node_off, nullptr, n,
+                        d_status, d_value_off, d_value_len};
+    TimedRegion t(c);
+    HIP_TRY(c, phant::launch_mpt_verify_nodeset(a, total_nodes, c->dv.base, c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_mpt_verify_nodeset(phant_ctx* c, const uint8_t* roots, uint32_t n_roots, const uint32_t* root_idx,
+                                 const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
+                                 const uint64_t* node_off, uint32_t total_nodes, uint32_t n, uint8_t* status,
+                                 uint64_t* value_off, uint32_t* value_len) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!roots || n_roots == 0 || !node_off || !status || (key_len && !keys) || (nodes_len && !nodes))
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset: null pointer");
+    DeviceGuard g(c->device);
+    hipStream_t s = c->stream;
+    const size_t need = ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) + ws_round((size_t)n * key_len + 4) +
+                        ws_round((size_t)nodes_len + 16) + ws_round(((size_t)total_nodes + 1) * 8) + ws_round(n) +
+                        ws_round((size_t)n * 8) + ws_round((size_t)n * 4);
+    int32_t rc = ws_reset(c, need);
+    if (rc) return rc;
+    uint8_t* d_roots = ws_take<uint8_t>(c, (size_t)n_roots * 32);
+    uint32_t* d_ridx = ws_take<uint32_t>(c, n);
+    uint8_t* d_keys = ws_take<uint8_t>(c, (size_t)n * key_len + 4);
+    uint8_t* d_nodes = ws_take<uint8_t>(c, (size_t)nodes_len + 16);
+    uint64_t* d_noff = ws_take<uint64_t>(c, (size_t)total_nodes + 1);
+    uint8_t* d_status = ws_take<uint8_t>(c, n);
+    uint64_t* d_voff = ws_take<uint64_t>(c, n);
+    uint32_t* d_vlen = ws_take<uint32_t>(c, n);
+    HIP_TRY(c, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 32, hipMemcpyHostToDevice, s));
+    if (root_idx) HIP_TRY(c, hipMemcpyAsync(d_ridx, root_idx, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
+    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nodes_len, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_noff, node_off, ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
+    rc = phant_mpt_verify_nodeset_dev(c, d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
+                                      d_noff, total_nodes, n, d_status, d_voff, d_vlen);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
+    if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (value_len) HIP_TRY(c, hipMemcpyAsync(value_len, d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return PHANT_OK;
+}
+
 /* ------------------------------------------------------------------ streaming */
 
 int32_t phant_host_alloc(phant_ctx* c, size_t bytes, void** out) {

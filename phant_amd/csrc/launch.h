@@ -49,6 +49,9 @@ struct FlatSide {
 size_t verify_flat_workspace_bytes(uint32_t total_nodes);
 hipError_t launch_mpt_verify_flat(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, FlatMode mode,
                                   hipStream_t st, const FlatSide* side);
+// node-SET witnesses (every node shipped once, any order; references resolved by hash)
+size_t verify_nodeset_workspace_bytes(uint32_t total_nodes);
+hipError_t launch_mpt_verify_nodeset(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, hipStream_t st);
 hipError_t launch_mpt_verdict(const uint8_t* d_status, const uint32_t* d_root_idx, uint32_t n,
                               uint32_t n_roots, uint32_t* d_fail_count, hipStream_t st);
 

@@ -932,6 +932,155 @@ __global__ void __launch_bounds__(256) walk_proofs_kernel(const FlatArgs a) {
     if (a.v.value_len) a.v.value_len[i] = vlen;
 }
 
+// ---------------------------------------------------------------- node-set witnesses
+// A witness that ships every node ONCE, in any order (what a block builder that deduplicates its proofs
+// sends): references are resolved by hash.  hash every node (the same class lists + hash_chunk_kernel as
+// the serial pipeline, nothing to deduplicate), put digest -> node into an open-addressing table, then
+// one lane per key walks from its root.  Semantics: DESIGN.md section 3 with "the node a 32-byte reference
+// points to" = the node of the set with that digest (none: MISSING_NODE; BAD_HASH / EXTRA_NODES /
+// INVALID_EMPTY cannot occur).
+constexpr uint32_t SET_EMPTY = 0xffffffffu;
+
+__global__ void __launch_bounds__(256) nodeset_insert_kernel(const FlatArgs a, uint32_t* tab, uint32_t tab_mask) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= a.total_nodes) return;
+    const uint64_t b = a.v.node_off[j], e = a.v.node_off[j + 1];
+    if (!(e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull)) return;  // never hashed: not in the set
+    uint32_t slot = a.digest[8ull * j] & tab_mask;
+    for (;;) {  // the table has >= 2 x total_nodes slots: terminates
+        const uint32_t prev = atomicCAS(&tab[slot], SET_EMPTY, j);
+        if (prev == SET_EMPTY) return;
+        // an identical node already there: one of them is enough (same digest => same bytes, up to Keccak)
+        const uint4* x = reinterpret_cast<const uint4*>(a.digest + 8ull * prev);
+        const uint4* y = reinterpret_cast<const uint4*>(a.digest + 8ull * j);
+        const uint4 x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+        if (((x0.x ^ y0.x) | (x0.y ^ y0.y) | (x0.z ^ y0.z) | (x0.w ^ y0.w) | (x1.x ^ y1.x) | (x1.y ^ y1.y) | (x1.z ^ y1.z) |
+             (x1.w ^ y1.w)) == 0u)
+            return;
+        slot = (slot + 1u) & tab_mask;
+    }
+}
+
+// the node of the set whose digest is want[], or SET_EMPTY
+PHANT_DEV uint32_t nodeset_find(const FlatArgs& a, const uint32_t* __restrict__ tab, uint32_t tab_mask,
+                                const uint32_t (&want)[8]) {
+    uint32_t slot = want[0] & tab_mask;
+    for (;;) {
+        const uint32_t j = tab[slot];
+        if (j == SET_EMPTY) return SET_EMPTY;
+        const uint4* x = reinterpret_cast<const uint4*>(a.digest + 8ull * j);
+        const uint4 x0 = x[0], x1 = x[1];
+        if (((x0.x ^ want[0]) | (x0.y ^ want[1]) | (x0.z ^ want[2]) | (x0.w ^ want[3]) | (x1.x ^ want[4]) | (x1.y ^ want[5]) |
+             (x1.z ^ want[6]) | (x1.w ^ want[7])) == 0u)
+            return j;
+        slot = (slot + 1u) & tab_mask;
+    }
+}
+
+__global__ void __launch_bounds__(256) nodeset_walk_kernel(const FlatArgs a, const uint32_t* tab, uint32_t tab_mask) {
+    __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.v.n) return;
+    uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
+    const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
+    const uint8_t* const nodes_end = a.v.nodes + a.v.nodes_len;
+    uint64_t voff = 0;
+    uint32_t vlen = 0, status = 0xffffffffu;
+    const uint32_t r = a.v.root_idx ? a.v.root_idx[i] : 0u;
+    if (r >= a.v.n_roots) {
+        status = PHANT_PROOF_BAD_INPUT;
+    } else {
+        const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * i;
+        const uint32_t nn = 2u * a.v.key_len;
+        const uint8_t* const slot_key = reinterpret_cast<const uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+        const bool key_in_lds = a.v.key_len <= WALK_KEY_BYTES;
+        if (key_in_lds) {
+            uint8_t* kdst = reinterpret_cast<uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+            for (uint32_t t = 0; t < a.v.key_len; ++t) kdst[t] = key[t];
+        }
+        uint32_t want[8];
+        {
+            GlobalBytes rb{a.v.roots + 32ull * r};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
+        }
+        WalkState w;
+        w.pos = 0;
+        w.status = PHANT_PROOF_BAD_INPUT;
+        w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
+        bool by_hash = true;
+        const uint8_t* cur = nullptr;
+        uint32_t cur_len = 0;
+        const uint8_t* staged_from = nullptr;
+        for (;;) {
+            if (by_hash) {
+                const uint32_t j = nodeset_find(a, tab, tab_mask, want);
+                if (j == SET_EMPTY) {
+                    status = PHANT_PROOF_MISSING_NODE;
+                    break;
+                }
+                const uint64_t b = a.v.node_off[j];
+                cur = a.v.nodes + b;
+                cur_len = (uint32_t)(a.v.node_off[j + 1] - b);
+                // a canonical full branch (checked by the wave that hashed it): the next reference is slot
+                // nib of the node, no decoding
+                if (a.canon[j] && w.pos < nn) {
+                    const uint32_t nib = key_in_lds ? key_nibble(slot_key, w.pos) : key_nibble(key, w.pos);
+                    const uint8_t* rb = cur + (4u + 33u * nib);
+                    const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
+                    want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
+                    want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
+                    w.pos += 1;
+                    continue;
+                }
+                staged_from = nullptr;
+                const uint32_t padded = (cur_len + 15u) & ~15u;
+                if (cur_len <= WALK_STAGE_BYTES && cur + padded <= nodes_end) {
+                    for (uint32_t o = 0; o < padded; o += 16u) {
+                        const uint4 q = load16u(cur + o);
+                        slot[o / 4u] = q.x;
+                        slot[o / 4u + 1u] = q.y;
+                        slot[o / 4u + 2u] = q.z;
+                        slot[o / 4u + 3u] = q.w;
+                    }
+                    staged_from = cur;
+                }
+            }
+            auto step_from = [&](const uint8_t* nb, const uint8_t* kp) __attribute__((always_inline)) -> uint32_t {
+                GlobalBytes nd{nb};
+                const uint32_t st = walk_node(nd, cur_len, kp, nn, w);
+                if (st == STEP_HASH) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) want[k] = nd.u32(w.ref_pay + 4 * k);
+                }
+                return st;
+            };
+            uint32_t step;
+            if (!key_in_lds) step = step_from(cur, key);
+            else if (staged_from) step = step_from(slot_node + (cur - staged_from), slot_key);
+            else step = step_from(cur, slot_key);
+            if (step == STEP_DONE) break;
+            if (step == STEP_HASH) {
+                by_hash = true;
+            } else {
+                cur = cur + w.ref_pay;
+                cur_len = w.ref_total;
+                by_hash = false;
+            }
+        }
+        if (status == 0xffffffffu) {
+            status = w.status;
+            if (status == PHANT_PROOF_PRESENT) {
+                voff = (uint64_t)(cur - a.v.nodes) + w.value_pay;
+                vlen = w.value_len;
+            }
+        }
+    }
+    a.v.status[i] = (uint8_t)status;
+    if (a.v.value_off) a.v.value_off[i] = voff;
+    if (a.v.value_len) a.v.value_len[i] = vlen;
+}
+
 // ---------------------------------------------------------------- host side
 static size_t rnd256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -1095,5 +1244,62 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
     }
     return hipGetLastError();
 }
+
+static uint32_t nodeset_table_entries(uint32_t total_nodes) {
+    uint32_t t = 1024;
+    while (t < 2u * total_nodes && t < (1u << 31)) t <<= 1;
+    return t;
+}
+
+size_t verify_nodeset_workspace_bytes(uint32_t total_nodes) {
+    return verify_flat_workspace_bytes(total_nodes) + rnd256((size_t)nodeset_table_entries(total_nodes) * 4);
+}
+
+hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, hipStream_t st) {
+    if (v.n == 0) return hipSuccess;
+    const size_t tn = total_nodes;
+    FlatArgs a;
+    a.v = v;
+    a.total_nodes = total_nodes;
+    a.dedup = 0;
+    a.half = 0;
+    a.p_mid = 0;
+    a.cmp_prio = 0;
+    // the flat pipeline's layout, of which this path uses the header, the stamps (all zero: no groups), the
+    // canonical-form flags, the class lists and the digests
+    const uint32_t te = table_entries(total_nodes);
+    uint8_t* p = ws;
+    a.cursors = reinterpret_cast<uint32_t*>(p);
+    a.late_cursors = reinterpret_cast<uint32_t*>(p) + 16;
+    p += FLAT_HEADER_BYTES;
+    a.table = reinterpret_cast<uint64_t*>(p);      p += 2 * rnd256((size_t)te * 8);
+    a.tmask = te - 1u;
+    a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);
+    a.canon = p;                                   p += rnd256(tn);
+    a.rep = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4);
+    a.ent = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4 * N_CLASS);
+    a.late_ent = reinterpret_cast<uint32_t*>(p);   p += rnd256(tn * 4 * N_CLASS);
+    a.digest = reinterpret_cast<uint32_t*>(p);     p += rnd256(tn * 32);
+    a.gkey = reinterpret_cast<uint64_t*>(p);       p += rnd256(tn * 8);
+    a.link = p;
+    uint32_t* tab = reinterpret_cast<uint32_t*>(ws + verify_flat_workspace_bytes(total_nodes));
+    const uint32_t tab_entries = nodeset_table_entries(total_nodes);
+    hipError_t e = hipMemsetAsync(ws, 0, FLAT_HEADER_BYTES, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.meta, 0, rnd256(tn * 4) + tn, st);  // stamps + canon
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(tab, 0xff, (size_t)tab_entries * 4, st);
+    if (e != hipSuccess) return e;
+    if (total_nodes) {
+        const uint32_t ng = (total_nodes + 255u) / 256u;
+        const uint32_t dg = (total_nodes + DEDUP_BLOCK - 1u) / DEDUP_BLOCK;
+        hipLaunchKernelGGL(dedup_kernel<DEDUP_SERIAL>, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);  // class lists only
+        hipLaunchKernelGGL(hash_chunk_kernel, dim3(ng + N_CLASS), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(nodeset_insert_kernel, dim3(ng), dim3(256), 0, st, a, tab, tab_entries - 1u);
+    }
+    hipLaunchKernelGGL(nodeset_walk_kernel, dim3((v.n + 255u) / 256u), dim3(256), 0, st, a, tab, tab_entries - 1u);
+    return hipGetLastError();
+}
+
 
 }  // namespace phant

@@ -256,3 +256,45 @@ def verify_submit(hw: HostWitness, slot: int, ctx: Context | None = None) -> Non
 def wait(slot: int, ctx: Context | None = None) -> None:
     ctx = ctx or default_context()
     ctx.check(ctx._lib.phant_wait(ctx.handle, slot))
+
+
+# ---------------------------------------------------------------------------- node-set witnesses
+def verify_nodeset(roots, root_idx, keys, key_len, nodes, node_off, ctx: Context | None = None):
+    """Host form of phant_mpt_verify_nodeset: `nodes` / `node_off` are an unordered SET of trie nodes, every
+    key is walked from its root with references resolved by hash.
+    numpy in -> (status u8[n], value_off u64[n], value_len u32[n])."""
+    ctx = ctx or default_context()
+    roots = np.ascontiguousarray(roots, np.uint8).reshape(-1)
+    n_roots = roots.size // 32
+    keys = np.ascontiguousarray(keys, np.uint8).reshape(-1)
+    nodes = np.ascontiguousarray(nodes, np.uint8).reshape(-1)
+    nodes_len = nodes.size
+    node_off = np.ascontiguousarray(node_off, np.uint64)
+    total_nodes = len(node_off) - 1
+    ri = None if root_idx is None else np.ascontiguousarray(root_idx, np.uint32)
+    n = len(ri) if ri is not None else (keys.size // key_len if key_len else 0)
+    if nodes.size == 0:
+        nodes = np.zeros(1, np.uint8)
+    if keys.size == 0:
+        keys = np.zeros(1, np.uint8)
+    status = np.zeros(max(n, 1), np.uint8)
+    voff = np.zeros(max(n, 1), np.uint64)
+    vlen = np.zeros(max(n, 1), np.uint32)
+    ctx.check(ctx._lib.phant_mpt_verify_nodeset(
+        ctx.handle, _np_ptr(roots), n_roots, None if ri is None else _np_ptr(ri), _np_ptr(keys), key_len,
+        _np_ptr(nodes), nodes_len, _np_ptr(node_off), total_nodes, n, _np_ptr(status), _np_ptr(voff), _np_ptr(vlen)))
+    return status[:n], voff[:n], vlen[:n]
+
+
+def verify_nodeset_dev(roots: torch.Tensor, root_idx: torch.Tensor | None, keys: torch.Tensor, nodes: torch.Tensor,
+                       node_off: torch.Tensor, status: torch.Tensor | None = None, ctx: Context | None = None) -> torch.Tensor:
+    """Device form, asynchronous on the ctx stream.  keys (n, key_len) u8, node_off (m + 1,) i64."""
+    ctx = ctx or default_context(nodes.device.index)
+    n = keys.shape[0]
+    if status is None:
+        status = torch.empty(n, dtype=torch.uint8, device=nodes.device)
+    ctx.check(ctx._lib.phant_mpt_verify_nodeset_dev(
+        ctx.handle, roots.data_ptr(), roots.numel() // 32, None if root_idx is None else root_idx.data_ptr(),
+        keys.data_ptr(), keys.shape[1], nodes.data_ptr(), nodes.numel(), node_off.data_ptr(), node_off.numel() - 1, n,
+        status.data_ptr(), None, None))
+    return status

@@ -181,3 +181,24 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
     perms = L * ((BRANCH_LEN + 1 + 135) // 136) + (leaf_len + 1 + 135) // 136
     return Witness(batch=batch, expected=expected, n_invalid=n_invalid, nodes_per_proof=depth,
                    bytes_per_proof=proof_bytes + 32, perms_per_proof=perms, seed=seed)
+
+
+def as_node_set(batch: ProofBatch, ctx=None):
+    """The distinct nodes of a per-proof witness, each shipped once: -> (nodes u8[], node_off i64[m + 1]).
+    Distinctness by Keccak-256 digest (computed with the product's batched kernel), first occurrence kept."""
+    from .crypto.hasher import keccak256_batch_dev
+    dig = keccak256_batch_dev(batch.nodes, batch.node_off, ctx=ctx)
+    d = dig.view(torch.int64)
+    # lexicographic sort on the four 64-bit words (stable sorts, least significant key first)
+    order = torch.arange(d.shape[0], device=d.device)
+    for c in (3, 2, 1, 0):
+        order = order[torch.argsort(d[order, c], stable=True)]
+    ds = d[order]
+    first = torch.ones(order.numel(), dtype=torch.bool, device=d.device)
+    first[1:] = (ds[1:] != ds[:-1]).any(dim=1)
+    keep = torch.sort(order[first]).values
+    lens = (batch.node_off[1:] - batch.node_off[:-1])[keep]
+    off = torch.zeros(keep.numel() + 1, dtype=torch.int64, device=d.device)
+    off[1:] = torch.cumsum(lens, 0)
+    idx = torch.repeat_interleave(batch.node_off[keep] - off[:-1], lens) + torch.arange(int(off[-1]), device=d.device)
+    return batch.nodes[idx].contiguous(), off

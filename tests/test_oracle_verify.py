@@ -174,3 +174,36 @@ def test_batch_form_flags_backwards_proof_first_node(oracle):
     st, _, _ = oracle.mpt_verify_batch(np.frombuffer(t.root(), np.uint8), None, np.frombuffer(b"".join(keys[:6]), np.uint8),
                                        32, nodes, node_off, bad)
     assert st[2] == 21 and st[0] == 1 and st[1] == 1 and st[4] == 1 and st[5] == 1
+
+
+def test_nodeset_form_agrees_with_ordered_proofs(oracle):
+    """A node SET built from the proofs of a batch verifies every key to the status its ordered proof
+    gets; a reference nothing in the set hashes to is MISSING_NODE; extra nodes in the set are harmless."""
+    import numpy as np
+    from tests.witness_util import random_kv, pack_proofs, node_set
+    rng = np.random.default_rng(12)
+    keys, vals = random_kv(rng, 300, 32, 1, 70)
+    t = oracle.Trie(keys, vals)
+    q = list(keys[:200]) + [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(60)]
+    proofs = [t.prove(k) for k in q]
+    nodes, node_off, pfn = pack_proofs(proofs)
+    root = np.frombuffer(t.root(), np.uint8)
+    karr = np.frombuffer(b"".join(q), np.uint8)
+    ordered, ovo, ovl = oracle.mpt_verify_batch(root, None, karr, 32, nodes, node_off, pfn)
+    sblob, soff = node_set(proofs, rng)
+    assert len(soff) - 1 < len(node_off) - 1  # the set is smaller than the shipped proofs
+    st, vo, vl = oracle.mpt_verify_nodeset(root, None, karr, 32, sblob, soff)
+    assert np.array_equal(st, ordered) and np.array_equal(vl, ovl)
+    for i in range(len(q)):  # same value bytes, wherever they sit
+        assert sblob[int(vo[i]):int(vo[i]) + int(vl[i])].tobytes() == nodes[int(ovo[i]):int(ovo[i]) + int(ovl[i])].tobytes()
+    # drop one leaf-level node: exactly the keys that pass through it lose their way
+    victim = proofs[0][-1]
+    kept = [nd for nd in dict.fromkeys(nd for p in proofs for nd in p) if nd != victim]
+    koff = np.zeros(len(kept) + 1, np.uint64)
+    koff[1:] = np.cumsum([len(x) for x in kept])
+    st2, _, _ = oracle.mpt_verify_nodeset(root, None, karr, 32, np.frombuffer(b"".join(kept), np.uint8), koff)
+    hit = np.array([victim in p for p in proofs])
+    assert (st2[hit] == 20).all() and np.array_equal(st2[~hit], ordered[~hit])
+    # empty set: nothing hashes to the root
+    st3, _, _ = oracle.mpt_verify_nodeset(root, None, karr[:64], 32, np.zeros(1, np.uint8), np.zeros(1, np.uint64))
+    assert (st3 == 20).all()

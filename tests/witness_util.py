@@ -166,3 +166,15 @@ def block_witness_json(oracle, rng, n_accounts=300, n_contracts=12, max_slots=12
     expected.append(2)
     keys.append(gk)
     return doc, expected, keys
+
+
+def node_set(proofs, rng=None):
+    """Union of the nodes of `proofs`, each node once, shuffled: -> (nodes u8[], node_off u64[m+1])."""
+    uniq = list(dict.fromkeys(nd for p in proofs for nd in p))
+    if rng is not None:
+        uniq = [uniq[i] for i in rng.permutation(len(uniq))]
+    off = np.zeros(len(uniq) + 1, np.uint64)
+    if uniq:
+        off[1:] = np.cumsum([len(x) for x in uniq])
+    blob = np.frombuffer(b"".join(uniq), np.uint8).copy() if uniq else np.zeros(0, np.uint8)
+    return blob, off
