@@ -255,6 +255,25 @@ PHANT_API int32_t phant_index_root_rlp(phant_ctx *ctx, const uint8_t *items,
 PHANT_API int32_t phant_index_root_be32(phant_ctx *ctx, const uint8_t *items,
                                         const uint64_t *item_off, uint32_t n, uint8_t out[32]);
 
+/* ------------------------------------------- sharded trie roots (multi-GPU mptize)
+ * a trie shards by the top key nibble -- 16 sub-tries, one exchange of <= 33-byte
+ * child references, then the root branch.  A rank calls phant_mpt_root_nodes over its sub-tries (one
+ * segment per top nibble, all keys of a segment sharing it): besides each segment's mptize root it gets
+ * the RLP of that root NODE -- an extension [HP(x p), next] or a leaf [HP(x rest), value] -- and
+ * phant_mpt_strip_first_nibble (host-only, no GPU) re-roots it one nibble lower: the node the full
+ * trie's root branch refers to in slot x (is_ref = 0: a node, to be embedded if shorter than 32 bytes
+ * and hashed otherwise, mpt.zig:104/:112), or, when the extension carried only that nibble, its child
+ * reference itself (is_ref = 1: 32 hash bytes or an embedded RLP < 32 bytes).
+ * phant_amd/shard.py::mptize_sharded is the tested composition (all-reduce of 16 x 33 bytes). */
+PHANT_API int32_t phant_mpt_root_nodes(phant_ctx *ctx, const uint8_t *keys, const uint32_t *key_off,
+                                       const uint8_t *vals, const uint64_t *val_off, uint32_t n,
+                                       const uint32_t *seg_first /* n_tries + 1 */, uint32_t n_tries,
+                                       uint8_t *roots /* n_tries x 32 */,
+                                       uint8_t *node_rlp /* n_tries x node_cap */, uint32_t node_cap,
+                                       uint32_t *node_len /* n_tries; 0 = empty trie; > node_cap = not written */);
+PHANT_API int32_t phant_mpt_strip_first_nibble(const uint8_t *node, uint32_t len, uint8_t *out,
+                                               uint32_t cap, uint32_t *out_len, uint32_t *is_ref);
+
 /* State root: the `StateDB.root()` the reference lacks
  * (src/blockchain/blockchain.zig:83-85).  Inputs are the AccountState fields
  * of src/state/types.zig:13-20 in struct-of-arrays form:

@@ -802,6 +802,103 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* sta
     return PHANT_OK;
 }
 
+/* ------------------------------------------------- sharded trie roots (multi-GPU mptize) */
+
+int32_t phant_mpt_root_nodes(phant_ctx* c, const uint8_t* keys, const uint32_t* key_off, const uint8_t* vals,
+                             const uint64_t* val_off, uint32_t n, const uint32_t* seg_first, uint32_t n_tries,
+                             uint8_t* roots, uint8_t* node_rlp, uint32_t node_cap, uint32_t* node_len) {
+    if (!c || !roots || !seg_first || n_tries == 0 || !node_rlp || !node_len || node_cap == 0)
+        return c ? fail(c, PHANT_E_INVALID_ARG, "mpt_root_nodes: bad argument") : PHANT_E_INVALID_ARG;
+    if (n && (!key_off || !val_off)) return fail(c, PHANT_E_INVALID_ARG, "mpt_root_nodes: null pointer");
+    DeviceGuard g(c->device);
+    std::string err;
+    const uint32_t zero32[1] = {0};
+    const uint64_t zero64[1] = {0};
+    int32_t rc = phant::trie_forest_host(c->ws, c->stream, keys, n ? key_off : zero32, vals, n ? val_off : zero64, n,
+                                         seg_first, n_tries, roots, err, node_rlp, node_cap, node_len);
+    if (rc) return fail(c, rc, err.c_str());
+    return PHANT_OK;
+}
+
+// host-only: no HIP call below
+int32_t phant_mpt_strip_first_nibble(const uint8_t* node, uint32_t len, uint8_t* out, uint32_t cap, uint32_t* out_len,
+                                     uint32_t* is_ref) {
+    if (!node || !out || !out_len || !is_ref) return PHANT_E_INVALID_ARG;
+    size_t pay, plen, total, ip, il, it;
+    bool is_list, item_list;
+    if (!host_rlp_item(node, len, pay, plen, total, is_list) || !is_list || total != len) return PHANT_E_INVALID_ARG;
+    const uint8_t* p = node + pay;
+    // item 0: the hex-prefix path (mpt.zig:285-314)
+    if (!host_rlp_item(p, plen, ip, il, it, item_list) || item_list || il == 0) return PHANT_E_INVALID_ARG;
+    const uint8_t* hp = p + ip;
+    const uint32_t flag = hp[0] >> 4;
+    if (flag > 3) return PHANT_E_INVALID_ARG;
+    const bool leaf = flag & 2u, odd = flag & 1u;
+    // item 1: value (leaf) or child reference (extension), kept as it is
+    const uint8_t* rest = p + it;
+    const size_t rest_len = plen - it;
+    size_t rp, rl, rt;
+    bool rlist;
+    if (!host_rlp_item(rest, rest_len, rp, rl, rt, rlist) || rt != rest_len) return PHANT_E_INVALID_ARG;  // 2 items
+    std::vector<uint8_t> nib;
+    if (odd) nib.push_back(hp[0] & 0x0f);
+    else if (hp[0] & 0x0f) return PHANT_E_INVALID_ARG;
+    for (size_t k = 1; k < il; ++k) {
+        nib.push_back(hp[k] >> 4);
+        nib.push_back(hp[k] & 0x0f);
+    }
+    if (nib.empty()) return PHANT_E_INVALID_ARG;  // nothing to strip
+    nib.erase(nib.begin());
+    if (nib.empty() && !leaf) {
+        // the extension only carried that one nibble: one level lower sits its child, as the reference says
+        *is_ref = 1;
+        if (!rlist && rl == 32) {
+            if (cap < 32) return PHANT_E_INVALID_ARG;
+            std::memcpy(out, rest + rp, 32);
+            *out_len = 32;
+        } else if (rlist && rt < 32) {
+            if (cap < rt) return PHANT_E_INVALID_ARG;
+            std::memcpy(out, rest, rt);
+            *out_len = (uint32_t)rt;
+        } else {
+            return PHANT_E_INVALID_ARG;
+        }
+        return PHANT_OK;
+    }
+    // re-encode [HP(nib), item1]
+    std::vector<uint8_t> h;
+    const uint8_t f = (uint8_t)((leaf ? 2 : 0) | (nib.size() & 1));
+    size_t k = 0;
+    if (nib.size() & 1) h.push_back((uint8_t)(f << 4 | nib[k++]));
+    else h.push_back((uint8_t)(f << 4));
+    for (; k + 1 < nib.size(); k += 2) h.push_back((uint8_t)(nib[k] << 4 | nib[k + 1]));
+    std::vector<uint8_t> body;
+    if (h.size() == 1 && h[0] < 0x80) body.push_back(h[0]);
+    else {
+        body.push_back((uint8_t)(0x80 + h.size()));  // <= 33 bytes
+        body.insert(body.end(), h.begin(), h.end());
+    }
+    body.insert(body.end(), rest, rest + rest_len);
+    std::vector<uint8_t> enc;
+    if (body.size() <= 55) enc.push_back((uint8_t)(0xc0 + body.size()));
+    else {
+        size_t l = body.size(), ll = 0;
+        uint8_t be[8];
+        while (l) {
+            be[ll++] = (uint8_t)l;
+            l >>= 8;
+        }
+        enc.push_back((uint8_t)(0xf7 + ll));
+        for (size_t q = 0; q < ll; ++q) enc.push_back(be[ll - 1 - q]);
+    }
+    enc.insert(enc.end(), body.begin(), body.end());
+    *is_ref = 0;
+    *out_len = (uint32_t)enc.size();
+    if (enc.size() > cap) return PHANT_E_OOM;  // out_len says how much is needed
+    std::memcpy(out, enc.data(), enc.size());
+    return PHANT_OK;
+}
+
 /* ---------------------------------------------------------------- trie root */
 
 int32_t phant_mpt_root(phant_ctx* c, const uint8_t* keys, const uint32_t* key_off,

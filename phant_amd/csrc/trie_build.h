@@ -20,7 +20,10 @@ int32_t trie_root_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, cons
 int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
                          const uint8_t* vals, const uint64_t* val_off, uint32_t n,
                          const uint32_t* seg_first, uint32_t n_tries, uint8_t* roots_out,
-                         std::string& err);
+                         std::string& err, uint8_t* root_enc_out = nullptr, uint32_t root_enc_cap = 0,
+                         uint32_t* root_enc_len_out = nullptr);
+// (root_enc_out: n_tries x root_enc_cap bytes, the RLP of each trie's root node; root_enc_len_out its length,
+//  0 for an empty trie, possibly > root_enc_cap -- then the bytes were not written)
 
 // calculateMPTRoot (src/blockchain/blockchain.zig:209-235) when !be32,
 // ExecutionPayload.toBlock keys (src/engine_api/execution_payload.zig:127-139)

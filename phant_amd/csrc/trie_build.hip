@@ -70,6 +70,9 @@ struct TrieDev {
     uint32_t* order;      // rep boundaries grouped by depth
     uint32_t* depth_cursor;  // 512
     uint8_t* roots;       // n_tries x 32
+    uint8_t* root_enc;    // optional: n_tries x root_enc_cap, the RLP of every trie's root node
+    uint32_t* root_enc_len;  // optional: its length (may exceed root_enc_cap: then only the length is valid)
+    uint32_t root_enc_cap;
     unsigned long long scratch_cap;
 };
 
@@ -302,7 +305,13 @@ PHANT_DEV uint8_t* put_hp(uint8_t* w, const TrieDev& t, uint32_t k, uint32_t ps,
 PHANT_DEV void deliver(const TrieDev& t, uint32_t parent, uint32_t nib, uint32_t first_key,
                        const uint8_t* enc, uint32_t enc_len, const Sponge& s, bool hashed) {
     if (parent == NONE) {
-        store_digest(s, t.roots + 32ull * trie_of(t, first_key));
+        const uint32_t tr = trie_of(t, first_key);
+        store_digest(s, t.roots + 32ull * tr);
+        if (t.root_enc) {  // the multi-GPU exchange re-roots this node one nibble lower (phant_mpt_root_nodes)
+            t.root_enc_len[tr] = enc_len;
+            if (enc_len <= t.root_enc_cap)
+                for (uint32_t k = 0; k < enc_len; ++k) t.root_enc[(uint64_t)tr * t.root_enc_cap + k] = enc[k];
+        }
         return;
     }
     const uint64_t slot = (uint64_t)t.dense[parent] * 16u + nib;
@@ -466,8 +475,12 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
                              const uint8_t* d_vals, const uint64_t* d_val_off, uint32_t n,
                              uint64_t total_key_bytes, uint64_t total_val_bytes,
                              const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_roots,
-                             std::string& err) {
+                             std::string& err, uint8_t* d_root_enc = nullptr, uint32_t* d_root_enc_len = nullptr,
+                             uint32_t root_enc_cap = 0) {
     TrieDev t{};
+    t.root_enc = d_root_enc;
+    t.root_enc_len = d_root_enc_len;
+    t.root_enc_cap = root_enc_cap;
     t.keys = d_keys;
     t.key_off = d_key_off;
     t.vals = d_vals;
@@ -571,7 +584,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
 int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
                          const uint8_t* vals, const uint64_t* val_off, uint32_t n,
                          const uint32_t* seg_first, uint32_t n_tries, uint8_t* roots_out,
-                         std::string& err) {
+                         std::string& err, uint8_t* root_enc_out, uint32_t root_enc_cap, uint32_t* root_enc_len_out) {
     if (n_tries == 0) return PHANT_OK;
     const uint64_t kb = n ? key_off[n] - key_off[0] : 0;
     const uint64_t vb = n ? val_off[n] - val_off[0] : 0;
@@ -596,13 +609,18 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
     }
     TB_TRY(ws.io.reset(DevArena::round(kb + 16) + DevArena::round(((size_t)n + 1) * 4) + DevArena::round(vb + 16) +
                        DevArena::round(((size_t)n + 1) * 8) + DevArena::round(((size_t)n_tries + 1) * 4) +
-                       DevArena::round((size_t)n_tries * 32) + 1024));
+                       DevArena::round((size_t)n_tries * 32) + DevArena::round((size_t)n_tries * root_enc_cap + 4) +
+                       DevArena::round((size_t)n_tries * 4) + 1024));
     uint8_t* d_keys = ws.io.take<uint8_t>(kb + 16);
     uint32_t* d_koff = ws.io.take<uint32_t>((size_t)n + 1);
     uint8_t* d_vals = ws.io.take<uint8_t>(vb + 16);
     uint64_t* d_voff = ws.io.take<uint64_t>((size_t)n + 1);
     uint32_t* d_seg = ws.io.take<uint32_t>((size_t)n_tries + 1);
     uint8_t* d_roots = ws.io.take<uint8_t>((size_t)n_tries * 32);
+    uint8_t* d_enc = ws.io.take<uint8_t>((size_t)n_tries * root_enc_cap + 4);
+    uint32_t* d_enc_len = ws.io.take<uint32_t>(n_tries);
+    const bool want_enc = root_enc_out && root_enc_len_out && root_enc_cap;
+    if (want_enc) TB_TRY(hipMemsetAsync(d_enc_len, 0, (size_t)n_tries * 4, st));
     std::vector<uint32_t> ko((size_t)n + 1, 0);
     std::vector<uint64_t> vo((size_t)n + 1, 0);
     for (uint32_t i = 0; i <= n && n; ++i) {
@@ -614,12 +632,17 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
     TB_TRY(hipMemcpyAsync(d_koff, ko.data(), ko.size() * 4, hipMemcpyHostToDevice, st));
     TB_TRY(hipMemcpyAsync(d_voff, vo.data(), vo.size() * 8, hipMemcpyHostToDevice, st));
     TB_TRY(hipMemcpyAsync(d_seg, seg_first, ((size_t)n_tries + 1) * 4, hipMemcpyHostToDevice, st));
-    int32_t rc = forest_device(ws, st, d_keys, d_koff, d_vals, d_voff, n, kb, vb, d_seg, n_tries, d_roots, err);
+    int32_t rc = forest_device(ws, st, d_keys, d_koff, d_vals, d_voff, n, kb, vb, d_seg, n_tries, d_roots, err,
+                               want_enc ? d_enc : nullptr, want_enc ? d_enc_len : nullptr, want_enc ? root_enc_cap : 0u);
     if (rc) {
         (void)hipStreamSynchronize(st);
         return rc;
     }
     TB_TRY(hipMemcpyAsync(roots_out, d_roots, (size_t)n_tries * 32, hipMemcpyDeviceToHost, st));
+    if (want_enc) {
+        TB_TRY(hipMemcpyAsync(root_enc_out, d_enc, (size_t)n_tries * root_enc_cap, hipMemcpyDeviceToHost, st));
+        TB_TRY(hipMemcpyAsync(root_enc_len_out, d_enc_len, (size_t)n_tries * 4, hipMemcpyDeviceToHost, st));
+    }
     TB_TRY(hipStreamSynchronize(st));
     return PHANT_OK;
 }
@@ -630,7 +653,8 @@ int32_t trie_root_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, cons
     const uint32_t seg[2] = {0, n};
     const uint32_t zero32[1] = {0};
     const uint64_t zero64[1] = {0};
-    return trie_forest_host(ws, st, keys, n ? key_off : zero32, vals, n ? val_off : zero64, n, seg, 1, out, err);
+    return trie_forest_host(ws, st, keys, n ? key_off : zero32, vals, n ? val_off : zero64, n, seg, 1, out, err, nullptr,
+                            0, nullptr);
 }
 
 // rlp.serialize(usize, i) as used at blockchain.zig:226-229

@@ -115,3 +115,141 @@ def verify_sharded(b: HostBatch, rank: int, world: int, verify=gpu_verify, group
     if world > 1:
         dist.all_reduce(fc, op=dist.ReduceOp.SUM, group=group)
     return mine, status, fc.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------------
+# Trie roots across GPUs (second bullet): mptize sharded by the top key nibble.
+#
+# Rank r owns the top nibbles x with x % world == r.  For each of them it builds the sub-trie of the keys
+# starting with x on its GPU (phant_mpt_root_nodes: one forest pass), re-roots the sub-trie's root node one
+# nibble lower (phant_mpt_strip_first_nibble, host) and turns the result into the reference the full
+# trie's root branch holds in slot x: the node itself if its RLP is shorter than 32 bytes, else its
+# Keccak-256 (mpt.zig:104/:112).  ONE all-reduce of 16 x 33 bytes (every slot is written by exactly one
+# rank, so SUM is a gather) and every rank forms the root branch `slot[0..16] || ""` (mpt.zig:216-231) and
+# hashes it.  A trie whose keys all start with the same nibble has no branch at the top: its only owner
+# computes the root directly and the same all-reduce carries it.
+
+EMPTY_MPT_ROOT = bytes.fromhex("56e81f171bcc55a6ff8345e692c0f86e5b48e01b996cadc001622fb5e363b421")
+
+
+def strip_first_nibble(node: bytes):
+    """phant_mpt_strip_first_nibble: -> (bytes, is_ref).  Host-only (works without a GPU)."""
+    import ctypes as C
+
+    from . import _lib as L
+
+    lib = L.lib()
+    src = np.frombuffer(node, np.uint8)
+    out = np.zeros(len(node) + 8, np.uint8)
+    n, is_ref = C.c_uint32(0), C.c_uint32(0)
+    rc = lib.phant_mpt_strip_first_nibble(src.ctypes.data_as(C.c_void_p), len(node), out.ctypes.data_as(C.c_void_p),
+                                          out.size, C.byref(n), C.byref(is_ref))
+    if rc != L.OK:
+        raise L.PhantError(rc, "phant_mpt_strip_first_nibble: not an extension / leaf node with a non-empty path")
+    return out[: n.value].tobytes(), bool(is_ref.value)
+
+
+def gpu_root_nodes(keys: list[bytes], vals: list[bytes], seg_first: list[int]):
+    """Product: (root hash, root node RLP) of every segment, one forest pass on this rank's GPU."""
+    import ctypes as C
+
+    from . import _lib as L
+    from .context import default_context
+    from .mpt import _pack
+
+    ctx = default_context()
+    kb, ko = _pack(keys, np.uint32)
+    vb, vo = _pack(vals, np.uint64)
+    nt = len(seg_first) - 1
+    cap = 64 + max((len(k) + len(v) for k, v in zip(keys, vals)), default=0) + 16  # a leaf root holds key + value
+    seg = np.asarray(seg_first, np.uint32)
+    roots = np.zeros((nt, 32), np.uint8)
+    enc = np.zeros((nt, cap), np.uint8)
+    ln = np.zeros(nt, np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    ctx.check(ctx._lib.phant_mpt_root_nodes(ctx.handle, p(kb), p(ko), p(vb), p(vo), len(keys), p(seg), nt, p(roots), p(enc),
+                                            cap, p(ln)))
+    return [(roots[t].tobytes(), enc[t, : int(ln[t])].tobytes()) for t in range(nt)]
+
+
+def gpu_keccak(data: bytes) -> bytes:
+    from .crypto.hasher import keccak256
+
+    return keccak256(data)
+
+
+def rank_child_refs(keys: list[bytes], vals: list[bytes], rank: int, world: int, root_nodes=gpu_root_nodes,
+                    keccak=gpu_keccak):
+    """This rank's share of the root branch: refs (16, 33) u8 / lens (16,) for the top nibbles it owns (0 = no
+    key under that nibble), plus (nibble, root hash) of its sub-tries (used when the trie has no top branch).
+    `keys` sorted and distinct (mpt.zig:39), every key at least one byte."""
+    refs = np.zeros((16, 33), np.uint8)
+    lens = np.zeros(16, np.int32)
+    segs, seg_first, sk, sv = [], [0], [], []
+    for x in range(16):
+        if x % world != rank:
+            continue
+        part = [(k, v) for k, v in zip(keys, vals) if (k[0] >> 4) == x]
+        if not part:
+            continue
+        segs.append(x)
+        sk += [k for k, _ in part]
+        sv += [v for _, v in part]
+        seg_first.append(len(sk))
+    sub_roots = {}
+    if segs:
+        for x, (root, node) in zip(segs, root_nodes(sk, sv, seg_first)):
+            sub_roots[x] = root
+            out, is_ref = strip_first_nibble(node)
+            ref = out if is_ref else (out if len(out) < 32 else keccak(out))
+            refs[x, : len(ref)] = np.frombuffer(ref, np.uint8)
+            lens[x] = len(ref)
+    return refs, lens, sub_roots
+
+
+def root_from_child_refs(refs: np.ndarray, lens: np.ndarray, keccak=gpu_keccak) -> bytes | None:
+    """Root of the trie whose top-level children are `refs` (>= 2 non-empty), or None when there is no top branch."""
+    if int((lens > 0).sum()) < 2:
+        return None
+    body = bytearray()
+    for x in range(16):
+        l = int(lens[x])
+        if l == 0:
+            body.append(0x80)
+        elif l == 32:
+            body.append(0xA0)
+            body += refs[x, :32].tobytes()
+        else:
+            body += refs[x, :l].tobytes()  # embedded child: its own RLP list
+    body.append(0x80)  # no value at the root (keys are at least one byte long)
+    n = len(body)
+    hdr = bytes([0xC0 + n]) if n <= 55 else bytes([0xF7 + (n.bit_length() + 7) // 8]) + n.to_bytes((n.bit_length() + 7) // 8, "big")
+    return keccak(hdr + bytes(body))
+
+
+def mptize_sharded(keys: list[bytes], vals: list[bytes], rank: int, world: int, group=None, device=None,
+                   root_nodes=gpu_root_nodes, keccak=gpu_keccak) -> bytes:
+    """mptize (mpt.zig:38-45) of `keys` / `vals` with the work sharded by top nibble over `world` ranks.  Every
+    rank passes the same sorted key list (or at least the keys it owns) and gets the same root."""
+    import torch
+    import torch.distributed as dist
+
+    refs, lens, sub_roots = rank_child_refs(keys, vals, rank, world, root_nodes, keccak)
+    # 16 x (33 ref bytes + length + 32 bytes of the sub-trie's own root): one collective
+    t = torch.zeros((16, 33 + 1 + 32), dtype=torch.int32)
+    t[:, :33] = torch.from_numpy(refs.astype(np.int32))
+    t[:, 33] = torch.from_numpy(lens)
+    for x, r in sub_roots.items():
+        t[x, 34:] = torch.from_numpy(np.frombuffer(r, np.uint8).astype(np.int32))
+    if device is not None:
+        t = t.to(device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t = t.cpu().numpy()
+    all_refs, all_lens = t[:, :33].astype(np.uint8), t[:, 33].astype(np.int32)
+    nz = np.nonzero(all_lens > 0)[0]
+    if len(nz) == 0:
+        return EMPTY_MPT_ROOT
+    if len(nz) == 1:
+        return t[nz[0], 34:].astype(np.uint8).tobytes()  # no top branch: that sub-trie's root is the root
+    return root_from_child_refs(all_refs, all_lens, keccak)

@@ -103,3 +103,31 @@ def test_state_root_random_vs_oracle(P, oracle):
                         storage=st))
     assert P.state.state_root(acc) == oracle.state_root(acc)
     assert P.state.state_root([]) == P.mpt.empty_mpt_root
+
+
+def test_sharded_mptize_matches_the_single_gpu_root(oracle):
+    """phant_mpt_root_nodes (forest pass with root-node RLP out) + strip + top-nibble exchange, world sizes
+    1..8 played back in one process on one GPU, against mptize on the GPU and on the oracle."""
+    import phant_amd
+    from phant_amd import shard
+    from tests.test_shard_trie import _cases
+    rng = np.random.default_rng(2)
+    for keys, vals in _cases(rng):
+        order = sorted(range(len(keys)), key=lambda i: keys[i])
+        keys, vals = [keys[i] for i in order], [vals[i] for i in order]
+        want = oracle.mptize(keys, vals)
+        assert phant_amd.mpt.mptize([phant_amd.mpt.KeyVal.init(k, v) for k, v in zip(keys, vals)]) == want
+        for world in (1, 2, 8):
+            refs = np.zeros((16, 33), np.uint8)
+            lens = np.zeros(16, np.int32)
+            subs = {}
+            for rank in range(world):
+                r, l, s = shard.rank_child_refs(keys, vals, rank, world)   # product callables: the GPU
+                refs += r
+                lens += l
+                subs.update(s)
+            got = shard.root_from_child_refs(refs, lens)
+            if got is None:
+                nz = np.nonzero(lens > 0)[0]
+                got = subs[int(nz[0])] if len(nz) else shard.EMPTY_MPT_ROOT
+            assert got == want, (world, len(keys))
