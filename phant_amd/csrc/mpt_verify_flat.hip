@@ -1144,18 +1144,26 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
     uint32_t* const cursors_b = reinterpret_cast<uint32_t*>(p) + 64;  // second half of a pipelined launch
     p += FLAT_HEADER_BYTES;
     a.table = reinterpret_cast<uint64_t*>(p);      p += rnd256((size_t)te * 8);
-    uint64_t* const table_b = reinterpret_cast<uint64_t*>(p); p += rnd256((size_t)te * 8);
     a.tmask = te - 1u;
     a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);  // zeroed with the header
     a.canon = p;                                   p += rnd256(tn);      // zeroed with the header
+    uint64_t* const table_b = reinterpret_cast<uint64_t*>(p); p += rnd256((size_t)te * 8);  // pipelined only
     a.rep = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4);
     a.ent = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4 * N_CLASS);
     a.late_ent = reinterpret_cast<uint32_t*>(p);   p += rnd256(tn * 4 * N_CLASS);  // overlap: late list; pipelined: second half
     a.digest = reinterpret_cast<uint32_t*>(p);     p += rnd256(tn * 32);
     a.gkey = reinterpret_cast<uint64_t*>(p);       p += rnd256(tn * 8);
     a.link = p;
-    // header, both tables, the stamps and the canonical-form flags are contiguous: one memset
-    hipError_t e = hipMemsetAsync(ws, 0, FLAT_HEADER_BYTES + 2 * rnd256((size_t)te * 8) + rnd256(tn * 4) + tn, st);
+    // header, table, stamps and canonical-form flags are contiguous: one memset (the second table of the
+    // pipelined mode follows them; without deduplication no table is consulted at all)
+    hipError_t e;
+    if (dedup) {
+        e = hipMemsetAsync(ws, 0, FLAT_HEADER_BYTES + rnd256((size_t)te * 8) + rnd256(tn * 4) + rnd256(tn) +
+                                      (pipelined ? rnd256((size_t)te * 8) : 0), st);
+    } else {
+        e = hipMemsetAsync(ws, 0, FLAT_HEADER_BYTES, st);
+        if (e == hipSuccess) e = hipMemsetAsync(a.meta, 0, rnd256(tn * 4) + tn, st);
+    }
     if (e != hipSuccess) return e;
     const uint32_t pg = (v.n + 255u) / 256u;
     const uint32_t cus = compute_units();
@@ -1272,10 +1280,11 @@ hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, 
     a.cursors = reinterpret_cast<uint32_t*>(p);
     a.late_cursors = reinterpret_cast<uint32_t*>(p) + 16;
     p += FLAT_HEADER_BYTES;
-    a.table = reinterpret_cast<uint64_t*>(p);      p += 2 * rnd256((size_t)te * 8);
+    a.table = reinterpret_cast<uint64_t*>(p);      p += rnd256((size_t)te * 8);
     a.tmask = te - 1u;
     a.meta = reinterpret_cast<uint32_t*>(p);       p += rnd256(tn * 4);
     a.canon = p;                                   p += rnd256(tn);
+    p += rnd256((size_t)te * 8);  // (second table of the pipelined verify mode)
     a.rep = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4);
     a.ent = reinterpret_cast<uint32_t*>(p);        p += rnd256(tn * 4 * N_CLASS);
     a.late_ent = reinterpret_cast<uint32_t*>(p);   p += rnd256(tn * 4 * N_CLASS);

@@ -12,10 +12,16 @@ echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee "$OUT/smoke.log"
 echo "== bench config3 (default) =="
 timeout 600 python bench.py 2>&1 | tail -1 | tee "$OUT/bench_config3.json"
-for mode in nodedup overlap fused; do
+for mode in nodedup overlap pipelined fused; do
   echo "== bench config3 $mode (A/B) =="
   timeout 300 python bench.py --verify-mode $mode --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_config3_$mode.json"
 done
+echo "== bench nodeset =="
+timeout 300 python bench.py --workload nodeset --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_nodeset.json"
+echo "== bench config5 (streamed) =="
+timeout 300 python bench.py --workload config5 --steps 64 --warmup 4 --stream-slots 2 --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_config5.json"
+echo "== stress (20 seeds) =="
+timeout 600 python tools/stress_verify.py --seeds 20 --first-seed 3000 2>&1 | tail -1 | tee "$OUT/stress.log"
 echo "== bench config2 =="
 timeout 300 python bench.py --workload config2 --cpu-seconds 5 2>&1 | tail -1 | tee "$OUT/bench_config2.json"
 cd /tmp
