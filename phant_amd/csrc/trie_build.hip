@@ -169,7 +169,7 @@ PHANT_DEV uint32_t rep_of(const TrieDev& t, uint32_t x, int32_t lcp_x, int32_t p
 
 __global__ void __launch_bounds__(256) identify_kernel(TrieDev t) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= t.n) return;
+    if (i >= t.n) return;  // (whole trailing lanes of the last wave: ballots below only see live lanes)
     // --- key i as a leaf (or a branch value) ---
     {
         const int32_t dl = t.lcp[i], dr = t.lcp[i + 1];
@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256) identify_kernel(TrieDev t) {
     }
     // --- boundary i as a branch node ---
     uint32_t dn = NONE;
+    bool is_rep = false;
     const int32_t d = t.lcp[i];
     if (i >= 1 && d >= 0) {
         const uint32_t p = prev_less(t, i, d + 1);
@@ -201,8 +202,25 @@ __global__ void __launch_bounds__(256) identify_kernel(TrieDev t) {
             t.nd_l[i] = l;
             t.nd_pd[i] = pd;
             t.nd_parent[i] = pd < 0 ? NONE : rep_of(t, l, pl, pd);
-            dn = atomicAdd(&t.counters[0], 1u);
-            atomicAdd(&t.counters[8 + d], 1u);
+            is_rep = true;
+        }
+    }
+    // dense ids and the per-depth histogram: ONE atomic per wave and counter, not one per node -- returning
+    // atomics on the same address are served one at a time (~12 ns each, tools/ubench/atomic_rate.hip), and a
+    // million keys have ~70 k branch nodes on a handful of depths
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long reps = __ballot(is_rep);
+    if (reps) {
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(reps)) base = atomicAdd(&t.counters[0], (uint32_t)__popcll(reps));
+        base = __shfl(base, __builtin_ctzll(reps), 64);
+        if (is_rep) dn = base + (uint32_t)__popcll(reps & ((1ull << lane) - 1ull));
+        unsigned long long todo = reps;
+        while (todo) {
+            const int32_t d0 = __shfl(d, __builtin_ctzll(todo), 64);
+            const unsigned long long same = __ballot(is_rep && d == d0);
+            if (lane == (uint32_t)__builtin_ctzll(same)) atomicAdd(&t.counters[8 + d0], (uint32_t)__popcll(same));
+            todo &= ~same;
         }
     }
     t.dense[i] = dn;
@@ -210,11 +228,20 @@ __global__ void __launch_bounds__(256) identify_kernel(TrieDev t) {
 
 __global__ void __launch_bounds__(256) order_kernel(TrieDev t, const uint32_t* depth_begin) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= t.n || i == 0) return;
-    if (t.dense[i] == NONE) return;
-    const int32_t d = t.lcp[i];
-    const uint32_t pos = atomicAdd(&t.depth_cursor[d], 1u);
-    t.order[depth_begin[d] + pos] = i;
+    const bool live = i < t.n && i != 0 && t.dense[i] != NONE;
+    const int32_t d = live ? t.lcp[i] : -1;
+    // one reservation per wave and depth (see identify_kernel)
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int32_t d0 = __shfl(d, __builtin_ctzll(todo), 64);
+        const unsigned long long same = __ballot(live && d == d0);
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(same)) base = atomicAdd(&t.depth_cursor[d0], (uint32_t)__popcll(same));
+        base = __shfl(base, __builtin_ctzll(same), 64);
+        if (live && d == d0) t.order[depth_begin[d0] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
+        todo &= ~same;
+    }
 }
 
 // ---- RLP helpers (row a10: canonical subset used at mpt.zig:127,198,236,268) ----
@@ -255,17 +282,26 @@ PHANT_DEV uint8_t* put_str(uint8_t* w, const uint8_t* s, uint64_t len) {
 // prefix sum across the 64 lanes, one atomic per wave.  Every lane of the wave
 // must call it.
 PHANT_DEV unsigned long long wave_alloc(unsigned long long* cursor, uint32_t size) {
-    const uint32_t lane = threadIdx.x & 63u;
+    // one reservation per 256-lane workgroup (every lane of the workgroup calls this exactly once, at the
+    // same place): same-address returning atomics are served one at a time, ~12 ns each
+    __shared__ uint32_t s_wave_total[4];
+    __shared__ unsigned long long s_block_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = size;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o, 64);
         if (lane >= (uint32_t)o) incl += up;
     }
-    const uint32_t total = __shfl(incl, 63, 64);
-    unsigned long long base = 0;
-    if (lane == 0 && total) base = atomicAdd(cursor, (unsigned long long)total);
-    base = __shfl(base, 0, 64);
+    if (lane == 63u) s_wave_total[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3];
+        s_block_base = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = s_block_base;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave_total[w];
     return base + (incl - size);
 }
 
