@@ -204,8 +204,7 @@ def main():
         fails = torch.zeros(1, dtype=torch.int32, device=dev)
 
         def step():
-            M.verify_batch_dev(b, status=status, ctx=ctx)
-            M.verdict_dev(status, None, 1, out=fails, ctx=ctx)
+            M.verify_batch_dev(b, status=status, ctx=ctx, fail_count=fails)  # statuses + per-root verdict
             if world > 1:
                 dist.all_reduce(fails)  # one pass/fail word per root, over xGMI (RCCL)
 

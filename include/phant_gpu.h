@@ -155,6 +155,17 @@ PHANT_API int32_t phant_mpt_verify_batch_dev(phant_ctx *ctx, const uint8_t *d_ro
                                              const uint32_t *d_proof_first_node, uint32_t n,
                                              uint8_t *d_status, uint64_t *d_value_off,
                                              uint32_t *d_value_len);
+/* phant_mpt_verify_batch_dev + phant_mpt_verdict_dev in one launch sequence: the pipeline's last kernel,
+ * through which every status passes anyway, also counts the failures per root (d_fail_count: n_roots x
+ * u32, overwritten).  Saves the extra memset + kernel of the separate verdict call. */
+PHANT_API int32_t phant_mpt_verify_verdict_dev(phant_ctx *ctx, const uint8_t *d_roots,
+                                               uint32_t n_roots, const uint32_t *d_root_idx,
+                                               const uint8_t *d_keys, uint32_t key_len,
+                                               const uint8_t *d_nodes, uint64_t nodes_len,
+                                               const uint64_t *d_node_off, uint32_t total_nodes,
+                                               const uint32_t *d_proof_first_node, uint32_t n,
+                                               uint8_t *d_status, uint64_t *d_value_off,
+                                               uint32_t *d_value_len, uint32_t *d_fail_count);
 /* One verdict per root: d_fail_count[r] = number of proofs against root r
  * whose status is not PRESENT/ABSENT (n_roots x u32, overwritten).  This is
  * the word each rank all-reduces in the multi-GPU path. */

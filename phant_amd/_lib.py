@@ -53,6 +53,8 @@ SYMBOLS = {
     "phant_mpt_verify_batch": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp]),
     "phant_mpt_verify_batch_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp,
                                           _vp, _vp]),
+    "phant_mpt_verify_verdict_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp,
+                                            _vp, _vp, _vp]),
     "phant_mpt_verdict_dev": (_i32, [_vp, _vp, _vp, _u32, _u32, _vp]),
     "phant_mpt_verify_nodeset": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
     "phant_mpt_verify_nodeset_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),

@@ -433,6 +433,33 @@ int32_t phant_mpt_verify_batch_dev(phant_ctx* c, const uint8_t* d_roots, uint32_
     return verify_resident(c, a, total_nodes);
 }
 
+int32_t phant_mpt_verify_verdict_dev(phant_ctx* c, const uint8_t* d_roots, uint32_t n_roots,
+                                     const uint32_t* d_root_idx, const uint8_t* d_keys,
+                                     uint32_t key_len, const uint8_t* d_nodes, uint64_t nodes_len,
+                                     const uint64_t* d_node_off, uint32_t total_nodes,
+                                     const uint32_t* d_proof_first_node, uint32_t n, uint8_t* d_status,
+                                     uint64_t* d_value_off, uint32_t* d_value_len, uint32_t* d_fail_count) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (!d_fail_count || n_roots == 0) return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_verdict_dev: bad argument");
+    DeviceGuard g(c->device);
+    if (n == 0) {
+        HIP_TRY(c, hipMemsetAsync(d_fail_count, 0, sizeof(uint32_t) * (size_t)n_roots, c->stream));
+        return PHANT_OK;
+    }
+    if (!d_roots || !d_node_off || !d_proof_first_node || !d_status || (key_len && !d_keys) || key_len > 0x3fffffffu)
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_verdict_dev: bad argument");
+    phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len,
+                        d_node_off, d_proof_first_node, n, d_status, d_value_off, d_value_len};
+    if (c->verify_fused) {  // the one-lane-per-proof A/B kernel has no tail kernel to carry the verdict
+        const int32_t rc = verify_resident(c, a, total_nodes);
+        if (rc) return rc;
+        HIP_TRY(c, phant::launch_mpt_verdict(d_status, d_root_idx, n, n_roots, d_fail_count, c->stream));
+        return PHANT_OK;
+    }
+    a.fail_count = d_fail_count;
+    return verify_resident(c, a, total_nodes);
+}
+
 int32_t phant_mpt_verdict_dev(phant_ctx* c, const uint8_t* d_status, const uint32_t* d_root_idx,
                               uint32_t n, uint32_t n_roots, uint32_t* d_fail_count) {
     if (!c) return PHANT_E_INVALID_ARG;

@@ -25,6 +25,8 @@ struct VerifyArgs {
     uint8_t* status;
     uint64_t* value_off;  // may be null
     uint32_t* value_len;  // may be null
+    uint32_t* fail_count = nullptr;  // may be null: n_roots counters of proofs that are not PRESENT/ABSENT,
+                                     // produced by the pipeline's last kernel (phant_mpt_verify_verdict_dev)
 };
 hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
 // re-verifies, one lane per proof, the proofs whose status byte is 0xff (the flat pipeline's

@@ -103,15 +103,32 @@ __global__ void __launch_bounds__(256) mpt_verify_fused_kernel(const VerifyArgs 
 __global__ void __launch_bounds__(256) mpt_verify_fixup_kernel(const VerifyArgs a, const uint32_t* all_a,
                                                                const uint32_t* all_b) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.n) return;
-    const bool all = (all_a && *all_a) || (all_b && *all_b);
-    if (!all && a.status[i] != 0xffu) return;
-    uint64_t voff;
-    uint32_t vlen;
-    const uint32_t st = verify_one(a, i, voff, vlen);
-    a.status[i] = (uint8_t)st;
-    if (a.value_off) a.value_off[i] = voff;
-    if (a.value_len) a.value_len[i] = vlen;
+    const bool in = i < a.n;
+    uint32_t st = PHANT_PROOF_PRESENT;
+    if (in) {
+        st = a.status[i];
+        const bool all = (all_a && *all_a) || (all_b && *all_b);
+        if (all || st == 0xffu) {
+            uint64_t voff;
+            uint32_t vlen;
+            st = verify_one(a, i, voff, vlen);
+            a.status[i] = (uint8_t)st;
+            if (a.value_off) a.value_off[i] = voff;
+            if (a.value_len) a.value_len[i] = vlen;
+        }
+    }
+    // the verdict, while every status passes through this kernel anyway (same counting as mpt_verdict_kernel;
+    // fail_count was zeroed by the first kernel of the launch)
+    if (a.fail_count) {
+        const bool bad = in && !(st == PHANT_PROOF_PRESENT || st == PHANT_PROOF_ABSENT);
+        if (a.root_idx == nullptr || a.n_roots == 1) {
+            const unsigned long long m = __ballot(bad);
+            if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&a.fail_count[0], (uint32_t)__popcll(m));
+        } else if (bad) {
+            const uint32_t r = a.root_idx[i];
+            if (r < a.n_roots) atomicAdd(&a.fail_count[r], 1u);
+        }
+    }
 }
 
 // fail_count[r] += #proofs against root r that are not PRESENT/ABSENT.

@@ -161,6 +161,9 @@ constexpr uint32_t PLAN_BATCH = 8;  // even: a batch starts on a key byte
 __global__ void __launch_bounds__(256) plan_kernel(const FlatArgs a) {
     uint32_t p_lo, p_hi;
     proof_range(a, p_lo, p_hi);
+    // first kernel of a launch: clear the verdict counters its last kernel will add to
+    if (a.v.fail_count && a.half != 2u && blockIdx.x == 0)
+        for (uint32_t r = threadIdx.x; r < a.v.n_roots; r += 256u) a.v.fail_count[r] = 0u;
     const uint32_t p = p_lo + blockIdx.x * 256u + threadIdx.x;
     if (p >= p_hi) return;
     const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
@@ -1165,6 +1168,10 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
         if (e == hipSuccess) e = hipMemsetAsync(a.meta, 0, rnd256(tn * 4) + tn, st);
     }
     if (e != hipSuccess) return e;
+    if (v.fail_count && !total_nodes) {  // no plan_kernel will run: clear the verdict counters here
+        e = hipMemsetAsync(v.fail_count, 0, sizeof(uint32_t) * (size_t)v.n_roots, st);
+        if (e != hipSuccess) return e;
+    }
     const uint32_t pg = (v.n + 255u) / 256u;
     const uint32_t cus = compute_units();
     const uint32_t ng = (total_nodes + 255u) / 256u;  // hash grid bound (64-node chunks, 4 waves) and link grid
@@ -1246,7 +1253,7 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uin
         hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(walk_proofs_kernel, dim3(pg), dim3(256), 0, st, a);
-    if (dedup) {
+    if (dedup || v.fail_count) {
         e = launch_mpt_verify_fixup(v, nullptr, nullptr, st);
         if (e != hipSuccess) return e;
     }

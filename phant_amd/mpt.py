@@ -169,8 +169,11 @@ class ProofBatch:
 
 
 def verify_batch_dev(b: ProofBatch, status: torch.Tensor | None = None, value_off: torch.Tensor | None = None,
-                     value_len: torch.Tensor | None = None, ctx: Context | None = None) -> torch.Tensor:
-    """Device form, asynchronous on the ctx stream.  Returns the status tensor."""
+                     value_len: torch.Tensor | None = None, ctx: Context | None = None,
+                     fail_count: torch.Tensor | None = None) -> torch.Tensor:
+    """Device form, asynchronous on the ctx stream.  Returns the status tensor.  With `fail_count`
+    (int32[n_roots], device) the per-root verdict is produced in the same launch
+    (phant_mpt_verify_verdict_dev)."""
     ctx = ctx or default_context(b.nodes.device.index)
     n = b.n
     dev = b.nodes.device
@@ -180,11 +183,15 @@ def verify_batch_dev(b: ProofBatch, status: torch.Tensor | None = None, value_of
         assert b.root_idx.dtype == torch.int32
     if status is None:
         status = torch.empty(n, dtype=torch.uint8, device=dev)
-    ctx.check(ctx._lib.phant_mpt_verify_batch_dev(
-        ctx.handle, b.roots.data_ptr(), b.n_roots, None if b.root_idx is None else b.root_idx.data_ptr(),
-        b.keys.data_ptr(), b.key_len, b.nodes.data_ptr(), b.nodes.numel(), b.node_off.data_ptr(),
-        b.node_off.numel() - 1, b.proof_first_node.data_ptr(), n, status.data_ptr(),
-        None if value_off is None else value_off.data_ptr(), None if value_len is None else value_len.data_ptr()))
+    args = (ctx.handle, b.roots.data_ptr(), b.n_roots, None if b.root_idx is None else b.root_idx.data_ptr(),
+            b.keys.data_ptr(), b.key_len, b.nodes.data_ptr(), b.nodes.numel(), b.node_off.data_ptr(),
+            b.node_off.numel() - 1, b.proof_first_node.data_ptr(), n, status.data_ptr(),
+            None if value_off is None else value_off.data_ptr(), None if value_len is None else value_len.data_ptr())
+    if fail_count is None:
+        ctx.check(ctx._lib.phant_mpt_verify_batch_dev(*args))
+    else:
+        assert fail_count.dtype == torch.int32 and fail_count.numel() >= b.n_roots
+        ctx.check(ctx._lib.phant_mpt_verify_verdict_dev(*args, fail_count.data_ptr()))
     return status
 
 

@@ -329,3 +329,31 @@ def test_block_witness_accounts_and_storage(M, oracle):
     bad = ~np.isin(want[0], (M.PROOF_PRESENT, M.PROOF_ABSENT))
     assert np.array_equal(fails, np.bincount(ridx[bad], minlength=len(roots)))
     assert fails.sum() > 0 and (fails == 0).any()
+
+
+def test_fused_verdict_equals_the_separate_call(M, oracle):
+    """phant_mpt_verify_verdict_dev: same statuses, and the per-root failure counts of
+    phant_mpt_verdict_dev, single-root and multi-root, also when reusing a dirty counter buffer."""
+    import phant_amd
+    from phant_amd.mpt import ProofBatch
+    from tests.witness_util import block_witness, pack_proofs
+    w = phant_amd.witness.account_witness(5000, depth=8, seed=9, corrupt_frac=0.1)
+    fc = torch.full((1,), 12345, dtype=torch.int32, device="cuda")
+    st = M.verify_batch_dev(w.batch, fail_count=fc)
+    assert torch.equal(st, w.expected) and int(fc.item()) == w.n_invalid == 250
+    roots, ridx, keys, proofs = block_witness(oracle, np.random.default_rng(77), n_accounts=400, n_contracts=9,
+                                              n_account_proofs=120, n_storage_proofs=500)
+    nodes, node_off, pfn = pack_proofs(proofs)
+    dev = "cuda"
+    b = ProofBatch(torch.from_numpy(np.frombuffer(b"".join(roots), np.uint8).copy()).to(dev).reshape(-1, 32),
+                   torch.from_numpy(ridx.astype(np.int32)).to(dev),
+                   torch.from_numpy(np.frombuffer(b"".join(keys), np.uint8).copy()).to(dev).reshape(-1, 32),
+                   torch.from_numpy(nodes).to(dev), torch.from_numpy(node_off.astype(np.int64)).to(dev),
+                   torch.from_numpy(pfn.astype(np.int32)).to(dev))
+    fc = torch.full((len(roots),), -7, dtype=torch.int32, device=dev)
+    st = M.verify_batch_dev(b, fail_count=fc)
+    sep = M.verdict_dev(st, b.root_idx, len(roots))
+    assert torch.equal(fc, sep) and int(fc.sum()) > 0
+    want = oracle.mpt_verify_batch(np.frombuffer(b"".join(roots), np.uint8), ridx, np.frombuffer(b"".join(keys), np.uint8), 32,
+                                   nodes, node_off, pfn)
+    assert np.array_equal(st.cpu().numpy(), want[0])
