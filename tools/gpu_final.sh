@@ -25,10 +25,17 @@ timeout 600 python tools/stress_verify.py --seeds 20 --first-seed 3000 2>&1 | ta
 echo "== bench config2 =="
 timeout 300 python bench.py --workload config2 --cpu-seconds 5 2>&1 | tail -1 | tee "$OUT/bench_config2.json"
 cd /tmp
-echo "== rocprofv3 --kernel-trace --stats (python bench.py --no-cpu-baseline) =="
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o prof -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > "$OUT/prof.log" 2>&1
+# per-kernel durations of ONE launch at a time (what roofline.kernel_avg_ms measures with HIP events) ...
+echo "== rocprofv3 --kernel-trace --stats (python bench.py --no-cpu-baseline --streams 1) =="
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o prof -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --streams 1 > "$OUT/prof.log" 2>&1
 for f in $(find "$OUT/prof" -name '*kernel_stats.csv'); do cp "$f" "$OUT/config3_kernel_stats.csv"; grep -E 'Name|phant::' "$f" | cut -d, -f1-5 | cut -c1-130; done
 rm -rf "$OUT/prof"
+# ... and of the default command (4 launch sequences in flight: kernels of different steps share the chip, so
+# their individual durations stretch while the step time shrinks)
+echo "== rocprofv3 --kernel-trace --stats (python bench.py --no-cpu-baseline) =="
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof4" -o prof -- python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline > "$OUT/prof4.log" 2>&1
+for f in $(find "$OUT/prof4" -name '*kernel_stats.csv'); do cp "$f" "$OUT/config3_kernel_stats_streams4.csv"; grep -E 'phant::' "$f" | cut -d, -f1-5 | cut -c1-130; done
+rm -rf "$OUT/prof4"
 cd "$GRAFT_REPO_ROOT"
 echo "== PMC calibration passes =="
 bash tools/gpu_pmc_calib.sh $TAG/calib > /dev/null 2>&1

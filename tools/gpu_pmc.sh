@@ -8,7 +8,7 @@ export TMPDIR=/tmp PYTHONUNBUFFERED=1
 cd /tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --verify-mode $MODE > "$OUT/$name.log" 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --verify-mode $MODE > "$OUT/$name.log" 2>&1
   for f in $(find "$OUT/$name" -name '*counter_collection.csv'); do
     (head -1 "$f"; grep -E 'phant::' "$f") > "$OUT/$name.csv"; rm -f "$f"
   done

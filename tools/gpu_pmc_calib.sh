@@ -16,7 +16,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   for f in $(find "$OUT/ub_$c" -name '*counter_collection.csv'); do cp "$f" "$OUT/ubench_$c.csv"; done
   rm -rf "$OUT/ub_$c"
   for mode in flat nodedup; do
-    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/b_$c" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --verify-mode $mode > "$OUT/b_$c.log" 2>&1
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/b_$c" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --verify-mode $mode > "$OUT/b_$c.log" 2>&1
     for f in $(find "$OUT/b_$c" -name '*counter_collection.csv'); do (head -1 "$f"; grep -E 'phant::' "$f") > "$OUT/${mode}_$c.csv"; done
     rm -rf "$OUT/b_$c"
   done
