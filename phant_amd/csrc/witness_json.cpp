@@ -154,7 +154,7 @@ bool hex_padded(const std::string& s, size_t width, uint8_t* dst) {
     std::vector<uint8_t> b;
     if (!hex_bytes(s, true, b) || b.size() > width) return false;
     std::memset(dst, 0, width);
-    std::memcpy(dst + (width - b.size()), b.data(), b.size());
+    if (!b.empty()) std::memcpy(dst + (width - b.size()), b.data(), b.size());
     return true;
 }
 

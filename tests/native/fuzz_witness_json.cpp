@@ -1,0 +1,78 @@
+// fuzz_witness_json.cpp -- memory-safety fuzz of the host-only witness parser (phant_amd/csrc/witness_json.cpp).
+// Built by tests/test_witness_json.py with g++ -fsanitize=address,undefined; reads a seed document from
+// argv[1], applies deterministic random damage (byte flips, truncations, insertions of structural
+// characters, duplicated spans) and parses every variant.  Any sanitizer report aborts the process.
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <string>
+
+#include "../../phant_amd/csrc/witness.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    std::ifstream f(argv[1], std::ios::binary);
+    const std::string seed((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const int iters = std::atoi(argv[2]);
+    static const char structural[] = "{}[]\",:\\x0 \n-e.tfn";
+    size_t ok = 0, bad = 0;
+    phant::Witness w;
+    std::string err;
+    if (!phant::witness_parse_json(seed.data(), seed.size(), w, err)) {
+        std::fprintf(stderr, "seed does not parse: %s\n", err.c_str());
+        return 3;
+    }
+    for (int it = 0; it < iters; ++it) {
+        std::string s = seed;
+        const int edits = 1 + (int)(rnd() % 4);
+        for (int e = 0; e < edits && !s.empty(); ++e) {
+            const size_t at = rnd() % s.size();
+            switch (rnd() % 6) {
+                case 0: s[at] = (char)(rnd() & 0xff); break;
+                case 1: s.resize(at); break;
+                case 2: s.insert(at, 1, structural[rnd() % (sizeof structural - 1)]); break;
+                case 3: s.erase(at, 1 + rnd() % 8); break;
+                case 4: {
+                    const size_t len = 1 + rnd() % 64;
+                    s.insert(rnd() % (s.size() + 1), s.substr(at, len));
+                    break;
+                }
+                default: s[at] = structural[rnd() % (sizeof structural - 1)]; break;
+            }
+        }
+        if (phant::witness_parse_json(s.data(), s.size(), w, err)) {
+            ++ok;
+            // a parsed witness must be internally consistent
+            if (w.proof_first_node.size() != w.root_idx.size() + 1 || w.preimage_off.size() != w.root_idx.size() + 1 ||
+                w.node_off.back() != w.nodes.size() || w.proof_first_node.back() != w.node_off.size() - 1 ||
+                w.roots.size() != 32 * (w.accounts.size() + 1)) {
+                std::fprintf(stderr, "inconsistent witness after edit %d\n", it);
+                return 4;
+            }
+        } else {
+            ++bad;
+            if (err.empty()) {
+                std::fprintf(stderr, "failure without a message at edit %d\n", it);
+                return 5;
+            }
+        }
+    }
+    // also the parser on raw garbage and on the empty string
+    for (int it = 0; it < 2000; ++it) {
+        std::string s(rnd() % 200, '\0');
+        for (auto& c : s) c = (char)(rnd() & 0xff);
+        (void)phant::witness_parse_json(s.data(), s.size(), w, err);
+    }
+    (void)phant::witness_parse_json(nullptr, 0, w, err);
+    std::printf("%zu variants parsed, %zu rejected\n", ok, bad);
+    return 0;
+}
