@@ -24,7 +24,7 @@ COMBOS = [
     ("nodedup", {}),
     ("fused", {}),
 ]
-KNOBS = ("PHANT_WALK_PF", "PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO", "PHANT_HASH_PERSISTENT", "PHANT_HASH_CHUNK")
+KNOBS = ("PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO", "PHANT_HASH_PERSISTENT", "PHANT_HASH_CHUNK")
 
 
 def main():
