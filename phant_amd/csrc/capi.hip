@@ -618,13 +618,20 @@ using phant::be_equals_padded;
 using phant::host_rlp_item;
 
 int32_t phant_witness_parse_json(const char* json, uint64_t len, phant_witness** out, char* err, uint32_t err_cap) {
+    return phant_witness_parse_json_mt(json, len, 1, out, err, err_cap);
+}
+
+int32_t phant_witness_parse_json_mt(const char* json, uint64_t len, uint32_t threads, phant_witness** out, char* err,
+                                    uint32_t err_cap) {
     if (err && err_cap) err[0] = 0;
     if (!out || (!json && len)) return PHANT_E_INVALID_ARG;
     *out = nullptr;
     phant_witness* w = new (std::nothrow) phant_witness();
     if (!w) return PHANT_E_OOM;
     std::string msg;
-    if (!phant::witness_parse_json(json, (size_t)len, w->w, msg)) {
+    const bool parsed = threads == 1 ? phant::witness_parse_json(json, (size_t)len, w->w, msg)
+                                     : phant::witness_parse_json_mt(json, (size_t)len, threads, w->w, msg);
+    if (!parsed) {
         if (err && err_cap) {
             std::strncpy(err, msg.c_str(), err_cap - 1);
             err[err_cap - 1] = 0;

@@ -38,5 +38,7 @@ struct Witness {
 };
 
 bool witness_parse_json(const char* json, size_t len, Witness& out, std::string& err);
+// the same result with the accounts parsed on `threads` host threads (0 = as many as the host has, at most 32)
+bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witness& out, std::string& err);
 
 }  // namespace phant

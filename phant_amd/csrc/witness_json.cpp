@@ -23,8 +23,10 @@
 //
 // Pure host code (no HIP calls): parsing is testable without a GPU.
 #include <cstdint>
+#include <cstddef>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "witness.h"
@@ -82,12 +84,43 @@ struct Parser {
         ++p;
         return true;
     }
+    // The raw characters between the quotes of the next string, without copying: one memchr per string.
+    // (Hex strings and member names contain no escapes; an escaped quote inside is stepped over and reported
+    // through `escaped`.)
+    bool str_view(const char*& b, const char*& e, bool& escaped) {
+        ws();
+        if (p >= end || *p != '"') return fail("expected a string");
+        ++p;
+        b = p;
+        escaped = false;
+        for (;;) {
+            const char* q = static_cast<const char*>(std::memchr(p, '"', (size_t)(end - p)));
+            if (!q) {
+                p = end;
+                return fail("unterminated string");
+            }
+            // a quote preceded by an odd number of backslashes is escaped
+            const char* r = q;
+            while (r > b && r[-1] == '\\') --r;
+            const size_t bs = (size_t)(q - r);
+            if (bs & 1) {
+                escaped = true;
+                p = q + 1;
+                continue;
+            }
+            if (bs) escaped = true;  // (a backslash elsewhere in the span makes it invalid hex: hex_append says so)
+            e = q;
+            p = q + 1;
+            return true;
+        }
+    }
     bool skip_value() {
         ws();
         if (p >= end) return fail("unexpected end");
         if (*p == '"') {
-            std::string s;
-            return str(s);
+            const char *b = nullptr, *e = nullptr;
+            bool esc = false;
+            return str_view(b, e, esc);
         }
         if (*p == '{' || *p == '[') {
             const char open = *p, close = open == '{' ? '}' : ']';
@@ -95,8 +128,9 @@ struct Parser {
             if (lit(close)) return true;
             for (;;) {
                 if (open == '{') {
-                    std::string k;
-                    if (!str(k) || !expect(':')) return false;
+                    const char *kb = nullptr, *ke = nullptr;
+                    bool esc = false;
+                    if (!str_view(kb, ke, esc) || !expect(':')) return false;
                 }
                 if (!skip_value()) return false;
                 if (lit(',')) continue;
@@ -175,15 +209,56 @@ struct Builder {
     void end_proof() { w.proof_first_node.push_back((uint32_t)(w.node_off.size() - 1)); }
 };
 
+// two hex digits -> one byte in ONE lookup: index = the two characters as a little-endian u16, value < 0 for
+// anything that is not a pair of hex digits (128 KiB, L2-resident while a witness is parsed)
+struct HexPairTable {
+    static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "the pair index below is the two characters as loaded");
+    int16_t v[65536];
+    HexPairTable() {
+        int8_t d[256];
+        for (int i = 0; i < 256; ++i) d[i] = -1;
+        for (int i = 0; i < 10; ++i) d['0' + i] = (int8_t)i;
+        for (int i = 0; i < 6; ++i) d['a' + i] = d['A' + i] = (int8_t)(10 + i);
+        for (int lo = 0; lo < 256; ++lo)      // first character (memory order) = high nibble
+            for (int hi = 0; hi < 256; ++hi)  // second character
+                v[lo | hi << 8] = (d[lo] < 0 || d[hi] < 0) ? (int16_t)-1 : (int16_t)(d[lo] << 4 | d[hi]);
+    }
+};
+const HexPairTable HEX2;
+
+// hex data (hexutils.zig:22-37: optional 0x, "0x0" / "" empty, even digit count) appended to `out`
+bool hex_append(const char* b, const char* e, std::vector<uint8_t>& out) {
+    if (e - b >= 2 && b[0] == '0' && (b[1] == 'x' || b[1] == 'X')) b += 2;
+    const size_t n = (size_t)(e - b);
+    if (n == 0 || (n == 1 && b[0] == '0')) return true;
+    if (n & 1) return false;
+    const size_t at = out.size();
+    out.resize(at + n / 2);
+    uint8_t* w = out.data() + at;
+    int bad = 0;
+    for (size_t i = 0; i < n; i += 2) {
+        uint16_t pair;
+        std::memcpy(&pair, b + i, 2);
+        const int v = HEX2.v[pair];
+        bad |= v;  // negative iff the pair is not two hex digits
+        *w++ = (uint8_t)v;
+    }
+    if (bad < 0) {
+        out.resize(at);
+        return false;
+    }
+    return true;
+}
+
 bool parse_node_array(Parser& ps, Builder& b) {
     if (!ps.expect('[')) return false;
     if (ps.lit(']')) return true;
-    std::string s;
-    std::vector<uint8_t> nd;
     for (;;) {
-        if (!ps.str(s)) return false;
-        if (!hex_bytes(s, false, nd)) return ps.fail("proof node is not hex data");
-        b.add_node(nd);
+        const char *sb = nullptr, *se = nullptr;
+        bool esc = false;
+        if (!ps.str_view(sb, se, esc)) return false;
+        if (esc || !hex_append(sb, se, b.w.nodes)) return ps.fail("proof node is not hex data");
+        b.w.node_off.push_back((uint64_t)b.w.nodes.size());
         if (ps.lit(',')) continue;
         return ps.expect(']');
     }
@@ -195,27 +270,30 @@ const uint8_t EMPTY_ROOT[32] = {0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 
 bool parse_storage_entry(Parser& ps, Builder& b, uint32_t account) {
     if (!ps.expect('{')) return false;
     bool have_key = false, have_proof = false;
-    uint8_t key[32];
     WitnessSlot slot{};
-    // the proof's nodes must follow the proof header in the packed arrays, but members may come in any
-    // order: remember where the node array is and parse it once the key is known
-    const char* proof_at = nullptr;
+    slot.proof = (uint32_t)b.w.root_idx.size();
+    slot.account = account;
+    // the proof header goes in first, its 32-byte key preimage is filled in when "key" is met (members may
+    // come in any order; the nodes are decoded straight into the blob when "proof" is met)
+    static const uint8_t zero32[32] = {0};
+    const size_t key_at = b.w.preimages.size();
+    b.begin_proof(1u + account, account, zero32, 32);
     std::string name, s;
     if (!ps.lit('}')) {
         for (;;) {
             if (!ps.str(name) || !ps.expect(':')) return false;
             if (name == "key") {
                 if (!ps.str(s)) return false;
-                if (!hex_padded(s, 32, key)) return ps.fail("storage key is not a hex quantity of at most 32 bytes");
+                if (!hex_padded(s, 32, b.w.preimages.data() + key_at))
+                    return ps.fail("storage key is not a hex quantity of at most 32 bytes");
                 have_key = true;
             } else if (name == "value") {
                 if (!ps.str(s)) return false;
                 if (!hex_padded(s, 32, slot.value)) return ps.fail("storage value is not a hex quantity of at most 32 bytes");
                 slot.has_value = 1;
             } else if (name == "proof") {
-                ps.ws();
-                proof_at = ps.p;
-                if (!ps.skip_value()) return false;
+                if (have_proof) return ps.fail("duplicate \"proof\"");
+                if (!parse_node_array(ps, b)) return false;
                 have_proof = true;
             } else if (!ps.skip_value()) {
                 return false;
@@ -226,17 +304,19 @@ bool parse_storage_entry(Parser& ps, Builder& b, uint32_t account) {
         }
     }
     if (!have_key || !have_proof) return ps.fail("storageProof entry needs \"key\" and \"proof\"");
-    slot.proof = (uint32_t)b.w.root_idx.size();
-    slot.account = account;
-    b.begin_proof(1u + account, account, key, 32);
-    Parser sub{proof_at, ps.end, std::string(), ps.start};
-    if (!parse_node_array(sub, b)) {
-        ps.p = sub.p;
-        return ps.fail(sub.err.c_str());
-    }
     b.end_proof();
     b.w.slots.push_back(slot);
     return true;
+}
+
+bool parse_storage_array(Parser& ps, Builder& b, uint32_t account) {
+    if (!ps.expect('[')) return false;
+    if (ps.lit(']')) return true;
+    for (;;) {
+        if (!parse_storage_entry(ps, b, account)) return false;
+        if (ps.lit(',')) continue;
+        return ps.expect(']');
+    }
 }
 
 bool parse_account(Parser& ps, Builder& b) {
@@ -244,9 +324,9 @@ bool parse_account(Parser& ps, Builder& b) {
     const uint32_t account = (uint32_t)b.w.accounts.size();
     WitnessAccount acc{};
     std::memcpy(acc.storage_hash, EMPTY_ROOT, 32);
-    bool have_addr = false;
-    const char* proof_at = nullptr;
-    const char* storage_at = nullptr;
+    bool have_addr = false, have_proof = false, have_storage = false;
+    size_t addr_at = 0;            // where the account proof's 20-byte preimage sits, once the proof is in
+    const char* storage_at = nullptr;  // "storageProof" met BEFORE "accountProof": parsed after the object
     std::string name, s;
     if (!ps.lit('}')) {
         for (;;) {
@@ -275,13 +355,26 @@ bool parse_account(Parser& ps, Builder& b) {
                 if (!hex_padded(s, 32, acc.balance)) return ps.fail("balance is not a hex quantity of at most 32 bytes");
                 acc.has_balance = 1;
             } else if (name == "accountProof") {
-                ps.ws();
-                proof_at = ps.p;
-                if (!ps.skip_value()) return false;
+                if (have_proof) return ps.fail("duplicate \"accountProof\"");
+                // the account proof comes first in the output; its nodes are decoded straight into the blob,
+                // the address is filled in when it is met
+                static const uint8_t zero20[20] = {0};
+                acc.proof = (uint32_t)b.w.root_idx.size();
+                addr_at = b.w.preimages.size();
+                b.begin_proof(0u, account, zero20, 20);
+                if (!parse_node_array(ps, b)) return false;
+                b.end_proof();
+                have_proof = true;
             } else if (name == "storageProof") {
-                ps.ws();
-                storage_at = ps.p;
-                if (!ps.skip_value()) return false;
+                if (have_storage) return ps.fail("duplicate \"storageProof\"");
+                have_storage = true;
+                if (have_proof) {
+                    if (!parse_storage_array(ps, b, account)) return false;
+                } else {  // rare member order: remember where it is and come back after the account proof
+                    ps.ws();
+                    storage_at = ps.p;
+                    if (!ps.skip_value()) return false;
+                }
             } else if (!ps.skip_value()) {
                 return false;
             }
@@ -290,31 +383,13 @@ bool parse_account(Parser& ps, Builder& b) {
             break;
         }
     }
-    if (!have_addr || !proof_at) return ps.fail("account needs \"address\" and \"accountProof\"");
-    acc.proof = (uint32_t)b.w.root_idx.size();
+    if (!have_addr || !have_proof) return ps.fail("account needs \"address\" and \"accountProof\"");
+    std::memcpy(b.w.preimages.data() + addr_at, acc.address, 20);
     b.w.accounts.push_back(acc);
     b.w.roots.insert(b.w.roots.end(), acc.storage_hash, acc.storage_hash + 32);  // root 1 + account
-    b.begin_proof(0u, account, acc.address, 20);
-    {
-        Parser sub{proof_at, ps.end, std::string(), ps.start};
-        if (!parse_node_array(sub, b)) {
-            ps.p = sub.p;
-            return ps.fail(sub.err.c_str());
-        }
-    }
-    b.end_proof();
     if (storage_at) {
         Parser sub{storage_at, ps.end, std::string(), ps.start};
-        bool ok = sub.expect('[');
-        if (ok && !sub.lit(']')) {
-            for (;;) {
-                if (!(ok = parse_storage_entry(sub, b, account))) break;
-                if (sub.lit(',')) continue;
-                ok = sub.expect(']');
-                break;
-            }
-        }
-        if (!ok) {
+        if (!parse_storage_array(sub, b, account)) {
             ps.p = sub.p;
             return ps.fail(sub.err.c_str());
         }
@@ -326,6 +401,7 @@ bool parse_account(Parser& ps, Builder& b) {
 
 bool witness_parse_json(const char* json, size_t len, Witness& w, std::string& err) {
     w = Witness();
+    w.nodes.reserve(len / 2);  // a witness is mostly hex: avoids regrowing the blob while it is filled
     w.node_off.push_back(0);
     w.proof_first_node.push_back(0);
     w.preimage_off.push_back(0);
@@ -378,6 +454,187 @@ bool witness_parse_json(const char* json, size_t len, Witness& w, std::string& e
         err = ps.err;
         w = Witness();
         return false;
+    }
+    return true;
+}
+
+// ---- the same with the accounts spread over host threads ----
+// A witness is tens to hundreds of megabytes of hex (2 characters per node byte), one thread decodes ~1.3
+// GB/s of it, and a GPU verifies the result at PCIe speed: the parser, not the copy, would bound a streaming
+// verifier.  Accounts are independent objects, so: one serial pass finds their spans (skipping a string is a
+// memchr), every thread parses a contiguous run of spans into its own Witness, and the pieces are
+// concatenated with their offsets re-based -- byte-identical to the serial result.
+bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witness& w, std::string& err) {
+    if (threads == 0) {
+        threads = std::thread::hardware_concurrency();
+        if (threads == 0) threads = 1;
+        if (threads > 32) threads = 32;
+    }
+    // ---- pass 1 (serial): top-level members, the span of every account object ----
+    struct Span {
+        const char *b, *e;
+    };
+    std::vector<Span> spans;
+    uint8_t state_root[32];
+    Parser ps{json, json + len, std::string(), json};
+    bool have_root = false, have_accounts = false;
+    bool ok = ps.expect('{');
+    std::string name, s;
+    if (ok && !ps.lit('}')) {
+        for (;;) {
+            if (!(ok = ps.str(name) && ps.expect(':'))) break;
+            if (name == "stateRoot") {
+                if (!(ok = ps.str(s))) break;
+                if (!hex_fixed(s, 32, state_root)) {
+                    ok = ps.fail("stateRoot is not 32 bytes of hex");
+                    break;
+                }
+                have_root = true;
+            } else if (name == "accounts") {
+                if (have_accounts) {
+                    ok = ps.fail("duplicate \"accounts\"");
+                    break;
+                }
+                have_accounts = true;
+                if (!(ok = ps.expect('['))) break;
+                if (!ps.lit(']')) {
+                    for (;;) {
+                        ps.ws();
+                        const char* b0 = ps.p;
+                        if (b0 >= ps.end || *b0 != '{') {
+                            ok = ps.fail("unexpected character");
+                            break;
+                        }
+                        if (!(ok = ps.skip_value())) break;
+                        spans.push_back(Span{b0, ps.p});
+                        if (ps.lit(',')) continue;
+                        ok = ps.expect(']');
+                        break;
+                    }
+                    if (!ok) break;
+                }
+            } else if (!(ok = ps.skip_value())) {
+                break;
+            }
+            if (ps.lit(',')) continue;
+            ok = ps.expect('}');
+            break;
+        }
+    }
+    if (ok) {
+        ps.ws();
+        if (ps.p != ps.end) ok = ps.fail("trailing characters");
+    }
+    // anything wrong at this level, or too little to share out: the serial parser reports it / does it
+    if (!ok || !have_root || threads < 2 || spans.size() < 2u * threads || len < (1u << 20))
+        return witness_parse_json(json, len, w, err);
+
+    // ---- pass 2 (parallel): contiguous runs of accounts of about equal size ----
+    const size_t T = threads;
+    std::vector<size_t> first(T + 1, spans.size());
+    {
+        const size_t total = (size_t)(spans.back().e - spans.front().b);
+        size_t t = 0;
+        first[0] = 0;
+        for (size_t i = 0; i < spans.size() && t + 1 < T; ++i) {
+            if ((size_t)(spans[i].b - spans.front().b) >= (t + 1) * total / T) first[++t] = i;
+        }
+        for (size_t k = t + 1; k <= T; ++k) first[k] = spans.size();
+    }
+    std::vector<Witness> part(T);
+    std::vector<std::string> perr(T);
+    std::vector<const char*> perr_at(T, nullptr);
+    auto work = [&](size_t t) {
+        Witness& lw = part[t];
+        lw.node_off.push_back(0);
+        lw.proof_first_node.push_back(0);
+        lw.preimage_off.push_back(0);
+        if (first[t] < first[t + 1]) lw.nodes.reserve((size_t)(spans[first[t + 1] - 1].e - spans[first[t]].b) / 2);
+        Builder b(lw);
+        for (size_t i = first[t]; i < first[t + 1]; ++i) {
+            Parser sub{spans[i].b, spans[i].e, std::string(), json};
+            bool good = parse_account(sub, b);
+            if (good) {
+                sub.ws();
+                if (sub.p != sub.end) good = sub.fail("unexpected character");
+            }
+            if (!good) {
+                perr[t] = sub.err;
+                perr_at[t] = sub.p;
+                return;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (size_t t = 0; t < T; ++t)
+        if (perr_at[t]) {  // the first failing thread holds the earliest error of the document
+            err = perr[t];
+            w = Witness();
+            return false;
+        }
+
+    // ---- pass 3 (parallel again): sizes are known now, every thread copies its piece to its place ----
+    std::vector<size_t> acc0(T + 1, 0), proof0(T + 1, 0), node0(T + 1, 0), pre0(T + 1, 0), byte0(T + 1, 0), slot0(T + 1, 0);
+    for (size_t t = 0; t < T; ++t) {
+        const Witness& lw = part[t];
+        acc0[t + 1] = acc0[t] + lw.accounts.size();
+        proof0[t + 1] = proof0[t] + lw.root_idx.size();
+        node0[t + 1] = node0[t] + (lw.node_off.size() - 1);
+        pre0[t + 1] = pre0[t] + lw.preimages.size();
+        byte0[t + 1] = byte0[t] + lw.nodes.size();
+        slot0[t + 1] = slot0[t] + lw.slots.size();
+    }
+    w = Witness();
+    w.roots.resize(32 * (acc0[T] + 1));
+    std::memcpy(w.roots.data(), state_root, 32);
+    w.root_idx.resize(proof0[T]);
+    w.account_of.resize(proof0[T]);
+    w.preimages.resize(pre0[T]);
+    w.preimage_off.resize(proof0[T] + 1);
+    w.nodes.resize(byte0[T]);
+    w.node_off.resize(node0[T] + 1);
+    w.proof_first_node.resize(proof0[T] + 1);
+    w.accounts.resize(acc0[T]);
+    w.slots.resize(slot0[T]);
+    w.node_off[0] = 0;
+    w.proof_first_node[0] = 0;
+    w.preimage_off[0] = 0;
+    auto place = [&](size_t t) {
+        const Witness& lw = part[t];
+        const uint32_t a0 = (uint32_t)acc0[t], p0 = (uint32_t)proof0[t], n0 = (uint32_t)node0[t], q0 = (uint32_t)pre0[t];
+        const uint64_t b0 = (uint64_t)byte0[t];
+        if (!lw.roots.empty()) std::memcpy(w.roots.data() + 32 * (1 + (size_t)a0), lw.roots.data(), lw.roots.size());
+        for (size_t i = 0; i < lw.root_idx.size(); ++i) {
+            w.root_idx[p0 + i] = lw.root_idx[i] ? lw.root_idx[i] + a0 : 0u;  // 0 = stateRoot, else 1 + account
+            w.account_of[p0 + i] = lw.account_of[i] + a0;
+        }
+        if (!lw.preimages.empty()) std::memcpy(w.preimages.data() + q0, lw.preimages.data(), lw.preimages.size());
+        for (size_t i = 1; i < lw.preimage_off.size(); ++i) w.preimage_off[p0 + i] = lw.preimage_off[i] + q0;
+        if (!lw.nodes.empty()) std::memcpy(w.nodes.data() + b0, lw.nodes.data(), lw.nodes.size());
+        for (size_t i = 1; i < lw.node_off.size(); ++i) w.node_off[n0 + i] = lw.node_off[i] + b0;
+        for (size_t i = 1; i < lw.proof_first_node.size(); ++i) w.proof_first_node[p0 + i] = lw.proof_first_node[i] + n0;
+        for (size_t i = 0; i < lw.accounts.size(); ++i) {
+            WitnessAccount a = lw.accounts[i];
+            a.proof += p0;
+            w.accounts[a0 + i] = a;
+        }
+        for (size_t i = 0; i < lw.slots.size(); ++i) {
+            WitnessSlot sl = lw.slots[i];
+            sl.proof += p0;
+            sl.account += a0;
+            w.slots[slot0[t] + i] = sl;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; ++t) th.emplace_back(place, t);
+        place(0);
+        for (auto& x : th) x.join();
     }
     return true;
 }

@@ -45,12 +45,13 @@ class ExecutionWitness:
         self._lib = L.lib()
 
     @staticmethod
-    def parse_json(text: str | bytes) -> "ExecutionWitness":
+    def parse_json(text: str | bytes, threads: int = 1) -> "ExecutionWitness":
+        """threads: host threads to parse the accounts on (0 = all the host has, at most 32)."""
         lib = L.lib()
         data = text.encode() if isinstance(text, str) else bytes(text)
         h = C.c_void_p()
         err = C.create_string_buffer(256)
-        rc = lib.phant_witness_parse_json(data, len(data), C.byref(h), err, 256)
+        rc = lib.phant_witness_parse_json_mt(data, len(data), threads, C.byref(h), err, 256)
         if rc != L.OK:
             raise WitnessFormatError(err.value.decode() or f"phant_witness_parse_json rc={rc}")
         return ExecutionWitness(h)

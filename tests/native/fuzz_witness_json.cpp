@@ -49,7 +49,19 @@ int main(int argc, char** argv) {
                 default: s[at] = structural[rnd() % (sizeof structural - 1)]; break;
             }
         }
-        if (phant::witness_parse_json(s.data(), s.size(), w, err)) {
+        const bool parsed = phant::witness_parse_json(s.data(), s.size(), w, err);
+        if ((it & 7) == 0) {  // the threaded parser must agree with the serial one, verdict and content
+            phant::Witness w2;
+            std::string err2;
+            const bool parsed2 = phant::witness_parse_json_mt(s.data(), s.size(), 3, w2, err2);
+            if (parsed != parsed2 || (parsed && (w.nodes != w2.nodes || w.node_off != w2.node_off || w.root_idx != w2.root_idx ||
+                                                 w.proof_first_node != w2.proof_first_node || w.preimages != w2.preimages ||
+                                                 w.roots != w2.roots))) {
+                std::fprintf(stderr, "threaded parser disagrees at edit %d\n", it);
+                return 6;
+            }
+        }
+        if (parsed) {
             ++ok;
             // a parsed witness must be internally consistent
             if (w.proof_first_node.size() != w.root_idx.size() + 1 || w.preimage_off.size() != w.root_idx.size() + 1 ||

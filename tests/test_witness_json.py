@@ -106,7 +106,7 @@ def test_parser_survives_damaged_documents_under_sanitizers(oracle, tmp_path):
         pytest.skip("no g++")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "fuzz_witness_json"
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
            os.path.join(root, "tests", "native", "fuzz_witness_json.cpp"),
            os.path.join(root, "phant_amd", "csrc", "witness_json.cpp"), "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -119,4 +119,62 @@ def test_parser_survives_damaged_documents_under_sanitizers(oracle, tmp_path):
     seed.write_text(json.dumps(doc))
     r = subprocess.run([str(exe), str(seed), "20000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    # a document large enough for the threaded parser to take its parallel path (>= 1 MiB)
+    big, _, _ = block_witness_json(oracle, np.random.default_rng(6), n_accounts=1500, n_contracts=40, max_slots=150,
+                                   n_touched=700, slots_per=6)
+    seed.write_text(json.dumps(big))
+    assert seed.stat().st_size > (1 << 20)
+    r = subprocess.run([str(exe), str(seed), "400"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     assert "variants parsed" in r.stdout
+
+
+def test_member_order_does_not_matter(EA, oracle):
+    """storageProof before accountProof, address last, proof before key: the packed arrays are the same
+    (account proof first, then its storage proofs, in document order of the entries)."""
+    rng = np.random.default_rng(9)
+    doc, _, _ = block_witness_json(oracle, rng, n_accounts=80, n_contracts=6, max_slots=30, n_touched=12, slots_per=4)
+    ref = EA.ExecutionWitness.parse_json(json.dumps(doc))
+    shuffled = {"accounts": [], "stateRoot": doc["stateRoot"]}
+    for a in doc["accounts"]:
+        sp = [{"proof": e["proof"], "value": e["value"], "key": e["key"]} for e in a["storageProof"]]
+        shuffled["accounts"].append({"storageProof": sp, "nonce": a["nonce"], "storageHash": a["storageHash"],
+                                     "accountProof": a["accountProof"], "codeHash": a["codeHash"],
+                                     "balance": a["balance"], "address": a["address"]})
+    got = EA.ExecutionWitness.parse_json(json.dumps(shuffled))
+    a, b = ref.info(), got.info()
+    for k in ("n_proofs", "n_roots", "n_accounts", "n_slots", "total_nodes", "nodes_len"):
+        assert a[k] == b[k], k
+    for k in ("roots", "root_idx", "account_of", "preimages", "preimage_off", "nodes", "node_off", "proof_first_node"):
+        assert np.array_equal(a[k], b[k]), k
+    ref.close()
+    got.close()
+    # duplicated members are rejected rather than silently merged
+    dup = json.dumps(doc["accounts"][0])[:-1] + ', "accountProof": []}'
+    with pytest.raises(EA.WitnessFormatError):
+        EA.ExecutionWitness.parse_json('{"stateRoot": "' + doc["stateRoot"] + '", "accounts": [' + dup + "]}")
+
+
+def test_threaded_parse_is_byte_identical(EA, oracle):
+    rng = np.random.default_rng(10)
+    doc, _, _ = block_witness_json(oracle, rng, n_accounts=3000, n_contracts=60, max_slots=200, n_touched=1500,
+                                   slots_per=8)
+    text = json.dumps(doc)
+    assert len(text) > (1 << 20)  # above the size where the threaded path engages
+    ref = EA.ExecutionWitness.parse_json(text, threads=1)
+    a = ref.info()
+    for threads in (2, 3, 8, 0):
+        got = EA.ExecutionWitness.parse_json(text, threads=threads)
+        b = got.info()
+        for k in ("n_proofs", "n_roots", "n_accounts", "n_slots", "total_nodes", "nodes_len"):
+            assert a[k] == b[k], (threads, k)
+        for k in ("roots", "root_idx", "account_of", "preimages", "preimage_off", "nodes", "node_off", "proof_first_node"):
+            assert np.array_equal(a[k], b[k]), (threads, k)
+        got.close()
+    ref.close()
+    # an error deep inside one account is reported by the threaded parser too
+    bad = text.replace('"accountProof": ["0x', '"accountProof": ["0xzz', 1)
+    bad = bad[: len(bad) // 2] + bad[len(bad) // 2:].replace('"0x', '"0xq', 1)
+    for threads in (1, 4):
+        with pytest.raises(EA.WitnessFormatError):
+            EA.ExecutionWitness.parse_json(bad, threads=threads)
