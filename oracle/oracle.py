@@ -78,6 +78,10 @@ def lib():
                                                  C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                                  C.c_void_p]
         _lib.oracle_mpt_verify_batch.restype = None
+        _lib.oracle_mpt_verify_batch_checked.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                         C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.oracle_mpt_verify_batch_checked.restype = None
         _lib.oracle_mpt_verify_nodeset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                                    C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]
@@ -224,6 +228,24 @@ def mpt_verify_batch(roots, root_idx, keys, key_len, nodes, node_off, proof_firs
     vlen = np.zeros(n, np.uint32)
     lib().oracle_mpt_verify_batch(_p(roots), None if ri is None else _p(ri), _p(keys), key_len, _p(nodes),
                                   _p(node_off), _p(pfn), n, _p(status), _p(voff), _p(vlen))
+    return status, voff, vlen
+
+
+def mpt_verify_batch_checked(roots, root_idx, keys, key_len, nodes, node_off, proof_first_node, nodes_len=None):
+    """mpt_verify_batch with the BAD_INPUT checks of DESIGN.md section 3 (arbitrary offsets are safe here)."""
+    roots = np.ascontiguousarray(roots, np.uint8)
+    keys = np.ascontiguousarray(keys, np.uint8)
+    nodes = np.ascontiguousarray(nodes, np.uint8)
+    node_off = np.ascontiguousarray(node_off, np.uint64)
+    pfn = np.ascontiguousarray(proof_first_node, np.uint32)
+    n = len(pfn) - 1
+    ri = None if root_idx is None else np.ascontiguousarray(root_idx, np.uint32)
+    status = np.zeros(n, np.uint8)
+    voff = np.zeros(n, np.uint64)
+    vlen = np.zeros(n, np.uint32)
+    lib().oracle_mpt_verify_batch_checked(_p(roots), roots.size // 32, None if ri is None else _p(ri), _p(keys), key_len,
+                                          _p(nodes), nodes.size if nodes_len is None else nodes_len, _p(node_off),
+                                          len(node_off) - 1, _p(pfn), n, _p(status), _p(voff), _p(vlen))
     return status, voff, vlen
 
 

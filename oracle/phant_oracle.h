@@ -102,6 +102,12 @@ enum {
 };
 
 /* Verify one proof.  value_off is relative to `nodes`. */
+/* oracle_mpt_verify_batch with the input checks of DESIGN.md section 3 (BAD_INPUT). */
+void oracle_mpt_verify_batch_checked(const uint8_t *roots, uint32_t n_roots, const uint32_t *root_idx,
+                                     const uint8_t *keys, uint32_t key_len, const uint8_t *nodes,
+                                     uint64_t nodes_len, const uint64_t *node_off, uint32_t total_nodes,
+                                     const uint32_t *proof_first_node, uint32_t n, uint8_t *status,
+                                     uint64_t *value_off, uint32_t *value_len);
 /* Node-SET witnesses: the m nodes are an unordered set, every reference is resolved by hash
  * (MISSING_NODE when no node of the set hashes to it; BAD_HASH / EXTRA_NODES / INVALID_EMPTY do not
  * occur).  0 = ok, -1 = out of memory. */

@@ -128,7 +128,8 @@ static int64_t nodeset_find(const nodeset *s, const uint8_t want[32]) {
  * EXTRA_NODES and no INVALID_EMPTY in that form. */
 static uint8_t verify_core(const uint8_t root[32], const uint8_t *key, uint32_t key_len,
                            const uint8_t *nodes, const uint64_t *node_off, uint32_t n_nodes,
-                           const nodeset *set, uint64_t *value_off, uint32_t *value_len) {
+                           const nodeset *set, uint64_t nodes_len /* ~0 = offsets are trusted */,
+                           uint64_t *value_off, uint32_t *value_len) {
     if (value_off)
         *value_off = 0;
     if (value_len)
@@ -158,6 +159,11 @@ static uint8_t verify_core(const uint8_t root[32], const uint8_t *key, uint32_t 
         } else if (by_hash) {
             if (used == n_nodes)
                 return ORACLE_PROOF_MISSING_NODE;
+            if (nodes_len != ~(uint64_t)0) { /* inconsistent node_off -> BAD_INPUT, when reached */
+                uint64_t b = node_off[used], e = node_off[used + 1];
+                if (e < b || e > nodes_len || e - b > 0x7fffffffull)
+                    return ORACLE_PROOF_BAD_INPUT;
+            }
             cur = nodes + node_off[used];
             cur_len = (size_t)(node_off[used + 1] - node_off[used]);
             used++;
@@ -282,7 +288,7 @@ static uint8_t verify_core(const uint8_t root[32], const uint8_t *key, uint32_t 
 uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key, uint32_t key_len,
                           const uint8_t *nodes, const uint64_t *node_off, uint32_t n_nodes,
                           uint64_t *value_off, uint32_t *value_len) {
-    return verify_core(root, key, key_len, nodes, node_off, n_nodes, NULL, value_off, value_len);
+    return verify_core(root, key, key_len, nodes, node_off, n_nodes, NULL, ~(uint64_t)0, value_off, value_len);
 }
 
 static const uint8_t *g_sort_digests; /* qsort has no context argument; the oracle is single-threaded here */
@@ -313,7 +319,7 @@ int oracle_mpt_verify_nodeset(const uint8_t *roots, const uint32_t *root_idx, co
         const uint8_t *root = roots + 32 * (size_t)(root_idx ? root_idx[i] : 0);
         uint64_t vo = 0;
         uint32_t vl = 0;
-        status[i] = verify_core(root, keys + (size_t)key_len * i, key_len, nodes, node_off, m, &set, &vo, &vl);
+        status[i] = verify_core(root, keys + (size_t)key_len * i, key_len, nodes, node_off, m, &set, ~(uint64_t)0, &vo, &vl);
         if (value_off)
             value_off[i] = vo;
         if (value_len)
@@ -345,6 +351,31 @@ void oracle_mpt_verify_batch(const uint8_t *roots, const uint32_t *root_idx, con
          * to `nodes`, so pass the sub-array and keep offsets absolute */
         status[i] = oracle_mpt_verify(root, keys + (size_t)key_len * i, key_len, nodes,
                                       node_off + f, l - f, &vo, &vl);
+        if (value_off)
+            value_off[i] = vo;
+        if (value_len)
+            value_len[i] = vl;
+    }
+}
+
+/* The batch form with every consistency check of DESIGN.md section 3 (what the C-ABI promises for
+ * arbitrary inputs): proof_first_node going backwards or past total_nodes, root_idx >= n_roots -> BAD_INPUT for
+ * that proof; a node whose offsets are inconsistent -> BAD_INPUT when the walk reaches it. */
+void oracle_mpt_verify_batch_checked(const uint8_t *roots, uint32_t n_roots, const uint32_t *root_idx,
+                                     const uint8_t *keys, uint32_t key_len, const uint8_t *nodes,
+                                     uint64_t nodes_len, const uint64_t *node_off, uint32_t total_nodes,
+                                     const uint32_t *proof_first_node, uint32_t n, uint8_t *status,
+                                     uint64_t *value_off, uint32_t *value_len) {
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t f = proof_first_node[i], l = proof_first_node[i + 1];
+        uint32_t r = root_idx ? root_idx[i] : 0;
+        uint64_t vo = 0;
+        uint32_t vl = 0;
+        if (l < f || l > total_nodes || r >= n_roots)
+            status[i] = ORACLE_PROOF_BAD_INPUT;
+        else
+            status[i] = verify_core(roots + 32 * (size_t)r, keys + (size_t)key_len * i, key_len, nodes, node_off + f,
+                                    l - f, NULL, nodes_len, &vo, &vl);
         if (value_off)
             value_off[i] = vo;
         if (value_len)

@@ -207,3 +207,38 @@ def test_nodeset_form_agrees_with_ordered_proofs(oracle):
     # empty set: nothing hashes to the root
     st3, _, _ = oracle.mpt_verify_nodeset(root, None, karr[:64], 32, np.zeros(1, np.uint8), np.zeros(1, np.uint64))
     assert (st3 == 20).all()
+
+
+def test_checked_batch_form(oracle):
+    """oracle_mpt_verify_batch_checked = the unchecked form on consistent inputs, and BAD_INPUT exactly where
+    DESIGN.md section 3 says (same cases as tests/test_gpu_verify.py::test_bad_offsets_are_flagged)."""
+    import numpy as np
+    from tests.witness_util import random_kv, pack_proofs
+    rng = np.random.default_rng(31)
+    keys, vals = random_kv(rng, 120, 32, 1, 70)
+    t = oracle.Trie(keys, vals)
+    q = keys[:60] + [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(20)]
+    proofs = [t.prove(k) for k in q]
+    for i in range(0, len(proofs), 7):
+        nd = bytearray(proofs[i][-1])
+        nd[len(nd) // 2] ^= 2
+        proofs[i] = proofs[i][:-1] + [bytes(nd)]
+    nodes, node_off, pfn = pack_proofs(proofs)
+    roots = np.frombuffer(t.root() + bytes(32), np.uint8)
+    ridx = (np.arange(len(q)) % 11 == 0).astype(np.uint32)
+    karr = np.frombuffer(b"".join(q), np.uint8)
+    a = oracle.mpt_verify_batch(roots, ridx, karr, 32, nodes, node_off, pfn)
+    b = oracle.mpt_verify_batch_checked(roots, ridx, karr, 32, nodes, node_off, pfn)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # root_idx out of range, proof_first_node past the node table
+    ridx2 = ridx.copy()
+    ridx2[3] = 2
+    pfn2 = pfn.copy()
+    pfn2[-1] = len(node_off) + 5
+    st, _, _ = oracle.mpt_verify_batch_checked(roots, ridx2, karr, 32, nodes, node_off, pfn2)
+    assert st[3] == 21 and st[-1] == 21
+    assert np.array_equal(np.delete(st, [3, len(q) - 1]), np.delete(a[0], [3, len(q) - 1]))
+    # the GPU test's case: offsets decreasing, then past the end
+    st, _, _ = oracle.mpt_verify_batch_checked(np.zeros(32, np.uint8), None, np.zeros(64, np.uint8), 32, np.zeros(100, np.uint8),
+                                               np.array([0, 50, 40, 1000], np.uint64), np.array([0, 1, 3], np.uint32))
+    assert st.tolist() == [16, 21]
