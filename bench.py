@@ -313,8 +313,11 @@ def main():
     if args.workload == "config3" and S > 1:
         # setup, not warm-up: every slot's ctx allocates its device workspace on its first call (hipMalloc
         # synchronises the device); keep that out of the W warm-up steps and the K timed steps
-        for _, c_, status_, fails_ in slots:
-            M.verify_batch_dev(b, status=status_, ctx=c_, fail_count=fails_)
+        for st_, c_, status_, fails_ in slots:
+            with torch.cuda.stream(st_):
+                M.verify_batch_dev(b, status=status_, ctx=c_, fail_count=fails_)
+                if world > 1:  # (a slot that K + W < S never reaches still ends with the all-rank verdict)
+                    dist.all_reduce(fails_)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -413,9 +416,9 @@ def main():
                                 "node-set pipeline = dedup_kernel (class lists) + hash_chunk_kernel + "
                                 "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
                                 "mpt_verify_fused_kernel" if args.verify_mode == "fused" else
-                                "verify pipeline = plan_kernel + dedup_kernel + hash_list_kernel + link_kernel + "
+                                "verify pipeline = plan_kernel + dedup_kernel + hash_chunk_kernel + link_kernel + "
                                 "walk_proofs_kernel + mpt_verify_fixup_kernel (one launch of the path, first "
-                                "kernel start to last kernel end; hash_list_kernel is ~55 % of it and is "
+                                "kernel start to last kernel end; hash_chunk_kernel is ~50 % of it and is "
                                 "integer-VALU-bound, see roofline.valu)"),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
