@@ -28,7 +28,12 @@
  *   device form `phant_xxx_dev(ctx, device pointers...)`  asynchronous on the
  *               ctx stream, inputs and outputs already resident in HBM (what
  *               bench.py times, and what a caller that keeps witnesses on the
- *               GPU uses).
+ *               GPU uses).  Device loads are dword-granular: of a byte buffer
+ *               (`d_blob`, `d_nodes`, `d_keys`) the kernels may read every
+ *               4-byte-aligned dword that holds one of its bytes, so a buffer
+ *               must not end inside a dword that the device cannot read --
+ *               true of anything hipMalloc'd (or a sub-range of it); nothing
+ *               beyond that dword is ever touched.
  */
 #ifndef PHANT_GPU_H
 #define PHANT_GPU_H

@@ -1,0 +1,32 @@
+"""Trie hasher parity (mptize, index roots, state root), a second time on the CPU: the test bodies of tests/test_gpu_trie.py (imported, unchanged) against
+libphant_emu.so -- the SAME kernel sources (phant_amd/csrc/*.hip) compiled for the host with g++ over
+tests/native/shim/hip/hip_runtime.h, which runs every workgroup with lockstep wavefronts (tests/emu.py).  Checks
+the logic and address arithmetic of the sources on every CPU run; not a substitute for -m gpu (which checks what
+hipcc made of them on the MI355X) and never used by the product: the loader patch lives and dies with this module."""
+import numpy as np
+import pytest
+
+from tests import emu
+
+try:
+    _LIB = emu.load_mirror_lib()
+except RuntimeError as e:  # no g++
+    pytest.skip(str(e), allow_module_level=True)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emulated_backend():
+    yield from emu.emulated_backend(_LIB)
+
+
+@pytest.fixture(scope="module")
+def P():
+    import phant_amd
+    return phant_amd
+
+
+from tests.test_gpu_trie import (  # noqa: E402,F401
+    test_mptize_reference_vectors, test_mptize_rejects_unsorted, test_mptize_random_vs_oracle,
+    test_mptize_variable_length_keys_and_branch_values, test_fixture_tx_and_withdrawal_roots,
+    test_index_root_be32_vs_oracle, test_fixture_state_roots, test_state_root_random_vs_oracle,
+    test_sharded_mptize_matches_the_single_gpu_root)

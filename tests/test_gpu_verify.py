@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 class _Mode:
     """phant_amd.mpt with every verify call bound to one ctx (flat pipeline serial / overlapped / without in-batch node dedup, or the fused kernel)."""
 
-    def __init__(self, mod, ctx):
-        self._mod, self._ctx = mod, ctx
+    def __init__(self, mod, ctx, mode=None):
+        self._mod, self._ctx, self.mode = mod, ctx, mode
 
     def __getattr__(self, name):
         return getattr(self._mod, name)
@@ -32,7 +32,7 @@ def M(request):
     ctx = phant_amd.Context(verify_fused=(request.param == "fused"), verify_nodedup=(request.param == "nodedup"),
                             verify_overlap=(request.param == "overlap"),
                             verify_pipelined=(request.param == "pipelined"))
-    yield _Mode(phant_amd.mpt, ctx)
+    yield _Mode(phant_amd.mpt, ctx, request.param)
     ctx.close()
 
 
@@ -357,3 +357,24 @@ def test_fused_verdict_equals_the_separate_call(M, oracle):
     want = oracle.mpt_verify_batch(np.frombuffer(b"".join(roots), np.uint8), ridx, np.frombuffer(b"".join(keys), np.uint8), 32,
                                    nodes, node_off, pfn)
     assert np.array_equal(st.cpu().numpy(), want[0])
+
+
+def test_keys_longer_than_the_lds_staging(M, oracle):
+    """Keys of 40 / 64 / 80 bytes: the walk kernel stages keys of up to 32 bytes in LDS and reads longer ones
+    from global memory, a branch of its own (every other test here has keys of <= 32 bytes)."""
+    from tests.witness_util import adversarial_proofs, pack_proofs
+    rng = np.random.default_rng(4064)
+    cases = adversarial_proofs(oracle, rng, shapes=[(150, 40, 0), (150, 64, 8), (40, 80, 0), (60, 33, 0)], garbage=0)
+    for key_len in (33, 40, 64, 80):
+        sel = [c for c in cases if len(c[1]) == key_len]
+        assert len(sel) > 50
+        roots = sorted({c[0] for c in sel})
+        ridx = np.array([roots.index(c[0]) for c in sel], np.uint32)
+        nodes, node_off, pfn = pack_proofs([c[2] for c in sel])
+        r = np.frombuffer(b"".join(roots), np.uint8)
+        keys = np.frombuffer(b"".join(c[1] for c in sel), np.uint8)
+        got = M.verify_batch(r, ridx, keys, key_len, nodes, node_off, pfn)
+        want = oracle.mpt_verify_batch(r, ridx, keys, key_len, nodes, node_off, pfn)
+        assert np.array_equal(got[0], want[0]), (key_len, got[0][:20], want[0][:20])
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        assert {M.PROOF_PRESENT, M.PROOF_ABSENT} <= set(got[0].tolist())

@@ -64,7 +64,7 @@ def _oracle_verify(oracle):
     return f
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, emulated=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -77,7 +77,16 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         b = _two_root_witness(O)
-        mine, status, fc = shard.verify_sharded(b, rank, world, verify=_oracle_verify(O))
+        if emulated:
+            # the product's own per-rank verifier (shard.gpu_verify -> C-ABI), the kernels run by the host
+            # emulation of tests/emu.py instead of a GPU
+            from tests import emu
+            backend = emu.emulated_backend(emu.load_mirror_lib())
+            next(backend)
+            mine, status, fc = shard.verify_sharded(b, rank, world)
+            backend.close()
+        else:
+            mine, status, fc = shard.verify_sharded(b, rank, world, verify=_oracle_verify(O))
         q.put((rank, mine.tolist(), status.tolist(), fc.tolist()))
     finally:
         dist.destroy_process_group()
@@ -108,8 +117,16 @@ def test_take_proofs_roundtrip(oracle):
     assert empty.n == 0 and empty.nodes.size == 0
 
 
-def test_world2_gloo_matches_single_process(oracle):
+@pytest.mark.parametrize("emulated", [False, True], ids=["oracle-per-rank", "emulated-kernels-per-rank"])
+def test_world2_gloo_matches_single_process(oracle, emulated):
     import torch.multiprocessing as mp
+
+    if emulated:
+        from tests import emu
+        try:
+            emu.build()  # once, before the ranks race for it
+        except RuntimeError as e:
+            pytest.skip(str(e))
 
     from phant_amd import shard
 
@@ -121,7 +138,7 @@ def test_world2_gloo_matches_single_process(oracle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, emulated)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in procs]

@@ -90,7 +90,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, emulated=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
@@ -104,17 +104,32 @@ def _worker(rank, world, port, q):
     try:
         out = []
         rng = np.random.default_rng(2)
+        if emulated:
+            from tests import emu
+            backend = emu.emulated_backend(emu.load_mirror_lib())
+            next(backend)
         for keys, vals in _cases(rng):
             order = sorted(range(len(keys)), key=lambda i: keys[i])
             keys, vals = [keys[i] for i in order], [vals[i] for i in order]
-            out.append(shard.mptize_sharded(keys, vals, rank, world, root_nodes=_oracle_root_nodes(O), keccak=O.keccak256).hex())
+            if emulated:  # the product defaults (phant_mpt_root_nodes / phant_keccak256), kernels on tests/emu.py
+                out.append(shard.mptize_sharded(keys, vals, rank, world).hex())
+            else:
+                out.append(shard.mptize_sharded(keys, vals, rank, world, root_nodes=_oracle_root_nodes(O), keccak=O.keccak256).hex())
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
-def test_world2_gloo(oracle):
+@pytest.mark.parametrize("emulated", [False, True], ids=["oracle-per-rank", "emulated-kernels-per-rank"])
+def test_world2_gloo(oracle, emulated):
     import torch.multiprocessing as mp
+
+    if emulated:
+        from tests import emu
+        try:
+            emu.build()  # once, before the ranks race for it
+        except RuntimeError as e:
+            pytest.skip(str(e))
 
     rng = np.random.default_rng(2)
     want = []
@@ -124,7 +139,7 @@ def test_world2_gloo(oracle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, emulated)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in procs]
