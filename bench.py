@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's headline metric on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--proofs P] [--workload config3|config2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--proofs P] [--workload config3|config2|config4|config5|nodeset]
 
 A "step" = one pass of the hot path over one batch of synthetic input already
 resident in HBM:
@@ -13,6 +13,10 @@ resident in HBM:
   config2: Keccak-256 of 1 048 576 x 136-byte messages (sponge kernel only).
   nodeset: config 3's proofs as a node SET (every distinct node shipped once, references resolved by
       hash; phant_mpt_verify_nodeset_dev).
+  config4: the witness of one 10 000-transaction block (phant_amd.witness.BLOCK_10K_TX: 20 000 depth-8 account
+      proofs + 60 000 storage proofs over 2 000 contracts of depth 3 / 5 / 7, 2 001 roots) as one multi-root
+      batch, sharded over the N GPUs (accounts by top key nibble, contracts whole): STRONG scaling, one
+      all-reduce of the per-root failure counts per step.
   config5: consecutive block witnesses streamed from pinned host memory through
       phant_mpt_verify_submit / phant_wait (copy-in of witness k+1 overlaps the kernels of witness k);
       a step = one witness of --stream-proofs depth-8 proofs; PCIe-bound by construction.
@@ -69,7 +73,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5", "nodeset"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5", "nodeset"])
+    ap.add_argument("--block-scale", type=float, default=1.0, help="config4: size of the block relative to 10k tx")
     ap.add_argument("--stream-proofs", type=int, default=20_000, help="proofs per streamed witness (config5)")
     ap.add_argument("--stream-slots", type=int, default=3, help="witnesses in flight (config5)")
     ap.add_argument("--verify-mode", default="flat", choices=["flat", "pipelined", "overlap", "nodedup", "fused"],
@@ -152,6 +157,36 @@ def cpu_baseline_config3(w, target_seconds):
     return out
 
 
+def cpu_baseline_block(w, target_seconds):
+    """config 4: the CPU oracle, 1 core, on an evenly strided sample of the block's proofs (all depth classes)."""
+    import numpy as np
+    from oracle import oracle as O
+    from phant_amd.shard import HostBatch, take_proofs
+
+    b = w.batch
+    hb = HostBatch(roots=b.roots.cpu().numpy(), root_idx=b.root_idx.cpu().numpy().astype(np.uint32),
+                   keys=b.keys.cpu().numpy(), nodes=b.nodes.cpu().numpy(),
+                   node_off=b.node_off.cpu().numpy().astype(np.uint64),
+                   proof_first_node=b.proof_first_node.cpu().numpy().astype(np.uint32))
+    exp = w.expected.cpu().numpy()
+
+    def run(cnt):
+        idx = np.linspace(0, hb.n - 1, cnt).astype(np.int64)
+        sub = take_proofs(hb, idx)
+        t0 = time.perf_counter()
+        st, _, _ = O.mpt_verify_batch(sub.roots, sub.root_idx, sub.keys, 32, sub.nodes, sub.node_off, sub.proof_first_node)
+        return st, time.perf_counter() - t0, idx
+
+    probe = min(hb.n, 2000)
+    st, dt, idx = run(probe)
+    cnt = int(max(probe, min(hb.n, probe / dt * target_seconds)))
+    st, dt, idx = run(cnt)
+    return {"value": cnt / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": f"{cnt} evenly strided proofs of the {hb.n}-proof block witness, oracle/verify.c single-threaded, "
+                      f"{dt:.1f} s", "host_cpus": os.cpu_count(),
+            "statuses_match_gpu_expected": bool((st == exp[idx]).all())}
+
+
 def cpu_baseline_config2(blob, n, target_seconds):
     import numpy as np
     from oracle import oracle as O
@@ -200,14 +235,19 @@ def main():
                             verify_overlap=(args.verify_mode == "overlap"),
                             verify_pipelined=(args.verify_mode == "pipelined"))
 
-    if args.workload == "config3":
-        w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
-                                              world=world, ctx=ctx)
+    proofs_like = args.workload in ("config3", "config4")  # a resident proof batch, verified + per-root verdict
+    if proofs_like:
+        if args.workload == "config3":
+            w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
+                                                  world=world, ctx=ctx)
+        else:
+            w = phant_amd.witness.block_witness(scale=args.block_scale, seed=4, device=dev, rank=rank, world=world,
+                                                ctx=ctx)
         b = w.batch
         n_units = b.n
         alg_bytes = b.algorithmic_bytes()
         status = torch.empty(n_units, dtype=torch.uint8, device=dev)
-        fails = torch.zeros(1, dtype=torch.int32, device=dev)
+        fails = torch.zeros(b.n_roots, dtype=torch.int32, device=dev)
         # S launch sequences in flight: step k runs on slot k mod S = its own HIP stream, ctx (workspace), status
         # and verdict buffers.  Every step is a full pass over the full batch; what overlaps is one step's
         # latency-bound plan / link / walk kernels with another step's VALU-bound hash kernel.
@@ -234,10 +274,19 @@ def main():
         def kernel_only():
             M.verify_batch_dev(b, status=status, ctx=ctx)
 
-        metric, unit = "mpt_proofs_verified_per_sec_depth%d" % args.depth, "proofs/s"
-        workload = (f"config3: {args.proofs} synthetic depth-{args.depth} account proofs per GPU against one state "
-                    f"root ({w.nodes_per_proof - 1} x 532 B full branches + 112 B leaf, {w.bytes_per_proof} B and "
-                    f"{w.perms_per_proof} Keccak-f per proof, 1% corrupted/exclusion, no cross-proof dedup)")
+        if args.workload == "config3":
+            metric, unit = "mpt_proofs_verified_per_sec_depth%d" % args.depth, "proofs/s"
+            workload = (f"config3: {args.proofs} synthetic depth-{args.depth} account proofs per GPU against one "
+                        f"state root ({w.nodes_per_proof - 1} x 532 B full branches + 112 B leaf, "
+                        f"{w.bytes_per_proof} B and {w.perms_per_proof} Keccak-f per proof, 1% corrupted/exclusion, "
+                        f"no cross-proof dedup)")
+        else:
+            metric, unit = "mpt_proofs_verified_per_sec_block_witness", "proofs/s"
+            workload = (f"config4: one synthetic {int(10000 * args.block_scale)}-tx block witness sharded over "
+                        f"{world} GPU(s): {n_units} account + storage proofs on this rank against {b.n_roots} roots "
+                        f"(state root + per-contract storage roots; depth 8 / 3 / 5 / 7 classes, "
+                        f"{w.nodes_per_proof:.2f} nodes, {w.bytes_per_proof:.0f} B and {w.perms_per_proof:.1f} "
+                        f"Keccak-f per proof on average, 1% corrupted/exclusion)")
     elif args.workload == "nodeset":
         w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
                                               world=world, ctx=ctx, corrupt_frac=0.0)
@@ -310,7 +359,7 @@ def main():
         torch.cuda.synchronize()
 
     streamed = args.workload == "config5"
-    if args.workload == "config3" and S > 1:
+    if proofs_like and S > 1:
         # setup, not warm-up: every slot's ctx allocates its device workspace on its first call (hipMalloc
         # synchronises the device); keep that out of the W warm-up steps and the K timed steps
         for st_, c_, status_, fails_ in slots:
@@ -340,13 +389,13 @@ def main():
     if args.workload == "nodeset":
         assert bool((status == 1).all()) and int(fails.item()) == 0, "node-set statuses differ from the expectation"
     single = None
-    if args.workload == "config3":
+    if proofs_like:
         exp_fail = torch.tensor([w.n_invalid], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(exp_fail)
         for _, _, status_, fails_ in slots:
             assert torch.equal(status_, w.expected), "verify statuses differ from the constructed expectation"
-            assert int(fails_.item()) == int(exp_fail.item()), (int(fails_.item()), int(exp_fail.item()))
+            assert int(fails_.sum().item()) == int(exp_fail.item()), (int(fails_.sum().item()), int(exp_fail.item()))
         if S > 1:  # the same K steps strictly one after the other, for the record
             barrier()
             t1 = time.perf_counter()
@@ -383,7 +432,7 @@ def main():
     k_avg_ms = sum(kms) / len(kms)
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
     extra = {}
-    if args.workload in ("config3", "config5") and args.verify_mode != "fused":
+    if args.workload in ("config3", "config4", "config5") and args.verify_mode != "fused":
         hashed = ctx.verify_stats()
         shipped = int(b.node_off.numel() - 1)
         kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
@@ -401,10 +450,10 @@ def main():
     line = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "scaling": "strong" if args.workload == "config4" else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}",
-                   "verify_mode": args.verify_mode if args.workload == "config3" else None,
-                   "streams": (S if args.workload == "config3" else 1)},
+                   "verify_mode": args.verify_mode if proofs_like else None,
+                   "streams": (S if proofs_like else 1)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "throughput_GBps": value / world * alg_bytes / n_units / 1e9,  # algorithmic bytes x the measured
@@ -431,7 +480,9 @@ def main():
                         "note": "PCIe Gen5 x16 spec; the streamed rate is H2D-bound, the kernels of one witness "
                                 "take roofline.kernel_avg_ms"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.workload in ("config3", "config5", "nodeset"):
+        if args.workload == "config4":
+            line["cpu_baseline"] = cpu_baseline_block(w, args.cpu_seconds)
+        elif args.workload in ("config3", "config5", "nodeset"):
             line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds)
         else:
             line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)

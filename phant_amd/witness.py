@@ -60,18 +60,27 @@ def _rand_u8(shape, gen, device):
 
 
 def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_frac: float = 0.01,
-                    rank: int = 0, world: int = 1, group=None, ctx=None) -> Witness:
+                    rank: int = 0, world: int = 1, group=None, ctx=None, n_tries: int = 0,
+                    value: bytes | None = None) -> Witness:
+    """n_tries = 0: one trie, shared by all ranks (the state trie).  n_tries >= 1: the n proofs are spread over
+    that many separate tries of the same depth, each with its own root (`batch.roots` is (<= n_tries, 32) and
+    `batch.root_idx` says which) -- the storage tries of a block witness; such tries belong to this rank
+    alone (any top nibble, no collective).  `value`: the RLP string payload of
+    every leaf (default: the 78-byte account body)."""
     assert 2 <= depth <= 9, "depth counts nodes per proof: (depth-1) branches + 1 leaf"
     assert world in (1, 2, 4, 8, 16)
     device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
     L = depth - 1  # branch levels; prefix of L nibbles identifies the leaf slot
-    owned_slots = (16 // world if world <= 16 else 0) * 16 ** (L - 1)
-    assert n <= owned_slots, f"depth {depth} has only {owned_slots} leaf slots per rank (asked for {n} proofs)"
+    shared_root = n_tries == 0
+    owned_slots = (16 // world if shared_root else 16) * 16 ** (L - 1)
+    assert n <= owned_slots * max(1, n_tries), \
+        f"depth {depth} has only {owned_slots} leaf slots per rank and trie (asked for {n} proofs, {n_tries} tries)"
     gen = torch.Generator(device=device)
     gen.manual_seed(seed * 1000003 + rank)
 
-    # ---- keys: distinct L-nibble prefixes, top nibble owned by this rank ----
-    owned = torch.tensor([x for x in range(16) if x % world == rank], device=device, dtype=torch.int64)
+    # ---- keys: distinct L-nibble prefixes (per trie), top nibble owned by this rank ----
+    owned = torch.tensor([x for x in range(16) if not shared_root or x % world == rank], device=device,
+                         dtype=torch.int64)
     rest_bits = 4 * (L - 1)
     need = n
     pref = torch.empty(0, dtype=torch.int64, device=device)
@@ -80,7 +89,10 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
         top = owned[torch.randint(0, owned.numel(), (m,), device=device, generator=gen)]
         rest = torch.randint(0, 1 << rest_bits, (m,), device=device, generator=gen) if rest_bits else \
             torch.zeros(m, dtype=torch.int64, device=device)
-        pref = torch.unique(torch.cat([pref, (top << rest_bits) | rest]))
+        cand = (top << rest_bits) | rest
+        if not shared_root:  # the trie number rides above the path: distinct (trie, path) pairs
+            cand = cand | (torch.randint(0, n_tries, (m,), device=device, generator=gen) << (4 * L))
+        pref = torch.unique(torch.cat([pref, cand]))
         need = n - pref.numel()
     pref = pref[torch.randperm(pref.numel(), device=device, generator=gen)[:n]]
     keys = _rand_u8((n, 32), gen, device)
@@ -91,18 +103,20 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
         keys[:, j // 2] = (b & 0x0F) | (nib << 4) if j % 2 == 0 else (b & 0xF0) | nib
 
     # ---- leaves ----
-    acct = _account_rlp()
+    acct = _account_rlp() if value is None else bytes(value)
+    assert len(acct) >= 2 and len(acct) < 200
+    val_hdr = bytes([0xB8, len(acct)]) if len(acct) > 55 else bytes([0x80 + len(acct)])
     path_nibbles = 64 - L
     if path_nibbles % 2:  # odd: flag 3, first nibble in the low half of byte 0
         hp = torch.cat([(0x30 | (keys[:, L // 2] & 0x0F)).unsqueeze(1), keys[:, L // 2 + 1:]], dim=1)
     else:
         hp = torch.cat([torch.full((n, 1), 0x20, dtype=torch.uint8, device=device), keys[:, L // 2:]], dim=1)
     hp_len = hp.shape[1]
-    assert 1 < hp_len <= 55 and len(acct) > 55
-    payload_len = 1 + hp_len + 2 + len(acct)
+    assert 1 < hp_len <= 55
+    payload_len = 1 + hp_len + len(val_hdr) + len(acct)
     assert 55 < payload_len < 256
     head = torch.tensor([0xF8, payload_len, 0x80 + hp_len], dtype=torch.uint8, device=device).expand(n, 3)
-    tail = torch.tensor(list(bytes([0xB8, len(acct)]) + acct), dtype=torch.uint8, device=device).expand(n, -1)
+    tail = torch.tensor(list(val_hdr + acct), dtype=torch.uint8, device=device).expand(n, -1)
     leaves = torch.cat([head, hp, tail], dim=1).contiguous()
     leaf_len = leaves.shape[1]
     child_hash = keccak256_fixed_dev(leaves.reshape(-1), leaf_len, n, ctx=ctx)
@@ -115,7 +129,7 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
     for l in range(L - 1, -1, -1):
         nib = (child_prefix & 0xF)
         parent_prefix = child_prefix >> 4
-        if l == 0 and world > 1:
+        if l == 0 and world > 1 and shared_root:
             # the root is shared by all ranks: gather the 16 level-1 hashes
             import torch.distributed as dist
             contrib = torch.zeros((16, 33), dtype=torch.int32, device=device)
@@ -146,10 +160,12 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
         level_nodes[l] = enc
         level_index[l] = uniq_inv[child_of_proof]
         child_hash = keccak256_fixed_dev(enc.reshape(-1), BRANCH_LEN, U, ctx=ctx)
-        if not (l == 0 and world > 1):
+        if not (l == 0 and world > 1 and shared_root):
             child_prefix = child_prefix_next
         child_of_proof = level_index[l]
-    root = child_hash.reshape(-1, 32)[:1].contiguous()
+    # level 0: one node per trie (parent prefix = the trie number), in ascending trie order
+    root = child_hash.reshape(-1, 32)[:1].contiguous() if shared_root else child_hash.reshape(-1, 32).contiguous()
+    root_idx = None if shared_root else child_of_proof.to(torch.int32).contiguous()
 
     # ---- ship every proof as its own node list ----
     proof_bytes = L * BRANCH_LEN + leaf_len
@@ -176,11 +192,75 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
         keys[excl, 31] ^= 0x01  # same path down to the leaf, different tail: proven absent
         expected[excl] = PROOF_ABSENT
         n_invalid = n_bad
-    batch = ProofBatch(roots=root, root_idx=None, keys=keys.contiguous(), nodes=nodes.reshape(-1),
+    batch = ProofBatch(roots=root, root_idx=root_idx, keys=keys.contiguous(), nodes=nodes.reshape(-1),
                        node_off=node_off.contiguous(), proof_first_node=pfn.contiguous())
     perms = L * ((BRANCH_LEN + 1 + 135) // 136) + (leaf_len + 1 + 135) // 136
     return Witness(batch=batch, expected=expected, n_invalid=n_invalid, nodes_per_proof=depth,
                    bytes_per_proof=proof_bytes + 32, perms_per_proof=perms, seed=seed)
+
+
+# BASELINE config 4: the witness of one 10 000-transaction block.  phant has no witness type yet (DESIGN.md
+# section 10), so the shape is an assumption, stated here: ~2 accounts touched per transaction = 20 000 account
+# proofs at depth 8 against the state root, and 60 000 storage proofs over 2 000 contracts in three classes --
+# 1 500 small ones (8 touched slots, storage trie depth 3), 450 medium (40 slots, depth 5), 50 large (600
+# slots, depth 7) -- each contract a trie and a root of its own (33-byte slot values).
+BLOCK_10K_TX = {"accounts": 20_000, "storage": [(3, 1500, 8), (5, 450, 40), (7, 50, 600)]}
+
+
+def block_witness(shape: dict | None = None, seed: int = 4, device=None, corrupt_frac: float = 0.01, rank: int = 0,
+                  world: int = 1, group=None, ctx=None, scale: float = 1.0) -> Witness:
+    """One block's account + storage proofs as ONE multi-root batch (root 0 = the state root, then the storage
+    roots).  `shape` = {"accounts": n, "storage": [(depth, contracts, slots_per_contract), ...]}, times `scale`.
+
+    Sharding: account proofs by the top key nibble as in account_witness (shared state root); contracts are
+    dealt to the ranks whole (contract c of a class to rank c % world), so a rank's storage roots are its own.
+    Every rank's `batch.roots` has the same layout -- state root, then per class and per rank the class's
+    contracts -- with the rows other ranks own zeroed: the per-root verdicts of all ranks add up with one
+    all-reduce (bench.py)."""
+    shape = shape or BLOCK_10K_TX
+    n_acc = max(2, int(shape["accounts"] * scale) // world)
+    parts = [account_witness(n_acc, depth=8, seed=seed, device=device, corrupt_frac=corrupt_frac, rank=rank,
+                             world=world, group=group, ctx=ctx)]
+    slot_value = bytes(range(0xA0, 0xA0 + 32))  # a 32-byte storage value, RLP a0 || 32 bytes in the leaf
+    part_roots = [1]  # roots each part contributes per rank
+    for k, (depth, contracts, slots) in enumerate(shape["storage"]):
+        per_rank = max(1, int(contracts * scale) // world)
+        w = account_witness(per_rank * slots, depth=depth, seed=seed * 31 + k, device=device,
+                            corrupt_frac=corrupt_frac, rank=rank, world=world, ctx=ctx, n_tries=per_rank,
+                            value=slot_value)
+        parts.append(w)
+        part_roots.append(per_rank)
+    # global root table: [state root | class 0: rank 0's tries, rank 1's, ... | class 1: ...]
+    dev = parts[0].batch.nodes.device
+    n_roots = 1 + world * sum(part_roots[1:])
+    roots = torch.zeros((n_roots, 32), dtype=torch.uint8, device=dev)
+    roots[0] = parts[0].batch.roots[0]
+    ridx, base = [torch.zeros(parts[0].batch.n, dtype=torch.int32, device=dev)], 1
+    for w, per_rank in zip(parts[1:], part_roots[1:]):
+        mine = base + rank * per_rank
+        have = w.batch.roots.shape[0]  # (a trie no proof landed in has no root)
+        roots[mine:mine + have] = w.batch.roots
+        ridx.append(w.batch.root_idx + mine)
+        base += world * per_rank
+    node_base, first_base, offs, pfns = 0, 0, [], []
+    for w in parts:
+        b = w.batch
+        offs.append(b.node_off[:-1] + node_base)
+        pfns.append(b.proof_first_node[:-1] + first_base)
+        node_base += int(b.nodes.numel())
+        first_base += int(b.node_off.numel() - 1)
+    offs.append(torch.tensor([node_base], dtype=torch.int64, device=dev))
+    pfns.append(torch.tensor([first_base], dtype=torch.int32, device=dev))
+    batch = ProofBatch(roots=roots, root_idx=torch.cat(ridx).contiguous(),
+                       keys=torch.cat([w.batch.keys for w in parts]).contiguous(),
+                       nodes=torch.cat([w.batch.nodes for w in parts]).contiguous(),
+                       node_off=torch.cat(offs).contiguous(), proof_first_node=torch.cat(pfns).contiguous())
+    n = batch.n
+    total_nodes = sum(w.nodes_per_proof * w.batch.n for w in parts)
+    total_perms = sum(w.perms_per_proof * w.batch.n for w in parts)
+    return Witness(batch=batch, expected=torch.cat([w.expected for w in parts]),
+                   n_invalid=sum(w.n_invalid for w in parts), nodes_per_proof=total_nodes / n,
+                   bytes_per_proof=(int(batch.nodes.numel()) + 32 * n) / n, perms_per_proof=total_perms / n, seed=seed)
 
 
 def as_node_set(batch: ProofBatch, ctx=None):

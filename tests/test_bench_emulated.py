@@ -1,0 +1,125 @@
+"""bench.py's control flow and JSON contract, dry-run on the CPU: the same main() with torch.cuda stubbed out
+(device memory = host memory, streams = no-ops) and phant_amd.Context bound to the emulated library
+(tests/emu.py), on miniature workloads.  Checks what the GPU box would only tell at round end: every workload
+builds, the timed statuses are the constructed ones, the verdict bookkeeping of the in-flight slots adds up, the
+line carries `roofline` and `cpu_baseline`.  The numbers themselves mean nothing here."""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import pytest
+
+from tests import emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+try:
+    _LIB = emu.load_mirror_lib()
+except RuntimeError as e:  # no g++
+    pytest.skip(str(e), allow_module_level=True)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emulated_backend():
+    yield from emu.emulated_backend(_LIB)
+
+
+@contextlib.contextmanager
+def _no_cuda():
+    import torch
+    import phant_amd
+
+    class _Stream:
+        cuda_stream = 0
+
+    real_device = torch.device
+    saved = (torch.device, torch.cuda.set_device, torch.cuda.current_stream, torch.cuda.Stream, torch.cuda.stream,
+             phant_amd.Context)
+
+    def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, verify_overlap=False,
+                verify_pipelined=False):
+        mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else "overlap" if verify_overlap else
+                "pipelined" if verify_pipelined else "flat")
+        return emu.mirror_context(_LIB, mode)
+
+    class _Device:  # torch.device("cuda", i) -> the CPU; isinstance checks inside torch still see a real device
+        def __new__(cls, *a, **k):
+            return real_device("cpu")
+
+    torch.device = _Device
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.Stream = lambda *a, **k: _Stream()
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    phant_amd.Context = context
+    try:
+        yield
+    finally:
+        (torch.device, torch.cuda.set_device, torch.cuda.current_stream, torch.cuda.Stream, torch.cuda.stream,
+         phant_amd.Context) = saved
+
+
+def _bench(argv):
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    sys.argv = ["bench.py", *argv]
+    out = io.StringIO()
+    try:
+        with _no_cuda(), contextlib.redirect_stdout(out):
+            bench.main()
+    finally:
+        sys.argv = old
+    lines = [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.getvalue()
+    return json.loads(lines[0])
+
+
+def _check_contract(line, steps, warmup):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == steps and line["warmup"] == warmup
+    assert line["vs_baseline"] is None and line["higher_is_better"] is True and "workload" in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+
+
+@pytest.mark.parametrize("mode,streams", [("flat", 3), ("flat", 1), ("fused", 2), ("pipelined", 2)])
+def test_config3_dry_run(mode, streams):
+    line = _bench(["--proofs", "300", "--steps", "3", "--warmup", "1", "--verify-mode", mode, "--streams",
+                   str(streams), "--cpu-seconds", "0.2"])
+    _check_contract(line, 3, 1)
+    assert line["metric"] == "mpt_proofs_verified_per_sec_depth8" and line["unit"] == "proofs/s"
+    assert line["scaling"] == "weak" and line["config"]["streams"] == streams
+    assert line["cpu_baseline"]["statuses_match_gpu_expected"] is True
+    assert ("single_stream" in line) == (streams > 1)
+    if mode != "fused":
+        assert 0 < line["roofline"]["nodes_hashed"] <= line["roofline"]["nodes_shipped"] == 300 * 8
+
+
+def test_config3_fewer_steps_than_slots():
+    line = _bench(["--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4", "--cpu-seconds", "0.2"])
+    _check_contract(line, 1, 0)
+
+
+def test_config4_dry_run():
+    line = _bench(["--workload", "config4", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--streams",
+                   "2", "--cpu-seconds", "0.2"])
+    _check_contract(line, 2, 1)
+    assert line["metric"] == "mpt_proofs_verified_per_sec_block_witness" and line["scaling"] == "strong"
+    assert line["cpu_baseline"]["statuses_match_gpu_expected"] is True
+    assert line["config"]["units_per_gpu_per_step"] == 1080
+
+
+def test_nodeset_and_config5_dry_run():
+    line = _bench(["--workload", "nodeset", "--proofs", "300", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
+    _check_contract(line, 2, 1)
+    line = _bench(["--workload", "config5", "--stream-proofs", "150", "--steps", "5", "--warmup", "1",
+                   "--cpu-seconds", "0.2"])
+    _check_contract(line, 5, 1)
+    assert "pcie" in line

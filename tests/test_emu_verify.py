@@ -32,7 +32,8 @@ from tests.test_gpu_verify import (  # noqa: E402,F401
     test_reference_vector_tries, test_random_tries, test_embedded_nodes_and_branch_values,
     test_mutation_fuzz_matches_oracle, test_garbage_committed_roots, test_bad_offsets_are_flagged,
     test_non_monotone_proof_first_node_matches_oracle, test_synthetic_depth8_small_vs_oracle,
-    test_synthetic_other_depths, test_block_witness_accounts_and_storage, test_keys_longer_than_the_lds_staging)
+    test_synthetic_other_depths, test_block_witness_accounts_and_storage, test_keys_longer_than_the_lds_staging,
+    test_synthetic_block_witness_vs_oracle)
 from tests.test_gpu_verify import test_streaming_submit_wait as _streaming_submit_wait  # noqa: E402
 
 

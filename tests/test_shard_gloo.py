@@ -150,3 +150,67 @@ def test_world2_gloo_matches_single_process(oracle, emulated):
         assert fc == want_fc.tolist(), (rank, fc, want_fc)   # same global verdict on every rank
         seen[np.asarray(mine, np.int64)] = np.asarray(status, np.uint8)
     assert np.array_equal(seen, full)                         # disjoint cover, identical statuses
+
+
+def _block_worker(rank, world, port, q):
+    """bench.py's config-4 step on every rank: build this rank's share of the block witness (the state root is
+    agreed on with one all-reduce inside the generator), verify it with the verdict fused in, all-reduce the
+    per-root failure counts.  Kernels on tests/emu.py, collectives on gloo."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import emu
+        backend = emu.emulated_backend(emu.load_mirror_lib())
+        next(backend)
+        import phant_amd
+        from phant_amd import mpt
+        w = phant_amd.witness.block_witness(scale=0.02, corrupt_frac=0.1, seed=6, rank=rank, world=world)
+        b = w.batch
+        fc = torch.zeros(b.n_roots, dtype=torch.int32)
+        st = mpt.verify_batch_dev(b, fail_count=fc)
+        ok = bool(torch.equal(st, w.expected))
+        local_fc = fc.clone()
+        dist.all_reduce(fc)
+        top = sorted(set((b.keys[:w_acc(w), 0] >> 4).tolist()))
+        q.put((rank, ok, w.n_invalid, local_fc.tolist(), fc.tolist(), b.roots.tolist(), top, b.n))
+        backend.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def w_acc(w):
+    return int((w.batch.root_idx == 0).sum())
+
+
+def test_world2_block_witness_generator_and_verdict(oracle):
+    import torch.multiprocessing as mp
+
+    from tests import emu
+    try:
+        emu.build()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_block_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, ok0, inv0, loc0, fc0, roots0, top0, n0), (_, ok1, inv1, loc1, fc1, roots1, top1, n1) = got
+    assert ok0 and ok1 and n0 == n1
+    assert fc0 == fc1 and sum(fc0) == inv0 + inv1 > 0           # one global verdict, on every rank
+    assert [a + b for a, b in zip(loc0, loc1)] == fc0
+    r0, r1 = np.array(roots0, np.uint8), np.array(roots1, np.uint8)
+    assert r0.shape == r1.shape and np.array_equal(r0[0], r1[0])  # the same state root
+    own0, own1 = r0[1:].any(axis=1), r1[1:].any(axis=1)
+    assert not (own0 & own1).any() and own0.sum() == own1.sum() > 0  # storage roots: disjoint owners
+    assert all(x % 2 == 0 for x in top0) and all(x % 2 == 1 for x in top1)  # accounts by top key nibble
