@@ -137,9 +137,15 @@ PHANT_API int32_t phant_keccak256_fixed_dev(phant_ctx *ctx, const uint8_t *d_blo
  *   root_idx         n entries (which root proof i is against) or NULL = all 0
  *   keys             n x key_len bytes (key_len = 32 for state/storage tries)
  *   nodes            all proof nodes back to back, nodes_len bytes
- *   node_off         total_nodes + 1 byte offsets into `nodes`
+ *   node_off         total_nodes + 1 byte offsets into `nodes`; in the host form
+ *                    total_nodes = proof_first_node[n] (its last entry)
  *   proof_first_node n + 1 entries: proof i = nodes
- *                    [proof_first_node[i], proof_first_node[i+1]), root first
+ *                    [proof_first_node[i], proof_first_node[i+1]), root first.
+ *                    A range that goes backwards or beyond total_nodes, a node
+ *                    offset pair that goes backwards or beyond nodes_len, or a
+ *                    root_idx >= n_roots gives that proof PHANT_PROOF_BAD_INPUT;
+ *                    nothing outside the buffers is read whatever these arrays
+ *                    (an untrusted witness) say
  *   status           n bytes out (PHANT_PROOF_*)
  *   value_off/len    n entries out, or NULL: for PRESENT, where in `nodes`
  *                    the value bytes sit

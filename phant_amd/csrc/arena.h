@@ -5,6 +5,17 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// Host-emulation test builds under AddressSanitizer only (tests/emu.py): the padding behind every sub-allocation
+// is poisoned, so that a kernel reading past one staged array into the next is caught.  Nothing in a hipcc build.
+#if defined(PHANT_HOST_EMU) && defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#define PHANT_ARENA_POISON(p, n) ASAN_POISON_MEMORY_REGION((p), (n))
+#define PHANT_ARENA_UNPOISON(p, n) ASAN_UNPOISON_MEMORY_REGION((p), (n))
+#else
+#define PHANT_ARENA_POISON(p, n) ((void)0)
+#define PHANT_ARENA_UNPOISON(p, n) ((void)0)
+#endif
+
 namespace phant {
 
 struct DevArena {
@@ -17,6 +28,7 @@ struct DevArena {
     // Contents are dropped; the caller guarantees no kernel still uses them.
     hipError_t reset(size_t total) {
         used = 0;
+        if (base) PHANT_ARENA_UNPOISON(base, cap);
         if (total <= cap) return hipSuccess;
         if (base) {
             hipError_t e = hipFree(base);  // implies a device synchronise
@@ -33,10 +45,13 @@ struct DevArena {
     template <class T>
     T* take(size_t count) {
         T* p = reinterpret_cast<T*>(base + used);
-        used += round(count * sizeof(T));
+        const size_t bytes = count * sizeof(T), dwords = (bytes + 3) / 4 * 4;  // (device loads are dword-granular)
+        PHANT_ARENA_POISON(base + used + dwords, round(bytes) - dwords);
+        used += round(bytes);
         return p;
     }
     void release() {
+        if (base) PHANT_ARENA_UNPOISON(base, cap);
         if (base) (void)hipFree(base);
         base = nullptr;
         cap = used = 0;

@@ -338,8 +338,10 @@ static int32_t ensure_side(phant_ctx* c) {
 
 // Runs the verify pipeline on device-resident arguments (shared by all forms) on stream `st` with the
 // workspace arena `dv`; `side` = helper stream of the overlap pipeline or nullptr (then it runs serially).
-static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes, hipStream_t st,
+static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, uint32_t total_nodes, hipStream_t st,
                                   phant::DevArena& dv, const phant::FlatSide* side, bool timed) {
+    phant::VerifyArgs a = a_in;
+    a.total_nodes = total_nodes;
     if (c->verify_fused) {
         if (timed) {
             TimedRegion t(c);
@@ -379,10 +381,10 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
                                  const uint32_t* root_idx, const uint8_t* keys, uint32_t key_len, const uint8_t* nodes,
                                  uint64_t nodes_len, const uint64_t* node_off, const uint32_t* proof_first_node,
                                  uint32_t n, uint8_t* status, uint64_t* value_off, uint32_t* value_len) {
-    // the number of node offsets the caller must have provided
-    uint32_t total_nodes = 0;
-    for (uint32_t i = 0; i <= n; ++i)
-        if (proof_first_node[i] > total_nodes) total_nodes = proof_first_node[i];
+    // The number of node offsets the caller provided is what the LAST entry of proof_first_node says
+    // (include/phant_gpu.h): node_off has proof_first_node[n] + 1 entries.  An earlier entry that points
+    // beyond it makes its proofs BAD_INPUT on the device; it never widens what is read from the caller.
+    const uint32_t total_nodes = proof_first_node[n];
     const size_t need = ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) +
                         ws_round((size_t)n * key_len + 4) + ws_round((size_t)nodes_len + 16) +
                         ws_round(((size_t)total_nodes + 1) * 8) + ws_round(((size_t)n + 1) * 4) +

@@ -27,6 +27,9 @@ struct VerifyArgs {
     uint32_t* value_len;  // may be null
     uint32_t* fail_count = nullptr;  // may be null: n_roots counters of proofs that are not PRESENT/ABSENT,
                                      // produced by the pipeline's last kernel (phant_mpt_verify_verdict_dev)
+    uint32_t total_nodes = 0;        // node_off has total_nodes + 1 entries: a proof whose node range reaches
+                                     // beyond it is BAD_INPUT before node_off is touched (set by the launchers'
+                                     // caller, capi.hip::verify_resident_on)
 };
 hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
 // re-verifies, one lane per proof, the proofs whose status byte is 0xff (the flat pipeline's

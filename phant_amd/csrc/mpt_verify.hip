@@ -23,7 +23,7 @@ PHANT_DEV uint32_t verify_one(const VerifyArgs& a, uint32_t i, uint64_t& voff, u
     voff = 0;
     vlen = 0;
     const uint32_t first = a.proof_first_node[i], last = a.proof_first_node[i + 1];
-    if (last < first) return PHANT_PROOF_BAD_INPUT;
+    if (last < first || last > a.total_nodes) return PHANT_PROOF_BAD_INPUT;  // (node_off ends at [total_nodes])
     if (last == first) return PHANT_PROOF_INVALID_EMPTY;
     const uint32_t r = a.root_idx ? a.root_idx[i] : 0u;
     if (r >= a.n_roots) return PHANT_PROOF_BAD_INPUT;

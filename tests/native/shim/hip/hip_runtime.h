@@ -7,7 +7,7 @@
 //   * device qualifiers are empty, `__shared__` is `static` (workgroups run one after another);
 //   * v_bitop3 / v_alignbit / v_alignbyte are bit-level restatements of the ISA definitions;
 //   * the runtime API (hipMalloc, hipMemcpyAsync, streams, events ...) is malloc / memcpy, synchronous;
-//   * hipLaunchKernelGGL runs the grid workgroup by workgroup.  Every work-item is a fiber (ucontext); the 64
+//   * hipLaunchKernelGGL runs the grid workgroup by workgroup.  Every work-item is a fiber (own stack, hand-rolled switch); the 64
 //     lanes of a wavefront advance in lockstep *at cross-lane operations*: a lane that reaches __ballot /
 //     __shfl / readlane / readfirstlane parks; when every lane of the wave is parked or finished, the parked
 //     lanes with the lowest call site form the active mask of that operation (the lowest-PC-first rule:
@@ -21,7 +21,6 @@
 // on another workgroup would hang), LDS capacity, register pressure.  It checks the logic and the address
 // arithmetic of the source; the -m gpu tests check the compiled kernels.
 #pragma once
-#include <ucontext.h>
 
 #include <chrono>
 #include <cstdint>
@@ -97,13 +96,43 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline void __threadfence() {}
 
 // ------------------------------------------------------------------------------------------------ the emulator
+// Fiber switch: save the callee-saved registers on the current stack, publish its stack pointer, adopt the other
+// one.  (ucontext's swapcontext does the same plus a sigprocmask system call per switch -- two thirds of the
+// emulator's run time.)  Weak, so that every translation unit including this header may carry it.
+#if !defined(__x86_64__)
+#error "tests/native/shim: the fiber switch is written for x86-64"
+#endif
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+__asm__(R"(
+    .text
+    .weak hipemu_switch
+    .type hipemu_switch, @function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+
 namespace hipemu {
 
 enum LaneState { READY, WAVE_WAIT, BLOCK_WAIT, DONE };
 enum WaveOp { OP_BALLOT, OP_READLANE, OP_READFIRST, OP_SHFL, OP_SHFL_UP };
 
 struct Lane {
-    ucontext_t ctx;
+    void* sp;        // saved stack pointer while switched out
     uint8_t* stack;
     uint32_t tid;
     LaneState state;
@@ -119,7 +148,7 @@ constexpr size_t STACK_BYTES = 512u << 10;
 struct Machine {
     std::vector<Lane> lanes;          // of the running workgroup
     std::vector<uint8_t*> stacks;     // pool, reused by every launch
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     void* sched_fake = nullptr;
     const void* sched_bottom = nullptr;
     size_t sched_size = 0;
@@ -142,7 +171,7 @@ inline void to_scheduler() {  // from a lane
 #if HIPEMU_ASAN
     __sanitizer_start_switch_fiber(l->state == DONE ? nullptr : &l->fake, M.sched_bottom, M.sched_size);
 #endif
-    swapcontext(&l->ctx, &M.sched);
+    hipemu_switch(&l->sp, M.sched_sp);
 #if HIPEMU_ASAN
     __sanitizer_finish_switch_fiber(l->fake, &M.sched_bottom, &M.sched_size);
 #endif
@@ -164,7 +193,7 @@ inline void run_lane(Lane& l) {  // from the scheduler
 #if HIPEMU_ASAN
     __sanitizer_start_switch_fiber(&M.sched_fake, l.stack, STACK_BYTES);
 #endif
-    swapcontext(&M.sched, &l.ctx);
+    hipemu_switch(&M.sched_sp, l.sp);
 #if HIPEMU_ASAN
     __sanitizer_finish_switch_fiber(M.sched_fake, nullptr, nullptr);
 #endif
@@ -279,11 +308,13 @@ inline void run_block(uint32_t n_threads) {
         l.tid = i;
         l.state = READY;
         l.fake = nullptr;
-        getcontext(&l.ctx);
-        l.ctx.uc_stack.ss_sp = l.stack;
-        l.ctx.uc_stack.ss_size = STACK_BYTES;
-        l.ctx.uc_link = nullptr;
-        makecontext(&l.ctx, (void (*)())lane_main, 0);
+        // a fresh fiber: six zeroed callee-saved registers, then lane_main as the address `ret` jumps to, then
+        // a null return address (lane_main never returns); at lane_main's entry rsp = 8 mod 16, as the ABI wants
+        void** top = reinterpret_cast<void**>(l.stack + STACK_BYTES);
+        top[-1] = nullptr;
+        top[-2] = reinterpret_cast<void*>(&lane_main);
+        for (int k = 3; k <= 8; ++k) top[-k] = nullptr;
+        l.sp = top - 8;
     }
     for (;;) {
         uint32_t done = 0, at_barrier = 0;

@@ -15,8 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SLICE = [
     ("tests/test_emu_keccak.py", None),
-    ("tests/test_emu_verify.py", "(flat or fused) and (embedded or bad_offsets or non_monotone or other_depths or "
-                                 "longer_than or garbage or reference_vector)"),
+    ("tests/test_emu_verify.py", "flat and (embedded or bad_offsets or non_monotone or other_depths or longer_than "
+                                 "or garbage or reference_vector or hostile)"),
+    ("tests/test_emu_verify.py", "fused and (embedded or bad_offsets or non_monotone or other_depths or longer_than "
+                                 "or garbage or reference_vector or hostile)"),
+    ("tests/test_emu_verify.py", "(pipelined or overlap or nodedup) and (hostile or other_depths-5 or embedded)"),
     ("tests/test_emu_nodeset.py", "damaged or garbage"),
     ("tests/test_emu_trie.py", "reference_vectors or variable_length or state_root_random or rejects"),
     ("tests/test_emu_witness.py", "clean_witness or damaged_account"),
@@ -34,11 +37,14 @@ def test_emulated_kernels_under_asan_and_ubsan():
             pytest.skip("sanitizer runtime not available: " + str(e)[-200:])
         raise
     env = dict(os.environ, LD_PRELOAD=preload, ASAN_OPTIONS="detect_leaks=0", PHANT_EMU_SANITIZE="1")
-    for module, expr in SLICE:
+    runs = []
+    for module, expr in SLICE:  # side by side: they share nothing but the (already built) library
         cmd = [sys.executable, "-m", "pytest", module, "-x", "-q", "-s", "-p", "no:cacheprovider"]
         if expr:
             cmd += ["-k", expr]
-        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-        tail = (r.stdout + r.stderr)[-4000:]
-        assert r.returncode == 0, f"{module}:\n{tail}"
-        assert " passed" in r.stdout and "failed" not in r.stdout, tail
+        runs.append((module, subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                              stderr=subprocess.STDOUT, text=True)))
+    for module, proc in runs:
+        out, _ = proc.communicate(timeout=1500)
+        assert proc.returncode == 0, f"{module}:\n{out[-4000:]}"
+        assert " passed" in out and " failed" not in out, out[-4000:]

@@ -51,3 +51,86 @@ def test_no_divergent_cross_lane_operation_was_seen():
     _LIB.hipemu_counters(out)
     assert out[0] > 0 and out[1] > 0
     assert out[2] == 0, tuple(out)
+
+
+def _hostile(rng, node_off, pfn, ridx, nodes_len, n_roots):
+    """a handful of damaged entries in the three index arrays of a batch"""
+    node_off, pfn, ridx = node_off.copy(), pfn.copy(), ridx.copy()
+    big = [0, 1, nodes_len - 1, nodes_len, nodes_len + 1, nodes_len + 600, 2 ** 31, 2 ** 32 - 1, 2 ** 32 + 5,
+           2 ** 63, 2 ** 64 - 1]
+    for _ in range(int(rng.integers(1, 6))):
+        kind = int(rng.integers(0, 6))
+        if kind == 0:      # a node offset anywhere, also far outside the blob
+            node_off[int(rng.integers(0, len(node_off)))] = big[int(rng.integers(0, len(big)))]
+        elif kind == 1:    # two neighbouring offsets swapped (a node of negative length)
+            i = int(rng.integers(0, len(node_off) - 1))
+            node_off[i], node_off[i + 1] = node_off[i + 1], node_off[i]
+        elif kind == 2:    # a node stretched over its successors
+            i = int(rng.integers(0, len(node_off) - 1))
+            node_off[i + 1] = min(int(node_off[i]) + int(rng.integers(0, 5000)), 2 ** 63)
+        elif kind == 3:    # a proof boundary anywhere, also past total_nodes (not the last entry: in the host
+            # form that one IS total_nodes, the length of node_off the caller vouches for)
+            pfn[int(rng.integers(0, len(pfn) - 1))] = int(rng.choice([0, 1, len(node_off) - 2, len(node_off) - 1,
+                                                                  len(node_off), len(node_off) + 7, 2 ** 31,
+                                                                  2 ** 32 - 1]))
+        elif kind == 4:    # proof boundaries swapped
+            i = int(rng.integers(0, len(pfn) - 2))
+            pfn[i], pfn[i + 1] = pfn[i + 1], pfn[i]
+        else:              # a root index out of range
+            ridx[int(rng.integers(0, len(ridx)))] = int(rng.choice([n_roots, n_roots + 1, 2 ** 31, 2 ** 32 - 1]))
+    return node_off, pfn, ridx
+
+
+def test_hostile_index_arrays_match_the_checked_oracle(M, oracle):
+    """node_off / proof_first_node / root_idx come from an untrusted witness: whatever they say, every proof gets
+    the status (and value location) the bounds-checked oracle gives it, and -- the point of running this under
+    ASan in tests/test_emu_sanitized.py -- no kernel reads outside the buffers it was handed."""
+    from tests.witness_util import block_witness, pack_proofs
+    rng = np.random.default_rng(1186)
+    roots, ridx, keys, proofs = block_witness(oracle, rng, n_accounts=200, n_contracts=5, max_slots=60,
+                                              n_account_proofs=60, n_storage_proofs=100)
+    nodes, node_off, pfn = pack_proofs(proofs)
+    r = np.frombuffer(b"".join(roots), np.uint8)
+    k = np.frombuffer(b"".join(keys), np.uint8)
+    ridx = ridx.astype(np.uint32)
+    seen = set()
+    for _ in range(40):
+        no, pf, ri = _hostile(rng, node_off, pfn, ridx, nodes.size, len(roots))
+        got = M.verify_batch(r, ri, k, 32, nodes, no, pf)
+        want = oracle.mpt_verify_batch_checked(r, ri, k, 32, nodes, no, pf)
+        assert np.array_equal(got[0], want[0]), (np.nonzero(got[0] != want[0])[0][:8], got[0][:12], want[0][:12])
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        seen |= set(got[0].tolist())
+    assert {M.PROOF_PRESENT, M.PROOF_BAD_INPUT, M.PROOF_BAD_HASH} <= seen
+
+
+def test_hostile_index_arrays_device_form(M, oracle):
+    """The same through phant_mpt_verify_verdict_dev, where total_nodes is an argument of its own: here the LAST
+    entry of proof_first_node may lie as well."""
+    import torch
+    from phant_amd.mpt import ProofBatch
+    from tests.witness_util import block_witness, pack_proofs
+    rng = np.random.default_rng(2930)
+    roots, ridx, keys, proofs = block_witness(oracle, rng, n_accounts=200, n_contracts=5, max_slots=60,
+                                              n_account_proofs=60, n_storage_proofs=100)
+    nodes, node_off, pfn = pack_proofs(proofs)
+    r = np.frombuffer(b"".join(roots), np.uint8).copy()
+    k = np.frombuffer(b"".join(keys), np.uint8).copy()
+    ridx = ridx.astype(np.uint32)
+    dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731  (a dword-rounded "device" copy under the emulator)
+    for it in range(25):
+        no, pf, ri = _hostile(rng, node_off, pfn, ridx, nodes.size, len(roots))
+        if it % 3 == 0:
+            pf[-1] = int(rng.choice([0, 5, len(node_off) + 3, 2 ** 31, 2 ** 32 - 1]))
+        b = ProofBatch(dev(r).reshape(-1, 32), dev(ri.view(np.int32)), dev(k).reshape(-1, 32), dev(nodes),
+                       dev(no.view(np.int64)), dev(pf.view(np.int32)))
+        fc = torch.full((len(roots),), 77, dtype=torch.int32).cuda()
+        vo = torch.zeros(b.n, dtype=torch.int64).cuda()
+        vl = torch.zeros(b.n, dtype=torch.int32).cuda()
+        st = M.verify_batch_dev(b, value_off=vo, value_len=vl, fail_count=fc).cpu().numpy()
+        want = oracle.mpt_verify_batch_checked(r, ri, k, 32, nodes, no, pf)
+        assert np.array_equal(st, want[0]), (it, np.nonzero(st != want[0])[0][:8])
+        assert np.array_equal(vo.numpy().view(np.uint64), want[1]) and np.array_equal(vl.numpy().view(np.uint32), want[2])
+        bad = ~np.isin(want[0], (M.PROOF_PRESENT, M.PROOF_ABSENT))
+        in_range = ri < len(roots)
+        assert np.array_equal(fc.numpy(), np.bincount(ri[bad & in_range], minlength=len(roots)))
