@@ -22,6 +22,7 @@ PROOF_BAD_RLP = 17
 PROOF_BAD_NODE = 18
 PROOF_EXTRA_NODES = 19
 PROOF_MISSING_NODE = 20
+PROOF_BAD_INPUT = 21
 
 E_UNSORTED = -5
 
@@ -86,6 +87,10 @@ def lib():
                                                    C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]
         _lib.oracle_mpt_verify_nodeset.restype = C.c_int
+        _lib.oracle_mpt_verify_nodeset_checked.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                           C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.oracle_mpt_verify_nodeset_checked.restype = C.c_int
         _lib.oracle_index_root_rlp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.oracle_index_root_rlp.restype = C.c_int
         _lib.oracle_index_root_be32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -268,6 +273,25 @@ def mpt_verify_nodeset(roots, root_idx, keys, key_len, nodes, node_off):
                                          _p(node_off), m, n, _p(status), _p(voff), _p(vlen))
     if rc:
         raise MemoryError("oracle_mpt_verify_nodeset")
+    return status, voff, vlen
+
+
+def mpt_verify_nodeset_checked(roots, root_idx, keys, key_len, nodes, node_off):
+    """mpt_verify_nodeset for arbitrary index arrays (malformed entries are not members; bad root_idx -> BAD_INPUT)."""
+    roots = np.ascontiguousarray(roots, np.uint8)
+    keys = np.ascontiguousarray(keys, np.uint8)
+    nodes = np.ascontiguousarray(nodes, np.uint8)
+    node_off = np.ascontiguousarray(node_off, np.uint64)
+    ri = None if root_idx is None else np.ascontiguousarray(root_idx, np.uint32)
+    n = keys.size // key_len if key_len else (0 if ri is None else len(ri))
+    status = np.zeros(n, np.uint8)
+    voff = np.zeros(n, np.uint64)
+    vlen = np.zeros(n, np.uint32)
+    rc = lib().oracle_mpt_verify_nodeset_checked(_p(roots), roots.size // 32, None if ri is None else _p(ri), _p(keys),
+                                                 key_len, _p(nodes), nodes.size, _p(node_off), len(node_off) - 1, n,
+                                                 _p(status), _p(voff), _p(vlen))
+    if rc:
+        raise MemoryError("oracle_mpt_verify_nodeset_checked")
     return status, voff, vlen
 
 

@@ -115,6 +115,12 @@ int oracle_mpt_verify_nodeset(const uint8_t *roots, const uint32_t *root_idx, co
                               uint32_t key_len, const uint8_t *nodes, const uint64_t *node_off,
                               uint32_t m, uint32_t n, uint8_t *status, uint64_t *value_off,
                               uint32_t *value_len);
+/* the same for an UNTRUSTED witness: malformed node_off entries are not members of the set, root_idx >= n_roots
+ * is BAD_INPUT (what phant_mpt_verify_nodeset does with arbitrary index arrays) */
+int oracle_mpt_verify_nodeset_checked(const uint8_t *roots, uint32_t n_roots, const uint32_t *root_idx,
+                                      const uint8_t *keys, uint32_t key_len, const uint8_t *nodes,
+                                      uint64_t nodes_len, const uint64_t *node_off, uint32_t m, uint32_t n,
+                                      uint8_t *status, uint64_t *value_off, uint32_t *value_len);
 uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key,
                           uint32_t key_len, const uint8_t *nodes,
                           const uint64_t *node_off, uint32_t n_nodes,

@@ -297,10 +297,12 @@ static int cmp_digest_idx(const void *a, const void *b) {
                   g_sort_digests + 32 * (size_t)*(const uint32_t *)b, 32);
 }
 
-int oracle_mpt_verify_nodeset(const uint8_t *roots, const uint32_t *root_idx, const uint8_t *keys,
-                              uint32_t key_len, const uint8_t *nodes, const uint64_t *node_off,
-                              uint32_t m, uint32_t n, uint8_t *status, uint64_t *value_off,
-                              uint32_t *value_len) {
+/* nodes_len == ~0 and n_roots == 0: offsets and root indices are trusted (oracle_mpt_verify_nodeset).  Otherwise
+ * the rules of DESIGN.md section 3 for an untrusted witness: an entry of node_off that goes backwards, ends
+ * beyond nodes_len or is longer than 2^31 - 1 bytes is not a member of the set; root_idx >= n_roots -> BAD_INPUT. */
+static int nodeset_verify(const uint8_t *roots, uint32_t n_roots, const uint32_t *root_idx, const uint8_t *keys,
+                          uint32_t key_len, const uint8_t *nodes, uint64_t nodes_len, const uint64_t *node_off,
+                          uint32_t m, uint32_t n, uint8_t *status, uint64_t *value_off, uint32_t *value_len) {
     uint8_t *dig = (uint8_t *)malloc(32 * (size_t)(m ? m : 1));
     uint32_t *order = (uint32_t *)malloc(4 * (size_t)(m ? m : 1));
     if (!dig || !order) {
@@ -308,15 +310,28 @@ int oracle_mpt_verify_nodeset(const uint8_t *roots, const uint32_t *root_idx, co
         free(order);
         return -1;
     }
+    uint32_t members = 0;
     for (uint32_t i = 0; i < m; ++i) {
-        oracle_keccak256(nodes + node_off[i], (size_t)(node_off[i + 1] - node_off[i]), dig + 32 * (size_t)i);
-        order[i] = i;
+        const uint64_t b = node_off[i], e = node_off[i + 1];
+        if (nodes_len != ~(uint64_t)0 && (e < b || e > nodes_len || e - b > 0x7fffffffull))
+            continue;
+        oracle_keccak256(nodes + b, (size_t)(e - b), dig + 32 * (size_t)i);
+        order[members++] = i;
     }
     g_sort_digests = dig;
-    qsort(order, m, sizeof(uint32_t), cmp_digest_idx);
-    nodeset set = {dig, order, m};
+    qsort(order, members, sizeof(uint32_t), cmp_digest_idx);
+    nodeset set = {dig, order, members};
     for (uint32_t i = 0; i < n; ++i) {
-        const uint8_t *root = roots + 32 * (size_t)(root_idx ? root_idx[i] : 0);
+        const uint32_t r = root_idx ? root_idx[i] : 0;
+        if (n_roots && r >= n_roots) {
+            status[i] = ORACLE_PROOF_BAD_INPUT;
+            if (value_off)
+                value_off[i] = 0;
+            if (value_len)
+                value_len[i] = 0;
+            continue;
+        }
+        const uint8_t *root = roots + 32 * (size_t)r;
         uint64_t vo = 0;
         uint32_t vl = 0;
         status[i] = verify_core(root, keys + (size_t)key_len * i, key_len, nodes, node_off, m, &set, ~(uint64_t)0, &vo, &vl);
@@ -328,6 +343,22 @@ int oracle_mpt_verify_nodeset(const uint8_t *roots, const uint32_t *root_idx, co
     free(dig);
     free(order);
     return 0;
+}
+
+int oracle_mpt_verify_nodeset(const uint8_t *roots, const uint32_t *root_idx, const uint8_t *keys,
+                              uint32_t key_len, const uint8_t *nodes, const uint64_t *node_off,
+                              uint32_t m, uint32_t n, uint8_t *status, uint64_t *value_off,
+                              uint32_t *value_len) {
+    return nodeset_verify(roots, 0, root_idx, keys, key_len, nodes, ~(uint64_t)0, node_off, m, n, status, value_off,
+                          value_len);
+}
+
+int oracle_mpt_verify_nodeset_checked(const uint8_t *roots, uint32_t n_roots, const uint32_t *root_idx,
+                                      const uint8_t *keys, uint32_t key_len, const uint8_t *nodes,
+                                      uint64_t nodes_len, const uint64_t *node_off, uint32_t m, uint32_t n,
+                                      uint8_t *status, uint64_t *value_off, uint32_t *value_len) {
+    return nodeset_verify(roots, n_roots, root_idx, keys, key_len, nodes, nodes_len, node_off, m, n, status,
+                          value_off, value_len);
 }
 
 void oracle_mpt_verify_batch(const uint8_t *roots, const uint32_t *root_idx, const uint8_t *keys,

@@ -27,3 +27,38 @@ def M():
 
 from tests.test_gpu_nodeset import (  # noqa: E402,F401
     test_random_tries, test_damaged_and_missing_nodes, test_garbage_committed_roots, test_block_witness_as_a_node_set)
+
+
+def test_hostile_index_arrays_match_the_checked_oracle(M, oracle):
+    """node_off / root_idx of a node-set witness are untrusted too: entries that go backwards, end beyond the blob
+    or are absurdly long are not members of the set, an out-of-range root index is BAD_INPUT; and under ASan
+    (tests/test_emu_sanitized.py) none of it makes a kernel read outside its buffers."""
+    from tests.witness_util import block_witness, node_set
+    rng = np.random.default_rng(77)
+    roots, ridx, keys, proofs = block_witness(oracle, rng, n_accounts=200, n_contracts=5, max_slots=60,
+                                              n_account_proofs=60, n_storage_proofs=100)
+    blob, off = node_set(proofs, rng)
+    r = np.frombuffer(b"".join(roots), np.uint8)
+    k = np.frombuffer(b"".join(keys), np.uint8)
+    ridx = ridx.astype(np.uint32)
+    big = [0, 1, blob.size - 1, blob.size, blob.size + 1, blob.size + 600, 2 ** 31, 2 ** 32 + 5, 2 ** 63, 2 ** 64 - 1]
+    seen = set()
+    for _ in range(30):
+        no, ri = off.copy(), ridx.copy()
+        for _ in range(int(rng.integers(1, 5))):
+            kind = int(rng.integers(0, 4))
+            i = int(rng.integers(0, len(no) - 1))
+            if kind == 0:
+                no[int(rng.integers(0, len(no)))] = big[int(rng.integers(0, len(big)))]
+            elif kind == 1:
+                no[i], no[i + 1] = no[i + 1], no[i]
+            elif kind == 2:
+                no[i + 1] = min(int(no[i]) + int(rng.integers(0, 5000)), 2 ** 63)
+            else:
+                ri[int(rng.integers(0, len(ri)))] = int(rng.choice([len(roots), 2 ** 31, 2 ** 32 - 1]))
+        got = M.verify_nodeset(r, ri, k, 32, blob, no)
+        want = oracle.mpt_verify_nodeset_checked(r, ri, k, 32, blob, no)
+        assert np.array_equal(got[0], want[0]), (np.nonzero(got[0] != want[0])[0][:8], got[0][:12], want[0][:12])
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        seen |= set(got[0].tolist())
+    assert {M.PROOF_PRESENT, M.PROOF_MISSING_NODE} <= seen

@@ -20,7 +20,7 @@ SLICE = [
     ("tests/test_emu_verify.py", "fused and (embedded or bad_offsets or non_monotone or other_depths or longer_than "
                                  "or garbage or reference_vector or hostile)"),
     ("tests/test_emu_verify.py", "(pipelined or overlap or nodedup) and (hostile or other_depths-5 or embedded)"),
-    ("tests/test_emu_nodeset.py", "damaged or garbage"),
+    ("tests/test_emu_nodeset.py", "damaged or garbage or hostile"),
     ("tests/test_emu_trie.py", "reference_vectors or variable_length or state_root_random or rejects"),
     ("tests/test_emu_witness.py", "clean_witness or damaged_account"),
 ]

@@ -242,3 +242,34 @@ def test_checked_batch_form(oracle):
     st, _, _ = oracle.mpt_verify_batch_checked(np.zeros(32, np.uint8), None, np.zeros(64, np.uint8), 32, np.zeros(100, np.uint8),
                                                np.array([0, 50, 40, 1000], np.uint64), np.array([0, 1, 3], np.uint32))
     assert st.tolist() == [16, 21]
+
+
+def test_checked_nodeset_form(oracle):
+    """oracle_mpt_verify_nodeset_checked: identical to the trusted form on a well-formed set; a malformed entry
+    is simply not a member (its dependants become MISSING_NODE), an out-of-range root index is BAD_INPUT."""
+    from tests.witness_util import node_set
+    o = oracle
+    rng = np.random.default_rng(31)
+    keys, vals = random_kv(rng, 200, 32, 1, 70)
+    t = o.Trie(keys, vals)
+    q = keys[:80]
+    blob, off = node_set([t.prove(k) for k in q], rng)
+    r = np.frombuffer(t.root() + bytes(32), np.uint8)
+    k = np.frombuffer(b"".join(q), np.uint8)
+    ridx = np.zeros(len(q), np.uint32)
+    a = o.mpt_verify_nodeset(r, ridx, k, 32, blob, off)
+    b = o.mpt_verify_nodeset_checked(r, ridx, k, 32, blob, off)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and (a[0] == o.PROOF_PRESENT).all()
+    # knock out the root node's entry: nothing resolves any more
+    root_at = [i for i in range(len(off) - 1) if o.keccak256(blob[int(off[i]):int(off[i + 1])].tobytes()) == t.root()][0]
+    bad = off.copy()
+    bad[root_at + 1] = 2 ** 40 if root_at + 1 == len(off) - 1 else bad[root_at + 1]
+    if root_at + 1 < len(off) - 1:
+        bad[root_at], bad[root_at + 1] = bad[root_at + 1], bad[root_at]  # negative length (and a stretched neighbour)
+    st, vo, vl = o.mpt_verify_nodeset_checked(r, ridx, k, 32, blob, bad)
+    assert (st == o.PROOF_MISSING_NODE).all() and not vo.any() and not vl.any()
+    ridx2 = ridx.copy()
+    ridx2[3] = 2
+    ridx2[5] = 1  # a root nothing hashes to
+    st, _, _ = o.mpt_verify_nodeset_checked(r, ridx2, k, 32, blob, off)
+    assert st[3] == o.PROOF_BAD_INPUT and st[5] == o.PROOF_MISSING_NODE and (np.delete(st, [3, 5]) == o.PROOF_PRESENT).all()
