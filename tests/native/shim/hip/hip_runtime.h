@@ -295,6 +295,31 @@ inline bool resolve_wave(uint32_t w0, uint32_t w1) {
     return true;
 }
 
+// HIPEMU_SCHEDULE=<seed>: workgroups, the waves of a workgroup and the lanes of a wave run in a pseudo-random
+// order (new for every launch) instead of ascending -- nothing in the programming model promises an order, so
+// results must not depend on it (whose table proposal or atomic lands first, which workgroup a counter sees).
+// 0 / unset: ascending.
+inline void shuffled(uint32_t n, std::vector<uint32_t>& out) {
+    static const unsigned long long seed = [] {
+        const char* e = std::getenv("HIPEMU_SCHEDULE");
+        return e ? std::strtoull(e, nullptr, 10) : 0ull;
+    }();
+    static unsigned long long state = seed * 0x9E3779B97F4A7C15ull + 1;
+    out.resize(n);
+    for (uint32_t i = 0; i < n; ++i) out[i] = i;
+    if (!seed) return;
+    for (uint32_t i = n; i > 1; --i) {  // Fisher-Yates on a splitmix64 stream
+        unsigned long long z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const uint32_t j = (uint32_t)(z % i);
+        const uint32_t t = out[i - 1];
+        out[i - 1] = out[j];
+        out[j] = t;
+    }
+}
+
 inline void run_block(uint32_t n_threads) {
     while (M.stacks.size() < n_threads) {
         void* p = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -316,13 +341,20 @@ inline void run_block(uint32_t n_threads) {
         for (int k = 3; k <= 8; ++k) top[-k] = nullptr;
         l.sp = top - 8;
     }
+    const uint32_t n_waves = (n_threads + 63) / 64;
+    std::vector<uint32_t> wave_order, lane_order;
+    shuffled(n_waves, wave_order);
+    shuffled(64, lane_order);
     for (;;) {
         uint32_t done = 0, at_barrier = 0;
-        for (uint32_t w0 = 0; w0 < n_threads; w0 += 64) {
+        for (uint32_t wi = 0; wi < n_waves; ++wi) {
+            const uint32_t w0 = wave_order[wi] * 64;
             const uint32_t w1 = w0 + 64 < n_threads ? w0 + 64 : n_threads;
             for (;;) {
-                for (uint32_t i = w0; i < w1; ++i)
-                    while (M.lanes[i].state == READY) run_lane(M.lanes[i]);  // until it parks or finishes
+                for (uint32_t li = 0; li < 64; ++li) {
+                    const uint32_t i = w0 + lane_order[li];
+                    while (i < w1 && M.lanes[i].state == READY) run_lane(M.lanes[i]);  // until it parks or finishes
+                }
                 if (!resolve_wave(w0, w1)) break;
             }
             for (uint32_t i = w0; i < w1; ++i) {
@@ -347,8 +379,10 @@ inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t, vo
     M.body = [=]() { kernel(args...); };
     blockDim_ = block;
     gridDim_ = grid;
+    std::vector<uint32_t> block_order;
+    shuffled(grid.x, block_order);
     for (uint32_t b = 0; b < grid.x; ++b) {
-        blockIdx_ = dim3(b);
+        blockIdx_ = dim3(block_order[b]);
         run_block(block.x);
     }
     M.body = nullptr;

@@ -1,0 +1,36 @@
+"""The emulated parity suite once more with the emulator's execution order shuffled (HIPEMU_SCHEDULE=<seed>:
+workgroups, the waves of a workgroup and the lanes of a wave each run in a pseudo-random order, new for every
+launch).  Nothing in the programming model promises an order, so the results -- which table proposal wins in the
+node dedup, which node-set insertion lands first, where an atomic cursor hands out space -- must not depend on it.
+Child processes: the seed is read once per process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests import emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_results_do_not_depend_on_the_execution_order():
+    try:
+        emu.build()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    runs = []
+    for seed, modules, expr in (
+            (3, ["tests/test_emu_verify.py"], "(flat or overlap) and not streaming"),
+            (11, ["tests/test_emu_verify.py"], "(pipelined or nodedup or fused) and not streaming and not depth8"),
+            (5, ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_witness.py"], None)):
+        cmd = [sys.executable, "-m", "pytest", *modules, "-x", "-q", "-p", "no:cacheprovider"]
+        if expr:
+            cmd += ["-k", expr]
+        env = dict(os.environ, HIPEMU_SCHEDULE=str(seed))
+        runs.append((seed, subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                            text=True)))
+    for seed, proc in runs:
+        out, _ = proc.communicate(timeout=1500)
+        assert proc.returncode == 0, f"HIPEMU_SCHEDULE={seed}:\n{out[-4000:]}"
+        assert " passed" in out and " failed" not in out, out[-4000:]
