@@ -123,3 +123,59 @@ def test_nodeset_and_config5_dry_run():
                    "--cpu-seconds", "0.2"])
     _check_contract(line, 5, 1)
     assert "pcie" in line
+
+
+def _rank_main(rank, world, port, argv, q):
+    """One rank of `torchrun ... bench.py --gpus N`: the environment torchrun would set, RCCL swapped for gloo."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    backend = emu.emulated_backend(emu.load_mirror_lib())
+    next(backend)
+    real_init = dist.init_process_group
+
+    def init(backend_name, device_id=None, **kw):
+        assert backend_name == "nccl"  # what bench.py asks for on the GPU box
+        return real_init("gloo", **kw)
+
+    dist.init_process_group = init
+    try:
+        q.put((rank, _bench(argv)))
+    except AssertionError as e:  # ranks other than 0 print nothing
+        q.put((rank, str(e)))
+    finally:
+        backend.close()
+
+
+@pytest.mark.parametrize("argv", [
+    ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "3"],
+    ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4"],
+    ["--gpus", "2", "--workload", "config4", "--block-scale", "0.02", "--steps", "2", "--warmup", "1", "--streams", "2"],
+    ["--gpus", "2", "--workload", "nodeset", "--proofs", "200", "--steps", "2", "--warmup", "1"],
+], ids=["config3", "config3-fewer-steps-than-slots", "config4", "nodeset"])
+def test_two_ranks_dry_run(argv):
+    """The N > 1 path the driver launches with torchrun (never run on real GPUs this round): both ranks build their
+    shard, agree on the state root, verify, all-reduce the verdict; rank 0 prints the one line."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, argv, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    line = got[0]
+    assert isinstance(line, dict), line
+    assert isinstance(got[1], str)  # rank 1 printed no JSON line (that is what its assertion message says)
+    assert line["n_gpus"] == 2 and "cpu_baseline" not in line and line["roofline"]["frac"] > 0
+    assert line["config"]["parallelism"] == "key-sharded x2"
+    if "config4" in argv:
+        assert line["scaling"] == "strong"
