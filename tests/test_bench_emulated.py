@@ -179,3 +179,18 @@ def test_two_ranks_dry_run(argv):
     assert line["config"]["parallelism"] == "key-sharded x2"
     if "config4" in argv:
         assert line["scaling"] == "strong"
+
+
+def test_smoke_dry_run(capsys):
+    """__graft_entry__.smoke() -- what the driver runs on the GPU box before the bench -- on the emulator."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as G
+    saved = (torch.cuda.is_available, torch.cuda.current_device)
+    torch.cuda.is_available, torch.cuda.current_device = (lambda: True), (lambda: 0)
+    try:
+        with _no_cuda():
+            G.smoke()
+    finally:
+        torch.cuda.is_available, torch.cuda.current_device = saved
+    assert "smoke OK" in capsys.readouterr().out
