@@ -18,6 +18,8 @@ for mode in nodedup overlap pipelined fused; do
 done
 echo "== bench nodeset =="
 timeout 300 python bench.py --workload nodeset --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_nodeset.json"
+echo "== bench config4 (one 10k-tx block witness, multi-root) =="
+timeout 300 python bench.py --workload config4 --cpu-seconds 5 2>&1 | tail -1 | tee "$OUT/bench_config4.json"
 echo "== bench config5 (streamed) =="
 timeout 300 python bench.py --workload config5 --steps 64 --warmup 4 --stream-slots 2 --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_config5.json"
 echo "== stress (20 seeds) =="
