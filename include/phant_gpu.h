@@ -127,6 +127,35 @@ PHANT_API int32_t phant_keccak256_fixed_dev(phant_ctx *ctx, const uint8_t *d_blo
                                             uint32_t msg_len, uint64_t stride, uint32_t n,
                                             uint8_t *d_out);
 
+/* ------------------------------------------------- other bulk Keccak users
+ * the per-item keccak256 calls next to the trie path, batched.
+ *
+ * Logs bloom -- replaces src/types/receipt.zig:37-48 `calculateLogsBloom(logs) LogsBloom` (and its
+ * `addToBloom`, :50-63) for all receipts of a block at once.  The bloom items of the block are flattened:
+ * item k = items[item_off[k] .. item_off[k+1]) is a log's 20-byte address or one of its 32-byte topics
+ * (any length is accepted) and belongs to receipt item_receipt[k]; blooms = n_receipts x 256 bytes out, each
+ * the OR over its items of the three bits addToBloom sets (bit index 0x7ff - (big-endian u16 at hash[2i] &
+ * 0x7ff), i = 0..2, counted from the most significant bit of byte 0).  An item whose receipt index is
+ * >= n_receipts is ignored.  Device form: d_blooms 4-byte aligned; zeroed by the call. */
+PHANT_API int32_t phant_logs_bloom(phant_ctx *ctx, const uint8_t *items, const uint64_t *item_off,
+                                   const uint32_t *item_receipt, uint32_t n_items, uint32_t n_receipts,
+                                   uint8_t *blooms);
+PHANT_API int32_t phant_logs_bloom_dev(phant_ctx *ctx, const uint8_t *d_items, const uint64_t *d_item_off,
+                                       const uint32_t *d_item_receipt, uint32_t n_items,
+                                       uint32_t n_receipts, uint8_t *d_blooms);
+/* Sender addresses -- the hashing half of src/signer/signer.zig:77-78 `keccak256(pubkey[1..])[12..]` for a
+ * block's recovered public keys: key i = 64 bytes at pubkeys + i * stride (stride >= 64; pass pk + 1 and
+ * stride 65 for 0x04-tagged keys), out20 = n x 20 bytes.  (The recovery itself stays libsecp256k1's,
+ * src/crypto/ecdsa.zig.)  Device form: d_out20 4-byte aligned.
+ *
+ * Transaction hashes (src/types/transaction.zig:183-187,223-228,256-261 = keccak256 of the EIP-2718 bytes) and
+ * code hashes (src/blockchain/vm.zig:284-298; keccak256("") is its `empty_hash`) are phant_keccak256_batch
+ * over the respective byte strings. */
+PHANT_API int32_t phant_sender_addresses(phant_ctx *ctx, const uint8_t *pubkeys, uint64_t stride,
+                                         uint32_t n, uint8_t *out20);
+PHANT_API int32_t phant_sender_addresses_dev(phant_ctx *ctx, const uint8_t *d_pubkeys, uint64_t stride,
+                                             uint32_t n, uint8_t *d_out20);
+
 /* ------------------------------------------------------- proof verification
  * ABSENT in the reference: this is the call the TODO at
  * src/engine_api/execution_payload.zig:177-178 asks for (witness field

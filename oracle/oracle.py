@@ -29,7 +29,7 @@ E_UNSORTED = -5
 
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("keccak.c", "mpt.c", "verify.c", "state.c", "phant_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("keccak.c", "mpt.c", "verify.c", "state.c", "bulk.c", "phant_oracle.h")]
     if not force and os.path.exists(_LIB_PATH):
         if all(os.path.getmtime(s) <= os.path.getmtime(_LIB_PATH) for s in srcs):
             return _LIB_PATH
@@ -91,6 +91,10 @@ def lib():
                                                            C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                                            C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.oracle_mpt_verify_nodeset_checked.restype = C.c_int
+        _lib.oracle_logs_bloom.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        _lib.oracle_logs_bloom.restype = None
+        _lib.oracle_sender_addresses.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+        _lib.oracle_sender_addresses.restype = None
         _lib.oracle_index_root_rlp.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.oracle_index_root_rlp.restype = C.c_int
         _lib.oracle_index_root_be32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -341,3 +345,24 @@ def state_root(accounts) -> bytes:
     if rc:
         raise ValueError(f"oracle_state_root rc={rc}")
     return out.tobytes()
+
+
+def logs_bloom(receipts) -> np.ndarray:
+    """receipts: list (one entry per receipt) of lists of items (a log's 20-byte address, then its 32-byte topics;
+    src/types/receipt.zig:37-48) -> (n_receipts, 256) uint8."""
+    flat = [it for r in receipts for it in r]
+    owner = np.array([i for i, r in enumerate(receipts) for _ in r], np.uint32)
+    blob, off = pack(flat, np.uint64)
+    out = np.zeros((len(receipts), 256), np.uint8)
+    lib().oracle_logs_bloom(_p(blob), _p(off), _p(owner if owner.size else np.zeros(1, np.uint32)), len(flat),
+                            len(receipts), _p(out if out.size else np.zeros(1, np.uint8)))
+    return out
+
+
+def sender_addresses(pubkeys: np.ndarray) -> np.ndarray:
+    """(n, 64) uint8 public keys (no 0x04 tag) -> (n, 20) addresses (src/signer/signer.zig:77-78)."""
+    pk = np.ascontiguousarray(pubkeys, np.uint8).reshape(-1, 64)
+    out = np.zeros((pk.shape[0], 20), np.uint8)
+    if pk.shape[0]:
+        lib().oracle_sender_addresses(_p(pk), 64, pk.shape[0], _p(out))
+    return out

@@ -160,6 +160,14 @@ int oracle_state_root(const uint8_t *addrs, const uint64_t *nonces,
                       const uint8_t *slot_vals, const uint32_t *slot_first,
                       uint32_t n, uint8_t out[32]);
 
+/* ---- the other bulk users of keccak256 (oracle/bulk.c) ---- */
+/* src/types/receipt.zig:37-63: blooms[r] = OR over the items of receipt r of the three bits addToBloom sets */
+void oracle_logs_bloom(const uint8_t *items, const uint64_t *item_off, const uint32_t *item_receipt, uint32_t n_items,
+                       uint32_t n_receipts, uint8_t *blooms);
+/* src/signer/signer.zig:77-78: keccak256(64-byte public key)[12..] */
+void oracle_sender_addresses(const uint8_t *pubkeys, uint64_t stride, uint32_t n, uint8_t *out20);
+
+
 #ifdef __cplusplus
 }
 #endif

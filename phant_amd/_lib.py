@@ -50,6 +50,10 @@ SYMBOLS = {
     "phant_keccak256_batch": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "phant_keccak256_batch_dev": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "phant_keccak256_fixed_dev": (_i32, [_vp, _vp, _u32, _u64, _u32, _vp]),
+    "phant_logs_bloom": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "phant_logs_bloom_dev": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "phant_sender_addresses": (_i32, [_vp, _vp, _u64, _u32, _vp]),
+    "phant_sender_addresses_dev": (_i32, [_vp, _vp, _u64, _u32, _vp]),
     "phant_mpt_verify_batch": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp]),
     "phant_mpt_verify_batch_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp,
                                           _vp, _vp]),

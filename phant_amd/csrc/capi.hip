@@ -323,6 +323,83 @@ int32_t phant_keccak256_with_prefix(phant_ctx* c, const uint8_t* prefix, uint64_
     return rc;
 }
 
+/* ------------------------------------------------- other bulk Keccak users */
+
+int32_t phant_logs_bloom_dev(phant_ctx* c, const uint8_t* d_items, const uint64_t* d_item_off,
+                             const uint32_t* d_item_receipt, uint32_t n_items, uint32_t n_receipts, uint8_t* d_blooms) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n_receipts == 0) return PHANT_OK;
+    if (!d_blooms || ((uintptr_t)d_blooms & 3u) || (n_items && (!d_item_off || !d_item_receipt)))
+        return fail(c, PHANT_E_INVALID_ARG, "logs_bloom_dev: null or unaligned pointer");
+    DeviceGuard g(c->device);
+    TimedRegion t(c);
+    HIP_TRY(c, phant::launch_logs_bloom(d_items, d_item_off, d_item_receipt, n_items, n_receipts, d_blooms, c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_logs_bloom(phant_ctx* c, const uint8_t* items, const uint64_t* item_off, const uint32_t* item_receipt,
+                         uint32_t n_items, uint32_t n_receipts, uint8_t* blooms) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n_receipts == 0) return PHANT_OK;
+    if (!blooms || (n_items && (!item_off || !item_receipt))) return fail(c, PHANT_E_INVALID_ARG, "logs_bloom: null pointer");
+    for (uint32_t i = 0; i < n_items; ++i)
+        if (item_off[i + 1] < item_off[i]) return fail(c, PHANT_E_INVALID_ARG, "logs_bloom: offsets not monotone");
+    const uint64_t lo = n_items ? item_off[0] : 0, hi = n_items ? item_off[n_items] : 0;
+    const size_t blob_len = (size_t)(hi - lo);
+    if (blob_len && !items) return fail(c, PHANT_E_INVALID_ARG, "logs_bloom: null items");
+    DeviceGuard g(c->device);
+    int32_t rc = ws_reset(c, ws_round(blob_len + 16) + ws_round(((size_t)n_items + 1) * 8) + ws_round((size_t)n_items * 4 + 4) +
+                                 ws_round((size_t)n_receipts * 256));
+    if (rc) return rc;
+    uint8_t* d_items = ws_take<uint8_t>(c, blob_len + 16);
+    uint64_t* d_off = ws_take<uint64_t>(c, (size_t)n_items + 1);
+    uint32_t* d_rcpt = ws_take<uint32_t>(c, (size_t)n_items + 1);
+    uint8_t* d_blooms = ws_take<uint8_t>(c, (size_t)n_receipts * 256);
+    std::vector<uint64_t> rel((size_t)n_items + 1, 0);
+    for (uint32_t i = 0; i <= n_items && n_items; ++i) rel[i] = item_off[i] - lo;
+    if (blob_len) HIP_TRY(c, hipMemcpyAsync(d_items, items + lo, blob_len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, c->stream));
+    if (n_items) HIP_TRY(c, hipMemcpyAsync(d_rcpt, item_receipt, (size_t)n_items * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, phant::launch_logs_bloom(d_items, d_off, d_rcpt, n_items, n_receipts, d_blooms, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(blooms, d_blooms, (size_t)n_receipts * 256, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_sender_addresses_dev(phant_ctx* c, const uint8_t* d_pubkeys, uint64_t stride, uint32_t n, uint8_t* d_out20) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!d_pubkeys || !d_out20 || ((uintptr_t)d_out20 & 3u) || stride < 64)
+        return fail(c, PHANT_E_INVALID_ARG, "sender_addresses_dev: bad argument");
+    DeviceGuard g(c->device);
+    TimedRegion t(c);
+    HIP_TRY(c, phant::launch_sender_addresses(d_pubkeys, stride, n, d_out20, c->stream));
+    return PHANT_OK;
+}
+
+int32_t phant_sender_addresses(phant_ctx* c, const uint8_t* pubkeys, uint64_t stride, uint32_t n, uint8_t* out20) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n == 0) return PHANT_OK;
+    if (!pubkeys || !out20 || stride < 64) return fail(c, PHANT_E_INVALID_ARG, "sender_addresses: bad argument");
+    DeviceGuard g(c->device);
+    int32_t rc = ws_reset(c, ws_round((size_t)n * 64 + 16) + ws_round((size_t)n * 20));
+    if (rc) return rc;
+    uint8_t* d_pk = ws_take<uint8_t>(c, (size_t)n * 64 + 16);
+    uint8_t* d_out = ws_take<uint8_t>(c, (size_t)n * 20);
+    if (stride == 64) {
+        HIP_TRY(c, hipMemcpyAsync(d_pk, pubkeys, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+    } else {  // pack: only the 64 key bytes travel
+        std::vector<uint8_t> packed((size_t)n * 64);
+        for (uint32_t i = 0; i < n; ++i) std::memcpy(packed.data() + 64 * (size_t)i, pubkeys + stride * i, 64);
+        HIP_TRY(c, hipMemcpyAsync(d_pk, packed.data(), packed.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // `packed` dies with this scope
+    }
+    HIP_TRY(c, phant::launch_sender_addresses(d_pk, 64, n, d_out, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out20, d_out, (size_t)n * 20, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PHANT_OK;
+}
+
 /* ------------------------------------------------------- proof verification */
 
 // helper stream + events of the overlap / pipelined modes (created on first use)

@@ -11,6 +11,13 @@ hipError_t launch_keccak256_var(const uint8_t* d_blob, const uint64_t* d_off, ui
 hipError_t launch_keccak256_fixed(const uint8_t* d_blob, uint32_t msg_len, uint64_t stride,
                                   uint32_t n, uint8_t* d_out, hipStream_t st);
 
+// bulk_keccak.hip: blooms n_receipts x 256 bytes (4-byte aligned, zeroed by the launcher); addresses n x 20 bytes
+// (4-byte aligned)
+hipError_t launch_logs_bloom(const uint8_t* d_items, const uint64_t* d_item_off, const uint32_t* d_item_receipt,
+                             uint32_t n_items, uint32_t n_receipts, uint8_t* d_blooms, hipStream_t st);
+hipError_t launch_sender_addresses(const uint8_t* d_pubkeys, uint64_t stride, uint32_t n, uint8_t* d_out,
+                                   hipStream_t st);
+
 struct VerifyArgs {
     const uint8_t* roots;
     uint32_t n_roots;

@@ -51,3 +51,16 @@ def state_root(accounts, ctx: Context | None = None) -> bytes:
                                         _np_ptr(code_off), _np_ptr(skb), _np_ptr(svb), _np_ptr(fi), n,
                                         _np_ptr(out)))
     return out.tobytes()
+
+
+def code_hashes(codes, ctx: Context | None = None) -> np.ndarray:
+    """keccak256 of every contract code in one launch <-> src/blockchain/vm.zig:284-298 `get_code_hash`
+    (an account without code gets keccak256("") = vm.zig:22 `empty_hash`, which is what hashing the empty string
+    gives).  -> (n, 32) uint8."""
+    from .crypto import hasher
+    cs = [bytes(c) for c in codes]
+    off = np.zeros(len(cs) + 1, np.uint64)
+    if cs:
+        off[1:] = np.cumsum([len(c) for c in cs])
+    blob = np.frombuffer(b"".join(cs), np.uint8).copy() if off[-1] else np.zeros(1, np.uint8)
+    return hasher.keccak256_batch(blob, off, ctx=ctx)

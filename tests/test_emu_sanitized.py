@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SLICE = [
     ("tests/test_emu_keccak.py", None),
+    ("tests/test_emu_bulk.py", None),
     ("tests/test_emu_verify.py", "flat and (embedded or bad_offsets or non_monotone or other_depths or longer_than "
                                  "or garbage or reference_vector or hostile)"),
     ("tests/test_emu_verify.py", "fused and (embedded or bad_offsets or non_monotone or other_depths or longer_than "

@@ -1,0 +1,55 @@
+"""oracle/bulk.c (logs bloom, sender addresses) against an independent numpy/python restatement of the cited
+reference lines and against the little the reference pins: the all-zero blooms of its fixtures, the transaction
+hashes of its tests (Tx.hash = keccak256 of the EIP-2718 encoding) and keccak256("") as the code hash of an
+account without code."""
+import numpy as np
+
+from tests import golden
+
+
+def _bloom_py(o, items):
+    bloom = bytearray(256)
+    for it in items:
+        h = o.keccak256(it)
+        for i in range(3):
+            w = int.from_bytes(h[2 * i:2 * i + 2], "big") & 0x7FF
+            bit_index = 0x7FF - w
+            bloom[bit_index // 8] |= 1 << (7 - bit_index % 8)
+    return bytes(bloom)
+
+
+def test_logs_bloom_matches_the_restated_lines(oracle):
+    rng = np.random.default_rng(8)
+    receipts = []
+    for r in range(40):
+        items = []
+        for _ in range(int(rng.integers(0, 6))):                      # logs
+            items.append(rng.integers(0, 256, 20, dtype=np.uint8).tobytes())           # address
+            for _ in range(int(rng.integers(0, 5))):                  # topics
+                items.append(rng.integers(0, 256, 32, dtype=np.uint8).tobytes())
+        receipts.append(items)
+    got = oracle.logs_bloom(receipts)
+    for r, items in enumerate(receipts):
+        assert got[r].tobytes() == _bloom_py(oracle, items), r
+    # no logs -> the all-zero bloom every fixture block of the reference carries
+    assert not oracle.logs_bloom([[], []]).any()
+    # a bloom has at most 3 bits per item, and each item's three bits are set
+    one = oracle.logs_bloom([[b"\x11" * 20]])[0]
+    assert 1 <= int(np.unpackbits(one).sum()) <= 3
+
+
+def test_sender_addresses_are_the_tail_of_the_key_hash(oracle):
+    rng = np.random.default_rng(9)
+    pk = rng.integers(0, 256, (50, 64), dtype=np.uint8)
+    got = oracle.sender_addresses(pk)
+    for i in range(50):
+        assert got[i].tobytes() == oracle.keccak256(pk[i].tobytes())[12:]
+
+
+def test_transaction_and_code_hashes_are_plain_keccak(oracle):
+    txs = [v for v in golden.keccak_vectors() if "transaction.zig" in v["source"]]
+    assert len(txs) == 2
+    for v in txs:
+        assert oracle.keccak256(bytes.fromhex(v["msg"])).hex() == v["digest"]
+    empty = [v for v in golden.keccak_vectors() if v["source"].startswith("src/blockchain/vm.zig")][0]
+    assert oracle.keccak256(b"").hex() == empty["digest"]  # get_code_hash of an account without code (vm.zig:292)
