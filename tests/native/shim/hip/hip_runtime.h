@@ -493,7 +493,13 @@ static inline hipError_t hipMalloc(T** p, size_t bytes) {
     void* q = nullptr;
     const size_t sz = bytes ? (bytes + 3) & ~(size_t)3 : 4;
     if (posix_memalign(&q, 256, sz) != 0) return hipErrorOutOfMemory;
-    std::memset(q, 0xA5, sz);  // uninitialised device memory is not zero
+    // uninitialised device memory is not zero, and not any particular value either: HIPEMU_FILL=<byte> picks
+    // what a fresh allocation holds (default 0xA5), so that a result depending on it shows up as a difference
+    static const int fill = [] {
+        const char* e = std::getenv("HIPEMU_FILL");
+        return e ? (int)(std::strtoul(e, nullptr, 0) & 0xff) : 0xA5;
+    }();
+    std::memset(q, fill, sz);
     *p = (T*)q;
     return hipSuccess;
 }

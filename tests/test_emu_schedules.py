@@ -1,6 +1,7 @@
 """The emulated parity suite once more with the emulator's execution order shuffled (HIPEMU_SCHEDULE=<seed>:
 workgroups, the waves of a workgroup and the lanes of a wave each run in a pseudo-random order, new for every
-launch).  Nothing in the programming model promises an order, so the results -- which table proposal wins in the
+launch) and with fresh "device" memory holding other bytes than usual (HIPEMU_FILL).  Nothing in the programming
+model promises an order or the contents of an allocation, so the results -- which table proposal wins in the
 node dedup, which node-set insertion lands first, where an atomic cursor hands out space -- must not depend on it.
 Child processes: the seed is read once per process."""
 import os
@@ -20,14 +21,16 @@ def test_results_do_not_depend_on_the_execution_order():
     except RuntimeError as e:
         pytest.skip(str(e))
     runs = []
-    for seed, modules, expr in (
-            (3, ["tests/test_emu_verify.py"], "(flat or overlap) and not streaming"),
-            (11, ["tests/test_emu_verify.py"], "(pipelined or nodedup or fused) and not streaming and not depth8"),
-            (5, ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_witness.py"], None)):
+    # (seed, what fresh "device" memory holds, ...): a result must not depend on uninitialised workspace either
+    for seed, fill, modules, expr in (
+            (3, "0x00", ["tests/test_emu_verify.py"], "(flat or overlap) and not streaming"),
+            (11, "0xff", ["tests/test_emu_verify.py"], "(pipelined or nodedup or fused) and not streaming and not depth8"),
+            (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_witness.py",
+                         "tests/test_emu_bulk.py"], None)):
         cmd = [sys.executable, "-m", "pytest", *modules, "-x", "-q", "-p", "no:cacheprovider"]
         if expr:
             cmd += ["-k", expr]
-        env = dict(os.environ, HIPEMU_SCHEDULE=str(seed))
+        env = dict(os.environ, HIPEMU_SCHEDULE=str(seed), HIPEMU_FILL=fill)
         runs.append((seed, subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                             text=True)))
     for seed, proc in runs:
