@@ -169,6 +169,18 @@ def load_mirror_lib(sanitize=None):
     return lib
 
 
+_mirror_lib = None
+
+
+def mirror_lib():
+    """The emulated library, built and loaded on first use (never at import or collection time: on the GPU box
+    these tests are deselected and nothing of this must get into the process)."""
+    global _mirror_lib
+    if _mirror_lib is None:
+        _mirror_lib = load_mirror_lib()
+    return _mirror_lib
+
+
 def mirror_context(lib, mode="flat"):
     """A phant_amd.Context whose phant_ctx lives in the emulated library (no torch.cuda involved)."""
     from phant_amd import _lib as L
@@ -186,10 +198,16 @@ def mirror_context(lib, mode="flat"):
     return EmuContext()
 
 
-def emulated_backend(lib):
+def emulated_backend(lib=None):
     """Generator for a module-scoped autouse fixture: while it is suspended, phant_amd's loader hands out the
     emulated library and its default context lives there; everything is put back afterwards."""
     from phant_amd import _lib as L, context as Cx
+    if lib is None:
+        try:
+            lib = mirror_lib()
+        except RuntimeError as e:  # no g++
+            import pytest
+            pytest.skip(str(e))
     saved_lib, saved_ctx = L._lib, dict(Cx._default)
     L._lib = lib
     Cx._default.clear()

@@ -15,15 +15,9 @@ from tests import emu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-try:
-    _LIB = emu.load_mirror_lib()
-except RuntimeError as e:  # no g++
-    pytest.skip(str(e), allow_module_level=True)
-
-
 @pytest.fixture(scope="module", autouse=True)
 def _emulated_backend():
-    yield from emu.emulated_backend(_LIB)
+    yield from emu.emulated_backend()
 
 
 @contextlib.contextmanager
@@ -42,7 +36,7 @@ def _no_cuda():
                 verify_pipelined=False):
         mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else "overlap" if verify_overlap else
                 "pipelined" if verify_pipelined else "flat")
-        return emu.mirror_context(_LIB, mode)
+        return emu.mirror_context(emu.mirror_lib(), mode)
 
     class _Device:  # torch.device("cuda", i) -> the CPU; isinstance checks inside torch still see a real device
         def __new__(cls, *a, **k):

@@ -8,15 +8,9 @@ import pytest
 
 from tests import emu
 
-try:
-    _LIB = emu.load_mirror_lib()
-except RuntimeError as e:  # no g++
-    pytest.skip(str(e), allow_module_level=True)
-
-
 @pytest.fixture(scope="module", autouse=True)
 def _emulated_backend():
-    yield from emu.emulated_backend(_LIB)
+    yield from emu.emulated_backend()
 
 
 @pytest.fixture(scope="module")

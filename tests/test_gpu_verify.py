@@ -357,45 +357,3 @@ def test_fused_verdict_equals_the_separate_call(M, oracle):
     want = oracle.mpt_verify_batch(np.frombuffer(b"".join(roots), np.uint8), ridx, np.frombuffer(b"".join(keys), np.uint8), 32,
                                    nodes, node_off, pfn)
     assert np.array_equal(st.cpu().numpy(), want[0])
-
-
-def test_synthetic_block_witness_vs_oracle(M, oracle):
-    """BASELINE config 4's generator (phant_amd.witness.block_witness) in miniature: account proofs against the
-    state root and storage proofs of three depth classes against per-contract roots in one multi-root batch;
-    statuses as constructed and as the oracle says, per-root verdict in the same launch."""
-    import phant_amd
-    w = phant_amd.witness.block_witness(scale=0.02, corrupt_frac=0.1, seed=6)
-    b = w.batch
-    assert b.n_roots == 1 + 30 + 9 + 1 and b.n == 400 + 240 + 360 + 600
-    fc = torch.full((b.n_roots,), -3, dtype=torch.int32, device=b.nodes.device)
-    st = M.verify_batch_dev(b, fail_count=fc)
-    assert torch.equal(st, w.expected)
-    want = oracle.mpt_verify_batch(b.roots.cpu().numpy().reshape(-1), b.root_idx.cpu().numpy().astype(np.uint32),
-                                   b.keys.cpu().numpy().reshape(-1), 32, b.nodes.cpu().numpy(),
-                                   b.node_off.cpu().numpy().astype(np.uint64),
-                                   b.proof_first_node.cpu().numpy().astype(np.uint32))
-    assert np.array_equal(st.cpu().numpy(), want[0])
-    bad = ~np.isin(want[0], (M.PROOF_PRESENT, M.PROOF_ABSENT))
-    assert np.array_equal(fc.cpu().numpy(), np.bincount(b.root_idx.cpu().numpy()[bad], minlength=b.n_roots))
-    assert int(fc.sum()) == w.n_invalid > 0 and {M.PROOF_PRESENT, M.PROOF_ABSENT, M.PROOF_BAD_HASH} <= set(want[0].tolist())
-
-
-def test_keys_longer_than_the_lds_staging(M, oracle):
-    """Keys of 40 / 64 / 80 bytes: the walk kernel stages keys of up to 32 bytes in LDS and reads longer ones
-    from global memory, a branch of its own (every other test here has keys of <= 32 bytes)."""
-    from tests.witness_util import adversarial_proofs, pack_proofs
-    rng = np.random.default_rng(4064)
-    cases = adversarial_proofs(oracle, rng, shapes=[(150, 40, 0), (150, 64, 8), (40, 80, 0), (60, 33, 0)], garbage=0)
-    for key_len in (33, 40, 64, 80):
-        sel = [c for c in cases if len(c[1]) == key_len]
-        assert len(sel) > 50
-        roots = sorted({c[0] for c in sel})
-        ridx = np.array([roots.index(c[0]) for c in sel], np.uint32)
-        nodes, node_off, pfn = pack_proofs([c[2] for c in sel])
-        r = np.frombuffer(b"".join(roots), np.uint8)
-        keys = np.frombuffer(b"".join(c[1] for c in sel), np.uint8)
-        got = M.verify_batch(r, ridx, keys, key_len, nodes, node_off, pfn)
-        want = oracle.mpt_verify_batch(r, ridx, keys, key_len, nodes, node_off, pfn)
-        assert np.array_equal(got[0], want[0]), (key_len, got[0][:20], want[0][:20])
-        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
-        assert {M.PROOF_PRESENT, M.PROOF_ABSENT} <= set(got[0].tolist())
