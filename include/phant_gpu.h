@@ -342,6 +342,18 @@ PHANT_API int32_t phant_state_root(phant_ctx *ctx, const uint8_t *addrs, const u
                                    const uint8_t *slot_vals, const uint32_t *slot_first,
                                    uint32_t n, uint8_t out[32]);
 
+/* The LEAVES of that state trie instead of its root -- what a rank of a multi-GPU state root (SURVEY.md
+ * section 8e) computes for the accounts it owns before the top-nibble exchange of mptize_sharded: keys = n x 32,
+ * keccak256(address) in ascending order; value i = vals[val_off[i] .. val_off[i+1]) =
+ * rlp([nonce, balance, storageRoot, codeHash]) of the account with that key, its storage root computed here
+ * (same forest pass as phant_state_root).  vals_cap: bytes available at `vals`; an account's RLP is at most
+ * 110 bytes.  phant_amd/shard.py::state_root_sharded is the tested composition. */
+PHANT_API int32_t phant_state_trie_leaves(phant_ctx *ctx, const uint8_t *addrs, const uint64_t *nonces,
+                                          const uint8_t *balances, const uint8_t *code,
+                                          const uint64_t *code_off, const uint8_t *slot_keys,
+                                          const uint8_t *slot_vals, const uint32_t *slot_first, uint32_t n,
+                                          uint8_t *keys, uint8_t *vals, uint64_t vals_cap, uint64_t *val_off);
+
 /* -------------------------------------------------------------- measurement
  * Device time of the last *_dev call -- every kernel it launched, first to
  * last -- measured with HIP events recorded on the ctx stream around the

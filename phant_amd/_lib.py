@@ -77,6 +77,7 @@ SYMBOLS = {
     "phant_index_root_rlp": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "phant_index_root_be32": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "phant_state_root": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "phant_state_trie_leaves": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),
     "phant_timing": (_i32, [_vp, _i32]),
     "phant_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "phant_verify_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 8)]),

@@ -912,4 +912,27 @@ int32_t phant_state_root(phant_ctx* c, const uint8_t* addrs, const uint64_t* non
     return PHANT_OK;
 }
 
+int32_t phant_state_trie_leaves(phant_ctx* c, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
+                                const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys,
+                                const uint8_t* slot_vals, const uint32_t* slot_first, uint32_t n, uint8_t* keys,
+                                uint8_t* vals, uint64_t vals_cap, uint64_t* val_off) {
+    if (!c || !val_off) return PHANT_E_INVALID_ARG;
+    if (n && (!addrs || !nonces || !balances || !code_off || !slot_first || !keys || !vals))
+        return fail(c, PHANT_E_INVALID_ARG, "state_trie_leaves: null pointer");
+    DeviceGuard g(c->device);
+    std::string err;
+    std::vector<uint8_t> k, v;
+    std::vector<uint64_t> vo;
+    int32_t rc = phant::state_leaves_host(c->ws, c->stream, addrs, nonces, balances, code, code_off, slot_keys, slot_vals,
+                                          slot_first, n, k, v, vo, err);
+    if (rc) return fail(c, rc, err.c_str());
+    if (v.size() > vals_cap) return fail(c, PHANT_E_INVALID_ARG, "state_trie_leaves: vals_cap too small (112 bytes per account suffice)");
+    if (n) {
+        std::memcpy(keys, k.data(), k.size());
+        std::memcpy(vals, v.data(), v.size());
+    }
+    std::memcpy(val_off, vo.data(), vo.size() * 8);
+    return PHANT_OK;
+}
+
 }  // extern "C"

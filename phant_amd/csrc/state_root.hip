@@ -98,11 +98,17 @@ size_t strip32(const uint8_t* v, const uint8_t** out) {
 
 }  // namespace
 
-int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
-                        const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
-                        const uint8_t* slot_keys, const uint8_t* slot_vals,
-                        const uint32_t* slot_first, uint32_t n, uint8_t out[32], std::string& err) {
-    if (n == 0) return trie_root_host(ws, st, nullptr, nullptr, nullptr, nullptr, 0, out, err);
+// The leaves of the state trie: keys = keccak256(address), ascending; values = rlp([nonce, balance, storageRoot,
+// codeHash]) with the storage roots computed here (one forest pass over all accounts' live slots).
+int32_t state_leaves_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
+                          const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
+                          const uint8_t* slot_keys, const uint8_t* slot_vals, const uint32_t* slot_first, uint32_t n,
+                          std::vector<uint8_t>& akeys, std::vector<uint8_t>& avals, std::vector<uint64_t>& avoff,
+                          std::string& err) {
+    akeys.clear();
+    avals.clear();
+    avoff.assign((size_t)n + 1, 0);
+    if (n == 0) return PHANT_OK;
     for (uint32_t a = 0; a < n; ++a)
         if (slot_first[a + 1] < slot_first[a]) {
             err = "slot_first not monotone";
@@ -158,9 +164,8 @@ int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, co
     std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
         return std::memcmp(&ha[(size_t)x * 32], &ha[(size_t)y * 32], 32) < 0;
     });
-    std::vector<uint8_t> akeys((size_t)n * 32), avals, payload;
-    std::vector<uint32_t> akoff(n + 1, 0);
-    std::vector<uint64_t> avoff(n + 1, 0);
+    std::vector<uint8_t> payload;
+    akeys.resize((size_t)n * 32);
     avals.reserve((size_t)n * 112);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t a = ord[i];
@@ -185,9 +190,23 @@ int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, co
             avals.push_back((uint8_t)payload.size());
         }
         avals.insert(avals.end(), payload.begin(), payload.end());
-        akoff[i + 1] = 32 * (i + 1);
         avoff[i + 1] = avals.size();
     }
+    return PHANT_OK;
+}
+
+int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
+                        const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
+                        const uint8_t* slot_keys, const uint8_t* slot_vals,
+                        const uint32_t* slot_first, uint32_t n, uint8_t out[32], std::string& err) {
+    if (n == 0) return trie_root_host(ws, st, nullptr, nullptr, nullptr, nullptr, 0, out, err);
+    std::vector<uint8_t> akeys, avals;
+    std::vector<uint64_t> avoff;
+    const int32_t rc = state_leaves_host(ws, st, addrs, nonces, balances, code, code_off, slot_keys, slot_vals,
+                                         slot_first, n, akeys, avals, avoff, err);
+    if (rc) return rc;
+    std::vector<uint32_t> akoff((size_t)n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) akoff[i + 1] = 32 * (i + 1);
     return trie_root_host(ws, st, akeys.data(), akoff.data(), avals.data(), avoff.data(), n, out, err);
 }
 

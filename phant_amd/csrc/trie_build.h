@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "arena.h"
 
@@ -36,5 +37,13 @@ int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, co
                         const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
                         const uint8_t* slot_keys, const uint8_t* slot_vals,
                         const uint32_t* slot_first, uint32_t n, uint8_t out[32], std::string& err);
+
+// the sorted leaves of that trie (keys n x 32 = keccak256(address) ascending, values = account RLP, val_off
+// n + 1), storage roots included: what a rank of a sharded state root feeds to the top-nibble exchange
+int32_t state_leaves_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
+                          const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
+                          const uint8_t* slot_keys, const uint8_t* slot_vals, const uint32_t* slot_first, uint32_t n,
+                          std::vector<uint8_t>& keys, std::vector<uint8_t>& vals, std::vector<uint64_t>& val_off,
+                          std::string& err);
 
 }  // namespace phant

@@ -253,3 +253,40 @@ def mptize_sharded(keys: list[bytes], vals: list[bytes], rank: int, world: int, 
     if len(nz) == 1:
         return t[nz[0], 34:].astype(np.uint8).tobytes()  # no top branch: that sub-trie's root is the root
     return root_from_child_refs(all_refs, all_lens, keccak)
+
+
+# ------------------------------------------------------------------------------------------------------
+# State root across GPUs: the state trie is keyed by keccak256(address), so it shards like any trie -- by the
+# top nibble of the HASHED address.  A rank hashes the addresses (20 bytes each: cheap, and every rank needs the
+# owner of every account anyway), keeps the accounts it owns, turns them into state-trie leaves on its GPU
+# (phant_state_trie_leaves: storage roots in one forest pass, account RLP) and enters mptize_sharded with them.
+def gpu_state_leaves(accounts):
+    from . import state
+    return state.state_trie_leaves(accounts)
+
+
+def gpu_keccak_many(items: list[bytes]) -> list[bytes]:
+    from .crypto import hasher
+    off = np.zeros(len(items) + 1, np.uint64)
+    if items:
+        off[1:] = np.cumsum([len(x) for x in items])
+    blob = np.frombuffer(b"".join(items), np.uint8).copy() if off[-1] else np.zeros(1, np.uint8)
+    return [d.tobytes() for d in hasher.keccak256_batch(blob, off)]
+
+
+def rank_state_leaves(accounts, rank: int, world: int, state_leaves=gpu_state_leaves, keccak_many=gpu_keccak_many):
+    """The state-trie leaves (sorted keys, values) of the accounts rank `rank` owns."""
+    accounts = list(accounts)
+    addr = [bytes(a["addr"] if isinstance(a, dict) else a.addr) for a in accounts]
+    hashed = keccak_many(addr) if accounts else []
+    mine = [a for a, h in zip(accounts, hashed) if (h[0] >> 4) % world == rank]
+    return state_leaves(mine) if mine else ([], [])
+
+
+def state_root_sharded(accounts, rank: int, world: int, group=None, device=None, state_leaves=gpu_state_leaves,
+                       keccak_many=gpu_keccak_many, root_nodes=gpu_root_nodes, keccak=gpu_keccak) -> bytes:
+    """`StateDB.root()` (the surface src/blockchain/blockchain.zig:83-85 lacks) of `accounts` (dicts / AccountState,
+    src/state/types.zig:13-20) with the work sharded over `world` ranks.  Every rank passes the same account list
+    (or at least the accounts it owns) and gets the same root."""
+    keys, vals = rank_state_leaves(accounts, rank, world, state_leaves, keccak_many)
+    return mptize_sharded(keys, vals, rank, world, group=group, device=device, root_nodes=root_nodes, keccak=keccak)

@@ -21,9 +21,8 @@ class AccountState:
     storage: dict = field(default_factory=dict)  # u256 slot -> u256 value
 
 
-def state_root(accounts, ctx: Context | None = None) -> bytes:
-    """accounts: iterable of AccountState (or dicts with the same keys)."""
-    ctx = ctx or default_context()
+def _soa(accounts):
+    """AccountState list -> the struct-of-arrays the C-ABI takes."""
     acc = [a if isinstance(a, AccountState) else AccountState(**a) for a in accounts]
     n = len(acc)
     addrs = np.zeros((max(n, 1), 20), np.uint8)
@@ -46,11 +45,30 @@ def state_root(accounts, ctx: Context | None = None) -> bytes:
     skb = np.frombuffer(b"".join(sk), np.uint8).copy() if sk else np.zeros(32, np.uint8)
     svb = np.frombuffer(b"".join(sv), np.uint8).copy() if sv else np.zeros(32, np.uint8)
     fi = np.array(first, np.uint32)
+    return n, (addrs, nonces, bal, code, code_off, skb, svb, fi)
+
+
+def state_root(accounts, ctx: Context | None = None) -> bytes:
+    """accounts: iterable of AccountState (or dicts with the same keys)."""
+    ctx = ctx or default_context()
+    n, arrays = _soa(accounts)
     out = np.zeros(32, np.uint8)
-    ctx.check(ctx._lib.phant_state_root(ctx.handle, _np_ptr(addrs), _np_ptr(nonces), _np_ptr(bal), _np_ptr(code),
-                                        _np_ptr(code_off), _np_ptr(skb), _np_ptr(svb), _np_ptr(fi), n,
-                                        _np_ptr(out)))
+    ctx.check(ctx._lib.phant_state_root(ctx.handle, *[_np_ptr(a) for a in arrays], n, _np_ptr(out)))
     return out.tobytes()
+
+
+def state_trie_leaves(accounts, ctx: Context | None = None):
+    """The leaves of the state trie of `accounts` (phant_state_trie_leaves): -> (keys, vals), two lists of
+    bytes, keys = keccak256(address) ascending, vals = rlp([nonce, balance, storageRoot, codeHash])."""
+    ctx = ctx or default_context()
+    n, arrays = _soa(accounts)
+    keys = np.zeros((max(n, 1), 32), np.uint8)
+    vals = np.zeros(max(n, 1) * 112, np.uint8)
+    off = np.zeros(n + 1, np.uint64)
+    ctx.check(ctx._lib.phant_state_trie_leaves(ctx.handle, *[_np_ptr(a) for a in arrays], n, _np_ptr(keys),
+                                               _np_ptr(vals), vals.size, _np_ptr(off)))
+    return ([keys[i].tobytes() for i in range(n)],
+            [vals[int(off[i]):int(off[i + 1])].tobytes() for i in range(n)])
 
 
 def code_hashes(codes, ctx: Context | None = None) -> np.ndarray:

@@ -219,3 +219,53 @@ def test_host_rlp_helpers_survive_damaged_nodes_under_sanitizers(oracle, tmp_pat
     r = subprocess.run([str(exe), str(p), "60000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-300:], r.stderr[-3000:])
     assert "stripped" in r.stdout
+
+
+def _state_worker(rank, world, port, q):
+    """shard.state_root_sharded with its product defaults on every rank (kernels on tests/emu.py, gloo for the one
+    all-reduce), over fixture states whose roots the reference pins."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from phant_amd import shard
+    from tests import emu, golden
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        backend = emu.emulated_backend(emu.load_mirror_lib())
+        next(backend)
+        fx = golden.fixtures()
+        cases = sorted(fx["cases"], key=lambda c: -len(c["pre"]))
+        out = []
+        for c in cases[:3] + cases[-2:]:
+            out.append((c["genesis_state_root"],
+                        shard.state_root_sharded(golden.accounts_of(c["pre"], fx["codes"]), rank, world).hex()))
+        out.append((shard.EMPTY_MPT_ROOT.hex(), shard.state_root_sharded([], rank, world).hex()))
+        q.put((rank, out))
+        backend.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_state_root_on_fixture_states():
+    import torch.multiprocessing as mp
+
+    from tests import emu
+    try:
+        emu.build()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_state_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, pairs in got:
+        assert len(pairs) == 6 and all(want == have for want, have in pairs), (rank, pairs)
