@@ -107,3 +107,21 @@ def test_unsorted_keys_and_slot_reuse(L, ctx, oracle):
     sub[1] = 99
     assert L.phant_mpt_verify_submit(*sub) == E_INVALID_ARG                # no such slot
     assert L.phant_wait(ctx.handle, 99) == E_INVALID_ARG
+
+
+def test_plain_c_caller(L, tmp_path):
+    """include/phant_gpu.h from plain C99 (what Zig's @cImport sees): compiles with -pedantic, links against the
+    library by symbol name, gets the reference's known answers."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    lib_dir = os.path.dirname(emu.build())
+    exe = str(tmp_path / "c_binding")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(emu.ROOT, "include"),
+                        os.path.join(emu.ROOT, "tests", "native", "c_binding.c"), "-L", lib_dir, "-lphant_emu",
+                        "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c binding OK" in r.stdout, r.stdout + r.stderr
