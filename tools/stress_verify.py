@@ -2,7 +2,11 @@
 """Differential stress of the verifier: many seeds of random tries + structural damage, every verify mode,
 per-proof and node-set forms, GPU (C-ABI) against the oracle.  Not part of the default test run.
 
-    python tools/stress_verify.py [--seeds 30] [--first-seed 1000]
+    python tools/stress_verify.py [--seeds 30] [--first-seed 1000] [--emulated]
+
+--emulated: no GPU -- the kernel sources on the host emulation of tests/emu.py (test infrastructure), e.g. as a
+long background campaign while the GPU budget is spent; with PHANT_EMU_SANITIZE=1 and libasan / libubsan
+preloaded (tests/test_emu_sanitized.py shows how) it runs the ASan + UBSan build.
 """
 import argparse
 import os
@@ -48,6 +52,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=30)
     ap.add_argument("--first-seed", type=int, default=1000)
+    ap.add_argument("--emulated", action="store_true")
+    ap.add_argument("--long-keys", action="store_true", help="also draw 33 / 40 / 64-byte keys (the walk kernel's "
+                                                                "non-LDS key path)")
     args = ap.parse_args()
     import phant_amd
     from oracle import oracle as O
@@ -55,11 +62,17 @@ def main():
 
     modes = {"flat": {}, "pipelined": {"verify_pipelined": True}, "overlap": {"verify_overlap": True},
              "nodedup": {"verify_nodedup": True}, "fused": {"verify_fused": True}}
-    ctxs = {m: phant_amd.Context(**kw) for m, kw in modes.items()}
+    if args.emulated:
+        from tests import emu
+        backend = emu.emulated_backend()
+        next(backend)
+        ctxs = {m: emu.mirror_context(emu.mirror_lib(), m) for m in modes}
+    else:
+        ctxs = {m: phant_amd.Context(**kw) for m, kw in modes.items()}
     bad = 0
     for seed in range(args.first_seed, args.first_seed + args.seeds):
         rng = np.random.default_rng(seed)
-        key_len = int(rng.choice([1, 2, 3, 20, 32, 32, 32]))
+        key_len = int(rng.choice([1, 2, 3, 20, 32, 32, 32] + ([33, 40, 64] if args.long_keys else [])))
         n = int(rng.integers(1, 1500 if key_len >= 3 else min(200, 256 ** key_len // 2)))
         shared = int(rng.choice([0, 0, 2, 6])) if key_len >= 20 else 0
         keys, vals = random_kv(rng, n, key_len, 1, int(rng.choice([3, 40, 120, 700])), shared)
