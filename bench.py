@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="config3: independent batches in flight, each on its own ctx + HIP stream (a validator "
                          "verifying consecutive witnesses); 1 = strictly one launch sequence after the other")
+    ap.add_argument("--graph", action="store_true",
+                    help="config3 / config4: replay each slot's kernel sequence as one hipGraph launch (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -252,14 +254,18 @@ def main():
         # and verdict buffers.  Every step is a full pass over the full batch; what overlaps is one step's
         # latency-bound plan / link / walk kernels with another step's VALU-bound hash kernel.
         S = max(1, min(args.streams, 8))
-        slots = [(torch.cuda.current_stream(dev), ctx, status, fails)]
-        for _ in range(S - 1):
+        # --graph (A/B, off by default): every slot's kernel sequence is replayed as one hipGraph launch
+        # (PHANT_CTX_VERIFY_GRAPH); the legacy default stream cannot be captured, so then slot 0 gets a stream
+        # and a ctx of its own as well (`ctx`, on torch's stream, built the witness and does the timing below)
+        slots = [] if args.graph else [(torch.cuda.current_stream(dev), ctx, status, fails)]
+        torch.cuda.synchronize()
+        while len(slots) < S:
             st_ = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st_):
                 c_ = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"),
                                        verify_nodedup=(args.verify_mode == "nodedup"),
                                        verify_overlap=(args.verify_mode == "overlap"),
-                                       verify_pipelined=(args.verify_mode == "pipelined"))
+                                       verify_pipelined=(args.verify_mode == "pipelined"), verify_graph=args.graph)
             slots.append((st_, c_, torch.empty_like(status), torch.zeros_like(fails)))
         turn = {"k": 0}
 
@@ -399,10 +405,12 @@ def main():
         if S > 1:  # the same K steps strictly one after the other, for the record
             barrier()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                M.verify_batch_dev(b, status=status, ctx=ctx, fail_count=fails)
-                if world > 1:
-                    dist.all_reduce(fails)
+            st0, c0, status0, fails0 = slots[0]
+            with torch.cuda.stream(st0):
+                for _ in range(args.steps):
+                    M.verify_batch_dev(b, status=status0, ctx=c0, fail_count=fails0)
+                    if world > 1:
+                        dist.all_reduce(fails0)
             barrier()
             e1 = time.perf_counter() - t1
             if world > 1:
@@ -453,7 +461,8 @@ def main():
         "scaling": "strong" if args.workload == "config4" else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}",
                    "verify_mode": args.verify_mode if proofs_like else None,
-                   "streams": (S if proofs_like else 1)},
+                   "streams": (S if proofs_like else 1),
+                   "graph": ([c_.graph_stats() for _, c_, _, _ in slots] if proofs_like and args.graph else False)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "throughput_GBps": value / world * alg_bytes / n_units / 1e9,  # algorithmic bytes x the measured

@@ -84,6 +84,12 @@ typedef struct phant_ctx phant_ctx;
                                        when the batch carries byte-identical copies (A/B) */
 #define PHANT_CTX_VERIFY_PIPELINED 16u /* flags: node-parallel pipeline over two half batches, the second a
                                           phase behind the first on a ctx-owned helper stream */
+#define PHANT_CTX_VERIFY_GRAPH 32u /* flags: device-form verify calls replay their kernel sequence as ONE
+                                    * hipGraph launch while the arguments (buffers, sizes) stay the same as
+                                    * in the previous call; captured again when they change.  Serial
+                                    * node-parallel modes on a real stream only (the legacy default stream
+                                    * cannot be captured): otherwise, or if capturing fails, calls launch
+                                    * directly as without the flag.  Env PHANT_VERIFY_GRAPH=0/1 overrides. */
 #define PHANT_CTX_VERIFY_OVERLAP 8u /* flags: node-parallel pipeline with the byte comparison running on a
                                        ctx-owned helper stream next to the hashing instead of before it */
 
@@ -365,6 +371,8 @@ PHANT_API int32_t phant_timing(phant_ctx *ctx, int32_t enable);
  * distinct nodes; synchronises the ctx stream.  All zero after a fused call. */
 PHANT_API int32_t phant_verify_stats(phant_ctx *ctx, uint32_t hashed[8]);
 PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
+/* out[0] = graphs captured, out[1] = graph launches served so far on this ctx (PHANT_CTX_VERIFY_GRAPH) */
+PHANT_API int32_t phant_graph_stats(phant_ctx *ctx, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,8 @@ class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
     def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
-                 verify_nodedup: bool = False, verify_overlap: bool = False, verify_pipelined: bool = False):
+                 verify_nodedup: bool = False, verify_overlap: bool = False, verify_pipelined: bool = False,
+                 verify_graph: bool = False):
         lib = L.lib()
         if not torch.cuda.is_available():
             raise L.PhantError(L.E_NO_DEVICE, "no GPU visible (phant_amd has no CPU fallback)")
@@ -36,6 +37,8 @@ class Context:
             flags |= 8  # PHANT_CTX_VERIFY_OVERLAP
         if verify_pipelined:
             flags |= 16  # PHANT_CTX_VERIFY_PIPELINED
+        if verify_graph:
+            flags |= 32  # PHANT_CTX_VERIFY_GRAPH
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
         h = C.c_void_p()
         rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))
@@ -65,6 +68,12 @@ class Context:
         out = (C.c_uint32 * 8)()
         self.check(self._lib.phant_verify_stats(self._h, C.byref(out)))
         return list(out)
+
+    def graph_stats(self) -> tuple[int, int]:
+        """(graphs captured, graph launches served) under verify_graph."""
+        out = (C.c_uint64 * 2)()
+        self.check(self._lib.phant_graph_stats(self._h, C.byref(out)))
+        return int(out[0]), int(out[1])
 
     def close(self):
         if getattr(self, "_h", None):

@@ -23,6 +23,7 @@
 #pragma once
 
 #include <chrono>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -154,8 +155,9 @@ struct Machine {
     size_t sched_size = 0;
     Lane* cur = nullptr;
     std::function<void()> body;
-    unsigned long long launches = 0, wave_ops = 0, divergent_ops = 0;
+    unsigned long long launches = 0, wave_ops = 0, divergent_ops = 0, graph_launches = 0;
     const char* kernel = "";
+    std::vector<std::function<void()>>* capture = nullptr;  // stream capture in progress: work is recorded, not run
 };
 inline Machine M;
 inline dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
@@ -374,6 +376,16 @@ inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t, vo
     if (M.cur) die("nested launch");
     if (block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) die("only 1-D launches are emulated");
     if (block.x == 0 || block.x > 1024) die("bad workgroup size");
+    if (M.capture) {  // a kernel node: its arguments are copied now, it runs at every hipGraphLaunch
+        auto* list = M.capture;
+        list->push_back([=]() {
+            auto* saved = M.capture;
+            M.capture = nullptr;
+            launch(name, kernel, grid, block, 0, nullptr, args...);
+            M.capture = saved;
+        });
+        return;
+    }
     M.kernel = name;
     ++M.launches;
     M.body = [=]() { kernel(args...); };
@@ -515,10 +527,18 @@ static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKi
     return hipSuccess;
 }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
+    if (hipemu::M.capture) {
+        hipemu::M.capture->push_back([=]() { if (n) std::memmove(d, s, n); });
+        return hipSuccess;
+    }
     if (n) std::memmove(d, s, n);
     return hipSuccess;
 }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) {
+    if (hipemu::M.capture) {
+        hipemu::M.capture->push_back([=]() { if (n) std::memset(d, v, n); });
+        return hipSuccess;
+    }
     if (n) std::memset(d, v, n);
     return hipSuccess;
 }
@@ -546,5 +566,36 @@ static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+
+// ---- stream capture / graphs: the captured work is a list of closures, replayed in order by hipGraphLaunch ----
+struct hipemu_graph {
+    std::vector<std::function<void()>> nodes;
+};
+typedef hipemu_graph* hipGraph_t;
+typedef hipemu_graph* hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+static inline hipError_t hipStreamBeginCapture(hipStream_t stream, hipStreamCaptureMode) {
+    if (!stream || hipemu::M.capture) return hipErrorInvalidValue;  // (the legacy default stream cannot be captured)
+    hipemu::M.capture = &(new hipemu_graph())->nodes;
+    return hipSuccess;
+}
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+    if (!hipemu::M.capture) return hipErrorInvalidValue;
+    *g = reinterpret_cast<hipemu_graph*>(reinterpret_cast<char*>(hipemu::M.capture) - offsetof(hipemu_graph, nodes));
+    hipemu::M.capture = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
+    *e = new hipemu_graph(*g);
+    return hipSuccess;
+}
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+    if (hipemu::M.capture) return hipErrorInvalidValue;
+    ++hipemu::M.graph_launches;
+    for (auto& f : e->nodes) f();
     return hipSuccess;
 }

@@ -33,9 +33,11 @@ def _no_cuda():
              phant_amd.Context)
 
     def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, verify_overlap=False,
-                verify_pipelined=False):
+                verify_pipelined=False, verify_graph=False):
         mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else "overlap" if verify_overlap else
                 "pipelined" if verify_pipelined else "flat")
+        if verify_graph and mode in ("flat", "nodedup"):
+            mode += "+graph"
         return emu.mirror_context(emu.mirror_lib(), mode)
 
     class _Device:  # torch.device("cuda", i) -> the CPU; isinstance checks inside torch still see a real device
@@ -94,6 +96,15 @@ def test_config3_dry_run(mode, streams):
     assert ("single_stream" in line) == (streams > 1)
     if mode != "fused":
         assert 0 < line["roofline"]["nodes_hashed"] <= line["roofline"]["nodes_shipped"] == 300 * 8
+
+
+def test_config3_graph_replay_dry_run():
+    line = _bench(["--proofs", "300", "--steps", "4", "--warmup", "2", "--streams", "2", "--graph", "--cpu-seconds", "0.2"])
+    _check_contract(line, 4, 2)
+    # per slot: one capture, then replays only (priming + warm-up + timed + the single-stream leg on slot 0)
+    g = line["config"]["graph"]
+    assert len(g) == 2 and all(c == 1 for c, _ in g) and g[0][1] == 1 + 1 + 2 + 4 and g[1][1] == 1 + 1 + 2
+    assert line["single_stream"]["value"] > 0
 
 
 def test_config3_fewer_steps_than_slots():

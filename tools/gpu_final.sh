@@ -16,6 +16,9 @@ for mode in nodedup overlap pipelined fused; do
   echo "== bench config3 $mode (A/B) =="
   timeout 300 python bench.py --verify-mode $mode --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_config3_$mode.json"
 done
+echo "== bench config3 --graph (A/B: one hipGraph launch per step and slot) =="
+timeout 300 python bench.py --graph --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_config3_graph.json"
+timeout 300 python bench.py --graph --streams 1 --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_config3_graph_s1.json"
 echo "== bench nodeset =="
 timeout 300 python bench.py --workload nodeset --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_nodeset.json"
 echo "== bench config4 (one 10k-tx block witness, multi-root) =="
