@@ -1128,8 +1128,10 @@ static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t h
     return (uint32_t)v;
 }
 
-hipError_t launch_mpt_verify_flat(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, FlatMode mode,
+hipError_t launch_mpt_verify_flat(const VerifyArgs& v_in, uint32_t total_nodes, uint8_t* ws, FlatMode mode,
                                   hipStream_t st, const FlatSide* side) {
+    VerifyArgs v = v_in;
+    v.total_nodes = total_nodes;  // (the lane-per-proof fixup bounds every proof's node range by it)
     if (v.n == 0) return hipSuccess;
     const bool dedup = mode != FLAT_NODEDUP;
     const bool have_side = side && side->stream && side->fork && side->join;
