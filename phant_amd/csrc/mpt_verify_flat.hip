@@ -246,15 +246,19 @@ constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte pat
 constexpr uint32_t DEDUP_BLOCK = 1024;
 constexpr uint32_t DEDUP_WAVES = DEDUP_BLOCK / 64;
 
-template <int MODE>
-__global__ void __launch_bounds__(DEDUP_BLOCK) dedup_kernel(const FlatArgs a) {
-    __shared__ uint32_t s_cnt[DEDUP_WAVES][N_CLASS];
+// BLOCK: workgroup size.  1024 everywhere (fewest cursor atomics); the 256 variant of COMPARE exists for the
+// overlap mode (PHANT_CMP_BLOCK=256): a workgroup of one wave per SIMD can become resident next to four hash
+// waves per SIMD, one of four waves per SIMD cannot until hash waves leave.
+template <int MODE, uint32_t BLOCK = DEDUP_BLOCK>
+__global__ void __launch_bounds__(BLOCK) dedup_kernel(const FlatArgs a) {
+    constexpr uint32_t WAVES = BLOCK / 64u;
+    __shared__ uint32_t s_cnt[WAVES][N_CLASS];
     __shared__ uint32_t s_base[N_CLASS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t n_lo, n_hi;
     node_range(a, n_lo, n_hi);
-    if (n_lo + blockIdx.x * DEDUP_BLOCK >= n_hi) return;  // (whole workgroup: the grid covers total_nodes)
-    const uint32_t j = n_lo + blockIdx.x * DEDUP_BLOCK + tid;
+    if (n_lo + blockIdx.x * BLOCK >= n_hi) return;  // (whole workgroup: the grid covers total_nodes)
+    const uint32_t j = n_lo + blockIdx.x * BLOCK + tid;
     const uint32_t N = n_hi;        // nodes this launch owns end here ...
     const uint32_t NT = a.total_nodes;  // ... ids and list strides are global
     // next to hash waves (which never stop issuing) these waves -- a few instructions, then a wait for
@@ -381,7 +385,7 @@ __global__ void __launch_bounds__(DEDUP_BLOCK) dedup_kernel(const FlatArgs a) {
     __syncthreads();
     if (tid < N_CLASS) {
         uint32_t tot = 0;
-        for (uint32_t w = 0; w < DEDUP_WAVES; ++w) tot += s_cnt[w][tid];
+        for (uint32_t w = 0; w < WAVES; ++w) tot += s_cnt[w][tid];
         s_base[tid] = tot ? atomicAdd(&cursors[tid], tot) : 0u;
     }
     __syncthreads();
@@ -1249,7 +1253,11 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v_in, uint32_t total_nodes, 
             if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
             launch_hash(a, st);
-            hipLaunchKernelGGL(dedup_kernel<DEDUP_COMPARE>, dim3(dg), dim3(DEDUP_BLOCK), cmp_lds, side->stream, a);
+            if (env_u32("PHANT_CMP_BLOCK", DEDUP_BLOCK, 256u, DEDUP_BLOCK) == 256u)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(dedup_kernel<DEDUP_COMPARE, 256u>), dim3((total_nodes + 255u) / 256u),
+                                   dim3(256), cmp_lds, side->stream, a);
+            else
+                hipLaunchKernelGGL(dedup_kernel<DEDUP_COMPARE>, dim3(dg), dim3(DEDUP_BLOCK), cmp_lds, side->stream, a);
             FlatArgs late = a;  // same kernel over the (normally empty) list of nodes that differed
             late.ent = a.late_ent;
             late.cursors = a.late_cursors;

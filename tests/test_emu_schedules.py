@@ -31,6 +31,9 @@ def test_results_do_not_depend_on_the_execution_order():
         if expr:
             cmd += ["-k", expr]
         env = dict(os.environ, HIPEMU_SCHEDULE=str(seed), HIPEMU_FILL=fill)
+        if seed == 3:  # this child also takes the overlap mode's alternative launch shape (round-2 A/B candidate):
+            # COMPARE as 256-thread workgroups next to the non-persistent hash kernel
+            env.update(PHANT_CMP_BLOCK="256", PHANT_HASH_PERSISTENT="0")
         runs.append((seed, subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                             text=True)))
     for seed, proc in runs:

@@ -21,10 +21,16 @@ COMBOS = [
     ("flat", {"PHANT_HASH_PERSISTENT": "1"}),
     ("pipelined", {}),
     ("overlap", {}),
+    # round-2 candidates (written after round 1's GPU budget was spent): COMPARE as one-wave-per-SIMD workgroups
+    # next to the hardware-dispatched hash kernel, at 4 and at 3 hash waves per SIMD
+    ("overlap", {"PHANT_HASH_PERSISTENT": "0", "PHANT_CMP_BLOCK": "256"}),
+    ("overlap", {"PHANT_HASH_PERSISTENT": "0"}),
+    ("overlap", {"PHANT_CMP_BLOCK": "256"}),
     ("nodedup", {}),
     ("fused", {}),
 ]
-KNOBS = ("PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO", "PHANT_HASH_PERSISTENT", "PHANT_HASH_CHUNK")
+KNOBS = ("PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO", "PHANT_HASH_PERSISTENT", "PHANT_HASH_CHUNK",
+         "PHANT_CMP_BLOCK")
 
 
 def main():
