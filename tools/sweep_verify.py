@@ -19,6 +19,7 @@ COMBOS = [
     ("flat", {}),
     ("flat", {"PHANT_HASH_CHUNK": "0"}),
     ("flat", {"PHANT_HASH_PERSISTENT": "1"}),
+    ("flat", {"PHANT_HASH_LDS_KB": "53"}),   # hash capped at 3 waves per SIMD (matters with launches in flight: bench.py)
     ("pipelined", {}),
     ("overlap", {}),
     # round-2 candidates (written after round 1's GPU budget was spent): COMPARE as one-wave-per-SIMD workgroups
@@ -30,7 +31,7 @@ COMBOS = [
     ("fused", {}),
 ]
 KNOBS = ("PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO", "PHANT_HASH_PERSISTENT", "PHANT_HASH_CHUNK",
-         "PHANT_CMP_BLOCK")
+         "PHANT_CMP_BLOCK", "PHANT_HASH_LDS_KB")
 
 
 def main():
