@@ -1204,10 +1204,11 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v_in, uint32_t total_nodes, 
     const uint32_t hg = (!persistent || ng + N_CLASS < slots) ? ng + N_CLASS : slots;
     const bool chunk_kernel = !persistent && env_u32("PHANT_HASH_CHUNK", 1u, 0u, 1u) != 0u;
     // PHANT_HASH_LDS_KB: an otherwise unused dynamic LDS allocation per hash workgroup caps how many of them a CU
-    // holds (160 KiB / it), i.e. the hash waves per SIMD, without recompiling: 40 -> 4, 53 -> 3, 80 -> 2.  For
+    // holds (160 KiB / it), i.e. the hash waves per SIMD, without recompiling: 40 -> 4, 53 -> 3, 63 -> 2 (a launch
+    // may ask for less than 64 KiB without further ado).  For
     // A/B runs with several launch sequences in flight, where the memory-bound kernels of other steps need
     // registers next to the hash; 0 = no cap.
-    const uint32_t hash_lds = env_u32("PHANT_HASH_LDS_KB", 0u, 0u, 160u) * 1024u;
+    const uint32_t hash_lds = env_u32("PHANT_HASH_LDS_KB", 0u, 0u, 63u) * 1024u;
     auto launch_hash = [&](const FlatArgs& fa, hipStream_t s) {
         if (chunk_kernel) hipLaunchKernelGGL(hash_chunk_kernel, dim3(hg), dim3(256), hash_lds, s, fa);
         else hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), hash_lds, s, fa);
