@@ -77,10 +77,11 @@ def parse():
     ap.add_argument("--block-scale", type=float, default=1.0, help="config4: size of the block relative to 10k tx")
     ap.add_argument("--stream-proofs", type=int, default=20_000, help="proofs per streamed witness (config5)")
     ap.add_argument("--stream-slots", type=int, default=3, help="witnesses in flight (config5)")
-    ap.add_argument("--verify-mode", default="flat", choices=["flat", "pipelined", "overlap", "nodedup", "fused"],
+    ap.add_argument("--verify-mode", default="flat", choices=["flat", "pipelined", "overlap", "nodedup", "fused", "mixed"],
                     help="flat = node-parallel pipeline with in-batch node dedup (default); overlap = the same with "
                          "the byte comparison on a helper stream next to the hashing; nodedup = same pipeline "
-                         "hashing every shipped node (A/B); fused = one lane per proof (A/B)")
+                         "hashing every shipped node (A/B); fused = one lane per proof (A/B); mixed = hash and COMPARE "
+                         "workgroups interleaved in one grid (A/B, unmeasured)")
     ap.add_argument("--streams", type=int, default=4,
                     help="config3: independent batches in flight, each on its own ctx + HIP stream (a validator "
                          "verifying consecutive witnesses); 1 = strictly one launch sequence after the other")
@@ -235,7 +236,7 @@ def main():
     ctx = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"),
                             verify_nodedup=(args.verify_mode == "nodedup"),
                             verify_overlap=(args.verify_mode == "overlap"),
-                            verify_pipelined=(args.verify_mode == "pipelined"))
+                            verify_pipelined=(args.verify_mode == "pipelined"), verify_mixed=(args.verify_mode == "mixed"))
 
     proofs_like = args.workload in ("config3", "config4")  # a resident proof batch, verified + per-root verdict
     if proofs_like:
@@ -265,7 +266,8 @@ def main():
                 c_ = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"),
                                        verify_nodedup=(args.verify_mode == "nodedup"),
                                        verify_overlap=(args.verify_mode == "overlap"),
-                                       verify_pipelined=(args.verify_mode == "pipelined"), verify_graph=args.graph)
+                                       verify_pipelined=(args.verify_mode == "pipelined"), verify_mixed=(args.verify_mode == "mixed"),
+                                       verify_graph=args.graph)
             slots.append((st_, c_, torch.empty_like(status), torch.zeros_like(fails)))
         turn = {"k": 0}
 

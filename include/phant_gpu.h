@@ -84,6 +84,10 @@ typedef struct phant_ctx phant_ctx;
                                        when the batch carries byte-identical copies (A/B) */
 #define PHANT_CTX_VERIFY_PIPELINED 16u /* flags: node-parallel pipeline over two half batches, the second a
                                           phase behind the first on a ctx-owned helper stream */
+#define PHANT_CTX_VERIFY_MIXED 64u /* flags: node-parallel pipeline with the byte comparison of the copies and
+                                    * the hashing of the representatives as ONE grid of interleaved
+                                    * workgroups (co-resident by construction; the single-stream form of
+                                    * PHANT_CTX_VERIFY_OVERLAP).  A/B candidate, unmeasured. */
 #define PHANT_CTX_VERIFY_GRAPH 32u /* flags: device-form verify calls replay their kernel sequence as ONE
                                     * hipGraph launch while the arguments (buffers, sizes) stay the same as
                                     * in the previous call; captured again when they change.  Serial

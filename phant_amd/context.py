@@ -18,7 +18,7 @@ class Context:
 
     def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
                  verify_nodedup: bool = False, verify_overlap: bool = False, verify_pipelined: bool = False,
-                 verify_graph: bool = False):
+                 verify_graph: bool = False, verify_mixed: bool = False):
         lib = L.lib()
         if not torch.cuda.is_available():
             raise L.PhantError(L.E_NO_DEVICE, "no GPU visible (phant_amd has no CPU fallback)")
@@ -39,6 +39,8 @@ class Context:
             flags |= 16  # PHANT_CTX_VERIFY_PIPELINED
         if verify_graph:
             flags |= 32  # PHANT_CTX_VERIFY_GRAPH
+        if verify_mixed:
+            flags |= 64  # PHANT_CTX_VERIFY_MIXED
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
         h = C.c_void_p()
         rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))

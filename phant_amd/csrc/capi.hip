@@ -146,11 +146,13 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     if (opts && (opts->flags & PHANT_CTX_VERIFY_NODEDUP)) flat = phant::FLAT_NODEDUP;
     if (opts && (opts->flags & PHANT_CTX_VERIFY_OVERLAP)) flat = phant::FLAT_OVERLAP;
     if (opts && (opts->flags & PHANT_CTX_VERIFY_PIPELINED)) flat = phant::FLAT_PIPELINED;
+    if (opts && (opts->flags & PHANT_CTX_VERIFY_MIXED)) flat = phant::FLAT_MIXED;
     if (const char* m = std::getenv("PHANT_VERIFY_MODE")) {  // overrides the flags (A/B without touching callers)
         fused = std::strcmp(m, "fused") == 0;
         flat = std::strcmp(m, "nodedup") == 0   ? phant::FLAT_NODEDUP
                : std::strcmp(m, "overlap") == 0   ? phant::FLAT_OVERLAP
                : std::strcmp(m, "pipelined") == 0 ? phant::FLAT_PIPELINED
+               : std::strcmp(m, "mixed") == 0     ? phant::FLAT_MIXED
                                                   : phant::FLAT_SERIAL;
     }
     int n = 0;
@@ -491,7 +493,8 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
     // (only the ctx's own device-form path -- `timed` -- replays a graph: the streaming slots stage into buffers
     // of their own and would re-capture per witness)
     if (timed && c->use_graph && st != nullptr && &dv == &c->dv &&
-        (c->flat_mode == phant::FLAT_SERIAL || c->flat_mode == phant::FLAT_NODEDUP) && a.n != 0) {
+        (c->flat_mode == phant::FLAT_SERIAL || c->flat_mode == phant::FLAT_NODEDUP || c->flat_mode == phant::FLAT_MIXED) &&
+        a.n != 0) {
         TimedRegion t(c);
         const int32_t served = verify_graph_launch(c, a, total_nodes, dv.base, st);
         if (served < 0) return served;

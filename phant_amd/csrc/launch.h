@@ -53,7 +53,9 @@ hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, const uint32_t* all_flag
 //                 groups' representatives (integer-VALU-bound) instead of in front of it
 //   FLAT_PIPELINED  two half batches, the second one a phase behind the first on `side->stream`: the
 //                 memory-bound kernels of one half run next to the VALU-bound hash of the other
-enum FlatMode : int { FLAT_SERIAL = 0, FLAT_NODEDUP = 1, FLAT_OVERLAP = 2, FLAT_PIPELINED = 3 };
+//   FLAT_MIXED    like FLAT_OVERLAP on ONE stream: the representatives' hash workgroups and the COMPARE workgroups
+//                 are interleaved in one grid (hash_compare_kernel), co-resident by construction
+enum FlatMode : int { FLAT_SERIAL = 0, FLAT_NODEDUP = 1, FLAT_OVERLAP = 2, FLAT_PIPELINED = 3, FLAT_MIXED = 4 };
 struct FlatSide {
     hipStream_t stream;           // non-blocking helper stream owned by the ctx
     hipEvent_t fork, join, mid;   // timing-disabled events

@@ -249,16 +249,16 @@ constexpr uint32_t DEDUP_WAVES = DEDUP_BLOCK / 64;
 // BLOCK: workgroup size.  1024 everywhere (fewest cursor atomics); the 256 variant of COMPARE exists for the
 // overlap mode (PHANT_CMP_BLOCK=256): a workgroup of one wave per SIMD can become resident next to four hash
 // waves per SIMD, one of four waves per SIMD cannot until hash waves leave.
-template <int MODE, uint32_t BLOCK = DEDUP_BLOCK>
-__global__ void __launch_bounds__(BLOCK) dedup_kernel(const FlatArgs a) {
+template <int MODE, uint32_t BLOCK>
+PHANT_DEV void dedup_body(const FlatArgs& a, const uint32_t block /* workgroup-uniform: which BLOCK nodes */) {
     constexpr uint32_t WAVES = BLOCK / 64u;
     __shared__ uint32_t s_cnt[WAVES][N_CLASS];
     __shared__ uint32_t s_base[N_CLASS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t n_lo, n_hi;
     node_range(a, n_lo, n_hi);
-    if (n_lo + blockIdx.x * BLOCK >= n_hi) return;  // (whole workgroup: the grid covers total_nodes)
-    const uint32_t j = n_lo + blockIdx.x * BLOCK + tid;
+    if (n_lo + block * BLOCK >= n_hi) return;  // (whole workgroup: the grid covers total_nodes)
+    const uint32_t j = n_lo + block * BLOCK + tid;
     const uint32_t N = n_hi;        // nodes this launch owns end here ...
     const uint32_t NT = a.total_nodes;  // ... ids and list strides are global
     // next to hash waves (which never stop issuing) these waves -- a few instructions, then a wait for
@@ -394,6 +394,11 @@ __global__ void __launch_bounds__(BLOCK) dedup_kernel(const FlatArgs a) {
         for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
         ent[(uint64_t)cls * NT + at] = j;
     }
+}
+
+template <int MODE, uint32_t BLOCK = DEDUP_BLOCK>
+__global__ void __launch_bounds__(BLOCK) dedup_kernel(const FlatArgs a) {
+    dedup_body<MODE, BLOCK>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------- canonical full branch, per rate block
@@ -623,10 +628,9 @@ __global__ void __launch_bounds__(256) hash_list_kernel(const FlatArgs a) {
 // runs out (see launch_mpt_verify_flat).  No register prefetch of the next rate block: without the 34-dword
 // buffer the kernel fits 4 waves per SIMD (<= 128 VGPRs) instead of 3, and four waves hide a block's load
 // latency as well as the buffer did.
-__global__ void __launch_bounds__(256, 4) hash_chunk_kernel(const FlatArgs a) {
+PHANT_DEV void hash_chunk_body(const FlatArgs& a, uint32_t q /* wave-uniform: position in the chunk queue */) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t N = a.total_nodes;
-    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     // queue position -> class and this lane's slot in ent[]; a short last chunk repeats its last node (same
     // digest stored twice) so that no lane is ever idle-masked
     uint32_t cls = N_CLASS, idx = 0;
@@ -683,6 +687,34 @@ __global__ void __launch_bounds__(256, 4) hash_chunk_kernel(const FlatArgs a) {
     uint4* o = reinterpret_cast<uint4*>(a.digest + 8ull * j);
     o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
     o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+}
+
+__global__ void __launch_bounds__(256, 4) hash_chunk_kernel(const FlatArgs a) {
+    hash_chunk_body(a, (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)));
+}
+
+// ---------------------------------------------------------------- hash + compare in one grid (FLAT_MIXED)
+// The overlap mode wants the byte comparison of the copies (an HBM stream, a handful of VALU instructions per
+// node) to run UNDER the hashing of the representatives (integer-VALU-bound).  As two kernels on two streams that
+// is at the mercy of what the dispatcher finds room for; here both kinds of workgroup are
+// one launch: of the grid's workgroups, evenly spread, `n_cmp` are COMPARE workgroups of 256 nodes each
+// (dedup_body<COMPARE, 256>) and the others hash one 64-node chunk per wave (hash_chunk_body), so that at any
+// moment a CU holds a mix of both whatever else is going on.  The number of hash workgroups that have work is
+// only known on the device (the class cursors CLASSIFY left): the grid covers the worst case and the workgroups
+// beyond the real total leave at once.
+__global__ void __launch_bounds__(256, 4) hash_compare_kernel(const FlatArgs a, const uint32_t n_cmp) {
+    uint32_t chunks = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < N_CLASS; ++c) chunks += (a.cursors[c] + 63u) / 64u;
+    const uint32_t n_hash = (chunks + 3u) / 4u, total = n_hash + n_cmp, b = blockIdx.x;
+    if (b >= total) return;
+    // Bresenham spread: workgroup b is a COMPARE one iff floor((b + 1) n_cmp / total) > floor(b n_cmp / total)
+    const uint32_t c0 = (uint32_t)(((uint64_t)b * n_cmp) / total), c1 = (uint32_t)(((uint64_t)(b + 1u) * n_cmp) / total);
+    if (c1 != c0) {
+        dedup_body<DEDUP_COMPARE, 256u>(a, c0);
+    } else {
+        hash_chunk_body(a, (uint32_t)__builtin_amdgcn_readfirstlane((b - c0) * 4u + (threadIdx.x >> 6)));
+    }
 }
 
 // ---------------------------------------------------------------- link
@@ -1248,7 +1280,16 @@ hipError_t launch_mpt_verify_flat(const VerifyArgs& v_in, uint32_t total_nodes, 
     }
     if (total_nodes) {
         hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
-        if (!overlap) {
+        if (mode == FLAT_MIXED) {
+            // CLASSIFY (trust the table) -> ONE grid of hash and COMPARE workgroups -> the (normally empty) late list
+            const uint32_t n_cmp = (total_nodes + 255u) / 256u;
+            hipLaunchKernelGGL(dedup_kernel<DEDUP_CLASSIFY>, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);
+            hipLaunchKernelGGL(hash_compare_kernel, dim3(ng + N_CLASS + n_cmp), dim3(256), 0, st, a, n_cmp);
+            FlatArgs late = a;
+            late.ent = a.late_ent;
+            late.cursors = a.late_cursors;
+            hipLaunchKernelGGL(hash_chunk_kernel, dim3(ng + N_CLASS), dim3(256), 0, st, late);
+        } else if (!overlap) {
             hipLaunchKernelGGL(dedup_kernel<DEDUP_SERIAL>, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);
             launch_hash(a, st);
         } else {

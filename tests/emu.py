@@ -89,8 +89,9 @@ class Opts(C.Structure):
     _fields_ = [("struct_size", _u32), ("device", _i32), ("stream", _vp), ("flags", _u32)]
 
 
-FUSED, NODEDUP, OVERLAP, PIPELINED, GRAPH = 2, 4, 8, 16, 32
-MODES = {"flat": 0, "nodedup": NODEDUP, "overlap": OVERLAP, "pipelined": PIPELINED, "fused": FUSED,
+FUSED, NODEDUP, OVERLAP, PIPELINED, GRAPH, MIXED = 2, 4, 8, 16, 32, 64
+MODES = {"flat": 0, "nodedup": NODEDUP, "overlap": OVERLAP, "pipelined": PIPELINED, "fused": FUSED, "mixed": MIXED,
+         "mixed+graph": GRAPH | MIXED | 1,
          "flat+graph": GRAPH | 1, "nodedup+graph": GRAPH | NODEDUP | 1}  # (graphs need a real stream: | 1 = own stream)
 
 

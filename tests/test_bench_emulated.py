@@ -33,10 +33,10 @@ def _no_cuda():
              phant_amd.Context)
 
     def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, verify_overlap=False,
-                verify_pipelined=False, verify_graph=False):
+                verify_pipelined=False, verify_graph=False, verify_mixed=False):
         mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else "overlap" if verify_overlap else
-                "pipelined" if verify_pipelined else "flat")
-        if verify_graph and mode in ("flat", "nodedup"):
+                "pipelined" if verify_pipelined else "mixed" if verify_mixed else "flat")
+        if verify_graph and mode in ("flat", "nodedup", "mixed"):
             mode += "+graph"
         return emu.mirror_context(emu.mirror_lib(), mode)
 
@@ -85,7 +85,7 @@ def _check_contract(line, steps, warmup):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
 
 
-@pytest.mark.parametrize("mode,streams", [("flat", 3), ("flat", 1), ("fused", 2), ("pipelined", 2)])
+@pytest.mark.parametrize("mode,streams", [("flat", 3), ("flat", 1), ("fused", 2), ("pipelined", 2), ("mixed", 2)])
 def test_config3_dry_run(mode, streams):
     line = _bench(["--proofs", "300", "--steps", "3", "--warmup", "1", "--verify-mode", mode, "--streams",
                    str(streams), "--cpu-seconds", "0.2"])

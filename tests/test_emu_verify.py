@@ -13,7 +13,9 @@ def _emulated_backend():
     yield from emu.emulated_backend()
 
 
-@pytest.fixture(scope="module", params=["flat", "pipelined", "overlap", "nodedup", "fused"])
+# "mixed" = PHANT_CTX_VERIFY_MIXED, the round-2 candidate (hash and COMPARE workgroups in one grid): not in the GPU
+# modules' fixture yet, so it takes every shared body here
+@pytest.fixture(scope="module", params=["flat", "pipelined", "overlap", "nodedup", "fused", "mixed"])
 def M(request):
     import phant_amd
     from tests.test_gpu_verify import _Mode
@@ -29,10 +31,19 @@ from tests.test_gpu_verify import (  # noqa: E402,F401
     test_synthetic_other_depths, test_block_witness_accounts_and_storage)
 from tests.test_gpu_x_verify_more import (  # noqa: E402,F401
     test_keys_longer_than_the_lds_staging, test_synthetic_block_witness_vs_oracle,
-    test_graph_replay_reads_fresh_data_and_recaptures_on_new_arguments)
+    test_graph_replay_reads_fresh_data_and_recaptures_on_new_arguments, test_mixed_mode_runs_the_shared_bodies)
 
 
-@pytest.fixture(scope="module", params=["flat", "nodedup"])
+@pytest.fixture(scope="module")
+def MX():
+    import phant_amd
+    from tests.test_gpu_verify import _Mode
+    ctx = emu.mirror_context(emu.mirror_lib(), "mixed")
+    yield _Mode(phant_amd.mpt, ctx, "mixed")
+    ctx.close()
+
+
+@pytest.fixture(scope="module", params=["flat", "nodedup", "mixed"])
 def MG(request):
     import phant_amd
     from tests.test_gpu_verify import _Mode

@@ -16,6 +16,10 @@ timeout 300 python bench.py --no-cpu-baseline --graph 2>&1 | tail -1 | tee "$OUT
 timeout 300 python bench.py --no-cpu-baseline --graph --streams 1 2>&1 | tail -1 | tee "$OUT/bench_config3_graph_s1.json"
 timeout 300 python bench.py --no-cpu-baseline --streams 1 2>&1 | tail -1 | tee "$OUT/bench_config3_s1.json"
 PHANT_HASH_LDS_KB=53 timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_config3_hash3waves.json"
+for s in 1 4; do
+  timeout 300 python bench.py --no-cpu-baseline --verify-mode mixed --streams $s 2>&1 | tail -1 | tee "$OUT/bench_config3_mixed_s$s.json"
+done
+timeout 300 python bench.py --no-cpu-baseline --verify-mode mixed --graph 2>&1 | tail -1 | tee "$OUT/bench_config3_mixed_graph.json"
 for s in 2 8; do
   timeout 300 python bench.py --no-cpu-baseline --streams $s 2>&1 | tail -1 | tee "$OUT/bench_config3_s$s.json"
   timeout 300 python bench.py --no-cpu-baseline --streams $s --graph 2>&1 | tail -1 | tee "$OUT/bench_config3_graph_s$s.json"

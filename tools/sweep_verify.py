@@ -27,6 +27,8 @@ COMBOS = [
     ("overlap", {"PHANT_HASH_PERSISTENT": "0", "PHANT_CMP_BLOCK": "256"}),
     ("overlap", {"PHANT_HASH_PERSISTENT": "0"}),
     ("overlap", {"PHANT_CMP_BLOCK": "256"}),
+    ("mixed", {}),                      # hash + COMPARE workgroups in one grid
+    ("mixed", {"PHANT_CMP_PRIO": "0"}),
     ("nodedup", {}),
     ("fused", {}),
 ]
@@ -54,7 +56,8 @@ def main():
             os.environ.pop(k, None)
         os.environ.update(env)
         ctx = phant_amd.Context(0, verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"),
-                                verify_overlap=(mode == "overlap"), verify_pipelined=(mode == "pipelined"))
+                                verify_overlap=(mode == "overlap"), verify_pipelined=(mode == "pipelined"),
+                                verify_mixed=(mode == "mixed"))
         status.fill_(0x77)
         for _ in range(3):
             M.verify_batch_dev(b, status=status, ctx=ctx)
