@@ -61,7 +61,7 @@ def main():
     from tests.witness_util import random_kv, pack_proofs, node_set
 
     modes = {"flat": {}, "pipelined": {"verify_pipelined": True}, "overlap": {"verify_overlap": True},
-             "nodedup": {"verify_nodedup": True}, "fused": {"verify_fused": True}}
+             "nodedup": {"verify_nodedup": True}, "fused": {"verify_fused": True}, "mixed": {"verify_mixed": True}}
     if args.emulated:
         from tests import emu
         backend = emu.emulated_backend()
