@@ -68,6 +68,7 @@ SYMBOLS = {
     "phant_wait": (_i32, [_vp, _u32]),
     "phant_witness_parse_json": (_i32, [C.c_char_p, _u64, C.POINTER(_vp), C.c_char_p, _u32]),
     "phant_witness_parse_json_mt": (_i32, [C.c_char_p, _u64, _u32, C.POINTER(_vp), C.c_char_p, _u32]),
+    "phant_witness_index_json": (_i32, [C.c_char_p, _u64, _u32, C.POINTER(_vp), C.c_char_p, _u32]),
     "phant_witness_free": (None, [_vp]),
     "phant_witness_get": (_i32, [_vp, _vp]),
     "phant_witness_verify": (_i32, [_vp, _vp, _vp, C.POINTER(_u32)]),

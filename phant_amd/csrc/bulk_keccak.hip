@@ -56,6 +56,65 @@ sender_address_kernel(const uint8_t* __restrict__ pubkeys, uint64_t stride, uint
     o[4] = s.hi[3];
 }
 
+// ---- a witness in its "index" form (witness.h): the proof nodes' hex digits still sit in the JSON text ----
+// One wave per node: byte k of node i = the two hex digits at json[node_src[i] + 2k].  Anything that is not a
+// hex digit sets err[0] and lowers err[1] to the first such node (both zero / 0xffffffff initialised by the
+// launcher); the decoded bytes of such a node are unspecified and the caller rejects the witness.
+PHANT_DEV uint32_t hex_nibble(uint32_t c, uint32_t& bad) {
+    const uint32_t digit = c - '0', alpha = (c | 0x20u) - 'a';
+    bad |= (digit > 9u && alpha > 5u) ? 1u : 0u;
+    return digit <= 9u ? digit : alpha + 10u;
+}
+
+__global__ void __launch_bounds__(256)
+hex_decode_kernel(const uint8_t* __restrict__ json, const uint64_t* __restrict__ node_src,
+                  const uint64_t* __restrict__ node_off, uint32_t total_nodes, uint8_t* __restrict__ nodes,
+                  uint32_t* __restrict__ err) {
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= total_nodes) return;
+    const uint64_t b = node_off[i], e = node_off[i + 1];
+    const uint8_t* src = json + node_src[i];
+    uint32_t bad = 0;
+    for (uint64_t k = lane; k < e - b; k += 64u) {
+        const uint32_t hi = hex_nibble(src[2u * k], bad), lo = hex_nibble(src[2u * k + 1u], bad);
+        nodes[b + k] = (uint8_t)((hi << 4) | lo);
+    }
+    if (bad) {
+        atomicOr(&err[0], 1u);
+        atomicMin(&err[1], i);
+    }
+}
+
+// the proven values (leaf payloads) of a batch, compacted for the host's consistency check: value i (at most
+// `cap` bytes of it) at out + i * cap
+__global__ void __launch_bounds__(256)
+gather_values_kernel(const uint8_t* __restrict__ nodes, const uint64_t* __restrict__ value_off,
+                     const uint32_t* __restrict__ value_len, uint32_t n, uint32_t cap, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t len = value_len[i] < cap ? value_len[i] : cap;
+    const uint8_t* v = nodes + value_off[i];
+    for (uint32_t k = 0; k < len; ++k) out[(uint64_t)i * cap + k] = v[k];
+}
+
+hipError_t launch_hex_decode(const uint8_t* d_json, const uint64_t* d_node_src, const uint64_t* d_node_off,
+                             uint32_t total_nodes, uint8_t* d_nodes, uint32_t* d_err, hipStream_t st) {
+    static const uint32_t init[2] = {0u, 0xffffffffu};
+    hipError_t e = hipMemcpyAsync(d_err, init, 8, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess || total_nodes == 0) return e;
+    hipLaunchKernelGGL(hex_decode_kernel, dim3((total_nodes + 3u) / 4u), dim3(256), 0, st, d_json, d_node_src, d_node_off,
+                       total_nodes, d_nodes, d_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_values(const uint8_t* d_nodes, const uint64_t* d_value_off, const uint32_t* d_value_len,
+                                uint32_t n, uint32_t cap, uint8_t* d_out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_values_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, d_nodes, d_value_off, d_value_len,
+                       n, cap, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_logs_bloom(const uint8_t* d_items, const uint64_t* d_item_off, const uint32_t* d_item_receipt,
                              uint32_t n_items, uint32_t n_receipts, uint8_t* d_blooms, hipStream_t st) {
     if (n_receipts == 0) return hipSuccess;

@@ -788,6 +788,25 @@ int32_t phant_witness_parse_json_mt(const char* json, uint64_t len, uint32_t thr
     return PHANT_OK;
 }
 
+int32_t phant_witness_index_json(const char* json, uint64_t len, uint32_t threads, phant_witness** out, char* err,
+                                 uint32_t err_cap) {
+    if (!out || (!json && len)) return PHANT_E_INVALID_ARG;
+    *out = nullptr;
+    phant_witness* w = new (std::nothrow) phant_witness();
+    if (!w) return PHANT_E_OOM;
+    std::string msg;
+    if (!phant::witness_index_json(json, (size_t)len, threads, w->w, msg)) {
+        if (err && err_cap) {
+            std::strncpy(err, msg.c_str(), err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        delete w;
+        return PHANT_E_INVALID_ARG;
+    }
+    *out = w;
+    return PHANT_OK;
+}
+
 void phant_witness_free(phant_witness* w) { delete w; }
 
 int32_t phant_witness_get(const phant_witness* pw, phant_witness_info* info) {
@@ -798,13 +817,13 @@ int32_t phant_witness_get(const phant_witness* pw, phant_witness_info* info) {
     info->n_accounts = (uint32_t)w.accounts.size();
     info->n_slots = (uint32_t)w.slots.size();
     info->total_nodes = (uint32_t)(w.node_off.size() - 1);
-    info->nodes_len = (uint64_t)w.nodes.size();
+    info->nodes_len = w.deferred ? w.nodes_bytes : (uint64_t)w.nodes.size();
     info->roots = w.roots.data();
     info->root_idx = w.root_idx.data();
     info->account_of = w.account_of.data();
     info->preimages = w.preimages.data();
     info->preimage_off = w.preimage_off.data();
-    info->nodes = w.nodes.data();
+    info->nodes = w.deferred ? nullptr : w.nodes.data();  // index form: the nodes are decoded on the device only
     info->node_off = w.node_off.data();
     info->proof_first_node = w.proof_first_node.data();
     return PHANT_OK;
@@ -819,13 +838,21 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* sta
     if (!status) return fail(c, PHANT_E_INVALID_ARG, "witness_verify: null status");
     const uint32_t n_roots = (uint32_t)(w.roots.size() / 32);
     const uint32_t total_nodes = (uint32_t)(w.node_off.size() - 1);
-    const size_t nodes_len = w.nodes.size(), pre_len = w.preimages.size();
+    // index form (phant_witness_index_json): the nodes' hex is still in the JSON text -- ship the text, decode on
+    // the device, fetch only the proven values back for the consistency check
+    const bool deferred = w.deferred;
+    constexpr uint32_t VAL_CAP = 128;  // an account body is <= 110 bytes, a slot value <= 33
+    const size_t nodes_len = deferred ? (size_t)w.nodes_bytes : w.nodes.size(), pre_len = w.preimages.size();
+    if (deferred && total_nodes && !w.json) return fail(c, PHANT_E_INVALID_ARG, "witness_verify: index-form witness without its JSON text");
     DeviceGuard g(c->device);
     hipStream_t s = c->stream;
     const size_t need = ws_round(pre_len + 16) + ws_round(((size_t)n + 1) * 8) + ws_round((size_t)n * 32) +
                         ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) + ws_round(nodes_len + 16) +
                         ws_round(((size_t)total_nodes + 1) * 8) + ws_round(((size_t)n + 1) * 4) + ws_round(n) +
-                        ws_round((size_t)n * 8) + ws_round((size_t)n * 4);
+                        ws_round((size_t)n * 8) + ws_round((size_t)n * 4) +
+                        (deferred ? ws_round(w.json_len + 16) + ws_round((size_t)total_nodes * 8 + 8) + ws_round(16) +
+                                        ws_round((size_t)n * VAL_CAP)
+                                  : 0);
     int32_t rc = ws_reset(c, need);
     if (rc) return rc;
     uint8_t* d_pre = ws_take<uint8_t>(c, pre_len + 16);
@@ -844,9 +871,21 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* sta
     HIP_TRY(c, hipMemcpyAsync(d_poff, poff64.data(), poff64.size() * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_roots, w.roots.data(), w.roots.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_ridx, w.root_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, w.nodes.data(), nodes_len, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_noff, w.node_off.data(), ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_pfn, w.proof_first_node.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+    uint32_t* d_err = nullptr;
+    uint8_t* d_vals = nullptr;
+    if (!deferred) {
+        if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, w.nodes.data(), nodes_len, hipMemcpyHostToDevice, s));
+    } else {
+        uint8_t* d_json = ws_take<uint8_t>(c, w.json_len + 16);
+        uint64_t* d_src = ws_take<uint64_t>(c, (size_t)total_nodes + 1);
+        d_err = ws_take<uint32_t>(c, 4);
+        d_vals = ws_take<uint8_t>(c, (size_t)n * VAL_CAP);
+        HIP_TRY(c, hipMemcpyAsync(d_json, w.json, w.json_len, hipMemcpyHostToDevice, s));
+        if (total_nodes) HIP_TRY(c, hipMemcpyAsync(d_src, w.node_src.data(), (size_t)total_nodes * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, phant::launch_hex_decode(d_json, d_src, d_noff, total_nodes, d_nodes, d_err, s));
+    }
     // secure-trie keys: keccak256(address) / keccak256(slot), one batched launch
     HIP_TRY(c, phant::launch_keccak256_var(d_pre, d_poff, n, d_keys, s));
     phant::VerifyArgs a{d_roots, n_roots, d_ridx, d_keys, 32, d_nodes, nodes_len, d_noff, d_pfn, n, d_status, d_voff, d_vlen};
@@ -858,10 +897,31 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* sta
     if (rc) return rc;
     std::vector<uint64_t> voff(n);
     std::vector<uint32_t> vlen(n);
+    std::vector<uint8_t> vals;
+    uint32_t herr[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(voff.data(), d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(vlen.data(), d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (deferred) {
+        vals.resize((size_t)n * VAL_CAP);
+        HIP_TRY(c, phant::launch_gather_values(d_nodes, d_voff, d_vlen, n, VAL_CAP, d_vals, s));
+        HIP_TRY(c, hipMemcpyAsync(vals.data(), d_vals, vals.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(herr, d_err, 8, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (deferred && herr[0]) {  // what the host parser says for the same document (witness_json.cpp)
+        char msg[96];
+        std::snprintf(msg, sizeof(msg), "witness_verify: proof node %u is not hex data", herr[1]);
+        return fail(c, PHANT_E_INVALID_ARG, msg);
+    }
+    // where proof p's proven value can be read on the host (index form: the compacted copy, cut at VAL_CAP -- a
+    // longer value is no account body / slot value and fails the checks below on its length)
+    auto value_of = [&](uint32_t p) -> const uint8_t* {
+        return deferred ? vals.data() + (size_t)p * VAL_CAP : w.nodes.data() + voff[p];
+    };
+    if (deferred)
+        for (uint32_t p = 0; p < n; ++p)
+            if (vlen[p] > VAL_CAP && status[p] == PHANT_PROOF_PRESENT) status[p] = PHANT_PROOF_MISMATCH;
 
     // ---- host: does what was proven agree with what the witness declares? ----
     std::vector<uint8_t> anchored(w.accounts.size(), 0);
@@ -869,7 +929,7 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* sta
         const phant::WitnessAccount& acc = w.accounts[ai];
         uint8_t& st = status[acc.proof];
         if (st == PHANT_PROOF_PRESENT) {
-            if (account_consistent(acc, w.nodes.data() + voff[acc.proof], vlen[acc.proof])) anchored[ai] = 1;
+            if (account_consistent(acc, value_of(acc.proof), vlen[acc.proof])) anchored[ai] = 1;
             else st = PHANT_PROOF_MISMATCH;
         } else if (st == PHANT_PROOF_ABSENT) {
             if (account_absent_consistent(acc)) anchored[ai] = 1;
@@ -891,7 +951,7 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* sta
             // slot value = rlp(minimal big-endian integer)
             size_t pay, len, total;
             bool is_list;
-            const uint8_t* v = w.nodes.data() + voff[sl.proof];
+            const uint8_t* v = value_of(sl.proof);
             if (!host_rlp_item(v, vlen[sl.proof], pay, len, total, is_list) || is_list || total != vlen[sl.proof] ||
                 !be_equals_padded(v + pay, len, sl.value))
                 st = PHANT_PROOF_MISMATCH;

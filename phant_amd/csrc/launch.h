@@ -18,6 +18,13 @@ hipError_t launch_logs_bloom(const uint8_t* d_items, const uint64_t* d_item_off,
 hipError_t launch_sender_addresses(const uint8_t* d_pubkeys, uint64_t stride, uint32_t n, uint8_t* d_out,
                                    hipStream_t st);
 
+// index-form witnesses: decode the nodes' hex digits out of the JSON text on the device (d_err: 2 dwords, [0] != 0
+// when some digit was not hex, [1] = the first such node), and compact the proven values for the host
+hipError_t launch_hex_decode(const uint8_t* d_json, const uint64_t* d_node_src, const uint64_t* d_node_off,
+                             uint32_t total_nodes, uint8_t* d_nodes, uint32_t* d_err, hipStream_t st);
+hipError_t launch_gather_values(const uint8_t* d_nodes, const uint64_t* d_value_off, const uint32_t* d_value_len,
+                                uint32_t n, uint32_t cap, uint8_t* d_out, hipStream_t st);
+
 struct VerifyArgs {
     const uint8_t* roots;
     uint32_t n_roots;

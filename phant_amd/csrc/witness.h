@@ -35,10 +35,21 @@ struct Witness {
     std::vector<uint32_t> proof_first_node; // proofs + 1
     std::vector<WitnessAccount> accounts;
     std::vector<WitnessSlot> slots;
+    // "index" form (witness_index_json): the proof nodes are NOT decoded on the host -- `nodes` stays empty,
+    // node_off holds the byte offsets the decoded nodes WILL have, node_src[i] is where node i's hex digits start
+    // in the JSON text (after an optional 0x), which the witness borrows until it is verified; the GPU decodes
+    // (bulk_keccak.hip::hex_decode_kernel) and reports digits that are not hex
+    bool deferred = false;
+    const char* json = nullptr;
+    size_t json_len = 0;
+    uint64_t nodes_bytes = 0;               // = node_off.back() in the index form
+    std::vector<uint64_t> node_src;         // total_nodes
 };
 
 bool witness_parse_json(const char* json, size_t len, Witness& out, std::string& err);
 // the same result with the accounts parsed on `threads` host threads (0 = as many as the host has, at most 32)
 bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witness& out, std::string& err);
+// index form: everything but the proof nodes' hex is parsed as above (threads as above, 1 = on the caller's thread)
+bool witness_index_json(const char* json, size_t len, unsigned threads, Witness& out, std::string& err);
 
 }  // namespace phant

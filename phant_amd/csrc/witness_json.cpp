@@ -257,6 +257,19 @@ bool parse_node_array(Parser& ps, Builder& b) {
         const char *sb = nullptr, *se = nullptr;
         bool esc = false;
         if (!ps.str_view(sb, se, esc)) return false;
+        if (b.w.deferred) {
+            // index form: note where the digits are and how many bytes they will make; the GPU decodes them
+            const char* h = sb;
+            if (se - h >= 2 && h[0] == '0' && (h[1] == 'x' || h[1] == 'X')) h += 2;
+            size_t n = (size_t)(se - h);
+            if (n == 1 && h[0] == '0') n = 0;  // "0x0" = empty (hexutils.zig:22-37)
+            if (esc || (n & 1)) return ps.fail("proof node is not hex data");
+            b.w.node_src.push_back((uint64_t)(h - b.w.json));
+            b.w.nodes_bytes += n / 2;
+            b.w.node_off.push_back(b.w.nodes_bytes);
+            if (ps.lit(',')) continue;
+            return ps.expect(']');
+        }
         if (esc || !hex_append(sb, se, b.w.nodes)) return ps.fail("proof node is not hex data");
         b.w.node_off.push_back((uint64_t)b.w.nodes.size());
         if (ps.lit(',')) continue;
@@ -399,9 +412,12 @@ bool parse_account(Parser& ps, Builder& b) {
 
 }  // namespace
 
-bool witness_parse_json(const char* json, size_t len, Witness& w, std::string& err) {
+static bool parse_single(const char* json, size_t len, Witness& w, std::string& err, bool deferred) {
     w = Witness();
-    w.nodes.reserve(len / 2);  // a witness is mostly hex: avoids regrowing the blob while it is filled
+    w.deferred = deferred;
+    w.json = deferred ? json : nullptr;
+    w.json_len = deferred ? len : 0;
+    if (!deferred) w.nodes.reserve(len / 2);  // a witness is mostly hex: avoids regrowing the blob while it is filled
     w.node_off.push_back(0);
     w.proof_first_node.push_back(0);
     w.preimage_off.push_back(0);
@@ -464,7 +480,11 @@ bool witness_parse_json(const char* json, size_t len, Witness& w, std::string& e
 // verifier.  Accounts are independent objects, so: one serial pass finds their spans (skipping a string is a
 // memchr), every thread parses a contiguous run of spans into its own Witness, and the pieces are
 // concatenated with their offsets re-based -- byte-identical to the serial result.
-bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witness& w, std::string& err) {
+bool witness_parse_json(const char* json, size_t len, Witness& w, std::string& err) {
+    return parse_single(json, len, w, err, false);
+}
+
+static bool parse_mt(const char* json, size_t len, unsigned threads, Witness& w, std::string& err, bool deferred) {
     if (threads == 0) {
         threads = std::thread::hardware_concurrency();
         if (threads == 0) threads = 1;
@@ -527,7 +547,7 @@ bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witne
     }
     // anything wrong at this level, or too little to share out: the serial parser reports it / does it
     if (!ok || !have_root || threads < 2 || spans.size() < 2u * threads || len < (1u << 20))
-        return witness_parse_json(json, len, w, err);
+        return parse_single(json, len, w, err, deferred);
 
     // ---- pass 2 (parallel): contiguous runs of accounts of about equal size ----
     const size_t T = threads;
@@ -546,10 +566,13 @@ bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witne
     std::vector<const char*> perr_at(T, nullptr);
     auto work = [&](size_t t) {
         Witness& lw = part[t];
+        lw.deferred = deferred;
+        lw.json = json;
         lw.node_off.push_back(0);
         lw.proof_first_node.push_back(0);
         lw.preimage_off.push_back(0);
-        if (first[t] < first[t + 1]) lw.nodes.reserve((size_t)(spans[first[t + 1] - 1].e - spans[first[t]].b) / 2);
+        if (!deferred && first[t] < first[t + 1])
+            lw.nodes.reserve((size_t)(spans[first[t + 1] - 1].e - spans[first[t]].b) / 2);
         Builder b(lw);
         for (size_t i = first[t]; i < first[t + 1]; ++i) {
             Parser sub{spans[i].b, spans[i].e, std::string(), json};
@@ -586,17 +609,22 @@ bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witne
         proof0[t + 1] = proof0[t] + lw.root_idx.size();
         node0[t + 1] = node0[t] + (lw.node_off.size() - 1);
         pre0[t + 1] = pre0[t] + lw.preimages.size();
-        byte0[t + 1] = byte0[t] + lw.nodes.size();
+        byte0[t + 1] = byte0[t] + (deferred ? (size_t)lw.nodes_bytes : lw.nodes.size());
         slot0[t + 1] = slot0[t] + lw.slots.size();
     }
     w = Witness();
+    w.deferred = deferred;
+    w.json = deferred ? json : nullptr;
+    w.json_len = deferred ? len : 0;
+    w.nodes_bytes = deferred ? byte0[T] : 0;
+    if (deferred) w.node_src.resize(node0[T]);
     w.roots.resize(32 * (acc0[T] + 1));
     std::memcpy(w.roots.data(), state_root, 32);
     w.root_idx.resize(proof0[T]);
     w.account_of.resize(proof0[T]);
     w.preimages.resize(pre0[T]);
     w.preimage_off.resize(proof0[T] + 1);
-    w.nodes.resize(byte0[T]);
+    if (!deferred) w.nodes.resize(byte0[T]);
     w.node_off.resize(node0[T] + 1);
     w.proof_first_node.resize(proof0[T] + 1);
     w.accounts.resize(acc0[T]);
@@ -616,6 +644,7 @@ bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witne
         if (!lw.preimages.empty()) std::memcpy(w.preimages.data() + q0, lw.preimages.data(), lw.preimages.size());
         for (size_t i = 1; i < lw.preimage_off.size(); ++i) w.preimage_off[p0 + i] = lw.preimage_off[i] + q0;
         if (!lw.nodes.empty()) std::memcpy(w.nodes.data() + b0, lw.nodes.data(), lw.nodes.size());
+        if (!lw.node_src.empty()) std::memcpy(w.node_src.data() + n0, lw.node_src.data(), lw.node_src.size() * 8);
         for (size_t i = 1; i < lw.node_off.size(); ++i) w.node_off[n0 + i] = lw.node_off[i] + b0;
         for (size_t i = 1; i < lw.proof_first_node.size(); ++i) w.proof_first_node[p0 + i] = lw.proof_first_node[i] + n0;
         for (size_t i = 0; i < lw.accounts.size(); ++i) {
@@ -637,6 +666,14 @@ bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witne
         for (auto& x : th) x.join();
     }
     return true;
+}
+
+bool witness_parse_json_mt(const char* json, size_t len, unsigned threads, Witness& w, std::string& err) {
+    return parse_mt(json, len, threads, w, err, false);
+}
+
+bool witness_index_json(const char* json, size_t len, unsigned threads, Witness& w, std::string& err) {
+    return threads == 1 ? parse_single(json, len, w, err, true) : parse_mt(json, len, threads, w, err, true);
 }
 
 }  // namespace phant

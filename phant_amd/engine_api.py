@@ -40,9 +40,10 @@ def _view(ptr, count, dtype):
 
 
 class ExecutionWitness:
-    def __init__(self, handle):
+    def __init__(self, handle, keep=None):
         self._h = handle
         self._lib = L.lib()
+        self._keep = keep  # index form: the JSON text the witness borrows until it is closed
 
     @staticmethod
     def parse_json(text: str | bytes, threads: int = 1) -> "ExecutionWitness":
@@ -55,6 +56,20 @@ class ExecutionWitness:
         if rc != L.OK:
             raise WitnessFormatError(err.value.decode() or f"phant_witness_parse_json rc={rc}")
         return ExecutionWitness(h)
+
+    @staticmethod
+    def index_json(text: str | bytes, threads: int = 1) -> "ExecutionWitness":
+        """The index form (phant_witness_index_json): the proof nodes' hex stays in the text and is decoded on the
+        GPU by verify(); the host only does the structural scan.  info()["nodes"] is empty for it."""
+        lib = L.lib()
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        buf = C.create_string_buffer(data, len(data))  # stable address for as long as the witness lives
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = lib.phant_witness_index_json(buf, len(data), threads, C.byref(h), err, 256)
+        if rc != L.OK:
+            raise WitnessFormatError(err.value.decode() or f"phant_witness_index_json rc={rc}")
+        return ExecutionWitness(h, keep=buf)
 
     def info(self) -> dict:
         """numpy views (valid while this object lives) of the packed arrays + counts."""
@@ -70,17 +85,21 @@ class ExecutionWitness:
                 "roots": _view(wi.roots, wi.n_roots * 32, np.uint8).reshape(-1, 32),
                 "root_idx": _view(wi.root_idx, n, np.uint32), "account_of": _view(wi.account_of, n, np.uint32),
                 "preimages": _view(wi.preimages, int(pre_off[-1]) if n else 0, np.uint8), "preimage_off": pre_off,
-                "nodes": _view(wi.nodes, wi.nodes_len, np.uint8),
+                "nodes": _view(wi.nodes, wi.nodes_len if wi.nodes else 0, np.uint8),
                 "node_off": _view(wi.node_off, wi.total_nodes + 1, np.uint64),
                 "proof_first_node": _view(wi.proof_first_node, n + 1, np.uint32)}
 
     def verify(self, ctx: Context | None = None):
-        """-> (status u8[n_proofs], n_failed).  Needs a GPU (no CPU fallback)."""
+        """-> (status u8[n_proofs], n_failed).  Needs a GPU (no CPU fallback).  An index-form witness whose proof
+        nodes turn out not to be hex raises WitnessFormatError here (the GPU is what reads them)."""
         ctx = ctx or default_context()
         n = self.info()["n_proofs"]
         status = np.zeros(max(n, 1), np.uint8)
         bad = C.c_uint32(0)
-        ctx.check(self._lib.phant_witness_verify(ctx.handle, self._h, status.ctypes.data_as(C.c_void_p), C.byref(bad)))
+        rc = self._lib.phant_witness_verify(ctx.handle, self._h, status.ctypes.data_as(C.c_void_p), C.byref(bad))
+        if rc == L.E_INVALID_ARG and self._keep is not None:
+            raise WitnessFormatError(self._lib.phant_last_error(ctx.handle).decode())
+        ctx.check(rc)
         return status[:n], int(bad.value)
 
     def close(self):
@@ -95,10 +114,11 @@ class ExecutionWitness:
             pass
 
 
-def new_payload_witness_ok(witness_json: str | bytes, ctx: Context | None = None) -> bool:
+def new_payload_witness_ok(witness_json: str | bytes, ctx: Context | None = None, on_gpu: bool = False) -> bool:
     """The check newPayloadV2Handler (execution_payload.zig:175-181) would make before
-    `blockchain.runBlock(block)`: every proof of the witness valid and consistent."""
-    w = ExecutionWitness.parse_json(witness_json)
+    `blockchain.runBlock(block)`: every proof of the witness valid and consistent.  on_gpu: index form, the nodes'
+    hex is decoded on the GPU."""
+    w = ExecutionWitness.index_json(witness_json) if on_gpu else ExecutionWitness.parse_json(witness_json)
     try:
         _, bad = w.verify(ctx)
         return bad == 0

@@ -61,6 +61,48 @@ int main(int argc, char** argv) {
                 return 6;
             }
         }
+        if ((it & 7) == 3) {
+            // the index form (proof nodes left as hex in the text, for the GPU to decode): whenever the full parser
+            // accepts, it accepts with the same arrays, and every node span it notes lies inside the text and decodes
+            // -- on the host here -- to the full parser's bytes; it may additionally accept documents whose only
+            // fault is a non-hex digit inside a proof node
+            phant::Witness w3;
+            std::string err3;
+            const bool indexed = phant::witness_index_json(s.data(), s.size(), (it & 8) ? 3u : 1u, w3, err3);
+            if (parsed && !indexed) {
+                std::fprintf(stderr, "index form rejects what the parser accepts at edit %d: %s\n", it, err3.c_str());
+                return 7;
+            }
+            if (indexed) {
+                if (w3.node_src.size() + 1 != w3.node_off.size() || w3.node_off.back() != w3.nodes_bytes || !w3.nodes.empty()) {
+                    std::fprintf(stderr, "inconsistent index-form witness at edit %d\n", it);
+                    return 8;
+                }
+                for (size_t k = 0; k < w3.node_src.size(); ++k) {
+                    const uint64_t n = w3.node_off[k + 1] - w3.node_off[k];
+                    if (w3.node_src[k] + 2 * n > s.size()) {
+                        std::fprintf(stderr, "node span outside the text at edit %d\n", it);
+                        return 9;
+                    }
+                }
+                if (parsed) {
+                    if (w3.node_off != w.node_off || w3.root_idx != w.root_idx || w3.proof_first_node != w.proof_first_node ||
+                        w3.preimages != w.preimages || w3.roots != w.roots) {
+                        std::fprintf(stderr, "index form disagrees with the parser at edit %d\n", it);
+                        return 10;
+                    }
+                    for (size_t k = 0; k < w3.node_src.size(); ++k)
+                        for (uint64_t j = 0; j < w3.node_off[k + 1] - w3.node_off[k]; ++j) {
+                            auto hv = [](char c) { return c <= '9' ? c - '0' : (c | 0x20) - 'a' + 10; };
+                            const char* h = s.data() + w3.node_src[k] + 2 * j;
+                            if ((uint8_t)((hv(h[0]) << 4) | hv(h[1])) != w.nodes[w3.node_off[k] + j]) {
+                                std::fprintf(stderr, "node %zu decodes differently at edit %d\n", k, it);
+                                return 11;
+                            }
+                        }
+                }
+            }
+        }
         if (parsed) {
             ++ok;
             // a parsed witness must be internally consistent

@@ -178,3 +178,31 @@ def test_threaded_parse_is_byte_identical(EA, oracle):
     for threads in (1, 4):
         with pytest.raises(EA.WitnessFormatError):
             EA.ExecutionWitness.parse_json(bad, threads=threads)
+
+
+def test_index_form_agrees_with_the_full_parse(EA, oracle):
+    """phant_witness_index_json (host part, no GPU): every array but the decoded nodes is the full parser's, for
+    one thread and several; the same malformed documents are rejected -- except digits that are not hex inside a
+    proof node, which only the GPU reads (tests/test_gpu_x_witness_index.py)."""
+    import json
+    doc, _, _ = block_witness_json(oracle, np.random.default_rng(21))
+    text = json.dumps(doc)
+    for threads in (1, 3):
+        a, b = EA.ExecutionWitness.parse_json(text, threads), EA.ExecutionWitness.index_json(text, threads)
+        ia, ib = a.info(), b.info()
+        for k, v in ia.items():
+            if k == "nodes":
+                assert ib[k].size == 0 and ia[k].size == ia["nodes_len"] == ib["nodes_len"]
+            elif hasattr(v, "shape"):
+                assert np.array_equal(v, ib[k]), k
+            else:
+                assert v == ib[k], k
+        a.close()
+        b.close()
+    for bad in (text[:-1], text.replace('"accountProof": [', '"accountProof": {', 1),
+                text.replace('"accountProof": ["0x', '"accountProof": ["0x0', 1),      # odd number of digits
+                text.replace('"address": "0x', '"address": "0y', 1)):
+        with pytest.raises(EA.WitnessFormatError):
+            EA.ExecutionWitness.index_json(bad)
+    ok = EA.ExecutionWitness.index_json(text.replace('"accountProof": ["0xf', '"accountProof": ["0xg', 1))
+    ok.close()  # (not hex, but that is for the GPU to say)

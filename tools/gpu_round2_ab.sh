@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 echo "== the GPU tests that have never run on hardware =="
-timeout 900 python -m pytest tests/test_gpu_x_verify_more.py tests/test_gpu_x_bulk.py tests/test_gpu_x_state_sharded.py -q --timeout 300 2>&1 | tail -12 | tee "$OUT/pytest_gpu_x.log"
+timeout 900 python -m pytest tests/test_gpu_x_verify_more.py tests/test_gpu_x_bulk.py tests/test_gpu_x_state_sharded.py tests/test_gpu_x_witness_index.py -q --timeout 300 2>&1 | tail -12 | tee "$OUT/pytest_gpu_x.log"
 echo "== smoke + the validated suite (kernels changed since: verify_one bound, host-form total_nodes) =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee "$OUT/smoke.log"
 timeout 1200 python -m pytest tests -m gpu -q --timeout 300 -k "not test_gpu_x" 2>&1 | tail -6 | tee "$OUT/pytest_gpu.log"
