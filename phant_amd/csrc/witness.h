@@ -2,10 +2,34 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace phant {
+
+// std::vector<uint8_t> whose resize() leaves new bytes uninitialised: the node blob is written exactly once, by the
+// hex decoder, and a zero-fill in front of that is a second pass over tens of megabytes
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U>
+    void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new (static_cast<void*>(p)) U;
+    }
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+};
+using ByteBlob = std::vector<uint8_t, DefaultInitAllocator<uint8_t>>;
 
 struct WitnessAccount {
     uint8_t address[20];
@@ -30,7 +54,7 @@ struct Witness {
     std::vector<uint32_t> account_of;       // per proof: index into accounts
     std::vector<uint8_t> preimages;         // 20-byte addresses / 32-byte slots, back to back
     std::vector<uint32_t> preimage_off;     // proofs + 1
-    std::vector<uint8_t> nodes;
+    ByteBlob nodes;
     std::vector<uint64_t> node_off;         // total_nodes + 1
     std::vector<uint32_t> proof_first_node; // proofs + 1
     std::vector<WitnessAccount> accounts;

@@ -24,6 +24,9 @@
 // Pure host code (no HIP calls): parsing is testable without a GPU.
 #include <cstdint>
 #include <cstddef>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstring>
 #include <string>
 #include <thread>
@@ -114,6 +117,16 @@ struct Parser {
             return true;
         }
     }
+    // the next string as a view; `is(lit)`: it is exactly that text (a name or value with escapes is none we know)
+    struct View {
+        const char *b = nullptr, *e = nullptr;
+        bool escaped = false;
+        bool is(const char* lit) const {
+            const size_t n = std::strlen(lit);
+            return !escaped && (size_t)(e - b) == n && std::memcmp(b, lit, n) == 0;
+        }
+    };
+    bool view(View& v) { return str_view(v.b, v.e, v.escaped); }
     bool skip_value() {
         ws();
         if (p >= end) return fail("unexpected end");
@@ -152,43 +165,44 @@ int hexval(char c) {
     return -1;
 }
 
-// hexutils.zig:22-37 prefixedhex2byteslice; `quantity` additionally accepts an odd number of digits
-// (left-padded with one zero nibble), as prefixedHexToInt does for integers
-bool hex_bytes(const std::string& s, bool quantity, std::vector<uint8_t>& out) {
-    out.clear();
-    size_t i = 0;
-    if (s.size() >= 2 && s[0] == '0' && (s[1] == 'x' || s[1] == 'X')) i = 2;
-    size_t n = s.size() - i;
-    if (n == 0) return true;
-    if (n == 1 && s[i] == '0') return true;  // "0x0": empty
+// hexutils.zig:22-37 prefixedhex2byteslice over the characters [b, e) of a JSON string; `quantity` additionally
+// accepts an odd number of digits (left-padded with one zero nibble), as prefixedHexToInt does for integers.
+// At most `cap` bytes are produced into `out` (more is an error); returns the byte count or -1.
+int hex_view(const char* b, const char* e, bool quantity, uint8_t* out, size_t cap) {
+    if (e - b >= 2 && b[0] == '0' && (b[1] == 'x' || b[1] == 'X')) b += 2;
+    size_t n = (size_t)(e - b);
+    if (n == 0) return 0;
+    if (n == 1 && b[0] == '0') return 0;  // "0x0": empty
+    size_t k = 0;
     if (n % 2) {
-        if (!quantity) return false;
-        const int v = hexval(s[i]);
-        if (v < 0) return false;
-        out.push_back((uint8_t)v);
-        ++i;
+        if (!quantity) return -1;
+        const int v = hexval(*b++);
+        if (v < 0 || cap == 0) return -1;
+        out[k++] = (uint8_t)v;
     }
-    for (; i + 1 < s.size(); i += 2) {
-        const int a = hexval(s[i]), b = hexval(s[i + 1]);
-        if (a < 0 || b < 0) return false;
-        out.push_back((uint8_t)(a << 4 | b));
+    for (; b + 1 < e; b += 2) {
+        const int hi = hexval(b[0]), lo = hexval(b[1]);
+        if (hi < 0 || lo < 0 || k == cap) return -1;
+        out[k++] = (uint8_t)(hi << 4 | lo);
     }
+    return (int)k;
+}
+
+bool hex_fixed(const char* b, const char* e, size_t want, uint8_t* dst) {
+    uint8_t tmp[32];
+    if (want > sizeof tmp || hex_view(b, e, false, tmp, want) != (int)want) return false;
+    std::memcpy(dst, tmp, want);
     return true;
 }
 
-bool hex_fixed(const std::string& s, size_t want, uint8_t* dst) {
-    std::vector<uint8_t> b;
-    if (!hex_bytes(s, false, b) || b.size() != want) return false;
-    std::memcpy(dst, b.data(), want);
-    return true;
-}
-
-// quantity or data of at most `width` bytes, right-aligned big-endian in `dst[width]`
-bool hex_padded(const std::string& s, size_t width, uint8_t* dst) {
-    std::vector<uint8_t> b;
-    if (!hex_bytes(s, true, b) || b.size() > width) return false;
+// quantity or data of at most `width` (<= 32) bytes, right-aligned big-endian in `dst[width]`
+bool hex_padded(const char* b, const char* e, size_t width, uint8_t* dst) {
+    uint8_t tmp[32];
+    if (width > sizeof tmp) return false;
+    const int n = hex_view(b, e, true, tmp, width);
+    if (n < 0) return false;
     std::memset(dst, 0, width);
-    if (!b.empty()) std::memcpy(dst + (width - b.size()), b.data(), b.size());
+    if (n) std::memcpy(dst + (width - (size_t)n), tmp, (size_t)n);
     return true;
 }
 
@@ -226,8 +240,36 @@ struct HexPairTable {
 };
 const HexPairTable HEX2;
 
+#if defined(__x86_64__)
+// 32 hex digits -> 16 bytes per step (AVX2, chosen at run time): digit = c - '0' if that is <= 9, else
+// (c | 0x20) - 'a' + 10 if that is 10..15, else invalid; pairs are folded with one multiply-add (16, 1).
+// Returns how many digits it consumed (a multiple of 32); `bad` is set when any was not a hex digit.
+__attribute__((target("avx2"))) size_t hex_decode_avx2(const char* b, size_t n, uint8_t* w, int& bad) {
+    const __m256i c0 = _mm256_set1_epi8('0'), ca = _mm256_set1_epi8('a'), k20 = _mm256_set1_epi8(0x20);
+    const __m256i k9 = _mm256_set1_epi8(9), k5 = _mm256_set1_epi8(5), k10 = _mm256_set1_epi8(10);
+    const __m256i weights = _mm256_set1_epi16(0x0110);  // (low byte 16, high byte 1): first digit is the high nibble
+    __m256i any_bad = _mm256_setzero_si256();
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(b + i));
+        const __m256i d = _mm256_sub_epi8(v, c0);                           // 0..9 for digits
+        const __m256i a = _mm256_sub_epi8(_mm256_or_si256(v, k20), ca);     // 0..5 for a-f / A-F
+        const __m256i d_ok = _mm256_cmpeq_epi8(_mm256_min_epu8(d, k9), d);
+        const __m256i a_ok = _mm256_cmpeq_epi8(_mm256_min_epu8(a, k5), a);
+        any_bad = _mm256_or_si256(any_bad, _mm256_andnot_si256(_mm256_or_si256(d_ok, a_ok), _mm256_set1_epi8(-1)));
+        const __m256i nib = _mm256_blendv_epi8(_mm256_add_epi8(a, k10), d, d_ok);
+        const __m256i pairs = _mm256_maddubs_epi16(nib, weights);           // 16 x u16, each one byte's value
+        const __m256i packed = _mm256_permute4x64_epi64(_mm256_packus_epi16(pairs, pairs), 0xD8);  // bytes 0..15 in the low lane
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(w + i / 2), _mm256_castsi256_si128(packed));
+    }
+    if (!_mm256_testz_si256(any_bad, any_bad)) bad = -1;
+    return i;
+}
+const bool HAVE_AVX2 = __builtin_cpu_supports("avx2");
+#endif
+
 // hex data (hexutils.zig:22-37: optional 0x, "0x0" / "" empty, even digit count) appended to `out`
-bool hex_append(const char* b, const char* e, std::vector<uint8_t>& out) {
+bool hex_append(const char* b, const char* e, ByteBlob& out) {
     if (e - b >= 2 && b[0] == '0' && (b[1] == 'x' || b[1] == 'X')) b += 2;
     const size_t n = (size_t)(e - b);
     if (n == 0 || (n == 1 && b[0] == '0')) return true;
@@ -236,7 +278,12 @@ bool hex_append(const char* b, const char* e, std::vector<uint8_t>& out) {
     out.resize(at + n / 2);
     uint8_t* w = out.data() + at;
     int bad = 0;
-    for (size_t i = 0; i < n; i += 2) {
+    size_t done = 0;
+#if defined(__x86_64__)
+    if (HAVE_AVX2) done = hex_decode_avx2(b, n, w, bad);
+    w += done / 2;
+#endif
+    for (size_t i = done; i < n; i += 2) {
         uint16_t pair;
         std::memcpy(&pair, b + i, 2);
         const int v = HEX2.v[pair];
@@ -291,20 +338,21 @@ bool parse_storage_entry(Parser& ps, Builder& b, uint32_t account) {
     static const uint8_t zero32[32] = {0};
     const size_t key_at = b.w.preimages.size();
     b.begin_proof(1u + account, account, zero32, 32);
-    std::string name, s;
+    Parser::View name, s;
     if (!ps.lit('}')) {
         for (;;) {
-            if (!ps.str(name) || !ps.expect(':')) return false;
-            if (name == "key") {
-                if (!ps.str(s)) return false;
-                if (!hex_padded(s, 32, b.w.preimages.data() + key_at))
+            if (!ps.view(name) || !ps.expect(':')) return false;
+            if (name.is("key")) {
+                if (!ps.view(s)) return false;
+                if (s.escaped || !hex_padded(s.b, s.e, 32, b.w.preimages.data() + key_at))
                     return ps.fail("storage key is not a hex quantity of at most 32 bytes");
                 have_key = true;
-            } else if (name == "value") {
-                if (!ps.str(s)) return false;
-                if (!hex_padded(s, 32, slot.value)) return ps.fail("storage value is not a hex quantity of at most 32 bytes");
+            } else if (name.is("value")) {
+                if (!ps.view(s)) return false;
+                if (s.escaped || !hex_padded(s.b, s.e, 32, slot.value))
+                    return ps.fail("storage value is not a hex quantity of at most 32 bytes");
                 slot.has_value = 1;
-            } else if (name == "proof") {
+            } else if (name.is("proof")) {
                 if (have_proof) return ps.fail("duplicate \"proof\"");
                 if (!parse_node_array(ps, b)) return false;
                 have_proof = true;
@@ -340,34 +388,35 @@ bool parse_account(Parser& ps, Builder& b) {
     bool have_addr = false, have_proof = false, have_storage = false;
     size_t addr_at = 0;            // where the account proof's 20-byte preimage sits, once the proof is in
     const char* storage_at = nullptr;  // "storageProof" met BEFORE "accountProof": parsed after the object
-    std::string name, s;
+    Parser::View name, s;
     if (!ps.lit('}')) {
         for (;;) {
-            if (!ps.str(name) || !ps.expect(':')) return false;
-            if (name == "address") {
-                if (!ps.str(s)) return false;
-                if (!hex_fixed(s, 20, acc.address)) return ps.fail("address is not 20 bytes of hex");
+            if (!ps.view(name) || !ps.expect(':')) return false;
+            if (name.is("address")) {
+                if (!ps.view(s)) return false;
+                if (s.escaped || !hex_fixed(s.b, s.e, 20, acc.address)) return ps.fail("address is not 20 bytes of hex");
                 have_addr = true;
-            } else if (name == "storageHash") {
-                if (!ps.str(s)) return false;
-                if (!hex_fixed(s, 32, acc.storage_hash)) return ps.fail("storageHash is not 32 bytes of hex");
+            } else if (name.is("storageHash")) {
+                if (!ps.view(s)) return false;
+                if (s.escaped || !hex_fixed(s.b, s.e, 32, acc.storage_hash)) return ps.fail("storageHash is not 32 bytes of hex");
                 acc.has_storage_hash = 1;
-            } else if (name == "codeHash") {
-                if (!ps.str(s)) return false;
-                if (!hex_fixed(s, 32, acc.code_hash)) return ps.fail("codeHash is not 32 bytes of hex");
+            } else if (name.is("codeHash")) {
+                if (!ps.view(s)) return false;
+                if (s.escaped || !hex_fixed(s.b, s.e, 32, acc.code_hash)) return ps.fail("codeHash is not 32 bytes of hex");
                 acc.has_code_hash = 1;
-            } else if (name == "nonce") {
-                if (!ps.str(s)) return false;
+            } else if (name.is("nonce")) {
+                if (!ps.view(s)) return false;
                 uint8_t n8[8];
-                if (!hex_padded(s, 8, n8)) return ps.fail("nonce is not a hex quantity of at most 8 bytes");
+                if (s.escaped || !hex_padded(s.b, s.e, 8, n8)) return ps.fail("nonce is not a hex quantity of at most 8 bytes");
                 acc.nonce = 0;
                 for (int i = 0; i < 8; ++i) acc.nonce = acc.nonce << 8 | n8[i];
                 acc.has_nonce = 1;
-            } else if (name == "balance") {
-                if (!ps.str(s)) return false;
-                if (!hex_padded(s, 32, acc.balance)) return ps.fail("balance is not a hex quantity of at most 32 bytes");
+            } else if (name.is("balance")) {
+                if (!ps.view(s)) return false;
+                if (s.escaped || !hex_padded(s.b, s.e, 32, acc.balance))
+                    return ps.fail("balance is not a hex quantity of at most 32 bytes");
                 acc.has_balance = 1;
-            } else if (name == "accountProof") {
+            } else if (name.is("accountProof")) {
                 if (have_proof) return ps.fail("duplicate \"accountProof\"");
                 // the account proof comes first in the output; its nodes are decoded straight into the blob,
                 // the address is filled in when it is met
@@ -378,7 +427,7 @@ bool parse_account(Parser& ps, Builder& b) {
                 if (!parse_node_array(ps, b)) return false;
                 b.end_proof();
                 have_proof = true;
-            } else if (name == "storageProof") {
+            } else if (name.is("storageProof")) {
                 if (have_storage) return ps.fail("duplicate \"storageProof\"");
                 have_storage = true;
                 if (have_proof) {
@@ -432,7 +481,7 @@ static bool parse_single(const char* json, size_t len, Witness& w, std::string& 
             if (!(ok = ps.str(name) && ps.expect(':'))) break;
             if (name == "stateRoot") {
                 if (!(ok = ps.str(s))) break;
-                if (!hex_fixed(s, 32, w.roots.data())) {
+                if (!hex_fixed(s.data(), s.data() + s.size(), 32, w.roots.data())) {
                     ok = ps.fail("stateRoot is not 32 bytes of hex");
                     break;
                 }
@@ -505,7 +554,7 @@ static bool parse_mt(const char* json, size_t len, unsigned threads, Witness& w,
             if (!(ok = ps.str(name) && ps.expect(':'))) break;
             if (name == "stateRoot") {
                 if (!(ok = ps.str(s))) break;
-                if (!hex_fixed(s, 32, state_root)) {
+                if (!hex_fixed(s.data(), s.data() + s.size(), 32, state_root)) {
                     ok = ps.fail("stateRoot is not 32 bytes of hex");
                     break;
                 }
