@@ -43,7 +43,8 @@ def _build(tmp_path):
 def test_device_code_on_host_matches_oracle_under_sanitizers(oracle, tmp_path):
     exe = _build(tmp_path)
     rng = np.random.default_rng(20250923)
-    proofs = adversarial_proofs(oracle, rng)
+    proofs = adversarial_proofs(oracle, rng, shapes=[(200, 32, 0), (120, 32, 6), (64, 2, 0), (50, 1, 0), (100, 40, 0),
+                                                     (80, 64, 8), (40, 80, 0), (1, 32, 0), (2, 48, 0)], garbage=2000)
     blob = bytearray(struct.pack("<I", len(proofs)))
     for root, key, nodes in proofs:
         blob += root + struct.pack("<I", len(key)) + key + struct.pack("<I", len(nodes))
