@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="config3: independent batches in flight, each on its own ctx + HIP stream (a validator "
                          "verifying consecutive witnesses); 1 = strictly one launch sequence after the other")
+    ap.add_argument("--messages", type=int, default=1 << 20, help="config2: 136-byte messages per GPU")
     ap.add_argument("--graph", action="store_true",
                     help="config3 / config4: replay each slot's kernel sequence as one hipGraph launch (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -347,7 +348,7 @@ def main():
         workload = (f"config5: consecutive witnesses of {args.stream_proofs} depth-{args.depth} proofs streamed from "
                     f"pinned host memory, {slots} in flight per GPU (H2D {hosts[0].h2d_bytes()} B per witness)")
     else:
-        n_units = 1 << 20
+        n_units = args.messages
         g = torch.Generator(device=dev)
         g.manual_seed(1 + rank)
         blob = torch.randint(0, 256, (n_units * 136,), dtype=torch.uint8, device=dev, generator=g)
@@ -359,7 +360,7 @@ def main():
 
         kernel_only = step
         metric, unit = "keccak256_136B_hashes_per_sec", "hashes/s"
-        workload = "config2: 1048576 x 136-byte Keccak-256 per GPU (2 Keccak-f per message, 168 B per message)"
+        workload = f"config2: {n_units} x 136-byte Keccak-256 per GPU (2 Keccak-f per message, 168 B per message)"
 
     def barrier():
         if world > 1:

@@ -121,6 +121,12 @@ def test_config4_dry_run():
     assert line["config"]["units_per_gpu_per_step"] == 1080
 
 
+def test_config2_dry_run():
+    line = _bench(["--workload", "config2", "--messages", "3000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
+    _check_contract(line, 2, 1)
+    assert line["metric"] == "keccak256_136B_hashes_per_sec" and line["config"]["units_per_gpu_per_step"] == 3000
+
+
 def test_nodeset_and_config5_dry_run():
     line = _bench(["--workload", "nodeset", "--proofs", "300", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
     _check_contract(line, 2, 1)
