@@ -22,9 +22,10 @@
 //        rate-block class with wave ballots + one block-level reservation per
 //        class (so every hashing wave runs the same number of permutations).
 //        Nodes without a representative are not opened here at all.
-//   hash_list_kernel  one lane per listed node, sponge in registers; while a
-//        532-byte node streams through the lane's registers its form is
-//        checked against the canonical full branch (canon[]).
+//   hash_chunk_kernel (hash_list_kernel: its persistent-grid form, used by the
+//        two-stream modes)  one lane per listed node, sponge in registers;
+//        while a 532-byte node streams through the lane's registers its form
+//        is checked against the canonical full branch (canon[]).
 //   link_kernel     one lane per node: does digest[rep[j]] equal the reference
 //        its parent (node j - 1 of the proof, a canonical full branch) holds
 //        for this key's nibble?  One status byte per node.
@@ -34,6 +35,12 @@
 //   fixup_kernel    proofs the walk could not settle from the tables (never
 //        in practice: a representative that is not self-represented) go
 //        through the one-lane-per-proof verifier.
+//
+// Modes (launch.h FlatMode): the sequence above on one stream (SERIAL), without the
+// deduplication (NODEDUP), with the comparison split off -- CLASSIFY trusts the
+// table, COMPARE checks it next to the hashing of the representatives -- on a
+// helper stream (OVERLAP) or as workgroups of the same grid as the hashing
+// (MIXED, hash_compare_kernel), or as two half batches a phase apart (PIPELINED).
 //
 // Soundness: rep[j] = r only if bytes(j) == bytes(r) (so keccak(j) ==
 // digest[r]) and digest[r] is only trusted when rep[r] == r (r was hashed);
