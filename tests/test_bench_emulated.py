@@ -85,7 +85,7 @@ def _check_contract(line, steps, warmup):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
 
 
-@pytest.mark.parametrize("mode,streams", [("flat", 3), ("flat", 1), ("fused", 2), ("pipelined", 2), ("mixed", 2)])
+@pytest.mark.parametrize("mode,streams", [("flat", 3), ("flat", 1), ("fused", 2), ("mixed", 2)])
 def test_config3_dry_run(mode, streams):
     line = _bench(["--proofs", "300", "--steps", "3", "--warmup", "1", "--verify-mode", mode, "--streams",
                    str(streams), "--cpu-seconds", "0.2"])
@@ -162,9 +162,8 @@ def _rank_main(rank, world, port, argv, q):
 @pytest.mark.parametrize("argv", [
     ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "3"],
     ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4"],
-    ["--gpus", "2", "--workload", "config4", "--block-scale", "0.02", "--steps", "2", "--warmup", "1", "--streams", "2"],
-    ["--gpus", "2", "--workload", "nodeset", "--proofs", "200", "--steps", "2", "--warmup", "1"],
-], ids=["config3", "config3-fewer-steps-than-slots", "config4", "nodeset"])
+    ["--gpus", "2", "--workload", "config4", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--streams", "2"],
+], ids=["config3", "config3-fewer-steps-than-slots", "config4"])
 def test_two_ranks_dry_run(argv):
     """The N > 1 path the driver launches with torchrun (never run on real GPUs this round): both ranks build their
     shard, agree on the state root, verify, all-reduce the verdict; rank 0 prints the one line."""

@@ -23,10 +23,12 @@ def test_results_do_not_depend_on_the_execution_order():
     runs = []
     # (seed, what fresh "device" memory holds, ...): a result must not depend on uninitialised workspace either
     for seed, fill, modules, expr in (
-            (3, "0x00", ["tests/test_emu_verify.py"], "(flat or overlap) and not streaming"),
-            (11, "0xff", ["tests/test_emu_verify.py"], "(pipelined or nodedup or fused) and not streaming and not depth8"),
-            (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_witness.py",
-                         "tests/test_emu_bulk.py"], None)):
+            (3, "0x00", ["tests/test_emu_verify.py"],
+             "(flat or overlap or mixed) and (random_tries or mutation or hostile_index_arrays_match or synthetic_block)"),
+            (11, "0xff", ["tests/test_emu_verify.py"],
+             "(pipelined or nodedup or fused) and (random_tries or mutation or non_monotone)"),
+            (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py"],
+             "not 20000 and not fixture_state")):
         cmd = [sys.executable, "-m", "pytest", *modules, "-x", "-q", "-p", "no:cacheprovider"]
         if expr:
             cmd += ["-k", expr]
