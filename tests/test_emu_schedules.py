@@ -27,7 +27,8 @@ def test_results_do_not_depend_on_the_execution_order():
              "(flat or overlap or mixed) and (random_tries or mutation or hostile_index_arrays_match or synthetic_block)"),
             (11, "0xff", ["tests/test_emu_verify.py"],
              "(pipelined or nodedup or fused) and (random_tries or mutation or non_monotone)"),
-            (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py"],
+            (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py",
+                         "tests/test_emu_witness.py"],
              "not 20000 and not fixture_state")):
         cmd = [sys.executable, "-m", "pytest", *modules, "-x", "-q", "-p", "no:cacheprovider"]
         if expr:
