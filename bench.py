@@ -477,6 +477,9 @@ def main():
                                 "node-set pipeline = dedup_kernel (class lists) + hash_chunk_kernel + "
                                 "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
                                 "mpt_verify_fused_kernel" if args.verify_mode == "fused" else
+                                "verify pipeline = plan_kernel + dedup_kernel (CLASSIFY) + hash_compare_kernel (hash and "
+                                "COMPARE workgroups in one grid) + hash_chunk_kernel (late list) + link_kernel + "
+                                "walk_proofs_kernel + mpt_verify_fixup_kernel" if args.verify_mode == "mixed" else
                                 "verify pipeline = plan_kernel + dedup_kernel + hash_chunk_kernel + link_kernel + "
                                 "walk_proofs_kernel + mpt_verify_fixup_kernel (one launch of the path, first "
                                 "kernel start to last kernel end; hash_chunk_kernel is ~50 % of it and is "
