@@ -19,10 +19,12 @@ OUT_DIR = os.path.join(ROOT, "tests", "native", "_build")
 
 def build(sanitize: bool = False) -> str:
     """-> path of libphant_emu[_san].so (rebuilt when a source is newer)."""
-    if not shutil.which("g++"):
-        raise RuntimeError("no g++")
+    cxx = os.environ.get("PHANT_EMU_CXX", "g++")  # (e.g. ROCm's clang++: a second opinion on the same sources)
+    if not shutil.which(cxx):
+        raise RuntimeError("no " + cxx)
     os.makedirs(OUT_DIR, exist_ok=True)
-    out = os.path.join(OUT_DIR, "libphant_emu_san.so" if sanitize else "libphant_emu.so")
+    tag = "" if cxx == "g++" else "_" + os.path.basename(cxx).replace("+", "x")
+    out = os.path.join(OUT_DIR, "libphant_emu" + tag + ("_san.so" if sanitize else ".so"))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "tests", "native", "hipemu_export.cpp"),
         os.path.join(ROOT, "include", "phant_gpu.h"), os.path.join(ROOT, "tests", "native", "shim", "hip", "hip_runtime.h")]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
@@ -36,17 +38,17 @@ def build(sanitize: bool = False) -> str:
         flags += ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
     procs = []
     for s in SOURCES + [os.path.join(ROOT, "tests", "native", "hipemu_export.cpp")]:
-        o = os.path.join(OUT_DIR, os.path.basename(s).split(".")[0] + ("_san.o" if sanitize else ".o"))
+        o = os.path.join(OUT_DIR, os.path.basename(s).split(".")[0] + tag + ("_san.o" if sanitize else ".o"))
         # (-O1, even with jump threading, tail merging, cross-jumping and block reordering off, already breaks
         # the call-site identity: tried, test_mutation_fuzz then disagrees with the oracle)
         opt = ["-O0"] if s.endswith(".hip") and s != "capi.hip" else ["-O1"] if sanitize else ["-O2"]
-        procs.append((s, o, subprocess.Popen(["g++", *flags, *opt, "-c", os.path.join(CSRC, s), "-o", o],
+        procs.append((s, o, subprocess.Popen([cxx, *flags, *opt, "-c", os.path.join(CSRC, s), "-o", o],
                                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, _, p in procs:
         log, _ = p.communicate()
         if p.returncode:
-            raise RuntimeError(f"g++ failed on {s}:\n{log[-4000:]}")
-    link = ["g++", "-shared", "-pthread", "-o", out + ".tmp", *[o for _, o, _ in procs]]
+            raise RuntimeError(f"{cxx} failed on {s}:\n{log[-4000:]}")
+    link = [cxx, "-shared", "-pthread", "-o", out + ".tmp", *[o for _, o, _ in procs]]
     if sanitize:
         link += ["-fsanitize=address,undefined"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
