@@ -511,6 +511,13 @@ static inline hipError_t hipMalloc(T** p, size_t bytes) {
         const char* e = std::getenv("HIPEMU_FILL");
         return e ? (int)(std::strtoul(e, nullptr, 0) & 0xff) : 0xA5;
     }();
+#if defined(__has_feature)
+#if __has_feature(memory_sanitizer)
+    (void)fill;  // MemorySanitizer build: leave the allocation uninitialised, that is what it tracks
+    *p = (T*)q;
+    return hipSuccess;
+#endif
+#endif
     std::memset(q, fill, sz);
     *p = (T*)q;
     return hipSuccess;
