@@ -86,5 +86,84 @@ int main(int argc, char** argv) {
         phant_ctx_destroy(ctx);
     }
     std::printf("msan: %llu proofs x 7 modes, checksum %llx\n", proofs, sum);
+
+    // ---- the trie hasher, the state root, the bulk Keccak users: synthetic inputs, every output USED ----
+    {
+        phant_ctx* ctx = nullptr;
+        phant_opts opts;
+        std::memset(&opts, 0, sizeof opts);
+        opts.struct_size = sizeof opts;
+        if (phant_ctx_create(&opts, &ctx) != PHANT_OK) return 4;
+        unsigned long long lcg = 0x2545F4914F6CDD1Dull;
+        auto rnd = [&]() { return (lcg = lcg * 6364136223846793005ull + 1442695040888963407ull) >> 33; };
+        const uint32_t n = 3000;
+        std::vector<uint8_t> keys((size_t)n * 32), vals;
+        std::vector<uint32_t> key_off(n + 1, 0);
+        std::vector<uint64_t> val_off(n + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) {
+            const unsigned long long head = (unsigned long long)(i + 1) * ((1ull << 40) + 12345ull);  // strictly increasing
+            for (int b = 0; b < 8; ++b) keys[(size_t)i * 32 + b] = (uint8_t)(head >> (56 - 8 * b));
+            for (int b = 8; b < 32; ++b) keys[(size_t)i * 32 + b] = (uint8_t)rnd();
+            const uint32_t vl = 1 + (uint32_t)(rnd() % 90);
+            for (uint32_t b = 0; b < vl; ++b) vals.push_back((uint8_t)rnd());
+            key_off[i + 1] = 32 * (i + 1);
+            val_off[i + 1] = vals.size();
+        }
+        uint8_t root[32];
+        unsigned long long acc = 0;
+        auto use = [&](const uint8_t* p, size_t len) { for (size_t i = 0; i < len; ++i) acc = acc * 131 + p[i]; };
+        if (phant_mpt_root(ctx, keys.data(), key_off.data(), vals.data(), val_off.data(), n, root) != PHANT_OK) return 6;
+        use(root, 32);
+        if (phant_index_root_rlp(ctx, vals.data(), val_off.data(), 700, root) != PHANT_OK) return 6;
+        use(root, 32);
+        if (phant_index_root_be32(ctx, vals.data(), val_off.data(), 700, root) != PHANT_OK) return 6;
+        use(root, 32);
+        // 16 sub-tries by top nibble with their root nodes
+        std::vector<uint32_t> seg_first{0};
+        for (uint32_t i = 1; i < n; ++i)
+            if ((keys[(size_t)i * 32] >> 4) != (keys[(size_t)(i - 1) * 32] >> 4)) seg_first.push_back(i);
+        seg_first.push_back(n);
+        const uint32_t nt = (uint32_t)seg_first.size() - 1;
+        std::vector<uint8_t> roots((size_t)nt * 32), enc((size_t)nt * 600);
+        std::vector<uint32_t> enc_len(nt);
+        if (phant_mpt_root_nodes(ctx, keys.data(), key_off.data(), vals.data(), val_off.data(), n, seg_first.data(), nt, roots.data(),
+                                 enc.data(), 600, enc_len.data()) != PHANT_OK)
+            return 6;
+        use(roots.data(), roots.size());
+        for (uint32_t t = 0; t < nt; ++t) use(enc.data() + (size_t)t * 600, enc_len[t] <= 600 ? enc_len[t] : 0);
+        // a state: 400 accounts, some with code and storage
+        const uint32_t na = 400;
+        std::vector<uint8_t> addrs((size_t)na * 20), bal((size_t)na * 32, 0), code, sk, sv;
+        std::vector<uint64_t> nonces(na), code_off(na + 1, 0);
+        std::vector<uint32_t> slot_first(na + 1, 0);
+        for (uint32_t a = 0; a < na; ++a) {
+            for (int b = 0; b < 20; ++b) addrs[(size_t)a * 20 + b] = (uint8_t)rnd();
+            nonces[a] = rnd() % 1000;
+            for (int b = 20; b < 32; ++b) bal[(size_t)a * 32 + b] = (uint8_t)rnd();
+            for (uint32_t b = 0, cl = (uint32_t)(rnd() % 3 ? 0 : rnd() % 200); b < cl; ++b) code.push_back((uint8_t)rnd());
+            code_off[a + 1] = code.size();
+            for (uint32_t s2 = 0, ns = (uint32_t)(rnd() % 5); s2 < ns; ++s2) {
+                for (int b = 0; b < 32; ++b) sk.push_back((uint8_t)rnd());
+                for (int b = 0; b < 32; ++b) sv.push_back(b < 24 || (rnd() % 4 == 0) ? 0 : (uint8_t)rnd());
+            }
+            slot_first[a + 1] = (uint32_t)(sk.size() / 32);
+        }
+        uint8_t one = 0;
+        if (phant_state_root(ctx, addrs.data(), nonces.data(), bal.data(), code.empty() ? &one : code.data(), code_off.data(),
+                             sk.empty() ? &one : sk.data(), sv.empty() ? &one : sv.data(), slot_first.data(), na, root) != PHANT_OK)
+            return 6;
+        use(root, 32);
+        // blooms and addresses
+        std::vector<uint8_t> blooms(64 * 256), a20((size_t)na * 20), pk((size_t)na * 64);
+        for (auto& x : pk) x = (uint8_t)rnd();
+        std::vector<uint32_t> owner(700);
+        for (auto& x : owner) x = (uint32_t)(rnd() % 64);
+        if (phant_logs_bloom(ctx, vals.data(), val_off.data(), owner.data(), 700, 64, blooms.data()) != PHANT_OK) return 6;
+        use(blooms.data(), blooms.size());
+        if (phant_sender_addresses(ctx, pk.data(), 64, na, a20.data()) != PHANT_OK) return 6;
+        use(a20.data(), a20.size());
+        phant_ctx_destroy(ctx);
+        std::printf("msan: trie / index roots / root nodes / state root / blooms / addresses, checksum %llx\n", acc);
+    }
     return 0;
 }

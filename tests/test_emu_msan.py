@@ -49,3 +49,4 @@ def test_batch_verification_under_memory_sanitizer(oracle, tmp_path):
     path.write_bytes(bytes(blob))
     r = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=850)
     assert r.returncode == 0 and ("%d proofs x 7 modes" % len(proofs)) in r.stdout, (r.stdout + r.stderr)[-4000:]
+    assert "trie / index roots / root nodes / state root / blooms / addresses" in r.stdout, r.stdout  # second phase
