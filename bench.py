@@ -25,9 +25,13 @@ N > 1: one process per GPU (torchrun), proofs sharded by the top key nibble,
 every rank verifies its own P proofs (weak scaling); the only data-path
 collective is the all-reduce of the per-root failure count (RCCL).  value =
 proofs of ALL ranks / max-over-ranks time.  --streams S (default 4) keeps S independent launch
-sequences in flight per GPU, each on its own ctx + HIP stream (a validator verifying consecutive
-witnesses): every step is still a full pass over the full batch; `single_stream` in the JSON line is the
-same K steps strictly one after the other, and `roofline.achieved` always refers to ONE launch.
+sequences in flight per GPU, each on its own ctx + HIP stream and each over a DIFFERENT witness (other seed: a
+validator verifying consecutive witnesses; no step re-reads the bytes the previous step on its slot left in
+L2 / Infinity Cache): every step is still a full pass over a full batch; `single_stream` in the JSON line is
+the same number of passes strictly one after the other (alternating witnesses), and `roofline.achieved` always
+refers to ONE launch.  A timed "step" is repeated --inner times back to back (default 20) so that the timed
+region is >= 100 ms; all per-step figures are per single pass.  The config-3 line also carries `strong`: the
+config-4 block witness split over the same N GPUs (strong scaling), measured right after.
 
 Prints ONE JSON line (rank 0) with `roofline` (HBM; algorithmic bytes per
 launch / average kernel duration measured with HIP events on the launch
@@ -77,11 +81,14 @@ def parse():
     ap.add_argument("--block-scale", type=float, default=1.0, help="config4: size of the block relative to 10k tx")
     ap.add_argument("--stream-proofs", type=int, default=20_000, help="proofs per streamed witness (config5)")
     ap.add_argument("--stream-slots", type=int, default=3, help="witnesses in flight (config5)")
-    ap.add_argument("--verify-mode", default="flat", choices=["flat", "pipelined", "overlap", "nodedup", "fused", "mixed"],
-                    help="flat = node-parallel pipeline with in-batch node dedup (default); overlap = the same with "
-                         "the byte comparison on a helper stream next to the hashing; nodedup = same pipeline "
-                         "hashing every shipped node (A/B); fused = one lane per proof (A/B); mixed = hash and COMPARE "
-                         "workgroups interleaved in one grid (A/B, unmeasured)")
+    ap.add_argument("--verify-mode", default="flat", choices=["flat", "nodedup", "fused"],
+                    help="flat = the two-tier pipeline (default: shallow trie levels deduplicated, deep ones hashed "
+                         "in place); nodedup = every shipped node hashed (A/B); fused = one lane per proof (A/B)")
+    ap.add_argument("--dedup-levels", type=int, default=None,
+                    help="flat: trie levels deduplicated (default: chosen from the batch size)")
+    ap.add_argument("--inner", type=int, default=20,
+                    help="config3 / config4: back-to-back passes per timed step (timed region >= 100 ms)")
+    ap.add_argument("--no-strong", action="store_true", help="config3: skip the config-4 strong-scaling object")
     ap.add_argument("--streams", type=int, default=4,
                     help="config3: independent batches in flight, each on its own ctx + HIP stream (a validator "
                          "verifying consecutive witnesses); 1 = strictly one launch sequence after the other")
@@ -211,6 +218,121 @@ def cpu_baseline_config2(blob, n, target_seconds):
             "host_cpus": os.cpu_count()}
 
 
+def mk_ctx(args, local_rank, graph=False, use_torch_stream=True):
+    import phant_amd
+    return phant_amd.Context(local_rank, use_torch_stream=use_torch_stream, verify_fused=(args.verify_mode == "fused"),
+                             verify_nodedup=(args.verify_mode == "nodedup"), verify_graph=graph,
+                             dedup_levels=(args.dedup_levels if args.verify_mode == "flat" else None))
+
+
+def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank, world, rank, ctx):
+    """A resident proof batch verified + reduced to the per-root verdict, S launch sequences in flight, slot k on its
+    own HIP stream / ctx (workspace) / status + verdict buffers and over its OWN witness (seed base + k: no pass
+    re-reads what the previous pass on its slot left in L2 / Infinity Cache).  -> dict of measurements."""
+    import torch
+    import torch.distributed as dist
+    from phant_amd import mpt as M
+
+    n_wit = max(S, 2)
+    wits = [make_witness(k) for k in range(n_wit)]
+    w0 = wits[0]
+    n_units = w0.batch.n
+    for w in wits:
+        assert w.batch.n == n_units and w.batch.n_roots == w0.batch.n_roots
+    # --graph (A/B, off by default): every slot's kernel sequence is replayed as one hipGraph launch
+    # (PHANT_CTX_VERIFY_GRAPH); the legacy default stream cannot be captured, so then slot 0 gets a stream and a ctx
+    # of its own as well (`ctx`, on torch's stream, built the witnesses and does the kernel timing below)
+    slots = []
+    torch.cuda.synchronize()
+    for k in range(S):
+        if k == 0 and not args.graph:
+            st_, c_ = torch.cuda.current_stream(dev), ctx
+        else:
+            st_ = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st_):
+                c_ = mk_ctx(args, local_rank, graph=args.graph)
+        slots.append((st_, c_, torch.empty(n_units, dtype=torch.uint8, device=dev),
+                      torch.zeros(w0.batch.n_roots, dtype=torch.int32, device=dev), wits[k]))
+    turn = {"k": 0}
+
+    def one_pass():
+        st_, c_, status_, fails_, w_ = slots[turn["k"] % S]
+        turn["k"] += 1
+        with torch.cuda.stream(st_):
+            M.verify_batch_dev(w_.batch, status=status_, ctx=c_, fail_count=fails_)  # statuses + per-root verdict
+            if world > 1:
+                dist.all_reduce(fails_)  # one pass/fail word per root, over xGMI (RCCL)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    # setup, not warm-up: every slot's ctx allocates its device workspace on its first call (hipMalloc synchronises
+    # the device); keep that out of the W warm-up steps and the K timed steps
+    for _ in range(S):
+        one_pass()
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps * inner):
+        one_pass()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    # correctness of what was timed
+    exp_fail = torch.tensor([0], dtype=torch.int32, device=dev)
+    for _, _, status_, fails_, w_ in slots:
+        assert torch.equal(status_, w_.expected), "verify statuses differ from the constructed expectation"
+        want = torch.tensor([w_.n_invalid], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(want)
+        assert int(fails_.sum().item()) == int(want.item()), (int(fails_.sum().item()), int(want.item()))
+    del exp_fail
+
+    # the same number of passes strictly one after the other on ONE stream, alternating between two witnesses
+    barrier()
+    st0, c0, status0, fails0, _ = slots[0]
+    t1 = time.perf_counter()
+    with torch.cuda.stream(st0):
+        for k in range(steps * inner):
+            M.verify_batch_dev(wits[k % n_wit].batch, status=status0, ctx=c0, fail_count=fails0)
+            if world > 1:
+                dist.all_reduce(fails0)
+    barrier()
+    e1 = max_over_ranks(time.perf_counter() - t1)
+
+    # device time of ONE launch of the path (all kernels of the pipeline, first start to last end): HIP events on the
+    # launch stream (phant_timing), alternating witnesses
+    dstatus = torch.empty(n_units, dtype=torch.uint8, device=dev)
+    ctx.timing(True)
+    kms = []
+    for k in range(max(10, min(steps * inner, 60))):
+        M.verify_batch_dev(wits[k % n_wit].batch, status=dstatus, ctx=ctx)
+        kms.append(ctx.last_kernel_ms())
+    ctx.timing(False)
+    hashed = ctx.verify_stats() if args.verify_mode != "fused" else None
+    passes = steps * inner
+    out = {"wits": wits, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
+           "value": n_units * world * passes / elapsed,
+           "single": {"value": n_units * world * passes / e1, "ms_per_step": e1 / passes * 1e3},
+           "k_avg_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed,
+           "graph": [c_.graph_stats() for _, c_, _, _, _ in slots] if args.graph else False}
+    for k, (st_, c_, _, _, _) in enumerate(slots):
+        if c_ is not ctx:
+            c_.close()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -233,69 +355,84 @@ def main():
     from phant_amd import mpt as M
     from phant_amd.crypto import hasher as H
 
-    # bound to torch's current stream on this device
-    ctx = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"),
-                            verify_nodedup=(args.verify_mode == "nodedup"),
-                            verify_overlap=(args.verify_mode == "overlap"),
-                            verify_pipelined=(args.verify_mode == "pipelined"), verify_mixed=(args.verify_mode == "mixed"))
+    ctx = mk_ctx(args, local_rank)  # bound to torch's current stream on this device
 
     proofs_like = args.workload in ("config3", "config4")  # a resident proof batch, verified + per-root verdict
+    streamed = args.workload == "config5"
+    single = None
+    extra = {}
+    strong = None
+    S = 1
+    inner = 1
+    graph_stats = False
     if proofs_like:
-        if args.workload == "config3":
-            w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
-                                                  world=world, ctx=ctx)
-        else:
-            w = phant_amd.witness.block_witness(scale=args.block_scale, seed=4, device=dev, rank=rank, world=world,
-                                                ctx=ctx)
-        b = w.batch
-        n_units = b.n
-        alg_bytes = b.algorithmic_bytes()
-        status = torch.empty(n_units, dtype=torch.uint8, device=dev)
-        fails = torch.zeros(b.n_roots, dtype=torch.int32, device=dev)
-        # S launch sequences in flight: step k runs on slot k mod S = its own HIP stream, ctx (workspace), status
-        # and verdict buffers.  Every step is a full pass over the full batch; what overlaps is one step's
-        # latency-bound plan / link / walk kernels with another step's VALU-bound hash kernel.
         S = max(1, min(args.streams, 8))
-        # --graph (A/B, off by default): every slot's kernel sequence is replayed as one hipGraph launch
-        # (PHANT_CTX_VERIFY_GRAPH); the legacy default stream cannot be captured, so then slot 0 gets a stream
-        # and a ctx of its own as well (`ctx`, on torch's stream, built the witness and does the timing below)
-        slots = [] if args.graph else [(torch.cuda.current_stream(dev), ctx, status, fails)]
-        torch.cuda.synchronize()
-        while len(slots) < S:
-            st_ = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(st_):
-                c_ = phant_amd.Context(local_rank, verify_fused=(args.verify_mode == "fused"),
-                                       verify_nodedup=(args.verify_mode == "nodedup"),
-                                       verify_overlap=(args.verify_mode == "overlap"),
-                                       verify_pipelined=(args.verify_mode == "pipelined"), verify_mixed=(args.verify_mode == "mixed"),
-                                       verify_graph=args.graph)
-            slots.append((st_, c_, torch.empty_like(status), torch.zeros_like(fails)))
-        turn = {"k": 0}
+        inner = max(1, args.inner)
 
-        def step():
-            st_, c_, status_, fails_ = slots[turn["k"] % S]
-            turn["k"] += 1
-            with torch.cuda.stream(st_):
-                M.verify_batch_dev(b, status=status_, ctx=c_, fail_count=fails_)  # statuses + per-root verdict
-                if world > 1:
-                    dist.all_reduce(fails_)  # one pass/fail word per root, over xGMI (RCCL)
+        def mk3(k):
+            return phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2 + k, device=dev, rank=rank,
+                                                     world=world, ctx=ctx)
 
-        def kernel_only():
-            M.verify_batch_dev(b, status=status, ctx=ctx)
+        def mk4(k):
+            return phant_amd.witness.block_witness(scale=args.block_scale, seed=4 + k, device=dev, rank=rank, world=world,
+                                                   ctx=ctx)
 
+        r = run_proof_bench(args, mk3 if args.workload == "config3" else mk4, S, args.steps, args.warmup, inner, dev,
+                            local_rank, world, rank, ctx)
+        w = r["wits"][0]
+        b = w.batch
+        n_units, elapsed, value, single, k_avg_ms = r["n_units"], r["elapsed"], r["value"], r["single"], r["k_avg_ms"]
+        graph_stats = r["graph"]
+        alg_bytes = b.algorithmic_bytes()
+        ms_per_step = r["ms_per_pass"]
         if args.workload == "config3":
             metric, unit = "mpt_proofs_verified_per_sec_depth%d" % args.depth, "proofs/s"
             workload = (f"config3: {args.proofs} synthetic depth-{args.depth} account proofs per GPU against one "
                         f"state root ({w.nodes_per_proof - 1} x 532 B full branches + 112 B leaf, "
                         f"{w.bytes_per_proof} B and {w.perms_per_proof} Keccak-f per proof, 1% corrupted/exclusion, "
-                        f"no cross-proof dedup)")
+                        f"no cross-proof dedup); every launch sequence in flight verifies its own witness (seeds 2.."
+                        f"{1 + max(S, 2)}: distinct data per slot), {inner} back-to-back passes per timed step")
         else:
             metric, unit = "mpt_proofs_verified_per_sec_block_witness", "proofs/s"
             workload = (f"config4: one synthetic {int(10000 * args.block_scale)}-tx block witness sharded over "
                         f"{world} GPU(s): {n_units} account + storage proofs on this rank against {b.n_roots} roots "
                         f"(state root + per-contract storage roots; depth 8 / 3 / 5 / 7 classes, "
                         f"{w.nodes_per_proof:.2f} nodes, {w.bytes_per_proof:.0f} B and {w.perms_per_proof:.1f} "
-                        f"Keccak-f per proof on average, 1% corrupted/exclusion)")
+                        f"Keccak-f per proof on average, 1% corrupted/exclusion); distinct witness per slot, "
+                        f"{inner} back-to-back passes per timed step")
+        if r["hashed"] is not None:
+            hashed = r["hashed"]
+            kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
+            # the second roofline of this path: Keccak-f is integer-VALU-bound.  Peak = what the product's round
+            # function sustains with nothing but permutations on the chip (tools/ubench/keccak_rate.hip,
+            # profiles/r1i/keccak_rate_ubench.txt: 10.3 G perm/s at 6 waves/SIMD)
+            extra = {"nodes_shipped": int(b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed)), "keccak_f_run": kf,
+                     "keccak_f_if_every_node_hashed": int(round(w.perms_per_proof * n_units)),
+                     "valu": {"bound": "valu", "achieved": kf / (k_avg_ms * 1e-3) / 1e9, "peak": 10.3,
+                              "unit": "G Keccak-f/s", "frac": kf / (k_avg_ms * 1e-3) / 1e9 / 10.3,
+                              "note": "permutations actually run / whole-pipeline time of one launch"}}
+        if args.workload == "config3" and not args.no_strong and args.verify_mode != "fused":
+            # BASELINE config 4 next to it: ONE block witness split over the same N GPUs (strong scaling): accounts by
+            # top key nibble, contracts dealt out whole, one all-reduce of the per-root verdicts per pass
+            del r
+            torch.cuda.synchronize()
+            r4 = run_proof_bench(args, mk4, S, max(2, args.steps // 2), 1, inner, dev, local_rank, world, rank, ctx)
+            w4 = r4["wits"][0]
+            tot = torch.tensor([r4["n_units"]], dtype=torch.int64, device=dev)
+            if world > 1:
+                dist.all_reduce(tot)
+            total_proofs = int(tot.item())
+            strong = {"workload": f"config4: one synthetic {int(10000 * args.block_scale)}-tx block witness "
+                                  f"({total_proofs} account + storage proofs, {w4.batch.n_roots} roots) split over "
+                                  f"{world} GPU(s)", "scaling": "strong", "metric": "mpt_proofs_verified_per_sec_block_witness",
+                      "value": total_proofs * r4["passes"] / r4["elapsed"], "unit": "proofs/s",
+                      "ms_per_step": r4["ms_per_pass"], "proofs_on_rank0": r4["n_units"],
+                      "single_stream": {"value": total_proofs * r4["passes"] / (r4["single"]["ms_per_step"] * 1e-3 * r4["passes"]),
+                                        "ms_per_step": r4["single"]["ms_per_step"]},
+                      "kernel_avg_ms": r4["k_avg_ms"],
+                      "roofline_frac": w4.batch.algorithmic_bytes() / (r4["k_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "nodes_hashed": int(sum(r4["hashed"])), "nodes_shipped": int(w4.batch.node_off.numel() - 1)}
+            del r4
     elif args.workload == "nodeset":
         w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
                                               world=world, ctx=ctx, corrupt_frac=0.0)
@@ -367,105 +504,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    streamed = args.workload == "config5"
-    if proofs_like and S > 1:
-        # setup, not warm-up: every slot's ctx allocates its device workspace on its first call (hipMalloc
-        # synchronises the device); keep that out of the W warm-up steps and the K timed steps
-        for st_, c_, status_, fails_ in slots:
-            with torch.cuda.stream(st_):
-                M.verify_batch_dev(b, status=status_, ctx=c_, fail_count=fails_)
-                if world > 1:  # (a slot that K + W < S never reaches still ends with the all-rank verdict)
-                    dist.all_reduce(fails_)
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    if streamed:
-        drain()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if streamed:
-        drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # correctness of what was timed
-    if args.workload == "nodeset":
-        assert bool((status == 1).all()) and int(fails.item()) == 0, "node-set statuses differ from the expectation"
-    single = None
-    if proofs_like:
-        exp_fail = torch.tensor([w.n_invalid], dtype=torch.int32, device=dev)
+    if not proofs_like:
+        for _ in range(args.warmup):
+            step()
+        if streamed:
+            drain()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if streamed:
+            drain()
+        barrier()
+        elapsed = time.perf_counter() - t0
         if world > 1:
-            dist.all_reduce(exp_fail)
-        for _, _, status_, fails_ in slots:
-            assert torch.equal(status_, w.expected), "verify statuses differ from the constructed expectation"
-            assert int(fails_.sum().item()) == int(exp_fail.item()), (int(fails_.sum().item()), int(exp_fail.item()))
-        if S > 1:  # the same K steps strictly one after the other, for the record
-            barrier()
-            t1 = time.perf_counter()
-            st0, c0, status0, fails0 = slots[0]
-            with torch.cuda.stream(st0):
-                for _ in range(args.steps):
-                    M.verify_batch_dev(b, status=status0, ctx=c0, fail_count=fails0)
-                    if world > 1:
-                        dist.all_reduce(fails0)
-            barrier()
-            e1 = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([e1], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                e1 = float(t.item())
-            single = {"value": n_units * world * args.steps / e1, "ms_per_step": e1 / args.steps * 1e3}
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        value = n_units * world * args.steps / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
 
-    if streamed:
-        for x, h in zip(wl, hosts):
-            assert torch.equal(h.status, x.expected.cpu()), "streamed statuses differ from the expectation"
-        # the kernels of one witness, device-resident, for the roofline object (the streamed rate itself is
-        # bounded by PCIe: see the pcie object)
-        dstatus = torch.empty(n_units, dtype=torch.uint8, device=dev)
+        # correctness of what was timed
+        if args.workload == "nodeset":
+            assert bool((status == 1).all()) and int(fails.item()) == 0, "node-set statuses differ from the expectation"
+        if streamed:
+            for x, h in zip(wl, hosts):
+                assert torch.equal(h.status, x.expected.cpu()), "streamed statuses differ from the expectation"
+            # the kernels of one witness, device-resident, for the roofline object (the streamed rate itself is
+            # bounded by PCIe: see the pcie object)
+            dstatus = torch.empty(n_units, dtype=torch.uint8, device=dev)
 
-        def kernel_only():
-            M.verify_batch_dev(wl[0].batch, status=dstatus, ctx=ctx)
+            def kernel_only():
+                M.verify_batch_dev(wl[0].batch, status=dstatus, ctx=ctx)
 
-    # device time of one launch of the path (all kernels of the verify pipeline / the sponge kernel),
-    # HIP events on the launch stream (phant_timing)
-    ctx.timing(True)
-    kms = []
-    for _ in range(max(5, min(args.steps, 50))):
-        kernel_only()
-        kms.append(ctx.last_kernel_ms())
-    ctx.timing(False)
-    k_avg_ms = sum(kms) / len(kms)
+        # device time of one launch of the path (all kernels of the verify pipeline / the sponge kernel),
+        # HIP events on the launch stream (phant_timing)
+        ctx.timing(True)
+        kms = []
+        for _ in range(max(5, min(args.steps, 50))):
+            kernel_only()
+            kms.append(ctx.last_kernel_ms())
+        ctx.timing(False)
+        k_avg_ms = sum(kms) / len(kms)
+        if streamed and args.verify_mode != "fused":
+            hashed = ctx.verify_stats()
+            extra = {"nodes_shipped": int(b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed))}
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
-    extra = {}
-    if args.workload in ("config3", "config4", "config5") and args.verify_mode != "fused":
-        hashed = ctx.verify_stats()
-        shipped = int(b.node_off.numel() - 1)
-        kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
-        # the second roofline of this path: Keccak-f is integer-VALU-bound.  Peak = what the product's round
-        # function sustains with nothing but permutations on the chip (tools/ubench/keccak_rate.hip,
-        # profiles/r1i/keccak_rate_ubench.txt: 10.3 G perm/s at 6 waves/SIMD, 9.7 G at the 3 this kernel fits)
-        extra = {"nodes_shipped": shipped, "nodes_hashed": int(sum(hashed)), "keccak_f_run": kf,
-                 "keccak_f_if_every_node_hashed": int(w.perms_per_proof * n_units),
-                 "valu": {"bound": "valu", "achieved": kf / (k_avg_ms * 1e-3) / 1e9, "peak": 10.3,
-                          "unit": "G Keccak-f/s", "frac": kf / (k_avg_ms * 1e-3) / 1e9 / 10.3,
-                          "note": "permutations actually run / whole-pipeline time; the hash kernel alone "
-                                  "runs them in ~55 % of that time"}}
 
-    value = n_units * world * args.steps / elapsed
+    pipeline = ("two-tier verify pipeline = hash_deep_kernel (in-place hashing of the deep levels, helper stream) next to "
+                "plan_kernel + dedup_kernel + hash_list_kernel (deduplicated shallow levels), then link_kernel + "
+                "walk_kernel (one launch of the path, first kernel start to last kernel end; the hash kernels are "
+                "integer-VALU-bound, see roofline.valu)")
     line = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong" if args.workload == "config4" else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}",
                    "verify_mode": args.verify_mode if proofs_like else None,
-                   "streams": (S if proofs_like else 1),
-                   "graph": ([c_.graph_stats() for _, c_, _, _ in slots] if proofs_like and args.graph else False)},
+                   "dedup_levels": (args.dedup_levels if proofs_like else None),
+                   "streams": (S if proofs_like else 1), "passes_per_timed_step": inner,
+                   "timed_region_ms": (ms_per_step * args.steps * inner if proofs_like else ms_per_step * args.steps),
+                   "graph": graph_stats},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "throughput_GBps": value / world * alg_bytes / n_units / 1e9,  # algorithmic bytes x the measured
@@ -474,20 +573,15 @@ def main():
                                                         if args.workload == "config3" else None)) else None),
                      "traffic_detail": tr,
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
-                                "node-set pipeline = dedup_kernel (class lists) + hash_chunk_kernel + "
+                                "node-set pipeline = dedup_kernel (class lists) + hash_list_kernel + "
                                 "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
-                                "mpt_verify_fused_kernel" if args.verify_mode == "fused" else
-                                "verify pipeline = plan_kernel + dedup_kernel (CLASSIFY) + hash_compare_kernel (hash and "
-                                "COMPARE workgroups in one grid) + hash_chunk_kernel (late list) + link_kernel + "
-                                "walk_proofs_kernel + mpt_verify_fixup_kernel" if args.verify_mode == "mixed" else
-                                "verify pipeline = plan_kernel + dedup_kernel + hash_chunk_kernel + link_kernel + "
-                                "walk_proofs_kernel + mpt_verify_fixup_kernel (one launch of the path, first "
-                                "kernel start to last kernel end; hash_chunk_kernel is ~50 % of it and is "
-                                "integer-VALU-bound, see roofline.valu)"),
+                                "mpt_verify_fused_kernel" if args.verify_mode == "fused" else pipeline),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
     if single is not None:
         line["single_stream"] = single
+    if strong is not None:
+        line["strong"] = strong
     if streamed:
         h2d = hosts[0].h2d_bytes() * world * args.steps / elapsed / 1e9
         line["pcie"] = {"h2d_GBps_all_gpus": h2d, "h2d_GBps_per_gpu": h2d / world, "peak_per_gpu": 63.0,

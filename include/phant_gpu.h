@@ -79,23 +79,21 @@ typedef struct phant_ctx phant_ctx;
 
 #define PHANT_CTX_OWN_STREAM 1u   /* flags: ignore `stream`, create a private non-blocking stream */
 #define PHANT_CTX_VERIFY_FUSED 2u /* flags: verify with the one-lane-per-proof kernel instead of the
-                                     node-parallel pipeline (A/B and debugging) */
-#define PHANT_CTX_VERIFY_NODEDUP 4u /* flags: node-parallel pipeline, but hash every shipped node even
-                                       when the batch carries byte-identical copies (A/B) */
-#define PHANT_CTX_VERIFY_PIPELINED 16u /* flags: node-parallel pipeline over two half batches, the second a
-                                          phase behind the first on a ctx-owned helper stream */
-#define PHANT_CTX_VERIFY_MIXED 64u /* flags: node-parallel pipeline with the byte comparison of the copies and
-                                    * the hashing of the representatives as ONE grid of interleaved
-                                    * workgroups (co-resident by construction; the single-stream form of
-                                    * PHANT_CTX_VERIFY_OVERLAP).  A/B candidate, unmeasured. */
+                                     two-tier pipeline (A/B and debugging) */
+#define PHANT_CTX_VERIFY_NODEDUP 4u /* flags: two-tier pipeline, but hash every shipped node even when the
+                                       batch carries byte-identical copies (A/B; = PHANT_CTX_DEDUP_LEVELS(0)) */
 #define PHANT_CTX_VERIFY_GRAPH 32u /* flags: device-form verify calls replay their kernel sequence as ONE
                                     * hipGraph launch while the arguments (buffers, sizes) stay the same as
-                                    * in the previous call; captured again when they change.  Serial
-                                    * node-parallel modes on a real stream only (the legacy default stream
-                                    * cannot be captured): otherwise, or if capturing fails, calls launch
-                                    * directly as without the flag.  Env PHANT_VERIFY_GRAPH=0/1 overrides. */
-#define PHANT_CTX_VERIFY_OVERLAP 8u /* flags: node-parallel pipeline with the byte comparison running on a
-                                       ctx-owned helper stream next to the hashing instead of before it */
+                                    * in the previous call; captured again when they change.  On a real
+                                    * stream only (the legacy default stream cannot be captured): otherwise,
+                                    * or if capturing fails, calls launch directly as without the flag.
+                                    * Env PHANT_VERIFY_GRAPH=0/1 overrides. */
+/* flags: how many trie levels, counted from the root, the verify pipeline deduplicates across the proofs of a
+ * batch (byte-compares copies instead of hashing them); deeper nodes are hashed in place.  Default (field 0):
+ * chosen from the batch size -- levels with fewer groups than proofs.  Correctness does not depend on it. */
+#define PHANT_CTX_DEDUP_LEVELS_SHIFT 8
+#define PHANT_CTX_DEDUP_LEVELS_MASK 0x1f00u
+#define PHANT_CTX_DEDUP_LEVELS(n) ((((uint32_t)(n) + 1u) << PHANT_CTX_DEDUP_LEVELS_SHIFT) & PHANT_CTX_DEDUP_LEVELS_MASK)
 
 typedef struct phant_opts {
     uint32_t struct_size; /* = sizeof(phant_opts) */
@@ -307,8 +305,14 @@ PHANT_API int32_t phant_witness_index_json(const char *json, uint64_t len, uint3
 PHANT_API void phant_witness_free(phant_witness *w);
 /* pointers stay valid until phant_witness_free */
 PHANT_API int32_t phant_witness_get(const phant_witness *w, phant_witness_info *info);
-PHANT_API int32_t phant_witness_verify(phant_ctx *ctx, const phant_witness *w, uint8_t *status,
-                                       uint32_t *n_failed);
+/* expected_state_root: the 32-byte state root the CALLER trusts (the parent header's stateRoot): account proofs are
+ * verified against IT, whatever the document declares as "stateRoot" -- a witness is an untrusted message, and a
+ * self-consistent trie under a root of the sender's choosing proves nothing about the chain.  A document whose own
+ * stateRoot differs therefore fails at its account proofs (PHANT_PROOF_BAD_HASH; the storage proofs below them
+ * PHANT_PROOF_MISMATCH).  NULL = verify against the document's own stateRoot: a CONSISTENCY check of the document
+ * (tests, tools), not a validation. */
+PHANT_API int32_t phant_witness_verify(phant_ctx *ctx, const phant_witness *w, const uint8_t *expected_state_root,
+                                       uint8_t *status, uint32_t *n_failed);
 
 /* ---------------------------------------------------------------- trie root
  * Replaces src/mpt/mpt.zig:38 `mptize(arena, list: []const KeyVal) !Hash32`
@@ -384,6 +388,10 @@ PHANT_API int32_t phant_timing(phant_ctx *ctx, int32_t enable);
  * of (c+1) rate blocks (c = 7: 8 or more) that were actually hashed, i.e.
  * distinct nodes; synchronises the ctx stream.  All zero after a fused call. */
 PHANT_API int32_t phant_verify_stats(phant_ctx *ctx, uint32_t hashed[8]);
+/* After a two-tier verify call on this ctx: out[0] = proofs the walk could not settle from the pipeline's tables and
+ * verified from scratch, out[1] = nodes decoded by walks that had to decode more than one node (both 0 for a witness
+ * of full-branch paths ending in a leaf); synchronises the ctx stream.  Diagnostics, not part of a result. */
+PHANT_API int32_t phant_verify_path_stats(phant_ctx *ctx, uint32_t out[2]);
 PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
 /* out[0] = graphs captured, out[1] = graph launches served so far on this ctx (PHANT_CTX_VERIFY_GRAPH) */
 PHANT_API int32_t phant_graph_stats(phant_ctx *ctx, uint64_t out[2]);

@@ -100,6 +100,10 @@ static int ref_kind(const rlp_item *it) {
     return REF_BAD;
 }
 
+/* keccak256(0x80): mpt.zig:10 empty_mpt_root */
+static const uint8_t EMPTY_MPT_ROOT[32] = {0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 0xff, 0x83, 0x45, 0xe6, 0x92, 0xc0, 0xf8, 0x6e,
+                                           0x5b, 0x48, 0xe0, 0x1b, 0x99, 0x6c, 0xad, 0xc0, 0x01, 0x62, 0x2f, 0xb5, 0xe3, 0x63, 0xb4, 0x21};
+
 /* A node SET (witness that ships every node once, in any order): nodes are found by their hash.
  * digests = n_nodes x 32, order = node indices sorted by digest (memcmp order). */
 typedef struct {
@@ -134,15 +138,17 @@ static uint8_t verify_core(const uint8_t root[32], const uint8_t *key, uint32_t 
         *value_off = 0;
     if (value_len)
         *value_len = 0;
+    /* The empty trie: a proof without nodes against root = keccak256(0x80) = empty_mpt_root
+     * (mpt.zig:10) proves absence -- what eth_getProof returns for a slot of an account without storage. */
     if (n_nodes == 0 && !set)
-        return ORACLE_PROOF_INVALID_EMPTY;
+        return memcmp(root, EMPTY_MPT_ROOT, 32) == 0 ? ORACLE_PROOF_ABSENT : ORACLE_PROOF_INVALID_EMPTY;
 
     const uint32_t nn = 2 * key_len;
     uint32_t pos = 0;  /* nibbles of the key consumed */
     uint32_t used = 0; /* proof nodes consumed */
     uint8_t want[32];
     memcpy(want, root, 32);
-    int by_hash = 1;
+    int by_hash = 1, at_root = 1;
     const uint8_t *cur = NULL;
     size_t cur_len = 0;
     uint8_t result;
@@ -152,8 +158,8 @@ static uint8_t verify_core(const uint8_t root[32], const uint8_t *key, uint32_t 
     for (;;) {
         if (by_hash && set) {
             int64_t i = nodeset_find(set, want);
-            if (i < 0)
-                return ORACLE_PROOF_MISSING_NODE;
+            if (i < 0) /* (the root of an empty trie needs no node) */
+                return at_root && memcmp(want, EMPTY_MPT_ROOT, 32) == 0 ? ORACLE_PROOF_ABSENT : ORACLE_PROOF_MISSING_NODE;
             cur = nodes + node_off[i];
             cur_len = (size_t)(node_off[i + 1] - node_off[i]);
         } else if (by_hash) {
@@ -171,6 +177,12 @@ static uint8_t verify_core(const uint8_t root[32], const uint8_t *key, uint32_t 
             oracle_keccak256(cur, cur_len, h);
             if (memcmp(h, want, 32) != 0)
                 return ORACLE_PROOF_BAD_HASH;
+        }
+        at_root = 0;
+        /* EmptyNode (mpt.zig:157-174): its RLP is the single byte 0x80 -- the whole (sub)trie is empty */
+        if (cur_len == 1 && cur[0] == 0x80) {
+            result = ORACLE_PROOF_ABSENT;
+            break;
         }
         rlp_item outer;
         if (rlp_decode(cur, cur_len, &outer) || outer.total != cur_len)

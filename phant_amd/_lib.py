@@ -71,7 +71,7 @@ SYMBOLS = {
     "phant_witness_index_json": (_i32, [C.c_char_p, _u64, _u32, C.POINTER(_vp), C.c_char_p, _u32]),
     "phant_witness_free": (None, [_vp]),
     "phant_witness_get": (_i32, [_vp, _vp]),
-    "phant_witness_verify": (_i32, [_vp, _vp, _vp, C.POINTER(_u32)]),
+    "phant_witness_verify": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(_u32)]),
     "phant_mpt_root": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "phant_mpt_root_nodes": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _u32, _vp]),
     "phant_mpt_strip_first_nibble": (_i32, [_vp, _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
@@ -83,6 +83,7 @@ SYMBOLS = {
     "phant_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "phant_graph_stats": (_i32, [_vp, _vp]),
     "phant_verify_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 8)]),
+    "phant_verify_path_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 2)]),
 }
 
 

@@ -17,8 +17,10 @@ class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
     def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
-                 verify_nodedup: bool = False, verify_overlap: bool = False, verify_pipelined: bool = False,
-                 verify_graph: bool = False, verify_mixed: bool = False):
+                 verify_nodedup: bool = False, verify_graph: bool = False, dedup_levels: int | None = None):
+        """verify_fused / verify_nodedup: the A/B forms of the verify pipeline (one lane per proof; every shipped
+        node hashed).  dedup_levels: how many trie levels from the root the two-tier pipeline deduplicates
+        (None = chosen from the batch size; PHANT_CTX_DEDUP_LEVELS)."""
         lib = L.lib()
         if not torch.cuda.is_available():
             raise L.PhantError(L.E_NO_DEVICE, "no GPU visible (phant_amd has no CPU fallback)")
@@ -33,14 +35,10 @@ class Context:
             flags |= 2  # PHANT_CTX_VERIFY_FUSED
         if verify_nodedup:
             flags |= 4  # PHANT_CTX_VERIFY_NODEDUP
-        if verify_overlap:
-            flags |= 8  # PHANT_CTX_VERIFY_OVERLAP
-        if verify_pipelined:
-            flags |= 16  # PHANT_CTX_VERIFY_PIPELINED
         if verify_graph:
             flags |= 32  # PHANT_CTX_VERIFY_GRAPH
-        if verify_mixed:
-            flags |= 64  # PHANT_CTX_VERIFY_MIXED
+        if dedup_levels is not None:
+            flags |= ((int(dedup_levels) + 1) << 8) & 0x1F00  # PHANT_CTX_DEDUP_LEVELS(n)
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
         h = C.c_void_p()
         rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))
@@ -70,6 +68,12 @@ class Context:
         out = (C.c_uint32 * 8)()
         self.check(self._lib.phant_verify_stats(self._h, C.byref(out)))
         return list(out)
+
+    def verify_path_stats(self) -> tuple[int, int]:
+        """(proofs verified from scratch by their walk lane, nodes decoded by walks that decoded more than one)."""
+        out = (C.c_uint32 * 2)()
+        self.check(self._lib.phant_verify_path_stats(self._h, C.byref(out)))
+        return int(out[0]), int(out[1])
 
     def graph_stats(self) -> tuple[int, int]:
         """(graphs captured, graph launches served) under verify_graph."""

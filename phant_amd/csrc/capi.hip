@@ -32,9 +32,10 @@ struct phant_ctx {
     phant::Workspaces ws;
     phant::DevArena dv;  // workspace of the device-form verify pipeline
     bool verify_fused = false;
-    phant::FlatMode flat_mode = phant::FLAT_SERIAL;
-    // helper stream of the overlap pipeline (created on first use)
-    phant::FlatSide side{nullptr, nullptr, nullptr, nullptr};
+    phant::VerifyTune tune;
+    int32_t dedup_levels = -1;  // trie levels deduplicated by the two-tier pipeline: < 0 = from the batch size, 0 = none
+    // helper stream of the two-tier pipeline: its deep tier runs there, next to the shallow tier (created on first use)
+    phant::FlatSide side{nullptr, nullptr, nullptr};
     // streaming slots (phant_mpt_verify_submit / phant_wait): own stream, staging and workspace each
     struct Slot {
         hipStream_t stream = nullptr;
@@ -142,18 +143,13 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         own = (opts->flags & PHANT_CTX_OWN_STREAM) != 0;
     }
     bool fused = opts && (opts->flags & PHANT_CTX_VERIFY_FUSED);
-    phant::FlatMode flat = phant::FLAT_SERIAL;
-    if (opts && (opts->flags & PHANT_CTX_VERIFY_NODEDUP)) flat = phant::FLAT_NODEDUP;
-    if (opts && (opts->flags & PHANT_CTX_VERIFY_OVERLAP)) flat = phant::FLAT_OVERLAP;
-    if (opts && (opts->flags & PHANT_CTX_VERIFY_PIPELINED)) flat = phant::FLAT_PIPELINED;
-    if (opts && (opts->flags & PHANT_CTX_VERIFY_MIXED)) flat = phant::FLAT_MIXED;
+    int32_t dedup_levels = -1;
+    if (opts && (opts->flags & PHANT_CTX_DEDUP_LEVELS_MASK))
+        dedup_levels = (int32_t)((opts->flags & PHANT_CTX_DEDUP_LEVELS_MASK) >> PHANT_CTX_DEDUP_LEVELS_SHIFT) - 1;
+    if (opts && (opts->flags & PHANT_CTX_VERIFY_NODEDUP)) dedup_levels = 0;
     if (const char* m = std::getenv("PHANT_VERIFY_MODE")) {  // overrides the flags (A/B without touching callers)
         fused = std::strcmp(m, "fused") == 0;
-        flat = std::strcmp(m, "nodedup") == 0   ? phant::FLAT_NODEDUP
-               : std::strcmp(m, "overlap") == 0   ? phant::FLAT_OVERLAP
-               : std::strcmp(m, "pipelined") == 0 ? phant::FLAT_PIPELINED
-               : std::strcmp(m, "mixed") == 0     ? phant::FLAT_MIXED
-                                                  : phant::FLAT_SERIAL;
+        if (std::strcmp(m, "nodedup") == 0) dedup_levels = 0;
     }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || dev < 0 || dev >= n) return PHANT_E_NO_DEVICE;
@@ -164,7 +160,13 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     if (!c) return PHANT_E_OOM;
     c->device = dev;
     c->verify_fused = fused;
-    c->flat_mode = flat;
+    c->dedup_levels = dedup_levels;
+    // diagnostics / A/B, read once per ctx (tools/sweep_verify.py): the deep tier's occupancy cap, serial tiers
+    if (const char* t = std::getenv("PHANT_HASH_LDS_KB")) {
+        const long kb = std::strtol(t, nullptr, 10);
+        c->tune.hash_lds = (uint32_t)(kb < 0 ? 0 : kb > 63 ? 63 : kb) * 1024u;  // (< 64 KiB needs no opt-in)
+    }
+    if (const char* t = std::getenv("PHANT_VERIFY_SERIAL")) c->tune.serial = t[0] == '1';
     c->use_graph = opts && (opts->flags & PHANT_CTX_VERIFY_GRAPH);
     if (const char* g = std::getenv("PHANT_VERIFY_GRAPH")) c->use_graph = g[0] == '1';
     DeviceGuard g(dev);
@@ -205,7 +207,6 @@ void phant_ctx_destroy(phant_ctx* c) {
     if (c->side.stream) (void)hipStreamSynchronize(c->side.stream);
     if (c->side.fork) (void)hipEventDestroy(c->side.fork);
     if (c->side.join) (void)hipEventDestroy(c->side.join);
-    if (c->side.mid) (void)hipEventDestroy(c->side.mid);
     if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -245,12 +246,24 @@ int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
     if (c->verify_fused || !c->dv.base) return PHANT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // the class cursors are words 0..7 of the verify workspace, the late-hash cursors of the overlap
-    // pipeline words 16..23, the second half's cursors of the pipelined mode words 64..71
-    // (mpt_verify_flat.hip)
-    uint32_t hdr[72];
+    if (c->side.stream) HIP_TRY(c, hipStreamSynchronize(c->side.stream));
+    // list counts and the deep tier's striped counters, in the header of the verify workspace (mpt_verify_v2.hip)
+    uint32_t hdr[phant::VERIFY_HEADER_WORDS];
     HIP_TRY(c, hipMemcpy(hdr, c->dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; ++i) hashed[i] = hdr[i] + hdr[16 + i] + hdr[64 + i];
+    phant::verify_stats_from_header(hdr, hashed);
+    return PHANT_OK;
+}
+
+int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    out[0] = out[1] = 0;
+    if (c->verify_fused || !c->dv.base) return PHANT_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->side.stream) HIP_TRY(c, hipStreamSynchronize(c->side.stream));
+    uint32_t hdr[phant::VERIFY_HEADER_WORDS];
+    HIP_TRY(c, hipMemcpy(hdr, c->dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
+    phant::verify_paths_from_header(hdr, out);
     return PHANT_OK;
 }
 
@@ -414,19 +427,18 @@ int32_t phant_sender_addresses(phant_ctx* c, const uint8_t* pubkeys, uint64_t st
 
 /* ------------------------------------------------------- proof verification */
 
-// helper stream + events of the overlap / pipelined modes (created on first use)
+// helper stream + events of the two-tier pipeline (created on first use)
 static int32_t ensure_side(phant_ctx* c) {
-    const bool need = !c->verify_fused && (c->flat_mode == phant::FLAT_OVERLAP || c->flat_mode == phant::FLAT_PIPELINED);
+    const bool need = !c->verify_fused && c->dedup_levels != 0;
     if (!need || c->side.stream) return PHANT_OK;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->side.mid, hipEventDisableTiming));
     return PHANT_OK;
 }
 
 // Runs the verify pipeline on device-resident arguments (shared by all forms) on stream `st` with the
-// workspace arena `dv`; `side` = helper stream of the overlap pipeline or nullptr (then it runs serially).
+// workspace arena `dv`; `side` = helper stream of the two-tier pipeline or nullptr (then its tiers run one after the other).
 static bool same_args(const phant::VerifyArgs& x, const phant::VerifyArgs& y) {
     return x.roots == y.roots && x.n_roots == y.n_roots && x.root_idx == y.root_idx && x.keys == y.keys &&
            x.key_len == y.key_len && x.nodes == y.nodes && x.nodes_len == y.nodes_len && x.node_off == y.node_off &&
@@ -435,13 +447,13 @@ static bool same_args(const phant::VerifyArgs& x, const phant::VerifyArgs& y) {
            x.total_nodes == y.total_nodes;
 }
 
-// The flat pipeline as one graph launch (PHANT_CTX_VERIFY_GRAPH; serial single-stream modes, a real stream --
-// the legacy default stream cannot be captured).  Capture happens when the arguments differ from the cached
+// The pipeline as one graph launch (PHANT_CTX_VERIFY_GRAPH; a real stream -- the legacy default stream cannot be
+// captured; the helper stream's fork / join are captured with it).  Capture happens when the arguments differ from the cached
 // ones: the kernels' arguments (pointers, sizes) and the launcher's tuning knobs are frozen into the graph, the
 // DATA behind the pointers is read afresh at every replay.  Returns 1 when the call was served, 0 when the caller
 // should launch directly (and graphs are switched off for this ctx if capturing failed), < 0 on a device error.
 static int32_t verify_graph_launch(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes, uint8_t* ws,
-                                   hipStream_t st) {
+                                   hipStream_t st, const phant::FlatSide* side) {
     if (!c->graph_exec || !same_args(a, c->graph_key) || ws != c->graph_ws) {
         if (c->graph_exec) {
             (void)hipGraphExecDestroy(c->graph_exec);
@@ -452,7 +464,7 @@ static int32_t verify_graph_launch(phant_ctx* c, const phant::VerifyArgs& a, uin
             c->use_graph = false;
             return 0;
         }
-        const hipError_t le = phant::launch_mpt_verify_flat(a, total_nodes, ws, c->flat_mode, st, nullptr);
+        const hipError_t le = phant::launch_mpt_verify(a, total_nodes, ws, c->dedup_levels, st, side, c->tune);
         const hipError_t ee = hipStreamEndCapture(st, &g);
         if (le != hipSuccess || ee != hipSuccess || !g || hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
             if (g) (void)hipGraphDestroy(g);
@@ -484,7 +496,7 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
         }
         return PHANT_OK;
     }
-    const size_t need = phant::verify_flat_workspace_bytes(total_nodes);
+    const size_t need = phant::verify_workspace_bytes(total_nodes);
     if (need > dv.cap) {
         HIP_TRY(c, hipStreamSynchronize(st));
         hipError_t e = dv.reset(need);
@@ -492,19 +504,17 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
     }
     // (only the ctx's own device-form path -- `timed` -- replays a graph: the streaming slots stage into buffers
     // of their own and would re-capture per witness)
-    if (timed && c->use_graph && st != nullptr && &dv == &c->dv &&
-        (c->flat_mode == phant::FLAT_SERIAL || c->flat_mode == phant::FLAT_NODEDUP || c->flat_mode == phant::FLAT_MIXED) &&
-        a.n != 0) {
+    if (timed && c->use_graph && st != nullptr && &dv == &c->dv && a.n != 0) {
         TimedRegion t(c);
-        const int32_t served = verify_graph_launch(c, a, total_nodes, dv.base, st);
+        const int32_t served = verify_graph_launch(c, a, total_nodes, dv.base, st, side);
         if (served < 0) return served;
         if (served == 1) return PHANT_OK;
     }
     if (timed) {
         TimedRegion t(c);
-        HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, dv.base, c->flat_mode, st, side));
+        HIP_TRY(c, phant::launch_mpt_verify(a, total_nodes, dv.base, c->dedup_levels, st, side, c->tune));
     } else {
-        HIP_TRY(c, phant::launch_mpt_verify_flat(a, total_nodes, dv.base, c->flat_mode, st, side));
+        HIP_TRY(c, phant::launch_mpt_verify(a, total_nodes, dv.base, c->dedup_levels, st, side, c->tune));
     }
     return PHANT_OK;
 }
@@ -624,8 +634,8 @@ int32_t phant_mpt_verify_batch(phant_ctx* c, const uint8_t* roots, uint32_t n_ro
     if (!c) return PHANT_E_INVALID_ARG;
     if (n == 0) return PHANT_OK;
     if (!roots || n_roots == 0 || !node_off || !proof_first_node || !status || (key_len && !keys) ||
-        (nodes_len && !nodes))
-        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_batch: null pointer");
+        (nodes_len && !nodes) || key_len > 0x3fffffffu)
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_batch: bad argument");
     DeviceGuard g(c->device);
     {
         const int32_t src = ensure_side(c);
@@ -669,7 +679,7 @@ int32_t phant_mpt_verify_nodeset(phant_ctx* c, const uint8_t* roots, uint32_t n_
                                  uint64_t* value_off, uint32_t* value_len) {
     if (!c) return PHANT_E_INVALID_ARG;
     if (n == 0) return PHANT_OK;
-    if (!roots || n_roots == 0 || !node_off || !status || (key_len && !keys) || (nodes_len && !nodes))
+    if (!roots || n_roots == 0 || !node_off || !status || (key_len && !keys) || (nodes_len && !nodes) || key_len > 0x3fffffffu)
         return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset: null pointer");
     DeviceGuard g(c->device);
     hipStream_t s = c->stream;
@@ -829,7 +839,8 @@ int32_t phant_witness_get(const phant_witness* pw, phant_witness_info* info) {
     return PHANT_OK;
 }
 
-int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* status, uint32_t* n_failed) {
+int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, const uint8_t* expected_state_root, uint8_t* status,
+                             uint32_t* n_failed) {
     if (!c || !pw) return PHANT_E_INVALID_ARG;
     const phant::Witness& w = pw->w;
     const uint32_t n = (uint32_t)w.root_idx.size();
@@ -870,6 +881,8 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, uint8_t* sta
     HIP_TRY(c, hipMemcpyAsync(d_pre, w.preimages.data(), pre_len, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_poff, poff64.data(), poff64.size() * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_roots, w.roots.data(), w.roots.size(), hipMemcpyHostToDevice, s));
+    // root 0 = the state root: the one the caller trusts, not the one the document claims
+    if (expected_state_root && n_roots) HIP_TRY(c, hipMemcpyAsync(d_roots, expected_state_root, 32, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_ridx, w.root_idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_noff, w.node_off.data(), ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_pfn, w.proof_first_node.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));

@@ -141,7 +141,14 @@ int32_t strip_first_nibble(const uint8_t* node, uint32_t len, uint8_t* out, uint
     std::vector<uint8_t> body;
     if (h.size() == 1 && h[0] < 0x80) body.push_back(h[0]);
     else {
-        body.push_back((uint8_t)(0x80 + h.size()));  // <= 33 bytes
+        // canonical RLP string header: keys go up to 255 bytes (128 path bytes), beyond the 55-byte short form
+        if (h.size() <= 55) {
+            body.push_back((uint8_t)(0x80 + h.size()));
+        } else {
+            body.push_back((uint8_t)(0xb7 + (h.size() > 0xff ? 2 : 1)));
+            if (h.size() > 0xff) body.push_back((uint8_t)(h.size() >> 8));
+            body.push_back((uint8_t)h.size());
+        }
         body.insert(body.end(), h.begin(), h.end());
     }
     body.insert(body.end(), rest, rest + rest_len);

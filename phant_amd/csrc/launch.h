@@ -46,30 +46,34 @@ struct VerifyArgs {
                                      // caller, capi.hip::verify_resident_on)
 };
 hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
-// re-verifies, one lane per proof, the proofs whose status byte is 0xff (the flat pipeline's
-// "could not settle from the tables" marker) -- or every proof when one of the two device flags (may be
-// null) is set: a pipelined launch found proof_first_node going backwards, so a proof of one half may
-// have read nodes the other half had not finished
-hipError_t launch_mpt_verify_fixup(const VerifyArgs& a, const uint32_t* all_flag_a, const uint32_t* all_flag_b,
-                                   hipStream_t st);
-// flat pipeline (plan -> dedup/compare -> class-sorted hashing of distinct nodes -> walk -> fixup);
-// ws = verify_flat_workspace_bytes().
-//   FLAT_SERIAL   compare, then hash, on one stream
-//   FLAT_NODEDUP  hash every shipped node (A/B)
-//   FLAT_OVERLAP  the byte comparison (an HBM stream) runs on `side->stream` NEXT TO the hashing of the
-//                 groups' representatives (integer-VALU-bound) instead of in front of it
-//   FLAT_PIPELINED  two half batches, the second one a phase behind the first on `side->stream`: the
-//                 memory-bound kernels of one half run next to the VALU-bound hash of the other
-//   FLAT_MIXED    like FLAT_OVERLAP on ONE stream: the representatives' hash workgroups and the COMPARE workgroups
-//                 are interleaved in one grid (hash_compare_kernel), co-resident by construction
-enum FlatMode : int { FLAT_SERIAL = 0, FLAT_NODEDUP = 1, FLAT_OVERLAP = 2, FLAT_PIPELINED = 3, FLAT_MIXED = 4 };
+// Two-tier pipeline (mpt_verify_v2.hip): the trie levels that repeat across proofs are deduplicated (plan ->
+// dedup/compare -> class-sorted hashing of the distinct nodes), the deeper ones hashed in place, then link -> walk.
+// ws = verify_workspace_bytes().  dedup_levels: how many levels from the root are deduplicated; < 0 = chosen from the
+// batch size, 0 = hash every shipped node (A/B).  `side` (may be null): helper stream + events owned by the ctx; with
+// it the deep tier runs NEXT TO the shallow tier (VALU-bound hashing beside a memory stream), without it in front.
 struct FlatSide {
-    hipStream_t stream;           // non-blocking helper stream owned by the ctx
-    hipEvent_t fork, join, mid;   // timing-disabled events
+    hipStream_t stream;       // non-blocking helper stream owned by the ctx
+    hipEvent_t fork, join;    // timing-disabled events
 };
-size_t verify_flat_workspace_bytes(uint32_t total_nodes);
-hipError_t launch_mpt_verify_flat(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, FlatMode mode,
-                                  hipStream_t st, const FlatSide* side);
+size_t verify_workspace_bytes(uint32_t total_nodes);
+// The deep tier's occupancy cap and a diagnostics switch (fixed per ctx).
+struct VerifyTune {
+    // An otherwise unused dynamic LDS allocation per workgroup of the deep tier caps how many of them a CU holds
+    // (160 KiB / it) WHILE the shallow tier's memory-bound kernels run next to it: 40 KiB -> 4 hash waves per SIMD,
+    // which leaves those kernels a slot per SIMD (measured on BASELINE config 3: 0.254 ms per launch uncapped,
+    // 0.237 at 40 KiB, 0.250 at 52 KiB = 3 waves).  Alone, the deep tier is launched without it.
+    uint32_t hash_lds = 40u * 1024u;
+    bool serial = false;  // diagnostics: the tiers one after the other on the ctx stream (clean per-kernel durations in a trace)
+};
+hipError_t launch_mpt_verify(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
+                             hipStream_t st, const FlatSide* side, const VerifyTune& tune);
+// nodes hashed per rate-block class by the last launch, from a host copy of the workspace's first
+// VERIFY_HEADER_WORDS words
+constexpr uint32_t VERIFY_HEADER_WORDS = 160;
+void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]);
+// out[0] = proofs the walk could not settle from the tables (verified from scratch by their lane), out[1] = nodes
+// decoded by walks that had to decode more than one
+void verify_paths_from_header(const uint32_t* hdr, uint32_t out[2]);
 // node-SET witnesses (every node shipped once, any order; references resolved by hash)
 size_t verify_nodeset_workspace_bytes(uint32_t total_nodes);
 hipError_t launch_mpt_verify_nodeset(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, hipStream_t st);

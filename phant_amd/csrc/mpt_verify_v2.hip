@@ -1,0 +1,1382 @@
+// mpt_verify_v2.hip -- batched proof verification, two-tier pipeline.
+//
+// A witness ships every proof as its own node list, so the upper trie levels arrive many times over
+// (BASELINE config 3: 800 k shipped nodes, ~354 k distinct), while the lower levels are all but unique.
+// Keccak-f is integer-VALU-bound on gfx950, comparing two nodes is a memory stream.
+// So the batch is cut at a depth S ("shallow levels", chosen on the host from the batch size):
+//
+//   deep tier (depth >= S): nothing to deduplicate.  hash_deep_kernel hashes these nodes in place -- wave =
+//        64 consecutive proofs at one depth, lane = proof -- with no planning, no lists and no table in front
+//        of it: it starts at once, on the helper stream, and is the VALU-bound bulk of the launch.
+//   shallow tier (depth < S), on the main stream, NEXT TO the deep tier (a memory stream beside VALU work):
+//        plan_kernel      one lane per proof: stamps every node with depth + key nibble, shallow nodes also
+//                         with the 64-bit key of their (root, depth, key-prefix) group; every multi-block
+//                         shallow node proposes itself as its group's representative in a 2-choice table
+//                         (plain stores, last writer wins -- correctness never depends on who wins).
+//        dedup_kernel     one lane per node looks its group up; a wave then reads the nodes that HAVE a
+//                         representative, 16 bytes per lane (coalesced), next to the representative's bytes
+//                         (L2 / Infinity-Cache hits).  Equal => rep[j] = representative (never hashed);
+//                         otherwise the node is listed for hashing, compacted per rate-block class.
+//        hash_list_kernel one lane per listed node, one 64-node chunk of one class per wave.
+//   Both hash kernels also settle, while the digest is still in registers, whether the node is what its
+//   parent commits to: the parent of node j inside a proof is node j - 1, and if that is a full 532-byte
+//   branch the reference for this key's nibble sits at a fixed place in its bytes (root nodes: the root
+//   table).  One status byte per hashed node (nstat[]): hashed / canonical full branch / link checked / ok.
+//        link_kernel      one lane per node: the walk's code for node j.  A hashed node reads its own nstat;
+//                         a copy inherits its representative's when their parents are the same bytes and the
+//                         same key nibble (cheap gathers from a few hot lines instead of 64 bytes per node).
+//        walk_kernel      one lane per proof steps over the run of nodes link_kernel settled and decodes the
+//                         rest (DESIGN.md section 3 order of checks) from an LDS copy -- for BASELINE's proofs
+//                         just the leaf; counts the per-root verdict; the (never seen) proof that cannot be
+//                         settled from the tables is verified from scratch by its lane (verify_one).
+//
+// Soundness: rep[j] = r only if bytes(j) == bytes(r), checked byte for byte (so keccak(j) == digest[r]), and r
+// is only trusted when nstat[r] says r itself was hashed; the group key is only a hint where to look.  A copy
+// inherits a link result only if its parent is byte-identical to the representative's parent (same rep) and the
+// key nibble is the same, which makes it the same comparison.  A stamp is only used by the proof that wrote it
+// (node ranges of proofs are disjoint when proof_first_node is monotone -- otherwise every proof is verified
+// from scratch).
+//
+// What it computes: the verifier missing at src/engine_api/execution_payload.zig:177-178, over the node
+// encodings of src/mpt/mpt.zig:187-193,216-231,254-261,285-314.
+#include <cstdlib>
+
+#include "launch.h"
+#include "mpt_verify_one.hip.h"
+
+namespace phant {
+namespace v2 {
+
+constexpr uint32_t N_CLASS = 8;        // class c = (c+1) rate blocks; last class = 8 or more
+constexpr uint32_t LIST_B532 = 8;      // list of the nodes that are exactly 532 bytes long
+constexpr uint32_t N_LIST = 9;
+constexpr uint32_t CLASS_NONE = 0xffu;
+constexpr uint32_t MAX_SHALLOW = 16;   // key prefix of <= 16 nibbles fits the 64-bit group key
+constexpr uint32_t STATUS_NEEDS_SLOW = 0xffu;
+constexpr uint32_t BRANCH_LEN = 532u;  // f9 02 11 | 16 x (a0 + 32 bytes) | 80
+
+// header words of the workspace (zeroed per call)
+constexpr uint32_t HDR_PFN_BROKEN = 9;   // some proof has last < first
+constexpr uint32_t HDR_SLOW = 10;        // proofs verified from scratch by their walk lane (reporting only)
+constexpr uint32_t HDR_OPENED = 11;      // nodes decoded by walks that decoded more than one (reporting only)
+constexpr uint32_t HDR_STAT = 16;        // + 16 x stripe + class: nodes hashed by the deep tier (reporting only)
+constexpr uint32_t HDR_STAT_STRIPES = 16;
+constexpr size_t HEADER_BYTES = 2048;
+
+// nstat[] bits
+constexpr uint32_t NS_HASHED = 1u, NS_CANON = 2u, NS_LINK_CHECKED = 4u, NS_LINK_OK = 8u;
+
+// plan_kernel -> node-parallel kernels, in meta[] (zeroed per call, so an unstamped node reads 0):
+// PRE_STAMP | PRE_NIB (nibble valid) | PRE_GROUP (shallow: rep[] / gkey[] valid) | nibble << 4 | depth << 8
+constexpr uint32_t PRE_NIB = 2u, PRE_GROUP = 4u, PRE_STAMP = 8u;
+
+PHANT_DEV uint32_t node_list(uint32_t len) {
+    if (len == BRANCH_LEN) return LIST_B532;
+    const uint32_t nb = len / RATE + 1u;
+    return (nb > N_CLASS ? N_CLASS : nb) - 1u;
+}
+
+struct __attribute__((packed, aligned(1))) U32x4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U32x3 { uint32_t x, y, z; };
+struct __attribute__((packed, aligned(1))) U32x1 { uint32_t x; };
+PHANT_DEV uint4 load16u(const uint8_t* p) {  // unaligned 16-byte global load
+    const U32x4 v = *reinterpret_cast<const U32x4*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+PHANT_DEV uint32_t load4u(const uint8_t* p) { return reinterpret_cast<const U32x1*>(p)->x; }
+// value of `v` in lane `i` (wave-uniform i).  The builtin returns int: without the cast a 64-bit
+// offset assembled from two halves gets its low half sign-extended (wrong for blobs > 2 GiB).
+PHANT_DEV uint32_t lane_u32(uint32_t v, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane(v, i); }
+PHANT_DEV uint64_t lane_u64(uint32_t lo, uint32_t hi, uint32_t i) {
+    return ((uint64_t)lane_u32(hi, i) << 32) | (uint64_t)lane_u32(lo, i);
+}
+
+// first 8 key bytes, big-endian (zero padded): the nibble prefix of depth d is its top 4d bits
+PHANT_DEV uint64_t key_prefix64(const uint8_t* __restrict__ key, uint32_t key_len) {
+    uint64_t kb = 0;
+    const uint32_t take = key_len < 8u ? key_len : 8u;
+    for (uint32_t t = 0; t < take; ++t) kb |= (uint64_t)key[t] << (56u - 8u * t);
+    return kb;
+}
+// 64-bit group key of (root, depth, first `d` key nibbles); murmur3 finaliser.
+PHANT_DEV uint64_t group_key(uint64_t kb, uint32_t root, uint32_t d) {
+    const uint64_t pre = d ? (kb >> (64u - 4u * d)) : 0ull;
+    uint64_t h = pre ^ ((uint64_t)(d + 1u) << 58) ^ ((uint64_t)root * 0x9E3779B97F4A7C15ull);
+    h ^= h >> 33;
+    h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    return h;
+}
+// Where a group's representative is proposed and looked up.  The levels next to the root -- few groups, each with
+// very many members: losing one of them to a collision would cost thousands of hashes -- are direct-mapped: level d
+// of root r has 16^d slots of its own, [n_roots (16^d - 1) / 15 + r 16^d, + 16^d), indexed by the key prefix.  The
+// levels below them share a hashed 2-choice table (a group that loses both its slots is hashed copy by copy).
+constexpr uint64_t GK_DIRECT = 1ull << 63;
+PHANT_DEV uint32_t direct_index(uint64_t kb, uint32_t root, uint32_t d, uint32_t n_roots) {
+    uint32_t width = 1u, below = 0u;  // 16^d, (16^d - 1) / 15
+    for (uint32_t t = 0; t < d; ++t) {
+        below += width;
+        width <<= 4;
+    }
+    const uint32_t pre = d ? (uint32_t)(kb >> (64u - 4u * d)) : 0u;
+    return n_roots * below + root * width + pre;
+}
+PHANT_DEV uint32_t gk_fp(uint64_t h) { return (uint32_t)(h >> 32) | 1u; }
+PHANT_DEV uint32_t gk_slot_a(uint64_t h, uint32_t mask) { return (uint32_t)h & mask; }
+PHANT_DEV uint32_t gk_slot_b(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 20) & mask; }
+
+struct Args {
+    VerifyArgs v;
+    uint32_t total_nodes;
+    uint32_t shallow;        // nodes of depth < shallow are deduplicated and hashed from the class lists; the
+                             // others are hashed in place by hash_deep_kernel.  0 = hash every shipped node (A/B)
+    uint32_t all_listed;     // node-set witnesses: every valid node goes to the lists (no stamps, no links)
+    uint32_t direct;         // levels [0, direct) of the shallow tier have a direct-mapped table, the others the hashed one
+    uint32_t* dtab;          // n_roots x (16^direct - 1) / 15 entries: node + 1 of a member of the group (0: none), zeroed per call
+    uint64_t* table;         // tmask + 1 entries {fp:32 | node:32}, zeroed per call
+    uint32_t tmask;
+    uint32_t* rep;           // total_nodes; meaningful where meta[] says PRE_GROUP
+    uint32_t* meta;          // total_nodes, zeroed per call
+    uint64_t* gkey;          // total_nodes; meaningful where meta[] says PRE_GROUP: GK_DIRECT | index into dtab, or the
+                             // 64-bit key of the group for the hashed table
+    uint32_t* ent;           // N_LIST x total_nodes: node ids to hash, per list
+    uint32_t* hdr;           // header: [0..8] list counts, HDR_*; zeroed per call
+    uint32_t* digest;        // total_nodes x 8
+    uint8_t* nstat;          // total_nodes: NS_* of the node, written by the lane that hashed it; zeroed per call
+    uint8_t* link;           // total_nodes (+ 16 readable): LINK_* code of link_kernel
+};
+
+// ---------------------------------------------------------------- plan
+// One lane per proof.  Stamps every node of the proof (up to the deepest position a walk can reach) with what
+// the node-parallel kernels need to know about its owner -- depth and the key nibble at that depth, shallow
+// nodes also the 64-bit key of their (root, depth, key prefix) group -- so that they never search for the
+// owning proof or touch the keys.  Every multi-block shallow node also proposes itself as the representative of
+// its group.  Plain stores: the last writer of a table slot wins.
+constexpr uint32_t PLAN_BATCH = 8;  // even: a batch starts on a key byte
+
+// The memory-bound kernels of the shallow tier run NEXT TO hash waves that never stop issuing: a few instructions,
+// then a wait for memory -- at equal priority they would only get the leftover issue slots.
+PHANT_DEV void beside_the_hashing() { __builtin_amdgcn_s_setprio(3); }
+
+__global__ void __launch_bounds__(256) plan_kernel(const Args a) {
+    beside_the_hashing();
+    // first kernel of the main stream: clear the verdict counters the walk will add to
+    if (a.v.fail_count && blockIdx.x == 0)
+        for (uint32_t r = threadIdx.x; r < a.v.n_roots; r += 256u) a.v.fail_count[r] = 0u;
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= a.v.n) return;
+    const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
+    if (last < first) {
+        // proof_first_node is not monotone: node ranges of OTHER proofs may then overlap, and a node stamped
+        // by one proof would be read by another.  Tell the walk not to trust anything derived from stamps.
+        a.hdr[HDR_PFN_BROKEN] = 1u;
+        return;  // BAD_INPUT: the walk reports it
+    }
+    if (last > a.total_nodes) return;  // BAD_INPUT: the walk reports it
+    const uint32_t root = a.v.root_idx ? a.v.root_idx[p] : 0u;
+    const uint8_t* key = a.v.keys + (uint64_t)a.v.key_len * p;
+    const uint64_t kb = key_prefix64(key, a.v.key_len);
+    const uint32_t nn = 2u * a.v.key_len;
+    uint32_t end = last - first;
+    end = end <= nn ? end : nn + 1u;  // a walk consumes at least one nibble per hashed node
+    // nodes [0, gend) get a group (a root index out of range -- the walk reports it -- must not index the direct map)
+    const uint32_t gend = root >= a.v.n_roots ? 0u : end < a.shallow ? end : a.shallow;
+    // the shallow nodes' offsets are all requested before the first store (the compiler may not move a load
+    // across the table / stamp stores itself -- they could alias)
+    for (uint32_t d0 = 0; d0 < end; d0 += PLAN_BATCH) {
+        uint64_t offs[PLAN_BATCH + 1];
+        uint32_t kb4 = 0;  // key bytes d0/2 .. d0/2 + 3 (PLAN_BATCH = 8 nibbles)
+        if (d0 < gend) {
+#pragma unroll
+            for (uint32_t u = 0; u <= PLAN_BATCH; ++u) {
+                const uint32_t d = d0 + u <= gend ? d0 + u : gend;
+                offs[u] = a.v.node_off[first + d];
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PLAN_BATCH / 2u; ++u)
+            if (d0 / 2u + u < a.v.key_len) kb4 |= (uint32_t)key[d0 / 2u + u] << (8u * u);
+#pragma unroll
+        for (uint32_t u = 0; u < PLAN_BATCH; ++u) {
+            const uint32_t d = d0 + u;
+            if (d < end) {
+                const uint32_t j = first + d;
+                uint32_t pm = PRE_STAMP | (d << 8);
+                if (d < nn) {
+                    const uint32_t kbyte = (kb4 >> (8u * (u >> 1))) & 0xffu;
+                    pm |= PRE_NIB | (((u & 1u) ? (kbyte & 0x0fu) : (kbyte >> 4)) << 4);
+                }
+                if (d < gend) {
+                    const uint64_t b = offs[u], e = offs[u + 1];
+                    const bool multi = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull && e - b >= RATE;
+                    pm |= PRE_GROUP;
+                    if (d < a.direct) {
+                        const uint32_t at = direct_index(kb, root, d, a.v.n_roots);
+                        a.gkey[j] = GK_DIRECT | at;
+                        if (multi) a.dtab[at] = j + 1u;
+                    } else {
+                        const uint64_t h = group_key(kb, root, d) & ~GK_DIRECT;
+                        a.gkey[j] = h;
+                        if (multi) {
+                            const uint64_t entry = ((uint64_t)gk_fp(h) << 32) | j;
+                            a.table[gk_slot_a(h, a.tmask)] = entry;
+                            a.table[gk_slot_b(h, a.tmask)] = entry;
+                        }
+                    }
+                }
+                a.meta[j] = pm;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dedup
+// all 64 lanes: are the `len` bytes at x and y equal?  16 bytes per lane per step.
+PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len, uint32_t lane) {
+    uint32_t diff = 0;
+    const uint32_t full = len & ~15u;
+    for (uint32_t o = 16u * lane; o < full; o += 1024u) {
+        const uint4 p = load16u(x + o), q = load16u(y + o);
+        diff |= (p.x ^ q.x) | (p.y ^ q.y) | (p.z ^ q.z) | (p.w ^ q.w);
+    }
+    if (lane < (len & 15u)) diff |= (uint32_t)(x[full + lane] ^ y[full + lane]);
+    return __ballot(diff != 0) == 0ull;
+}
+
+constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte path
+
+// Workgroups of 256 lanes = one wave per SIMD: such a workgroup finds room next to the deep tier's hash waves where
+// one of four waves per SIMD has to wait for all of them at once (measured: 0.250 -> 0.237 ms per launch).  The price
+// is one returning atomicAdd per workgroup and non-empty list on the SAME few cursors (served one at a time, ~11.6 ns
+// each, tools/ubench/atomic_rate.hip): ~3 000 of them for BASELINE config 3, spread over the kernel's run.
+constexpr uint32_t DEDUP_BLOCK = 256;
+
+__global__ void __launch_bounds__(DEDUP_BLOCK) dedup_kernel(const Args a) {
+    constexpr uint32_t WAVES = DEDUP_BLOCK / 64u;
+    __shared__ uint32_t s_cnt[WAVES][N_LIST];
+    __shared__ uint32_t s_base[N_LIST];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t NT = a.total_nodes;
+    const uint32_t j = blockIdx.x * DEDUP_BLOCK + tid;
+    beside_the_hashing();
+
+    // ---- lane-per-node metadata (coalesced) ----
+    bool valid = false, listed = false;
+    uint64_t b = 0, cb = 0;
+    uint32_t len = 0, cand = j;
+    if (j < NT) {
+        const uint64_t e = a.v.node_off[j + 1];
+        b = a.v.node_off[j];
+        if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
+            valid = true;
+            len = (uint32_t)(e - b);
+            const uint32_t stamp = a.all_listed ? 0u : a.meta[j];
+            // shallow stamped nodes are this tier's; the deep ones are hashed in place, nodes no walk reaches never
+            listed = a.all_listed || ((stamp & PRE_STAMP) && (stamp >> 8) < a.shallow);
+            if (len >= RATE && (stamp & PRE_GROUP)) {
+                const uint64_t h = a.gkey[j];
+                uint32_t c = j;  // the group's proposed representative
+                if (h & GK_DIRECT) {
+                    const uint32_t t = a.dtab[(uint32_t)h];
+                    if (t) c = t - 1u;
+                } else {
+                    const uint32_t fp = gk_fp(h);
+                    uint64_t en = a.table[gk_slot_a(h, a.tmask)];
+                    if ((uint32_t)(en >> 32) != fp) en = a.table[gk_slot_b(h, a.tmask)];
+                    if ((uint32_t)(en >> 32) == fp) c = (uint32_t)en;
+                }
+                if (c < NT && c != j) {
+                    // a representative is only usable if it is a well-formed node of the same length
+                    const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
+                    if (c1 >= c0 && c1 <= a.v.nodes_len && c1 - c0 == len) {
+                        cand = c;
+                        cb = c0;
+                    }
+                }
+            }
+        }
+    }
+
+    uint32_t my_rep = j;
+    // ---- this lane's share of a 532-byte node: bytes [16 lane, 16 lane + 16) for lane < 33; the lanes
+    // above all take the last 16 bytes [516, 532) (redundant cover: no lane is ever masked off, so
+    // every load below is unconditional and the loads of several nodes overlap) ----
+    const uint32_t coff = lane < 33u ? 16u * lane : BRANCH_LEN - 16u;
+    // everything that selects a node below is wave-uniform: say so, or the compiler predicates per lane
+    const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32), cb_lo = (uint32_t)cb, cb_hi = (uint32_t)(cb >> 32);
+
+    // ---- 532-byte nodes that have a representative: DEDUP_UNROLL nodes per trip, all their loads issued
+    // before any is used.  A short last trip repeats its last node (idempotent) so that the body has no
+    // conditionals.  Nodes WITHOUT a representative are not opened here at all: the hash kernel reads
+    // them (once), and checks their form while it has them in registers. ----
+    unsigned long long todo = __ballot(valid && len == BRANCH_LEN && cand != j);
+    while (todo) {
+        uint32_t ii[DEDUP_UNROLL], cj[DEDUP_UNROLL];
+        uint4 x[DEDUP_UNROLL], y[DEDUP_UNROLL];
+        uint32_t i = 0;
+#pragma unroll
+        for (int u = 0; u < DEDUP_UNROLL; ++u) {
+            if (todo) {
+                i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+            }
+            ii[u] = i;
+            cj[u] = lane_u32(cand, i);
+            const uint8_t* own = a.v.nodes + lane_u64(b_lo, b_hi, i);
+            const uint8_t* oth = a.v.nodes + lane_u64(cb_lo, cb_hi, i);
+            x[u] = load16u(own + coff);
+            y[u] = load16u(oth + coff);
+        }
+#pragma unroll
+        for (int u = 0; u < DEDUP_UNROLL; ++u) {
+            // acc | (x ^ y), dword by dword
+            uint32_t diff = x[u].x ^ y[u].x;
+            diff = __builtin_amdgcn_bitop3_b32(x[u].y, y[u].y, diff, 0xBE);
+            diff = __builtin_amdgcn_bitop3_b32(x[u].z, y[u].z, diff, 0xBE);
+            diff = __builtin_amdgcn_bitop3_b32(x[u].w, y[u].w, diff, 0xBE);
+            const bool same = __ballot(diff != 0) == 0ull;
+            if (same && lane == ii[u]) my_rep = cj[u];
+        }
+    }
+
+    // ---- other multi-block nodes (sparse branches >= 136 bytes): generic compare, one at a time ----
+    todo = __ballot(valid && len >= RATE && len != BRANCH_LEN && cand != j);
+    while (todo) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t ll = lane_u32(len, i);
+        const uint8_t* o = a.v.nodes + lane_u64(b_lo, b_hi, i);
+        const uint8_t* c = a.v.nodes + lane_u64(cb_lo, cb_hi, i);
+        const bool eq = wave_bytes_equal(o, c, ll, lane);
+        if (lane == i && eq) my_rep = cand;
+    }
+
+    // ---- results + per-list compaction of the nodes that must be hashed ----
+    const bool need = listed && my_rep == j;
+    const uint32_t cls = valid ? node_list(len) : CLASS_NONE;
+    if (j < NT) a.rep[j] = my_rep;
+    uint32_t my_rank = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < N_LIST; ++c) {
+        const unsigned long long m = __ballot(need && cls == c);
+        if (lane == 0) s_cnt[wave][c] = (uint32_t)__popcll(m);
+        if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (tid < N_LIST) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < WAVES; ++w) tot += s_cnt[w][tid];
+        s_base[tid] = tot ? atomicAdd(&a.hdr[tid], tot) : 0u;
+    }
+    __syncthreads();
+    if (need) {
+        uint32_t at = s_base[cls] + my_rank;
+        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
+        a.ent[(uint64_t)cls * NT + at] = j;
+    }
+}
+
+// ---------------------------------------------------------------- canonical full branch, per rate block
+// f9 02 11 | 16 x (a0 + 32 bytes) | 80 = 532 bytes: what the marker bytes of rate block K (bytes
+// [136 K, 136 K + 136) of the node, as 34 little-endian dwords) must be.  The hash kernels hold exactly
+// these dwords in registers when they absorb the block, so checking the form of a node there costs ~10
+// VALU operations per block and no memory traffic.
+struct BranchMask {
+    uint32_t m[4][RATE_DWORDS];
+    uint32_t v[4][RATE_DWORDS];
+};
+constexpr BranchMask make_branch_mask() {
+    BranchMask r{};
+    for (uint32_t q = 0; q < BRANCH_LEN; ++q) {
+        int want = -1;
+        if (q == 0) want = 0xf9;
+        else if (q == 1) want = 0x02;
+        else if (q == 2) want = 0x11;
+        else if (q == BRANCH_LEN - 1u) want = 0x80;
+        else if ((q - 3u) % 33u == 0u) want = 0xa0;
+        if (want >= 0) {
+            const uint32_t k = q / RATE, i = (q % RATE) / 4u, sh = 8u * (q % 4u);
+            r.m[k][i] |= 0xffu << sh;
+            r.v[k][i] |= (uint32_t)want << sh;
+        }
+    }
+    return r;
+}
+constexpr BranchMask BRANCH_MASK = make_branch_mask();
+
+template <int K, int NDW>
+PHANT_DEV uint32_t branch_block_bad_k(const uint32_t (&d)[RATE_DWORDS]) {
+    uint32_t bad = 0;
+#pragma unroll
+    for (int i = 0; i < NDW; ++i) {
+        if (BRANCH_MASK.m[K][i] != 0u) bad |= (d[i] ^ BRANCH_MASK.v[K][i]) & BRANCH_MASK.m[K][i];
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------- one node per lane through the sponge
+// What a hash lane knows about its node.
+struct LaneNode {
+    const uint8_t* ptr;     // first byte
+    uint32_t len;
+    bool active;
+};
+
+// One rate block of a 532-byte node into the sponge: K = which block (0..3), NDW = its message dwords (34, or 31 for
+// the last block: 124 message bytes, then the padding -- two constants, nothing masked per lane, nothing read beyond
+// the node's last byte).  Returns nonzero iff the block contradicts the canonical full branch.
+// (Tried and dropped, DESIGN.md section 9: absorbing in two halves behind a compiler fence to stay at <= 96 VGPRs / 5
+// waves per SIMD -- the second memory round trip per block cost more than the fifth wave gave.)
+template <int K, int NDW>
+PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
+    uint32_t d[RATE_DWORDS];
+    if constexpr (NDW == 34) {
+        load_block_wide(d, p);
+    } else {
+        static_assert(NDW == 31, "last block of a 532-byte node: 124 message bytes");
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            const uint4 v = load16u(p + 16 * c);
+            d[4 * c] = v.x;
+            d[4 * c + 1] = v.y;
+            d[4 * c + 2] = v.z;
+            d[4 * c + 3] = v.w;
+        }
+        const U32x3 t = *reinterpret_cast<const U32x3*>(p + 112);
+        d[28] = t.x;
+        d[29] = t.y;
+        d[30] = t.z;
+        d[31] = 0x00000001u;  // pad 0x01 right behind the 124 message bytes
+        d[32] = 0u;
+        d[33] = 0x80000000u;  // ... 0x80 in the last byte of the rate
+    }
+    const uint32_t bad = branch_block_bad_k<K, NDW>(d);
+    xor_block(s, d);
+    return bad;
+}
+
+// Keccak-256 of a node that is exactly 532 bytes long, for every lane of the wave (wave-uniform: all active lanes
+// have such a node; inactive lanes hash whatever `ptr` points at -- the launcher gives them a readable one).  Three
+// full rate blocks and a last one of 124 message bytes: the padding is two constants, nothing is masked per lane, and
+// nothing beyond the node's last byte is read.  Returns nonzero iff the node is NOT the canonical full branch.
+PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
+    sponge_zero(s);
+    uint32_t bad = absorb_b532_block<0, 34>(s, p);
+    keccak_f1600(s);
+    bad |= absorb_b532_block<1, 34>(s, p + RATE);
+    keccak_f1600(s);
+    bad |= absorb_b532_block<2, 34>(s, p + 2u * RATE);
+    keccak_f1600(s);
+    bad |= absorb_b532_block<3, 31>(s, p + 3u * RATE);
+    keccak_f1600(s);
+    return bad;
+}
+
+// Keccak-256 of one node per lane, any lengths (exec-masked loop: the wave runs as many permutations as its longest
+// node needs).  `safe_end`: one past the last byte of the node blob.  No look at the node's form: 532-byte nodes go
+// through hash_b532.
+PHANT_DEV void hash_any(Sponge& s, const uint8_t* __restrict__ p, uint32_t len, const uint8_t* __restrict__ safe_end) {
+    sponge_zero(s);
+    uint32_t left = len;
+    while (left >= RATE) {
+        absorb_full_block_wide(s, p);
+        keccak_f1600(s);
+        p += RATE;
+        left -= RATE;
+    }
+    if (p + RATE <= safe_end) {
+        uint32_t d[RATE_DWORDS];
+        load_block_wide(d, p);  // the whole window; bytes past the node are masked off
+        absorb_loaded_final(s, d, left);
+    } else {  // last node of the blob: narrow loads that never leave the message
+        const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+        absorb_final_block(s, reinterpret_cast<const uint32_t*>(p - sh), sh, left);
+    }
+    keccak_f1600(s);
+}
+
+// Keccak-256 of one node per lane where every lane's node has the SAME length `len` < 136 (wave-uniform): the
+// padding masks are scalars.
+PHANT_DEV void hash_short_uniform(Sponge& s, const uint8_t* __restrict__ p, uint32_t len /* wave-uniform */) {
+    sponge_zero(s);
+    uint32_t d[RATE_DWORDS];
+    load_block_wide(d, p);
+#pragma unroll
+    for (int i = 0; i < (int)RATE_DWORDS; ++i) {
+        const int m = (int)len - 4 * i;  // message bytes inside this dword (scalar)
+        const uint32_t t = 1u << ((m & 3) * 8);
+        const uint32_t keep = m >= 4 ? 0xffffffffu : (m <= 0 ? 0u : t - 1u);
+        uint32_t pad = (m >= 0 && m < 4) ? t : 0u;
+        if (i == (int)RATE_DWORDS - 1) pad ^= 0x80000000u;
+        const uint32_t v = (d[i] & keep) ^ pad;
+        if (i & 1) s.hi[i >> 1] = v;
+        else s.lo[i >> 1] = v;
+    }
+    keccak_f1600(s);
+}
+
+// proof owning node j: pfn[p] <= j < pfn[p+1] (only root nodes ask)
+PHANT_DEV uint32_t find_proof(const uint32_t* __restrict__ pfn, uint32_t n, uint32_t j) {
+    uint32_t lo = 0, hi = n;  // invariant (for monotone pfn): pfn[lo] <= j < pfn[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (pfn[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// Where the 32 bytes node j must hash to are (nullptr: not known without decoding the parent).  `d`: depth of the
+// node in its proof, `root`: the proof's root index, `nib_parent`: the key nibble at depth d - 1 (or >= 16: none),
+// `b`: byte offset of node j.  The parent of node j is node j - 1 = bytes [node_off[j-1], b); if that is 532 bytes
+// long, the reference of a full branch for that nibble starts at byte 4 + 33 nib (link_kernel only believes the
+// comparison when the parent turns out to be the canonical full branch).
+PHANT_DEV const uint8_t* ref_location(const Args& a, uint32_t j, uint32_t d, uint32_t root, uint32_t nib_parent, uint64_t b) {
+    if (d == 0u) return root < a.v.n_roots ? a.v.roots + 32ull * root : nullptr;
+    if (nib_parent >= 16u) return nullptr;
+    const uint64_t pb = a.v.node_off[j - 1u];
+    if (pb > b || b - pb != BRANCH_LEN) return nullptr;
+    return a.v.nodes + pb + (4u + 33u * nib_parent);
+}
+
+struct RefBytes { uint4 lo, hi; };
+PHANT_DEV RefBytes load_ref(const uint8_t* q) {
+    RefBytes r;
+    r.lo = r.hi = make_uint4(0, 0, 0, 0);
+    if (q) {
+        r.lo = load16u(q);
+        r.hi = load16u(q + 16);
+    }
+    return r;
+}
+PHANT_DEV bool digest_equals(const Sponge& s, const RefBytes& r) {
+    const uint32_t diff = (s.lo[0] ^ r.lo.x) | (s.hi[0] ^ r.lo.y) | (s.lo[1] ^ r.lo.z) | (s.hi[1] ^ r.lo.w) |
+                          (s.lo[2] ^ r.hi.x) | (s.hi[2] ^ r.hi.y) | (s.lo[3] ^ r.hi.z) | (s.hi[3] ^ r.hi.w);
+    return diff == 0u;
+}
+PHANT_DEV void store_node_digest(const Args& a, uint32_t j, const Sponge& s) {
+    uint4* o = reinterpret_cast<uint4*>(a.digest + 8ull * j);
+    o[0] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
+    o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+}
+
+// ---------------------------------------------------------------- hash, shallow tier: one list chunk per wave
+// Wave q hashes chunk q (64 nodes of one list, the lists with the most rate blocks first) and exits; the grid covers
+// the worst case and the dispatcher keeps every SIMD full until the lists run out.  A short last chunk repeats its
+// last node (same results stored twice) so that no lane is ever idle-masked.
+__global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
+    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t N = a.total_nodes;
+    // On the critical path (plan -> dedup -> this -> link -> walk) with fewer waves than the chip has SIMDs, while the
+    // deep tier's waves, which are many and in nobody's way, compete for the same issue slots: go first.
+    __builtin_amdgcn_s_setprio(2);
+    // queue order: 8+ blocks, 7, 6, 5, [532-byte list], 4 (others), 3, 2, 1
+    uint32_t cls = N_LIST, idx = 0;
+#pragma unroll
+    for (int o = 0; o < (int)N_LIST; ++o) {
+        const int c = o < 4 ? 7 - o : (o == 4 ? (int)LIST_B532 : 8 - o);
+        const uint32_t cnt = a.hdr[c];
+        const uint32_t chunks = (cnt + 63u) / 64u;
+        if (cls == N_LIST) {
+            if (q < chunks) {
+                cls = (uint32_t)c;
+                idx = q * 64u + lane;
+                idx = idx < cnt ? idx : cnt - 1u;
+            } else {
+                q -= chunks;
+            }
+        }
+    }
+    if (cls == N_LIST) return;
+    const uint32_t j = a.ent[(uint64_t)cls * N + idx];
+    const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
+    const uint64_t b = a.v.node_off[j];
+    const uint32_t len = (uint32_t)(a.v.node_off[j + 1] - b);
+    const uint8_t* const p = a.v.nodes + b;
+
+    // the reference this node must hash to: requested now, compared after the last permutation
+    const uint8_t* refp = nullptr;
+    if (!a.all_listed) {
+        const uint32_t m = a.meta[j];
+        const uint32_t d = m >> 8;
+        uint32_t root = 0, nibp = 16u;
+        if (d == 0u) {
+            if (a.v.root_idx) root = a.v.root_idx[find_proof(a.v.proof_first_node, a.v.n, j)];
+        } else {
+            const uint32_t mp = a.meta[j - 1u];
+            if ((mp & PRE_NIB) && (mp >> 8) == d - 1u) nibp = (mp >> 4) & 15u;
+        }
+        if (m & PRE_STAMP) refp = ref_location(a, j, d, root, nibp, b);
+    }
+    const RefBytes ref = load_ref(refp);
+
+    Sponge s;
+    uint32_t bad;
+    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
+    if (cls == LIST_B532) {
+        bad = hash_b532(s, p);
+    } else if (cls == 0u && __ballot(len != len0 || p + RATE > safe_end) == 0ull) {
+        hash_short_uniform(s, p, len0);  // one length below the rate for the whole chunk: BASELINE's leaves
+        bad = 1u;
+    } else {
+        hash_any(s, p, len, safe_end);
+        bad = 1u;
+    }
+    uint32_t ns = NS_HASHED | (bad == 0u ? NS_CANON : 0u);
+    if (refp) ns |= NS_LINK_CHECKED | (digest_equals(s, ref) ? NS_LINK_OK : 0u);
+    a.nstat[j] = (uint8_t)ns;
+    store_node_digest(a, j, s);
+}
+
+// ---------------------------------------------------------------- hash, deep tier: in place
+// Wave = 64 consecutive proofs at one depth, lane = proof.  Nothing is looked up: a proof's node at depth d is node
+// proof_first_node[p] + d, its key nibble comes from the key.  The grid's y covers DEEP_LEVELS depths per pass
+// (deepest last: the leaves, the short chunks, fill the tail); a wave whose proofs are all shorter leaves at once.
+constexpr uint32_t DEEP_LEVELS = 8;
+
+__global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const uint32_t waves_per_level) {
+    // the 32 reference bytes wait in LDS while the sponge has the registers ([dword][lane]: conflict-free)
+    __shared__ uint32_t s_ref[8][256];
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t level = w / waves_per_level;  // 0 .. DEEP_LEVELS - 1
+    const uint32_t p = (w % waves_per_level) * 64u + lane;
+    const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
+    const uint32_t nn = 2u * a.v.key_len;
+    // (a wave normally makes one trip: everything about the proof is re-read per trip rather than kept in
+    // registers across the sponge)
+    for (uint32_t d = a.shallow + level;; d += DEEP_LEVELS) {
+        uint32_t first = 0, count = 0, root = 0;
+        if (p < a.v.n) {
+            first = a.v.proof_first_node[p];
+            const uint32_t last = a.v.proof_first_node[p + 1];
+            if (last >= first && last <= a.total_nodes) count = last - first;
+            if (a.v.root_idx) root = a.v.root_idx[p];
+        }
+        if (__ballot(d < count) == 0ull) break;
+        const uint32_t j = first + d;
+        bool active = d < count;
+        uint64_t b = 0;
+        uint32_t len = 0;
+        if (active) {
+            const uint64_t e = a.v.node_off[j + 1];
+            b = a.v.node_off[j];
+            active = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull;
+            len = active ? (uint32_t)(e - b) : 0u;
+        }
+        const bool roomy = a.v.nodes_len >= BRANCH_LEN;
+        const uint8_t* const ptr = a.v.nodes + (active ? b : 0ull);
+        const uint8_t* refp = nullptr;
+        if (active) {
+            const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * p;
+            const uint32_t nibp = (d >= 1u && d - 1u < nn) ? key_nibble(key, d - 1u) : 16u;
+            refp = ref_location(a, j, d, root, nibp, b);
+        }
+        {
+            const RefBytes ref = load_ref(refp);
+            const uint32_t t = threadIdx.x;
+            s_ref[0][t] = ref.lo.x; s_ref[1][t] = ref.lo.y; s_ref[2][t] = ref.lo.z; s_ref[3][t] = ref.lo.w;
+            s_ref[4][t] = ref.hi.x; s_ref[5][t] = ref.hi.y; s_ref[6][t] = ref.hi.z; s_ref[7][t] = ref.hi.w;
+        }
+        {   // reporting only: nodes hashed per rate-block class (striped counters, one add per wave and class)
+            const uint32_t cls = len / RATE < N_CLASS ? len / RATE : N_CLASS - 1u;
+            const unsigned long long any = __ballot(active);
+            const uint32_t c0 = any ? lane_u32(cls, (uint32_t)__builtin_ctzll(any)) : 0u;
+            const unsigned long long same = __ballot(active && cls == c0);
+            if (same == any) {
+                if (lane == 0 && any) atomicAdd(&a.hdr[HDR_STAT + N_CLASS * (w % HDR_STAT_STRIPES) + c0], (uint32_t)__popcll(any));
+            } else if (active) {
+                atomicAdd(&a.hdr[HDR_STAT + N_CLASS * (w % HDR_STAT_STRIPES) + cls], 1u);
+            }
+        }
+        // what must survive the sponge: one word of flags (and the lane's proof index)
+        enum : uint32_t { F_ACTIVE = 1u, F_REF = 2u, F_CANON = 4u };
+        uint32_t flags = (active ? F_ACTIVE : 0u) | (refp != nullptr ? F_REF : 0u);
+        Sponge s;
+        const bool is532 = active && len == BRANCH_LEN;
+        if (roomy && __ballot(is532) != 0ull) {
+            // the lanes with a 532-byte node (the others run along on a readable address: the blob's first bytes)
+            const uint32_t bad = hash_b532(s, is532 ? ptr : a.v.nodes);
+            if (is532 && bad == 0u) flags |= F_CANON;
+        }
+        const bool rest = active && !(roomy && is532);
+        if (__ballot(rest) != 0ull) {
+            const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
+            if (len0 < RATE && __ballot(!rest || len != len0 || ptr + RATE > safe_end) == 0ull) {
+                hash_short_uniform(s, ptr, len0);  // every lane, one length below the rate: BASELINE's leaves
+            } else if (rest) {
+                hash_any(s, ptr, len, safe_end);
+            }
+        }
+        if (flags & F_ACTIVE) {
+            const uint32_t j = a.v.proof_first_node[p] + d;  // (re-read: not kept across the sponge)
+            uint32_t ns = NS_HASHED | ((flags & F_CANON) ? NS_CANON : 0u);
+            if (flags & F_REF) {
+                const uint32_t t = threadIdx.x;
+                RefBytes ref;
+                ref.lo = make_uint4(s_ref[0][t], s_ref[1][t], s_ref[2][t], s_ref[3][t]);
+                ref.hi = make_uint4(s_ref[4][t], s_ref[5][t], s_ref[6][t], s_ref[7][t]);
+                ns |= NS_LINK_CHECKED | (digest_equals(s, ref) ? NS_LINK_OK : 0u);
+            }
+            a.nstat[j] = (uint8_t)ns;
+            store_node_digest(a, j, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- link
+// One lane per node: the walk's code for node j.
+//   LINK_FAST     hash matches, node is a canonical full branch stamped with this key's nibble: step over
+//   LINK_HASH_OK  hash matches, node must be decoded (BASELINE: the account leaf)
+//   LINK_BAD_HASH / LINK_SLOW   settle the proof (DESIGN.md section 3 order: they come after BAD_INPUT)
+//   LINK_GENERIC  nothing established (parent not canonical, offsets bad, ...): the walk does it all
+// A code of a node at depth >= 1 is only ever consulted by a walk that stepped over the parent with LINK_FAST, i.e.
+// the parent IS a canonical full branch -- which is what makes "the 32 bytes at 4 + 33 nibble" its reference.
+enum : uint32_t { LINK_GENERIC = 0, LINK_FAST = 1, LINK_HASH_OK = 2, LINK_BAD_HASH = 3, LINK_SLOW = 4 };
+
+PHANT_DEV uint32_t code_of(uint32_t ns, uint32_t m) {
+    if (!(ns & NS_LINK_CHECKED)) return LINK_GENERIC;
+    if (!(ns & NS_LINK_OK)) return LINK_BAD_HASH;
+    return ((m & PRE_NIB) && (ns & NS_CANON)) ? LINK_FAST : LINK_HASH_OK;
+}
+
+__global__ void __launch_bounds__(256) link_kernel(const Args a) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= a.total_nodes) return;
+    uint32_t code = LINK_GENERIC;
+    const uint32_t m = a.meta[j];
+    if (m & PRE_STAMP) {
+        const uint32_t d = m >> 8;
+        const uint32_t r = (m & PRE_GROUP) ? a.rep[j] : j;
+        if (r == j) {
+            const uint32_t ns = a.nstat[j];
+            code = (ns & NS_HASHED) ? code_of(ns, m) : LINK_GENERIC;  // (not hashed: bad offsets; the walk reports it)
+        } else if (r >= a.total_nodes) {
+            code = LINK_SLOW;
+        } else {
+            const uint32_t ns = a.nstat[r];
+            const uint32_t mr = a.meta[r];
+            if (!(ns & NS_HASHED)) {
+                code = LINK_SLOW;  // a representative that was not hashed itself
+            } else if (d == 0u) {
+                // a copy of another proof's root node: compare the representative's digest with THIS proof's root
+                uint32_t root = 0;
+                if (a.v.root_idx) root = a.v.root_idx[find_proof(a.v.proof_first_node, a.v.n, j)];
+                if (root < a.v.n_roots) {
+                    const RefBytes want = load_ref(a.v.roots + 32ull * root);
+                    const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * r);
+                    const uint4 d0 = dg[0], d1 = dg[1];
+                    const uint32_t diff = (d0.x ^ want.lo.x) | (d0.y ^ want.lo.y) | (d0.z ^ want.lo.z) | (d0.w ^ want.lo.w) |
+                                          (d1.x ^ want.hi.x) | (d1.y ^ want.hi.y) | (d1.z ^ want.hi.z) | (d1.w ^ want.hi.w);
+                    code = diff ? LINK_BAD_HASH : (((m & PRE_NIB) && (ns & NS_CANON)) ? LINK_FAST : LINK_HASH_OK);
+                }
+            } else if ((mr & PRE_STAMP) && (mr >> 8) >= 1u && r >= 1u) {
+                // the representative's link result is this node's if it was the same comparison: the parents
+                // (nodes j - 1 and r - 1) are the same bytes -- same representative -- and the same key nibble
+                const uint32_t mp = a.meta[j - 1u], mq = a.meta[r - 1u];
+                const uint32_t pj = (mp & PRE_GROUP) ? a.rep[j - 1u] : j - 1u;
+                const uint32_t pr = (mq & PRE_GROUP) ? a.rep[r - 1u] : r - 1u;
+                if ((mp & PRE_NIB) && (mq & PRE_NIB) && (mp >> 8) == d - 1u && (mq >> 8) == (mr >> 8) - 1u &&
+                    ((mp >> 4) & 15u) == ((mq >> 4) & 15u) && pj == pr) {
+                    code = code_of(ns, m);
+                } else if ((mp & PRE_NIB) && (mp >> 8) == d - 1u) {
+                    // not the same comparison (the representative sits in a proof whose parent node differs, e.g. a
+                    // damaged one): compare the representative's digest with the reference in THIS proof's parent
+                    const uint8_t* refp = ref_location(a, j, d, 0u, (mp >> 4) & 15u, a.v.node_off[j]);
+                    if (refp) {
+                        const RefBytes want = load_ref(refp);
+                        const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * r);
+                        const uint4 d0 = dg[0], d1 = dg[1];
+                        const uint32_t diff = (d0.x ^ want.lo.x) | (d0.y ^ want.lo.y) | (d0.z ^ want.lo.z) | (d0.w ^ want.lo.w) |
+                                              (d1.x ^ want.hi.x) | (d1.y ^ want.hi.y) | (d1.z ^ want.hi.z) | (d1.w ^ want.hi.w);
+                        code = diff ? LINK_BAD_HASH : (((m & PRE_NIB) && (ns & NS_CANON)) ? LINK_FAST : LINK_HASH_OK);
+                    }
+                }
+            }
+        }
+    }
+    a.link[j] = (uint8_t)code;
+}
+
+// ---------------------------------------------------------------- walk
+// Nodes the generic decoder opens (for BASELINE's proofs: the 112-byte account leaf) are first copied
+// into a per-lane LDS slot with 16-byte loads, together with the key: the RLP decoder and the path
+// comparison read single bytes one after the other, and from HBM/L2 every one of those ~100 dependent
+// reads cost a full cache round trip (the per-CU L1 does not hold 256 lanes' nodes).
+constexpr uint32_t WALK_STAGE_BYTES = 192;  // nodes up to this size are staged; longer ones are read in place
+constexpr uint32_t WALK_KEY_BYTES = 32;
+constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  // odd stride: no bank pile-up
+
+// digest of node j as the pipeline knows it: the node's own, or its representative's (identical bytes)
+PHANT_DEV bool known_digest(const Args& a, uint32_t j, uint32_t& rj) {
+    const uint32_t m = a.meta[j];
+    rj = (m & PRE_GROUP) ? a.rep[j] : j;
+    return rj < a.total_nodes && (a.nstat[rj] & NS_HASHED);
+}
+
+__global__ void __launch_bounds__(256) walk_kernel(const Args a) {
+    __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool in = i < a.v.n;
+    uint32_t status = PHANT_PROOF_PRESENT;
+    if (in) {
+        uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
+        const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
+        const uint8_t* const nodes_end = a.v.nodes + a.v.nodes_len;
+        uint64_t voff = 0;
+        uint32_t vlen = 0;
+        const uint32_t first = a.v.proof_first_node[i], last = a.v.proof_first_node[i + 1];
+        const uint32_t r = a.v.root_idx ? a.v.root_idx[i] : 0u;
+        if (last < first || last > a.total_nodes || r >= a.v.n_roots) {
+            status = PHANT_PROOF_BAD_INPUT;
+        } else if (last == first) {  // no nodes: only the empty trie is proven that way (absence)
+            uint32_t rw[8];
+            GlobalBytes rb{a.v.roots + 32ull * r};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rw[k] = rb.u32(4 * k);
+            status = is_empty_root(rw) ? PHANT_PROOF_ABSENT : PHANT_PROOF_INVALID_EMPTY;
+        } else if (a.hdr[HDR_PFN_BROKEN] != 0u) {
+            status = STATUS_NEEDS_SLOW;  // stamps may be another proof's: nothing derived from them is used
+        } else {
+            const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * i;
+            const uint32_t nn = 2u * a.v.key_len;
+            // Two pointers, never merged into one variable: the compiler only emits ds_read for the LDS copies
+            // if each access site sees where its pointer comes from (a pointer that may be either turns every
+            // byte access into a flat load, which goes through the vector-memory path even when it hits LDS).
+            const uint8_t* const slot_key = reinterpret_cast<const uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+            const bool key_in_lds = a.v.key_len <= WALK_KEY_BYTES;  // the lane's own slot: no barrier needed
+            if (key_in_lds) {
+                uint8_t* kdst = reinterpret_cast<uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+                for (uint32_t t = 0; t < a.v.key_len; ++t) kdst[t] = key[t];
+            }
+            WalkState w;
+            w.pos = 0;
+            w.status = PHANT_PROOF_BAD_INPUT;
+            w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
+            uint32_t used = first;
+            status = 0xffffffffu;
+
+            // ---- the run of nodes link_kernel settled: one byte each, eight at a time ----
+            bool hash_known = false;  // the node at `used` is already known to hash to its reference
+            for (bool run = true; run && used < last;) {
+                const uint8_t* lp = a.link + used;  // link[] is padded: 8 bytes past the last node are readable
+                const uint32_t c0 = load4u(lp), c1 = load4u(lp + 4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (!run || used >= last) continue;
+                    const uint32_t c = ((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 0xffu;
+                    if (c == LINK_FAST) {  // depth == pos and nibble == key nibble by construction of the stamp
+                        ++used;
+                        w.pos += 1;
+                    } else {
+                        run = false;
+                        if (c == LINK_BAD_HASH) status = PHANT_PROOF_BAD_HASH;
+                        else if (c == LINK_SLOW) status = STATUS_NEEDS_SLOW;
+                        else hash_known = c == LINK_HASH_OK;
+                    }
+                }
+            }
+
+            // ---- everything else: the reference the next node must hash to, then node by node ----
+            uint32_t want[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (status == 0xffffffffu && !hash_known) {
+                if (used == first) {
+                    GlobalBytes rb{a.v.roots + 32ull * r};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
+                } else {
+                    // stepped over node used - 1 (a canonical full branch): its slot for this key's nibble
+                    const uint32_t mp = a.meta[used - 1u];
+                    const uint8_t* rb = a.v.nodes + a.v.node_off[used - 1u] + (4u + 33u * ((mp >> 4) & 15u));
+                    const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
+                    want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
+                    want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
+                }
+            }
+            bool by_hash = true;
+            const uint8_t* cur = nullptr;
+            uint32_t cur_len = 0, opened = 0;
+            const uint8_t* staged_from = nullptr;  // global address of the node currently in the slot
+            for (;;) {
+                if (status != 0xffffffffu) break;  // settled from the link codes
+                ++opened;
+                if (by_hash) {
+                    if (used == last) {
+                        status = PHANT_PROOF_MISSING_NODE;
+                        break;
+                    }
+                    const uint32_t j = used;
+                    const uint64_t b = a.v.node_off[j], e = a.v.node_off[j + 1];
+                    if (e < b || e > a.v.nodes_len || e - b > 0x7fffffffull) {
+                        status = PHANT_PROOF_BAD_INPUT;
+                        break;
+                    }
+                    cur = a.v.nodes + b;
+                    cur_len = (uint32_t)(e - b);
+                    ++used;
+                    if (hash_known) {
+                        hash_known = false;  // a hash lane compared the digest with the parent's reference
+                    } else {
+                        uint32_t rj;
+                        if (!known_digest(a, j, rj)) {
+                            status = STATUS_NEEDS_SLOW;
+                            break;
+                        }
+                        const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
+                        const uint4 d0 = dg[0], d1 = dg[1];
+                        const uint32_t diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
+                                              (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
+                        if (diff) {
+                            status = PHANT_PROOF_BAD_HASH;
+                            break;
+                        }
+                    }
+                    // a node reached through a hash: stage it (embedded children are decoded inside their
+                    // parent's copy)
+                    staged_from = nullptr;
+                    const uint32_t padded = (cur_len + 15u) & ~15u;
+                    if (cur_len <= WALK_STAGE_BYTES && cur + padded <= nodes_end) {
+                        for (uint32_t o = 0; o < padded; o += 16u) {
+                            const uint4 q = load16u(cur + o);
+                            slot[o / 4u] = q.x;
+                            slot[o / 4u + 1u] = q.y;
+                            slot[o / 4u + 2u] = q.z;
+                            slot[o / 4u + 3u] = q.w;
+                        }
+                        staged_from = cur;
+                    }
+                }
+                // decode + one step of the walk, with the node and the key each read from where they are
+                auto step_from = [&](const uint8_t* nb, const uint8_t* kp) __attribute__((always_inline)) -> uint32_t {
+                    GlobalBytes nd{nb};
+                    const uint32_t st = walk_node(nd, cur_len, kp, nn, w);
+                    if (st == STEP_HASH) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) want[k] = nd.u32(w.ref_pay + 4 * k);
+                    }
+                    return st;
+                };
+                uint32_t step;
+                if (!key_in_lds) step = step_from(cur, key);
+                else if (staged_from) step = step_from(slot_node + (cur - staged_from), slot_key);
+                else step = step_from(cur, slot_key);
+                if (step == STEP_DONE) break;
+                if (step == STEP_HASH) {
+                    by_hash = true;
+                } else {
+                    cur = cur + w.ref_pay;
+                    cur_len = w.ref_total;
+                    by_hash = false;
+                }
+            }
+            if (opened > 1u) atomicAdd(&a.hdr[HDR_OPENED], opened);
+            if (status == 0xffffffffu) {
+                status = w.status;
+                if (status == PHANT_PROOF_PRESENT || status == PHANT_PROOF_ABSENT) {
+                    if (used != last) {
+                        status = PHANT_PROOF_EXTRA_NODES;
+                    } else if (status == PHANT_PROOF_PRESENT) {
+                        voff = (uint64_t)(cur - a.v.nodes) + w.value_pay;
+                        vlen = w.value_len;
+                    }
+                }
+            }
+        }
+        if (status == STATUS_NEEDS_SLOW) atomicAdd(&a.hdr[HDR_SLOW], 1u);  // slow_kernel's: verified from scratch
+        a.v.status[i] = (uint8_t)status;
+        if (a.v.value_off) a.v.value_off[i] = voff;
+        if (a.v.value_len) a.v.value_len[i] = vlen;
+    }
+    // the verdict, while every status passes through this kernel anyway (fail_count was zeroed by plan_kernel)
+    if (a.v.fail_count) {
+        const bool bad = in && !(status == PHANT_PROOF_PRESENT || status == PHANT_PROOF_ABSENT || status == STATUS_NEEDS_SLOW);
+        if (a.v.root_idx == nullptr || a.v.n_roots == 1) {
+            const unsigned long long m = __ballot(bad);
+            if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&a.v.fail_count[0], (uint32_t)__popcll(m));
+        } else if (bad) {
+            const uint32_t r = a.v.root_idx[i];
+            if (r < a.v.n_roots) atomicAdd(&a.v.fail_count[r], 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- second opinion
+// Proofs the walk marked 0xff ("could not be settled from the tables": a representative that was not hashed itself, a
+// digest nobody computed, proof_first_node going backwards) are verified from scratch by one lane each.  Never seen
+// on a well-formed witness: every workgroup first looks at the walk's count of such proofs and leaves when it is 0.
+// A small grid that strides over the proofs.
+PHANT_DEV void slow_one(const struct Args& a, uint32_t i);
+__global__ void __launch_bounds__(256) slow_kernel(const Args a) {
+    if (a.hdr[HDR_SLOW] == 0u) return;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.v.n; i += gridDim.x * 256u) slow_one(a, i);
+}
+PHANT_DEV void slow_one(const Args& a, uint32_t i) {
+    if (a.v.status[i] != STATUS_NEEDS_SLOW) return;
+    uint64_t voff;
+    uint32_t vlen;
+    const uint32_t st = verify_one(a.v, i, voff, vlen);
+    a.v.status[i] = (uint8_t)st;
+    if (a.v.value_off) a.v.value_off[i] = voff;
+    if (a.v.value_len) a.v.value_len[i] = vlen;
+    if (a.v.fail_count && !(st == PHANT_PROOF_PRESENT || st == PHANT_PROOF_ABSENT)) {
+        const uint32_t r = a.v.root_idx ? a.v.root_idx[i] : 0u;
+        if (r < a.v.n_roots) atomicAdd(&a.v.fail_count[r], 1u);
+    }
+}
+
+// ---------------------------------------------------------------- node-set witnesses
+// A witness that ships every node ONCE, in any order (what a block builder that deduplicates its proofs
+// sends): references are resolved by hash.  Hash every node (the class lists + hash_list_kernel, nothing to
+// deduplicate, no links), put digest -> node into an open-addressing table, then one lane per key walks from its
+// root.  Semantics: DESIGN.md section 3 with "the node a 32-byte reference points to" = the node of the set with
+// that digest (none: MISSING_NODE; BAD_HASH / EXTRA_NODES / INVALID_EMPTY cannot occur).
+constexpr uint32_t SET_EMPTY = 0xffffffffu;
+
+__global__ void __launch_bounds__(256) nodeset_insert_kernel(const Args a, uint32_t* tab, uint32_t tab_mask) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= a.total_nodes) return;
+    const uint64_t b = a.v.node_off[j], e = a.v.node_off[j + 1];
+    if (!(e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull)) return;  // never hashed: not in the set
+    uint32_t slot = a.digest[8ull * j] & tab_mask;
+    for (;;) {  // the table has >= 2 x total_nodes slots: terminates
+        const uint32_t prev = atomicCAS(&tab[slot], SET_EMPTY, j);
+        if (prev == SET_EMPTY) return;
+        // an identical node already there: one of them is enough (same digest => same bytes, up to Keccak)
+        const uint4* x = reinterpret_cast<const uint4*>(a.digest + 8ull * prev);
+        const uint4* y = reinterpret_cast<const uint4*>(a.digest + 8ull * j);
+        const uint4 x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+        if (((x0.x ^ y0.x) | (x0.y ^ y0.y) | (x0.z ^ y0.z) | (x0.w ^ y0.w) | (x1.x ^ y1.x) | (x1.y ^ y1.y) | (x1.z ^ y1.z) |
+             (x1.w ^ y1.w)) == 0u)
+            return;
+        slot = (slot + 1u) & tab_mask;
+    }
+}
+
+// the node of the set whose digest is want[], or SET_EMPTY
+PHANT_DEV uint32_t nodeset_find(const Args& a, const uint32_t* __restrict__ tab, uint32_t tab_mask,
+                                const uint32_t (&want)[8]) {
+    uint32_t slot = want[0] & tab_mask;
+    for (;;) {
+        const uint32_t j = tab[slot];
+        if (j == SET_EMPTY) return SET_EMPTY;
+        const uint4* x = reinterpret_cast<const uint4*>(a.digest + 8ull * j);
+        const uint4 x0 = x[0], x1 = x[1];
+        if (((x0.x ^ want[0]) | (x0.y ^ want[1]) | (x0.z ^ want[2]) | (x0.w ^ want[3]) | (x1.x ^ want[4]) | (x1.y ^ want[5]) |
+             (x1.z ^ want[6]) | (x1.w ^ want[7])) == 0u)
+            return j;
+        slot = (slot + 1u) & tab_mask;
+    }
+}
+
+__global__ void __launch_bounds__(256) nodeset_walk_kernel(const Args a, const uint32_t* tab, uint32_t tab_mask) {
+    __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.v.n) return;
+    uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
+    const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
+    const uint8_t* const nodes_end = a.v.nodes + a.v.nodes_len;
+    uint64_t voff = 0;
+    uint32_t vlen = 0, status = 0xffffffffu;
+    const uint32_t r = a.v.root_idx ? a.v.root_idx[i] : 0u;
+    if (r >= a.v.n_roots) {
+        status = PHANT_PROOF_BAD_INPUT;
+    } else {
+        const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * i;
+        const uint32_t nn = 2u * a.v.key_len;
+        const uint8_t* const slot_key = reinterpret_cast<const uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+        const bool key_in_lds = a.v.key_len <= WALK_KEY_BYTES;
+        if (key_in_lds) {
+            uint8_t* kdst = reinterpret_cast<uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+            for (uint32_t t = 0; t < a.v.key_len; ++t) kdst[t] = key[t];
+        }
+        uint32_t want[8];
+        {
+            GlobalBytes rb{a.v.roots + 32ull * r};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
+        }
+        WalkState w;
+        w.pos = 0;
+        w.status = PHANT_PROOF_BAD_INPUT;
+        w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
+        bool by_hash = true, at_root = true;
+        const uint8_t* cur = nullptr;
+        uint32_t cur_len = 0;
+        const uint8_t* staged_from = nullptr;
+        for (;;) {
+            if (by_hash) {
+                const uint32_t j = nodeset_find(a, tab, tab_mask, want);
+                if (j == SET_EMPTY) {  // (the root of an empty trie needs no node)
+                    status = (at_root && is_empty_root(want)) ? PHANT_PROOF_ABSENT : PHANT_PROOF_MISSING_NODE;
+                    break;
+                }
+                at_root = false;
+                const uint64_t b = a.v.node_off[j];
+                cur = a.v.nodes + b;
+                cur_len = (uint32_t)(a.v.node_off[j + 1] - b);
+                // a canonical full branch (checked by the wave that hashed it): the next reference is slot
+                // nib of the node, no decoding
+                if ((a.nstat[j] & NS_CANON) && w.pos < nn) {
+                    const uint32_t nib = key_in_lds ? key_nibble(slot_key, w.pos) : key_nibble(key, w.pos);
+                    const uint8_t* rb = cur + (4u + 33u * nib);
+                    const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
+                    want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
+                    want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
+                    w.pos += 1;
+                    continue;
+                }
+                staged_from = nullptr;
+                const uint32_t padded = (cur_len + 15u) & ~15u;
+                if (cur_len <= WALK_STAGE_BYTES && cur + padded <= nodes_end) {
+                    for (uint32_t o = 0; o < padded; o += 16u) {
+                        const uint4 q = load16u(cur + o);
+                        slot[o / 4u] = q.x;
+                        slot[o / 4u + 1u] = q.y;
+                        slot[o / 4u + 2u] = q.z;
+                        slot[o / 4u + 3u] = q.w;
+                    }
+                    staged_from = cur;
+                }
+            }
+            auto step_from = [&](const uint8_t* nb, const uint8_t* kp) __attribute__((always_inline)) -> uint32_t {
+                GlobalBytes nd{nb};
+                const uint32_t st = walk_node(nd, cur_len, kp, nn, w);
+                if (st == STEP_HASH) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) want[k] = nd.u32(w.ref_pay + 4 * k);
+                }
+                return st;
+            };
+            uint32_t step;
+            if (!key_in_lds) step = step_from(cur, key);
+            else if (staged_from) step = step_from(slot_node + (cur - staged_from), slot_key);
+            else step = step_from(cur, slot_key);
+            if (step == STEP_DONE) break;
+            if (step == STEP_HASH) {
+                by_hash = true;
+            } else {
+                cur = cur + w.ref_pay;
+                cur_len = w.ref_total;
+                by_hash = false;
+            }
+        }
+        if (status == 0xffffffffu) {
+            status = w.status;
+            if (status == PHANT_PROOF_PRESENT) {
+                voff = (uint64_t)(cur - a.v.nodes) + w.value_pay;
+                vlen = w.value_len;
+            }
+        }
+    }
+    a.v.status[i] = (uint8_t)status;
+    if (a.v.value_off) a.v.value_off[i] = voff;
+    if (a.v.value_len) a.v.value_len[i] = vlen;
+}
+
+// ---------------------------------------------------------------- host side
+static size_t rnd256(size_t x) { return (x + 255) / 256 * 256; }
+
+// Levels [0, S) are deduplicated.  Deduplication pays where a level has fewer groups than proofs pass through it:
+// 16^d groups per root at depth d against n proofs (keys are Keccak outputs: uniform).  Beyond that the table
+// lookups and the byte comparison cost more than hashing the rare duplicate.
+static uint32_t shallow_levels(uint32_t n, int32_t forced) {
+    if (forced >= 0) return (uint32_t)forced < MAX_SHALLOW ? (uint32_t)forced : MAX_SHALLOW;
+    if (n < 2) return 0;
+    uint32_t s = 1;
+    uint64_t groups = 16;  // of level s
+    while (s < MAX_SHALLOW && groups <= 4ull * n) {
+        ++s;
+        groups *= 16;
+    }
+    return s;
+}
+
+// Levels [0, D) are direct-mapped: as many as fit DIRECT_MAX_ENTRIES slots (n_roots (16^D - 1) / 15), at most all of the
+// shallow tier.
+constexpr uint64_t DIRECT_MAX_ENTRIES = 1ull << 21;
+static uint32_t direct_levels(uint32_t n_roots, uint32_t shallow, uint64_t& entries) {
+    uint32_t d = 0;
+    uint64_t below = 0, width = 1;  // (16^d - 1) / 15, 16^d
+    entries = 0;
+    while (d < shallow && (below + width) * n_roots <= DIRECT_MAX_ENTRIES) {
+        below += width;
+        width *= 16;
+        ++d;
+        entries = below * n_roots;
+    }
+    return d;
+}
+
+// the hashed table of levels [direct, shallow): 4 x its groups (at most one per (root, level, prefix) and per node)
+static uint32_t table_entries(uint32_t n, uint32_t n_roots, uint32_t direct, uint32_t shallow, uint32_t total_nodes) {
+    uint64_t per_root = 0, g = 1;
+    for (uint32_t d = 0; d < shallow && per_root < (1ull << 40); ++d, g *= 16)
+        if (d >= direct) per_root += g;
+    uint64_t groups = per_root * (n_roots ? n_roots : 1u);
+    const uint64_t by_nodes = (uint64_t)n * (shallow - direct) < total_nodes ? (uint64_t)n * (shallow - direct) : total_nodes;
+    if (groups > by_nodes) groups = by_nodes;
+    uint32_t t = 1024;
+    while (t < 4 * groups && t < (1u << 26)) t <<= 1;
+    return t;
+}
+
+struct Layout {
+    size_t dtab, table, meta, nstat, rep, ent, digest, gkey, link, end;
+};
+static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries) {
+    const size_t tn = total_nodes;
+    Layout l;
+    size_t p = HEADER_BYTES;
+    l.dtab = p;   p += rnd256((size_t)direct_entries * 4);
+    l.table = p;  p += rnd256((size_t)te * 8);
+    l.meta = p;   p += rnd256(tn * 4);
+    l.nstat = p;  p += rnd256(tn);        // header .. nstat: zeroed per call, contiguous
+    l.rep = p;    p += rnd256(tn * 4);
+    l.ent = p;    p += rnd256(tn * 4 * N_LIST);
+    l.digest = p; p += rnd256(tn * 32);
+    l.gkey = p;   p += rnd256(tn * 8);
+    l.link = p;   p += rnd256(tn + 16);
+    l.end = p + 1024;
+    return l;
+}
+
+size_t workspace_bytes(uint32_t total_nodes) {
+    // sized for the largest tables any (n, n_roots) can ask for with this many nodes
+    uint32_t t = 1024;
+    while (t < 4ull * total_nodes && t < (1u << 26)) t <<= 1;
+    return layout(total_nodes, t, DIRECT_MAX_ENTRIES).end;
+}
+
+static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
+    a.hdr = reinterpret_cast<uint32_t*>(ws);
+    a.dtab = reinterpret_cast<uint32_t*>(ws + l.dtab);
+    a.table = reinterpret_cast<uint64_t*>(ws + l.table);
+    a.tmask = te - 1u;
+    a.meta = reinterpret_cast<uint32_t*>(ws + l.meta);
+    a.nstat = ws + l.nstat;
+    a.rep = reinterpret_cast<uint32_t*>(ws + l.rep);
+    a.ent = reinterpret_cast<uint32_t*>(ws + l.ent);
+    a.digest = reinterpret_cast<uint32_t*>(ws + l.digest);
+    a.gkey = reinterpret_cast<uint64_t*>(ws + l.gkey);
+    a.link = ws + l.link;
+}
+
+}  // namespace v2
+
+size_t verify_workspace_bytes(uint32_t total_nodes) { return v2::workspace_bytes(total_nodes); }
+
+hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
+                             hipStream_t st, const FlatSide* side, const VerifyTune& tune) {
+    using namespace v2;
+    VerifyArgs v = v_in;
+    v.total_nodes = total_nodes;  // (verify_one bounds every proof's node range by it)
+    if (v.n == 0) return hipSuccess;
+    Args a;
+    a.v = v;
+    a.total_nodes = total_nodes;
+    a.shallow = shallow_levels(v.n, dedup_levels);
+    a.all_listed = 0;
+    uint64_t direct_entries = 0;
+    a.direct = direct_levels(v.n_roots, a.shallow, direct_entries);
+    const uint32_t te = table_entries(v.n, v.n_roots, a.direct, a.shallow, total_nodes);
+    const Layout l = layout(total_nodes, te, direct_entries);
+    bind(a, ws, l, te);
+    // header, tables, stamps and node states are contiguous: one memset
+    hipError_t e = hipMemsetAsync(ws, 0, l.rep, st);
+    if (e != hipSuccess) return e;
+    if (v.fail_count && !total_nodes) {  // no plan_kernel will run: clear the verdict counters here
+        e = hipMemsetAsync(v.fail_count, 0, sizeof(uint32_t) * (size_t)v.n_roots, st);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t pg = (v.n + 255u) / 256u;
+    if (total_nodes) {
+        const uint32_t ng = (total_nodes + 255u) / 256u;
+        const uint32_t dg = (total_nodes + DEDUP_BLOCK - 1u) / DEDUP_BLOCK;
+        const uint32_t wpl = (v.n + 63u) / 64u;                       // waves per level of the deep tier
+        const uint32_t deep_grid = (wpl * DEEP_LEVELS + 3u) / 4u;
+        const bool two = side && side->stream && side->fork && side->join && a.shallow != 0u && !tune.serial;
+        // deep tier: no inputs but the witness, so it starts at once -- on the helper stream, next to the shallow tier
+        hipStream_t ds = st;
+        const uint32_t deep_lds = two ? tune.hash_lds : 0u;  // (alone, the deep tier takes every wave slot it can get)
+        if (two) {
+            if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
+            ds = side->stream;
+        }
+        hipLaunchKernelGGL(hash_deep_kernel, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl);
+        if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
+        if (a.shallow) {
+            hipLaunchKernelGGL(dedup_kernel, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);
+            // grid bound: every shallow node listed (64-node chunks, 4 waves per workgroup) + one short chunk per list
+            const uint64_t listed = (uint64_t)v.n * a.shallow < total_nodes ? (uint64_t)v.n * a.shallow : total_nodes;
+            const uint32_t hg = (uint32_t)((listed + 255u) / 256u) + N_LIST;
+            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, st, a);
+        }
+        if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL(walk_kernel, dim3(pg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(slow_kernel, dim3(pg < 64u ? pg : 64u), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+static uint32_t nodeset_table_entries(uint32_t total_nodes) {
+    uint32_t t = 1024;
+    while (t < 2u * total_nodes && t < (1u << 31)) t <<= 1;
+    return t;
+}
+
+size_t verify_nodeset_workspace_bytes(uint32_t total_nodes) {
+    return v2::workspace_bytes(total_nodes) + v2::rnd256((size_t)nodeset_table_entries(total_nodes) * 4);
+}
+
+hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, hipStream_t st) {
+    using namespace v2;
+    if (v.n == 0) return hipSuccess;
+    Args a;
+    a.v = v;
+    a.total_nodes = total_nodes;
+    a.shallow = 0;
+    a.direct = 0;
+    a.all_listed = 1;
+    const uint32_t te = 1024;
+    const Layout l = layout(total_nodes, te, 0);
+    bind(a, ws, l, te);
+    uint32_t* tab = reinterpret_cast<uint32_t*>(ws + workspace_bytes(total_nodes));
+    const uint32_t tab_entries = nodeset_table_entries(total_nodes);
+    hipError_t e = hipMemsetAsync(ws, 0, HEADER_BYTES, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.nstat, 0, total_nodes, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(tab, 0xff, (size_t)tab_entries * 4, st);
+    if (e != hipSuccess) return e;
+    if (total_nodes) {
+        const uint32_t ng = (total_nodes + 255u) / 256u;
+        const uint32_t dg = (total_nodes + DEDUP_BLOCK - 1u) / DEDUP_BLOCK;
+        hipLaunchKernelGGL(dedup_kernel, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);  // class lists only
+        hipLaunchKernelGGL(hash_list_kernel, dim3(ng + N_LIST), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(nodeset_insert_kernel, dim3(ng), dim3(256), 0, st, a, tab, tab_entries - 1u);
+    }
+    hipLaunchKernelGGL(nodeset_walk_kernel, dim3((v.n + 255u) / 256u), dim3(256), 0, st, a, tab, tab_entries - 1u);
+    return hipGetLastError();
+}
+
+// nodes hashed per rate-block class by the last launch on this workspace (host copy of the header)
+void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]) {
+    using namespace v2;
+    for (uint32_t c = 0; c < N_CLASS; ++c) {
+        hashed[c] = hdr[c];
+        for (uint32_t s = 0; s < HDR_STAT_STRIPES; ++s) hashed[c] += hdr[HDR_STAT + N_CLASS * s + c];
+    }
+    hashed[BRANCH_LEN / RATE] += hdr[LIST_B532];
+}
+void verify_paths_from_header(const uint32_t* hdr, uint32_t out[2]) {
+    out[0] = hdr[v2::HDR_SLOW];
+    out[1] = hdr[v2::HDR_OPENED];
+}
+
+}  // namespace phant

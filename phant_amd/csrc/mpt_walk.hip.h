@@ -87,6 +87,13 @@ PHANT_DEV uint32_t ref_kind(const RlpItem& it) {
     return REF_BAD;
 }
 
+// Is the 32-byte reference (8 little-endian dwords) keccak256(0x80) = empty_mpt_root (mpt.zig:10)?  A proof without
+// nodes against such a root proves absence.
+PHANT_DEV bool is_empty_root(const uint32_t (&w)[8]) {
+    return w[0] == 0x171fe856u && w[1] == 0xa655cc1bu && w[2] == 0xe64583ffu && w[3] == 0x6ef8c092u && w[4] == 0x1be0485bu &&
+           w[5] == 0xc0ad6c99u && w[6] == 0xb52f6201u && w[7] == 0x21b463e3u;
+}
+
 PHANT_DEV uint32_t key_nibble(const uint8_t* __restrict__ key, uint32_t i) {
     const uint32_t b = key[i >> 1];
     return (i & 1u) ? (b & 0x0fu) : (b >> 4);
@@ -110,6 +117,11 @@ struct WalkState {
 template <class Bytes>
 PHANT_DEV uint32_t walk_node(const Bytes& nd, uint32_t nd_len, const uint8_t* __restrict__ key,
                              uint32_t nn, WalkState& w) {
+    // EmptyNode (mpt.zig:157-174): its RLP is the single byte 0x80 -- the whole (sub)trie is empty
+    if (nd_len == 1u && nd.byte(0) == 0x80u) {
+        w.status = PHANT_PROOF_ABSENT;
+        return STEP_DONE;
+    }
     RlpItem outer;
     if (!rlp_decode(nd, 0, nd_len, outer) || outer.total != nd_len) {
         w.status = PHANT_PROOF_BAD_RLP;

@@ -720,6 +720,13 @@ int32_t index_root_host(Workspaces& ws, hipStream_t st, const uint8_t* items, co
     std::vector<uint32_t> key_off((size_t)n + 1, 0);
     std::vector<uint64_t> val_off((size_t)n + 1, 0);
     std::vector<uint8_t> vals;
+    // the caller's offsets are indexed into `items` on the host below: they must not go backwards
+    for (uint32_t i = 0; i < n; ++i) {
+        if (item_off[i + 1] < item_off[i]) {
+            err = "index_root: item offsets not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+    }
     if (be32) {
         // execution_payload.zig:127-139: 32-byte key, index big-endian in the tail;
         // ascending index is ascending key, values stay in place

@@ -343,11 +343,13 @@ bool parse_storage_entry(Parser& ps, Builder& b, uint32_t account) {
         for (;;) {
             if (!ps.view(name) || !ps.expect(':')) return false;
             if (name.is("key")) {
+                if (have_key) return ps.fail("duplicate \"key\"");
                 if (!ps.view(s)) return false;
                 if (s.escaped || !hex_padded(s.b, s.e, 32, b.w.preimages.data() + key_at))
                     return ps.fail("storage key is not a hex quantity of at most 32 bytes");
                 have_key = true;
             } else if (name.is("value")) {
+                if (slot.has_value) return ps.fail("duplicate \"value\"");
                 if (!ps.view(s)) return false;
                 if (s.escaped || !hex_padded(s.b, s.e, 32, slot.value))
                     return ps.fail("storage value is not a hex quantity of at most 32 bytes");
@@ -392,19 +394,25 @@ bool parse_account(Parser& ps, Builder& b) {
     if (!ps.lit('}')) {
         for (;;) {
             if (!ps.view(name) || !ps.expect(':')) return false;
+            // (a member that occurs twice is rejected, whichever it is: "the last one wins" here and "the first one
+            // wins" in another JSON consumer of the client would be two different witnesses)
             if (name.is("address")) {
+                if (have_addr) return ps.fail("duplicate \"address\"");
                 if (!ps.view(s)) return false;
                 if (s.escaped || !hex_fixed(s.b, s.e, 20, acc.address)) return ps.fail("address is not 20 bytes of hex");
                 have_addr = true;
             } else if (name.is("storageHash")) {
+                if (acc.has_storage_hash) return ps.fail("duplicate \"storageHash\"");
                 if (!ps.view(s)) return false;
                 if (s.escaped || !hex_fixed(s.b, s.e, 32, acc.storage_hash)) return ps.fail("storageHash is not 32 bytes of hex");
                 acc.has_storage_hash = 1;
             } else if (name.is("codeHash")) {
+                if (acc.has_code_hash) return ps.fail("duplicate \"codeHash\"");
                 if (!ps.view(s)) return false;
                 if (s.escaped || !hex_fixed(s.b, s.e, 32, acc.code_hash)) return ps.fail("codeHash is not 32 bytes of hex");
                 acc.has_code_hash = 1;
             } else if (name.is("nonce")) {
+                if (acc.has_nonce) return ps.fail("duplicate \"nonce\"");
                 if (!ps.view(s)) return false;
                 uint8_t n8[8];
                 if (s.escaped || !hex_padded(s.b, s.e, 8, n8)) return ps.fail("nonce is not a hex quantity of at most 8 bytes");
@@ -412,6 +420,7 @@ bool parse_account(Parser& ps, Builder& b) {
                 for (int i = 0; i < 8; ++i) acc.nonce = acc.nonce << 8 | n8[i];
                 acc.has_nonce = 1;
             } else if (name.is("balance")) {
+                if (acc.has_balance) return ps.fail("duplicate \"balance\"");
                 if (!ps.view(s)) return false;
                 if (s.escaped || !hex_padded(s.b, s.e, 32, acc.balance))
                     return ps.fail("balance is not a hex quantity of at most 32 bytes");
@@ -480,6 +489,10 @@ static bool parse_single(const char* json, size_t len, Witness& w, std::string& 
         for (;;) {
             if (!(ok = ps.str(name) && ps.expect(':'))) break;
             if (name == "stateRoot") {
+                if (have_root) {
+                    ok = ps.fail("duplicate \"stateRoot\"");
+                    break;
+                }
                 if (!(ok = ps.str(s))) break;
                 if (!hex_fixed(s.data(), s.data() + s.size(), 32, w.roots.data())) {
                     ok = ps.fail("stateRoot is not 32 bytes of hex");
@@ -553,6 +566,10 @@ static bool parse_mt(const char* json, size_t len, unsigned threads, Witness& w,
         for (;;) {
             if (!(ok = ps.str(name) && ps.expect(':'))) break;
             if (name == "stateRoot") {
+                if (have_root) {
+                    ok = ps.fail("duplicate \"stateRoot\"");
+                    break;
+                }
                 if (!(ok = ps.str(s))) break;
                 if (!hex_fixed(s.data(), s.data() + s.size(), 32, state_root)) {
                     ok = ps.fail("stateRoot is not 32 bytes of hex");

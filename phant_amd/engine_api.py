@@ -89,14 +89,20 @@ class ExecutionWitness:
                 "node_off": _view(wi.node_off, wi.total_nodes + 1, np.uint64),
                 "proof_first_node": _view(wi.proof_first_node, n + 1, np.uint32)}
 
-    def verify(self, ctx: Context | None = None):
-        """-> (status u8[n_proofs], n_failed).  Needs a GPU (no CPU fallback).  An index-form witness whose proof
-        nodes turn out not to be hex raises WitnessFormatError here (the GPU is what reads them)."""
+    def verify(self, ctx: Context | None = None, expected_state_root: bytes | None = None):
+        """-> (status u8[n_proofs], n_failed).  Needs a GPU (no CPU fallback).  expected_state_root: the 32-byte root the
+        caller TRUSTS (the parent header's): account proofs are verified against it, whatever the document declares;
+        None = against the document's own stateRoot, which checks the document's consistency and nothing else.  An
+        index-form witness whose proof nodes turn out not to be hex raises WitnessFormatError here (the GPU is what
+        reads them)."""
         ctx = ctx or default_context()
         n = self.info()["n_proofs"]
         status = np.zeros(max(n, 1), np.uint8)
         bad = C.c_uint32(0)
-        rc = self._lib.phant_witness_verify(ctx.handle, self._h, status.ctypes.data_as(C.c_void_p), C.byref(bad))
+        if expected_state_root is not None and len(expected_state_root) != 32:
+            raise ValueError("expected_state_root must be 32 bytes")
+        root = None if expected_state_root is None else C.create_string_buffer(bytes(expected_state_root), 32)
+        rc = self._lib.phant_witness_verify(ctx.handle, self._h, root, status.ctypes.data_as(C.c_void_p), C.byref(bad))
         if rc == L.E_INVALID_ARG and self._keep is not None:
             raise WitnessFormatError(self._lib.phant_last_error(ctx.handle).decode())
         ctx.check(rc)
@@ -114,13 +120,16 @@ class ExecutionWitness:
             pass
 
 
-def new_payload_witness_ok(witness_json: str | bytes, ctx: Context | None = None, on_gpu: bool = False) -> bool:
+def new_payload_witness_ok(witness_json: str | bytes, parent_state_root: bytes, ctx: Context | None = None,
+                           on_gpu: bool = False) -> bool:
     """The check newPayloadV2Handler (execution_payload.zig:175-181) would make before
-    `blockchain.runBlock(block)`: every proof of the witness valid and consistent.  on_gpu: index form, the nodes'
-    hex is decoded on the GPU."""
+    `blockchain.runBlock(block)`: every proof of the witness valid against `parent_state_root` -- the state root of the
+    parent header the node already trusts (blockchain.zig keeps it as prev_block.state_root), NOT the "stateRoot" the
+    untrusted document declares -- and consistent with what the document says it proves.  on_gpu: index form, the
+    nodes' hex is decoded on the GPU."""
     w = ExecutionWitness.index_json(witness_json) if on_gpu else ExecutionWitness.parse_json(witness_json)
     try:
-        _, bad = w.verify(ctx)
+        _, bad = w.verify(ctx, expected_state_root=parent_state_root)
         return bad == 0
     finally:
         w.close()

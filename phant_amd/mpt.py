@@ -294,8 +294,10 @@ def verify_nodeset(roots, root_idx, keys, key_len, nodes, node_off, ctx: Context
 
 
 def verify_nodeset_dev(roots: torch.Tensor, root_idx: torch.Tensor | None, keys: torch.Tensor, nodes: torch.Tensor,
-                       node_off: torch.Tensor, status: torch.Tensor | None = None, ctx: Context | None = None) -> torch.Tensor:
-    """Device form, asynchronous on the ctx stream.  keys (n, key_len) u8, node_off (m + 1,) i64."""
+                       node_off: torch.Tensor, status: torch.Tensor | None = None, ctx: Context | None = None,
+                       value_off: torch.Tensor | None = None, value_len: torch.Tensor | None = None) -> torch.Tensor:
+    """Device form, asynchronous on the ctx stream.  keys (n, key_len) u8, node_off (m + 1,) i64; value_off (n,) i64 and
+    value_len (n,) i32 (optional outputs): where in `nodes` the proven value of a PRESENT key lies."""
     ctx = ctx or default_context(nodes.device.index)
     n = keys.shape[0]
     if status is None:
@@ -303,5 +305,6 @@ def verify_nodeset_dev(roots: torch.Tensor, root_idx: torch.Tensor | None, keys:
     ctx.check(ctx._lib.phant_mpt_verify_nodeset_dev(
         ctx.handle, roots.data_ptr(), roots.numel() // 32, None if root_idx is None else root_idx.data_ptr(),
         keys.data_ptr(), keys.shape[1], nodes.data_ptr(), nodes.numel(), node_off.data_ptr(), node_off.numel() - 1, n,
-        status.data_ptr(), None, None))
+        status.data_ptr(), None if value_off is None else value_off.data_ptr(),
+        None if value_len is None else value_len.data_ptr()))
     return status

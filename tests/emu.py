@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "phant_amd", "csrc")
-SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_flat.hip", "trie_build.hip", "state_root.hip",
+SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v2.hip", "trie_build.hip", "state_root.hip",
            "capi.hip", "witness_json.cpp", "host_rlp.cpp"]
 OUT_DIR = os.path.join(ROOT, "tests", "native", "_build")
 
@@ -84,6 +84,7 @@ _PROTOS = {
                                             _vp, _vp, _vp]),
     "phant_mpt_verify_nodeset": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
     "phant_verify_stats": (_i32, [_vp, _vp]),
+    "phant_verify_path_stats": (_i32, [_vp, _vp]),
 }
 
 
@@ -91,9 +92,17 @@ class Opts(C.Structure):
     _fields_ = [("struct_size", _u32), ("device", _i32), ("stream", _vp), ("flags", _u32)]
 
 
-FUSED, NODEDUP, OVERLAP, PIPELINED, GRAPH, MIXED = 2, 4, 8, 16, 32, 64
-MODES = {"flat": 0, "nodedup": NODEDUP, "overlap": OVERLAP, "pipelined": PIPELINED, "fused": FUSED, "mixed": MIXED,
-         "mixed+graph": GRAPH | MIXED | 1,
+FUSED, NODEDUP, GRAPH = 2, 4, 32
+
+
+def LEVELS(n):  # PHANT_CTX_DEDUP_LEVELS(n): the two-tier pipeline with the first n trie levels deduplicated
+    return ((n + 1) << 8) & 0x1F00
+
+
+# "flat" = the two-tier pipeline with its tier split chosen from the batch size; levelsN force the split (1: only the
+# root nodes are deduplicated, 16: every level, nothing left for the in-place tier)
+MODES = {"flat": 0, "nodedup": NODEDUP, "fused": FUSED, "levels1": LEVELS(1), "levels3": LEVELS(3), "levels16": LEVELS(16),
+         "levels3+graph": GRAPH | LEVELS(3) | 1,
          "flat+graph": GRAPH | 1, "nodedup+graph": GRAPH | NODEDUP | 1}  # (graphs need a real stream: | 1 = own stream)
 
 

@@ -1,6 +1,6 @@
 // leak_check.cpp -- emulated library only (device pointers are host pointers there): create / use / destroy every
-// kind of ctx state the C-ABI owns -- arenas, the verify workspace, helper streams and events of the overlap /
-// pipelined modes, a captured graph, streaming slots, parsed and index-form witnesses -- in a stand-alone
+// kind of ctx state the C-ABI owns -- arenas, the verify workspace, the helper stream and events of the two-tier verify
+// pipeline, a captured graph, streaming slots, parsed and index-form witnesses -- in a stand-alone
 // executable, so that LeakSanitizer (which cannot run inside the Python process of the other emulated tests)
 // reports anything phant_ctx_destroy / phant_witness_free forgets.
 #include <cstdio>
@@ -27,7 +27,7 @@ int main() {
     constexpr uint64_t LEAF_LEN = 13;
     const uint64_t node_off[2] = {0, LEAF_LEN};
     const uint32_t pfn[2] = {0, 1};
-    for (uint32_t flags : {0u, 2u, 4u, 8u, 16u, 64u, 32u | 1u, 32u | 64u | 1u, 1u}) {
+    for (uint32_t flags : {0u, 2u, 4u, PHANT_CTX_DEDUP_LEVELS(1), PHANT_CTX_DEDUP_LEVELS(16), 32u | 1u, 32u | PHANT_CTX_DEDUP_LEVELS(3) | 1u, 1u}) {
         phant_ctx* ctx = nullptr;
         phant_opts opts;
         std::memset(&opts, 0, sizeof opts);
@@ -69,7 +69,7 @@ int main() {
                         : phant_witness_parse_json_mt(doc.data(), doc.size(), 2, &w, err, sizeof err)) == PHANT_OK);
             uint8_t st[2];
             uint32_t bad = 0;
-            CHECK(phant_witness_verify(ctx, w, st, &bad) == PHANT_OK && bad == 2);
+            CHECK(phant_witness_verify(ctx, w, form ? nullptr : (const uint8_t*)"0123456789abcdef0123456789abcdef", st, &bad) == PHANT_OK && bad == 2);
             phant_witness_free(w);
         }
         phant_ctx_destroy(ctx);

@@ -32,11 +32,11 @@ def _no_cuda():
     saved = (torch.device, torch.cuda.set_device, torch.cuda.current_stream, torch.cuda.Stream, torch.cuda.stream,
              phant_amd.Context)
 
-    def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, verify_overlap=False,
-                verify_pipelined=False, verify_graph=False, verify_mixed=False):
-        mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else "overlap" if verify_overlap else
-                "pipelined" if verify_pipelined else "mixed" if verify_mixed else "flat")
-        if verify_graph and mode in ("flat", "nodedup", "mixed"):
+    def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, verify_graph=False,
+                dedup_levels=None):
+        mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else
+                "levels%d" % dedup_levels if dedup_levels is not None else "flat")
+        if verify_graph and mode != "fused":
             mode += "+graph"
         return emu.mirror_context(emu.mirror_lib(), mode)
 
@@ -85,36 +85,53 @@ def _check_contract(line, steps, warmup):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
 
 
-@pytest.mark.parametrize("mode,streams", [("flat", 3), ("flat", 1), ("fused", 2), ("mixed", 2)])
-def test_config3_dry_run(mode, streams):
+@pytest.mark.parametrize("mode,streams,inner", [("flat", 3, 2), ("flat", 1, 1), ("fused", 2, 1), ("nodedup", 2, 1)])
+def test_config3_dry_run(mode, streams, inner):
     line = _bench(["--proofs", "300", "--steps", "3", "--warmup", "1", "--verify-mode", mode, "--streams",
-                   str(streams), "--cpu-seconds", "0.2"])
+                   str(streams), "--cpu-seconds", "0.2", "--inner", str(inner), "--block-scale", "0.01"])
     _check_contract(line, 3, 1)
     assert line["metric"] == "mpt_proofs_verified_per_sec_depth8" and line["unit"] == "proofs/s"
     assert line["scaling"] == "weak" and line["config"]["streams"] == streams
+    assert line["config"]["passes_per_timed_step"] == inner
     assert line["cpu_baseline"]["statuses_match_gpu_expected"] is True
-    assert ("single_stream" in line) == (streams > 1)
+    assert line["single_stream"]["value"] > 0
     if mode != "fused":
         assert 0 < line["roofline"]["nodes_hashed"] <= line["roofline"]["nodes_shipped"] == 300 * 8
+        # BASELINE config 4 (one block witness, strong scaling) rides on the config-3 line
+        st = line["strong"]
+        assert st["scaling"] == "strong" and st["value"] > 0 and st["proofs_on_rank0"] == 1080
+        assert 0 < st["nodes_hashed"] <= st["nodes_shipped"]
+    else:
+        assert "strong" not in line
+
+
+def test_config3_forced_tier_split_dry_run():
+    line = _bench(["--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "1", "--cpu-seconds", "0.2", "--inner", "1",
+                   "--dedup-levels", "3", "--no-strong"])
+    _check_contract(line, 1, 0)
+    assert line["config"]["dedup_levels"] == 3 and "strong" not in line
 
 
 def test_config3_graph_replay_dry_run():
-    line = _bench(["--proofs", "300", "--steps", "4", "--warmup", "2", "--streams", "2", "--graph", "--cpu-seconds", "0.2"])
+    line = _bench(["--proofs", "300", "--steps", "4", "--warmup", "2", "--streams", "2", "--graph", "--cpu-seconds", "0.2",
+                   "--inner", "1", "--no-strong"])
     _check_contract(line, 4, 2)
-    # per slot: one capture, then replays only (priming + warm-up + timed + the single-stream leg on slot 0)
+    # per slot: one capture for its own witness, then replays only (priming + warm-up + timed); the single-stream leg
+    # alternates between the two witnesses on slot 0, which captures again at every change of arguments
     g = line["config"]["graph"]
-    assert len(g) == 2 and all(c == 1 for c, _ in g) and g[0][1] == 1 + 1 + 2 + 4 and g[1][1] == 1 + 1 + 2
+    assert len(g) == 2 and g[1] == [1, 1 + 1 + 2] and g[0][0] == 1 + 3 and g[0][1] == 1 + 1 + 2 + 4
     assert line["single_stream"]["value"] > 0
 
 
 def test_config3_fewer_steps_than_slots():
-    line = _bench(["--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4", "--cpu-seconds", "0.2"])
+    line = _bench(["--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4", "--cpu-seconds", "0.2", "--inner", "1",
+                   "--no-strong"])
     _check_contract(line, 1, 0)
 
 
 def test_config4_dry_run():
     line = _bench(["--workload", "config4", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--streams",
-                   "2", "--cpu-seconds", "0.2"])
+                   "2", "--cpu-seconds", "0.2", "--inner", "1"])
     _check_contract(line, 2, 1)
     assert line["metric"] == "mpt_proofs_verified_per_sec_block_witness" and line["scaling"] == "strong"
     assert line["cpu_baseline"]["statuses_match_gpu_expected"] is True
@@ -160,9 +177,10 @@ def _rank_main(rank, world, port, argv, q):
 
 
 @pytest.mark.parametrize("argv", [
-    ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "3"],
-    ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4"],
-    ["--gpus", "2", "--workload", "config4", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--streams", "2"],
+    ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "3", "--inner", "2", "--block-scale", "0.01"],
+    ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4", "--inner", "1", "--no-strong"],
+    ["--gpus", "2", "--workload", "config4", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--streams", "2",
+     "--inner", "1"],
 ], ids=["config3", "config3-fewer-steps-than-slots", "config4"])
 def test_two_ranks_dry_run(argv):
     """The N > 1 path the driver launches with torchrun (never run on real GPUs this round): both ranks build their
@@ -189,6 +207,9 @@ def test_two_ranks_dry_run(argv):
     assert line["config"]["parallelism"] == "key-sharded x2"
     if "config4" in argv:
         assert line["scaling"] == "strong"
+    elif "--no-strong" not in argv:
+        # what a SCALE run reads: the strong-scaling config-4 figure next to the weak config-3 one
+        assert line["strong"]["scaling"] == "strong" and line["strong"]["value"] > 0
 
 
 def test_smoke_dry_run(capsys):

@@ -24,9 +24,9 @@ def test_results_do_not_depend_on_the_execution_order():
     # (seed, what fresh "device" memory holds, ...): a result must not depend on uninitialised workspace either
     for seed, fill, modules, expr in (
             (3, "0x00", ["tests/test_emu_verify.py"],
-             "(flat or overlap or mixed) and (random_tries or mutation or hostile_index_arrays_match or synthetic_block)"),
+             "(flat or levels3 or levels16) and (random_tries or mutation or hostile_index_arrays_match or synthetic_block)"),
             (11, "0xff", ["tests/test_emu_verify.py"],
-             "(pipelined or nodedup or fused) and (random_tries or mutation or non_monotone)"),
+             "(levels1 or nodedup or fused) and (random_tries or mutation or non_monotone)"),
             (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py",
                          "tests/test_emu_witness.py"],
              "not 20000 and not fixture_state")):
@@ -34,9 +34,8 @@ def test_results_do_not_depend_on_the_execution_order():
         if expr:
             cmd += ["-k", expr]
         env = dict(os.environ, HIPEMU_SCHEDULE=str(seed), HIPEMU_FILL=fill)
-        if seed == 3:  # this child also takes the overlap mode's alternative launch shape (round-2 A/B candidate):
-            # COMPARE as 256-thread workgroups next to the non-persistent hash kernel
-            env.update(PHANT_CMP_BLOCK="256", PHANT_HASH_PERSISTENT="0")
+        if seed == 3:  # this child also takes the diagnostics form: the two tiers one after the other on one stream
+            env.update(PHANT_VERIFY_SERIAL="1")
         runs.append((seed, subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                             text=True)))
     for seed, proc in runs:

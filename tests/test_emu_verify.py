@@ -15,9 +15,9 @@ def _emulated_backend():
     yield from emu.emulated_backend()
 
 
-# "mixed" = PHANT_CTX_VERIFY_MIXED, the round-2 candidate (hash and COMPARE workgroups in one grid): not in the GPU
-# modules' fixture yet, so it takes every shared body here
-@pytest.fixture(scope="module", params=["flat", "pipelined", "overlap", "nodedup", "fused", "mixed"])
+# levelsN = the two-tier pipeline with its tier split forced (tests/emu.py): 1 = only root nodes deduplicated, 16 = every
+# level (nothing left for the in-place tier); "flat" chooses it from the batch size
+@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused"])
 def M(request):
     import phant_amd
     from tests.test_gpu_verify import _Mode
@@ -29,23 +29,15 @@ def M(request):
 from tests.test_gpu_verify import (  # noqa: E402,F401
     test_reference_vector_tries, test_random_tries, test_embedded_nodes_and_branch_values,
     test_mutation_fuzz_matches_oracle, test_garbage_committed_roots, test_bad_offsets_are_flagged,
+    test_empty_trie_proves_absence,
     test_non_monotone_proof_first_node_matches_oracle, test_synthetic_depth8_small_vs_oracle,
     test_synthetic_other_depths, test_block_witness_accounts_and_storage)
 from tests.test_gpu_x_verify_more import (  # noqa: E402,F401
     test_keys_longer_than_the_lds_staging, test_synthetic_block_witness_vs_oracle,
-    test_graph_replay_reads_fresh_data_and_recaptures_on_new_arguments, test_mixed_mode_runs_the_shared_bodies)
+    test_graph_replay_reads_fresh_data_and_recaptures_on_new_arguments)
 
 
-@pytest.fixture(scope="module")
-def MX():
-    import phant_amd
-    from tests.test_gpu_verify import _Mode
-    ctx = emu.mirror_context(emu.mirror_lib(), "mixed")
-    yield _Mode(phant_amd.mpt, ctx, "mixed")
-    ctx.close()
-
-
-@pytest.fixture(scope="module", params=["flat", "nodedup", "mixed"])
+@pytest.fixture(scope="module", params=["flat", "nodedup", "levels3"])
 def MG(request):
     import phant_amd
     from tests.test_gpu_verify import _Mode

@@ -103,7 +103,7 @@ def test_block_witness_as_a_node_set(M, oracle):
     assert {M.PROOF_PRESENT, M.PROOF_ABSENT, M.PROOF_MISSING_NODE} <= set(got[0].tolist())
 
 
-def test_depth8_node_set_full_size(M):
+def test_depth8_node_set_full_size(M, oracle):
     """BASELINE config 3's trie as a node set: the 100 000 proofs' ~354 k distinct nodes, shipped once."""
     import phant_amd
     w = phant_amd.witness.account_witness(100_000, depth=8, seed=2, corrupt_frac=0.0)
@@ -128,11 +128,22 @@ def test_depth8_node_set_full_size(M):
     idx = torch.repeat_interleave(b.node_off[keep] - new_off[:-1], klen) + torch.arange(int(new_off[-1]), device=b.nodes.device)
     set_nodes = b.nodes[idx].contiguous()
     assert 340_000 < keep.numel() < 370_000
-    st = M.verify_nodeset_dev(b.roots, None, b.keys, set_nodes, new_off)
+    vo = torch.empty(n, dtype=torch.int64, device="cuda")
+    vl = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = M.verify_nodeset_dev(b.roots, None, b.keys, set_nodes, new_off, value_off=vo, value_len=vl)
     torch.cuda.synchronize()
+    # all 100 000 statuses and value ranges against the oracle's node-set verifier on the same arrays
+    want = oracle.mpt_verify_nodeset(b.roots.cpu().numpy(), None, b.keys.cpu().numpy(), 32, set_nodes.cpu().numpy(),
+                                     new_off.cpu().numpy().astype(np.uint64))
+    assert np.array_equal(st.cpu().numpy(), want[0])
+    assert np.array_equal(vo.cpu().numpy().view(np.uint64), want[1])
+    assert np.array_equal(vl.cpu().numpy().view(np.uint32), want[2])
     assert (st == M.PROOF_PRESENT).all()
     # the exclusion keys of the same construction
     w2 = phant_amd.witness.account_witness(100_000, depth=8, seed=2, corrupt_frac=0.02)
     absent = w2.expected == M.PROOF_ABSENT
     st2 = M.verify_nodeset_dev(b.roots, None, w2.batch.keys, set_nodes, new_off)
+    want2 = oracle.mpt_verify_nodeset(b.roots.cpu().numpy(), None, w2.batch.keys.cpu().numpy(), 32, set_nodes.cpu().numpy(),
+                                      new_off.cpu().numpy().astype(np.uint64))
+    assert np.array_equal(st2.cpu().numpy(), want2[0])
     assert (st2[absent] == M.PROOF_ABSENT).all() and (st2[~absent] == M.PROOF_PRESENT).all()

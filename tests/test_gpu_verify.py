@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 class _Mode:
-    """phant_amd.mpt with every verify call bound to one ctx (flat pipeline serial / overlapped / without in-batch node dedup, or the fused kernel)."""
+    """phant_amd.mpt with every verify call bound to one ctx (two-tier pipeline with its tier split chosen or forced, without in-batch node dedup, or the one-lane-per-proof kernel)."""
 
     def __init__(self, mod, ctx, mode=None):
         self._mod, self._ctx, self.mode = mod, ctx, mode
@@ -26,12 +26,11 @@ class _Mode:
         return self._mod.verify_batch_dev(*a, ctx=self._ctx, **k)
 
 
-@pytest.fixture(scope="module", params=["flat", "pipelined", "overlap", "nodedup", "fused"])
+@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused"])
 def M(request):
     import phant_amd
     ctx = phant_amd.Context(verify_fused=(request.param == "fused"), verify_nodedup=(request.param == "nodedup"),
-                            verify_overlap=(request.param == "overlap"),
-                            verify_pipelined=(request.param == "pipelined"))
+                            dedup_levels=(int(request.param[6:]) if request.param.startswith("levels") else None))
     yield _Mode(phant_amd.mpt, ctx, request.param)
     ctx.close()
 
@@ -158,6 +157,31 @@ def test_mutation_fuzz_matches_oracle(M, oracle):
     assert len(set(got[0].tolist())) >= 5  # the fuzz reaches many distinct outcomes
 
 
+def test_empty_trie_proves_absence(M, oracle):
+    """a proof without nodes (and the one-node proof [0x80]) against root = empty_mpt_root
+    (mpt.zig:10) proves absence -- eth_getProof's answer for a slot of an account without storage; against another
+    root they are INVALID_EMPTY / BAD_HASH.  Mixed into a batch of ordinary proofs, multi-root."""
+    rng = np.random.default_rng(31)
+    keys, vals = random_kv(rng, 40, 32, 1, 60)
+    t = oracle.Trie(keys, vals)
+    empty = bytes.fromhex("56e81f171bcc55a6ff8345e692c0f86e5b48e01b996cadc001622fb5e363b421")
+    roots = [t.root(), empty, bytes(32)]
+    q, ridx, proofs = [], [], []
+    for i, k in enumerate(keys[:30]):
+        q.append(k); ridx.append(0); proofs.append(t.prove(k))
+        slot = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        kind = i % 5
+        q.append(slot)
+        ridx.append(1 if kind in (0, 1, 4) else 2)
+        proofs.append([] if kind in (0, 2) else [b"\x80"] if kind in (1, 3) else [b"\x80", b"\x80"])
+    got, want = _both(M, oracle, roots, np.array(ridx, np.uint32), q, 32, proofs)
+    _assert_same(got, want)
+    st = got[0].reshape(-1, 2)
+    assert (st[:, 0] == M.PROOF_PRESENT).all()
+    assert st[0::5, 1].tolist() == [M.PROOF_ABSENT] * 6 and st[1::5, 1].tolist() == [M.PROOF_ABSENT] * 6
+    assert (st[2::5, 1] == M.PROOF_INVALID_EMPTY).all() and (st[3::5, 1] == 16).all() and (st[4::5, 1] == 19).all()
+
+
 def test_garbage_committed_roots(M, oracle):
     """Nodes that hash correctly but are not MPT nodes: structure checks, same code as the oracle."""
     key = bytes(32)
@@ -216,15 +240,23 @@ def test_synthetic_other_depths(M, oracle, depth):
     assert np.array_equal(st.cpu().numpy(), want[0])
 
 
-def test_config3_full_size_properties(M):
-    """BASELINE config 3 at full size (100 k depth-8 proofs, one root): every status is the one the
-    construction forces, the per-root verdict counts exactly the corrupted proofs, and verifying is
-    idempotent."""
+def test_config3_full_size_properties(M, oracle):
+    """BASELINE config 3 at full size (100 k depth-8 proofs, one root): all 100 000 statuses and value ranges are
+    the oracle's (oracle/verify.c on the same arrays, ~1.5 s of CPU), which are also the ones the construction
+    forces; the per-root verdict counts exactly the corrupted proofs, and verifying is idempotent."""
     import phant_amd
     w = phant_amd.witness.account_witness(100_000, depth=8, seed=2)
     vo = torch.empty(w.batch.n, dtype=torch.int64, device="cuda")
     vl = torch.empty(w.batch.n, dtype=torch.int32, device="cuda")
     st = M.verify_batch_dev(w.batch, value_off=vo, value_len=vl)
+    torch.cuda.synchronize()
+    b = w.batch
+    want = oracle.mpt_verify_batch(b.roots.cpu().numpy(), None, b.keys.cpu().numpy(), 32, b.nodes.cpu().numpy(),
+                                   b.node_off.cpu().numpy().astype(np.uint64),
+                                   b.proof_first_node.cpu().numpy().astype(np.uint32))
+    assert np.array_equal(st.cpu().numpy(), want[0])
+    assert np.array_equal(vo.cpu().numpy().view(np.uint64), want[1])
+    assert np.array_equal(vl.cpu().numpy().view(np.uint32), want[2])
     assert torch.equal(st, w.expected)
     assert int(M.verdict_dev(st, None, 1).item()) == w.n_invalid == 500
     st2 = M.verify_batch_dev(w.batch)

@@ -36,12 +36,41 @@ def test_clean_witness(EA, built):
     doc, expected, _ = built
     st, bad, _ = _run(EA, doc)
     assert st.tolist() == expected and bad == 0
-    assert EA.new_payload_witness_ok(json.dumps(doc))
+    trusted = bytes.fromhex(doc["stateRoot"][2:])
+    assert EA.new_payload_witness_ok(json.dumps(doc), trusted)
     assert PRESENT in expected and ABSENT in expected
+    # slots of accounts without storage (proof [] / ["0x80"] against empty_mpt_root) are in there, proven absent
+    assert any(a["storageHash"].endswith("63b421") and a["storageProof"] for a in doc["accounts"])
+
+
+def test_a_forged_state_root_is_rejected(EA, oracle, built):
+    """The witness is an untrusted message: a self-consistent trie under a root of the sender's choosing verifies
+    against ITSELF (consistency) but not against the state root the node trusts (the parent header's) -- which is
+    what the engine hook checks (new_payload_witness_ok must not anchor on the document's own stateRoot)."""
+    doc, expected, _ = built
+    trusted = bytes.fromhex(doc["stateRoot"][2:])
+    forged, fexp, _ = block_witness_json(oracle, np.random.default_rng(100), n_accounts=40, n_contracts=3, n_touched=10)
+    assert forged["stateRoot"] != doc["stateRoot"]
+    w = EA.ExecutionWitness.parse_json(json.dumps(forged))
+    st, bad = w.verify()                                 # against its own root: a consistent document
+    assert st.tolist() == fexp and bad == 0
+    st, bad = w.verify(expected_state_root=trusted)      # against the trusted root: nothing is anchored
+    w.close()
+    want = []
+    for a in forged["accounts"]:
+        want += [16] + [MISMATCH] * len(a["storageProof"])   # BAD_HASH at the root node; storage roots unanchored
+    assert st.tolist() == want and bad == len(want)
+    assert not EA.new_payload_witness_ok(json.dumps(forged), trusted)
+    assert EA.new_payload_witness_ok(json.dumps(forged), bytes.fromhex(forged["stateRoot"][2:]))
+    # the document's own claim does not matter either way: the honest witness under a lying "stateRoot" member passes
+    lying = copy.deepcopy(doc)
+    lying["stateRoot"] = forged["stateRoot"]
+    assert EA.new_payload_witness_ok(json.dumps(lying), trusted)
 
 
 def _first_contract(doc):
-    return next(i for i, a in enumerate(doc["accounts"]) if len(a["storageProof"]) >= 2)
+    return next(i for i, a in enumerate(doc["accounts"])
+                if len(a["storageProof"]) >= 2 and not a["storageHash"].endswith("63b421"))  # (a contract WITH storage)
 
 
 def _proof_index(doc, account, slot=None):
@@ -68,7 +97,7 @@ def test_declared_fields_must_match_the_proven_leaf(EA, built):
             want[ia + 1 + s] = MISMATCH
         assert st.tolist() == want, field
         assert bad == 1 + len(doc["accounts"][c]["storageProof"])
-        assert not EA.new_payload_witness_ok(json.dumps(doc))
+        assert not EA.new_payload_witness_ok(json.dumps(doc), bytes.fromhex(doc["stateRoot"][2:]))
 
 
 def test_wrong_storage_hash_and_slot_value(EA, built):

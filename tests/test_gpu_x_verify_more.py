@@ -52,13 +52,13 @@ def test_keys_longer_than_the_lds_staging(M, oracle):
         assert {M.PROOF_PRESENT, M.PROOF_ABSENT} <= set(got[0].tolist())
 
 
-@pytest.fixture(scope="module", params=["flat", "nodedup", "mixed"])
+@pytest.fixture(scope="module", params=["flat", "nodedup", "levels3"])
 def MG(request):
     """A ctx with PHANT_CTX_VERIFY_GRAPH on a stream of its own (the legacy default stream cannot be captured)."""
     import phant_amd
     from tests.test_gpu_verify import _Mode
     ctx = phant_amd.Context(use_torch_stream=False, verify_graph=True, verify_nodedup=(request.param == "nodedup"),
-                            verify_mixed=(request.param == "mixed"))
+                            dedup_levels=(3 if request.param == "levels3" else None))
     yield _Mode(phant_amd.mpt, ctx, request.param + "+graph")
     ctx.close()
 
@@ -111,31 +111,3 @@ def test_graph_replay_reads_fresh_data_and_recaptures_on_new_arguments(MG, oracl
     st3 = MG.verify_batch_dev(w3.batch)
     ctx.sync()
     assert torch.equal(st3, w3.expected) and ctx.graph_stats() == (3, 7)
-
-
-@pytest.fixture(scope="module")
-def MX():
-    """PHANT_CTX_VERIFY_MIXED: hash and COMPARE workgroups interleaved in one grid (round-2 candidate)."""
-    import phant_amd
-    from tests.test_gpu_verify import _Mode
-    ctx = phant_amd.Context(verify_mixed=True)
-    yield _Mode(phant_amd.mpt, ctx, "mixed")
-    ctx.close()
-
-
-def test_mixed_mode_runs_the_shared_bodies(MX, oracle):
-    """Every oracle-checked body of tests/test_gpu_verify.py that takes (M, oracle), through the mixed mode."""
-    from tests import test_gpu_verify as T
-    T.test_reference_vector_tries(MX, oracle)
-    for n, key_len, shared in ((17, 32, 0), (300, 32, 0), (300, 32, 6), (200, 3, 0)):
-        T.test_random_tries(MX, oracle, n, key_len, shared)
-    T.test_embedded_nodes_and_branch_values(MX, oracle)
-    T.test_mutation_fuzz_matches_oracle(MX, oracle)
-    T.test_garbage_committed_roots(MX, oracle)
-    T.test_non_monotone_proof_first_node_matches_oracle(MX, oracle)
-    T.test_synthetic_depth8_small_vs_oracle(MX, oracle)
-    for depth in (2, 5, 9):
-        T.test_synthetic_other_depths(MX, oracle, depth)
-    T.test_block_witness_accounts_and_storage(MX, oracle)
-    test_keys_longer_than_the_lds_staging(MX, oracle)
-    test_synthetic_block_witness_vs_oracle(MX, oracle)

@@ -37,15 +37,17 @@ def test_index_form_verifies_like_the_parsed_form(EA, oracle):
             assert sa.tolist() == expected and ba == 0
         else:
             assert ba > 0 and {16, 22} <= set(sa.tolist())
-    assert EA.new_payload_witness_ok(json.dumps(doc), on_gpu=True)
-    assert not EA.new_payload_witness_ok(json.dumps(damaged), on_gpu=True)
+    trusted = bytes.fromhex(doc["stateRoot"][2:])
+    assert EA.new_payload_witness_ok(json.dumps(doc), trusted, on_gpu=True)
+    assert not EA.new_payload_witness_ok(json.dumps(damaged), trusted, on_gpu=True)
+    assert not EA.new_payload_witness_ok(json.dumps(doc), bytes(32), on_gpu=True)  # a root the node does not trust
 
 
 def test_non_hex_digits_are_found_by_the_gpu(EA, oracle):
     doc, _, _ = block_witness_json(oracle, np.random.default_rng(98))
     text = json.dumps(doc)
-    k = text.index('"storageProof"')
-    k = text.index('"proof": ["0x', k) + len('"proof": ["0x') + 40
+    import re
+    k = re.search(r'"proof": \["0x[0-9a-f]{64}', text).end() - 20   # inside a storage proof's first (long) node
     bad = text[:k] + "G" + text[k + 1:]
     with pytest.raises(EA.WitnessFormatError):
         EA.ExecutionWitness.parse_json(bad)                    # the host parser reads the digits itself

@@ -104,7 +104,8 @@ def test_malformed_nodes_with_matching_hash(oracle):
     def run(node):
         return o.mpt_verify(o.keccak256(node), key, [node])[0]
 
-    assert run(b"\x80") == o.PROOF_BAD_NODE                      # a string, not a list
+    assert run(b"\x80") == o.PROOF_ABSENT                        # EmptyNode's RLP (mpt.zig:157-174): the empty trie
+    assert run(b"\x81\xff") == o.PROOF_BAD_NODE                  # a string, not a list
     assert run(b"\xc0") == o.PROOF_BAD_NODE                      # empty list: 0 items
     assert run(b"\xc1\x80") == o.PROOF_BAD_NODE                  # 1 item
     assert run(b"\xc3\x80\x80\x80") == o.PROOF_BAD_NODE          # 3 items
@@ -273,3 +274,30 @@ def test_checked_nodeset_form(oracle):
     ridx2[5] = 1  # a root nothing hashes to
     st, _, _ = o.mpt_verify_nodeset_checked(r, ridx2, k, 32, blob, off)
     assert st[3] == o.PROOF_BAD_INPUT and st[5] == o.PROOF_MISSING_NODE and (np.delete(st, [3, 5]) == o.PROOF_PRESENT).all()
+
+
+EMPTY_ROOT = bytes.fromhex("56e81f171bcc55a6ff8345e692c0f86e5b48e01b996cadc001622fb5e363b421")  # mpt.zig:10
+
+
+def test_empty_trie_proves_absence(oracle):
+    """against root = empty_mpt_root (src/mpt/mpt.zig:10, keccak256(0x80)) a proof WITHOUT nodes
+    -- what eth_getProof returns for a slot of an account without storage -- and the one-node proof [0x80] (EmptyNode's
+    RLP, mpt.zig:157-174) prove absence; against any other root they stay INVALID_EMPTY / BAD_HASH."""
+    o = oracle
+    key = bytes(range(32))
+    assert o.keccak256(b"\x80") == EMPTY_ROOT == o.mptize([], [])
+    assert o.mpt_verify(EMPTY_ROOT, key, []) == (o.PROOF_ABSENT, None)
+    assert o.mpt_verify(EMPTY_ROOT, key, [b"\x80"]) == (o.PROOF_ABSENT, None)
+    other = bytes(32)
+    assert o.mpt_verify(other, key, [])[0] == o.PROOF_INVALID_EMPTY
+    assert o.mpt_verify(other, key, [b"\x80"])[0] == 16  # BAD_HASH
+    assert o.mpt_verify(EMPTY_ROOT, key, [b"\x80", b"\x80"])[0] == 19  # EXTRA_NODES
+    assert o.mpt_verify(EMPTY_ROOT, key, [b"\x81"])[0] == 16
+    # node set: the root of an empty trie needs no node; any other root does
+    roots = np.frombuffer(EMPTY_ROOT + other, np.uint8)
+    st, _, _ = o.mpt_verify_nodeset(roots, np.array([0, 1], np.uint32), np.frombuffer(key + key, np.uint8), 32,
+                                    np.zeros(1, np.uint8), np.zeros(1, np.uint64))
+    assert st.tolist() == [o.PROOF_ABSENT, 20]
+    st, _, _ = o.mpt_verify_nodeset(roots, np.array([0, 1], np.uint32), np.frombuffer(key + key, np.uint8), 32,
+                                    np.frombuffer(b"\x80", np.uint8), np.array([0, 1], np.uint64))
+    assert st.tolist() == [o.PROOF_ABSENT, 20]

@@ -153,6 +153,24 @@ def test_member_order_does_not_matter(EA, oracle):
     dup = json.dumps(doc["accounts"][0])[:-1] + ', "accountProof": []}'
     with pytest.raises(EA.WitnessFormatError):
         EA.ExecutionWitness.parse_json('{"stateRoot": "' + doc["stateRoot"] + '", "accounts": [' + dup + "]}")
+    # ... every recognised member, at every level ("last one wins" would let a document mean different
+    # things to this parser and to a first-one-wins JSON reader elsewhere in the client) -- in all three parsers
+    acct = next(x for x in doc["accounts"] if x["storageProof"])
+    base = json.dumps(acct)[:-1]
+    slot = json.dumps(acct["storageProof"][0])[:-1]
+    docs = ['{"stateRoot": "%s", "accounts": [], "stateRoot": "%s"}' % (doc["stateRoot"], "0x" + "00" * 32)]
+    for member in ("address", "storageHash", "codeHash", "nonce", "balance", "storageProof"):
+        docs.append('{"stateRoot": "%s", "accounts": [%s, "%s": %s}]}' % (doc["stateRoot"], base, member, json.dumps(acct[member])))
+    for member in ("key", "value", "proof"):
+        entry = '%s, "%s": %s}' % (slot, member, json.dumps(acct["storageProof"][0][member]))
+        one = dict(acct, storageProof=[])
+        docs.append('{"stateRoot": "%s", "accounts": [%s, "storageProof": [%s]}]}'
+                    % (doc["stateRoot"], json.dumps({k: v for k, v in one.items() if k != "storageProof"})[:-1], entry))
+    for text in docs:
+        for parse in (lambda t: EA.ExecutionWitness.parse_json(t), lambda t: EA.ExecutionWitness.parse_json(t, threads=2),
+                      lambda t: EA.ExecutionWitness.index_json(t)):
+            with pytest.raises(EA.WitnessFormatError, match="duplicate"):
+                parse(text)
 
 
 def test_threaded_parse_is_byte_identical(EA, oracle):

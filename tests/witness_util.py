@@ -157,14 +157,24 @@ def block_witness_json(oracle, rng, n_accounts=300, n_contracts=12, max_slots=12
                 obj["storageProof"].append({"key": q(slot), "value": q(val), "proof": [hx(n) for n in tries[i].prove(sk)]})
                 expected.append(st)
                 keys.append(sk)
+        elif rng.random() < 0.5:
+            # an account WITHOUT storage (storageHash = empty_mpt_root): eth_getProof answers a slot query with
+            # "proof": [] (some clients: ["0x80"]) -- absence in the empty trie, DESIGN.md section 3
+            for form in ([], ["0x80"])[:int(rng.integers(1, 3))]:
+                slot = int(rng.integers(0, 1 << 62))
+                obj["storageProof"].append({"key": q(slot), "value": "0x0", "proof": list(form)})
+                expected.append(2)
+                keys.append(oracle.keccak256(slot.to_bytes(32, "big")))
         doc["accounts"].append(obj)
     # an address the state does not hold: exclusion proof, empty account
     ghost = rng.integers(0, 256, 20, dtype=np.uint8).tobytes()
     gk = oracle.keccak256(ghost)
+    gslot = int(rng.integers(0, 1 << 62))  # ... and a slot of it: nothing there either
     doc["accounts"].append({"address": hx(ghost), "accountProof": [hx(n) for n in state.prove(gk)], "balance": "0x0",
-                            "codeHash": hx(empty_code), "nonce": "0x0", "storageHash": hx(empty_root), "storageProof": []})
-    expected.append(2)
-    keys.append(gk)
+                            "codeHash": hx(empty_code), "nonce": "0x0", "storageHash": hx(empty_root),
+                            "storageProof": [{"key": q(gslot), "value": "0x0", "proof": []}]})
+    expected += [2, 2]
+    keys += [gk, oracle.keccak256(gslot.to_bytes(32, "big"))]
     return doc, expected, keys
 
 

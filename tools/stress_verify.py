@@ -60,8 +60,8 @@ def main():
     from oracle import oracle as O
     from tests.witness_util import random_kv, pack_proofs, node_set
 
-    modes = {"flat": {}, "pipelined": {"verify_pipelined": True}, "overlap": {"verify_overlap": True},
-             "nodedup": {"verify_nodedup": True}, "fused": {"verify_fused": True}, "mixed": {"verify_mixed": True}}
+    modes = {"flat": {}, "levels1": {"dedup_levels": 1}, "levels3": {"dedup_levels": 3}, "levels16": {"dedup_levels": 16},
+             "nodedup": {"verify_nodedup": True}, "fused": {"verify_fused": True}}
     if args.emulated:
         from tests import emu
         backend = emu.emulated_backend()

@@ -16,24 +16,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 COMBOS = [
-    ("flat", {}),
-    ("flat", {"PHANT_HASH_CHUNK": "0"}),
-    ("flat", {"PHANT_HASH_PERSISTENT": "1"}),
-    ("flat", {"PHANT_HASH_LDS_KB": "53"}),   # hash capped at 3 waves per SIMD (matters with launches in flight: bench.py)
-    ("pipelined", {}),
-    ("overlap", {}),
-    # round-2 candidates (written after round 1's GPU budget was spent): COMPARE as one-wave-per-SIMD workgroups
-    # next to the hardware-dispatched hash kernel, at 4 and at 3 hash waves per SIMD
-    ("overlap", {"PHANT_HASH_PERSISTENT": "0", "PHANT_CMP_BLOCK": "256"}),
-    ("overlap", {"PHANT_HASH_PERSISTENT": "0"}),
-    ("overlap", {"PHANT_CMP_BLOCK": "256"}),
-    ("mixed", {}),                      # hash + COMPARE workgroups in one grid
-    ("mixed", {"PHANT_CMP_PRIO": "0"}),
-    ("nodedup", {}),
-    ("fused", {}),
+    # hash kernels: PHANT_HASH_WAVES 5 = <= 96 VGPRs, split absorb; 4 = <= 128 VGPRs, split absorb; 3 = <= 128 VGPRs, whole
+    # rate blocks (the compiler free to prefetch).  PHANT_HASH_LDS_KB caps the deep tier's workgroups per CU (= its waves
+    # per SIMD) by an otherwise unused LDS allocation: 40 -> 4, 52 -> 3, i.e. what is left to the memory-bound kernels beside
+    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "52", "PHANT_DEDUP_BLOCK": "256"}),
+    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "52", "PHANT_DEDUP_BLOCK": "256", "PHANT_LIST_PRIO": "0"}),
+    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "40", "PHANT_DEDUP_BLOCK": "256"}),
+    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "40", "PHANT_DEDUP_BLOCK": "256", "PHANT_LIST_PRIO": "0"}),
+    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "63", "PHANT_DEDUP_BLOCK": "256"}),
+    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "52"}),
+    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "0", "PHANT_DEDUP_BLOCK": "256"}),
+    ("flat", None, {"PHANT_HASH_WAVES": "4", "PHANT_HASH_LDS_KB": "52", "PHANT_DEDUP_BLOCK": "256"}),
+    ("flat", None, {"PHANT_HASH_WAVES": "5", "PHANT_HASH_LDS_KB": "40", "PHANT_DEDUP_BLOCK": "256"}),
+    ("nodedup", None, {"PHANT_HASH_WAVES": "3"}),
+    ("nodedup", None, {"PHANT_HASH_WAVES": "5"}),
 ]
-KNOBS = ("PHANT_HASH_WPS", "PHANT_CMP_LDS_KB", "PHANT_CMP_PRIO", "PHANT_HASH_PERSISTENT", "PHANT_HASH_CHUNK",
-         "PHANT_CMP_BLOCK", "PHANT_HASH_LDS_KB")
+KNOBS = ("PHANT_HASH_WAVES", "PHANT_HASH_LDS_KB", "PHANT_VERIFY_SERIAL", "PHANT_DEDUP_BLOCK", "PHANT_LIST_PRIO")
 
 
 def main():
@@ -51,13 +49,11 @@ def main():
     b = w.batch
     status = torch.empty(b.n, dtype=torch.uint8, device=dev)
     lines = []
-    for mode, env in COMBOS:
+    for mode, levels, env in COMBOS:
         for k in KNOBS:
             os.environ.pop(k, None)
         os.environ.update(env)
-        ctx = phant_amd.Context(0, verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"),
-                                verify_overlap=(mode == "overlap"), verify_pipelined=(mode == "pipelined"),
-                                verify_mixed=(mode == "mixed"))
+        ctx = phant_amd.Context(0, verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"), dedup_levels=levels)
         status.fill_(0x77)
         for _ in range(3):
             M.verify_batch_dev(b, status=status, ctx=ctx)
@@ -75,9 +71,10 @@ def main():
             kms.append(ctx.last_kernel_ms())
         ctx.timing(False)
         hashed = ctx.verify_stats() if mode != "fused" else []
-        line = {"mode": mode, "env": env, "ok": ok, "wall_ms": round(wall, 4), "event_ms": round(sum(kms) / len(kms), 4),
+        paths = ctx.verify_path_stats() if mode != "fused" else (0, 0)
+        line = {"mode": mode, "dedup_levels": levels, "env": env, "ok": ok, "wall_ms": round(wall, 4), "event_ms": round(sum(kms) / len(kms), 4),
                 "event_min_ms": round(min(kms), 4), "proofs_per_s": round(b.n / (wall * 1e-3)),
-                "nodes_hashed": int(sum(hashed)), "keccak_f": int(sum((c + 1) * h for c, h in enumerate(hashed)))}
+                "nodes_hashed": int(sum(hashed)), "slow_proofs": paths[0], "walk_opened": paths[1], "keccak_f": int(sum((c + 1) * h for c, h in enumerate(hashed)))}
         print(json.dumps(line), flush=True)
         lines.append(line)
         ctx.close()
