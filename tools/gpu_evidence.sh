@@ -1,0 +1,56 @@
+#!/bin/bash
+# Round evidence run on the GPU box: parity suite, smoke, bench lines of every workload, rocprofv3 kernel stats, PMC
+# passes (HBM traffic with calibration, SQ counters of the hash kernels).  Usage (through gpurun): bash tools/gpu_evidence.sh <tag>
+OUT=$PWD/gpurun_out/${1:-evidence}
+mkdir -p "$OUT"; ulimit -c 0; export TMPDIR=/tmp PYTHONUNBUFFERED=1; R=$PWD
+( rocm-smi --showproductname; rocminfo | grep -m3 -E "Marketing|gfx"; nproc; lscpu | grep "Model name" ) > "$OUT/env.log" 2>&1
+timeout 100 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1 || { echo "smoke failed"; tail -5 "$OUT/smoke.log"; exit 1; }
+tail -1 "$OUT/smoke.log"
+if [ "$2" != "nopytest" ]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q --timeout 400 > "$OUT/pytest_gpu.log" 2>&1; tail -3 "$OUT/pytest_gpu.log"
+fi
+b() { tag=$1; shift; timeout 400 python bench.py "$@" 2>&1 | grep '^{' | tail -1 > "$OUT/bench_$tag.json"; python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_$tag.json"))
+    print("$tag", round(d["value"] / 1e6, 1), "M/s", "ms", round(d["ms_per_step"], 4), "kernel", round(d["roofline"]["kernel_avg_ms"], 4), "frac", round(d["roofline"]["frac"], 3), "single", d.get("single_stream", {}).get("ms_per_step"), "strong", (d.get("strong") or {}).get("value"))
+except Exception as e:
+    print("$tag FAILED", e)
+PY
+}
+b config3 --cpu-seconds 8
+b config3_nodedup --no-cpu-baseline --no-strong --verify-mode nodedup
+b config3_fused --no-cpu-baseline --no-strong --verify-mode fused --steps 5
+b config3_1M --no-cpu-baseline --no-strong --proofs 1000000 --steps 5 --inner 4 --streams 2
+b config4 --workload config4 --cpu-seconds 5
+b config4_nodedup --workload config4 --no-cpu-baseline --verify-mode nodedup
+b config2 --workload config2 --cpu-seconds 3
+b nodeset --workload nodeset --no-cpu-baseline
+b config5 --workload config5 --no-cpu-baseline
+prof() {  # tag, env..., (BARGS)
+  tag=$1; shift
+  ( cd /tmp && rm -rf /tmp/prof_$tag && timeout 300 env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python $R/bench.py --no-cpu-baseline --steps 5 --inner 10 --no-strong $BARGS > "$OUT/prof_$tag.log" 2>&1 )
+  f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && (head -1 "$f"; grep "phant" "$f") > "$OUT/config3_kernel_stats_$tag.csv"
+  echo "== $tag"; cut -d, -f1-4 "$OUT/config3_kernel_stats_$tag.csv" | cut -c1-150
+}
+BARGS="--streams 1" prof concurrent X=1
+BARGS="--streams 1" prof serial PHANT_VERIFY_SERIAL=1
+BARGS="--streams 4" prof streams4 X=1
+BARGS="--streams 1 --workload config4" prof config4 X=1
+# ---- PMC passes: counters in their own runs, kernel trace only
+pmc() {  # name, counters, mode
+  name=$1; ctr=$2; mode=$3
+  ( cd /tmp && rm -rf /tmp/pmc_$name && timeout 300 env PHANT_VERIFY_SERIAL=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --inner 1 --no-strong --no-cpu-baseline --streams 1 --verify-mode $mode > "$OUT/pmc_$name.log" 2>&1 )
+  for f in $(find /tmp/pmc_$name -name '*counter_collection.csv'); do (head -1 "$f"; grep -E 'phant::' "$f") > "$OUT/$name.csv"; done
+}
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rm -rf /tmp/ub_$c && timeout 120 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/ub_$c -o pmc -- $R/tools/ubench/load_align > "$OUT/ub_$c.log" 2>&1 )
+  for f in $(find /tmp/ub_$c -name '*counter_collection.csv'); do cp "$f" "$OUT/ubench_$c.csv"; done
+  pmc flat_$c $c flat
+  pmc nodedup_$c $c nodedup
+done
+pmc flat_SQ1 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" flat
+pmc flat_SQ2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE" flat
+python tools/pmc_traffic.py "$OUT" > "$OUT/pmc_traffic.json" 2> "$OUT/pmc_traffic.err"; head -c 600 "$OUT/pmc_traffic.json"; tail -2 "$OUT/pmc_traffic.err"
+ls "$OUT" | wc -l

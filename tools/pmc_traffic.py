@@ -8,11 +8,12 @@ gfx950 reports exactly half of a wide coalesced read and is uncalibrated for oth
 correction factor used here is derived from a known byte count in the same access pattern:
   * stream_read / node_read (tools/ubench/load_align.hip, 408 004 096 B read once): factor for 16 B/lane
     coalesced reads -> applied to dedup_kernel (same loads);
-  * hash_list_kernel in nodedup mode reads every shipped node once (one node per lane, unaligned 16 B
-    loads): factor = known bytes / reported -> applied to hash_list_kernel in every mode;
+  * hash_deep_kernel in nodedup mode reads every shipped node once (one node per lane, unaligned 16 B
+    loads): factor = known bytes / reported -> applied to both hash kernels in every mode;
   * fillBufferAligned (408 004 096 B written): WRITE_SIZE factor;
-  * the remaining kernels (plan, walk, fixup: scattered 4..32-byte accesses) are left at 1.0 and marked
+  * the remaining kernels (plan, link, walk: scattered 4..32-byte accesses) are left at 1.0 and marked
     uncalibrated -- a lower bound.
+The PMC passes run the pipeline's tiers one after the other (PHANT_VERIFY_SERIAL=1): counters are per dispatch.
 """
 import collections
 import csv
@@ -38,11 +39,12 @@ f_node = (750000 * 532) / ub_f["node_read<4>"]
 f_write = UB_BYTES / ub_w["__amd_rocclr_fillBufferAligned"]
 
 nd_f = mean_by_kernel(os.path.join(d, "nodedup_FETCH_SIZE.csv"))
-# nodedup: 100000 proofs x (7 x 532 + 112) node bytes, + 8-byte offsets (2 per node) + 4-byte list entry,
-# + the 136-byte window of the last rate block reaching past the node (12 B per branch, 24 B per leaf)
+# nodedup: every shipped node hashed in place by hash_deep_kernel: 100000 proofs x (7 x 532 + 112) node bytes,
+# + 8-byte offsets (2 per node), + the 136-byte window of a leaf's only rate block reaching past it (24 B per leaf),
+# + 8 B of proof_first_node and one key byte per node
 n = 100000
-known_hash = n * 3836 + 800000 * (16 + 4) + 700000 * 12 + 100000 * 24 + 700000 * 1
-hk = "phant::hash_chunk_kernel" if "phant::hash_chunk_kernel" in nd_f else "phant::hash_list_kernel"
+known_hash = n * 3836 + 800000 * (16 + 8 + 1) + 100000 * 24
+hk = "phant::v2::hash_deep_kernel"
 f_hash = known_hash / nd_f[hk]
 
 out = {"unit": "bytes per launch (100000 depth-8 proofs)", "factors": {
