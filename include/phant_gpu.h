@@ -258,6 +258,36 @@ PHANT_API int32_t phant_mpt_verify_submit(phant_ctx *ctx, uint32_t slot, const u
                                           uint8_t *status, uint64_t *value_off, uint32_t *value_len);
 PHANT_API int32_t phant_wait(phant_ctx *ctx, uint32_t slot);
 
+/* ------------------------------------------------------------ several GPUs, one process
+ * phant's host is ONE process (src/main.zig:143-149), so the multi-GPU form of the path is inside the library: a
+ * phant_comm owns one ctx (device, private stream, workspaces) per device and an RCCL communicator over them
+ * (RCCL is looked up at run time; a one-device comm does not need it).  A witness shards with no data-path
+ * collective -- proof i is verified on device phant_comm_owner(key_i) = (key_i[0] >> 4) mod N (trie keys are Keccak
+ * outputs: uniform) -- and the only exchange is ONE all-reduce (sum) of the n_roots x u32 failure counts over xGMI.
+ * devices = NULL: devices 0 .. n_devices - 1; n_devices = 0: all visible devices.  flags: PHANT_CTX_* of the
+ * per-device ctxs (the stream and graph flags are ignored).  Externally synchronised like a ctx. */
+typedef struct phant_comm phant_comm;
+PHANT_API int32_t phant_comm_create(const int32_t *devices, uint32_t n_devices, uint32_t flags, phant_comm **out);
+PHANT_API void phant_comm_destroy(phant_comm *comm);
+PHANT_API uint32_t phant_comm_size(const phant_comm *comm);
+PHANT_API phant_ctx *phant_comm_ctx(phant_comm *comm, uint32_t rank); /* rank's ctx: for device-form calls on its device */
+PHANT_API const char *phant_comm_last_error(const phant_comm *comm);
+PHANT_API uint32_t phant_comm_owner(const phant_comm *comm, const uint8_t *key, uint32_t key_len);
+/* Host form of phant_mpt_verify_batch over all devices of the comm (same arguments and outputs, results in the
+ * caller's proof order, value_off into the caller's node blob) + fail_count[r] (n_roots, may be NULL) = proofs against
+ * root r that are not PRESENT / ABSENT, summed over the devices by the all-reduce: the "one pass/fail per root".
+ * The index arrays are read on the host here (the witness is re-packed per device): inconsistent proof_first_node /
+ * node_off make the CALL fail with PHANT_E_INVALID_ARG instead of costing single proofs a BAD_INPUT. */
+PHANT_API int32_t phant_mpt_verify_sharded(phant_comm *comm, const uint8_t *roots, uint32_t n_roots,
+                                           const uint32_t *root_idx, const uint8_t *keys, uint32_t key_len,
+                                           const uint8_t *nodes, uint64_t nodes_len, const uint64_t *node_off,
+                                           const uint32_t *proof_first_node, uint32_t n, uint8_t *status,
+                                           uint64_t *value_off, uint32_t *value_len, uint32_t *fail_count);
+/* Device form of the exchange for callers that keep their shards resident (phant_mpt_verify_verdict_dev on every
+ * phant_comm_ctx): d_fail_count[rank] = that device's n_roots counters; summed in place on every device, on the
+ * ranks' own streams (not waited for). */
+PHANT_API int32_t phant_comm_allreduce_verdict(phant_comm *comm, uint32_t *const *d_fail_count, uint32_t n_roots);
+
 /* ------------------------------------------------------------ block witness
  * The step before the kernel: the engine-API witness as JSON, parsed into
  * the packed arrays above and verified in one call.  phant has no witness type yet

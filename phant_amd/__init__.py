@@ -12,4 +12,4 @@ hand-written HIP for gfx950).  There is no CPU fallback.
 from . import _lib  # noqa: F401
 from .context import Context, default_context  # noqa: F401
 from .crypto import hasher  # noqa: F401
-from . import mpt, state, witness, engine_api, types, signer  # noqa: F401
+from . import mpt, state, witness, engine_api, types, signer, comm  # noqa: F401

@@ -84,6 +84,14 @@ SYMBOLS = {
     "phant_graph_stats": (_i32, [_vp, _vp]),
     "phant_verify_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 8)]),
     "phant_verify_path_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 2)]),
+    "phant_comm_create": (_i32, [_vp, _u32, _u32, C.POINTER(_vp)]),
+    "phant_comm_destroy": (None, [_vp]),
+    "phant_comm_size": (_u32, [_vp]),
+    "phant_comm_ctx": (_vp, [_vp, _u32]),
+    "phant_comm_last_error": (C.c_char_p, [_vp]),
+    "phant_comm_owner": (_u32, [_vp, _vp, _u32]),
+    "phant_mpt_verify_sharded": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "phant_comm_allreduce_verdict": (_i32, [_vp, _vp, _u32]),
 }
 
 

@@ -1,0 +1,71 @@
+"""phant_comm: several GPUs of ONE process behind one handle (include/phant_gpu.h, csrc/comm.hip).
+
+The form a single-process host like phant (src/main.zig:143-149) uses: one ctx per device inside the library, proofs
+dealt out by the top nibble of their trie key, one RCCL all-reduce of the per-root failure counts.  (The
+one-process-per-GPU form of the same exchange, over torch.distributed, is phant_amd/shard.py -- what bench.py runs
+under torchrun.)"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _p(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Comm:
+    def __init__(self, devices: list[int] | None = None, n_devices: int = 0, flags: int = 0):
+        """devices: HIP ordinals (default: 0 .. n_devices - 1; n_devices = 0: every visible device)."""
+        self._lib = L.lib()
+        h = C.c_void_p()
+        arr = None
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*devices)
+            n_devices = len(devices)
+        rc = self._lib.phant_comm_create(arr, n_devices, flags, C.byref(h))
+        if rc != L.OK:
+            raise L.PhantError(rc, "phant_comm_create failed (needs gfx950 devices; RCCL for more than one)")
+        self._h = h
+
+    @property
+    def size(self) -> int:
+        return int(self._lib.phant_comm_size(self._h))
+
+    def owner(self, key: bytes) -> int:
+        buf = (C.c_uint8 * max(1, len(key))).from_buffer_copy(bytes(key) or b"\0")
+        return int(self._lib.phant_comm_owner(self._h, buf, len(key)))
+
+    def verify_sharded(self, roots, root_idx, keys, key_len, nodes, node_off, proof_first_node):
+        """Host form, argument meaning of mpt.verify_batch -> (status, value_off, value_len, fail_count[n_roots])."""
+        roots = np.ascontiguousarray(roots, np.uint8)
+        keys = np.ascontiguousarray(keys, np.uint8)
+        nodes = np.ascontiguousarray(nodes, np.uint8)
+        node_off = np.ascontiguousarray(node_off, np.uint64)
+        pfn = np.ascontiguousarray(proof_first_node, np.uint32)
+        ri = None if root_idx is None else np.ascontiguousarray(root_idx, np.uint32)
+        n = len(pfn) - 1
+        n_roots = roots.size // 32
+        status = np.zeros(max(n, 1), np.uint8)
+        voff = np.zeros(max(n, 1), np.uint64)
+        vlen = np.zeros(max(n, 1), np.uint32)
+        fails = np.zeros(max(n_roots, 1), np.uint32)
+        rc = self._lib.phant_mpt_verify_sharded(self._h, _p(roots), n_roots, _p(ri), _p(keys), key_len, _p(nodes), nodes.size,
+                                                _p(node_off), _p(pfn), n, _p(status), _p(voff), _p(vlen), _p(fails))
+        if rc != L.OK:
+            raise L.PhantError(rc, self._lib.phant_comm_last_error(self._h).decode())
+        return status[:n], voff[:n], vlen[:n], fails[:n_roots]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.phant_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -533,7 +533,8 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
                                  const phant::FlatSide* side, bool timed, const uint8_t* roots, uint32_t n_roots,
                                  const uint32_t* root_idx, const uint8_t* keys, uint32_t key_len, const uint8_t* nodes,
                                  uint64_t nodes_len, const uint64_t* node_off, const uint32_t* proof_first_node,
-                                 uint32_t n, uint8_t* status, uint64_t* value_off, uint32_t* value_len) {
+                                 uint32_t n, uint8_t* status, uint64_t* value_off, uint32_t* value_len,
+                                 uint32_t** d_fail_out = nullptr /* != null: the per-root verdict, left on the device */) {
     // The number of node offsets the caller provided is what the LAST entry of proof_first_node says
     // (include/phant_gpu.h): node_off has proof_first_node[n] + 1 entries.  An earlier entry that points
     // beyond it makes its proofs BAD_INPUT on the device; it never widens what is read from the caller.
@@ -541,7 +542,7 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
     const size_t need = ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) +
                         ws_round((size_t)n * key_len + 4) + ws_round((size_t)nodes_len + 16) +
                         ws_round(((size_t)total_nodes + 1) * 8) + ws_round(((size_t)n + 1) * 4) +
-                        ws_round(n) + ws_round((size_t)n * 8) + ws_round((size_t)n * 4);
+                        ws_round(n) + ws_round((size_t)n * 8) + ws_round((size_t)n * 4) + ws_round((size_t)n_roots * 4);
     if (need > io.cap) HIP_TRY(c, hipStreamSynchronize(s));
     {
         hipError_t e = io.reset(need);
@@ -556,6 +557,7 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
     uint8_t* d_status = io.take<uint8_t>(n);
     uint64_t* d_voff = io.take<uint64_t>(n);
     uint32_t* d_vlen = io.take<uint32_t>(n);
+    uint32_t* d_fail = io.take<uint32_t>(n_roots);
     HIP_TRY(c, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 32, hipMemcpyHostToDevice, s));
     if (root_idx) HIP_TRY(c, hipMemcpyAsync(d_ridx, root_idx, (size_t)n * 4, hipMemcpyHostToDevice, s));
     if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
@@ -564,8 +566,21 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
     HIP_TRY(c, hipMemcpyAsync(d_pfn, proof_first_node, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
     phant::VerifyArgs a{d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
                         d_noff, d_pfn, n, d_status, d_voff, d_vlen};
-    const int32_t vrc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
-    if (vrc) return vrc;
+    if (d_fail_out) {
+        *d_fail_out = d_fail;
+        if (c->verify_fused) {  // the one-lane-per-proof A/B kernel has no tail kernel to carry the verdict
+            const int32_t frc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
+            if (frc) return frc;
+            HIP_TRY(c, phant::launch_mpt_verdict(d_status, a.root_idx, n, n_roots, d_fail, s));
+        } else {
+            a.fail_count = d_fail;
+            const int32_t frc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
+            if (frc) return frc;
+        }
+    } else {
+        const int32_t vrc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
+        if (vrc) return vrc;
+    }
     HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
     if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     if (value_len) HIP_TRY(c, hipMemcpyAsync(value_len, d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -764,6 +779,41 @@ int32_t phant_wait(phant_ctx* c, uint32_t slot) {
     HIP_TRY(c, hipStreamSynchronize(sl.stream));
     return PHANT_OK;
 }
+
+}  // extern "C"
+
+/* ------------------------------------------------- internal: what comm.hip (several devices in one process) builds on */
+namespace phant {
+
+// Stage a host witness on the ctx's own stream, verify it there (helper stream included) with the per-root verdict left
+// in a device array of the ctx, queue the copies of statuses / values back to the caller's buffers.  Does NOT wait.
+int32_t ctx_verify_host_async_verdict(phant_ctx* c, const uint8_t* roots, uint32_t n_roots, const uint32_t* root_idx,
+                                      const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
+                                      const uint64_t* node_off, const uint32_t* proof_first_node, uint32_t n,
+                                      uint8_t* status, uint64_t* value_off, uint32_t* value_len, uint32_t** d_fail) {
+    DeviceGuard g(c->device);
+    {
+        const int32_t src = ensure_side(c);
+        if (src) return src;
+    }
+    return verify_host_async(c, c->stream, c->ws.io, c->dv, &c->side, false, roots, n_roots, root_idx, keys, key_len, nodes,
+                             nodes_len, node_off, proof_first_node, n, status, value_off, value_len, d_fail);
+}
+// a device array of n_roots zeroed counters owned by the ctx (a rank without proofs still takes part in the reduction)
+int32_t ctx_zero_verdict(phant_ctx* c, uint32_t n_roots, uint32_t** d_fail) {
+    DeviceGuard g(c->device);
+    const int32_t rc = ws_reset(c, ws_round((size_t)n_roots * 4));
+    if (rc) return rc;
+    *d_fail = ws_take<uint32_t>(c, n_roots);
+    HIP_TRY(c, hipMemsetAsync(*d_fail, 0, (size_t)n_roots * 4, c->stream));
+    return PHANT_OK;
+}
+hipStream_t ctx_stream(phant_ctx* c) { return c->stream; }
+int ctx_device(const phant_ctx* c) { return c->device; }
+
+}  // namespace phant
+
+extern "C" {
 
 /* ------------------------------------------------------------------ block witness */
 

@@ -1,0 +1,383 @@
+// comm.hip -- several GPUs behind ONE process and one C-ABI handle (phant_comm_*).
+//
+// phant's host is a single process (src/main.zig:143-149: one Blockchain, httpz workers calling one handler), so the
+// multi-GPU form of the path lives inside the library: a phant_comm owns one phant_ctx (stream, workspaces) per
+// device and an RCCL communicator over them.  Proofs are independent given their root, so a witness SHARDS with no
+// data-path collective: proof i belongs to device (key_i[0] >> 4) mod N (keys are Keccak outputs, hence uniform),
+// every device verifies its shard with the two-tier pipeline, and the only exchange is ONE all-reduce (sum) of the
+// n_roots x u32 failure counts -- 4 bytes per root over xGMI, latency-bound, issued for all devices from this
+// thread between ncclGroupStart / ncclGroupEnd on the devices' own streams.
+//
+// RCCL is looked up at run time (a symbol the process already has -- e.g. PyTorch's -- or librccl.so.1): the library
+// links and loads without it, a single-device comm never needs it.  The torchrun form of the same exchange (one
+// process per GPU, torch.distributed) is phant_amd/shard.py.
+//
+// What it stands in for: the per-block witness check at src/engine_api/execution_payload.zig:175-181 when a node has
+// 8 GPUs; BASELINE config 4.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/phant_gpu.h"
+
+#ifndef PHANT_HOST_EMU
+#include <dlfcn.h>
+#endif
+
+struct phant_ctx;
+namespace phant {
+int32_t ctx_verify_host_async_verdict(phant_ctx* c, const uint8_t* roots, uint32_t n_roots, const uint32_t* root_idx,
+                                      const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
+                                      const uint64_t* node_off, const uint32_t* proof_first_node, uint32_t n,
+                                      uint8_t* status, uint64_t* value_off, uint32_t* value_len, uint32_t** d_fail);
+int32_t ctx_zero_verdict(phant_ctx* c, uint32_t n_roots, uint32_t** d_fail);
+hipStream_t ctx_stream(phant_ctx* c);
+int ctx_device(const phant_ctx* c);
+}  // namespace phant
+
+namespace {
+
+// ---- the five RCCL entry points this file uses, resolved at run time ----
+typedef void* rccl_comm_t;
+struct Rccl {
+    int (*comm_init_all)(rccl_comm_t*, int, const int*) = nullptr;
+    int (*comm_destroy)(rccl_comm_t) = nullptr;
+    int (*all_reduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, rccl_comm_t, hipStream_t) = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    const char* (*error_string)(int) = nullptr;
+    bool ok() const { return comm_init_all && comm_destroy && all_reduce && group_start && group_end; }
+};
+constexpr int RCCL_UINT32 = 3, RCCL_SUM = 0;  // ncclUint32, ncclSum (rccl.h)
+
+#ifndef PHANT_HOST_EMU
+bool load_rccl(Rccl& r, std::string& err) {
+    void* h = nullptr;
+    // a copy the process already carries (PyTorch ships its own) wins: two RCCLs in one process is asking for trouble
+    void* probe = dlsym(RTLD_DEFAULT, "ncclCommInitAll");
+    if (!probe) {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) {
+            err = "RCCL not found (librccl.so.1)";
+            return false;
+        }
+    }
+    auto sym = [&](const char* n) -> void* { return h ? dlsym(h, n) : dlsym(RTLD_DEFAULT, n); };
+    r.comm_init_all = reinterpret_cast<decltype(r.comm_init_all)>(sym("ncclCommInitAll"));
+    r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(sym("ncclCommDestroy"));
+    r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(sym("ncclAllReduce"));
+    r.group_start = reinterpret_cast<decltype(r.group_start)>(sym("ncclGroupStart"));
+    r.group_end = reinterpret_cast<decltype(r.group_end)>(sym("ncclGroupEnd"));
+    r.error_string = reinterpret_cast<decltype(r.error_string)>(sym("ncclGetErrorString"));
+    if (!r.ok()) {
+        err = "RCCL lacks an entry point";
+        return false;
+    }
+    return true;
+}
+#else
+// Host-emulation test build (tests/emu.py): "devices" are the host, so the collective is a loop.  Same call pattern as
+// the real thing -- the all-reduce of every rank is noted between group_start and group_end and carried out at the end.
+struct EmuCall {
+    const uint32_t* send;
+    uint32_t* recv;
+    size_t count;
+};
+std::vector<EmuCall> g_emu_calls;
+int emu_init_all(rccl_comm_t* c, int n, const int*) {
+    for (int i = 0; i < n; ++i) c[i] = reinterpret_cast<rccl_comm_t>((uintptr_t)(i + 1));
+    return 0;
+}
+int emu_destroy(rccl_comm_t) { return 0; }
+int emu_all_reduce(const void* s, void* r, size_t count, int dtype, int op, rccl_comm_t, hipStream_t) {
+    if (dtype != RCCL_UINT32 || op != RCCL_SUM) return 1;
+    g_emu_calls.push_back({static_cast<const uint32_t*>(s), static_cast<uint32_t*>(r), count});
+    return 0;
+}
+int emu_group_start() {
+    g_emu_calls.clear();
+    return 0;
+}
+int emu_group_end() {
+    if (g_emu_calls.empty()) return 0;
+    const size_t count = g_emu_calls[0].count;
+    std::vector<uint32_t> sum(count, 0);
+    for (const EmuCall& c : g_emu_calls) {
+        if (c.count != count) return 1;
+        for (size_t i = 0; i < count; ++i) sum[i] += c.send[i];
+    }
+    for (const EmuCall& c : g_emu_calls) std::memcpy(c.recv, sum.data(), count * 4);
+    g_emu_calls.clear();
+    return 0;
+}
+const char* emu_error_string(int) { return "emulated RCCL error"; }
+bool load_rccl(Rccl& r, std::string&) {
+    r.comm_init_all = emu_init_all;
+    r.comm_destroy = emu_destroy;
+    r.all_reduce = emu_all_reduce;
+    r.group_start = emu_group_start;
+    r.group_end = emu_group_end;
+    r.error_string = emu_error_string;
+    return true;
+}
+#endif
+
+// one device's shard of a witness, gathered on the host (proof order kept)
+struct Shard {
+    std::vector<uint32_t> proofs;  // indices into the caller's batch
+    std::vector<uint8_t> keys, nodes, status;
+    std::vector<uint32_t> root_idx, pfn, value_len;
+    std::vector<uint64_t> node_off, value_off;
+    uint32_t* d_fail = nullptr;
+    int32_t rc = PHANT_OK;
+};
+
+}  // namespace
+
+struct phant_comm {
+    std::vector<phant_ctx*> ctx;
+    std::vector<int> devices;
+    std::vector<rccl_comm_t> rccl;
+    Rccl api;
+    bool have_rccl = false;
+    std::string err;
+    std::vector<Shard> shards;
+};
+
+namespace {
+
+int32_t cfail(phant_comm* c, int32_t code, const std::string& what) {
+    if (c) c->err = what;
+    return code;
+}
+
+// RCCL all-reduce (sum) of `count` u32 per rank, in place, on the ranks' own streams
+int32_t all_reduce_u32(phant_comm* c, const std::vector<uint32_t*>& bufs, size_t count) {
+    const size_t n = c->ctx.size();
+    if (n == 1 || count == 0) return PHANT_OK;
+    int rc = c->api.group_start();
+    for (size_t r = 0; r < n && rc == 0; ++r)
+        rc = c->api.all_reduce(bufs[r], bufs[r], count, RCCL_UINT32, RCCL_SUM, c->rccl[r], phant::ctx_stream(c->ctx[r]));
+    const int rc2 = c->api.group_end();
+    if (rc == 0) rc = rc2;
+    if (rc != 0)
+        return cfail(c, PHANT_E_DEVICE, std::string("RCCL all-reduce: ") + (c->api.error_string ? c->api.error_string(rc) : "error"));
+    return PHANT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t flags, phant_comm** out) {
+    if (!out) return PHANT_E_INVALID_ARG;
+    *out = nullptr;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return PHANT_E_NO_DEVICE;
+    if (n_devices == 0) n_devices = (uint32_t)have;  // all of them
+    if (n_devices > 64) return PHANT_E_INVALID_ARG;
+    phant_comm* c = new (std::nothrow) phant_comm();
+    if (!c) return PHANT_E_OOM;
+    for (uint32_t r = 0; r < n_devices; ++r) {
+        const int d = devices ? devices[r] : (int)r;
+        for (int prev : c->devices)
+            if (prev == d) {  // (RCCL cannot put one device into a communicator twice)
+                phant_comm_destroy(c);
+                return PHANT_E_INVALID_ARG;
+            }
+        phant_opts o;
+        o.struct_size = sizeof(o);
+        o.device = d;
+        o.stream = nullptr;
+        o.flags = PHANT_CTX_OWN_STREAM | (flags & ~(uint32_t)PHANT_CTX_VERIFY_GRAPH);
+        phant_ctx* x = nullptr;
+        const int32_t rc = phant_ctx_create(&o, &x);
+        if (rc != PHANT_OK) {
+            phant_comm_destroy(c);
+            return rc;
+        }
+        c->ctx.push_back(x);
+        c->devices.push_back(d);
+    }
+    if (n_devices > 1) {
+        if (!load_rccl(c->api, c->err)) {
+            phant_comm_destroy(c);
+            return PHANT_E_UNSUPPORTED;
+        }
+        c->rccl.assign(n_devices, nullptr);
+        if (c->api.comm_init_all(c->rccl.data(), (int)n_devices, c->devices.data()) != 0) {
+            c->rccl.clear();
+            phant_comm_destroy(c);
+            return PHANT_E_DEVICE;
+        }
+        c->have_rccl = true;
+    }
+    c->shards.resize(n_devices);
+    *out = c;
+    return PHANT_OK;
+}
+
+void phant_comm_destroy(phant_comm* c) {
+    if (!c) return;
+    for (phant_ctx* x : c->ctx) (void)phant_stream_sync(x);
+    if (c->have_rccl)
+        for (rccl_comm_t k : c->rccl)
+            if (k) (void)c->api.comm_destroy(k);
+    for (phant_ctx* x : c->ctx) phant_ctx_destroy(x);
+    delete c;
+}
+
+uint32_t phant_comm_size(const phant_comm* c) { return c ? (uint32_t)c->ctx.size() : 0u; }
+
+phant_ctx* phant_comm_ctx(phant_comm* c, uint32_t rank) { return (c && rank < c->ctx.size()) ? c->ctx[rank] : nullptr; }
+
+const char* phant_comm_last_error(const phant_comm* c) { return c ? c->err.c_str() : "null comm"; }
+
+uint32_t phant_comm_owner(const phant_comm* c, const uint8_t* key, uint32_t key_len) {
+    const uint32_t n = phant_comm_size(c);
+    if (n <= 1 || key_len == 0 || !key) return 0;
+    return (uint32_t)(key[0] >> 4) % n;
+}
+
+int32_t phant_comm_allreduce_verdict(phant_comm* c, uint32_t* const* d_fail_count, uint32_t n_roots) {
+    if (!c || !d_fail_count) return PHANT_E_INVALID_ARG;
+    std::vector<uint32_t*> bufs(d_fail_count, d_fail_count + c->ctx.size());
+    for (uint32_t* p : bufs)
+        if (!p) return cfail(c, PHANT_E_INVALID_ARG, "comm_allreduce_verdict: null buffer");
+    return all_reduce_u32(c, bufs, n_roots);
+}
+
+int32_t phant_mpt_verify_sharded(phant_comm* c, const uint8_t* roots, uint32_t n_roots, const uint32_t* root_idx,
+                                 const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
+                                 const uint64_t* node_off, const uint32_t* proof_first_node, uint32_t n, uint8_t* status,
+                                 uint64_t* value_off, uint32_t* value_len, uint32_t* fail_count) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (fail_count)
+        for (uint32_t r = 0; r < n_roots; ++r) fail_count[r] = 0;
+    if (n == 0) return PHANT_OK;
+    if (!roots || n_roots == 0 || !node_off || !proof_first_node || !status || (key_len && !keys) ||
+        (nodes_len && !nodes) || key_len > 0x3fffffffu)
+        return cfail(c, PHANT_E_INVALID_ARG, "mpt_verify_sharded: bad argument");
+    const uint32_t W = (uint32_t)c->ctx.size();
+    const uint32_t total_nodes = proof_first_node[n];  // node_off has proof_first_node[n] + 1 entries (as in the batch form)
+    // This form reads the index arrays on the HOST (it re-packs the witness per device), so unlike the single-device
+    // forms -- where a bad entry costs its proof a BAD_INPUT on the device -- it insists on consistent ones.
+    for (uint32_t i = 0; i < n; ++i)
+        if (proof_first_node[i + 1] < proof_first_node[i] || proof_first_node[i + 1] > total_nodes)
+            return cfail(c, PHANT_E_INVALID_ARG, "mpt_verify_sharded: proof_first_node is not monotone");
+    for (uint32_t j = 0; j < total_nodes; ++j)
+        if (node_off[j + 1] < node_off[j] || node_off[j + 1] > nodes_len || node_off[j + 1] - node_off[j] > 0x7fffffffull)
+            return cfail(c, PHANT_E_INVALID_ARG, "mpt_verify_sharded: node_off is inconsistent");
+
+    // ---- deal the proofs out ----
+    for (Shard& s : c->shards) {
+        s.proofs.clear();
+        s.d_fail = nullptr;
+        s.rc = PHANT_OK;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        c->shards[phant_comm_owner(c, keys ? keys + (size_t)key_len * i : nullptr, key_len)].proofs.push_back(i);
+
+    // ---- per device, on a host thread of its own: gather the shard, stage it, verify (asynchronous) ----
+    auto work = [&](uint32_t r) {
+        Shard& s = c->shards[r];
+        const uint32_t m = (uint32_t)s.proofs.size();
+        if (m == 0) {
+            s.rc = phant::ctx_zero_verdict(c->ctx[r], n_roots, &s.d_fail);
+            return;
+        }
+        s.keys.resize((size_t)m * key_len);
+        s.root_idx.resize(root_idx ? m : 0);
+        s.pfn.assign((size_t)m + 1, 0);
+        s.node_off.clear();
+        s.nodes.clear();
+        s.status.assign(m, 0);
+        s.value_off.assign(m, 0);
+        s.value_len.assign(m, 0);
+        s.node_off.push_back(0);
+        for (uint32_t k = 0; k < m; ++k) {
+            const uint32_t i = s.proofs[k];
+            if (key_len) std::memcpy(s.keys.data() + (size_t)k * key_len, keys + (size_t)i * key_len, key_len);
+            if (root_idx) s.root_idx[k] = root_idx[i];
+            const uint32_t f = proof_first_node[i], l = proof_first_node[i + 1];
+            s.pfn[k] = (uint32_t)(s.node_off.size() - 1);
+            for (uint32_t j = f; j < l; ++j) {
+                const uint64_t b = node_off[j], e = node_off[j + 1];
+                s.nodes.insert(s.nodes.end(), nodes + b, nodes + e);
+                s.node_off.push_back(s.nodes.size());
+            }
+            s.pfn[k + 1] = (uint32_t)(s.node_off.size() - 1);
+        }
+        s.rc = phant::ctx_verify_host_async_verdict(
+            c->ctx[r], roots, n_roots, root_idx ? s.root_idx.data() : nullptr, s.keys.data(), key_len, s.nodes.data(),
+            s.nodes.size(), s.node_off.data(), s.pfn.data(), m, s.status.data(), s.value_off.data(), s.value_len.data(), &s.d_fail);
+    };
+#ifndef PHANT_HOST_EMU
+    if (W == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (uint32_t r = 0; r < W; ++r) th.emplace_back(work, r);
+        for (std::thread& t : th) t.join();
+    }
+#else  // (the host emulation of the HIP runtime is single-threaded)
+    for (uint32_t r = 0; r < W; ++r) work(r);
+#endif
+    for (uint32_t r = 0; r < W; ++r)
+        if (c->shards[r].rc != PHANT_OK) {
+            for (phant_ctx* x : c->ctx) (void)phant_stream_sync(x);  // nothing of a failed call stays in flight
+            return cfail(c, c->shards[r].rc, std::string("mpt_verify_sharded: device ") + std::to_string(c->devices[r]) + ": " +
+                                                 phant_last_error(c->ctx[r]));
+        }
+
+    // ---- the one exchange: per-root failure counts, summed over the devices (RCCL over xGMI) ----
+    std::vector<uint32_t*> bufs(W);
+    for (uint32_t r = 0; r < W; ++r) bufs[r] = c->shards[r].d_fail;
+    int32_t rc = all_reduce_u32(c, bufs, n_roots);
+    if (rc == PHANT_OK && fail_count) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        hipError_t e = hipSetDevice(c->devices[0]);
+        if (e == hipSuccess) e = hipMemcpyAsync(fail_count, bufs[0], (size_t)n_roots * 4, hipMemcpyDeviceToHost, phant::ctx_stream(c->ctx[0]));
+        if (prev >= 0) (void)hipSetDevice(prev);
+        if (e != hipSuccess) rc = cfail(c, PHANT_E_DEVICE, "mpt_verify_sharded: copying the verdict back");
+    }
+    for (phant_ctx* x : c->ctx) {
+        const int32_t src = phant_stream_sync(x);
+        if (rc == PHANT_OK && src != PHANT_OK) rc = cfail(c, src, std::string("mpt_verify_sharded: ") + phant_last_error(x));
+    }
+    if (rc != PHANT_OK) return rc;
+
+    // ---- results back into the caller's order; value offsets back into the caller's node blob ----
+    for (uint32_t r = 0; r < W; ++r) {
+        const Shard& s = c->shards[r];
+        for (uint32_t k = 0; k < (uint32_t)s.proofs.size(); ++k) {
+            const uint32_t i = s.proofs[k];
+            status[i] = s.status[k];
+            if (value_len) value_len[i] = s.value_len[k];
+            if (value_off) {
+                uint64_t vo = 0;
+                if (s.status[k] == PHANT_PROOF_PRESENT) {
+                    // the value lies in this proof's last node: shard offset - shard node start + caller's node start
+                    const uint32_t f = proof_first_node[i], l = proof_first_node[i + 1];
+                    const uint32_t sf = s.pfn[k];
+                    uint32_t j = 0;
+                    while (j + 1 < l - f && s.node_off[sf + j + 1] <= s.value_off[k]) ++j;
+                    vo = s.value_off[k] - s.node_off[sf + j] + node_off[f + j];
+                }
+                value_off[i] = vo;
+            }
+        }
+    }
+    return PHANT_OK;
+}
+
+}  // extern "C"

@@ -486,9 +486,23 @@ static inline const char* hipGetErrorString(hipError_t e) {
     return e == hipSuccess ? "hipSuccess" : e == hipErrorOutOfMemory ? "hipErrorOutOfMemory" : "hipError";
 }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+// HIPEMU_DEVICES=n: n "devices" (all of them the host; only the current-device bookkeeping differs) -- for the
+// several-devices-in-one-process entry points (phant_comm_*)
+namespace hipemu {
+inline int n_devices() {  // (read at every call: a test may set it after the library was loaded)
+    const char* e = std::getenv("HIPEMU_DEVICES");
+    const int n = e && *e ? std::atoi(e) : 1;
+    return (n < 1 || n > 64) ? 1 : n;
+}
+inline int current_device = 0;
+}  // namespace hipemu
+static inline hipError_t hipGetDeviceCount(int* n) { *n = hipemu::n_devices(); return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = hipemu::current_device; return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) {
+    if (d < 0 || d >= hipemu::n_devices()) return hipErrorInvalidValue;
+    hipemu::current_device = d;
+    return hipSuccess;
+}
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = hipemu::EMU_CUS; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     std::memset(p, 0, sizeof(*p));

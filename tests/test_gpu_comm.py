@@ -1,0 +1,115 @@
+"""phant_comm_* on the MI355X: a comm over the one device a gpurun box has (no RCCL needed for it) must give exactly
+what the single ctx gives; the bodies are shared with tests/test_emu_comm.py, which runs them at 1 / 2 / 3 / 8
+emulated devices on the CPU."""
+import numpy as np
+import pytest
+
+from tests.witness_util import random_kv, pack_proofs, block_witness
+
+
+def _batch(oracle, rng, n_keys=300, n_miss=60):
+    keys, vals = random_kv(rng, n_keys, 32, 1, 70)
+    t = oracle.Trie(keys, vals)
+    q = list(keys[:200]) + [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_miss)]
+    proofs = [t.prove(k) for k in q]
+    # damage a few: flip a byte in some node
+    for i in range(0, len(proofs), 17):
+        p = list(proofs[i])
+        nd = bytearray(p[len(p) // 2])
+        nd[len(nd) // 2] ^= 0x10
+        p[len(p) // 2] = bytes(nd)
+        proofs[i] = p
+    nodes, node_off, pfn = pack_proofs(proofs)
+    return t.root(), q, nodes, node_off, pfn
+
+
+def body_sharded_matches_oracle_and_single_ctx(comm, oracle):
+    import phant_amd
+    rng = np.random.default_rng(41)
+    root, q, nodes, node_off, pfn = _batch(oracle, rng)
+    r = np.frombuffer(root, np.uint8)
+    karr = np.frombuffer(b"".join(q), np.uint8)
+    want = oracle.mpt_verify_batch(r, None, karr, 32, nodes, node_off, pfn)
+    st, vo, vl, fails = comm.verify_sharded(r, None, karr, 32, nodes, node_off, pfn)
+    assert np.array_equal(st, want[0]) and np.array_equal(vo, want[1]) and np.array_equal(vl, want[2])
+    assert int(fails[0]) == int(((want[0] != 1) & (want[0] != 2)).sum()) > 0
+    single = phant_amd.mpt.verify_batch(r, None, karr, 32, nodes, node_off, pfn)
+    assert np.array_equal(st, single[0]) and np.array_equal(vo, single[1]) and np.array_equal(vl, single[2])
+    # the deal: every proof went to the device its key's top nibble names
+    owners = np.array([comm.owner(k) for k in q])
+    assert set(owners.tolist()) <= set(range(comm.size)) and (owners == (np.array([k[0] >> 4 for k in q]) % comm.size)).all()
+    # a second call through the same comm (workspaces reused), fewer proofs, an empty batch
+    st2, _, _, f2 = comm.verify_sharded(r, None, karr[:32 * 5], 32, nodes, node_off[:int(pfn[5]) + 1], pfn[:6])
+    assert np.array_equal(st2, want[0][:5])
+    st0, _, _, f0 = comm.verify_sharded(r, None, np.zeros(0, np.uint8), 32, np.zeros(0, np.uint8), np.zeros(1, np.uint64),
+                                        np.zeros(1, np.uint32))
+    assert st0.size == 0 and int(f0[0]) == 0
+
+
+def body_block_witness_per_root_verdict(comm, oracle):
+    """Config 4 in miniature: account + storage proofs against many roots, damaged ones mixed in; the per-root verdict is
+    the all-reduced sum of what every device saw."""
+    rng = np.random.default_rng(43)
+    roots, root_idx, keys, proofs = block_witness(oracle, rng, n_accounts=120, n_contracts=10, max_slots=40,
+                                                  n_account_proofs=60, n_storage_proofs=150)
+    nodes, node_off, pfn = pack_proofs(proofs)
+    r = np.frombuffer(b"".join(roots), np.uint8)
+    karr = np.frombuffer(b"".join(keys), np.uint8)
+    ri = np.asarray(root_idx, np.uint32)
+    want = oracle.mpt_verify_batch(r, ri, karr, 32, nodes, node_off, pfn)
+    st, vo, vl, fails = comm.verify_sharded(r, ri, karr, 32, nodes, node_off, pfn)
+    assert np.array_equal(st, want[0]) and np.array_equal(vo, want[1]) and np.array_equal(vl, want[2])
+    bad = (want[0] != 1) & (want[0] != 2)
+    assert np.array_equal(fails, np.bincount(ri[bad], minlength=len(roots)).astype(np.uint32))
+
+
+def body_rejects_inconsistent_index_arrays(comm, oracle):
+    from phant_amd import _lib as L
+    rng = np.random.default_rng(44)
+    root, q, nodes, node_off, pfn = _batch(oracle, rng, n_keys=40, n_miss=5)
+    r = np.frombuffer(root, np.uint8)
+    karr = np.frombuffer(b"".join(q), np.uint8)
+    for damage in ("pfn", "off"):
+        p2, o2 = pfn.copy(), node_off.copy()
+        if damage == "pfn":
+            p2[3] = p2[4] + 1
+        else:
+            o2[5] = o2[4] - 1 if o2[4] else 10 ** 12
+        with pytest.raises(L.PhantError) as e:
+            comm.verify_sharded(r, None, karr, 32, nodes, o2, p2)
+        assert e.value.code == L.E_INVALID_ARG
+
+
+@pytest.fixture(scope="module")
+def comm1():
+    import phant_amd
+    c = phant_amd.comm.Comm(devices=[0])
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_one_device_comm_matches_oracle_and_single_ctx(comm1, oracle):
+    body_sharded_matches_oracle_and_single_ctx(comm1, oracle)
+
+
+@pytest.mark.gpu
+def test_one_device_comm_block_witness(comm1, oracle):
+    body_block_witness_per_root_verdict(comm1, oracle)
+    body_rejects_inconsistent_index_arrays(comm1, oracle)
+
+
+@pytest.mark.gpu
+def test_rccl_is_found_and_a_one_rank_allreduce_runs(comm1):
+    """What a 1-GPU box can say about the RCCL path: the library is found at run time and an all-reduce over a
+    one-rank communicator leaves the counters as they are (phant_comm_allreduce_verdict on the comm's ctx stream)."""
+    import ctypes as C
+    import torch
+    from phant_amd import _lib as L
+    lib = L.lib()
+    fc = torch.tensor([3, 0, 7], dtype=torch.int32, device="cuda")
+    arr = (C.c_void_p * 1)(fc.data_ptr())
+    torch.cuda.synchronize()
+    assert lib.phant_comm_allreduce_verdict(comm1._h, arr, 3) == 0
+    assert lib.phant_stream_sync(lib.phant_comm_ctx(comm1._h, 0)) == 0
+    assert fc.tolist() == [3, 0, 7]
