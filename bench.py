@@ -17,6 +17,8 @@ resident in HBM:
       proofs + 60 000 storage proofs over 2 000 contracts of depth 3 / 5 / 7, 2 001 roots) as one multi-root
       batch, sharded over the N GPUs (accounts by top key nibble, contracts whole): STRONG scaling, one
       all-reduce of the per-root failure counts per step.
+  mptize: the state-trie hasher (src/mpt/mpt.zig:38-119 mptize): the root of the trie of --keys sorted random 32-byte
+      keys with 78-byte values (account bodies), arrays resident in HBM (phant_mpt_root_dev).
   config5: consecutive block witnesses streamed from pinned host memory through
       phant_mpt_verify_submit / phant_wait (copy-in of witness k+1 overlaps the kernels of witness k);
       a step = one witness of --stream-proofs depth-8 proofs; PCIe-bound by construction.
@@ -77,7 +79,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5", "nodeset"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5", "nodeset", "mptize"])
+    ap.add_argument("--keys", type=int, default=1_000_000, help="mptize: sorted 32-byte keys (78-byte values) per GPU")
     ap.add_argument("--block-scale", type=float, default=1.0, help="config4: size of the block relative to 10k tx")
     ap.add_argument("--stream-proofs", type=int, default=20_000, help="proofs per streamed witness (config5)")
     ap.add_argument("--stream-slots", type=int, default=3, help="witnesses in flight (config5)")
@@ -216,6 +219,32 @@ def cpu_baseline_config2(blob, n, target_seconds):
     return {"value": cnt * reps / dt, "unit": "hashes/s", "cores": 1, "kind": "port",
             "sample": f"{reps} x first {cnt} messages, oracle/keccak.c single-threaded, {dt:.1f} s",
             "host_cpus": os.cpu_count()}
+
+
+def cpu_baseline_mptize(keys_t, vals_t, n, root_t, target_seconds):
+    """oracle/mpt.c (the restatement of mpt.zig:38-119), 1 core, on a prefix of the same sorted keys; at full size the
+    root is compared with the GPU's."""
+    import numpy as np
+    from oracle import oracle as O
+
+    def run(cnt):
+        kb = keys_t[: cnt * 32].cpu().numpy()
+        vb = vals_t[: cnt * 78].cpu().numpy()
+        ko = (np.arange(cnt + 1, dtype=np.uint32) * 32)
+        vo = (np.arange(cnt + 1, dtype=np.uint64) * 78)
+        t0 = time.perf_counter()
+        r = O.mptize_packed(kb, ko, vb, vo)
+        return r, time.perf_counter() - t0
+
+    probe = min(n, 20000)
+    _, dt = run(probe)
+    cnt = int(max(probe, min(n, probe / dt * target_seconds)))
+    r, dt = run(cnt)
+    out = {"value": cnt / dt, "unit": "keys/s", "cores": 1, "kind": "port",
+           "sample": f"first {cnt} of the {n} sorted keys, oracle/mpt.c single-threaded, {dt:.1f} s", "host_cpus": os.cpu_count()}
+    if cnt == n:
+        out["root_matches_gpu"] = bool(bytes(r) == bytes(root_t.cpu().numpy().tobytes()))
+    return out
 
 
 def mk_ctx(args, local_rank, graph=False, use_torch_stream=True):
@@ -455,6 +484,39 @@ def main():
         metric, unit = "mpt_keys_verified_per_sec_depth%d_nodeset" % args.depth, "proofs/s"
         workload = (f"nodeset: {args.proofs} depth-{args.depth} keys per GPU against one state root, witness = the "
                     f"{set_off.numel() - 1} distinct nodes shipped once ({set_nodes.numel()} B)")
+    elif args.workload == "mptize":
+        # the state-trie hasher: n sorted distinct random 32-byte keys (hashed addresses), 78-byte values (account RLP)
+        n_units = args.keys
+        g = torch.Generator(device=dev)
+        g.manual_seed(7 + rank)
+        k64 = torch.randint(-(1 << 62), 1 << 62, (int(n_units * 1.01) + 16, 4), dtype=torch.int64, device=dev, generator=g)
+        # sort by the big-endian byte order of the key = lexicographic order of the four words taken as unsigned
+        kb = k64.view(torch.uint8).reshape(-1, 32)
+        be = torch.flip(kb.reshape(-1, 4, 8), dims=[2]).contiguous().view(torch.int64).reshape(-1, 4)  # words as BE values
+        order = torch.arange(be.shape[0], device=dev)
+        for c in (3, 2, 1, 0):
+            u = be[order, c]
+            order = order[torch.argsort(u ^ (-(1 << 63)), stable=True)]  # unsigned order
+        kb = kb[order]
+        keep = torch.ones(kb.shape[0], dtype=torch.bool, device=dev)
+        keep[1:] = (kb[1:] != kb[:-1]).any(dim=1)
+        kb = kb[keep][:n_units].contiguous()
+        assert kb.shape[0] == n_units
+        keys_t = kb.reshape(-1)
+        key_off = (torch.arange(n_units + 1, device=dev, dtype=torch.int64) * 32).to(torch.int32)
+        vals_t = torch.randint(0, 256, (n_units * 78,), dtype=torch.uint8, device=dev, generator=g)
+        val_off = torch.arange(n_units + 1, device=dev, dtype=torch.int64) * 78
+        root = torch.empty(32, dtype=torch.uint8, device=dev)
+        alg_bytes = int(keys_t.numel() + vals_t.numel() + 32)
+        torch.cuda.synchronize()
+
+        def step():
+            M.mptize_dev(keys_t, key_off, vals_t, val_off, out=root, ctx=ctx)
+
+        kernel_only = step
+        metric, unit = "mpt_trie_keys_hashed_per_sec", "keys/s"
+        workload = (f"mptize: root of the trie of {n_units} sorted random 32-byte keys with 78-byte values per GPU, arrays "
+                    f"resident in HBM (phant_mpt_root_dev; {alg_bytes} B = keys + values + root)")
     elif args.workload == "config5":
         # 4 distinct witnesses in pinned host memory, submitted round-robin; results land in pinned buffers
         from phant_amd import mpt as MM
@@ -575,6 +637,9 @@ def main():
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
                                 "node-set pipeline = dedup_kernel (class lists) + hash_list_kernel + "
                                 "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
+                                "trie hasher = lcp_kernel + tree_level_kernel x log n + identify_kernel + order_kernel + "
+                                "leaf_kernel + branch_kernel per depth (first start to last end, two counter read-backs "
+                                "in between)" if args.workload == "mptize" else
                                 "mpt_verify_fused_kernel" if args.verify_mode == "fused" else pipeline),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
@@ -589,7 +654,9 @@ def main():
                         "note": "PCIe Gen5 x16 spec; the streamed rate is H2D-bound, the kernels of one witness "
                                 "take roofline.kernel_avg_ms"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.workload == "config4":
+        if args.workload == "mptize":
+            line["cpu_baseline"] = cpu_baseline_mptize(keys_t, vals_t, n_units, root, args.cpu_seconds)
+        elif args.workload == "config4":
             line["cpu_baseline"] = cpu_baseline_block(w, args.cpu_seconds)
         elif args.workload in ("config3", "config5", "nodeset"):
             line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds)

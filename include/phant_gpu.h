@@ -354,6 +354,13 @@ PHANT_API int32_t phant_witness_verify(phant_ctx *ctx, const phant_witness *w, c
 PHANT_API int32_t phant_mpt_root(phant_ctx *ctx, const uint8_t *keys, const uint32_t *key_off,
                                  const uint8_t *vals, const uint64_t *val_off, uint32_t n,
                                  uint8_t out[32]);
+/* The same over DEVICE-resident arrays (PCIe out of the picture): d_key_off / d_val_off are relative to d_keys /
+ * d_vals, key_bytes / val_bytes their totals (= d_key_off[n] / d_val_off[n], known to the caller who packed them); the
+ * root is written to d_root (device, 32 bytes, 4-byte aligned).  Keys of at most 255 bytes; the call synchronises the
+ * ctx stream (it reads the depth histogram and the UNSORTED flag back while it builds). */
+PHANT_API int32_t phant_mpt_root_dev(phant_ctx *ctx, const uint8_t *d_keys, const uint32_t *d_key_off, uint64_t key_bytes,
+                                     const uint8_t *d_vals, const uint64_t *d_val_off, uint64_t val_bytes, uint32_t n,
+                                     uint8_t *d_root);
 
 /* Callers of mptize ("next" rows):
  * src/blockchain/blockchain.zig:209-235 calculateMPTRoot -- key rlp(index) */

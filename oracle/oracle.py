@@ -166,6 +166,19 @@ def mptize(keys, vals) -> bytes:
     return out.tobytes()
 
 
+def mptize_packed(key_blob, key_off, val_blob, val_off) -> bytes:
+    """mptize over already packed arrays (numpy u8 / u32 offsets / u8 / u64 offsets)."""
+    kb = np.ascontiguousarray(key_blob, np.uint8)
+    ko = np.ascontiguousarray(key_off, np.uint32)
+    vb = np.ascontiguousarray(val_blob, np.uint8)
+    vo = np.ascontiguousarray(val_off, np.uint64)
+    out = np.zeros(32, np.uint8)
+    rc = lib().oracle_mptize(_p(kb), _p(ko), _p(vb), _p(vo), len(ko) - 1, _p(out))
+    if rc:
+        raise ValueError(f"oracle_mptize rc={rc}")
+    return out.tobytes()
+
+
 class Trie:
     """Materialised oracle trie for proof extraction."""
 

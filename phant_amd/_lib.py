@@ -84,6 +84,7 @@ SYMBOLS = {
     "phant_graph_stats": (_i32, [_vp, _vp]),
     "phant_verify_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 8)]),
     "phant_verify_path_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 2)]),
+    "phant_mpt_root_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _u32, _vp]),
     "phant_comm_create": (_i32, [_vp, _u32, _u32, C.POINTER(_vp)]),
     "phant_comm_destroy": (None, [_vp]),
     "phant_comm_size": (_u32, [_vp]),

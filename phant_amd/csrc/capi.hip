@@ -1064,6 +1064,20 @@ int32_t phant_mpt_root(phant_ctx* c, const uint8_t* keys, const uint32_t* key_of
     return PHANT_OK;
 }
 
+int32_t phant_mpt_root_dev(phant_ctx* c, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
+                           const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n, uint8_t* d_root) {
+    if (!c || !d_root || ((uintptr_t)d_root & 3u)) return PHANT_E_INVALID_ARG;
+    if (n && (!d_key_off || !d_val_off || (key_bytes && !d_keys) || (val_bytes && !d_vals)))
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_root_dev: null pointer");
+    DeviceGuard g(c->device);
+    std::string err;
+    TimedRegion t(c);
+    const int32_t rc = phant::trie_root_dev(c->ws, c->stream, d_keys, d_key_off, key_bytes, d_vals, d_val_off, val_bytes, n,
+                                            d_root, err);
+    if (rc) return fail(c, rc, err.c_str());
+    return PHANT_OK;
+}
+
 int32_t phant_index_root_rlp(phant_ctx* c, const uint8_t* items, const uint64_t* item_off,
                              uint32_t n, uint8_t out[32]) {
     if (!c || !out) return PHANT_E_INVALID_ARG;

@@ -16,6 +16,13 @@ int32_t trie_root_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, cons
                        const uint8_t* vals, const uint64_t* val_off, uint32_t n, uint8_t out[32],
                        std::string& err);
 
+// mptize over DEVICE-resident arrays (key_off / val_off relative to d_keys / d_vals, n + 1 entries each, the byte
+// totals given by the caller who packed them); the root lands in d_root (device).  The pass reads two small counter
+// blocks back in between (depth bins, the UNSORTED flag), i.e. it synchronises the stream twice.
+int32_t trie_root_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
+                      const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n, uint8_t* d_root,
+                      std::string& err);
+
 // A forest of independent tries in one pass: trie t owns keys
 // [seg_first[t], seg_first[t+1]); roots_out = n_tries x 32 bytes.
 int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,

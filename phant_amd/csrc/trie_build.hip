@@ -167,11 +167,23 @@ PHANT_DEV uint32_t rep_of(const TrieDev& t, uint32_t x, int32_t lcp_x, int32_t p
     return next_less(t, PL, pd + 1);
 }
 
-__global__ void __launch_bounds__(256) identify_kernel(TrieDev t) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= t.n) return;  // (whole trailing lanes of the last wave: ballots below only see live lanes)
+// Workgroups of 1 024 lanes for the two kernels that count into a handful of global counters: atomics on one address
+// are served one at a time (~12 ns each, tools/ubench/atomic_rate.hip) whether they return a value or not, and a
+// million keys have their ~335 k branch nodes on three or four depths -- one atomic per WAVE and depth was 47 000
+// of them (0.55 ms in each of the two kernels); the counting now happens in LDS, one global atomic per WORKGROUP
+// and depth.
+constexpr uint32_t COUNT_BLOCK = 1024;
+
+__global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
+    __shared__ uint32_t s_hist[MAX_DEPTH_BINS];
+    __shared__ uint32_t s_wave_reps[COUNT_BLOCK / 64];
+    __shared__ uint32_t s_dense_base;
+    const uint32_t i = blockIdx.x * COUNT_BLOCK + threadIdx.x;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK) s_hist[b] = 0u;
+    __syncthreads();
+    const bool in = i < t.n;
     // --- key i as a leaf (or a branch value) ---
-    {
+    if (in) {
         const int32_t dl = t.lcp[i], dr = t.lcp[i + 1];
         const int32_t di = dl > dr ? dl : dr;
         if (di < 0) {
@@ -191,8 +203,8 @@ __global__ void __launch_bounds__(256) identify_kernel(TrieDev t) {
     // --- boundary i as a branch node ---
     uint32_t dn = NONE;
     bool is_rep = false;
-    const int32_t d = t.lcp[i];
-    if (i >= 1 && d >= 0) {
+    const int32_t d = in ? t.lcp[i] : -1;
+    if (in && i >= 1 && d >= 0) {
         const uint32_t p = prev_less(t, i, d + 1);
         if (t.lcp[p] < d) {  // leftmost boundary of value d in its interval
             const uint32_t l = p;
@@ -205,43 +217,45 @@ __global__ void __launch_bounds__(256) identify_kernel(TrieDev t) {
             is_rep = true;
         }
     }
-    // dense ids and the per-depth histogram: ONE atomic per wave and counter, not one per node -- returning
-    // atomics on the same address are served one at a time (~12 ns each, tools/ubench/atomic_rate.hip), and a
-    // million keys have ~70 k branch nodes on a handful of depths
-    const uint32_t lane = threadIdx.x & 63u;
+    // dense ids: ranks inside the workgroup (ballot + the waves' totals in LDS), one global reservation; the
+    // per-depth histogram: LDS counters, one global add per depth the workgroup met
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long reps = __ballot(is_rep);
-    if (reps) {
-        uint32_t base = 0;
-        if (lane == (uint32_t)__builtin_ctzll(reps)) base = atomicAdd(&t.counters[0], (uint32_t)__popcll(reps));
-        base = __shfl(base, __builtin_ctzll(reps), 64);
-        if (is_rep) dn = base + (uint32_t)__popcll(reps & ((1ull << lane) - 1ull));
-        unsigned long long todo = reps;
-        while (todo) {
-            const int32_t d0 = __shfl(d, __builtin_ctzll(todo), 64);
-            const unsigned long long same = __ballot(is_rep && d == d0);
-            if (lane == (uint32_t)__builtin_ctzll(same)) atomicAdd(&t.counters[8 + d0], (uint32_t)__popcll(same));
-            todo &= ~same;
-        }
+    if (lane == 0) s_wave_reps[wave] = (uint32_t)__popcll(reps);
+    if (is_rep) atomicAdd(&s_hist[d], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < COUNT_BLOCK / 64u; ++w) tot += s_wave_reps[w];
+        s_dense_base = tot ? atomicAdd(&t.counters[0], tot) : 0u;
     }
-    t.dense[i] = dn;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK)
+        if (s_hist[b]) atomicAdd(&t.counters[8 + b], s_hist[b]);
+    __syncthreads();
+    if (is_rep) {
+        uint32_t base = s_dense_base;
+        for (uint32_t w = 0; w < wave; ++w) base += s_wave_reps[w];
+        dn = base + (uint32_t)__popcll(reps & ((1ull << lane) - 1ull));
+    }
+    if (in) t.dense[i] = dn;
 }
 
-__global__ void __launch_bounds__(256) order_kernel(TrieDev t, const uint32_t* depth_begin) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__global__ void __launch_bounds__(COUNT_BLOCK) order_kernel(TrieDev t, const uint32_t* depth_begin) {
+    __shared__ uint32_t s_cnt[MAX_DEPTH_BINS];
+    __shared__ uint32_t s_base[MAX_DEPTH_BINS];
+    const uint32_t i = blockIdx.x * COUNT_BLOCK + threadIdx.x;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK) s_cnt[b] = 0u;
+    __syncthreads();
     const bool live = i < t.n && i != 0 && t.dense[i] != NONE;
     const int32_t d = live ? t.lcp[i] : -1;
-    // one reservation per wave and depth (see identify_kernel)
-    const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long todo = __ballot(live);
-    while (todo) {
-        const int32_t d0 = __shfl(d, __builtin_ctzll(todo), 64);
-        const unsigned long long same = __ballot(live && d == d0);
-        uint32_t base = 0;
-        if (lane == (uint32_t)__builtin_ctzll(same)) base = atomicAdd(&t.depth_cursor[d0], (uint32_t)__popcll(same));
-        base = __shfl(base, __builtin_ctzll(same), 64);
-        if (live && d == d0) t.order[depth_begin[d0] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
-        todo &= ~same;
-    }
+    // rank inside the workgroup's share of depth d (LDS), then one global reservation per workgroup and depth;
+    // the order inside a depth bin is immaterial (it is a work list)
+    const uint32_t local = live ? atomicAdd(&s_cnt[d], 1u) : 0u;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK)
+        if (s_cnt[b]) s_base[b] = atomicAdd(&t.depth_cursor[b], s_cnt[b]);
+    __syncthreads();
+    if (live) t.order[depth_begin[d] + s_base[d] + local] = i;
 }
 
 // ---- RLP helpers (row a10: canonical subset used at mpt.zig:127,198,236,268) ----
@@ -336,6 +350,39 @@ PHANT_DEV uint8_t* put_hp(uint8_t* w, const TrieDev& t, uint32_t k, uint32_t ps,
     return w;
 }
 
+// ---- nodes staged in LDS ----
+// A lane used to write its node's RLP byte by byte into a global scratch blob and hash it from there: 64 lanes x one
+// byte per store instruction = 64 partial-line writes per instruction, which is what the leaf and branch kernels'
+// time was made of (1.5 ms each per million keys against 0.13 ms of Keccak-f).  Now the lane builds the node in an LDS
+// slot of its own (same helpers: after inlining the compiler sees an LDS address and emits ds_write_b8), appends the
+// Keccak padding there, and the sponge absorbs whole dwords from LDS -- no masks, no global round trip.  A node that
+// does not fit its slot takes the old way through the scratch blob.
+// Slot layout: STAGE_DW dwords per lane, odd (consecutive lanes' equal offsets fall into different banks).
+template <uint32_t STAGE_DW>
+PHANT_DEV void stage_clear(uint32_t* slot) {
+#pragma unroll
+    for (uint32_t k = 0; k < STAGE_DW; ++k) slot[k] = 0u;
+}
+// rate blocks needed by `total` message bytes (pad10*1 always adds at least one byte)
+PHANT_DEV uint32_t blocks_of(uint32_t total) { return total / RATE + 1u; }
+// Keccak-256 of the `total` bytes at the start of a ZERO-FILLED slot (capacity >= blocks_of(total) * 136 bytes)
+PHANT_DEV void keccak256_staged(Sponge& s, uint32_t* slot, uint32_t total) {
+    uint8_t* b = reinterpret_cast<uint8_t*>(slot);
+    const uint32_t nb = blocks_of(total);
+    b[total] = 0x01;                         // domain byte of Keccak-256 (hasher.zig -> Zig std Keccak256)
+    b[nb * RATE - 1u] |= 0x80;               // (the same byte when total = 136 nb - 1: 0x81)
+    sponge_zero(s);
+    for (uint32_t k = 0; k < nb; ++k) {      // exec-masked: lanes run as many blocks as their node has
+        const uint32_t* w = slot + k * RATE_DWORDS;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+            s.lo[i] ^= w[2 * i];
+            s.hi[i] ^= w[2 * i + 1];
+        }
+        keccak_f1600(s);
+    }
+}
+
 // Deliver a finished node's reference (<= 32 bytes) to its parent slot, or to
 // the trie's root output.
 PHANT_DEV void deliver(const TrieDev& t, uint32_t parent, uint32_t nib, uint32_t first_key,
@@ -376,8 +423,26 @@ __global__ void __launch_bounds__(256) leaf_kernel(TrieDev t) {
         payload = hp_rlp_size(nl - ps) + rlp_str_size(vlen, vlen ? v[0] : 0u);
         total = (uint32_t)(rlp_list_hdr_size(payload) + payload);
     }
-    const unsigned long long at = wave_alloc(t.cursor, (total + 3u) & ~3u);
+    // one rate block of LDS per lane (a state-trie leaf is ~112 bytes); longer leaves go through the scratch blob
+    constexpr uint32_t STAGE_DW = RATE_DWORDS + 1u;  // 35: odd
+    __shared__ uint32_t s_stage[256 * STAGE_DW];
+    const bool staged = live && total < RATE;
+    const unsigned long long at = wave_alloc(t.cursor, (live && !staged) ? ((total + 3u) & ~3u) : 0u);
     if (!live) return;
+    const uint32_t parent = t.leaf_parent[i];
+    const bool hashed = total >= 32u || parent == NONE;
+    Sponge s;
+    if (staged) {
+        uint32_t* slot = s_stage + threadIdx.x * STAGE_DW;
+        stage_clear<STAGE_DW>(slot);
+        uint8_t* enc = reinterpret_cast<uint8_t*>(slot);
+        uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
+        w = put_hp(w, t, i, ps, nl, true);
+        w = put_str(w, v, vlen);
+        if (hashed) keccak256_staged(s, slot, total);
+        deliver(t, parent, ps ? nib_at(t, i, ps - 1) : 0u, i, enc, total, s, hashed);
+        return;
+    }
     if (at + total > t.scratch_cap) {
         atomicOr(&t.counters[2], 1u);
         return;
@@ -386,17 +451,77 @@ __global__ void __launch_bounds__(256) leaf_kernel(TrieDev t) {
     uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
     w = put_hp(w, t, i, ps, nl, true);
     w = put_str(w, v, vlen);
-    const uint32_t parent = t.leaf_parent[i];
-    const bool hashed = total >= 32u || parent == NONE;
-    Sponge s;
     if (hashed) keccak256_global(s, enc, total);
     deliver(t, parent, ps ? nib_at(t, i, ps - 1) : 0u, i, enc, total, s, hashed);
 }
 
 // BranchNode (mpt.zig:216-231) at nibble depth d, plus the ExtensionNode above
 // it when the parent is more than one nibble up (mpt.zig:83-106, :187-193).
-__global__ void __launch_bounds__(256) branch_kernel(TrieDev t, uint32_t begin, uint32_t count) {
-    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+// Writes the 17-item list into `enc` (LDS slot or scratch blob: the caller's pointer decides what the stores are).
+PHANT_DEV uint8_t* put_branch(uint8_t* enc, const TrieDev& t, uint32_t dn, uint64_t payload, const uint8_t* v, uint64_t vlen) {
+    uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
+    for (uint32_t k = 0; k < 16; ++k) {
+        const uint64_t slot = (uint64_t)dn * 16u + k;
+        const uint32_t sl = t.slot_len[slot];
+        const uint8_t* src = t.slot_bytes + slot * 32u;
+        if (sl == 0) {
+            *w++ = 0x80;
+        } else {
+            if (sl == 32u) {
+                *w++ = 0xa0;
+                // a 32-byte reference: two aligned 16-byte loads from the slot table, bytes out
+                const uint4 q0 = reinterpret_cast<const uint4*>(src)[0], q1 = reinterpret_cast<const uint4*>(src)[1];
+                const uint32_t qq[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                for (int b = 0; b < 32; ++b) w[b] = (uint8_t)(qq[b >> 2] >> (8 * (b & 3)));
+            } else {
+                for (uint32_t b = 0; b < sl; ++b) w[b] = src[b];
+            }
+            w += sl;
+        }
+    }
+    if (vlen)
+        w = put_str(w, v, vlen);
+    else
+        *w++ = 0x80;
+    return w;
+}
+// ExtensionNode [HP(path), ref] over nibbles [ps, pe) of key l; ref = the 32-byte digest in s, or the `total` bytes at
+// `inner` (a branch shorter than 32 bytes is embedded).  Returns the node's length.
+PHANT_DEV uint32_t put_extension(uint8_t* xenc, const TrieDev& t, uint32_t l, uint32_t ps, uint32_t pe, bool inner_hashed,
+                                 const Sponge& s, const uint8_t* inner, uint32_t total) {
+    const uint32_t ref_size = inner_hashed ? 33u : total;
+    const uint64_t xpayload = hp_rlp_size(pe - ps) + ref_size;
+    uint8_t* x = put_hdr(xenc, xpayload, 0xc0u, 0xf7u);
+    x = put_hp(x, t, l, ps, pe, false);
+    if (inner_hashed) {
+        *x++ = 0xa0;
+        // digest bytes, little-endian lanes
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = s.lo[k], hi = s.hi[k];
+            for (int b = 0; b < 4; ++b) x[8 * k + b] = (uint8_t)(lo >> (8 * b));
+            for (int b = 0; b < 4; ++b) x[8 * k + 4 + b] = (uint8_t)(hi >> (8 * b));
+        }
+        x += 32;
+    } else {
+        for (uint32_t b = 0; b < total; ++b) x[b] = inner[b];
+        x += total;
+    }
+    return (uint32_t)(x - xenc);
+}
+
+// One wave per workgroup: the LDS slot of a lane holds four rate blocks (a full 17-item branch is 532 bytes).
+constexpr uint32_t BRANCH_LANES = 64;
+constexpr uint32_t BRANCH_STAGE_BLOCKS = 4;
+constexpr uint32_t BRANCH_STAGE_DW = BRANCH_STAGE_BLOCKS * RATE_DWORDS + 1u;  // 137: odd
+constexpr uint32_t BRANCH_STAGE_BYTES = BRANCH_STAGE_BLOCKS * RATE;
+
+__global__ void __launch_bounds__(BRANCH_LANES) branch_kernel(TrieDev t, uint32_t begin, uint32_t count) {
+    __shared__ uint32_t s_stage[BRANCH_LANES * BRANCH_STAGE_DW];
+    __shared__ uint32_t s_total;
+    __shared__ unsigned long long s_base;
+    const uint32_t q = blockIdx.x * BRANCH_LANES + threadIdx.x;
     const bool live = q < count;
     uint32_t i = 0, dn = 0, total = 0, vk = NONE;
     uint64_t payload = 0, vlen = 0;
@@ -404,8 +529,12 @@ __global__ void __launch_bounds__(256) branch_kernel(TrieDev t, uint32_t begin, 
     if (live) {
         i = t.order[begin + q];
         dn = t.dense[i];
+        // the 16 slot lengths: one aligned 16-byte load
+        const uint4 sl4 = *reinterpret_cast<const uint4*>(t.slot_len + (uint64_t)dn * 16u);
+        const uint32_t slw[4] = {sl4.x, sl4.y, sl4.z, sl4.w};
+#pragma unroll
         for (uint32_t k = 0; k < 16; ++k) {
-            const uint32_t sl = t.slot_len[(uint64_t)dn * 16u + k];
+            const uint32_t sl = (slw[k >> 2] >> (8u * (k & 3u))) & 0xffu;
             payload += sl == 0 ? 1u : (sl == 32u ? 33u : sl);
         }
         vk = t.value_key[i];
@@ -422,64 +551,69 @@ __global__ void __launch_bounds__(256) branch_kernel(TrieDev t, uint32_t begin, 
     const uint32_t l = live ? t.nd_l[i] : 0u;
     // extension size bound: list hdr (<=3) + HP string (<= 2 + ext_len/2 + 1) + ref (<= 33)
     const uint32_t ext_cap = (live && ext_len) ? (40u + ext_len / 2u + 4u) : 0u;
-    const unsigned long long at = wave_alloc(t.cursor, ((total + 3u) & ~3u) + ((ext_cap + 3u) & ~3u));
-    if (!live) return;
-    if (at + total + ext_cap + 8 > t.scratch_cap) {
-        atomicOr(&t.counters[2], 1u);
-        return;
-    }
-    uint8_t* enc = t.scratch + at;
-    uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
-    for (uint32_t k = 0; k < 16; ++k) {
-        const uint64_t slot = (uint64_t)dn * 16u + k;
-        const uint32_t sl = t.slot_len[slot];
-        const uint8_t* src = t.slot_bytes + slot * 32u;
-        if (sl == 0) {
-            *w++ = 0x80;
-        } else {
-            if (sl == 32u) *w++ = 0xa0;
-            for (uint32_t b = 0; b < sl; ++b) w[b] = src[b];
-            w += sl;
-        }
-    }
-    if (vlen)
-        w = put_str(w, v, vlen);
-    else
-        *w++ = 0x80;
-
-    const uint32_t parent = t.nd_parent[i];
-    const bool is_root = parent == NONE;
-    bool hashed = total >= 32u || (is_root && ext_len == 0);
-    Sponge s;
-    if (hashed) keccak256_global(s, enc, total);
-    uint32_t out_len = total;
-    if (ext_len) {
-        // ExtensionNode [HP(path), ref]; path = key l, nibbles [pd+1, d)
-        uint8_t* xenc = enc + ((total + 3u) & ~3u);
-        const uint32_t ref_size = hashed ? 33u : total;
-        const uint64_t xpayload = hp_rlp_size(ext_len) + ref_size;
-        uint8_t* x = put_hdr(xenc, xpayload, 0xc0u, 0xf7u);
-        x = put_hp(x, t, l, (uint32_t)(pd + 1), (uint32_t)d, false);
-        if (hashed) {
-            *x++ = 0xa0;
-            // digest bytes, little-endian lanes
+    // staged in LDS when the branch leaves room for the padding in its four blocks and the extension fits two
+    const bool staged = live && payload < BRANCH_STAGE_BYTES - 8u && total < BRANCH_STAGE_BYTES && ext_cap < 2u * RATE;
+    // the others reserve room in the scratch blob: one reservation per workgroup (= wave)
+    {
+        const uint32_t need = (live && !staged) ? (((total + 3u) & ~3u) + ((ext_cap + 3u) & ~3u)) : 0u;
+        uint32_t incl = need;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t lo = s.lo[k], hi = s.hi[k];
-                for (int b = 0; b < 4; ++b) x[8 * k + b] = (uint8_t)(lo >> (8 * b));
-                for (int b = 0; b < 4; ++b) x[8 * k + 4 + b] = (uint8_t)(hi >> (8 * b));
-            }
-            x += 32;
-        } else {
-            for (uint32_t b = 0; b < total; ++b) x[b] = enc[b];
-            x += total;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if ((threadIdx.x & 63u) >= (uint32_t)o) incl += up;
         }
-        out_len = (uint32_t)(x - xenc);
-        enc = xenc;
-        hashed = out_len >= 32u || is_root;
-        if (hashed) keccak256_global(s, enc, out_len);
+        if (threadIdx.x == BRANCH_LANES - 1u) s_total = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_total ? atomicAdd(t.cursor, (unsigned long long)s_total) : 0ull;
+        __syncthreads();
+        if (!live) return;
+        const uint32_t parent = t.nd_parent[i];
+        const bool is_root = parent == NONE;
+        bool hashed = total >= 32u || (is_root && ext_len == 0);
+        Sponge s;
+        sponge_zero(s);
+        if (staged) {
+            uint32_t* slot = s_stage + threadIdx.x * BRANCH_STAGE_DW;
+            stage_clear<BRANCH_STAGE_DW>(slot);
+            uint8_t* enc = reinterpret_cast<uint8_t*>(slot);
+            (void)put_branch(enc, t, dn, payload, v, vlen);
+            if (hashed) keccak256_staged(s, slot, total);
+            uint32_t out_len = total;
+            if (ext_len) {
+                // the extension gets a clean region: behind an embedded branch (shorter than 32 bytes), or the
+                // whole slot again once the branch is a digest in registers
+                uint32_t* xslot = slot + 2u * RATE_DWORDS;
+                if (hashed) {
+                    stage_clear<BRANCH_STAGE_DW>(slot);
+                    xslot = slot;
+                }
+                uint8_t* xenc = reinterpret_cast<uint8_t*>(xslot);
+                out_len = put_extension(xenc, t, l, (uint32_t)(pd + 1), (uint32_t)d, hashed, s, enc, total);
+                enc = xenc;
+                hashed = out_len >= 32u || is_root;
+                if (hashed) keccak256_staged(s, xslot, out_len);
+            }
+            deliver(t, parent, is_root ? 0u : nib_at(t, l, (uint32_t)pd), l, enc, out_len, s, hashed);
+            return;
+        }
+        const unsigned long long at = s_base + (incl - need);
+        if (at + total + ext_cap + 8 > t.scratch_cap) {
+            atomicOr(&t.counters[2], 1u);
+            return;
+        }
+        uint8_t* enc = t.scratch + at;
+        (void)put_branch(enc, t, dn, payload, v, vlen);
+        if (hashed) keccak256_global(s, enc, total);
+        uint32_t out_len = total;
+        if (ext_len) {
+            uint8_t* xenc = enc + ((total + 3u) & ~3u);
+            out_len = put_extension(xenc, t, l, (uint32_t)(pd + 1), (uint32_t)d, hashed, s, enc, total);
+            enc = xenc;
+            hashed = out_len >= 32u || is_root;
+            if (hashed) keccak256_global(s, enc, out_len);
+        }
+        deliver(t, parent, is_root ? 0u : nib_at(t, l, (uint32_t)pd), l, enc, out_len, s, hashed);
     }
-    deliver(t, parent, is_root ? 0u : nib_at(t, l, (uint32_t)pd), l, enc, out_len, s, hashed);
 }
 
 __global__ void __launch_bounds__(256) fill_empty_roots_kernel(uint8_t* roots, uint32_t n_tries) {
@@ -567,7 +701,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     if (M > n + 1) hipLaunchKernelGGL(tree_pad_kernel, dim3(blocks(M - n - 1)), dim3(256), 0, st, t);
     for (uint32_t w = M / 2; w >= 1; w >>= 1)
         hipLaunchKernelGGL(tree_level_kernel, dim3(blocks(w)), dim3(256), 0, st, t.tree, w);
-    hipLaunchKernelGGL(identify_kernel, dim3(blocks(n)), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(identify_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
     TB_TRY(hipGetLastError());
 
     std::vector<uint32_t> cnt(8 + MAX_DEPTH_BINS);
@@ -599,12 +733,12 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     t.scratch_cap = cap;
     TB_TRY(hipMemsetAsync(t.slot_len, 0, (size_t)n_rep * 16, st));
 
-    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3(blocks(n)), dim3(256), 0, st, t, d_depth_begin);
+    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t, d_depth_begin);
     hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t);
     for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
         const uint32_t c = cnt[8 + d];
         if (!c) continue;
-        hipLaunchKernelGGL(branch_kernel, dim3(blocks(c)), dim3(256), 0, st, t, depth_begin[d], c);
+        hipLaunchKernelGGL(branch_kernel, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t, depth_begin[d], c);
     }
     TB_TRY(hipGetLastError());
     uint32_t flags[3];
@@ -681,6 +815,19 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
     }
     TB_TRY(hipStreamSynchronize(st));
     return PHANT_OK;
+}
+
+int32_t trie_root_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
+                      const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n, uint8_t* d_root,
+                      std::string& err) {
+    // the one trie's segment table: two words in the io arena (nothing else of a device-form call lives there)
+    TB_TRY(ws.io.reset(1024));
+    uint32_t* d_seg = ws.io.take<uint32_t>(2);
+    const uint32_t seg[2] = {0, n};
+    TB_TRY(hipMemcpyAsync(d_seg, seg, sizeof seg, hipMemcpyHostToDevice, st));
+    const int32_t rc = forest_device(ws, st, d_keys, d_key_off, d_vals, d_val_off, n, key_bytes, val_bytes, d_seg, 1, d_root, err);
+    if (rc) (void)hipStreamSynchronize(st);
+    return rc;
 }
 
 int32_t trie_root_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,

@@ -93,6 +93,19 @@ def mptize(keyvals, ctx: Context | None = None) -> bytes:
     return mptize_packed(kb, ko, vb, vo, ctx)
 
 
+def mptize_dev(keys: torch.Tensor, key_off: torch.Tensor, vals: torch.Tensor, val_off: torch.Tensor,
+               out: torch.Tensor | None = None, ctx: Context | None = None) -> torch.Tensor:
+    """mptize over device-resident packed arrays (phant_mpt_root_dev): keys u8[], key_off i32[n + 1], vals u8[],
+    val_off i64[n + 1] -> root u8[32] on the device.  Keys strictly increasing (mpt.zig:39) else PHANT_E_UNSORTED."""
+    ctx = ctx or default_context(keys.device.index)
+    n = key_off.numel() - 1
+    if out is None:
+        out = torch.empty(32, dtype=torch.uint8, device=keys.device)
+    ctx.check(ctx._lib.phant_mpt_root_dev(ctx.handle, keys.data_ptr(), key_off.data_ptr(), keys.numel(), vals.data_ptr(),
+                                          val_off.data_ptr(), vals.numel(), n, out.data_ptr()))
+    return out
+
+
 def index_root_rlp(items, ctx: Context | None = None) -> bytes:
     """calculateMPTRoot (blockchain.zig:209-235): item i under key rlp(i)."""
     ctx = ctx or default_context()

@@ -44,6 +44,37 @@ def test_mptize_random_vs_oracle(P, oracle, n, key_len, shared, vmax):
     assert P.mpt.mptize(kvs) == oracle.mptize(keys, vals)
 
 
+def test_mptize_device_form_matches_host_form_and_oracle(P, oracle):
+    """phant_mpt_root_dev: the same trie from device-resident packed arrays -- reference vectors, random tries with
+    fixed and variable-length keys, the empty trie; unsorted keys are refused."""
+    import torch
+    from phant_amd import _lib as L
+
+    def dev_root(keys, vals):
+        kb = np.frombuffer(b"".join(keys), np.uint8)
+        ko = np.concatenate([[0], np.cumsum([len(k) for k in keys])]).astype(np.int32)
+        vb = np.frombuffer(b"".join(vals), np.uint8)
+        vo = np.concatenate([[0], np.cumsum([len(v) for v in vals])]).astype(np.int64)
+        t = lambda a, dt: (torch.from_numpy(np.array(a)) if a.size else torch.zeros(0, dtype=dt)).cuda()
+        out = P.mpt.mptize_dev(t(kb, torch.uint8), t(ko, torch.int32), t(vb, torch.uint8), t(vo, torch.int64))
+        torch.cuda.synchronize()
+        return bytes(out.cpu().numpy().tobytes())
+
+    for v in golden.mpt_vectors():
+        keys = [bytes.fromhex(k) for k in v["keys"]]
+        vals = [bytes.fromhex(x) for x in v["values"]]
+        assert dev_root(keys, vals).hex() == v["root"], v["name"]
+    for n, key_len, shared, vmax in ((1, 32, 0, 40), (700, 32, 0, 120), (900, 32, 10, 40), (3000, 3, 0, 10), (300, 4, 0, 700)):
+        rng = np.random.default_rng(1000 + n)
+        keys, vals = random_kv(rng, n, key_len, 1, vmax, shared)
+        want = oracle.mptize(keys, vals)
+        assert dev_root(keys, vals) == want
+        assert P.mpt.mptize([P.mpt.KeyVal.init(k, x) for k, x in zip(keys, vals)]) == want
+    with pytest.raises(L.PhantError) as e:
+        dev_root([b"\x02", b"\x01"], [b"a", b"b"])
+    assert e.value.code == L.E_UNSORTED
+
+
 def test_mptize_variable_length_keys_and_branch_values(P, oracle):
     rng = np.random.default_rng(77)
     keys = set()
