@@ -39,3 +39,10 @@ def accounts_of(case_accounts, codes):
             "storage": {int(k or "0", 16): int(v or "0", 16) for k, v in a["storage"].items()},
         })
     return out
+
+
+def public_kats():
+    """Public Ethereum known answers that are NOT from the reference (tests/golden/public_kats.json says where they
+    come from): a non-zero logs bloom and two address-from-key vectors, which the reference's own goldens lack."""
+    with open(os.path.join(_G, "public_kats.json")) as f:
+        return json.load(f)

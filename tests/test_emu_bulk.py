@@ -20,5 +20,5 @@ def P():
 
 
 from tests.test_gpu_x_bulk import (  # noqa: E402,F401
-    test_logs_blooms_vs_oracle, test_logs_bloom_edge_cases, test_sender_addresses_vs_oracle,
+    test_logs_blooms_vs_oracle, test_logs_bloom_edge_cases, test_sender_addresses_vs_oracle, test_public_known_answers,
     test_transaction_hashes_reference_vectors, test_code_hashes)

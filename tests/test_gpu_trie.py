@@ -108,6 +108,52 @@ def test_index_root_be32_vs_oracle(P, oracle):
         assert P.mpt.index_root_rlp(items) == oracle.index_root_rlp(items)
 
 
+def _rlp_str(b):
+    if len(b) == 1 and b[0] < 0x80:
+        return bytes(b)
+    if len(b) <= 55:
+        return bytes([0x80 + len(b)]) + bytes(b)
+    ll = (len(b).bit_length() + 7) // 8
+    return bytes([0xb7 + ll]) + len(b).to_bytes(ll, "big") + bytes(b)
+
+
+def _rlp_list(items):
+    p = b"".join(items)
+    if len(p) <= 55:
+        return bytes([0xc0 + len(p)]) + p
+    ll = (len(p).bit_length() + 7) // 8
+    return bytes([0xf7 + ll]) + len(p).to_bytes(ll, "big") + p
+
+
+def test_receipt_trie_shaped_items(P, oracle):
+    """receiptTrie, the third caller of calculateMPTRoot (src/blockchain/blockchain.zig:201): items shaped like the
+    reference's Receipt encoding (src/types/receipt.zig:13-35: rlp([succeeded, cumulative_gas_used, bloom[256],
+    logs])), blooms computed by the GPU's logs-bloom kernel, through phant_index_root_rlp against the oracle -- the
+    fixtures' own receiptTrie values need EVM execution and cannot serve as vectors."""
+    rng = np.random.default_rng(77)
+    for n in (1, 3, 127, 128, 129, 300):
+        receipts_logs = []
+        for _ in range(n):
+            logs = [(rng.integers(0, 256, 20, dtype=np.uint8).tobytes(),
+                     [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(int(rng.integers(0, 4)))])
+                    for _ in range(int(rng.integers(0, 4)))]
+            receipts_logs.append(logs)
+        blooms = P.types.receipt.logs_blooms(receipts_logs)
+        assert np.array_equal(blooms, oracle.logs_bloom([[x for a, ts in logs for x in (a, *ts)] for logs in receipts_logs]))
+        items, gas = [], 0
+        for r, logs in enumerate(receipts_logs):
+            gas += int(rng.integers(21000, 500000))
+            enc_logs = _rlp_list([_rlp_list([_rlp_str(a), _rlp_list([_rlp_str(t) for t in ts]),
+                                             _rlp_str(rng.integers(0, 256, int(rng.integers(0, 80)), dtype=np.uint8).tobytes())])
+                                  for a, ts in logs])
+            ok = b"\x01" if rng.random() < 0.9 else b""
+            body = _rlp_list([_rlp_str(ok), _rlp_str(gas.to_bytes((gas.bit_length() + 7) // 8, "big")),
+                              _rlp_str(blooms[r].tobytes()), enc_logs])
+            items.append(body if r % 3 else bytes([2]) + body)   # every third one typed (EIP-2718 prefix)
+        assert all(len(x) > 260 for x in items)
+        assert P.mpt.index_root_rlp(items) == oracle.index_root_rlp(items)
+
+
 def test_fixture_state_roots(P):
     fx = golden.fixtures()
     n = 0

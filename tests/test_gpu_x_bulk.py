@@ -58,6 +58,19 @@ def test_logs_bloom_edge_cases(P, oracle):
     assert not got[0].any() and got[1].any() and not got[2].any()
 
 
+def test_public_known_answers(P):
+    """Non-reference public vectors (tests/golden/public_kats.json): go-ethereum's TestBloomExtensively bloom and the
+    addresses of the private keys 1 and 2 -- the GPU kernels against published answers, no oracle in between."""
+    k = golden.public_kats()
+    b = k["bloom_extensively"]
+    logs = [((b["item_format"] % i).encode(), []) for i in range(b["count"])]   # 100 items of one receipt
+    bloom = P.types.receipt.calculate_logs_bloom(logs)
+    assert P.crypto.hasher.keccak256(bloom).hex() == b["keccak256_of_bloom"]
+    pks = np.frombuffer(b"".join(bytes.fromhex(a["pubkey"]) for a in k["addresses"]), np.uint8).reshape(-1, 64)
+    got = P.signer.addresses_from_pubkeys(pks)
+    assert [g.tobytes().hex() for g in got] == [a["address"] for a in k["addresses"]]
+
+
 def test_sender_addresses_vs_oracle(P, oracle):
     rng = np.random.default_rng(62)
     for n in (1, 2, 255, 256, 257, 5000):

@@ -53,3 +53,17 @@ def test_transaction_and_code_hashes_are_plain_keccak(oracle):
         assert oracle.keccak256(bytes.fromhex(v["msg"])).hex() == v["digest"]
     empty = [v for v in golden.keccak_vectors() if v["source"].startswith("src/blockchain/vm.zig")][0]
     assert oracle.keccak256(b"").hex() == empty["digest"]  # get_code_hash of an account without code (vm.zig:292)
+
+
+def test_public_known_answers_pin_bloom_bits_and_address_slice(oracle):
+    """The reference holds no known answer for a non-zero bloom or an address-from-key, so these two public Ethereum
+    vectors (NOT from /root/reference; provenance in tests/golden/public_kats.json) are what keeps a transposed bit
+    order or a wrong byte slice from hiding behind two restatements by the same hand."""
+    k = golden.public_kats()
+    b = k["bloom_extensively"]
+    items = [(b["item_format"] % i).encode() for i in range(b["count"])]
+    bloom = oracle.logs_bloom([items])[0].tobytes()
+    assert oracle.keccak256(bloom).hex() == b["keccak256_of_bloom"]
+    pks = np.frombuffer(b"".join(bytes.fromhex(a["pubkey"]) for a in k["addresses"]), np.uint8).reshape(-1, 64)
+    got = oracle.sender_addresses(pks)
+    assert [g.tobytes().hex() for g in got] == [a["address"] for a in k["addresses"]]
