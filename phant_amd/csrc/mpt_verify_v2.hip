@@ -461,14 +461,26 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 // have such a node; inactive lanes hash whatever `ptr` points at -- the launcher gives them a readable one).  Three
 // full rate blocks and a last one of 124 message bytes: the padding is two constants, nothing is masked per lane, and
 // nothing beyond the node's last byte is read.  Returns nonzero iff the node is NOT the canonical full branch.
+// LADDER: the wave's issue priority falls as it gets on (3 for the first block .. 0 for the last).  VALU issue on a
+// SIMD is arbitrated by priority, then age -- left alone, the oldest of four co-resident hash waves takes ~60 % of the
+// slots, finishes first, and the youngest ends up running its last permutations alone at single-wave speed (6.9
+// instead of 9.8 G perm/s).  With the ladder a wave that is behind outranks the ones ahead: they advance block by
+// block together and finish together.  Measured on BASELINE config 3 (profiles/r2_a/sweep_ladder.jsonl): the deep
+// tier alone 7 us shorter, a launch 0.2515 -> 0.2449 ms.  (The list kernel keeps one raised priority instead: its few
+// waves are the critical path.)
+template <bool LADDER>
 PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
     sponge_zero(s);
+    if (LADDER) __builtin_amdgcn_s_setprio(3);
     uint32_t bad = absorb_b532_block<0, 34>(s, p);
     keccak_f1600(s);
+    if (LADDER) __builtin_amdgcn_s_setprio(2);
     bad |= absorb_b532_block<1, 34>(s, p + RATE);
     keccak_f1600(s);
+    if (LADDER) __builtin_amdgcn_s_setprio(1);
     bad |= absorb_b532_block<2, 34>(s, p + 2u * RATE);
     keccak_f1600(s);
+    if (LADDER) __builtin_amdgcn_s_setprio(0);
     bad |= absorb_b532_block<3, 31>(s, p + 3u * RATE);
     keccak_f1600(s);
     return bad;
@@ -617,7 +629,7 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
     uint32_t bad;
     const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
     if (cls == LIST_B532) {
-        bad = hash_b532(s, p);
+        bad = hash_b532<false>(s, p);
     } else if (cls == 0u && __ballot(len != len0 || p + RATE > safe_end) == 0ull) {
         hash_short_uniform(s, p, len0);  // one length below the rate for the whole chunk: BASELINE's leaves
         bad = 1u;
@@ -699,7 +711,7 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
         const bool is532 = active && len == BRANCH_LEN;
         if (roomy && __ballot(is532) != 0ull) {
             // the lanes with a 532-byte node (the others run along on a readable address: the blob's first bytes)
-            const uint32_t bad = hash_b532(s, is532 ? ptr : a.v.nodes);
+            const uint32_t bad = hash_b532<true>(s, is532 ? ptr : a.v.nodes);
             if (is532 && bad == 0u) flags |= F_CANON;
         }
         const bool rest = active && !(roomy && is532);

@@ -16,22 +16,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 COMBOS = [
-    # hash kernels: PHANT_HASH_WAVES 5 = <= 96 VGPRs, split absorb; 4 = <= 128 VGPRs, split absorb; 3 = <= 128 VGPRs, whole
-    # rate blocks (the compiler free to prefetch).  PHANT_HASH_LDS_KB caps the deep tier's workgroups per CU (= its waves
-    # per SIMD) by an otherwise unused LDS allocation: 40 -> 4, 52 -> 3, i.e. what is left to the memory-bound kernels beside
-    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "52", "PHANT_DEDUP_BLOCK": "256"}),
-    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "52", "PHANT_DEDUP_BLOCK": "256", "PHANT_LIST_PRIO": "0"}),
-    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "40", "PHANT_DEDUP_BLOCK": "256"}),
-    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "40", "PHANT_DEDUP_BLOCK": "256", "PHANT_LIST_PRIO": "0"}),
-    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "63", "PHANT_DEDUP_BLOCK": "256"}),
-    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "52"}),
-    ("flat", None, {"PHANT_HASH_WAVES": "3", "PHANT_HASH_LDS_KB": "0", "PHANT_DEDUP_BLOCK": "256"}),
-    ("flat", None, {"PHANT_HASH_WAVES": "4", "PHANT_HASH_LDS_KB": "52", "PHANT_DEDUP_BLOCK": "256"}),
-    ("flat", None, {"PHANT_HASH_WAVES": "5", "PHANT_HASH_LDS_KB": "40", "PHANT_DEDUP_BLOCK": "256"}),
-    ("nodedup", None, {"PHANT_HASH_WAVES": "3"}),
-    ("nodedup", None, {"PHANT_HASH_WAVES": "5"}),
+    # PHANT_HASH_LDS_KB caps the deep tier's workgroups per CU (= its waves per SIMD) while the shallow tier runs beside it
+    # (40 -> 4, 52 -> 3, 0 = no cap; default 40); PHANT_VERIFY_SERIAL=1: the tiers one after the other (diagnostics)
+    ("flat", None, {}),
+    ("flat", None, {"PHANT_HASH_LDS_KB": "0"}),
+    ("flat", None, {"PHANT_HASH_LDS_KB": "52"}),
+    ("flat", None, {"PHANT_VERIFY_SERIAL": "1"}),
+    ("flat", 4, {}),
+    ("flat", 6, {}),
+    ("flat", 8, {}),                                     # every level of a depth-8 proof deduplicated: no in-place tier
+    ("nodedup", None, {}),
+    ("fused", None, {}),
 ]
-KNOBS = ("PHANT_HASH_WAVES", "PHANT_HASH_LDS_KB", "PHANT_VERIFY_SERIAL", "PHANT_DEDUP_BLOCK", "PHANT_LIST_PRIO")
+KNOBS = ("PHANT_HASH_LDS_KB", "PHANT_VERIFY_SERIAL")
 
 
 def main():
