@@ -28,7 +28,8 @@
 //        walk_kernel      one lane per proof steps over the run of nodes link_kernel settled and decodes the
 //                         rest (DESIGN.md section 3 order of checks) from an LDS copy -- for BASELINE's proofs
 //                         just the leaf; counts the per-root verdict; the (never seen) proof that cannot be
-//                         settled from the tables is verified from scratch by its lane (verify_one).
+//                         settled from the tables is verified from scratch by its lane (verify_one, a rare branch
+//                         of the same kernel: a kernel of its own cost 5 us per launch for nothing).
 //
 // Soundness: rep[j] = r only if bytes(j) == bytes(r), checked byte for byte (so keccak(j) == digest[r]), and r
 // is only trusted when nstat[r] says r itself was hashed; the group key is only a hint where to look.  A copy
@@ -997,7 +998,10 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                 }
             }
         }
-        if (status == STATUS_NEEDS_SLOW) atomicAdd(&a.hdr[HDR_SLOW], 1u);  // slow_kernel's: verified from scratch
+        if (status == STATUS_NEEDS_SLOW) {
+            atomicAdd(&a.hdr[HDR_SLOW], 1u);
+            status = verify_one(a.v, i, voff, vlen);  // from scratch, by this lane (never on a well-formed witness)
+        }
         a.v.status[i] = (uint8_t)status;
         if (a.v.value_off) a.v.value_off[i] = voff;
         if (a.v.value_len) a.v.value_len[i] = vlen;
@@ -1012,30 +1016,6 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
             const uint32_t r = a.v.root_idx[i];
             if (r < a.v.n_roots) atomicAdd(&a.v.fail_count[r], 1u);
         }
-    }
-}
-
-// ---------------------------------------------------------------- second opinion
-// Proofs the walk marked 0xff ("could not be settled from the tables": a representative that was not hashed itself, a
-// digest nobody computed, proof_first_node going backwards) are verified from scratch by one lane each.  Never seen
-// on a well-formed witness: every workgroup first looks at the walk's count of such proofs and leaves when it is 0.
-// A small grid that strides over the proofs.
-PHANT_DEV void slow_one(const struct Args& a, uint32_t i);
-__global__ void __launch_bounds__(256) slow_kernel(const Args a) {
-    if (a.hdr[HDR_SLOW] == 0u) return;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.v.n; i += gridDim.x * 256u) slow_one(a, i);
-}
-PHANT_DEV void slow_one(const Args& a, uint32_t i) {
-    if (a.v.status[i] != STATUS_NEEDS_SLOW) return;
-    uint64_t voff;
-    uint32_t vlen;
-    const uint32_t st = verify_one(a.v, i, voff, vlen);
-    a.v.status[i] = (uint8_t)st;
-    if (a.v.value_off) a.v.value_off[i] = voff;
-    if (a.v.value_len) a.v.value_len[i] = vlen;
-    if (a.v.fail_count && !(st == PHANT_PROOF_PRESENT || st == PHANT_PROOF_ABSENT)) {
-        const uint32_t r = a.v.root_idx ? a.v.root_idx[i] : 0u;
-        if (r < a.v.n_roots) atomicAdd(&a.v.fail_count[r], 1u);
     }
 }
 
@@ -1332,7 +1312,6 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(walk_kernel, dim3(pg), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(slow_kernel, dim3(pg < 64u ? pg : 64u), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
