@@ -139,18 +139,26 @@ def test_config4_dry_run():
 
 
 def test_config2_dry_run():
-    line = _bench(["--workload", "config2", "--messages", "3000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
+    line = _bench(["--workload", "config2", "--messages", "3000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2", "--inner", "2"])
     _check_contract(line, 2, 1)
     assert line["metric"] == "keccak256_136B_hashes_per_sec" and line["config"]["units_per_gpu_per_step"] == 3000
 
 
 def test_nodeset_and_config5_dry_run():
-    line = _bench(["--workload", "nodeset", "--proofs", "300", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
+    line = _bench(["--workload", "nodeset", "--proofs", "300", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2", "--inner", "1"])
     _check_contract(line, 2, 1)
     line = _bench(["--workload", "config5", "--stream-proofs", "150", "--steps", "5", "--warmup", "1",
                    "--cpu-seconds", "0.2"])
     _check_contract(line, 5, 1)
     assert "pcie" in line
+
+
+def test_mptize_dry_run():
+    line = _bench(["--workload", "mptize", "--keys", "3000", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0.2"])
+    _check_contract(line, 1, 1)
+    assert line["metric"] == "mpt_trie_keys_hashed_per_sec" and line["config"]["units_per_gpu_per_step"] == 3000
+    assert line["cpu_baseline"]["root_matches_gpu"] is True
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 3000 * (32 + 78) + 32
 
 
 def _rank_main(rank, world, port, argv, q):
