@@ -77,7 +77,7 @@ PHANT_DEV void absorb_final_block(Sponge& s, const uint32_t* __restrict__ w, uin
 // 1 x dwordx2 (9 vector-memory instructions instead of 35 dword loads + 34 v_alignbyte).  With one
 // node per lane every load touches 64 different cache lines, so the instruction count is what loads
 // the CU's address/L1 pipeline: 35 loads per block kept it ~65 % busy next to the VALU-bound
-// permutation, 9 do not (DESIGN.md section 9).
+// permutation, 9 do not (DESIGN.md section 7).
 struct __attribute__((packed, aligned(1))) PackedU32x4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) PackedU32x2 { uint32_t x, y; };
 

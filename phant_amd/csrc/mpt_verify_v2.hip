@@ -2,7 +2,7 @@
 //
 // A witness ships every proof as its own node list, so the upper trie levels arrive many times over
 // (BASELINE config 3: 800 k shipped nodes, ~354 k distinct), while the lower levels are all but unique.
-// Keccak-f is integer-VALU-bound on gfx950 (DESIGN.md section 9), comparing two nodes is a memory stream.
+// Keccak-f is integer-VALU-bound on gfx950 (DESIGN.md section 7), comparing two nodes is a memory stream.
 // So the batch is cut at a depth S ("shallow levels", chosen on the host from the batch size):
 //
 //   deep tier (depth >= S): nothing to deduplicate.  hash_deep_kernel hashes these nodes in place -- wave =
@@ -428,7 +428,7 @@ struct LaneNode {
 // One rate block of a 532-byte node into the sponge: K = which block (0..3), NDW = its message dwords (34, or 31 for
 // the last block: 124 message bytes, then the padding -- two constants, nothing masked per lane, nothing read beyond
 // the node's last byte).  Returns nonzero iff the block contradicts the canonical full branch.
-// (Tried and dropped, DESIGN.md section 9: absorbing in two halves behind a compiler fence to stay at <= 96 VGPRs / 5
+// (Tried and dropped, DESIGN.md section 7.5: absorbing in two halves behind a compiler fence to stay at <= 96 VGPRs / 5
 // waves per SIMD -- the second memory round trip per block cost more than the fifth wave gave.)
 template <int K, int NDW>
 PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {

@@ -1,6 +1,6 @@
-"""More proof-verification parity through the C-ABI -- tests written after round 1's GPU budget was spent (green on
-the host emulation of the same kernel sources, tests/test_emu_verify.py, never yet run on hardware).  The file
-name sorts after every module that HAS run on the MI355X, so that `pytest -x` reaches those first."""
+"""More proof-verification parity through the C-ABI (round 1's late additions and round 2's full-size config 4 case;
+all run on the MI355X in round 2, profiles/r2_*/pytest_gpu.log; most bodies also run on the host emulation of the
+kernel sources, tests/test_emu_verify.py)."""
 import numpy as np
 import pytest
 import torch
@@ -29,6 +29,31 @@ def test_synthetic_block_witness_vs_oracle(M, oracle):
     bad = ~np.isin(want[0], (M.PROOF_PRESENT, M.PROOF_ABSENT))
     assert np.array_equal(fc.cpu().numpy(), np.bincount(b.root_idx.cpu().numpy()[bad], minlength=b.n_roots))
     assert int(fc.sum()) == w.n_invalid > 0 and {M.PROOF_PRESENT, M.PROOF_ABSENT, M.PROOF_BAD_HASH} <= set(want[0].tolist())
+
+
+def test_config4_full_size_vs_oracle(M, oracle):
+    """BASELINE config 4 at full size (bench.py's block witness: 80 000 proofs against 2 001 roots, 496 000 nodes): every
+    status, every value range and every per-root failure count are the oracle's (oracle/verify.c over the same arrays,
+    ~1 s of CPU)."""
+    import phant_amd
+    w = phant_amd.witness.block_witness(seed=9)
+    b = w.batch
+    assert b.n == 80_000 and b.n_roots == 2_001
+    fc = torch.full((b.n_roots,), -3, dtype=torch.int32, device=b.nodes.device)
+    vo = torch.empty(b.n, dtype=torch.int64, device=b.nodes.device)
+    vl = torch.empty(b.n, dtype=torch.int32, device=b.nodes.device)
+    st = M.verify_batch_dev(b, fail_count=fc, value_off=vo, value_len=vl)
+    want = oracle.mpt_verify_batch(b.roots.cpu().numpy().reshape(-1), b.root_idx.cpu().numpy().astype(np.uint32),
+                                   b.keys.cpu().numpy().reshape(-1), 32, b.nodes.cpu().numpy(),
+                                   b.node_off.cpu().numpy().astype(np.uint64),
+                                   b.proof_first_node.cpu().numpy().astype(np.uint32))
+    assert np.array_equal(st.cpu().numpy(), want[0])
+    assert np.array_equal(vo.cpu().numpy().view(np.uint64), want[1])
+    assert np.array_equal(vl.cpu().numpy().view(np.uint32), want[2])
+    assert torch.equal(st, w.expected)
+    bad = ~np.isin(want[0], (M.PROOF_PRESENT, M.PROOF_ABSENT))
+    assert np.array_equal(fc.cpu().numpy(), np.bincount(b.root_idx.cpu().numpy()[bad], minlength=b.n_roots))
+    assert int(fc.sum()) == w.n_invalid > 0
 
 
 def test_keys_longer_than_the_lds_staging(M, oracle):

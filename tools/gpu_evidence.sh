@@ -27,6 +27,12 @@ b config4_nodedup --workload config4 --no-cpu-baseline --verify-mode nodedup
 b config2 --workload config2 --cpu-seconds 3
 b nodeset --workload nodeset --no-cpu-baseline
 b config5 --workload config5 --no-cpu-baseline
+b config5_100k --workload config5 --no-cpu-baseline --stream-proofs 100000
+b config3_graph --no-cpu-baseline --no-strong --graph
+b config3_graph_s1 --no-cpu-baseline --no-strong --graph --streams 1
+b mptize --workload mptize --cpu-seconds 8 --steps 10
+timeout 600 python tools/stress_verify.py --seeds 20 --first-seed 3000 2>&1 | tail -1 | tee "$OUT/stress.log"
+timeout 300 python tools/stress_trie.py --seeds 10 2>&1 | tail -1 | tee "$OUT/stress_trie.log"
 prof() {  # tag, env..., (BARGS)
   tag=$1; shift
   ( cd /tmp && rm -rf /tmp/prof_$tag && timeout 300 env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python $R/bench.py --no-cpu-baseline --steps 5 --inner 10 --no-strong $BARGS > "$OUT/prof_$tag.log" 2>&1 )
@@ -38,6 +44,8 @@ BARGS="--streams 1" prof concurrent X=1
 BARGS="--streams 1" prof serial PHANT_VERIFY_SERIAL=1
 BARGS="--streams 4" prof streams4 X=1
 BARGS="--streams 1 --workload config4" prof config4 X=1
+( cd /tmp && rm -rf /tmp/prof_t && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o p -- python $R/bench.py --workload mptize --no-cpu-baseline --steps 10 > "$OUT/prof_mptize.log" 2>&1 )
+f=$(find /tmp/prof_t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && (head -1 "$f"; grep "phant" "$f") > "$OUT/mptize_kernel_stats.csv"
 # ---- PMC passes: counters in their own runs, kernel trace only
 pmc() {  # name, counters, mode
   name=$1; ctr=$2; mode=$3
