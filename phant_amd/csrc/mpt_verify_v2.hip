@@ -254,7 +254,7 @@ constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte pat
 // each, tools/ubench/atomic_rate.hip): ~3 000 of them for BASELINE config 3, spread over the kernel's run.
 constexpr uint32_t DEDUP_BLOCK = 256;
 
-__global__ void __launch_bounds__(DEDUP_BLOCK) dedup_kernel(const Args a) {
+__global__ void __launch_bounds__(DEDUP_BLOCK) __attribute__((amdgpu_num_vgpr(48))) dedup_kernel(const Args a) {
     constexpr uint32_t WAVES = DEDUP_BLOCK / 64u;
     __shared__ uint32_t s_cnt[WAVES][N_LIST];
     __shared__ uint32_t s_base[N_LIST];
@@ -301,20 +301,21 @@ __global__ void __launch_bounds__(DEDUP_BLOCK) dedup_kernel(const Args a) {
     }
 
     uint32_t my_rep = j;
-    // ---- this lane's share of a 532-byte node: bytes [16 lane, 16 lane + 16) for lane < 33; the lanes
-    // above all take the last 16 bytes [516, 532) (redundant cover: no lane is ever masked off, so
-    // every load below is unconditional and the loads of several nodes overlap) ----
-    const uint32_t coff = lane < 33u ? 16u * lane : BRANCH_LEN - 16u;
+    // ---- 532-byte nodes that have a representative.  A half wave covers bytes [0, 512) of one node (16 per lane), so
+    // a trip of DEDUP_UNROLL steps compares 2 * DEDUP_UNROLL nodes with all their loads issued before any is used; a
+    // short last trip repeats its last node (idempotent), so the body has no conditionals.  The last 28 bytes of
+    // every node that got this far are compared below, lane per node (they share their cache lines with bytes just
+    // read).  (A whole wave per node -- 34 useful lanes of 64 -- is twice the trips and the instructions.)  Nodes
+    // WITHOUT a representative are not opened here at all: the hash kernel reads them (once), and checks their form
+    // while it has them in registers. ----
+    const uint32_t coff = 16u * (lane & 31u);
+    const bool upper = lane >= 32u;
     // everything that selects a node below is wave-uniform: say so, or the compiler predicates per lane
     const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32), cb_lo = (uint32_t)cb, cb_hi = (uint32_t)(cb >> 32);
-
-    // ---- 532-byte nodes that have a representative: DEDUP_UNROLL nodes per trip, all their loads issued
-    // before any is used.  A short last trip repeats its last node (idempotent) so that the body has no
-    // conditionals.  Nodes WITHOUT a representative are not opened here at all: the hash kernel reads
-    // them (once), and checks their form while it has them in registers. ----
-    unsigned long long todo = __ballot(valid && len == BRANCH_LEN && cand != j);
+    const bool is532 = valid && len == BRANCH_LEN && cand != j;
+    unsigned long long todo = __ballot(is532);
     while (todo) {
-        uint32_t ii[DEDUP_UNROLL], cj[DEDUP_UNROLL];
+        uint32_t i0[DEDUP_UNROLL], i1[DEDUP_UNROLL];
         uint4 x[DEDUP_UNROLL], y[DEDUP_UNROLL];
         uint32_t i = 0;
 #pragma unroll
@@ -323,12 +324,16 @@ __global__ void __launch_bounds__(DEDUP_BLOCK) dedup_kernel(const Args a) {
                 i = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
             }
-            ii[u] = i;
-            cj[u] = lane_u32(cand, i);
-            const uint8_t* own = a.v.nodes + lane_u64(b_lo, b_hi, i);
-            const uint8_t* oth = a.v.nodes + lane_u64(cb_lo, cb_hi, i);
-            x[u] = load16u(own + coff);
-            y[u] = load16u(oth + coff);
+            i0[u] = i;
+            if (todo) {
+                i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+            }
+            i1[u] = i;
+            const uint64_t own0 = lane_u64(b_lo, b_hi, i0[u]), own1 = lane_u64(b_lo, b_hi, i1[u]);
+            const uint64_t oth0 = lane_u64(cb_lo, cb_hi, i0[u]), oth1 = lane_u64(cb_lo, cb_hi, i1[u]);
+            x[u] = load16u(a.v.nodes + (upper ? own1 : own0) + coff);
+            y[u] = load16u(a.v.nodes + (upper ? oth1 : oth0) + coff);
         }
 #pragma unroll
         for (int u = 0; u < DEDUP_UNROLL; ++u) {
@@ -337,9 +342,18 @@ __global__ void __launch_bounds__(DEDUP_BLOCK) dedup_kernel(const Args a) {
             diff = __builtin_amdgcn_bitop3_b32(x[u].y, y[u].y, diff, 0xBE);
             diff = __builtin_amdgcn_bitop3_b32(x[u].z, y[u].z, diff, 0xBE);
             diff = __builtin_amdgcn_bitop3_b32(x[u].w, y[u].w, diff, 0xBE);
-            const bool same = __ballot(diff != 0) == 0ull;
-            if (same && lane == ii[u]) my_rep = cj[u];
+            const unsigned long long m = __ballot(diff != 0);
+            if ((uint32_t)m == 0u && lane == i0[u]) my_rep = cand;
+            if ((uint32_t)(m >> 32) == 0u && lane == i1[u]) my_rep = cand;
         }
+    }
+    if (is532 && my_rep != j) {  // bytes [504, 532)
+        const uint8_t* const own = a.v.nodes + b + (BRANCH_LEN - 28u);
+        const uint8_t* const oth = a.v.nodes + cb + (BRANCH_LEN - 28u);
+        const uint4 p0 = load16u(own), p1 = load16u(own + 12), q0 = load16u(oth), q1 = load16u(oth + 12);
+        uint32_t diff = (p0.x ^ q0.x) | (p0.y ^ q0.y) | (p0.z ^ q0.z) | (p0.w ^ q0.w);
+        diff |= (p1.x ^ q1.x) | (p1.y ^ q1.y) | (p1.z ^ q1.z) | (p1.w ^ q1.w);
+        if (diff) my_rep = j;
     }
 
     // ---- other multi-block nodes (sparse branches >= 136 bytes): generic compare, one at a time ----

@@ -225,6 +225,34 @@ def test_synthetic_depth8_small_vs_oracle(M, oracle):
     assert int(fails.item()) == w.n_invalid == 75
 
 
+def test_one_byte_off_in_a_duplicate_node(M, oracle):
+    """Copies of an upper-level branch are compared with their group's representative instead of being hashed: one byte
+    changed anywhere in a copy -- first byte, the seams of the compare's lane layout (bytes 15/16, 511/512), the range its
+    tail step covers (504-531), last byte -- must fail exactly that proof, whichever of the copies is the representative."""
+    import phant_amd
+    w = phant_amd.witness.account_witness(2000, depth=8, seed=11, corrupt_frac=0.0)
+    b = w.batch
+    nodes = b.nodes.clone()
+    node_off = b.node_off.cpu().numpy()
+    pfn = b.proof_first_node.cpu().numpy()
+    rng = np.random.default_rng(5)
+    offsets = [0, 3, 15, 16, 255, 256, 503, 504, 511, 512, 515, 516, 519, 520, 527, 528, 531]
+    proofs = rng.choice(b.n, size=len(offsets) * 3, replace=False)
+    for t, p in enumerate(proofs):
+        level = t % 3  # a node of depth 0 / 1 / 2: all shared by many proofs
+        at = int(node_off[pfn[p] + level]) + offsets[t // 3]
+        nodes[at] ^= 0x40
+    from phant_amd.mpt import ProofBatch
+    bad = ProofBatch(roots=b.roots, root_idx=b.root_idx, keys=b.keys, nodes=nodes, node_off=b.node_off,
+                               proof_first_node=b.proof_first_node)
+    st = M.verify_batch_dev(bad).cpu().numpy()
+    want = oracle.mpt_verify_batch(b.roots.cpu().numpy(), None, b.keys.cpu().numpy(), 32, nodes.cpu().numpy(),
+                                   node_off.astype(np.uint64), pfn.astype(np.uint32))
+    assert np.array_equal(st, want[0])
+    failed = np.flatnonzero(~np.isin(st, (M.PROOF_PRESENT, M.PROOF_ABSENT)))
+    assert sorted(failed.tolist()) == sorted(proofs.tolist())
+
+
 @pytest.mark.parametrize("depth", [2, 3, 5, 9])
 def test_synthetic_other_depths(M, oracle, depth):
     import phant_amd
