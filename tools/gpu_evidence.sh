@@ -46,6 +46,7 @@ BARGS="--streams 4" prof streams4 X=1
 BARGS="--streams 1 --workload config4" prof config4 X=1
 ( cd /tmp && rm -rf /tmp/prof_t && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o p -- python $R/bench.py --workload mptize --no-cpu-baseline --steps 10 > "$OUT/prof_mptize.log" 2>&1 )
 f=$(find /tmp/prof_t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && (head -1 "$f"; grep "phant" "$f") > "$OUT/mptize_kernel_stats.csv"
+( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/ubench/hash_stage.hip -o /tmp/hash_stage && timeout 120 /tmp/hash_stage ) > "$OUT/hash_stage_ubench.txt" 2>&1; tail -12 "$OUT/hash_stage_ubench.txt"
 # ---- PMC passes: counters in their own runs, kernel trace only
 pmc() {  # name, counters, mode
   name=$1; ctr=$2; mode=$3
