@@ -80,4 +80,10 @@ hipError_t launch_mpt_verify_nodeset(const VerifyArgs& a, uint32_t total_nodes, 
 hipError_t launch_mpt_verdict(const uint8_t* d_status, const uint32_t* d_root_idx, uint32_t n,
                               uint32_t n_roots, uint32_t* d_fail_count, hipStream_t st);
 
+// radix_sort.hip: the order of n 32-byte digests (ascending; grouped by d_seg_of[i] < n_seg when given) as a permutation in
+// device memory inside `ws` (order_workspace_bytes(n)); *d_flag_out != 0 afterwards: not decided, order it another way
+size_t order_workspace_bytes(uint32_t n);
+hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* ws,
+                                uint32_t** d_order_out, uint32_t** d_flag_out, uint32_t prefix_bits, hipStream_t st);
+
 }  // namespace phant

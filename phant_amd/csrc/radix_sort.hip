@@ -1,0 +1,229 @@
+// radix_sort.hip -- ordering hashed keys on the GPU (internal; used by state_root.hip).
+//
+// The secure tries of src/state (statedb.zig / types.zig:13-20 -> DESIGN.md section 9) are keyed by Keccak outputs, so
+// before a trie can be hashed its leaves have to be put in key order.  Round 1 did that on the host (std::sort with
+// 32-byte memcmp: ~0.2 s per million keys, behind a device-to-host copy of every digest).  Here: a stable LSD radix
+// sort of (64-bit key, 32-bit value) pairs, 8 bits per pass, three kernels per pass --
+//   radix_hist    per-workgroup digit histogram of a tile of 2 048 pairs (LDS atomics) -> hist[digit][workgroup]
+//   radix_scan    exclusive scan of that table in place (one workgroup; the table has 256 x n / 2 048 entries)
+//   radix_scatter every wave ranks its 512 pairs digit by digit in index order (a lane's rank among the lanes of its
+//                 wave with the same digit comes from eight ballots), the workgroup adds the waves' totals to the
+//                 scanned base, pairs go to their final place
+// The key of a leaf is the first 8 bytes of its hashed key, big-endian; leaves of several tries (the storage slots of
+// many accounts) are then regrouped by a second, equally stable sort on the trie index.  Two leaves of one trie whose
+// hashed keys share 64 bits can end up in the wrong order -- order_check_kernel compares every neighbouring pair in full
+// and raises a flag; the caller then orders that batch on the host, as before.  (Finding such keys costs an attacker
+// 2^32 hashes: the fallback has to be correct, not fast.)
+//
+// HBM-bound byte shuffling; nothing here is GEMM-shaped.  Per pass: 12 n bytes read twice, written once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "launch.h"
+
+namespace phant {
+namespace {
+
+constexpr uint32_t SORT_THREADS = 256;
+constexpr uint32_t SORT_ITEMS = 8;                             // rounds of 64 pairs per wave
+constexpr uint32_t SORT_TILE = SORT_THREADS * SORT_ITEMS;      // pairs per workgroup
+constexpr uint32_t SORT_WAVES = SORT_THREADS / 64u;
+
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t shift,
+                                                                  uint32_t* __restrict__ hist, uint32_t n_tiles) {
+    __shared__ uint32_t s_hist[256];
+    s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+    for (uint32_t r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t i = base + r * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_tiles + blockIdx.x] = s_hist[threadIdx.x];
+}
+
+// exclusive scan of `total` counters in place, one workgroup of 1 024 lanes
+__global__ void __launch_bounds__(1024) radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t total) {
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (total + 1023u) / 1024u;
+    const uint32_t lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += hist[i];
+    s_sum[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele, inclusive
+        const uint32_t v = t >= d ? s_sum[t - d] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[t] - sum;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t c = hist[i];
+        hist[i] = run;
+        run += c;
+    }
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                     uint32_t n, uint32_t shift, const uint32_t* __restrict__ hist,
+                                                                     uint32_t n_tiles) {
+    __shared__ uint32_t s_wave[SORT_WAVES][256];  // pairs of each digit seen so far by the wave; then: where its run starts
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t w = 0; w < SORT_WAVES; ++w) s_wave[w][tid] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE + wave * (64u * SORT_ITEMS);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint64_t k[SORT_ITEMS];
+    uint32_t v[SORT_ITEMS], rank[SORT_ITEMS];
+#pragma unroll
+    for (uint32_t r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t i = base + r * 64u + lane;
+        const bool valid = i < n;
+        k[r] = valid ? keys[i] : 0ull;
+        v[r] = valid ? vals[i] : 0u;
+        const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);  // the lanes of this round with my digit
+#pragma unroll
+        for (uint32_t b = 0; b < 8u; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(valid && bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t before = 0u;  // pairs with my digit in the rounds before, read and bumped by the lowest peer
+        const uint32_t leader = valid ? (uint32_t)__builtin_ctzll(peers) : lane;
+        if (valid && leader == lane) {
+            before = s_wave[wave][d];
+            s_wave[wave][d] = before + (uint32_t)__popcll(peers);
+        }
+        before = (uint32_t)__shfl((int)before, (int)leader);
+        rank[r] = before + (uint32_t)__popcll(peers & lt);
+    }
+    __syncthreads();
+    {   // digit tid: the run of this workgroup starts at the scanned base; wave w's part of it behind the waves before
+        uint32_t at = hist[tid * n_tiles + blockIdx.x];
+        for (uint32_t w = 0; w < SORT_WAVES; ++w) {
+            const uint32_t c = s_wave[w][tid];
+            s_wave[w][tid] = at;
+            at += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t i = base + r * 64u + lane;
+        if (i < n) {
+            const uint32_t pos = s_wave[wave][(uint32_t)(k[r] >> shift) & 255u] + rank[r];
+            keys_out[pos] = k[r];
+            vals_out[pos] = v[r];
+        }
+    }
+}
+
+// key = the first 8 bytes of digest i as a big-endian number (numeric order = byte order), value = i
+__global__ void __launch_bounds__(256) digest_prefix_kernel(const uint8_t* __restrict__ digests, uint32_t n, uint64_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(digests + 32ull * i);
+    const uint32_t a = __builtin_bswap32(w[0]), b = __builtin_bswap32(w[1]);
+    keys[i] = ((uint64_t)a << 32) | b;
+    vals[i] = i;
+}
+
+// key = the segment (trie) of the item a pair carries
+__global__ void __launch_bounds__(256) segment_key_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ seg_of, uint32_t n,
+                                                          uint64_t* __restrict__ keys) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) keys[i] = seg_of[vals[i]];
+}
+
+// neighbours in the result: same segment and not strictly ascending as 32-byte strings -> flag
+__global__ void __launch_bounds__(256) order_check_kernel(const uint8_t* __restrict__ digests, const uint32_t* __restrict__ order,
+                                                          const uint32_t* __restrict__ seg_of, uint32_t n, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x + 1u;
+    if (i >= n) return;
+    const uint32_t x = order[i - 1u], y = order[i];
+    if (seg_of) {
+        const uint32_t sx = seg_of[x], sy = seg_of[y];
+        if (sx != sy) {
+            if (sx > sy) *flag = 1u;
+            return;
+        }
+    }
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(digests + 32ull * x);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(digests + 32ull * y);
+    int cmp = 0;
+    for (int wd = 0; wd < 8 && cmp == 0; ++wd) {
+        const uint32_t a = __builtin_bswap32(p[wd]), b = __builtin_bswap32(q[wd]);
+        cmp = a < b ? -1 : a > b ? 1 : 0;
+    }
+    if (cmp >= 0) *flag = 1u;
+}
+
+uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1u) / SORT_TILE; }
+
+// stable sort of the pairs by key bits [lo, hi) (multiples of 8); the result ends up in (keys, vals) -- the pointers are
+// swapped with their alternates after every pass
+hipError_t sort_pairs(uint64_t*& keys, uint32_t*& vals, uint64_t*& keys_alt, uint32_t*& vals_alt, uint32_t n, uint32_t lo, uint32_t hi,
+                      uint32_t* hist, hipStream_t st) {
+    const uint32_t tiles = sort_tiles(n);
+    for (uint32_t shift = lo; shift < hi; shift += 8u) {
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(SORT_THREADS), 0, st, keys, n, shift, hist, tiles);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 256u * tiles);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(SORT_THREADS), 0, st, keys, vals, keys_alt, vals_alt, n, shift, hist, tiles);
+        uint64_t* tk = keys; keys = keys_alt; keys_alt = tk;
+        uint32_t* tv = vals; vals = vals_alt; vals_alt = tv;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t order_workspace_bytes(uint32_t n) {
+    const size_t r = 256;
+    auto rnd = [&](size_t b) { return (b + r - 1) / r * r; };
+    return 2 * rnd((size_t)n * 8) + 2 * rnd((size_t)n * 4) + rnd((size_t)256 * sort_tiles(n) * 4) + rnd(4) + 6 * r;
+}
+
+// order[0..n): the items (digests d_digests[i], 32 bytes each) in ascending order of (seg_of[i], digest i); seg_of may be
+// null (one segment).  *d_flag (device, zeroed here) becomes nonzero if the result is NOT in that order (64-bit prefix
+// ties, duplicate keys): the caller must then order the batch another way.  prefix_bits < 64 (tests): sort on fewer bits.
+hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* ws,
+                                uint32_t** d_order_out, uint32_t** d_flag_out, uint32_t prefix_bits, hipStream_t st) {
+    auto rnd = [](size_t b) { return (b + 255) / 256 * 256; };
+    uint64_t* keys = reinterpret_cast<uint64_t*>(ws);
+    uint64_t* keys_alt = reinterpret_cast<uint64_t*>(ws + rnd((size_t)n * 8));
+    uint8_t* p = ws + 2 * rnd((size_t)n * 8);
+    uint32_t* vals = reinterpret_cast<uint32_t*>(p);
+    uint32_t* vals_alt = reinterpret_cast<uint32_t*>(p + rnd((size_t)n * 4));
+    p += 2 * rnd((size_t)n * 4);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(p);
+    p += rnd((size_t)256 * sort_tiles(n) * 4);
+    uint32_t* flag = reinterpret_cast<uint32_t*>(p);
+    hipError_t e = hipMemsetAsync(flag, 0, 4, st);
+    if (e != hipSuccess) return e;
+    *d_flag_out = flag;
+    if (n == 0) {
+        *d_order_out = vals;
+        return hipSuccess;
+    }
+    const uint32_t g = (n + 255u) / 256u;
+    hipLaunchKernelGGL(digest_prefix_kernel, dim3(g), dim3(256), 0, st, d_digests, n, keys, vals);
+    const uint32_t bits = prefix_bits >= 64u ? 64u : (prefix_bits + 7u) / 8u * 8u;
+    if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 64u - bits, 64u, hist, st)) != hipSuccess) return e;
+    if (d_seg_of && n_seg > 1u) {
+        uint32_t seg_bits = 8;
+        while (seg_bits < 32u && ((uint64_t)1 << seg_bits) < n_seg) seg_bits += 8;
+        hipLaunchKernelGGL(segment_key_kernel, dim3(g), dim3(256), 0, st, vals, d_seg_of, n, keys);
+        if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 0u, seg_bits, hist, st)) != hipSuccess) return e;
+    }
+    if (n > 1u) hipLaunchKernelGGL(order_check_kernel, dim3((n - 1u + 255u) / 256u), dim3(256), 0, st, d_digests, vals, d_seg_of, n, flag);
+    *d_order_out = vals;
+    return hipGetLastError();
+}
+
+}  // namespace phant

@@ -7,9 +7,11 @@
 // keccak256(be32(slot)), value rlp(minimal-BE(value)); zero-valued slots do not
 // exist (src/state/statedb.zig:112-119).  All Keccak work (addresses, slots,
 // code, every trie node) runs on the GPU; one forest pass hashes every
-// account's storage trie at once, a second pass the account trie.  The host
-// only orders keys and packs the <= 110-byte account records.
+// account's storage trie at once, a second pass the account trie.  The hashed
+// keys are put in order on the GPU as well (radix_sort.hip); the host packs
+// the <= 110-byte account records.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -42,6 +44,48 @@ int32_t hash_fixed(Workspaces& ws, hipStream_t st, const uint8_t* host, uint32_t
     SR_TRY(launch_keccak256_fixed(d_in, rec_len, rec_len, n, d_out, st));
     SR_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));
     SR_TRY(hipStreamSynchronize(st));
+    return PHANT_OK;
+}
+
+// keccak256 of n fixed-size records and the order of the digests, both on the GPU: order[k] = the record whose digest is
+// the k-th smallest -- within its segment, segments ascending, when seg_of (host, n entries < n_seg, or null) is given.
+// Digests and order come back to the host.  If the device sort reports that its 64-bit keys did not decide the order
+// (radix_sort.hip), the batch is ordered here instead.
+int32_t hash_fixed_ordered(Workspaces& ws, hipStream_t st, const uint8_t* host, uint32_t rec_len, uint32_t n,
+                           const uint32_t* seg_of, uint32_t n_seg, std::vector<uint8_t>& digests,
+                           std::vector<uint32_t>& order, std::string& err) {
+    digests.resize((size_t)n * 32);
+    order.resize(n);
+    if (!n) return PHANT_OK;
+    uint32_t prefix_bits = 64;  // tests shrink it to reach the host fallback
+    if (const char* t = std::getenv("PHANT_SORT_PREFIX_BITS")) prefix_bits = (uint32_t)std::strtoul(t, nullptr, 10);
+    SR_TRY(ws.io.reset(DevArena::round((size_t)n * rec_len + 16) + DevArena::round((size_t)n * 32) +
+                       DevArena::round((size_t)n * 4) + DevArena::round(order_workspace_bytes(n)) + 1024));
+    uint8_t* d_in = ws.io.take<uint8_t>((size_t)n * rec_len + 16);
+    uint8_t* d_out = ws.io.take<uint8_t>((size_t)n * 32);
+    uint32_t* d_seg = seg_of ? ws.io.take<uint32_t>(n) : nullptr;
+    uint8_t* d_sort = ws.io.take<uint8_t>(order_workspace_bytes(n));
+    SR_TRY(hipMemcpyAsync(d_in, host, (size_t)n * rec_len, hipMemcpyHostToDevice, st));
+    if (seg_of) SR_TRY(hipMemcpyAsync(d_seg, seg_of, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    SR_TRY(launch_keccak256_fixed(d_in, rec_len, rec_len, n, d_out, st));
+    uint32_t *d_order = nullptr, *d_flag = nullptr;
+    SR_TRY(launch_order_digests(d_out, d_seg, n, n_seg, d_sort, &d_order, &d_flag, prefix_bits, st));
+    uint32_t flag = 0;
+    SR_TRY(hipMemcpyAsync(digests.data(), d_out, digests.size(), hipMemcpyDeviceToHost, st));
+    SR_TRY(hipMemcpyAsync(order.data(), d_order, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    SR_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+    SR_TRY(hipStreamSynchronize(st));
+    if (flag) {
+        if (std::getenv("PHANT_SORT_NO_FALLBACK")) {  // tests: prove which path ordered the batch
+            err = "device sort undecided (64-bit key prefixes tie or keys repeat)";
+            return PHANT_E_UNSUPPORTED;
+        }
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            if (seg_of && seg_of[x] != seg_of[y]) return seg_of[x] < seg_of[y];
+            return std::memcmp(&digests[(size_t)x * 32], &digests[(size_t)y * 32], 32) < 0;
+        });
+    }
     return PHANT_OK;
 }
 
@@ -127,14 +171,12 @@ int32_t state_leaves_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, 
     const uint32_t m = (uint32_t)live.size();
     std::vector<uint8_t> live_keys((size_t)m * 32), hk;
     for (uint32_t j = 0; j < m; ++j) std::memcpy(&live_keys[(size_t)j * 32], slot_keys + 32ull * live[j], 32);
-    int32_t rc = hash_fixed(ws, st, live_keys.data(), 32, m, hk, err);
-    if (rc) return rc;
-    std::vector<uint32_t> perm(m);
-    std::iota(perm.begin(), perm.end(), 0u);
+    std::vector<uint32_t> seg_of(m), perm;
     for (uint32_t a = 0; a < n; ++a)
-        std::sort(perm.begin() + acc_first[a], perm.begin() + acc_first[a + 1], [&](uint32_t x, uint32_t y) {
-            return std::memcmp(&hk[(size_t)x * 32], &hk[(size_t)y * 32], 32) < 0;
-        });
+        for (uint32_t j = acc_first[a]; j < acc_first[a + 1]; ++j) seg_of[j] = a;
+    // hashed slot keys, ordered per account (the live slots are grouped by account already: a stable regrouping)
+    int32_t rc = hash_fixed_ordered(ws, st, live_keys.data(), 32, m, seg_of.data(), n, hk, perm, err);
+    if (rc) return rc;
     std::vector<uint8_t> skeys((size_t)m * 32), svals;
     std::vector<uint32_t> skoff(m + 1, 0);
     std::vector<uint64_t> svoff(m + 1, 0);
@@ -155,15 +197,11 @@ int32_t state_leaves_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, 
 
     // ---- accounts ----
     std::vector<uint8_t> ha, hc;
-    rc = hash_fixed(ws, st, addrs, 20, n, ha, err);
+    std::vector<uint32_t> ord;
+    rc = hash_fixed_ordered(ws, st, addrs, 20, n, nullptr, 1, ha, ord, err);
     if (rc) return rc;
     rc = hash_var(ws, st, code, code_off, n, hc, err);
     if (rc) return rc;
-    std::vector<uint32_t> ord(n);
-    std::iota(ord.begin(), ord.end(), 0u);
-    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
-        return std::memcmp(&ha[(size_t)x * 32], &ha[(size_t)y * 32], 32) < 0;
-    });
     std::vector<uint8_t> payload;
     akeys.resize((size_t)n * 32);
     avals.reserve((size_t)n * 112);

@@ -182,6 +182,39 @@ def test_state_root_random_vs_oracle(P, oracle):
     assert P.state.state_root([]) == P.mpt.empty_mpt_root
 
 
+def _random_accounts(rng, n, max_slots):
+    acc = []
+    for i in range(n):
+        st = {}
+        for _ in range(int(rng.integers(0, max_slots + 1))):
+            st[int(rng.integers(0, 2 ** 62))] = int(rng.integers(0, 4) > 0) * int(rng.integers(1, 2 ** 62))
+        acc.append(dict(addr=rng.integers(0, 256, 20, dtype=np.uint8).tobytes(), nonce=int(rng.integers(0, 1000)),
+                        balance=int(rng.integers(0, 2 ** 62)), code=b"", storage=st))
+    return acc
+
+
+def test_state_root_orders_its_leaves_on_the_gpu(P, oracle, monkeypatch):
+    """phant_state_root sorts hashed addresses and hashed slot keys on the device (radix_sort.hip: 64-bit prefixes, then a
+    regrouping by account): accounts with many slots (several sort tiles, every digit pass populated) and many accounts,
+    against the oracle; and the same state with the device sort reduced to 8 / 16 key bits, where nearly every neighbour
+    ties, the order check raises its flag and the host orders the batch (the path a 64-bit prefix collision takes)."""
+    rng = np.random.default_rng(77)
+    acc = _random_accounts(rng, 40, 700) + _random_accounts(rng, 2500, 3)
+    want = oracle.state_root(acc)
+    monkeypatch.setenv("PHANT_SORT_NO_FALLBACK", "1")   # (test knob: fail instead of ordering on the host)
+    assert P.state.state_root(acc) == want              # ... so this order is the device's
+    monkeypatch.setenv("PHANT_SORT_PREFIX_BITS", "8")
+    with pytest.raises(Exception):
+        P.state.state_root(acc)
+    monkeypatch.delenv("PHANT_SORT_NO_FALLBACK")
+    for bits in ("8", "16"):
+        monkeypatch.setenv("PHANT_SORT_PREFIX_BITS", bits)
+        assert P.state.state_root(acc) == want
+    monkeypatch.delenv("PHANT_SORT_PREFIX_BITS")
+    one = _random_accounts(rng, 1, 5000)   # one account, one big storage trie
+    assert P.state.state_root(one) == oracle.state_root(one)
+
+
 def test_sharded_mptize_matches_the_single_gpu_root(oracle):
     """phant_mpt_root_nodes (forest pass with root-node RLP out) + strip + top-nibble exchange, world sizes
     1..8 played back in one process on one GPU, against mptize on the GPU and on the oracle."""
