@@ -96,8 +96,6 @@ def parse():
                     help="config3: independent batches in flight, each on its own ctx + HIP stream (a validator "
                          "verifying consecutive witnesses); 1 = strictly one launch sequence after the other")
     ap.add_argument("--messages", type=int, default=1 << 20, help="config2: 136-byte messages per GPU")
-    ap.add_argument("--graph", action="store_true",
-                    help="config3 / config4: replay each slot's kernel sequence as one hipGraph launch (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -247,10 +245,10 @@ def cpu_baseline_mptize(keys_t, vals_t, n, root_t, target_seconds):
     return out
 
 
-def mk_ctx(args, local_rank, graph=False, use_torch_stream=True):
+def mk_ctx(args, local_rank, use_torch_stream=True):
     import phant_amd
     return phant_amd.Context(local_rank, use_torch_stream=use_torch_stream, verify_fused=(args.verify_mode == "fused"),
-                             verify_nodedup=(args.verify_mode == "nodedup"), verify_graph=graph,
+                             verify_nodedup=(args.verify_mode == "nodedup"),
                              dedup_levels=(args.dedup_levels if args.verify_mode == "flat" else None))
 
 
@@ -268,18 +266,15 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     n_units = w0.batch.n
     for w in wits:
         assert w.batch.n == n_units and w.batch.n_roots == w0.batch.n_roots
-    # --graph (A/B, off by default): every slot's kernel sequence is replayed as one hipGraph launch
-    # (PHANT_CTX_VERIFY_GRAPH); the legacy default stream cannot be captured, so then slot 0 gets a stream and a ctx
-    # of its own as well (`ctx`, on torch's stream, built the witnesses and does the kernel timing below)
     slots = []
     torch.cuda.synchronize()
     for k in range(S):
-        if k == 0 and not args.graph:
+        if k == 0:
             st_, c_ = torch.cuda.current_stream(dev), ctx
         else:
             st_ = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st_):
-                c_ = mk_ctx(args, local_rank, graph=args.graph)
+                c_ = mk_ctx(args, local_rank)
         slots.append((st_, c_, torch.empty(n_units, dtype=torch.uint8, device=dev),
                       torch.zeros(w0.batch.n_roots, dtype=torch.int32, device=dev), wits[k]))
     turn = {"k": 0}
@@ -354,8 +349,7 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     out = {"wits": wits, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
            "value": n_units * world * passes / elapsed,
            "single": {"value": n_units * world * passes / e1, "ms_per_step": e1 / passes * 1e3},
-           "k_avg_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed,
-           "graph": [c_.graph_stats() for _, c_, _, _, _ in slots] if args.graph else False}
+           "k_avg_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed}
     for k, (st_, c_, _, _, _) in enumerate(slots):
         if c_ is not ctx:
             c_.close()
@@ -393,7 +387,6 @@ def main():
     strong = None
     S = 1
     inner = 1
-    graph_stats = False
     if proofs_like:
         S = max(1, min(args.streams, 8))
         inner = max(1, args.inner)
@@ -411,7 +404,6 @@ def main():
         w = r["wits"][0]
         b = w.batch
         n_units, elapsed, value, single, k_avg_ms = r["n_units"], r["elapsed"], r["value"], r["single"], r["k_avg_ms"]
-        graph_stats = r["graph"]
         alg_bytes = b.algorithmic_bytes()
         ms_per_step = r["ms_per_pass"]
         if args.workload == "config3":
@@ -627,8 +619,7 @@ def main():
                    "verify_mode": args.verify_mode if proofs_like else None,
                    "dedup_levels": (args.dedup_levels if proofs_like else None),
                    "streams": (S if proofs_like else 1), "passes_per_timed_step": inner,
-                   "timed_region_ms": ms_per_step * args.steps * inner,
-                   "graph": graph_stats},
+                   "timed_region_ms": ms_per_step * args.steps * inner},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "throughput_GBps": value / world * alg_bytes / n_units / 1e9,  # algorithmic bytes x the measured

@@ -82,12 +82,6 @@ typedef struct phant_ctx phant_ctx;
                                      two-tier pipeline (A/B and debugging) */
 #define PHANT_CTX_VERIFY_NODEDUP 4u /* flags: two-tier pipeline, but hash every shipped node even when the
                                        batch carries byte-identical copies (A/B; = PHANT_CTX_DEDUP_LEVELS(0)) */
-#define PHANT_CTX_VERIFY_GRAPH 32u /* flags: device-form verify calls replay their kernel sequence as ONE
-                                    * hipGraph launch while the arguments (buffers, sizes) stay the same as
-                                    * in the previous call; captured again when they change.  On a real
-                                    * stream only (the legacy default stream cannot be captured): otherwise,
-                                    * or if capturing fails, calls launch directly as without the flag.
-                                    * Env PHANT_VERIFY_GRAPH=0/1 overrides. */
 /* flags: how many trie levels, counted from the root, the verify pipeline deduplicates across the proofs of a
  * batch (byte-compares copies instead of hashing them); deeper nodes are hashed in place.  Default (field 0):
  * chosen from the batch size -- levels with fewer groups than proofs.  Correctness does not depend on it. */
@@ -265,7 +259,7 @@ PHANT_API int32_t phant_wait(phant_ctx *ctx, uint32_t slot);
  * collective -- proof i is verified on device phant_comm_owner(key_i) = (key_i[0] >> 4) mod N (trie keys are Keccak
  * outputs: uniform) -- and the only exchange is ONE all-reduce (sum) of the n_roots x u32 failure counts over xGMI.
  * devices = NULL: devices 0 .. n_devices - 1; n_devices = 0: all visible devices.  flags: PHANT_CTX_* of the
- * per-device ctxs (the stream and graph flags are ignored).  Externally synchronised like a ctx. */
+ * per-device ctxs (the stream flag is ignored).  Externally synchronised like a ctx. */
 typedef struct phant_comm phant_comm;
 PHANT_API int32_t phant_comm_create(const int32_t *devices, uint32_t n_devices, uint32_t flags, phant_comm **out);
 PHANT_API void phant_comm_destroy(phant_comm *comm);
@@ -430,8 +424,6 @@ PHANT_API int32_t phant_verify_stats(phant_ctx *ctx, uint32_t hashed[8]);
  * of full-branch paths ending in a leaf); synchronises the ctx stream.  Diagnostics, not part of a result. */
 PHANT_API int32_t phant_verify_path_stats(phant_ctx *ctx, uint32_t out[2]);
 PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
-/* out[0] = graphs captured, out[1] = graph launches served so far on this ctx (PHANT_CTX_VERIFY_GRAPH) */
-PHANT_API int32_t phant_graph_stats(phant_ctx *ctx, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

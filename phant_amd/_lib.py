@@ -81,7 +81,6 @@ SYMBOLS = {
     "phant_state_trie_leaves": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),
     "phant_timing": (_i32, [_vp, _i32]),
     "phant_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
-    "phant_graph_stats": (_i32, [_vp, _vp]),
     "phant_verify_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 8)]),
     "phant_verify_path_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 2)]),
     "phant_mpt_root_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _u32, _vp]),

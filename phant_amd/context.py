@@ -17,7 +17,7 @@ class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
     def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
-                 verify_nodedup: bool = False, verify_graph: bool = False, dedup_levels: int | None = None):
+                 verify_nodedup: bool = False, dedup_levels: int | None = None):
         """verify_fused / verify_nodedup: the A/B forms of the verify pipeline (one lane per proof; every shipped
         node hashed).  dedup_levels: how many trie levels from the root the two-tier pipeline deduplicates
         (None = chosen from the batch size; PHANT_CTX_DEDUP_LEVELS)."""
@@ -35,8 +35,6 @@ class Context:
             flags |= 2  # PHANT_CTX_VERIFY_FUSED
         if verify_nodedup:
             flags |= 4  # PHANT_CTX_VERIFY_NODEDUP
-        if verify_graph:
-            flags |= 32  # PHANT_CTX_VERIFY_GRAPH
         if dedup_levels is not None:
             flags |= ((int(dedup_levels) + 1) << 8) & 0x1F00  # PHANT_CTX_DEDUP_LEVELS(n)
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
@@ -73,12 +71,6 @@ class Context:
         """(proofs verified from scratch by their walk lane, nodes decoded by walks that decoded more than one)."""
         out = (C.c_uint32 * 2)()
         self.check(self._lib.phant_verify_path_stats(self._h, C.byref(out)))
-        return int(out[0]), int(out[1])
-
-    def graph_stats(self) -> tuple[int, int]:
-        """(graphs captured, graph launches served) under verify_graph."""
-        out = (C.c_uint64 * 2)()
-        self.check(self._lib.phant_graph_stats(self._h, C.byref(out)))
         return int(out[0]), int(out[1])
 
     def close(self):

@@ -42,13 +42,6 @@ struct phant_ctx {
         phant::DevArena io, dv;
         bool busy = false;
     } slots[PHANT_MAX_SLOTS];
-    // PHANT_CTX_VERIFY_GRAPH: the kernel sequence of the last device-form verify call, captured once and
-    // replayed as ONE graph launch while the call's arguments stay the same (same buffers, same sizes)
-    bool use_graph = false;
-    hipGraphExec_t graph_exec = nullptr;
-    phant::VerifyArgs graph_key{};
-    uint8_t* graph_ws = nullptr;
-    unsigned long long graph_replays = 0, graph_captures = 0;
     // stream-side timing of the last device-form call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -167,8 +160,6 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         c->tune.hash_lds = (uint32_t)(kb < 0 ? 0 : kb > 63 ? 63 : kb) * 1024u;  // (< 64 KiB needs no opt-in)
     }
     if (const char* t = std::getenv("PHANT_VERIFY_SERIAL")) c->tune.serial = t[0] == '1';
-    c->use_graph = opts && (opts->flags & PHANT_CTX_VERIFY_GRAPH);
-    if (const char* g = std::getenv("PHANT_VERIFY_GRAPH")) c->use_graph = g[0] == '1';
     DeviceGuard g(dev);
     if (!own) {
         c->stream = (hipStream_t)stream;  // nullptr = the default stream
@@ -191,7 +182,6 @@ void phant_ctx_destroy(phant_ctx* c) {
     if (!c) return;
     DeviceGuard g(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     c->ws.release();
     c->dv.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -439,50 +429,6 @@ static int32_t ensure_side(phant_ctx* c) {
 
 // Runs the verify pipeline on device-resident arguments (shared by all forms) on stream `st` with the
 // workspace arena `dv`; `side` = helper stream of the two-tier pipeline or nullptr (then its tiers run one after the other).
-static bool same_args(const phant::VerifyArgs& x, const phant::VerifyArgs& y) {
-    return x.roots == y.roots && x.n_roots == y.n_roots && x.root_idx == y.root_idx && x.keys == y.keys &&
-           x.key_len == y.key_len && x.nodes == y.nodes && x.nodes_len == y.nodes_len && x.node_off == y.node_off &&
-           x.proof_first_node == y.proof_first_node && x.n == y.n && x.status == y.status &&
-           x.value_off == y.value_off && x.value_len == y.value_len && x.fail_count == y.fail_count &&
-           x.total_nodes == y.total_nodes;
-}
-
-// The pipeline as one graph launch (PHANT_CTX_VERIFY_GRAPH; a real stream -- the legacy default stream cannot be
-// captured; the helper stream's fork / join are captured with it).  Capture happens when the arguments differ from the cached
-// ones: the kernels' arguments (pointers, sizes) and the launcher's tuning knobs are frozen into the graph, the
-// DATA behind the pointers is read afresh at every replay.  Returns 1 when the call was served, 0 when the caller
-// should launch directly (and graphs are switched off for this ctx if capturing failed), < 0 on a device error.
-static int32_t verify_graph_launch(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes, uint8_t* ws,
-                                   hipStream_t st, const phant::FlatSide* side) {
-    if (!c->graph_exec || !same_args(a, c->graph_key) || ws != c->graph_ws) {
-        if (c->graph_exec) {
-            (void)hipGraphExecDestroy(c->graph_exec);
-            c->graph_exec = nullptr;
-        }
-        hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-            c->use_graph = false;
-            return 0;
-        }
-        const hipError_t le = phant::launch_mpt_verify(a, total_nodes, ws, c->dedup_levels, st, side, c->tune);
-        const hipError_t ee = hipStreamEndCapture(st, &g);
-        if (le != hipSuccess || ee != hipSuccess || !g || hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
-            if (g) (void)hipGraphDestroy(g);
-            c->graph_exec = nullptr;
-            c->use_graph = false;
-            (void)hipGetLastError();
-            return 0;
-        }
-        (void)hipGraphDestroy(g);
-        c->graph_key = a;
-        c->graph_ws = ws;
-        ++c->graph_captures;
-    }
-    HIP_TRY(c, hipGraphLaunch(c->graph_exec, st));
-    ++c->graph_replays;
-    return 1;
-}
-
 static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, uint32_t total_nodes, hipStream_t st,
                                   phant::DevArena& dv, const phant::FlatSide* side, bool timed) {
     phant::VerifyArgs a = a_in;
@@ -501,14 +447,6 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
         HIP_TRY(c, hipStreamSynchronize(st));
         hipError_t e = dv.reset(need);
         if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(verify workspace)", e);
-    }
-    // (only the ctx's own device-form path -- `timed` -- replays a graph: the streaming slots stage into buffers
-    // of their own and would re-capture per witness)
-    if (timed && c->use_graph && st != nullptr && &dv == &c->dv && a.n != 0) {
-        TimedRegion t(c);
-        const int32_t served = verify_graph_launch(c, a, total_nodes, dv.base, st, side);
-        if (served < 0) return served;
-        if (served == 1) return PHANT_OK;
     }
     if (timed) {
         TimedRegion t(c);
@@ -1135,13 +1073,6 @@ int32_t phant_state_trie_leaves(phant_ctx* c, const uint8_t* addrs, const uint64
         std::memcpy(vals, v.data(), v.size());
     }
     std::memcpy(val_off, vo.data(), vo.size() * 8);
-    return PHANT_OK;
-}
-
-int32_t phant_graph_stats(phant_ctx* c, uint64_t out[2]) {
-    if (!c || !out) return PHANT_E_INVALID_ARG;
-    out[0] = c->graph_captures;
-    out[1] = c->graph_replays;
     return PHANT_OK;
 }
 

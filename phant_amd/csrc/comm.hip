@@ -197,7 +197,7 @@ int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t f
         o.struct_size = sizeof(o);
         o.device = d;
         o.stream = nullptr;
-        o.flags = PHANT_CTX_OWN_STREAM | (flags & ~(uint32_t)PHANT_CTX_VERIFY_GRAPH);
+        o.flags = PHANT_CTX_OWN_STREAM | flags;
         phant_ctx* x = nullptr;
         const int32_t rc = phant_ctx_create(&o, &x);
         if (rc != PHANT_OK) {

@@ -92,7 +92,7 @@ class Opts(C.Structure):
     _fields_ = [("struct_size", _u32), ("device", _i32), ("stream", _vp), ("flags", _u32)]
 
 
-FUSED, NODEDUP, GRAPH = 2, 4, 32
+FUSED, NODEDUP = 2, 4
 
 
 def LEVELS(n):  # PHANT_CTX_DEDUP_LEVELS(n): the two-tier pipeline with the first n trie levels deduplicated
@@ -101,9 +101,7 @@ def LEVELS(n):  # PHANT_CTX_DEDUP_LEVELS(n): the two-tier pipeline with the firs
 
 # "flat" = the two-tier pipeline with its tier split chosen from the batch size; levelsN force the split (1: only the
 # root nodes are deduplicated, 16: every level, nothing left for the in-place tier)
-MODES = {"flat": 0, "nodedup": NODEDUP, "fused": FUSED, "levels1": LEVELS(1), "levels3": LEVELS(3), "levels16": LEVELS(16),
-         "levels3+graph": GRAPH | LEVELS(3) | 1,
-         "flat+graph": GRAPH | 1, "nodedup+graph": GRAPH | NODEDUP | 1}  # (graphs need a real stream: | 1 = own stream)
+MODES = {"flat": 0, "nodedup": NODEDUP, "fused": FUSED, "levels1": LEVELS(1), "levels3": LEVELS(3), "levels16": LEVELS(16)}
 
 
 def _p(a):

@@ -1,6 +1,6 @@
 // leak_check.cpp -- emulated library only (device pointers are host pointers there): create / use / destroy every
 // kind of ctx state the C-ABI owns -- arenas, the verify workspace, the helper stream and events of the two-tier verify
-// pipeline, a captured graph, streaming slots, parsed and index-form witnesses -- in a stand-alone
+// pipeline, streaming slots, parsed and index-form witnesses -- in a stand-alone
 // executable, so that LeakSanitizer (which cannot run inside the Python process of the other emulated tests)
 // reports anything phant_ctx_destroy / phant_witness_free forgets.
 #include <cstdio>
@@ -27,7 +27,7 @@ int main() {
     constexpr uint64_t LEAF_LEN = 13;
     const uint64_t node_off[2] = {0, LEAF_LEN};
     const uint32_t pfn[2] = {0, 1};
-    for (uint32_t flags : {0u, 2u, 4u, PHANT_CTX_DEDUP_LEVELS(1), PHANT_CTX_DEDUP_LEVELS(16), 32u | 1u, 32u | PHANT_CTX_DEDUP_LEVELS(3) | 1u, 1u}) {
+    for (uint32_t flags : {0u, 2u, 4u, PHANT_CTX_DEDUP_LEVELS(1), PHANT_CTX_DEDUP_LEVELS(16), PHANT_CTX_DEDUP_LEVELS(3) | 1u, 1u}) {
         phant_ctx* ctx = nullptr;
         phant_opts opts;
         std::memset(&opts, 0, sizeof opts);

@@ -32,12 +32,9 @@ def _no_cuda():
     saved = (torch.device, torch.cuda.set_device, torch.cuda.current_stream, torch.cuda.Stream, torch.cuda.stream,
              phant_amd.Context)
 
-    def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, verify_graph=False,
-                dedup_levels=None):
+    def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, dedup_levels=None):
         mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else
                 "levels%d" % dedup_levels if dedup_levels is not None else "flat")
-        if verify_graph and mode != "fused":
-            mode += "+graph"
         return emu.mirror_context(emu.mirror_lib(), mode)
 
     class _Device:  # torch.device("cuda", i) -> the CPU; isinstance checks inside torch still see a real device
@@ -110,17 +107,6 @@ def test_config3_forced_tier_split_dry_run():
                    "--dedup-levels", "3", "--no-strong"])
     _check_contract(line, 1, 0)
     assert line["config"]["dedup_levels"] == 3 and "strong" not in line
-
-
-def test_config3_graph_replay_dry_run():
-    line = _bench(["--proofs", "300", "--steps", "4", "--warmup", "2", "--streams", "2", "--graph", "--cpu-seconds", "0.2",
-                   "--inner", "1", "--no-strong"])
-    _check_contract(line, 4, 2)
-    # per slot: one capture for its own witness, then replays only (priming + warm-up + timed); the single-stream leg
-    # alternates between the two witnesses on slot 0, which captures again at every change of arguments
-    g = line["config"]["graph"]
-    assert len(g) == 2 and g[1] == [1, 1 + 1 + 2] and g[0][0] == 1 + 3 and g[0][1] == 1 + 1 + 2 + 4
-    assert line["single_stream"]["value"] > 0
 
 
 def test_config3_fewer_steps_than_slots():

@@ -52,7 +52,7 @@ def test_emulated_kernels_under_asan_and_ubsan():
 
 def test_ctx_and_witness_lifecycles_do_not_leak(tmp_path):
     """tests/native/leak_check.cpp against the sanitized emulated library, LeakSanitizer on: every kind of state a
-    ctx or a witness owns (arenas, helper streams and events, a captured graph, streaming slots, both witness forms)
+    ctx or a witness owns (arenas, helper streams and events, streaming slots, both witness forms)
     is created, used and destroyed, for every mode flag."""
     import shutil
     if not shutil.which("g++"):

@@ -33,17 +33,9 @@ from tests.test_gpu_verify import (  # noqa: E402,F401
     test_non_monotone_proof_first_node_matches_oracle, test_synthetic_depth8_small_vs_oracle,
     test_synthetic_other_depths, test_block_witness_accounts_and_storage)
 from tests.test_gpu_x_verify_more import (  # noqa: E402,F401
-    test_keys_longer_than_the_lds_staging, test_synthetic_block_witness_vs_oracle,
-    test_graph_replay_reads_fresh_data_and_recaptures_on_new_arguments)
+    test_keys_longer_than_the_lds_staging, test_synthetic_block_witness_vs_oracle)
 
 
-@pytest.fixture(scope="module", params=["flat", "nodedup", "levels3"])
-def MG(request):
-    import phant_amd
-    from tests.test_gpu_verify import _Mode
-    ctx = emu.mirror_context(emu.mirror_lib(), request.param + "+graph")
-    yield _Mode(phant_amd.mpt, ctx, request.param + "+graph")
-    ctx.close()
 from tests.test_gpu_verify import test_streaming_submit_wait as _streaming_submit_wait  # noqa: E402
 
 

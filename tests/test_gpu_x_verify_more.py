@@ -75,64 +75,3 @@ def test_keys_longer_than_the_lds_staging(M, oracle):
         assert np.array_equal(got[0], want[0]), (key_len, got[0][:20], want[0][:20])
         assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
         assert {M.PROOF_PRESENT, M.PROOF_ABSENT} <= set(got[0].tolist())
-
-
-@pytest.fixture(scope="module", params=["flat", "nodedup", "levels3"])
-def MG(request):
-    """A ctx with PHANT_CTX_VERIFY_GRAPH on a stream of its own (the legacy default stream cannot be captured)."""
-    import phant_amd
-    from tests.test_gpu_verify import _Mode
-    ctx = phant_amd.Context(use_torch_stream=False, verify_graph=True, verify_nodedup=(request.param == "nodedup"),
-                            dedup_levels=(3 if request.param == "levels3" else None))
-    yield _Mode(phant_amd.mpt, ctx, request.param + "+graph")
-    ctx.close()
-
-
-def test_graph_replay_reads_fresh_data_and_recaptures_on_new_arguments(MG, oracle):
-    """PHANT_CTX_VERIFY_GRAPH: the second and later calls with the same buffers are ONE graph launch each; the
-    graph freezes the arguments, not the data -- a witness changed in place is verified as changed; other buffers
-    (or sizes) capture again; results are those of the direct launch and of the oracle throughout."""
-    import phant_amd
-    ctx = MG._ctx
-    w = phant_amd.witness.account_witness(2000, depth=8, seed=19, corrupt_frac=0.1)
-    b = w.batch
-    torch.cuda.synchronize()                                   # the witness was built on torch's stream
-    st = torch.full((b.n,), 0xEE, dtype=torch.uint8, device=b.nodes.device)
-    fc = torch.full((1,), -5, dtype=torch.int32, device=b.nodes.device)
-    for _ in range(3):
-        MG.verify_batch_dev(b, status=st, fail_count=fc)
-    ctx.sync()
-    assert torch.equal(st, w.expected) and int(fc.item()) == w.n_invalid
-    assert ctx.graph_stats() == (1, 3)
-    # the same buffers, other contents: break proof 7's leaf, repair nothing else
-    victim = int(torch.nonzero(w.expected == MG.PROOF_PRESENT)[3, 0])
-    pos = int(b.node_off[int(b.proof_first_node[victim + 1])].item()) - 1   # last byte of its last node
-    b.nodes[pos] ^= 0x40
-    torch.cuda.synchronize()
-    MG.verify_batch_dev(b, status=st, fail_count=fc)
-    ctx.sync()
-    assert ctx.graph_stats() == (1, 4)
-    want = w.expected.clone()
-    want[victim] = MG.PROOF_BAD_HASH
-    assert torch.equal(st, want) and int(fc.item()) == w.n_invalid + 1
-    ref = oracle.mpt_verify_batch(b.roots.cpu().numpy(), None, b.keys.cpu().numpy(), 32, b.nodes.cpu().numpy(),
-                                  b.node_off.cpu().numpy().astype(np.uint64),
-                                  b.proof_first_node.cpu().numpy().astype(np.uint32))
-    assert np.array_equal(st.cpu().numpy(), ref[0])
-    # another output buffer: captured again, same answer; value outputs as well
-    st2 = torch.empty_like(st)
-    vo = torch.zeros(b.n, dtype=torch.int64, device=st.device)
-    vl = torch.zeros(b.n, dtype=torch.int32, device=st.device)
-    torch.cuda.synchronize()
-    MG.verify_batch_dev(b, status=st2, value_off=vo, value_len=vl)
-    MG.verify_batch_dev(b, status=st2, value_off=vo, value_len=vl)
-    ctx.sync()
-    assert ctx.graph_stats() == (2, 6)
-    assert torch.equal(st2, want)
-    assert np.array_equal(vo.cpu().numpy().view(np.uint64), ref[1]) and np.array_equal(vl.cpu().numpy().view(np.uint32), ref[2])
-    # a smaller batch through the same ctx (other sizes): again a capture, and the first graph is gone
-    w3 = phant_amd.witness.account_witness(300, depth=5, seed=20, corrupt_frac=0.2)
-    torch.cuda.synchronize()
-    st3 = MG.verify_batch_dev(w3.batch)
-    ctx.sync()
-    assert torch.equal(st3, w3.expected) and ctx.graph_stats() == (3, 7)

@@ -28,8 +28,6 @@ b config2 --workload config2 --cpu-seconds 3
 b nodeset --workload nodeset --no-cpu-baseline
 b config5 --workload config5 --no-cpu-baseline
 b config5_100k --workload config5 --no-cpu-baseline --stream-proofs 100000
-b config3_graph --no-cpu-baseline --no-strong --graph
-b config3_graph_s1 --no-cpu-baseline --no-strong --graph --streams 1
 b mptize --workload mptize --cpu-seconds 8 --steps 10
 timeout 600 python tools/stress_verify.py --seeds 20 --first-seed 3000 2>&1 | tail -1 | tee "$OUT/stress.log"
 timeout 300 python tools/stress_trie.py --seeds 10 2>&1 | tail -1 | tee "$OUT/stress_trie.log"
