@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../phant_amd/csrc/absorb.hip.h"
 using namespace phant;
@@ -128,8 +129,9 @@ __global__ void __launch_bounds__(256) stream_kernel(const uint4* src, size_t n1
     if (acc == 0x12345u) out[0] = acc;
 }
 
-int main() {
-    const uint32_t n = 100000, wpl = (n + 63) / 64;
+int main(int argc, char** argv) {
+    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 100000, wpl = (n + 63) / 64;
+    const float perms = 8.0f * n;
     const size_t bytes = (size_t)n * 3836 + 4096;
     uint8_t* nodes;
     uint32_t *d0, *d1;
@@ -178,7 +180,7 @@ int main() {
                 best = ms < best ? ms : best;
             }
             printf("pad %2u KiB  %-18s %7.1f us  %5.2f G perm/s\n", pad / 1024, mode == 0 ? "direct" : mode == 1 ? "staged" : "staged+prefetch",
-                   best * 1e3f, 800000.0f / (best * 1e-3f) / 1e9f);
+                   best * 1e3f, perms / (best * 1e-3f) / 1e9f);
         }
     }
     // ---- the same with a memory stream running next to the hashing (second stream, ~3 waves per SIMD of it)
@@ -209,7 +211,7 @@ int main() {
                 if (ms < best) { best = ms; sbest = sms; }
             }
             printf("next to a %4u-workgroup memory stream (%.0f us): %-18s %7.1f us  %5.2f G perm/s\n", sgrid, sbest * 1e3f,
-                   mode == 0 ? "direct" : mode == 1 ? "staged" : "staged+prefetch", best * 1e3f, 800000.0f / (best * 1e-3f) / 1e9f);
+                   mode == 0 ? "direct" : mode == 1 ? "staged" : "staged+prefetch", best * 1e3f, perms / (best * 1e-3f) / 1e9f);
         }
     }
     for (uint32_t sgrid : {0u, 768u, 2048u}) {
@@ -219,8 +221,8 @@ int main() {
                 hipDeviceSynchronize();
                 if (sgrid) hipLaunchKernelGGL(stream_kernel, dim3(sgrid), dim3(256), 0, sb, (const uint4*)nodes, bytes / 16, 2u, d0);
                 hipEventRecord(a, sa);
-                if (lit) hipLaunchKernelGGL(perms_only<1>, dim3(grid), dim3(256), 48u * 1024u, sa, 3126u, d0);
-                else hipLaunchKernelGGL(perms_only<0>, dim3(grid), dim3(256), 48u * 1024u, sa, 3126u, d0);
+                if (lit) hipLaunchKernelGGL(perms_only<1>, dim3(grid), dim3(256), 48u * 1024u, sa, 2u * wpl, d0);
+                else hipLaunchKernelGGL(perms_only<0>, dim3(grid), dim3(256), 48u * 1024u, sa, 2u * wpl, d0);
                 hipEventRecord(b, sa);
                 hipDeviceSynchronize();
                 float ms;
@@ -228,7 +230,7 @@ int main() {
                 best = ms < best ? ms : best;
             }
             printf("permutations only, %s, next to a %4u-workgroup memory stream: %7.1f us  %5.2f G perm/s\n",
-                   lit ? "constants as literals " : "constants by scalar load", sgrid, best * 1e3f, 800000.0f / (best * 1e-3f) / 1e9f);
+                   lit ? "constants as literals " : "constants by scalar load", sgrid, best * 1e3f, perms / (best * 1e-3f) / 1e9f);
         }
     }
     return 0;
