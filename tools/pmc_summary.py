@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Average the rocprofv3 --pmc CSVs written by tools/gpu_pmc.sh per kernel: python tools/pmc_summary.py gpurun_out/<tag>"""
+"""Average the rocprofv3 --pmc CSVs written by tools/gpu_evidence.sh (flat_*.csv) per kernel: python tools/pmc_summary.py gpurun_out/<tag>"""
 import collections
 import csv
 import glob
@@ -8,7 +8,7 @@ import sys
 
 d = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(os.path.join(d, "*.csv"))):
+for f in sorted(glob.glob(os.path.join(d, "flat_*.csv"))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

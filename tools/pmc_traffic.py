@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM traffic per verify launch from the rocprofv3 PMC passes of tools/gpu_pmc_calib.sh.
+"""HBM traffic per verify launch from the rocprofv3 PMC passes of tools/gpu_evidence.sh.
 
     python tools/pmc_traffic.py gpurun_out/<tag> > profiles/<round>/pmc_traffic.json
 
@@ -7,7 +7,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md 
 gfx950 reports exactly half of a wide coalesced read and is uncalibrated for other patterns, so every
 correction factor used here is derived from a known byte count in the same access pattern:
   * stream_read / node_read (tools/ubench/load_align.hip, 408 004 096 B read once): factor for 16 B/lane
-    coalesced reads -> applied to dedup_kernel (same loads);
+    coalesced reads; node_read_half = dedup_kernel's pattern since round 2 (a half wave per node) -> applied to it;
   * hash_deep_kernel in nodedup mode reads every shipped node once (one node per lane, unaligned 16 B
     loads): factor = known bytes / reported -> applied to both hash kernels in every mode;
   * fillBufferAligned (408 004 096 B written): WRITE_SIZE factor;
@@ -36,6 +36,8 @@ ub_f = mean_by_kernel(os.path.join(d, "ubench_FETCH_SIZE.csv"))
 ub_w = mean_by_kernel(os.path.join(d, "ubench_WRITE_SIZE.csv"))
 f_stream = UB_BYTES / ub_f["stream_read"]
 f_node = (750000 * 532) / ub_f["node_read<4>"]
+# dedup_kernel's pattern since round 2 (a half wave per node + lane-per-node tail): 749 952 nodes are read (whole waves of 64)
+f_half = (749952 * 532) / ub_f["node_read_half<4>"] if "node_read_half<4>" in ub_f else f_node
 f_write = UB_BYTES / ub_w["__amd_rocclr_fillBufferAligned"]
 
 nd_f = mean_by_kernel(os.path.join(d, "nodedup_FETCH_SIZE.csv"))
@@ -49,6 +51,7 @@ f_hash = known_hash / nd_f[hk]
 
 out = {"unit": "bytes per launch (100000 depth-8 proofs)", "factors": {
     "stream_read_uint4": round(f_stream, 3), "node_read_16B_per_lane": round(f_node, 3),
+    "node_read_half_wave_per_node": round(f_half, 3),
     "hash kernel (from nodedup known bytes)": round(f_hash, 3), "write": round(f_write, 3)}}
 for mode in ("flat", "nodedup"):
     fr = mean_by_kernel(os.path.join(d, f"{mode}_FETCH_SIZE.csv"))
@@ -58,7 +61,7 @@ for mode in ("flat", "nodedup"):
     for k in fr:
         if not k.startswith("phant::") or "keccak256_fixed" in k or "verdict" in k:
             continue
-        fac = f_node if "dedup_kernel" in k else f_hash if "hash_" in k else 1.0
+        fac = f_half if "dedup_kernel" in k else f_hash if "hash_" in k else 1.0
         r = fr[k] * fac
         w = wr.get(k, 0.0) * f_write
         per[k] = {"read": round(r), "write": round(w), "read_factor": round(fac, 3),
