@@ -662,20 +662,20 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
 // Wave = 64 consecutive proofs at one depth, lane = proof.  Nothing is looked up: a proof's node at depth d is node
 // proof_first_node[p] + d, its key nibble comes from the key.  The grid's y covers DEEP_LEVELS depths per pass
 // (deepest last: the leaves, the short chunks, fill the tail); a wave whose proofs are all shorter leaves at once.
-constexpr uint32_t DEEP_LEVELS = 8;
+constexpr uint32_t DEEP_LEVELS = 8;  // at most; the launcher picks fewer when the batch's proofs are short (see there)
 
-__global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const uint32_t waves_per_level) {
+__global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const uint32_t waves_per_level, const uint32_t levels) {
     // the 32 reference bytes wait in LDS while the sponge has the registers ([dword][lane]: conflict-free)
     __shared__ uint32_t s_ref[8][256];
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t level = w / waves_per_level;  // 0 .. DEEP_LEVELS - 1
+    const uint32_t level = w / waves_per_level;  // 0 .. levels - 1
     const uint32_t p = (w % waves_per_level) * 64u + lane;
     const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
     const uint32_t nn = 2u * a.v.key_len;
     // (a wave normally makes one trip: everything about the proof is re-read per trip rather than kept in
     // registers across the sponge)
-    for (uint32_t d = a.shallow + level;; d += DEEP_LEVELS) {
+    for (uint32_t d = a.shallow + level;; d += levels) {
         uint32_t first = 0, count = 0, root = 0;
         if (p < a.v.n) {
             first = a.v.proof_first_node[p];
@@ -1302,7 +1302,14 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         const uint32_t ng = (total_nodes + 255u) / 256u;
         const uint32_t dg = (total_nodes + DEDUP_BLOCK - 1u) / DEDUP_BLOCK;
         const uint32_t wpl = (v.n + 63u) / 64u;                       // waves per level of the deep tier
-        const uint32_t deep_grid = (wpl * DEEP_LEVELS + 3u) / 4u;
+        // One pass of the grid covers `levels` depths below the shallow tier, a wave whose proofs go deeper loops.  Sized
+        // from the batch's average proof length (+ 1): a wave of a level no proof reaches still has to be dispatched and
+        // read its proofs' lengths before it can leave -- with 8 levels for depth-8 proofs above a 5-level shallow tier
+        // that was 7 800 such waves next to 4 700 working ones.
+        const uint64_t avg_len = (total_nodes + v.n - 1u) / v.n;
+        const uint32_t deep_levels = avg_len + 1u <= a.shallow ? 1u
+                                     : (uint32_t)(avg_len + 1u - a.shallow < DEEP_LEVELS ? avg_len + 1u - a.shallow : DEEP_LEVELS);
+        const uint32_t deep_grid = (wpl * deep_levels + 3u) / 4u;
         const bool two = side && side->stream && side->fork && side->join && a.shallow != 0u && !tune.serial;
         // deep tier: no inputs but the witness, so it starts at once -- on the helper stream, next to the shallow tier
         hipStream_t ds = st;
@@ -1312,7 +1319,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
             ds = side->stream;
         }
-        hipLaunchKernelGGL(hash_deep_kernel, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl);
+        hipLaunchKernelGGL(hash_deep_kernel, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl, deep_levels);
         if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
         if (a.shallow) {
