@@ -21,7 +21,8 @@ resident in HBM:
       keys with 78-byte values (account bodies), arrays resident in HBM (phant_mpt_root_dev).
   config5: consecutive block witnesses streamed from pinned host memory through
       phant_mpt_verify_submit / phant_wait (copy-in of witness k+1 overlaps the kernels of witness k);
-      a step = one witness of --stream-proofs depth-8 proofs; PCIe-bound by construction.
+      a step = one block witness (config 4's shape; --stream-proofs P: account witnesses of P depth-8 proofs instead);
+      --steps 64 = 256 witnesses (4 back-to-back per step); PCIe-bound by construction.
 
 N > 1: one process per GPU (torchrun), proofs sharded by the top key nibble,
 every rank verifies its own P proofs (weak scaling); the only data-path
@@ -82,7 +83,8 @@ def parse():
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5", "nodeset", "mptize"])
     ap.add_argument("--keys", type=int, default=1_000_000, help="mptize: sorted 32-byte keys (78-byte values) per GPU")
     ap.add_argument("--block-scale", type=float, default=1.0, help="config4: size of the block relative to 10k tx")
-    ap.add_argument("--stream-proofs", type=int, default=20_000, help="proofs per streamed witness (config5)")
+    ap.add_argument("--stream-proofs", type=int, default=0,
+                    help="config5: stream account witnesses of this many depth-8 proofs instead of block witnesses (A/B)")
     ap.add_argument("--stream-slots", type=int, default=2, help="witnesses in flight (config5)")
     ap.add_argument("--verify-mode", default="flat", choices=["flat", "nodedup", "fused"],
                     help="flat = the two-tier pipeline (default: shallow trie levels deduplicated, deep ones hashed "
@@ -512,12 +514,18 @@ def main():
     elif args.workload == "config5":
         # 4 distinct witnesses in pinned host memory, submitted round-robin; results land in pinned buffers
         from phant_amd import mpt as MM
-        wl = [phant_amd.witness.account_witness(args.stream_proofs, depth=args.depth, seed=40 + k, device=dev,
-                                                rank=rank, world=world, ctx=ctx) for k in range(4)]
+        if args.stream_proofs:
+            wl = [phant_amd.witness.account_witness(args.stream_proofs, depth=args.depth, seed=40 + k, device=dev,
+                                                    rank=rank, world=world, ctx=ctx) for k in range(4)]
+        else:  # BASELINE config 5: block witnesses (config 4's shape; this rank's share of each)
+            wl = [phant_amd.witness.block_witness(scale=args.block_scale, seed=40 + k, device=dev, rank=rank, world=world,
+                                                  ctx=ctx) for k in range(4)]
         hosts = [MM.to_host(x.batch) for x in wl]
         w = wl[0]
         b = w.batch
-        n_units = args.stream_proofs
+        n_units = b.n
+        for x in wl:
+            assert x.batch.n == n_units
         alg_bytes = wl[0].batch.algorithmic_bytes()
         slots = max(1, min(args.stream_slots, 4))
         state = {"k": 0, "pending": []}
@@ -535,9 +543,15 @@ def main():
                 MM.wait(state["pending"].pop(0), ctx)
 
         kernel_only = None
-        metric, unit = "mpt_proofs_verified_per_sec_depth%d_streamed" % args.depth, "proofs/s"
-        workload = (f"config5: consecutive witnesses of {args.stream_proofs} depth-{args.depth} proofs streamed from "
-                    f"pinned host memory, {slots} in flight per GPU (H2D {hosts[0].h2d_bytes()} B per witness)")
+        if args.stream_proofs:
+            metric, unit = "mpt_proofs_verified_per_sec_depth%d_streamed" % args.depth, "proofs/s"
+            what = f"witnesses of {args.stream_proofs} depth-{args.depth} account proofs"
+        else:
+            metric, unit = "mpt_proofs_verified_per_sec_block_witness_streamed", "proofs/s"
+            what = (f"synthetic {int(10000 * args.block_scale)}-tx block witnesses ({n_units} account + storage proofs against "
+                    f"{b.n_roots} roots on this rank each; 4 distinct ones in rotation)")
+        workload = (f"config5: consecutive {what} streamed from pinned host memory, {slots} in flight per GPU "
+                    f"(H2D {hosts[0].h2d_bytes()} B per witness)")
     else:
         n_units = args.messages
         g = torch.Generator(device=dev)
@@ -650,6 +664,8 @@ def main():
         if args.workload == "mptize":
             line["cpu_baseline"] = cpu_baseline_mptize(keys_t, vals_t, n_units, root, args.cpu_seconds)
         elif args.workload == "config4":
+            line["cpu_baseline"] = cpu_baseline_block(w, args.cpu_seconds)
+        elif args.workload == "config5" and not args.stream_proofs:
             line["cpu_baseline"] = cpu_baseline_block(w, args.cpu_seconds)
         elif args.workload in ("config3", "config5", "nodeset"):
             line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds)

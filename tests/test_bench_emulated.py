@@ -136,7 +136,12 @@ def test_nodeset_and_config5_dry_run():
     line = _bench(["--workload", "config5", "--stream-proofs", "150", "--steps", "5", "--warmup", "1",
                    "--cpu-seconds", "0.2"])
     _check_contract(line, 5, 1)
-    assert "pcie" in line
+    assert "pcie" in line and line["metric"] == "mpt_proofs_verified_per_sec_depth8_streamed"
+    # the default: block witnesses (config 4's shape) in rotation
+    line = _bench(["--workload", "config5", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
+    _check_contract(line, 2, 1)
+    assert line["metric"] == "mpt_proofs_verified_per_sec_block_witness_streamed" and "pcie" in line
+    assert line["config"]["units_per_gpu_per_step"] == 200 + 15 * 8 + 4 * 40 + 1 * 600
 
 
 def test_mptize_dry_run():

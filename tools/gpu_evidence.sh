@@ -26,8 +26,9 @@ b config4 --workload config4 --cpu-seconds 5
 b config4_nodedup --workload config4 --no-cpu-baseline --verify-mode nodedup
 b config2 --workload config2 --cpu-seconds 3
 b nodeset --workload nodeset --no-cpu-baseline
-b config5 --workload config5 --no-cpu-baseline
-b config5_100k --workload config5 --no-cpu-baseline --stream-proofs 100000
+b config5 --workload config5 --steps 64 --cpu-seconds 3
+b config5_20k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 20000
+b config5_100k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 100000
 b mptize --workload mptize --cpu-seconds 8 --steps 10
 timeout 600 python tools/stress_verify.py --seeds 20 --first-seed 3000 2>&1 | tail -1 | tee "$OUT/stress.log"
 timeout 300 python tools/stress_trie.py --seeds 10 2>&1 | tail -1 | tee "$OUT/stress_trie.log"
