@@ -115,22 +115,15 @@ int32_t hash_var(Workspaces& ws, hipStream_t st, const uint8_t* blob, const uint
     return PHANT_OK;
 }
 
-// canonical RLP of a byte string (row a10)
-void put_rlp_str(std::vector<uint8_t>& o, const uint8_t* s, size_t len) {
+// canonical RLP of a byte string of <= 32 bytes (row a10) into a buffer the caller sized (<= 33 bytes: no long form); returns the end
+uint8_t* put_rlp_short(uint8_t* o, const uint8_t* s, size_t len) {
     if (len == 1 && s[0] < 0x80) {
-        o.push_back(s[0]);
-        return;
+        *o++ = s[0];
+        return o;
     }
-    if (len <= 55) {
-        o.push_back((uint8_t)(0x80 + len));
-    } else {
-        uint8_t be[8];
-        size_t n = 0;
-        for (size_t v = len; v; v >>= 8) be[n++] = (uint8_t)v;
-        o.push_back((uint8_t)(0xb7 + n));
-        for (size_t i = 0; i < n; ++i) o.push_back(be[n - 1 - i]);
-    }
-    o.insert(o.end(), s, s + len);
+    *o++ = (uint8_t)(0x80 + len);
+    std::memcpy(o, s, len);
+    return o + len;
 }
 
 size_t strip32(const uint8_t* v, const uint8_t** out) {
@@ -177,18 +170,21 @@ int32_t state_leaves_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, 
     // hashed slot keys, ordered per account (the live slots are grouped by account already: a stable regrouping)
     int32_t rc = hash_fixed_ordered(ws, st, live_keys.data(), 32, m, seg_of.data(), n, hk, perm, err);
     if (rc) return rc;
-    std::vector<uint8_t> skeys((size_t)m * 32), svals;
+    // the leaves of all storage tries in that order: 32-byte hashed keys, values rlp(minimal big-endian), <= 33 bytes
+    std::vector<uint8_t> skeys((size_t)m * 32), svals((size_t)m * 33);
     std::vector<uint32_t> skoff(m + 1, 0);
     std::vector<uint64_t> svoff(m + 1, 0);
-    svals.reserve((size_t)m * 33);
-    for (uint32_t j = 0; j < m; ++j) {
-        const uint32_t src = perm[j];
-        std::memcpy(&skeys[(size_t)j * 32], &hk[(size_t)src * 32], 32);
-        const uint8_t* v;
-        const size_t vl = strip32(slot_vals + 32ull * live[src], &v);
-        put_rlp_str(svals, v, vl);
-        skoff[j + 1] = 32 * (j + 1);
-        svoff[j + 1] = svals.size();
+    {
+        uint8_t* o = svals.data();
+        for (uint32_t j = 0; j < m; ++j) {
+            const uint32_t src = perm[j];
+            std::memcpy(&skeys[(size_t)j * 32], &hk[(size_t)src * 32], 32);
+            const uint8_t* v;
+            const size_t vl = strip32(slot_vals + 32ull * live[src], &v);
+            o = put_rlp_short(o, v, vl);
+            skoff[j + 1] = 32 * (j + 1);
+            svoff[j + 1] = (uint64_t)(o - svals.data());
+        }
     }
     std::vector<uint8_t> sroots((size_t)n * 32);
     rc = trie_forest_host(ws, st, skeys.data(), skoff.data(), svals.data(), svoff.data(), m, acc_first.data(), n,
@@ -202,33 +198,41 @@ int32_t state_leaves_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, 
     if (rc) return rc;
     rc = hash_var(ws, st, code, code_off, n, hc, err);
     if (rc) return rc;
-    std::vector<uint8_t> payload;
+    // account leaves in key order: rlp([nonce, balance, storageRoot, codeHash]) -- payload <= 9 + 33 + 33 + 33 = 108
+    // bytes, so the list header is one byte (<= 55) or f8 + one length byte; written in place, sized for the worst case
     akeys.resize((size_t)n * 32);
-    avals.reserve((size_t)n * 112);
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t a = ord[i];
-        std::memcpy(&akeys[(size_t)i * 32], &ha[(size_t)a * 32], 32);
-        payload.clear();
-        uint8_t nb[8];
-        size_t nn = 0;
-        for (int s = 56; s >= 0; s -= 8) {
-            const uint8_t b = (uint8_t)(nonces[a] >> s);
-            if (nn || b) nb[nn++] = b;
+    avals.resize((size_t)n * 110);
+    {
+        uint8_t* o = avals.data();
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t a = ord[i];
+            std::memcpy(&akeys[(size_t)i * 32], &ha[(size_t)a * 32], 32);
+            uint8_t body[108];
+            uint8_t* q = body;
+            uint8_t nb[8];
+            size_t nn = 0;
+            for (int sh = 56; sh >= 0; sh -= 8) {
+                const uint8_t bt = (uint8_t)(nonces[a] >> sh);
+                if (nn || bt) nb[nn++] = bt;
+            }
+            q = put_rlp_short(q, nb, nn);
+            const uint8_t* bv;
+            const size_t bl = strip32(balances + 32ull * a, &bv);
+            q = put_rlp_short(q, bv, bl);
+            q = put_rlp_short(q, &sroots[(size_t)a * 32], 32);
+            q = put_rlp_short(q, &hc[(size_t)a * 32], 32);
+            const size_t plen = (size_t)(q - body);
+            if (plen <= 55) {
+                *o++ = (uint8_t)(0xc0 + plen);
+            } else {
+                *o++ = 0xf8;
+                *o++ = (uint8_t)plen;
+            }
+            std::memcpy(o, body, plen);
+            o += plen;
+            avoff[i + 1] = (uint64_t)(o - avals.data());
         }
-        put_rlp_str(payload, nb, nn);
-        const uint8_t* bv;
-        const size_t bl = strip32(balances + 32ull * a, &bv);
-        put_rlp_str(payload, bv, bl);
-        put_rlp_str(payload, &sroots[(size_t)a * 32], 32);
-        put_rlp_str(payload, &hc[(size_t)a * 32], 32);
-        if (payload.size() <= 55) {
-            avals.push_back((uint8_t)(0xc0 + payload.size()));
-        } else {
-            avals.push_back(0xf8);  // payload <= 110 bytes
-            avals.push_back((uint8_t)payload.size());
-        }
-        avals.insert(avals.end(), payload.begin(), payload.end());
-        avoff[i + 1] = avals.size();
+        avals.resize((size_t)(o - avals.data()));
     }
     return PHANT_OK;
 }
