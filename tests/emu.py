@@ -17,6 +17,11 @@ SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_
 OUT_DIR = os.path.join(ROOT, "tests", "native", "_build")
 
 
+
+class EmuBuildError(Exception):
+    """The kernel sources do not compile for the host: a failure of the tests that need them, never a reason to skip
+    (callers skip on RuntimeError = no host compiler at all)."""
+
 def build(sanitize: bool = False) -> str:
     """-> path of libphant_emu[_san].so (rebuilt when a source is newer)."""
     cxx = os.environ.get("PHANT_EMU_CXX", "g++")  # (e.g. ROCm's clang++: a second opinion on the same sources)
@@ -47,13 +52,13 @@ def build(sanitize: bool = False) -> str:
     for s, _, p in procs:
         log, _ = p.communicate()
         if p.returncode:
-            raise RuntimeError(f"{cxx} failed on {s}:\n{log[-4000:]}")
+            raise EmuBuildError(f"{cxx} failed on {s}:\n{log[-4000:]}")
     link = [cxx, "-shared", "-pthread", "-o", out + ".tmp", *[o for _, o, _ in procs]]
     if sanitize:
         link += ["-fsanitize=address,undefined"]
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode:
-        raise RuntimeError("link failed:\n" + r.stdout[-4000:])
+        raise EmuBuildError("link failed:\n" + r.stdout[-4000:])
     os.replace(out + ".tmp", out)
     return out
 
