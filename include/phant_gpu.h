@@ -282,6 +282,13 @@ PHANT_API int32_t phant_mpt_verify_sharded(phant_comm *comm, const uint8_t *root
  * ranks' own streams (not waited for). */
 PHANT_API int32_t phant_comm_allreduce_verdict(phant_comm *comm, uint32_t *const *d_fail_count, uint32_t n_roots);
 
+/* mptize (src/mpt/mpt.zig:38-45, arguments as phant_mpt_root, every key at least one byte) with the work spread over the
+ * comm's devices by the top key nibble: device d hashes the sub-tries of the nibbles x with x mod N == d
+ * (phant_mpt_root_nodes, one forest pass), the host re-roots their root nodes (phant_mpt_strip_first_nibble) and forms
+ * the root branch.  Single process: collecting the sixteen child references IS the exchange. */
+PHANT_API int32_t phant_mpt_root_sharded(phant_comm *comm, const uint8_t *keys, const uint32_t *key_off,
+                                         const uint8_t *vals, const uint64_t *val_off, uint32_t n, uint8_t out[32]);
+
 /* ------------------------------------------------------------ block witness
  * The step before the kernel: the engine-API witness as JSON, parsed into
  * the packed arrays above and verified in one call.  phant has no witness type yet

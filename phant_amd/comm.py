@@ -59,6 +59,18 @@ class Comm:
             raise L.PhantError(rc, self._lib.phant_comm_last_error(self._h).decode())
         return status[:n], voff[:n], vlen[:n], fails[:n_roots]
 
+    def mptize(self, keys: list[bytes], vals: list[bytes]) -> bytes:
+        """mptize (mpt.zig:38-45) of sorted distinct keys (>= 1 byte each), the sub-tries of the sixteen top nibbles dealt
+        out to the comm's devices (phant_mpt_root_sharded)."""
+        from .mpt import _pack
+        kb, ko = _pack(keys, np.uint32)
+        vb, vo = _pack(vals, np.uint64)
+        out = np.zeros(32, np.uint8)
+        rc = self._lib.phant_mpt_root_sharded(self._h, _p(kb), _p(ko), _p(vb), _p(vo), len(keys), _p(out))
+        if rc != L.OK:
+            raise L.PhantError(rc, self._lib.phant_comm_last_error(self._h).decode())
+        return out.tobytes()
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.phant_comm_destroy(self._h)

@@ -380,4 +380,144 @@ int32_t phant_mpt_verify_sharded(phant_comm* c, const uint8_t* roots, uint32_t n
     return PHANT_OK;
 }
 
+// mptize (src/mpt/mpt.zig:38-45) with the work spread over the comm's devices by the top key nibble:
+// device d builds the sub-tries of the nibbles x with x mod N == d in one forest pass (phant_mpt_root_nodes), the host
+// re-roots each sub-trie's root node one nibble lower (phant_mpt_strip_first_nibble), embeds-or-hashes it
+// (mpt.zig:104/:112) and forms the root branch.  One process: the "exchange" of the 16 child references is the host
+// collecting them -- no collective.
+int32_t phant_mpt_root_sharded(phant_comm* c, const uint8_t* keys, const uint32_t* key_off, const uint8_t* vals,
+                               const uint64_t* val_off, uint32_t n, uint8_t out[32]) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    if (n == 0) return phant_mpt_root(c->ctx[0], nullptr, nullptr, nullptr, nullptr, 0, out);
+    if (!keys || !key_off || !val_off) return cfail(c, PHANT_E_INVALID_ARG, "mpt_root_sharded: null argument");
+    // the sixteen top-nibble ranges of the (sorted) key list; order and key lengths are checked here because the
+    // ranges are cut on the host (within a range the device checks them, PHANT_E_UNSORTED)
+    uint32_t first[17];
+    uint32_t at = 0;
+    for (uint32_t x = 0; x < 16; ++x) {
+        first[x] = at;
+        while (at < n) {
+            if (key_off[at + 1] <= key_off[at]) return cfail(c, PHANT_E_UNSUPPORTED, "mpt_root_sharded: empty key (needs a root value)");
+            if ((uint32_t)(keys[key_off[at]] >> 4) != x) break;
+            ++at;
+        }
+    }
+    first[16] = at;
+    if (at != n) return cfail(c, PHANT_E_UNSORTED, "mpt_root_sharded: keys are not sorted");
+    const uint32_t W = (uint32_t)c->ctx.size();
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t l = (uint64_t)(key_off[i + 1] - key_off[i]) + (val_off[i + 1] - val_off[i]);
+        longest = l > longest ? (uint32_t)(l > 0x7fffffffull ? 0x7fffffffull : l) : longest;
+    }
+    const uint32_t cap = longest + 80u;  // a sub-trie that is one leaf: key path + value + headers
+    struct Part {
+        std::vector<uint32_t> nibbles;
+        std::vector<uint8_t> roots, enc;
+        std::vector<uint32_t> len;
+        int32_t rc = PHANT_OK;
+    };
+    std::vector<Part> parts(W);
+    auto work = [&](uint32_t d) {
+        Part& p = parts[d];
+        // this device's nibble ranges are not adjacent in the caller's arrays (every W-th one): one forest call per range
+        // -- or, on a one-device comm, where they tile the whole list, one call with a segment per range
+        for (uint32_t x = d; x < 16; x += W)
+            if (first[x + 1] > first[x]) p.nibbles.push_back(x);
+        if (p.nibbles.empty()) return;
+        const uint32_t nt = (uint32_t)p.nibbles.size();
+        p.roots.assign((size_t)nt * 32, 0);
+        p.enc.assign((size_t)nt * cap, 0);
+        p.len.assign(nt, 0);
+        if (W == 1) {
+            std::vector<uint32_t> seg;
+            for (uint32_t x : p.nibbles) seg.push_back(first[x]);
+            seg.push_back(n);
+            // (with every nibble on one device the ranges tile [0, n): empty ranges are simply not listed)
+            p.rc = phant_mpt_root_nodes(c->ctx[d], keys, key_off, vals, val_off, n, seg.data(), nt, p.roots.data(), p.enc.data(), cap,
+                                        p.len.data());
+            return;
+        }
+        for (uint32_t t = 0; t < nt && p.rc == PHANT_OK; ++t) {
+            const uint32_t x = p.nibbles[t], lo = first[x], cnt = first[x + 1] - first[x];
+            const uint32_t seg[2] = {0u, cnt};
+            // key_off / val_off of a range are offsets into the caller's blobs: the entry point re-bases them itself
+            p.rc = phant_mpt_root_nodes(c->ctx[d], keys, key_off + lo, vals, val_off + lo, cnt, seg, 1, &p.roots[(size_t)t * 32],
+                                        &p.enc[(size_t)t * cap], cap, &p.len[t]);
+        }
+    };
+#ifndef PHANT_HOST_EMU
+    {
+        std::vector<std::thread> th;
+        for (uint32_t d = 1; d < W; ++d) th.emplace_back(work, d);
+        work(0);
+        for (std::thread& t : th) t.join();
+    }
+#else  // (the host emulation of the HIP runtime is single-threaded)
+    for (uint32_t d = 0; d < W; ++d) work(d);
+#endif
+    for (uint32_t d = 0; d < W; ++d)
+        if (parts[d].rc != PHANT_OK) return cfail(c, parts[d].rc, std::string("mpt_root_sharded: device ") + std::to_string(d) + ": " + phant_last_error(c->ctx[d]));
+    // ---- the root branch from the sixteen child references ----
+    uint8_t refs[16][33];
+    uint32_t lens[16] = {0};
+    uint32_t filled = 0;
+    const uint8_t* only_root = nullptr;
+    std::vector<uint8_t> tmp((size_t)cap + 16);
+    for (uint32_t d = 0; d < W; ++d)
+        for (size_t t = 0; t < parts[d].nibbles.size(); ++t) {
+            const uint32_t x = parts[d].nibbles[t], ln = parts[d].len[t];
+            if (ln == 0 || ln > cap) return cfail(c, PHANT_E_DEVICE, "mpt_root_sharded: sub-trie root node missing");
+            uint32_t out_len = 0, is_ref = 0;
+            const int32_t rc = phant_mpt_strip_first_nibble(&parts[d].enc[t * cap], ln, tmp.data(), (uint32_t)tmp.size(), &out_len, &is_ref);
+            if (rc != PHANT_OK) return cfail(c, rc, "mpt_root_sharded: strip_first_nibble");
+            if (is_ref || out_len < 32) {
+                if (out_len > 33) return cfail(c, PHANT_E_DEVICE, "mpt_root_sharded: child reference too long");
+                std::memcpy(refs[x], tmp.data(), out_len);
+                lens[x] = out_len;
+            } else {
+                const int32_t hrc = phant_keccak256(c->ctx[d], tmp.data(), out_len, refs[x]);
+                if (hrc != PHANT_OK) return cfail(c, hrc, "mpt_root_sharded: keccak256");
+                lens[x] = 32;
+            }
+            ++filled;
+            only_root = &parts[d].roots[t * 32];
+        }
+    if (filled == 1) {  // no branch at the top: that sub-trie's root is the root
+        std::memcpy(out, only_root, 32);
+        return PHANT_OK;
+    }
+    uint8_t node[3 + 16 * 33 + 1];
+    size_t body = 0;
+    uint8_t* b = node + 3;
+    for (uint32_t x = 0; x < 16; ++x) {
+        if (lens[x] == 0) {
+            b[body++] = 0x80;
+        } else if (lens[x] == 32) {
+            b[body++] = 0xa0;
+            std::memcpy(b + body, refs[x], 32);
+            body += 32;
+        } else {
+            std::memcpy(b + body, refs[x], lens[x]);  // an embedded child: its own RLP
+            body += lens[x];
+        }
+    }
+    b[body++] = 0x80;  // no value at the root (every key has at least one byte)
+    uint8_t* start;
+    if (body <= 55) {
+        start = node + 2;
+        start[0] = (uint8_t)(0xc0 + body);
+    } else if (body <= 255) {
+        start = node + 1;
+        start[0] = 0xf8;
+        start[1] = (uint8_t)body;
+    } else {
+        start = node;
+        start[0] = 0xf9;
+        start[1] = (uint8_t)(body >> 8);
+        start[2] = (uint8_t)body;
+    }
+    return phant_keccak256(c->ctx[0], start, (uint64_t)(b + body - start), out);
+}
+
 }  // extern "C"

@@ -30,7 +30,8 @@ def comm(request):
 
 
 from tests.test_gpu_comm import (  # noqa: E402,F401
-    body_sharded_matches_oracle_and_single_ctx, body_block_witness_per_root_verdict, body_rejects_inconsistent_index_arrays)
+    body_sharded_matches_oracle_and_single_ctx, body_block_witness_per_root_verdict, body_rejects_inconsistent_index_arrays,
+    body_sharded_mptize_matches_the_oracle)
 
 
 def test_sharded_matches_oracle_and_single_ctx(comm, oracle):
@@ -39,6 +40,10 @@ def test_sharded_matches_oracle_and_single_ctx(comm, oracle):
 
 def test_block_witness_per_root_verdict(comm, oracle):
     body_block_witness_per_root_verdict(comm, oracle)
+
+
+def test_sharded_mptize(comm, oracle):
+    body_sharded_mptize_matches_the_oracle(comm, oracle)
 
 
 def test_rejects_inconsistent_index_arrays(comm, oracle):

@@ -63,6 +63,30 @@ def body_block_witness_per_root_verdict(comm, oracle):
     assert np.array_equal(fails, np.bincount(ri[bad], minlength=len(roots)).astype(np.uint32))
 
 
+def body_sharded_mptize_matches_the_oracle(comm, oracle):
+    """phant_mpt_root_sharded: the sub-tries of the sixteen top nibbles on the comm's devices, root branch formed on the
+    host -- same root as the oracle's mptize and as the single-ctx call, for every shape of the top of the trie (full
+    branch, two nibbles, one nibble = no top branch, a single leaf, short keys with embedded children); unsorted keys and
+    an empty key are refused, the empty list gives empty_mpt_root."""
+    import phant_amd
+    from phant_amd import _lib as L
+    from tests.test_shard_trie import _cases
+    rng = np.random.default_rng(2)
+    for keys, vals in _cases(rng):
+        order = sorted(range(len(keys)), key=lambda i: keys[i])
+        keys, vals = [keys[i] for i in order], [vals[i] for i in order]
+        want = oracle.mptize(keys, vals)
+        assert comm.mptize(keys, vals) == want, len(keys)
+    assert comm.mptize([], []) == phant_amd.mpt.empty_mpt_root
+    keys, vals = random_kv(rng, 50, 32, 1, 40)
+    order = sorted(range(len(keys)), key=lambda i: keys[i])
+    keys, vals = [keys[i] for i in order], [vals[i] for i in order]
+    with pytest.raises(L.PhantError):
+        comm.mptize(keys[::-1], vals[::-1])
+    with pytest.raises(L.PhantError):
+        comm.mptize([b""] + keys, [b"v"] + vals)
+
+
 def body_rejects_inconsistent_index_arrays(comm, oracle):
     from phant_amd import _lib as L
     rng = np.random.default_rng(44)
@@ -100,6 +124,10 @@ def test_one_device_comm_block_witness(comm1, oracle):
 
 
 @pytest.mark.gpu
+def test_one_device_comm_mptize(comm1, oracle):
+    body_sharded_mptize_matches_the_oracle(comm1, oracle)
+
+
 def test_rccl_is_found_and_a_one_rank_allreduce_runs(comm1):
     """What a 1-GPU box can say about the RCCL path: the library is found at run time and an all-reduce over a
     one-rank communicator leaves the counters as they are (phant_comm_allreduce_verdict on the comm's ctx stream)."""
