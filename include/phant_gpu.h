@@ -289,6 +289,14 @@ PHANT_API int32_t phant_comm_allreduce_verdict(phant_comm *comm, uint32_t *const
 PHANT_API int32_t phant_mpt_root_sharded(phant_comm *comm, const uint8_t *keys, const uint32_t *key_off,
                                          const uint8_t *vals, const uint64_t *val_off, uint32_t n, uint8_t out[32]);
 
+/* StateDB.root() (arguments of phant_state_root) over the comm's devices: an account belongs to the device that owns the
+ * top nibble of keccak256(address); every device turns its accounts into state-trie leaves (phant_state_trie_leaves) and
+ * hashes the sub-tries of its nibbles, the root branch is formed on the host. */
+PHANT_API int32_t phant_state_root_sharded(phant_comm *comm, const uint8_t *addrs, const uint64_t *nonces,
+                                           const uint8_t *balances, const uint8_t *code, const uint64_t *code_off,
+                                           const uint8_t *slot_keys, const uint8_t *slot_vals,
+                                           const uint32_t *slot_first, uint32_t n, uint8_t out[32]);
+
 /* ------------------------------------------------------------ block witness
  * The step before the kernel: the engine-API witness as JSON, parsed into
  * the packed arrays above and verified in one call.  phant has no witness type yet

@@ -71,6 +71,17 @@ class Comm:
             raise L.PhantError(rc, self._lib.phant_comm_last_error(self._h).decode())
         return out.tobytes()
 
+    def state_root(self, accounts) -> bytes:
+        """state.state_root over the comm's devices (phant_state_root_sharded): accounts dealt out by the top nibble of
+        their hashed address."""
+        from .state import _soa
+        n, arrays = _soa(accounts)
+        out = np.zeros(32, np.uint8)
+        rc = self._lib.phant_state_root_sharded(self._h, *[_p(a) for a in arrays], n, _p(out))
+        if rc != L.OK:
+            raise L.PhantError(rc, self._lib.phant_comm_last_error(self._h).decode())
+        return out.tobytes()
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.phant_comm_destroy(self._h)

@@ -173,6 +173,160 @@ int32_t all_reduce_u32(phant_comm* c, const std::vector<uint32_t*>& bufs, size_t
     return PHANT_OK;
 }
 
+// a sorted key / value list in host memory (offsets as in phant_mpt_root)
+struct KeyList {
+    const uint8_t* keys = nullptr;
+    const uint32_t* key_off = nullptr;
+    const uint8_t* vals = nullptr;
+    const uint64_t* val_off = nullptr;
+    uint32_t n = 0;
+};
+
+// The root of the trie over the union of lists[d] (d = device), where device d hashes the sub-tries of the top nibbles x
+// with x mod W == d out of ITS list (keys of other nibbles in that list are ignored: phant_mpt_root_sharded hands every
+// device the same list, phant_state_root_sharded each its own).  Root branch formed on the host.
+int32_t sharded_root(phant_comm* c, const std::vector<KeyList>& lists, uint8_t out[32], const char* who) {
+    const uint32_t W = (uint32_t)c->ctx.size();
+    struct Part {
+        uint32_t first[17];
+        std::vector<uint32_t> nibbles;
+        std::vector<uint8_t> roots, enc;
+        std::vector<uint32_t> len;
+        uint32_t cap = 0;
+        int32_t rc = PHANT_OK;
+        std::string err;
+    };
+    std::vector<Part> parts(W);
+    // the sixteen top-nibble ranges of each (sorted) list; order across ranges and key lengths are checked here because
+    // the ranges are cut on the host (within a range the device checks the order: PHANT_E_UNSORTED)
+    for (uint32_t d = 0; d < W; ++d) {
+        const KeyList& l = lists[d];
+        Part& p = parts[d];
+        uint32_t at = 0, longest = 0;
+        for (uint32_t x = 0; x < 16; ++x) {
+            p.first[x] = at;
+            while (at < l.n) {
+                if (l.key_off[at + 1] <= l.key_off[at]) return cfail(c, PHANT_E_UNSUPPORTED, std::string(who) + ": empty key (needs a root value)");
+                if ((uint32_t)(l.keys[l.key_off[at]] >> 4) != x) break;
+                ++at;
+            }
+        }
+        p.first[16] = at;
+        if (at != l.n) return cfail(c, PHANT_E_UNSORTED, std::string(who) + ": keys are not sorted");
+        for (uint32_t i = 0; i < l.n; ++i) {
+            const uint64_t sz = (uint64_t)(l.key_off[i + 1] - l.key_off[i]) + (l.val_off[i + 1] - l.val_off[i]);
+            if (sz > longest) longest = sz > 0x7fffffffull ? 0x7fffffffu : (uint32_t)sz;
+        }
+        p.cap = longest + 80u;  // a sub-trie that is one leaf: key path + value + headers
+    }
+    auto work = [&](uint32_t d) {
+        const KeyList& l = lists[d];
+        Part& p = parts[d];
+        for (uint32_t x = d; x < 16; x += W)
+            if (p.first[x + 1] > p.first[x]) p.nibbles.push_back(x);
+        if (p.nibbles.empty()) return;
+        const uint32_t nt = (uint32_t)p.nibbles.size(), cap = p.cap;
+        p.roots.assign((size_t)nt * 32, 0);
+        p.enc.assign((size_t)nt * cap, 0);
+        p.len.assign(nt, 0);
+        // the nibble ranges a device owns are not adjacent in its list unless it owns all of them: one forest call
+        // per range -- or, when they tile the whole list, one call with a segment per range
+        bool tiles = p.first[p.nibbles[0]] == 0;
+        for (uint32_t t = 0; t + 1 < nt && tiles; ++t) tiles = p.first[p.nibbles[t] + 1] == p.first[p.nibbles[t + 1]];
+        tiles = tiles && p.first[p.nibbles[nt - 1] + 1] == l.n;
+        if (tiles) {
+            std::vector<uint32_t> seg;
+            for (uint32_t x : p.nibbles) seg.push_back(p.first[x]);
+            seg.push_back(l.n);
+            p.rc = phant_mpt_root_nodes(c->ctx[d], l.keys, l.key_off, l.vals, l.val_off, l.n, seg.data(), nt, p.roots.data(), p.enc.data(),
+                                        cap, p.len.data());
+        } else {
+            for (uint32_t t = 0; t < nt && p.rc == PHANT_OK; ++t) {
+                const uint32_t x = p.nibbles[t], lo = p.first[x], cnt = p.first[x + 1] - p.first[x];
+                const uint32_t seg[2] = {0u, cnt};
+                // (the entry point re-bases offsets that do not start at zero)
+                p.rc = phant_mpt_root_nodes(c->ctx[d], l.keys, l.key_off + lo, l.vals, l.val_off + lo, cnt, seg, 1, &p.roots[(size_t)t * 32],
+                                            &p.enc[(size_t)t * cap], cap, &p.len[t]);
+            }
+        }
+        if (p.rc != PHANT_OK) p.err = phant_last_error(c->ctx[d]);
+    };
+#ifndef PHANT_HOST_EMU
+    {
+        std::vector<std::thread> th;
+        for (uint32_t d = 1; d < W; ++d) th.emplace_back(work, d);
+        work(0);
+        for (std::thread& t : th) t.join();
+    }
+#else  // (the host emulation of the HIP runtime is single-threaded)
+    for (uint32_t d = 0; d < W; ++d) work(d);
+#endif
+    for (uint32_t d = 0; d < W; ++d)
+        if (parts[d].rc != PHANT_OK) return cfail(c, parts[d].rc, std::string(who) + ": device " + std::to_string(d) + ": " + parts[d].err);
+    // ---- the root branch from the sixteen child references ----
+    uint8_t refs[16][33];
+    uint32_t lens[16] = {0};
+    uint32_t filled = 0;
+    const uint8_t* only_root = nullptr;
+    std::vector<uint8_t> tmp;
+    for (uint32_t d = 0; d < W; ++d)
+        for (size_t t = 0; t < parts[d].nibbles.size(); ++t) {
+            const uint32_t x = parts[d].nibbles[t], ln = parts[d].len[t], cap = parts[d].cap;
+            if (ln == 0 || ln > cap) return cfail(c, PHANT_E_DEVICE, std::string(who) + ": sub-trie root node missing");
+            tmp.resize((size_t)cap + 16);
+            uint32_t out_len = 0, is_ref = 0;
+            const int32_t rc = phant_mpt_strip_first_nibble(&parts[d].enc[t * cap], ln, tmp.data(), (uint32_t)tmp.size(), &out_len, &is_ref);
+            if (rc != PHANT_OK) return cfail(c, rc, std::string(who) + ": strip_first_nibble");
+            if (is_ref || out_len < 32) {
+                if (out_len > 33) return cfail(c, PHANT_E_DEVICE, std::string(who) + ": child reference too long");
+                std::memcpy(refs[x], tmp.data(), out_len);
+                lens[x] = out_len;
+            } else {
+                const int32_t hrc = phant_keccak256(c->ctx[d], tmp.data(), out_len, refs[x]);
+                if (hrc != PHANT_OK) return cfail(c, hrc, std::string(who) + ": keccak256");
+                lens[x] = 32;
+            }
+            ++filled;
+            only_root = &parts[d].roots[t * 32];
+        }
+    if (filled == 0) return phant_mpt_root(c->ctx[0], nullptr, nullptr, nullptr, nullptr, 0, out);
+    if (filled == 1) {  // no branch at the top: that sub-trie's root is the root
+        std::memcpy(out, only_root, 32);
+        return PHANT_OK;
+    }
+    uint8_t node[3 + 16 * 33 + 1];
+    size_t body = 0;
+    uint8_t* b = node + 3;
+    for (uint32_t x = 0; x < 16; ++x) {
+        if (lens[x] == 0) {
+            b[body++] = 0x80;
+        } else if (lens[x] == 32) {
+            b[body++] = 0xa0;
+            std::memcpy(b + body, refs[x], 32);
+            body += 32;
+        } else {
+            std::memcpy(b + body, refs[x], lens[x]);  // an embedded child: its own RLP
+            body += lens[x];
+        }
+    }
+    b[body++] = 0x80;  // no value at the root (every key has at least one byte)
+    uint8_t* start;
+    if (body <= 55) {
+        start = node + 2;
+        start[0] = (uint8_t)(0xc0 + body);
+    } else if (body <= 255) {
+        start = node + 1;
+        start[0] = 0xf8;
+        start[1] = (uint8_t)body;
+    } else {
+        start = node;
+        start[0] = 0xf9;
+        start[1] = (uint8_t)(body >> 8);
+        start[2] = (uint8_t)body;
+    }
+    return phant_keccak256(c->ctx[0], start, (uint64_t)(b + body - start), out);
+}
+
 }  // namespace
 
 extern "C" {
@@ -390,61 +544,77 @@ int32_t phant_mpt_root_sharded(phant_comm* c, const uint8_t* keys, const uint32_
     if (!c || !out) return PHANT_E_INVALID_ARG;
     if (n == 0) return phant_mpt_root(c->ctx[0], nullptr, nullptr, nullptr, nullptr, 0, out);
     if (!keys || !key_off || !val_off) return cfail(c, PHANT_E_INVALID_ARG, "mpt_root_sharded: null argument");
-    // the sixteen top-nibble ranges of the (sorted) key list; order and key lengths are checked here because the
-    // ranges are cut on the host (within a range the device checks them, PHANT_E_UNSORTED)
-    uint32_t first[17];
-    uint32_t at = 0;
-    for (uint32_t x = 0; x < 16; ++x) {
-        first[x] = at;
-        while (at < n) {
-            if (key_off[at + 1] <= key_off[at]) return cfail(c, PHANT_E_UNSUPPORTED, "mpt_root_sharded: empty key (needs a root value)");
-            if ((uint32_t)(keys[key_off[at]] >> 4) != x) break;
-            ++at;
-        }
-    }
-    first[16] = at;
-    if (at != n) return cfail(c, PHANT_E_UNSORTED, "mpt_root_sharded: keys are not sorted");
     const uint32_t W = (uint32_t)c->ctx.size();
-    uint32_t longest = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t l = (uint64_t)(key_off[i + 1] - key_off[i]) + (val_off[i + 1] - val_off[i]);
-        longest = l > longest ? (uint32_t)(l > 0x7fffffffull ? 0x7fffffffull : l) : longest;
+    // every device gets the same list; it takes the nibble ranges it owns
+    std::vector<KeyList> lists(W, KeyList{keys, key_off, vals, val_off, n});
+    return sharded_root(c, lists, out, "mpt_root_sharded");
+}
+
+// StateDB.root() (the reference lacks it: src/blockchain/blockchain.zig:83-85; arguments of phant_state_root) over the
+// comm's devices.  The state trie is keyed by keccak256(address), so an account belongs to the device that owns the top
+// nibble of its HASHED address: the addresses are hashed once (device 0), the accounts dealt out, every device turns its
+// share into state-trie leaves (storage roots in one forest pass, account RLP: phant_state_trie_leaves) and hashes the
+// sub-tries of its nibbles; the root branch is formed on the host as for phant_mpt_root_sharded.
+int32_t phant_state_root_sharded(phant_comm* c, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
+                                 const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys,
+                                 const uint8_t* slot_vals, const uint32_t* slot_first, uint32_t n, uint8_t out[32]) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    if (n == 0) return phant_mpt_root(c->ctx[0], nullptr, nullptr, nullptr, nullptr, 0, out);
+    if (!addrs || !nonces || !balances || !code_off || !slot_first)
+        return cfail(c, PHANT_E_INVALID_ARG, "state_root_sharded: null argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (code_off[i + 1] < code_off[i] || slot_first[i + 1] < slot_first[i])
+            return cfail(c, PHANT_E_INVALID_ARG, "state_root_sharded: code_off / slot_first not monotone");
+    const uint32_t W = (uint32_t)c->ctx.size();
+    // ---- who owns which account ----
+    std::vector<uint8_t> ha((size_t)n * 32);
+    {
+        std::vector<uint64_t> off((size_t)n + 1);
+        for (uint32_t i = 0; i <= n; ++i) off[i] = 20ull * i;
+        const int32_t rc = phant_keccak256_batch(c->ctx[0], addrs, off.data(), n, ha.data());
+        if (rc != PHANT_OK) return cfail(c, rc, std::string("state_root_sharded: ") + phant_last_error(c->ctx[0]));
     }
-    const uint32_t cap = longest + 80u;  // a sub-trie that is one leaf: key path + value + headers
-    struct Part {
-        std::vector<uint32_t> nibbles;
-        std::vector<uint8_t> roots, enc;
-        std::vector<uint32_t> len;
+    struct Share {
+        std::vector<uint8_t> addrs, balances, code, slot_keys, slot_vals, keys, vals;
+        std::vector<uint64_t> nonces, code_off, val_off;
+        std::vector<uint32_t> slot_first, key_off;
         int32_t rc = PHANT_OK;
+        std::string err;
     };
-    std::vector<Part> parts(W);
+    std::vector<Share> sh(W);
+    for (Share& s : sh) {
+        s.code_off.push_back(0);
+        s.slot_first.push_back(0);
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        Share& s = sh[(uint32_t)(ha[(size_t)i * 32] >> 4) % W];
+        s.addrs.insert(s.addrs.end(), addrs + 20ull * i, addrs + 20ull * i + 20);
+        s.nonces.push_back(nonces[i]);
+        s.balances.insert(s.balances.end(), balances + 32ull * i, balances + 32ull * i + 32);
+        if (code_off[i + 1] > code_off[i]) s.code.insert(s.code.end(), code + code_off[i], code + code_off[i + 1]);
+        s.code_off.push_back(s.code.size());
+        for (uint32_t t = slot_first[i]; t < slot_first[i + 1]; ++t) {
+            s.slot_keys.insert(s.slot_keys.end(), slot_keys + 32ull * t, slot_keys + 32ull * t + 32);
+            s.slot_vals.insert(s.slot_vals.end(), slot_vals + 32ull * t, slot_vals + 32ull * t + 32);
+        }
+        s.slot_first.push_back((uint32_t)(s.slot_keys.size() / 32));
+    }
+    // ---- every device: its accounts -> state-trie leaves ----
     auto work = [&](uint32_t d) {
-        Part& p = parts[d];
-        // this device's nibble ranges are not adjacent in the caller's arrays (every W-th one): one forest call per range
-        // -- or, on a one-device comm, where they tile the whole list, one call with a segment per range
-        for (uint32_t x = d; x < 16; x += W)
-            if (first[x + 1] > first[x]) p.nibbles.push_back(x);
-        if (p.nibbles.empty()) return;
-        const uint32_t nt = (uint32_t)p.nibbles.size();
-        p.roots.assign((size_t)nt * 32, 0);
-        p.enc.assign((size_t)nt * cap, 0);
-        p.len.assign(nt, 0);
-        if (W == 1) {
-            std::vector<uint32_t> seg;
-            for (uint32_t x : p.nibbles) seg.push_back(first[x]);
-            seg.push_back(n);
-            // (with every nibble on one device the ranges tile [0, n): empty ranges are simply not listed)
-            p.rc = phant_mpt_root_nodes(c->ctx[d], keys, key_off, vals, val_off, n, seg.data(), nt, p.roots.data(), p.enc.data(), cap,
-                                        p.len.data());
-            return;
-        }
-        for (uint32_t t = 0; t < nt && p.rc == PHANT_OK; ++t) {
-            const uint32_t x = p.nibbles[t], lo = first[x], cnt = first[x + 1] - first[x];
-            const uint32_t seg[2] = {0u, cnt};
-            // key_off / val_off of a range are offsets into the caller's blobs: the entry point re-bases them itself
-            p.rc = phant_mpt_root_nodes(c->ctx[d], keys, key_off + lo, vals, val_off + lo, cnt, seg, 1, &p.roots[(size_t)t * 32],
-                                        &p.enc[(size_t)t * cap], cap, &p.len[t]);
-        }
+        Share& s = sh[d];
+        const uint32_t m = (uint32_t)s.nonces.size();
+        s.key_off.assign((size_t)m + 1, 0);
+        for (uint32_t i = 0; i <= m; ++i) s.key_off[i] = 32u * i;
+        s.val_off.assign((size_t)m + 1, 0);
+        if (m == 0) return;
+        s.keys.resize((size_t)m * 32);
+        s.vals.resize((size_t)m * 112);
+        const uint8_t one = 0;
+        s.rc = phant_state_trie_leaves(c->ctx[d], s.addrs.data(), s.nonces.data(), s.balances.data(), s.code.empty() ? &one : s.code.data(),
+                                       s.code_off.data(), s.slot_keys.empty() ? &one : s.slot_keys.data(),
+                                       s.slot_vals.empty() ? &one : s.slot_vals.data(), s.slot_first.data(), m, s.keys.data(),
+                                       s.vals.data(), s.vals.size(), s.val_off.data());
+        if (s.rc != PHANT_OK) s.err = phant_last_error(c->ctx[d]);
     };
 #ifndef PHANT_HOST_EMU
     {
@@ -453,71 +623,15 @@ int32_t phant_mpt_root_sharded(phant_comm* c, const uint8_t* keys, const uint32_
         work(0);
         for (std::thread& t : th) t.join();
     }
-#else  // (the host emulation of the HIP runtime is single-threaded)
+#else
     for (uint32_t d = 0; d < W; ++d) work(d);
 #endif
-    for (uint32_t d = 0; d < W; ++d)
-        if (parts[d].rc != PHANT_OK) return cfail(c, parts[d].rc, std::string("mpt_root_sharded: device ") + std::to_string(d) + ": " + phant_last_error(c->ctx[d]));
-    // ---- the root branch from the sixteen child references ----
-    uint8_t refs[16][33];
-    uint32_t lens[16] = {0};
-    uint32_t filled = 0;
-    const uint8_t* only_root = nullptr;
-    std::vector<uint8_t> tmp((size_t)cap + 16);
-    for (uint32_t d = 0; d < W; ++d)
-        for (size_t t = 0; t < parts[d].nibbles.size(); ++t) {
-            const uint32_t x = parts[d].nibbles[t], ln = parts[d].len[t];
-            if (ln == 0 || ln > cap) return cfail(c, PHANT_E_DEVICE, "mpt_root_sharded: sub-trie root node missing");
-            uint32_t out_len = 0, is_ref = 0;
-            const int32_t rc = phant_mpt_strip_first_nibble(&parts[d].enc[t * cap], ln, tmp.data(), (uint32_t)tmp.size(), &out_len, &is_ref);
-            if (rc != PHANT_OK) return cfail(c, rc, "mpt_root_sharded: strip_first_nibble");
-            if (is_ref || out_len < 32) {
-                if (out_len > 33) return cfail(c, PHANT_E_DEVICE, "mpt_root_sharded: child reference too long");
-                std::memcpy(refs[x], tmp.data(), out_len);
-                lens[x] = out_len;
-            } else {
-                const int32_t hrc = phant_keccak256(c->ctx[d], tmp.data(), out_len, refs[x]);
-                if (hrc != PHANT_OK) return cfail(c, hrc, "mpt_root_sharded: keccak256");
-                lens[x] = 32;
-            }
-            ++filled;
-            only_root = &parts[d].roots[t * 32];
-        }
-    if (filled == 1) {  // no branch at the top: that sub-trie's root is the root
-        std::memcpy(out, only_root, 32);
-        return PHANT_OK;
+    std::vector<KeyList> lists(W);
+    for (uint32_t d = 0; d < W; ++d) {
+        if (sh[d].rc != PHANT_OK) return cfail(c, sh[d].rc, "state_root_sharded: device " + std::to_string(d) + ": " + sh[d].err);
+        lists[d] = KeyList{sh[d].keys.data(), sh[d].key_off.data(), sh[d].vals.data(), sh[d].val_off.data(), (uint32_t)sh[d].nonces.size()};
     }
-    uint8_t node[3 + 16 * 33 + 1];
-    size_t body = 0;
-    uint8_t* b = node + 3;
-    for (uint32_t x = 0; x < 16; ++x) {
-        if (lens[x] == 0) {
-            b[body++] = 0x80;
-        } else if (lens[x] == 32) {
-            b[body++] = 0xa0;
-            std::memcpy(b + body, refs[x], 32);
-            body += 32;
-        } else {
-            std::memcpy(b + body, refs[x], lens[x]);  // an embedded child: its own RLP
-            body += lens[x];
-        }
-    }
-    b[body++] = 0x80;  // no value at the root (every key has at least one byte)
-    uint8_t* start;
-    if (body <= 55) {
-        start = node + 2;
-        start[0] = (uint8_t)(0xc0 + body);
-    } else if (body <= 255) {
-        start = node + 1;
-        start[0] = 0xf8;
-        start[1] = (uint8_t)body;
-    } else {
-        start = node;
-        start[0] = 0xf9;
-        start[1] = (uint8_t)(body >> 8);
-        start[2] = (uint8_t)body;
-    }
-    return phant_keccak256(c->ctx[0], start, (uint64_t)(b + body - start), out);
+    return sharded_root(c, lists, out, "state_root_sharded");
 }
 
 }  // extern "C"

@@ -23,7 +23,16 @@ class EmuBuildError(Exception):
     (callers skip on RuntimeError = no host compiler at all)."""
 
 def build(sanitize: bool = False) -> str:
-    """-> path of libphant_emu[_san].so (rebuilt when a source is newer)."""
+    """-> path of libphant_emu[_san].so (rebuilt when a source is newer).  One builder at a time: the two ranks of a
+    world-2 test are separate processes and may both find the library stale."""
+    import fcntl
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(sanitize)
+
+
+def _build(sanitize: bool) -> str:
     cxx = os.environ.get("PHANT_EMU_CXX", "g++")  # (e.g. ROCm's clang++: a second opinion on the same sources)
     if not shutil.which(cxx):
         raise RuntimeError("no " + cxx)

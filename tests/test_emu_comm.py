@@ -31,7 +31,7 @@ def comm(request):
 
 from tests.test_gpu_comm import (  # noqa: E402,F401
     body_sharded_matches_oracle_and_single_ctx, body_block_witness_per_root_verdict, body_rejects_inconsistent_index_arrays,
-    body_sharded_mptize_matches_the_oracle)
+    body_sharded_mptize_matches_the_oracle, body_sharded_state_root)
 
 
 def test_sharded_matches_oracle_and_single_ctx(comm, oracle):
@@ -40,6 +40,10 @@ def test_sharded_matches_oracle_and_single_ctx(comm, oracle):
 
 def test_block_witness_per_root_verdict(comm, oracle):
     body_block_witness_per_root_verdict(comm, oracle)
+
+
+def test_sharded_state_root(comm, oracle):
+    body_sharded_state_root(comm, oracle)
 
 
 def test_sharded_mptize(comm, oracle):

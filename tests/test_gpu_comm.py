@@ -87,6 +87,27 @@ def body_sharded_mptize_matches_the_oracle(comm, oracle):
         comm.mptize([b""] + keys, [b"v"] + vals)
 
 
+def body_sharded_state_root(comm, oracle):
+    """phant_state_root_sharded against the oracle and the reference's fixture state roots: accounts with and without
+    storage and code, dealt out by the top nibble of their hashed address."""
+    from tests import golden
+    rng = np.random.default_rng(31)
+    acc = []
+    for i in range(700):
+        st = {int(rng.integers(0, 2 ** 62)): int(rng.integers(0, 3)) * int(rng.integers(1, 2 ** 62)) for _ in range(int(rng.integers(0, 5)))}
+        acc.append(dict(addr=rng.integers(0, 256, 20, dtype=np.uint8).tobytes(), nonce=int(rng.integers(0, 1000)),
+                        balance=int(rng.integers(0, 2 ** 62)) ** 2,
+                        code=rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8).tobytes(), storage=st))
+    assert comm.state_root(acc) == oracle.state_root(acc)
+    assert comm.state_root(acc[:1]) == oracle.state_root(acc[:1])       # one account: no branch at the top
+    assert comm.state_root([]) == oracle.state_root([])
+    fx = golden.fixtures()
+    for c in fx["cases"][:10]:   # the reference's own state roots (src/tests/fixtures/shanghai)
+        assert comm.state_root(golden.accounts_of(c["pre"], fx["codes"])).hex() == c["genesis_state_root"], c["name"]
+        if "post" in c:
+            assert comm.state_root(golden.accounts_of(c["post"], fx["codes"])).hex() == c["post_state_root"], c["name"]
+
+
 def body_rejects_inconsistent_index_arrays(comm, oracle):
     from phant_amd import _lib as L
     rng = np.random.default_rng(44)
@@ -124,10 +145,16 @@ def test_one_device_comm_block_witness(comm1, oracle):
 
 
 @pytest.mark.gpu
+def test_one_device_comm_state_root(comm1, oracle):
+    body_sharded_state_root(comm1, oracle)
+
+
+@pytest.mark.gpu
 def test_one_device_comm_mptize(comm1, oracle):
     body_sharded_mptize_matches_the_oracle(comm1, oracle)
 
 
+@pytest.mark.gpu
 def test_rccl_is_found_and_a_one_rank_allreduce_runs(comm1):
     """What a 1-GPU box can say about the RCCL path: the library is found at run time and an all-reduce over a
     one-rank communicator leaves the counters as they are (phant_comm_allreduce_verdict on the comm's ctx stream)."""
