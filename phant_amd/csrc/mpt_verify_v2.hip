@@ -481,8 +481,8 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 // slots, finishes first, and the youngest ends up running its last permutations alone at single-wave speed (6.9
 // instead of 9.8 G perm/s).  With the ladder a wave that is behind outranks the ones ahead: they advance block by
 // block together and finish together.  Measured on BASELINE config 3 (profiles/r2_a/sweep_ladder.jsonl): the deep
-// tier alone 7 us shorter, a launch 0.2515 -> 0.2449 ms.  (The list kernel keeps one raised priority instead: its few
-// waves are the critical path.)
+// tier alone 7 us shorter, a launch 0.2515 -> 0.2449 ms.  The list kernel uses it as well (its other classes keep one
+// raised priority: few waves, on the critical path).
 template <bool LADDER>
 PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
     sponge_zero(s);
@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
     uint32_t bad;
     const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
     if (cls == LIST_B532) {
-        bad = hash_b532<false>(s, p);
+        bad = hash_b532<true>(s, p);  // (same-box A/B, three runs each: config 4 +1.8 %, one launch at a time -2 %)
     } else if (cls == 0u && __ballot(len != len0 || p + RATE > safe_end) == 0ull) {
         hash_short_uniform(s, p, len0);  // one length below the rate for the whole chunk: BASELINE's leaves
         bad = 1u;
