@@ -32,7 +32,7 @@ sequences in flight per GPU, each on its own ctx + HIP stream and each over a DI
 validator verifying consecutive witnesses; no step re-reads the bytes the previous step on its slot left in
 L2 / Infinity Cache): every step is still a full pass over a full batch; `single_stream` in the JSON line is
 the same number of passes strictly one after the other (alternating witnesses), and `roofline.achieved` always
-refers to ONE launch.  A timed "step" is repeated --inner times back to back (default 20) so that the timed
+refers to ONE launch.  A timed "step" is repeated --inner times back to back (default 30) so that the timed
 region is >= 100 ms; all per-step figures are per single pass.  The config-3 line also carries `strong`: the
 config-4 block witness split over the same N GPUs (strong scaling), measured right after.
 
@@ -91,7 +91,7 @@ def parse():
                          "in place); nodedup = every shipped node hashed (A/B); fused = one lane per proof (A/B)")
     ap.add_argument("--dedup-levels", type=int, default=None,
                     help="flat: trie levels deduplicated (default: chosen from the batch size)")
-    ap.add_argument("--inner", type=int, default=20,
+    ap.add_argument("--inner", type=int, default=30,
                     help="config3 / config4 / config2 / nodeset: back-to-back passes per timed step (timed region >= 100 ms)")
     ap.add_argument("--no-strong", action="store_true", help="config3: skip the config-4 strong-scaling object")
     ap.add_argument("--streams", type=int, default=4,
@@ -130,8 +130,16 @@ def cpu_baseline_config3(w, target_seconds):
     cnt = int(max(probe, min(n, rate * target_seconds)))
     st, dt = run(cnt)
     ok = bool((st == w.expected[:cnt].cpu().numpy()).all())
-    out = {"value": cnt / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-           "sample": f"first {cnt} of the {n} config-3 proofs, oracle/verify.c single-threaded, {dt:.1f} s",
+    passes = 1
+    if cnt == n:  # the whole batch is less CPU work than asked for: verify it again until the sample is long enough
+        while dt < target_seconds and passes < 16:
+            st2, dt2 = run(cnt)
+            ok = ok and bool((st2 == st).all())
+            dt += dt2
+            passes += 1
+    out = {"value": cnt * passes / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+           "sample": f"first {cnt} of the {n} config-3 proofs{' x %d passes' % passes if passes > 1 else ''}, "
+                     f"oracle/verify.c single-threaded, {dt:.1f} s",
            "host_cpus": os.cpu_count(), "statuses_match_gpu_expected": ok}
     # the same scalar code on all host cores, one slice of proofs per thread (ctypes releases the GIL);
     # phant itself is single-threaded, so this is the generous reading of "the CPU path"
