@@ -226,4 +226,12 @@ hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_
     return hipGetLastError();
 }
 
+// exclusive prefix sum of d[0 .. n) in place (one workgroup; n up to a few million).  With n + 1 entries and d[n] = 0 on entry,
+// d[n] is the total on exit.
+hipError_t launch_exclusive_scan_u32(uint32_t* d, uint32_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, d, n);
+    return hipGetLastError();
+}
+
 }  // namespace phant

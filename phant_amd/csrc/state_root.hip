@@ -5,11 +5,19 @@
 // Secure trie: account key keccak256(addr), value
 // rlp([nonce, balance, storageRoot, keccak256(code)]); storage key
 // keccak256(be32(slot)), value rlp(minimal-BE(value)); zero-valued slots do not
-// exist (src/state/statedb.zig:112-119).  All Keccak work (addresses, slots,
-// code, every trie node) runs on the GPU; one forest pass hashes every
-// account's storage trie at once, a second pass the account trie.  The hashed
-// keys are put in order on the GPU as well (radix_sort.hip); the host packs
-// the <= 110-byte account records.
+// exist (src/state/statedb.zig:112-119).
+//
+// Device-resident since round 2: the caller's arrays are copied to the GPU once and everything between them and the
+// root happens there -- the live slots are picked out (flag, prefix sum, compaction), their keys and the addresses
+// hashed, the hashed keys ordered (radix_sort.hip: per account for the slots, one run for the accounts), the leaves of
+// all storage tries written in that order (RLP of the minimal big-endian value), ONE forest pass over them
+// (trie_build.hip) for the storage roots, the account leaves rlp([nonce, balance, storageRoot, codeHash]) written in key
+// order, a second pass for the state trie.  The host reads back a handful of counters (how many live slots, how many
+// value bytes, "is the order decided": each a stream synchronisation) and, for the state root, 32 bytes.
+// Round 1 hashed on the GPU and did the rest on the host: five pageable round trips of digests and leaves, std::sort with
+// 32-byte memcmp, byte-wise packing -- 128 ms per 200 000 accounts x 5 slots against ~20 ms now (tools/bench_state.py).
+//
+// HBM-bound byte shuffling around the Keccak kernels; nothing here is GEMM-shaped.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -32,105 +40,323 @@ namespace {
         }                                                                     \
     } while (0)
 
-// keccak256 of n fixed-size records on the GPU, digests back to the host
-int32_t hash_fixed(Workspaces& ws, hipStream_t st, const uint8_t* host, uint32_t rec_len, uint32_t n,
-                   std::vector<uint8_t>& out, std::string& err) {
-    out.resize((size_t)n * 32);
-    if (!n) return PHANT_OK;
-    SR_TRY(ws.io.reset(DevArena::round((size_t)n * rec_len + 16) + DevArena::round((size_t)n * 32) + 512));
-    uint8_t* d_in = ws.io.take<uint8_t>((size_t)n * rec_len + 16);
-    uint8_t* d_out = ws.io.take<uint8_t>((size_t)n * 32);
-    SR_TRY(hipMemcpyAsync(d_in, host, (size_t)n * rec_len, hipMemcpyHostToDevice, st));
-    SR_TRY(launch_keccak256_fixed(d_in, rec_len, rec_len, n, d_out, st));
-    SR_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));
+inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
+
+// ------------------------------------------------------------------ kernels
+// bytes of the minimal big-endian form of a 32-byte value (0 for zero); v is 4-byte aligned
+__device__ __forceinline__ uint32_t be_len32(const uint8_t* v) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(v);
+    for (uint32_t i = 0; i < 8u; ++i) {
+        const uint32_t x = __builtin_bswap32(w[i]);  // most significant byte first
+        if (x) return 32u - 4u * i - (uint32_t)(__builtin_clz(x) >> 3);
+    }
+    return 0u;
+}
+// canonical RLP of a byte string of <= 32 bytes at `o`; returns its length
+__device__ __forceinline__ uint32_t put_rlp_short(uint8_t* o, const uint8_t* s, uint32_t len) {
+    if (len == 1u && s[0] < 0x80u) {
+        o[0] = s[0];
+        return 1u;
+    }
+    o[0] = (uint8_t)(0x80u + len);
+    for (uint32_t i = 0; i < len; ++i) o[1u + i] = s[i];
+    return 1u + len;
+}
+__device__ __forceinline__ uint32_t rlp_short_len(const uint8_t* s, uint32_t len) { return (len == 1u && s[0] < 0x80u) ? 1u : 1u + len; }
+
+// live[s] = 1 iff slot s holds a non-zero value (statedb.zig:112-119: zero = absent); live[m] = 0 (the scan's total lands there)
+__global__ void __launch_bounds__(256) slot_live_kernel(const uint8_t* __restrict__ slot_vals, uint32_t m, uint32_t* __restrict__ live) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s > m) return;
+    live[s] = s < m ? (be_len32(slot_vals + 32ull * s) != 0u) : 0u;
+}
+
+// pos = exclusive scan of live: live slot s becomes storage leaf pos[s] (before ordering): its key, where it came from, whose it is
+__global__ void __launch_bounds__(256) slot_compact_kernel(const uint32_t* __restrict__ pos, const uint8_t* __restrict__ slot_keys,
+                                                           const uint32_t* __restrict__ slot_first, uint32_t n_acc, uint32_t m,
+                                                           uint8_t* __restrict__ live_keys, uint32_t* __restrict__ live_src,
+                                                           uint32_t* __restrict__ seg_of) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= m || pos[s + 1] == pos[s]) return;
+    const uint32_t j = pos[s];
+    const uint4* k = reinterpret_cast<const uint4*>(slot_keys + 32ull * s);
+    uint4* o = reinterpret_cast<uint4*>(live_keys + 32ull * j);
+    o[0] = k[0];
+    o[1] = k[1];
+    live_src[j] = s;
+    // the account a with slot_first[a] <= s < slot_first[a + 1]: the last a whose first slot is not behind s
+    uint32_t lo = 0, hi = n_acc;  // invariant: slot_first[lo] <= s, answer in [lo, hi)
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (slot_first[mid] <= s) lo = mid;
+        else hi = mid;
+    }
+    seg_of[j] = lo;
+}
+
+// storage trie a owns leaves [acc_first[a], acc_first[a + 1])
+__global__ void __launch_bounds__(256) acc_first_kernel(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ slot_first, uint32_t n_acc,
+                                                        uint32_t* __restrict__ acc_first) {
+    const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+    if (a <= n_acc) acc_first[a] = pos[slot_first[a]];
+}
+
+// leaf j of the ordered storage leaves: length of rlp(minimal big-endian value); len[L] = 0
+__global__ void __launch_bounds__(256) slot_leaf_len_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ live_src,
+                                                            const uint8_t* __restrict__ slot_vals, uint32_t L, uint32_t* __restrict__ len) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j > L) return;
+    uint32_t l = 0;
+    if (j < L) {
+        const uint8_t* v = slot_vals + 32ull * live_src[order[j]];
+        const uint32_t vl = be_len32(v);
+        l = rlp_short_len(v + (32u - vl), vl);
+    }
+    len[j] = l;
+}
+
+__global__ void __launch_bounds__(256) slot_leaf_write_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ live_src,
+                                                              const uint8_t* __restrict__ slot_vals, const uint8_t* __restrict__ hk,
+                                                              const uint32_t* __restrict__ off, uint32_t L, uint8_t* __restrict__ skeys,
+                                                              uint32_t* __restrict__ skoff, uint8_t* __restrict__ svals,
+                                                              uint64_t* __restrict__ svoff) {
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j > L) return;
+    skoff[j] = 32u * j;
+    svoff[j] = off[j];
+    if (j == L) return;
+    const uint32_t src = order[j];
+    const uint4* k = reinterpret_cast<const uint4*>(hk + 32ull * src);
+    uint4* o = reinterpret_cast<uint4*>(skeys + 32ull * j);
+    o[0] = k[0];
+    o[1] = k[1];
+    const uint8_t* v = slot_vals + 32ull * live_src[src];
+    const uint32_t vl = be_len32(v);
+    put_rlp_short(svals + off[j], v + (32u - vl), vl);
+}
+
+// minimal big-endian bytes of a u64 (0 bytes for zero) into b[8]; returns the count
+__device__ __forceinline__ uint32_t be_u64(uint64_t x, uint8_t (&b)[8]) {
+    uint32_t n = 0;
+    for (int sh = 56; sh >= 0; sh -= 8) {
+        const uint8_t t = (uint8_t)(x >> sh);
+        if (n || t) b[n++] = t;
+    }
+    return n;
+}
+
+// account leaf i (key order): length of rlp([nonce, balance, storageRoot, codeHash]); len[n] = 0
+__global__ void __launch_bounds__(256) account_len_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ nonces,
+                                                          const uint8_t* __restrict__ balances, uint32_t n, uint32_t* __restrict__ len) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i > n) return;
+    uint32_t l = 0;
+    if (i < n) {
+        const uint32_t a = order[i];
+        uint8_t nb[8];
+        const uint32_t nl = be_u64(nonces[a], nb);
+        const uint8_t* bv = balances + 32ull * a;
+        const uint32_t bl = be_len32(bv);
+        const uint32_t payload = rlp_short_len(nb, nl) + rlp_short_len(bv + (32u - bl), bl) + 33u + 33u;
+        l = payload <= 55u ? 1u + payload : 2u + payload;  // (<= 108 bytes: at most one length byte)
+    }
+    len[i] = l;
+}
+
+__global__ void __launch_bounds__(256) account_write_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ nonces,
+                                                            const uint8_t* __restrict__ balances, const uint8_t* __restrict__ sroots,
+                                                            const uint8_t* __restrict__ hc, const uint8_t* __restrict__ ha,
+                                                            const uint32_t* __restrict__ off, uint32_t n, uint8_t* __restrict__ akeys,
+                                                            uint32_t* __restrict__ akoff, uint8_t* __restrict__ avals,
+                                                            uint64_t* __restrict__ avoff) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i > n) return;
+    akoff[i] = 32u * i;
+    avoff[i] = off[i];
+    if (i == n) return;
+    const uint32_t a = order[i];
+    const uint4* k = reinterpret_cast<const uint4*>(ha + 32ull * a);
+    uint4* ko = reinterpret_cast<uint4*>(akeys + 32ull * i);
+    ko[0] = k[0];
+    ko[1] = k[1];
+    uint8_t nb[8];
+    const uint32_t nl = be_u64(nonces[a], nb);
+    const uint8_t* bv = balances + 32ull * a;
+    const uint32_t bl = be_len32(bv);
+    const uint32_t payload = rlp_short_len(nb, nl) + rlp_short_len(bv + (32u - bl), bl) + 33u + 33u;
+    uint8_t* o = avals + off[i];
+    if (payload <= 55u) {
+        *o++ = (uint8_t)(0xc0u + payload);
+    } else {
+        *o++ = 0xf8;
+        *o++ = (uint8_t)payload;
+    }
+    o += put_rlp_short(o, nb, nl);
+    o += put_rlp_short(o, bv + (32u - bl), bl);
+    o += put_rlp_short(o, sroots + 32ull * a, 32u);
+    put_rlp_short(o, hc + 32ull * a, 32u);
+}
+
+// ------------------------------------------------------------------ host side
+// the permutation radix_sort.hip left undecided (64-bit prefixes tie / keys repeat), made on the host instead
+int32_t order_on_host(hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t* d_order, std::string& err) {
+    if (std::getenv("PHANT_SORT_NO_FALLBACK")) {  // tests: prove which path ordered the batch
+        err = "device sort undecided (64-bit key prefixes tie or keys repeat)";
+        return PHANT_E_UNSUPPORTED;
+    }
+    std::vector<uint8_t> dg((size_t)n * 32);
+    std::vector<uint32_t> seg(d_seg_of ? n : 0), order(n);
+    SR_TRY(hipMemcpyAsync(dg.data(), d_digests, dg.size(), hipMemcpyDeviceToHost, st));
+    if (d_seg_of) SR_TRY(hipMemcpyAsync(seg.data(), d_seg_of, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     SR_TRY(hipStreamSynchronize(st));
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        if (d_seg_of && seg[x] != seg[y]) return seg[x] < seg[y];
+        return std::memcmp(&dg[(size_t)x * 32], &dg[(size_t)y * 32], 32) < 0;
+    });
+    SR_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    SR_TRY(hipStreamSynchronize(st));  // (`order` goes out of scope)
     return PHANT_OK;
 }
 
-// keccak256 of n fixed-size records and the order of the digests, both on the GPU: order[k] = the record whose digest is
-// the k-th smallest -- within its segment, segments ascending, when seg_of (host, n entries < n_seg, or null) is given.
-// Digests and order come back to the host.  If the device sort reports that its 64-bit keys did not decide the order
-// (radix_sort.hip), the batch is ordered here instead.
-int32_t hash_fixed_ordered(Workspaces& ws, hipStream_t st, const uint8_t* host, uint32_t rec_len, uint32_t n,
-                           const uint32_t* seg_of, uint32_t n_seg, std::vector<uint8_t>& digests,
-                           std::vector<uint32_t>& order, std::string& err) {
-    digests.resize((size_t)n * 32);
-    order.resize(n);
-    if (!n) return PHANT_OK;
+// digests (device) -> their order in device memory; the device sort, or the host's if that one reports ties
+int32_t order_digests(hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* d_sort_ws,
+                      uint32_t** d_order, std::string& err) {
     uint32_t prefix_bits = 64;  // tests shrink it to reach the host fallback
     if (const char* t = std::getenv("PHANT_SORT_PREFIX_BITS")) prefix_bits = (uint32_t)std::strtoul(t, nullptr, 10);
-    SR_TRY(ws.io.reset(DevArena::round((size_t)n * rec_len + 16) + DevArena::round((size_t)n * 32) +
-                       DevArena::round((size_t)n * 4) + DevArena::round(order_workspace_bytes(n)) + 1024));
-    uint8_t* d_in = ws.io.take<uint8_t>((size_t)n * rec_len + 16);
-    uint8_t* d_out = ws.io.take<uint8_t>((size_t)n * 32);
-    uint32_t* d_seg = seg_of ? ws.io.take<uint32_t>(n) : nullptr;
-    uint8_t* d_sort = ws.io.take<uint8_t>(order_workspace_bytes(n));
-    SR_TRY(hipMemcpyAsync(d_in, host, (size_t)n * rec_len, hipMemcpyHostToDevice, st));
-    if (seg_of) SR_TRY(hipMemcpyAsync(d_seg, seg_of, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    SR_TRY(launch_keccak256_fixed(d_in, rec_len, rec_len, n, d_out, st));
-    uint32_t *d_order = nullptr, *d_flag = nullptr;
-    SR_TRY(launch_order_digests(d_out, d_seg, n, n_seg, d_sort, &d_order, &d_flag, prefix_bits, st));
+    uint32_t* d_flag = nullptr;
+    SR_TRY(launch_order_digests(d_digests, d_seg_of, n, n_seg, d_sort_ws, d_order, &d_flag, prefix_bits, st));
     uint32_t flag = 0;
-    SR_TRY(hipMemcpyAsync(digests.data(), d_out, digests.size(), hipMemcpyDeviceToHost, st));
-    SR_TRY(hipMemcpyAsync(order.data(), d_order, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     SR_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
     SR_TRY(hipStreamSynchronize(st));
-    if (flag) {
-        if (std::getenv("PHANT_SORT_NO_FALLBACK")) {  // tests: prove which path ordered the batch
-            err = "device sort undecided (64-bit key prefixes tie or keys repeat)";
-            return PHANT_E_UNSUPPORTED;
-        }
-        std::iota(order.begin(), order.end(), 0u);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            if (seg_of && seg_of[x] != seg_of[y]) return seg_of[x] < seg_of[y];
-            return std::memcmp(&digests[(size_t)x * 32], &digests[(size_t)y * 32], 32) < 0;
-        });
-    }
-    return PHANT_OK;
+    return flag ? order_on_host(st, d_digests, d_seg_of, n, *d_order, err) : PHANT_OK;
 }
 
-int32_t hash_var(Workspaces& ws, hipStream_t st, const uint8_t* blob, const uint64_t* off, uint32_t n,
-                 std::vector<uint8_t>& out, std::string& err) {
-    out.resize((size_t)n * 32);
-    if (!n) return PHANT_OK;
-    const uint64_t lo = off[0], len = off[n] - off[0];
-    std::vector<uint64_t> rel((size_t)n + 1);
-    for (uint32_t i = 0; i <= n; ++i) {
-        if (i && off[i] < off[i - 1]) {
+// the state trie's leaves in device memory (inside ws.io: valid until the next call that stages something there)
+struct DevLeaves {
+    uint8_t* keys = nullptr;      // n x 32, ascending
+    uint32_t* key_off = nullptr;  // n + 1
+    uint8_t* vals = nullptr;
+    uint64_t* val_off = nullptr;  // n + 1
+    uint64_t val_bytes = 0;
+    uint32_t* seg = nullptr;      // {0, n}: the one trie's segment table
+    uint8_t* root = nullptr;      // 32 bytes for the caller's forest pass
+};
+
+int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
+                         const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys, const uint8_t* slot_vals,
+                         const uint32_t* slot_first, uint32_t n, DevLeaves& out, std::string& err) {
+    for (uint32_t a = 0; a < n; ++a) {
+        if (slot_first[a + 1] < slot_first[a]) {
+            err = "slot_first not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+        if (code_off[a + 1] < code_off[a]) {
             err = "code_off not monotone";
             return PHANT_E_INVALID_ARG;
         }
-        rel[i] = off[i] - lo;
     }
-    SR_TRY(ws.io.reset(DevArena::round((size_t)len + 16) + DevArena::round(rel.size() * 8) +
-                       DevArena::round((size_t)n * 32) + 1024));
-    uint8_t* d_in = ws.io.take<uint8_t>((size_t)len + 16);
-    uint64_t* d_off = ws.io.take<uint64_t>(rel.size());
-    uint8_t* d_out = ws.io.take<uint8_t>((size_t)n * 32);
-    if (len) SR_TRY(hipMemcpyAsync(d_in, blob + lo, (size_t)len, hipMemcpyHostToDevice, st));
-    SR_TRY(hipMemcpyAsync(d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, st));
-    SR_TRY(launch_keccak256_var(d_in, d_off, n, d_out, st));
-    SR_TRY(hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, st));
-    SR_TRY(hipStreamSynchronize(st));
+    const uint32_t m = slot_first[n] - slot_first[0];
+    const uint64_t code_bytes = code_off[n] - code_off[0];
+    const size_t n1 = (size_t)n + 1, m1 = (size_t)m + 1;
+    auto R = [](size_t b) { return DevArena::round(b); };
+    const size_t sort_ws = order_workspace_bytes(m > n ? m : n);
+    SR_TRY(ws.io.reset(R(20 * (size_t)n + 16) + R(8 * (size_t)n) + R(32 * (size_t)n) + R(code_bytes + 16) + R(8 * n1) + 2 * R(32 * (size_t)m + 16) +
+                       2 * R(4 * n1) + R(4 * m1) + R(32 * (size_t)m + 16) + 2 * R(4 * (size_t)m + 4) + R(32 * (size_t)m + 16) + R(sort_ws) +
+                       R(4 * m1) + R(32 * (size_t)m + 16) + R(4 * m1) + R(33 * (size_t)m + 16) + R(8 * m1) + R(32 * (size_t)n) +
+                       2 * R(32 * (size_t)n) + R(4 * n1) + R(32 * (size_t)n + 16) + R(4 * n1) + R(112 * (size_t)n + 16) + R(8 * n1) + 8192));
+    // ---- the caller's arrays, once ----
+    uint8_t* d_addrs = ws.io.take<uint8_t>(20 * (size_t)n + 16);
+    uint64_t* d_nonces = ws.io.take<uint64_t>(n);
+    uint8_t* d_bal = ws.io.take<uint8_t>(32 * (size_t)n);
+    uint8_t* d_code = ws.io.take<uint8_t>(code_bytes + 16);
+    uint64_t* d_code_off = ws.io.take<uint64_t>(n1);
+    uint8_t* d_skeys_in = ws.io.take<uint8_t>(32 * (size_t)m + 16);
+    uint8_t* d_svals_in = ws.io.take<uint8_t>(32 * (size_t)m + 16);
+    uint32_t* d_slot_first = ws.io.take<uint32_t>(n1);
+    SR_TRY(hipMemcpyAsync(d_addrs, addrs, 20 * (size_t)n, hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_nonces, nonces, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_bal, balances, 32 * (size_t)n, hipMemcpyHostToDevice, st));
+    if (code_bytes) SR_TRY(hipMemcpyAsync(d_code, code + code_off[0], code_bytes, hipMemcpyHostToDevice, st));
+    std::vector<uint64_t> rel_code(n1);
+    std::vector<uint32_t> rel_slot(n1);
+    for (size_t i = 0; i < n1; ++i) {
+        rel_code[i] = code_off[i] - code_off[0];
+        rel_slot[i] = slot_first[i] - slot_first[0];
+    }
+    SR_TRY(hipMemcpyAsync(d_code_off, rel_code.data(), 8 * n1, hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_slot_first, rel_slot.data(), 4 * n1, hipMemcpyHostToDevice, st));
+    if (m) {
+        SR_TRY(hipMemcpyAsync(d_skeys_in, slot_keys + 32ull * slot_first[0], 32 * (size_t)m, hipMemcpyHostToDevice, st));
+        SR_TRY(hipMemcpyAsync(d_svals_in, slot_vals + 32ull * slot_first[0], 32 * (size_t)m, hipMemcpyHostToDevice, st));
+    }
+
+    // ---- storage: live slots -> hashed keys -> per-account order -> leaves -> one forest pass ----
+    uint32_t* d_acc_first = ws.io.take<uint32_t>(n1);
+    uint32_t* d_pos = ws.io.take<uint32_t>(m1);
+    uint8_t* d_live_keys = ws.io.take<uint8_t>(32 * (size_t)m + 16);
+    uint32_t* d_live_src = ws.io.take<uint32_t>((size_t)m + 1);
+    uint32_t* d_seg_of = ws.io.take<uint32_t>((size_t)m + 1);
+    uint8_t* d_hk = ws.io.take<uint8_t>(32 * (size_t)m + 16);
+    uint8_t* d_sort = ws.io.take<uint8_t>(sort_ws);
+    uint32_t* d_len = ws.io.take<uint32_t>(m1);
+    uint8_t* d_lkeys = ws.io.take<uint8_t>(32 * (size_t)m + 16);
+    uint32_t* d_lkoff = ws.io.take<uint32_t>(m1);
+    uint8_t* d_lvals = ws.io.take<uint8_t>(33 * (size_t)m + 16);
+    uint64_t* d_lvoff = ws.io.take<uint64_t>(m1);
+    uint8_t* d_sroots = ws.io.take<uint8_t>(32 * (size_t)n);
+    uint32_t L = 0;
+    hipLaunchKernelGGL(slot_live_kernel, dim3(blocks(m1)), dim3(256), 0, st, d_svals_in, m, d_pos);
+    SR_TRY(launch_exclusive_scan_u32(d_pos, m + 1u, st));
+    SR_TRY(hipMemcpyAsync(&L, d_pos + m, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(acc_first_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_pos, d_slot_first, n, d_acc_first);
+    if (m) hipLaunchKernelGGL(slot_compact_kernel, dim3(blocks(m)), dim3(256), 0, st, d_pos, d_skeys_in, d_slot_first, n, m, d_live_keys, d_live_src, d_seg_of);
+    SR_TRY(hipStreamSynchronize(st));  // L
+    uint64_t leaf_bytes = 0;
+    if (L) {
+        SR_TRY(launch_keccak256_fixed(d_live_keys, 32, 32, L, d_hk, st));
+        uint32_t* d_order = nullptr;
+        const int32_t rc = order_digests(st, d_hk, d_seg_of, L, n, d_sort, &d_order, err);
+        if (rc) return rc;
+        hipLaunchKernelGGL(slot_leaf_len_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, L, d_len);
+        SR_TRY(launch_exclusive_scan_u32(d_len, L + 1u, st));
+        uint32_t vb = 0;
+        SR_TRY(hipMemcpyAsync(&vb, d_len + L, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(slot_leaf_write_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, d_hk, d_len, L,
+                           d_lkeys, d_lkoff, d_lvals, d_lvoff);
+        SR_TRY(hipStreamSynchronize(st));  // vb
+        leaf_bytes = vb;
+    }
+    int32_t rc = trie_forest_dev(ws, st, d_lkeys, d_lkoff, 32ull * L, d_lvals, d_lvoff, leaf_bytes, L, d_acc_first, n, d_sroots, err);
+    if (rc) return rc;
+
+    // ---- accounts: hashed addresses in order, code hashes, leaves ----
+    uint8_t* d_ha = ws.io.take<uint8_t>(32 * (size_t)n);
+    uint8_t* d_hc = ws.io.take<uint8_t>(32 * (size_t)n);
+    uint32_t* d_alen = ws.io.take<uint32_t>(n1);
+    out.keys = ws.io.take<uint8_t>(32 * (size_t)n + 16);
+    out.key_off = ws.io.take<uint32_t>(n1);
+    out.vals = ws.io.take<uint8_t>(112 * (size_t)n + 16);
+    out.val_off = ws.io.take<uint64_t>(n1);
+    out.seg = ws.io.take<uint32_t>(2);
+    out.root = ws.io.take<uint8_t>(32);
+    SR_TRY(launch_keccak256_fixed(d_addrs, 20, 20, n, d_ha, st));
+    SR_TRY(launch_keccak256_var(d_code, d_code_off, n, d_hc, st));
+    uint32_t* d_aorder = nullptr;
+    rc = order_digests(st, d_ha, nullptr, n, 1, d_sort, &d_aorder, err);
+    if (rc) return rc;
+    hipLaunchKernelGGL(account_len_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_aorder, d_nonces, d_bal, n, d_alen);
+    SR_TRY(launch_exclusive_scan_u32(d_alen, n + 1u, st));
+    uint32_t avb = 0;
+    SR_TRY(hipMemcpyAsync(&avb, d_alen + n, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(account_write_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_aorder, d_nonces, d_bal, d_sroots, d_hc, d_ha, d_alen, n, out.keys,
+                       out.key_off, out.vals, out.val_off);
+    const uint32_t seg[2] = {0u, n};
+    SR_TRY(hipMemcpyAsync(out.seg, seg, sizeof seg, hipMemcpyHostToDevice, st));
+    SR_TRY(hipStreamSynchronize(st));  // avb, and `seg` / the rel_* vectors may go
+    out.val_bytes = avb;
+    SR_TRY(hipGetLastError());
     return PHANT_OK;
-}
-
-// canonical RLP of a byte string of <= 32 bytes (row a10) into a buffer the caller sized (<= 33 bytes: no long form); returns the end
-uint8_t* put_rlp_short(uint8_t* o, const uint8_t* s, size_t len) {
-    if (len == 1 && s[0] < 0x80) {
-        *o++ = s[0];
-        return o;
-    }
-    *o++ = (uint8_t)(0x80 + len);
-    std::memcpy(o, s, len);
-    return o + len;
-}
-
-size_t strip32(const uint8_t* v, const uint8_t** out) {
-    size_t z = 0;
-    while (z < 32 && v[z] == 0) ++z;
-    *out = v + z;
-    return 32 - z;
 }
 
 }  // namespace
@@ -146,94 +372,15 @@ int32_t state_leaves_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, 
     avals.clear();
     avoff.assign((size_t)n + 1, 0);
     if (n == 0) return PHANT_OK;
-    for (uint32_t a = 0; a < n; ++a)
-        if (slot_first[a + 1] < slot_first[a]) {
-            err = "slot_first not monotone";
-            return PHANT_E_INVALID_ARG;
-        }
-    // ---- storage: live (non-zero) slots, hashed keys, per-account order ----
-    std::vector<uint32_t> live;       // slot indices with non-zero value
-    std::vector<uint32_t> acc_first(n + 1, 0);
-    for (uint32_t a = 0; a < n; ++a) {
-        for (uint32_t s = slot_first[a]; s < slot_first[a + 1]; ++s) {
-            const uint8_t* v;
-            if (strip32(slot_vals + 32ull * s, &v)) live.push_back(s);
-        }
-        acc_first[a + 1] = (uint32_t)live.size();
-    }
-    const uint32_t m = (uint32_t)live.size();
-    std::vector<uint8_t> live_keys((size_t)m * 32), hk;
-    for (uint32_t j = 0; j < m; ++j) std::memcpy(&live_keys[(size_t)j * 32], slot_keys + 32ull * live[j], 32);
-    std::vector<uint32_t> seg_of(m), perm;
-    for (uint32_t a = 0; a < n; ++a)
-        for (uint32_t j = acc_first[a]; j < acc_first[a + 1]; ++j) seg_of[j] = a;
-    // hashed slot keys, ordered per account (the live slots are grouped by account already: a stable regrouping)
-    int32_t rc = hash_fixed_ordered(ws, st, live_keys.data(), 32, m, seg_of.data(), n, hk, perm, err);
+    DevLeaves l;
+    const int32_t rc = state_leaves_dev(ws, st, addrs, nonces, balances, code, code_off, slot_keys, slot_vals, slot_first, n, l, err);
     if (rc) return rc;
-    // the leaves of all storage tries in that order: 32-byte hashed keys, values rlp(minimal big-endian), <= 33 bytes
-    std::vector<uint8_t> skeys((size_t)m * 32), svals((size_t)m * 33);
-    std::vector<uint32_t> skoff(m + 1, 0);
-    std::vector<uint64_t> svoff(m + 1, 0);
-    {
-        uint8_t* o = svals.data();
-        for (uint32_t j = 0; j < m; ++j) {
-            const uint32_t src = perm[j];
-            std::memcpy(&skeys[(size_t)j * 32], &hk[(size_t)src * 32], 32);
-            const uint8_t* v;
-            const size_t vl = strip32(slot_vals + 32ull * live[src], &v);
-            o = put_rlp_short(o, v, vl);
-            skoff[j + 1] = 32 * (j + 1);
-            svoff[j + 1] = (uint64_t)(o - svals.data());
-        }
-    }
-    std::vector<uint8_t> sroots((size_t)n * 32);
-    rc = trie_forest_host(ws, st, skeys.data(), skoff.data(), svals.data(), svoff.data(), m, acc_first.data(), n,
-                          sroots.data(), err);
-    if (rc) return rc;
-
-    // ---- accounts ----
-    std::vector<uint8_t> ha, hc;
-    std::vector<uint32_t> ord;
-    rc = hash_fixed_ordered(ws, st, addrs, 20, n, nullptr, 1, ha, ord, err);
-    if (rc) return rc;
-    rc = hash_var(ws, st, code, code_off, n, hc, err);
-    if (rc) return rc;
-    // account leaves in key order: rlp([nonce, balance, storageRoot, codeHash]) -- payload <= 9 + 33 + 33 + 33 = 108
-    // bytes, so the list header is one byte (<= 55) or f8 + one length byte; written in place, sized for the worst case
     akeys.resize((size_t)n * 32);
-    avals.resize((size_t)n * 110);
-    {
-        uint8_t* o = avals.data();
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t a = ord[i];
-            std::memcpy(&akeys[(size_t)i * 32], &ha[(size_t)a * 32], 32);
-            uint8_t body[108];
-            uint8_t* q = body;
-            uint8_t nb[8];
-            size_t nn = 0;
-            for (int sh = 56; sh >= 0; sh -= 8) {
-                const uint8_t bt = (uint8_t)(nonces[a] >> sh);
-                if (nn || bt) nb[nn++] = bt;
-            }
-            q = put_rlp_short(q, nb, nn);
-            const uint8_t* bv;
-            const size_t bl = strip32(balances + 32ull * a, &bv);
-            q = put_rlp_short(q, bv, bl);
-            q = put_rlp_short(q, &sroots[(size_t)a * 32], 32);
-            q = put_rlp_short(q, &hc[(size_t)a * 32], 32);
-            const size_t plen = (size_t)(q - body);
-            if (plen <= 55) {
-                *o++ = (uint8_t)(0xc0 + plen);
-            } else {
-                *o++ = 0xf8;
-                *o++ = (uint8_t)plen;
-            }
-            std::memcpy(o, body, plen);
-            o += plen;
-            avoff[i + 1] = (uint64_t)(o - avals.data());
-        }
-        avals.resize((size_t)(o - avals.data()));
-    }
+    avals.resize(l.val_bytes);
+    SR_TRY(hipMemcpyAsync(akeys.data(), l.keys, akeys.size(), hipMemcpyDeviceToHost, st));
+    if (l.val_bytes) SR_TRY(hipMemcpyAsync(avals.data(), l.vals, l.val_bytes, hipMemcpyDeviceToHost, st));
+    SR_TRY(hipMemcpyAsync(avoff.data(), l.val_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
+    SR_TRY(hipStreamSynchronize(st));
     return PHANT_OK;
 }
 
@@ -242,14 +389,14 @@ int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, co
                         const uint8_t* slot_keys, const uint8_t* slot_vals,
                         const uint32_t* slot_first, uint32_t n, uint8_t out[32], std::string& err) {
     if (n == 0) return trie_root_host(ws, st, nullptr, nullptr, nullptr, nullptr, 0, out, err);
-    std::vector<uint8_t> akeys, avals;
-    std::vector<uint64_t> avoff;
-    const int32_t rc = state_leaves_host(ws, st, addrs, nonces, balances, code, code_off, slot_keys, slot_vals,
-                                         slot_first, n, akeys, avals, avoff, err);
+    DevLeaves l;
+    int32_t rc = state_leaves_dev(ws, st, addrs, nonces, balances, code, code_off, slot_keys, slot_vals, slot_first, n, l, err);
     if (rc) return rc;
-    std::vector<uint32_t> akoff((size_t)n + 1, 0);
-    for (uint32_t i = 0; i < n; ++i) akoff[i + 1] = 32 * (i + 1);
-    return trie_root_host(ws, st, akeys.data(), akoff.data(), avals.data(), avoff.data(), n, out, err);
+    rc = trie_forest_dev(ws, st, l.keys, l.key_off, 32ull * n, l.vals, l.val_off, l.val_bytes, n, l.seg, 1, l.root, err);
+    if (rc) return rc;
+    SR_TRY(hipMemcpyAsync(out, l.root, 32, hipMemcpyDeviceToHost, st));
+    SR_TRY(hipStreamSynchronize(st));
+    return PHANT_OK;
 }
 
 }  // namespace phant

@@ -23,6 +23,11 @@ int32_t trie_root_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, con
                       const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n, uint8_t* d_root,
                       std::string& err);
 
+// the forest pass over device-resident arrays (segment table and roots in device memory too); t1 / t2 arenas only
+int32_t trie_forest_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
+                        const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n,
+                        const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_roots, std::string& err);
+
 // A forest of independent tries in one pass: trie t owns keys
 // [seg_first[t], seg_first[t+1]); roots_out = n_tries x 32 bytes.
 int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,

@@ -817,6 +817,16 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
     return PHANT_OK;
 }
 
+// The forest pass over device-resident arrays for callers that own the io arena themselves (state_root.hip): d_seg_first
+// (n_tries + 1 entries) and d_roots (n_tries x 32) are device memory as well.  Uses the t1 / t2 arenas only.
+int32_t trie_forest_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
+                        const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n,
+                        const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_roots, std::string& err) {
+    const int32_t rc = forest_device(ws, st, d_keys, d_key_off, d_vals, d_val_off, n, key_bytes, val_bytes, d_seg_first, n_tries, d_roots, err);
+    if (rc) (void)hipStreamSynchronize(st);
+    return rc;
+}
+
 int32_t trie_root_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
                       const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n, uint8_t* d_root,
                       std::string& err) {
