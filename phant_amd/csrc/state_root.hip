@@ -257,6 +257,10 @@ int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, c
         }
     }
     const uint32_t m = slot_first[n] - slot_first[0];
+    if ((uint64_t)n * 112u > 0xffffffffull || (uint64_t)m * 33u > 0xffffffffull) {  // (leaf offsets are scanned as 32-bit counters)
+        err = "state root: more than 4 GiB of leaves in one call";
+        return PHANT_E_UNSUPPORTED;
+    }
     const uint64_t code_bytes = code_off[n] - code_off[0];
     const size_t n1 = (size_t)n + 1, m1 = (size_t)m + 1;
     auto R = [](size_t b) { return DevArena::round(b); };
