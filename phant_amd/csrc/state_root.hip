@@ -15,7 +15,7 @@
 // order, a second pass for the state trie.  The host reads back a handful of counters (how many live slots, how many
 // value bytes, "is the order decided": each a stream synchronisation) and, for the state root, 32 bytes.
 // Round 1 hashed on the GPU and did the rest on the host: five pageable round trips of digests and leaves, std::sort with
-// 32-byte memcmp, byte-wise packing -- 128 ms per 200 000 accounts x 5 slots against ~20 ms now (tools/bench_state.py).
+// 32-byte memcmp, byte-wise packing -- 121 ms per 200 000 accounts x 5 slots against 9.8 ms now (tools/bench_state.py).
 //
 // HBM-bound byte shuffling around the Keccak kernels; nothing here is GEMM-shaped.
 #include <algorithm>
