@@ -260,8 +260,13 @@ constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte pat
 // is one returning atomicAdd per workgroup and non-empty list on the SAME few cursors (served one at a time, ~11.6 ns
 // each, tools/ubench/atomic_rate.hip): ~3 000 of them for BASELINE config 3, spread over the kernel's run.
 constexpr uint32_t DEDUP_BLOCK = 256;
+#ifdef PHANT_HOST_EMU
+#define PHANT_NUM_VGPR(n)  // (a register budget means nothing to a host compiler; clang rejects the attribute there)
+#else
+#define PHANT_NUM_VGPR(n) __attribute__((amdgpu_num_vgpr(n)))
+#endif
 
-__global__ void __launch_bounds__(DEDUP_BLOCK) __attribute__((amdgpu_num_vgpr(48))) dedup_kernel(const Args a) {
+__global__ void __launch_bounds__(DEDUP_BLOCK) PHANT_NUM_VGPR(48) dedup_kernel(const Args a) {
     constexpr uint32_t WAVES = DEDUP_BLOCK / 64u;
     __shared__ uint32_t s_cnt[WAVES][N_LIST];
     __shared__ uint32_t s_base[N_LIST];
