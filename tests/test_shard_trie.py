@@ -33,6 +33,12 @@ def _cases(rng):
     yield [bytes([0x30 | (k[0] & 0x0F)]) + k[1:] for k in sorted(set(ks))][:250], vs[:250]  # one top nibble only
     yield random_kv(rng, 120, 2, 1, 6)                       # short keys, short values: embedded children
     yield random_kv(rng, 40, 1, 1, 3)
+    # long keys: the sub-trie roots are leaves / extensions whose re-rooted hex-prefix path needs the LONG RLP string
+    # header (> 55 bytes: keys of 56 bytes and more), 56 / 57 being the boundary
+    yield random_kv(rng, 20, 120, 1, 40)
+    yield random_kv(rng, 5, 200, 1, 40)
+    yield random_kv(rng, 30, 56, 1, 40)
+    yield random_kv(rng, 30, 57, 1, 40, 6)
     ks, vs = random_kv(rng, 64, 32, 1, 50)
     yield [k for k in ks if (k[0] >> 4) in (2, 11)], [v for k, v in zip(ks, vs) if (k[0] >> 4) in (2, 11)]  # two nibbles
 
