@@ -1205,12 +1205,22 @@ static size_t rnd256(size_t x) { return (x + 255) / 256 * 256; }
 // Levels [0, S) are deduplicated.  Deduplication pays where a level has fewer groups than proofs pass through it:
 // 16^d groups per root at depth d against n proofs (keys are Keccak outputs: uniform).  Beyond that the table
 // lookups and the byte comparison cost more than hashing the rare duplicate.
-static uint32_t shallow_levels(uint32_t n, int32_t forced) {
+static uint32_t shallow_levels(uint32_t n, uint32_t n_roots, int32_t forced) {
     if (forced >= 0) return (uint32_t)forced < MAX_SHALLOW ? (uint32_t)forced : MAX_SHALLOW;
     if (n < 2) return 0;
+    // A batch against many roots is many smaller batches: with the proofs spread evenly each root would see n / n_roots of
+    // them, with one big trie next to many small ones (a block witness: the state trie and the contracts' storage tries)
+    // the big one far more.  n / sqrt(n_roots) sits between the two (measured on BASELINE config 4, 80 000 proofs against
+    // 2 001 roots: 4 levels -> one launch 0.203 ms, 5 levels -- what n alone gives -- 0.223, 3 levels 0.216).
+    uint64_t n_eff = n;
+    if (n_roots > 1u) {
+        uint64_t r = 1;
+        while ((r + 1) * (r + 1) <= n_roots) ++r;
+        n_eff = n / r ? n / r : 1;
+    }
     uint32_t s = 1;
     uint64_t groups = 16;  // of level s
-    while (s < MAX_SHALLOW && groups <= 4ull * n) {
+    while (s < MAX_SHALLOW && groups <= 4ull * n_eff) {
         ++s;
         groups *= 16;
     }
@@ -1300,7 +1310,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     Args a;
     a.v = v;
     a.total_nodes = total_nodes;
-    a.shallow = shallow_levels(v.n, dedup_levels);
+    a.shallow = shallow_levels(v.n, v.n_roots, dedup_levels);
     a.all_listed = 0;
     uint64_t direct_entries = 0;
     a.direct = direct_levels(v.n_roots, a.shallow, direct_entries);
