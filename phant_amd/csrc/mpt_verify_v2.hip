@@ -1361,7 +1361,13 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
             // grid bound: every shallow node listed (64-node chunks, 4 waves per workgroup) + one short chunk per list
             const uint64_t listed = (uint64_t)v.n * a.shallow < total_nodes ? (uint64_t)v.n * a.shallow : total_nodes;
             const uint32_t hg = (uint32_t)((listed + 255u) / 256u) + N_LIST;
-            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), 0, st, a);
+            // Next to the deep tier the list kernel's workgroups count against the same cap (same LDS footprint: any three
+            // hash workgroups per CU), so that a fourth hash wave never takes the registers the comparison, link and walk
+            // waves of this and other launches need -- for single-root batches, where the list is small next to the deep tier
+            // (same-box A/B, config 3: 4 in flight +1.5 %, one launch -1.8 %; config 4, whose list kernel is the longer one:
+            // 4 in flight +1.5 % but one launch +8 %: left alone there)
+            const uint32_t list_lds = (two && v.n_roots == 1u) ? tune.hash_lds + 8192u : 0u;
+            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), list_lds, st, a);
         }
         if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
         hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
