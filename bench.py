@@ -346,8 +346,21 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     e1 = max_over_ranks(time.perf_counter() - t1)
 
     # device time of ONE launch of the path (all kernels of the pipeline, first start to last end): HIP events on the
-    # launch stream (phant_timing), alternating witnesses
+    # launch stream around a run of launches issued back to back (alternating witnesses, no verdict exchange), divided
+    # by their number.  (Per-launch event pairs with a host synchronisation after each -- phant_timing, kept as
+    # `kernel_synced_avg_ms` -- let the device idle between launches and read 1-4 % longer, box to box.)
     dstatus = torch.empty(n_units, dtype=torch.uint8, device=dev)
+    n_timed = max(10, min(steps * inner, 120))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(st0):
+        for k in range(4):
+            M.verify_batch_dev(wits[k % n_wit].batch, status=dstatus, ctx=ctx)
+        ev0.record(st0)
+        for k in range(n_timed):
+            M.verify_batch_dev(wits[k % n_wit].batch, status=dstatus, ctx=ctx)
+        ev1.record(st0)
+    torch.cuda.synchronize()
+    k_evt_ms = ev0.elapsed_time(ev1) / n_timed
     ctx.timing(True)
     kms = []
     for k in range(max(10, min(steps * inner, 60))):
@@ -359,7 +372,7 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     out = {"wits": wits, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
            "value": n_units * world * passes / elapsed,
            "single": {"value": n_units * world * passes / e1, "ms_per_step": e1 / passes * 1e3},
-           "k_avg_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed}
+           "k_avg_ms": k_evt_ms, "k_synced_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed}
     for k, (st_, c_, _, _, _) in enumerate(slots):
         if c_ is not ctx:
             c_.close()
@@ -431,13 +444,14 @@ def main():
                         f"{w.nodes_per_proof:.2f} nodes, {w.bytes_per_proof:.0f} B and {w.perms_per_proof:.1f} "
                         f"Keccak-f per proof on average, 1% corrupted/exclusion); distinct witness per slot, "
                         f"{inner} back-to-back passes per timed step")
+        extra = {"kernel_synced_avg_ms": r["k_synced_ms"]}
         if r["hashed"] is not None:
             hashed = r["hashed"]
             kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
             # the second roofline of this path: Keccak-f is integer-VALU-bound.  Peak = what the product's round
             # function sustains with nothing but permutations on the chip (tools/ubench/keccak_rate.hip,
             # profiles/r1i/keccak_rate_ubench.txt: 10.3 G perm/s at 6 waves/SIMD)
-            extra = {"nodes_shipped": int(b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed)), "keccak_f_run": kf,
+            extra = {**extra, "nodes_shipped": int(b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed)), "keccak_f_run": kf,
                      "keccak_f_if_every_node_hashed": int(round(w.perms_per_proof * n_units)),
                      "valu": {"bound": "valu", "achieved": kf / (k_avg_ms * 1e-3) / 1e9, "peak": 10.3,
                               "unit": "G Keccak-f/s", "frac": kf / (k_avg_ms * 1e-3) / 1e9 / 10.3,

@@ -30,7 +30,18 @@ def _no_cuda():
 
     real_device = torch.device
     saved = (torch.device, torch.cuda.set_device, torch.cuda.current_stream, torch.cuda.Stream, torch.cuda.stream,
-             phant_amd.Context)
+             phant_amd.Context, torch.cuda.Event)
+
+    class _Event:  # wall-clock stand-in for a HIP event (the emulated runtime executes at launch)
+        def __init__(self, *a, **k):
+            self.t = 0.0
+
+        def record(self, *a, **k):
+            import time
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
 
     def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, dedup_levels=None):
         mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else
@@ -46,12 +57,13 @@ def _no_cuda():
     torch.cuda.current_stream = lambda *a, **k: _Stream()
     torch.cuda.Stream = lambda *a, **k: _Stream()
     torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.Event = _Event
     phant_amd.Context = context
     try:
         yield
     finally:
         (torch.device, torch.cuda.set_device, torch.cuda.current_stream, torch.cuda.Stream, torch.cuda.stream,
-         phant_amd.Context) = saved
+         phant_amd.Context, torch.cuda.Event) = saved
 
 
 def _bench(argv):
