@@ -215,6 +215,34 @@ def test_state_root_orders_its_leaves_on_the_gpu(P, oracle, monkeypatch):
     assert P.state.state_root(one) == oracle.state_root(one)
 
 
+def test_state_root_edge_cases(P, oracle):
+    """Zero-valued slots do not exist (statedb.zig:112-119): an account whose slots are all zero has the empty storage
+    root; accounts without code / with a zero balance / nonce; the same slot twice in one account is refused (the storage
+    trie's keys must be distinct); one account with one slot."""
+    rng = np.random.default_rng(5)
+    mk = lambda st, **k: dict(addr=rng.integers(0, 256, 20, dtype=np.uint8).tobytes(), nonce=k.get("nonce", 0),
+                              balance=k.get("balance", 0), code=k.get("code", b""), storage=st)
+    acc = [mk({1: 0, 2: 0, 3: 0}), mk({}), mk({7: 5}, nonce=2 ** 64 - 1, balance=2 ** 256 - 1, code=b"\x60" * 700),
+           mk({5: 0, 6: 1, 2 ** 256 - 1: 2 ** 256 - 1}), mk({0: 0x7f}), mk({0: 0x80})]
+    want = oracle.state_root(acc)
+    assert P.state.state_root(acc) == want
+    same = [dict(a, storage={s: v for s, v in a["storage"].items() if v}) for a in acc]
+    assert P.state.state_root(same) == want
+    assert P.state.state_root(acc[4:5]) == oracle.state_root(acc[4:5])
+    # the C-ABI takes slots as arrays, so a slot can be listed twice there
+    import ctypes as C
+    from phant_amd.state import _soa
+    from phant_amd.context import default_context
+    from phant_amd import _lib as L
+    n, (addrs, nonces, bal, code, code_off, sk, sv, first) = _soa([mk({9: 1, 10: 2})])
+    sk[32:64] = sk[0:32]
+    out = np.zeros(32, np.uint8)
+    ctx = default_context()
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    rc = ctx._lib.phant_state_root(ctx.handle, p(addrs), p(nonces), p(bal), p(code), p(code_off), p(sk), p(sv), p(first), n, p(out))
+    assert rc != L.OK
+
+
 def test_sharded_mptize_matches_the_single_gpu_root(oracle):
     """phant_mpt_root_nodes (forest pass with root-node RLP out) + strip + top-nibble exchange, world sizes
     1..8 played back in one process on one GPU, against mptize on the GPU and on the oracle."""
