@@ -199,7 +199,7 @@ def test_garbage_committed_roots(M, oracle):
     _assert_same(got, want)
 
 
-def test_bad_offsets_are_flagged(M):
+def test_bad_offsets_are_flagged(M, oracle):
     root = np.zeros(32, np.uint8)
     keys = np.zeros(64, np.uint8)
     nodes = np.zeros(100, np.uint8)
@@ -207,6 +207,8 @@ def test_bad_offsets_are_flagged(M):
     pfn = np.array([0, 1, 3], np.uint32)
     st, _, _ = M.verify_batch(root, None, keys, 32, nodes, node_off, pfn)
     assert st[0] == M.PROOF_BAD_HASH and st[1] == M.PROOF_BAD_INPUT
+    want = oracle.mpt_verify_batch_checked(root, None, keys, 32, nodes, node_off, pfn)   # (the rules of DESIGN.md section 3)
+    assert np.array_equal(st, want[0])
 
 
 def test_synthetic_depth8_small_vs_oracle(M, oracle):
