@@ -488,7 +488,9 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 // have such a node; inactive lanes hash whatever `ptr` points at -- the launcher gives them a readable one).  Three
 // full rate blocks and a last one of 124 message bytes: the padding is two constants, nothing is masked per lane, and
 // nothing beyond the node's last byte is read.  Returns nonzero iff the node is NOT the canonical full branch.
-// LADDER: the wave's issue priority falls as it gets on (3 for the first block .. 0 for the last).  VALU issue on a
+// LADDER: the wave's issue priority falls as it gets on (2, 1, 1, 0 over the four blocks: below the memory-bound kernels' 3
+// throughout -- same-box A/B of ladders: 3,2,1,0 one launch 0.2251 ms, 2,1,1,0 0.2221, 1,1,1,0 0.2234; flatter ones
+// (2,1,0,0 / 1,1,0,0) gain 1.9 % with four launches in flight and lose 2.5 % one at a time).  VALU issue on a
 // SIMD is arbitrated by priority, then age -- left alone, the oldest of four co-resident hash waves takes ~60 % of the
 // slots, finishes first, and the youngest ends up running its last permutations alone at single-wave speed (6.9
 // instead of 9.8 G perm/s).  With the ladder a wave that is behind outranks the ones ahead: they advance block by
@@ -498,10 +500,10 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 template <bool LADDER>
 PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
     sponge_zero(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(3);
+    if (LADDER) __builtin_amdgcn_s_setprio(2);
     uint32_t bad = absorb_b532_block<0, 34>(s, p);
     keccak_f1600(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(2);
+    if (LADDER) __builtin_amdgcn_s_setprio(1);
     bad |= absorb_b532_block<1, 34>(s, p + RATE);
     keccak_f1600(s);
     if (LADDER) __builtin_amdgcn_s_setprio(1);
