@@ -262,6 +262,9 @@ def mk_ctx(args, local_rank, use_torch_stream=True):
                              dedup_levels=(args.dedup_levels if args.verify_mode == "flat" else None))
 
 
+_SLOT_STREAMS = []
+
+
 def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank, world, rank, ctx):
     """A resident proof batch verified + reduced to the per-root verdict, S launch sequences in flight, slot k on its
     own HIP stream / ctx (workspace) / status + verdict buffers and over its OWN witness (seed base + k: no pass
@@ -282,7 +285,11 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
         if k == 0:
             st_, c_ = torch.cuda.current_stream(dev), ctx
         else:
-            st_ = torch.cuda.Stream(device=dev)
+            # (the slot streams are made once per process: a second set -- the `strong` leg after the headline one -- would
+            # be other entries of torch's stream pool, and slots whose streams share a hardware queue do not overlap)
+            while len(_SLOT_STREAMS) < k:
+                _SLOT_STREAMS.append(torch.cuda.Stream(device=dev))
+            st_ = _SLOT_STREAMS[k - 1]
             with torch.cuda.stream(st_):
                 c_ = mk_ctx(args, local_rank)
         slots.append((st_, c_, torch.empty(n_units, dtype=torch.uint8, device=dev),
