@@ -86,6 +86,8 @@ size_t order_workspace_bytes(uint32_t n);
 hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* ws,
                                 uint32_t** d_order_out, uint32_t** d_flag_out, uint32_t prefix_bits, hipStream_t st);
 
-hipError_t launch_exclusive_scan_u32(uint32_t* d, uint32_t n, hipStream_t st);
+// exclusive prefix sum of d[0 .. n) in place; d 16-byte aligned, scratch = scan_scratch_entries(n) counters of device memory
+size_t scan_scratch_entries(uint32_t n);
+hipError_t launch_exclusive_scan_u32(uint32_t* d, uint32_t n, uint32_t* scratch, hipStream_t st);
 
 }  // namespace phant

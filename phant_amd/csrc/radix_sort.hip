@@ -5,7 +5,7 @@
 // 32-byte memcmp: ~0.2 s per million keys, behind a device-to-host copy of every digest).  Here: a stable LSD radix
 // sort of (64-bit key, 32-bit value) pairs, 8 bits per pass, three kernels per pass --
 //   radix_hist    per-workgroup digit histogram of a tile of 2 048 pairs (LDS atomics) -> hist[digit][workgroup]
-//   radix_scan    exclusive scan of that table in place (one workgroup; the table has 256 x n / 2 048 entries)
+//   exclusive_scan of that table in place (256 x n / 2 048 entries; tiled, see below)
 //   radix_scatter every wave ranks its 512 pairs digit by digit in index order (a lane's rank among the lanes of its
 //                 wave with the same digit comes from eight ballots), the workgroup adds the waves' totals to the
 //                 scanned base, pairs go to their final place
@@ -43,28 +43,104 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint64_t
     hist[threadIdx.x * n_tiles + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-// exclusive scan of `total` counters in place, one workgroup of 1 024 lanes
-__global__ void __launch_bounds__(1024) radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t total) {
-    __shared__ uint32_t s_sum[1024];
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (total + 1023u) / 1024u;
-    const uint32_t lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += hist[i];
-    s_sum[t] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele, inclusive
-        const uint32_t v = t >= d ? s_sum[t - d] : 0u;
-        __syncthreads();
-        s_sum[t] += v;
-        __syncthreads();
+// ---- exclusive scan of 32-bit counters, in place.  Tiles of 2 048 counters (8 per lane, contiguous: a lane's two 16-byte
+// loads), three launches per level: the tiles' sums, the scan of those sums (this very scan, one level up), the tiles'
+// own scans on top of their offsets.  (Round 2's first version was ONE workgroup walking the whole array, a lane per
+// contiguous stretch: 273 us per call on the digit tables of a million-key sort, 6 of the 8 ms of a state root.) ----
+constexpr uint32_t SCAN_THREADS = 256;
+constexpr uint32_t SCAN_ITEMS = 8;
+constexpr uint32_t SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+// the workgroup's running total before lane `tid` (exclusive), and in *total the whole workgroup's sum
+__device__ __forceinline__ uint32_t scan_block_exclusive(uint32_t mine, uint32_t tid, uint32_t* s_wave /* [4] */, uint32_t* total) {
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t inc = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, d);
+        if (lane >= d) inc += v;
     }
-    uint32_t run = s_sum[t] - sum;
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t c = hist[i];
-        hist[i] = run;
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SCAN_THREADS / 64u; ++w) {
+        const uint32_t c = s_wave[w];
+        if (w < wave) before += c;
+        all += c;
+    }
+    *total = all;
+    return before + inc - mine;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_kernel(const uint32_t* __restrict__ d, uint32_t n, uint32_t* __restrict__ sums) {
+    __shared__ uint32_t s_wave[SCAN_THREADS / 64u];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t at = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)tid * SCAN_ITEMS;
+    uint32_t mine = 0;
+    if (at + SCAN_ITEMS <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(d + at), b = *reinterpret_cast<const uint4*>(d + at + 4);
+        mine = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
+        for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
+            if (at + i < n) mine += d[at + i];
+    }
+    uint32_t total;
+    scan_block_exclusive(mine, tid, s_wave, &total);
+    if (tid == 0) sums[blockIdx.x] = total;
+}
+
+// offs: the scanned sums of the tiles (null: one tile, starts at zero)
+__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(uint32_t* __restrict__ d, uint32_t n, const uint32_t* __restrict__ offs) {
+    __shared__ uint32_t s_wave[SCAN_THREADS / 64u];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t at = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)tid * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    const bool whole = at + SCAN_ITEMS <= n;
+    if (whole) {
+        const uint4 a = *reinterpret_cast<const uint4*>(d + at), b = *reinterpret_cast<const uint4*>(d + at + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < SCAN_ITEMS; ++i) v[i] = at + i < n ? d[at + i] : 0u;
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < SCAN_ITEMS; ++i) mine += v[i];
+    uint32_t total;
+    uint32_t run = scan_block_exclusive(mine, tid, s_wave, &total) + (offs ? offs[blockIdx.x] : 0u);
+#pragma unroll
+    for (uint32_t i = 0; i < SCAN_ITEMS; ++i) {
+        const uint32_t c = v[i];
+        v[i] = run;
         run += c;
     }
+    if (whole) {
+        *reinterpret_cast<uint4*>(d + at) = make_uint4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint4*>(d + at + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < SCAN_ITEMS; ++i)
+            if (at + i < n) d[at + i] = v[i];
+    }
+}
+
+uint32_t scan_tiles(uint32_t n) { return (uint32_t)(((uint64_t)n + SCAN_TILE - 1u) / SCAN_TILE); }
+
+// d: 16-byte aligned.  scratch: scan_scratch_entries(n) counters.
+hipError_t exclusive_scan(uint32_t* d, uint32_t n, uint32_t* scratch, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint32_t tiles = scan_tiles(n);
+    if (tiles == 1u) {
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, d, n, (const uint32_t*)nullptr);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(tiles), dim3(SCAN_THREADS), 0, st, d, n, scratch);
+    // (the next level's scratch starts on a 16-byte boundary behind this level's sums)
+    const hipError_t e = exclusive_scan(scratch, tiles, scratch + (tiles + 3u) / 4u * 4u, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(SCAN_THREADS), 0, st, d, n, (const uint32_t*)scratch);
+    return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
@@ -169,11 +245,12 @@ uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1u) / SORT_TILE; }
 // stable sort of the pairs by key bits [lo, hi) (multiples of 8); the result ends up in (keys, vals) -- the pointers are
 // swapped with their alternates after every pass
 hipError_t sort_pairs(uint64_t*& keys, uint32_t*& vals, uint64_t*& keys_alt, uint32_t*& vals_alt, uint32_t n, uint32_t lo, uint32_t hi,
-                      uint32_t* hist, hipStream_t st) {
+                      uint32_t* hist, uint32_t* scan_scratch, hipStream_t st) {
     const uint32_t tiles = sort_tiles(n);
     for (uint32_t shift = lo; shift < hi; shift += 8u) {
         hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(SORT_THREADS), 0, st, keys, n, shift, hist, tiles);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, hist, 256u * tiles);
+        const hipError_t e = exclusive_scan(hist, 256u * tiles, scan_scratch, st);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(SORT_THREADS), 0, st, keys, vals, keys_alt, vals_alt, n, shift, hist, tiles);
         uint64_t* tk = keys; keys = keys_alt; keys_alt = tk;
         uint32_t* tv = vals; vals = vals_alt; vals_alt = tv;
@@ -183,10 +260,18 @@ hipError_t sort_pairs(uint64_t*& keys, uint32_t*& vals, uint64_t*& keys_alt, uin
 
 }  // namespace
 
+// counters of scratch an exclusive scan of n counters needs (the tiles' sums, level by level)
+size_t scan_scratch_entries(uint32_t n) {
+    size_t total = 4;
+    for (uint32_t t = scan_tiles(n); t > 1u; t = scan_tiles(t)) total += ((size_t)t + 3) / 4 * 4;
+    return total;
+}
+
 size_t order_workspace_bytes(uint32_t n) {
     const size_t r = 256;
     auto rnd = [&](size_t b) { return (b + r - 1) / r * r; };
-    return 2 * rnd((size_t)n * 8) + 2 * rnd((size_t)n * 4) + rnd((size_t)256 * sort_tiles(n) * 4) + rnd(4) + 6 * r;
+    return 2 * rnd((size_t)n * 8) + 2 * rnd((size_t)n * 4) + rnd((size_t)256 * sort_tiles(n) * 4) + rnd(4) +
+           rnd(4 * scan_scratch_entries(256u * sort_tiles(n))) + 6 * r;
 }
 
 // order[0..n): the items (digests d_digests[i], 32 bytes each) in ascending order of (seg_of[i], digest i); seg_of may be
@@ -204,6 +289,8 @@ hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_
     uint32_t* hist = reinterpret_cast<uint32_t*>(p);
     p += rnd((size_t)256 * sort_tiles(n) * 4);
     uint32_t* flag = reinterpret_cast<uint32_t*>(p);
+    p += rnd(4);
+    uint32_t* scan_scratch = reinterpret_cast<uint32_t*>(p);
     hipError_t e = hipMemsetAsync(flag, 0, 4, st);
     if (e != hipSuccess) return e;
     *d_flag_out = flag;
@@ -214,24 +301,20 @@ hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_
     const uint32_t g = (n + 255u) / 256u;
     hipLaunchKernelGGL(digest_prefix_kernel, dim3(g), dim3(256), 0, st, d_digests, n, keys, vals);
     const uint32_t bits = prefix_bits >= 64u ? 64u : (prefix_bits + 7u) / 8u * 8u;
-    if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 64u - bits, 64u, hist, st)) != hipSuccess) return e;
+    if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 64u - bits, 64u, hist, scan_scratch, st)) != hipSuccess) return e;
     if (d_seg_of && n_seg > 1u) {
         uint32_t seg_bits = 8;
         while (seg_bits < 32u && ((uint64_t)1 << seg_bits) < n_seg) seg_bits += 8;
         hipLaunchKernelGGL(segment_key_kernel, dim3(g), dim3(256), 0, st, vals, d_seg_of, n, keys);
-        if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 0u, seg_bits, hist, st)) != hipSuccess) return e;
+        if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 0u, seg_bits, hist, scan_scratch, st)) != hipSuccess) return e;
     }
     if (n > 1u) hipLaunchKernelGGL(order_check_kernel, dim3((n - 1u + 255u) / 256u), dim3(256), 0, st, d_digests, vals, d_seg_of, n, flag);
     *d_order_out = vals;
     return hipGetLastError();
 }
 
-// exclusive prefix sum of d[0 .. n) in place (one workgroup; n up to a few million).  With n + 1 entries and d[n] = 0 on entry,
-// d[n] is the total on exit.
-hipError_t launch_exclusive_scan_u32(uint32_t* d, uint32_t n, hipStream_t st) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, d, n);
-    return hipGetLastError();
-}
+// exclusive prefix sum of d[0 .. n) in place (d 16-byte aligned; scratch: scan_scratch_entries(n) counters).  With n + 1
+// entries and d[n] = 0 on entry, d[n] is the total on exit.
+hipError_t launch_exclusive_scan_u32(uint32_t* d, uint32_t n, uint32_t* scratch, hipStream_t st) { return exclusive_scan(d, n, scratch, st); }
 
 }  // namespace phant

@@ -265,10 +265,11 @@ int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, c
     const size_t n1 = (size_t)n + 1, m1 = (size_t)m + 1;
     auto R = [](size_t b) { return DevArena::round(b); };
     const size_t sort_ws = order_workspace_bytes(m > n ? m : n);
+    const size_t scan_entries = scan_scratch_entries((m > n ? m : n) + 1u);
     SR_TRY(ws.io.reset(R(20 * (size_t)n + 16) + R(8 * (size_t)n) + R(32 * (size_t)n) + R(code_bytes + 16) + R(8 * n1) + 2 * R(32 * (size_t)m + 16) +
                        2 * R(4 * n1) + R(4 * m1) + R(32 * (size_t)m + 16) + 2 * R(4 * (size_t)m + 4) + R(32 * (size_t)m + 16) + R(sort_ws) +
                        R(4 * m1) + R(32 * (size_t)m + 16) + R(4 * m1) + R(33 * (size_t)m + 16) + R(8 * m1) + R(32 * (size_t)n) +
-                       2 * R(32 * (size_t)n) + R(4 * n1) + R(32 * (size_t)n + 16) + R(4 * n1) + R(112 * (size_t)n + 16) + R(8 * n1) + 8192));
+                       2 * R(32 * (size_t)n) + R(4 * n1) + R(32 * (size_t)n + 16) + R(4 * n1) + R(112 * (size_t)n + 16) + R(8 * n1) + R(4 * scan_entries) + 8192));
     // ---- the caller's arrays, once ----
     uint8_t* d_addrs = ws.io.take<uint8_t>(20 * (size_t)n + 16);
     uint64_t* d_nonces = ws.io.take<uint64_t>(n);
@@ -309,9 +310,10 @@ int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, c
     uint8_t* d_lvals = ws.io.take<uint8_t>(33 * (size_t)m + 16);
     uint64_t* d_lvoff = ws.io.take<uint64_t>(m1);
     uint8_t* d_sroots = ws.io.take<uint8_t>(32 * (size_t)n);
+    uint32_t* d_scan = ws.io.take<uint32_t>(scan_entries);
     uint32_t L = 0;
     hipLaunchKernelGGL(slot_live_kernel, dim3(blocks(m1)), dim3(256), 0, st, d_svals_in, m, d_pos);
-    SR_TRY(launch_exclusive_scan_u32(d_pos, m + 1u, st));
+    SR_TRY(launch_exclusive_scan_u32(d_pos, m + 1u, d_scan, st));
     SR_TRY(hipMemcpyAsync(&L, d_pos + m, 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(acc_first_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_pos, d_slot_first, n, d_acc_first);
     if (m) hipLaunchKernelGGL(slot_compact_kernel, dim3(blocks(m)), dim3(256), 0, st, d_pos, d_skeys_in, d_slot_first, n, m, d_live_keys, d_live_src, d_seg_of);
@@ -323,7 +325,7 @@ int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, c
         const int32_t rc = order_digests(st, d_hk, d_seg_of, L, n, d_sort, &d_order, err);
         if (rc) return rc;
         hipLaunchKernelGGL(slot_leaf_len_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, L, d_len);
-        SR_TRY(launch_exclusive_scan_u32(d_len, L + 1u, st));
+        SR_TRY(launch_exclusive_scan_u32(d_len, L + 1u, d_scan, st));
         uint32_t vb = 0;
         SR_TRY(hipMemcpyAsync(&vb, d_len + L, 4, hipMemcpyDeviceToHost, st));
         hipLaunchKernelGGL(slot_leaf_write_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, d_hk, d_len, L,
@@ -350,7 +352,7 @@ int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, c
     rc = order_digests(st, d_ha, nullptr, n, 1, d_sort, &d_aorder, err);
     if (rc) return rc;
     hipLaunchKernelGGL(account_len_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_aorder, d_nonces, d_bal, n, d_alen);
-    SR_TRY(launch_exclusive_scan_u32(d_alen, n + 1u, st));
+    SR_TRY(launch_exclusive_scan_u32(d_alen, n + 1u, d_scan, st));
     uint32_t avb = 0;
     SR_TRY(hipMemcpyAsync(&avb, d_alen + n, 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(account_write_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_aorder, d_nonces, d_bal, d_sroots, d_hc, d_ha, d_alen, n, out.keys,
