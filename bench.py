@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--proofs", type=int, default=100_000, help="proofs per GPU (config3)")
     ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--proof-order", choices=("random", "sorted"), default="random",
+                    help="config 3: order of the proofs in the batch (BASELINE: random; sorted = ascending keys, an A/B)")
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5", "nodeset", "mptize"])
     ap.add_argument("--keys", type=int, default=1_000_000, help="mptize: sorted 32-byte keys (78-byte values) per GPU")
     ap.add_argument("--block-scale", type=float, default=1.0, help="config4: size of the block relative to 10k tx")
@@ -423,7 +425,7 @@ def main():
 
         def mk3(k):
             return phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2 + k, device=dev, rank=rank,
-                                                     world=world, ctx=ctx)
+                                                     world=world, ctx=ctx, key_order=args.proof_order)
 
         def mk4(k):
             return phant_amd.witness.block_witness(scale=args.block_scale, seed=4 + k, device=dev, rank=rank, world=world,
@@ -442,7 +444,8 @@ def main():
                         f"state root ({w.nodes_per_proof - 1} x 532 B full branches + 112 B leaf, "
                         f"{w.bytes_per_proof} B and {w.perms_per_proof} Keccak-f per proof, 1% corrupted/exclusion, "
                         f"no cross-proof dedup); every launch sequence in flight verifies its own witness (seeds 2.."
-                        f"{1 + max(S, 2)}: distinct data per slot), {inner} back-to-back passes per timed step")
+                        f"{1 + max(S, 2)}: distinct data per slot), {inner} back-to-back passes per timed step"
+                        + ("" if args.proof_order == "random" else "; PROOFS IN ASCENDING KEY ORDER (not BASELINE's order)"))
         else:
             metric, unit = "mpt_proofs_verified_per_sec_block_witness", "proofs/s"
             workload = (f"config4: one synthetic {int(10000 * args.block_scale)}-tx block witness sharded over "

@@ -61,8 +61,10 @@ def _rand_u8(shape, gen, device):
 
 def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_frac: float = 0.01,
                     rank: int = 0, world: int = 1, group=None, ctx=None, n_tries: int = 0,
-                    value: bytes | None = None) -> Witness:
-    """n_tries = 0: one trie, shared by all ranks (the state trie).  n_tries >= 1: the n proofs are spread over
+                    value: bytes | None = None, key_order: str = "random") -> Witness:
+    """key_order: "random" (BASELINE: the proofs arrive in no particular order) or "sorted" (ascending keys, as a producer
+    that walks the trie would list them -- an A/B for how much the order matters to the verifier).
+    n_tries = 0: one trie, shared by all ranks (the state trie).  n_tries >= 1: the n proofs are spread over
     that many separate tries of the same depth, each with its own root (`batch.roots` is (<= n_tries, 32) and
     `batch.root_idx` says which) -- the storage tries of a block witness; such tries belong to this rank
     alone (any top nibble, no collective).  `value`: the RLP string payload of
@@ -95,6 +97,9 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
         pref = torch.unique(torch.cat([pref, cand]))
         need = n - pref.numel()
     pref = pref[torch.randperm(pref.numel(), device=device, generator=gen)[:n]]
+    assert key_order in ("random", "sorted")
+    if key_order == "sorted":
+        pref = torch.sort(pref).values
     keys = _rand_u8((n, 32), gen, device)
     # write the L prefix nibbles into the key
     for j in range(L):
