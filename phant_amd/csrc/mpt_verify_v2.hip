@@ -1207,9 +1207,18 @@ static size_t rnd256(size_t x) { return (x + 255) / 256 * 256; }
 // Levels [0, S) are deduplicated.  Deduplication pays where a level has fewer groups than proofs pass through it:
 // 16^d groups per root at depth d against n proofs (keys are Keccak outputs: uniform).  Beyond that the table
 // lookups and the byte comparison cost more than hashing the rare duplicate.
-static uint32_t shallow_levels(uint32_t n, uint32_t n_roots, int32_t forced) {
+// A batch the chip can hash in a few rounds of waves is hashed whole: below ~530 000 Keccak-f (72 MB of nodes; eight per SIMD
+// lane slot) the shallow tier's extra kernels and the fork / join of the helper stream cost more than the hashing they save.
+// Measured (profiles/r2_d/small_batches_*.jsonl, block_witness_scale_vs_levels.jsonl), one launch / four in flight:
+//   depth-8 proofs, one root:  150 proofs 78 -> 56 us;  1 000  82 -> 59;  3 000  97 -> 61;  10 000 (39 MB) 103 -> 80, 171 -> 276 M
+//                              proofs/s;  16 000 (62 MB) 106 -> 85, 251 -> 293 M;  20 000 (77 MB) equal;  24 000 (92 MB): 339 vs 292 M
+//   block witnesses:           8 000 proofs (23 MB) 130 -> 276 M proofs/s;  16 000 (46 MB) 247 -> 352 M;  24 000 (69 MB) 310 -> 368 M;
+//                              32 000 (92 MB) equal;  40 000 (115 MB): 440 vs 377 M for the two tiers
+constexpr uint64_t HASH_EVERYTHING_BELOW_BYTES = 72000000ull;
+
+static uint32_t shallow_levels(uint32_t n, uint32_t n_roots, uint64_t nodes_len, int32_t forced) {
     if (forced >= 0) return (uint32_t)forced < MAX_SHALLOW ? (uint32_t)forced : MAX_SHALLOW;
-    if (n < 2) return 0;
+    if (n < 2 || nodes_len < HASH_EVERYTHING_BELOW_BYTES) return 0;
     // A batch against many roots is many smaller batches: with the proofs spread evenly each root would see n / n_roots of
     // them, with one big trie next to many small ones (a block witness: the state trie and the contracts' storage tries)
     // the big one far more.  n / sqrt(n_roots) sits between the two (measured on BASELINE config 4, 80 000 proofs against
@@ -1312,7 +1321,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     Args a;
     a.v = v;
     a.total_nodes = total_nodes;
-    a.shallow = shallow_levels(v.n, v.n_roots, dedup_levels);
+    a.shallow = shallow_levels(v.n, v.n_roots, v.nodes_len, dedup_levels);
     a.all_listed = 0;
     uint64_t direct_entries = 0;
     a.direct = direct_levels(v.n_roots, a.shallow, direct_entries);

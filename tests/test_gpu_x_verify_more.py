@@ -75,3 +75,22 @@ def test_keys_longer_than_the_lds_staging(M, oracle):
         assert np.array_equal(got[0], want[0]), (key_len, got[0][:20], want[0][:20])
         assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
         assert {M.PROOF_PRESENT, M.PROOF_ABSENT} <= set(got[0].tolist())
+
+
+def test_small_batches_are_hashed_whole_large_ones_in_two_tiers():
+    """The tier split chosen from the batch (no forced level): a batch the chip hashes in a few rounds of waves -- under 72 MB
+    of nodes -- skips the deduplicating tier (every shipped node is hashed: fewer kernels, no helper stream), BASELINE
+    config 3's 387 MB does not (the measurements behind the threshold: profiles/r2_d/).  Statuses as
+    constructed either way."""
+    import phant_amd
+    ctx = phant_amd.Context()
+    try:
+        for n, whole in ((3_000, True), (100_000, False)):
+            w = phant_amd.witness.account_witness(n, depth=8, seed=21, ctx=ctx)
+            st = phant_amd.mpt.verify_batch_dev(w.batch, ctx=ctx)
+            assert torch.equal(st, w.expected)
+            shipped = int(w.batch.node_off.numel() - 1)
+            hashed = sum(ctx.verify_stats())
+            assert (hashed == shipped) if whole else (hashed < shipped // 2), (n, hashed, shipped)
+    finally:
+        ctx.close()
