@@ -161,18 +161,18 @@ constexpr uint32_t PLAN_BATCH = 8;  // even: a batch starts on a key byte
 // then a wait for memory -- at equal priority they would only get the leftover issue slots.
 PHANT_DEV void beside_the_hashing() { __builtin_amdgcn_s_setprio(3); }
 
-// header, tables, stamps, node states: zeroed per call (16 bytes per lane; bytes = multiple of 256)
-__global__ void __launch_bounds__(256) zero_kernel(uint4* p, size_t n16) {
+// header, tables, stamps, node states: zeroed per call (16 bytes per lane; bytes = multiple of 256) -- and, as the first
+// kernel of the launch, the verdict counters the walk will add to
+__global__ void __launch_bounds__(256) zero_kernel(uint4* p, size_t n16, uint32_t* fail_count, uint32_t n_roots) {
     beside_the_hashing();
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (fail_count)
+        for (size_t r = i; r < n_roots; r += (size_t)gridDim.x * 256u) fail_count[r] = 0u;
 }
 
 __global__ void __launch_bounds__(256) plan_kernel(const Args a) {
     beside_the_hashing();
-    // first kernel of the main stream: clear the verdict counters the walk will add to
-    if (a.v.fail_count && blockIdx.x == 0)
-        for (uint32_t r = threadIdx.x; r < a.v.n_roots; r += 256u) a.v.fail_count[r] = 0u;
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= a.v.n) return;
     const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
@@ -695,6 +695,9 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
             first = a.v.proof_first_node[p];
             const uint32_t last = a.v.proof_first_node[p + 1];
             if (last >= first && last <= a.total_nodes) count = last - first;
+            // (node ranges of other proofs may overlap then: what a lane finds out about a node holds for ITS proof's key
+            // and parent only -- the walk must not use it.  plan_kernel says the same when it runs; with S = 0 it does not)
+            if (last < first) a.hdr[HDR_PFN_BROKEN] = 1u;
             if (a.v.root_idx) root = a.v.root_idx[p];
         }
         if (__ballot(d < count) == 0ull) break;
@@ -857,8 +860,11 @@ constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  
 
 // digest of node j as the pipeline knows it: the node's own, or its representative's (identical bytes)
 PHANT_DEV bool known_digest(const Args& a, uint32_t j, uint32_t& rj) {
-    const uint32_t m = a.meta[j];
-    rj = (m & PRE_GROUP) ? a.rep[j] : j;
+    rj = j;
+    if (a.shallow != 0u) {  // (S = 0: no stamps, no representatives)
+        const uint32_t m = a.meta[j];
+        if (m & PRE_GROUP) rj = a.rep[j];
+    }
     return rj < a.total_nodes && (a.nstat[rj] & NS_HASHED);
 }
 
@@ -905,15 +911,19 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
             uint32_t used = first;
             status = 0xffffffffu;
 
-            // ---- the run of nodes link_kernel settled: one byte each, eight at a time ----
+            // ---- the run of nodes link_kernel settled: one byte each, eight at a time.  With S = 0 there is neither
+            // plan_kernel nor link_kernel: every node was hashed in place by a lane that knew the proof's key, its state byte
+            // says it all, and the depth the stamp would carry is the walk's own position (it only steps over LINK_FAST) ----
+            const bool direct = a.shallow == 0u;
             bool hash_known = false;  // the node at `used` is already known to hash to its reference
             for (bool run = true; run && used < last;) {
-                const uint8_t* lp = a.link + used;  // link[] is padded: 8 bytes past the last node are readable
+                const uint8_t* lp = (direct ? a.nstat : a.link) + used;  // both are followed by 8 readable bytes
                 const uint32_t c0 = load4u(lp), c1 = load4u(lp + 4);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (!run || used >= last) continue;
-                    const uint32_t c = ((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 0xffu;
+                    uint32_t c = ((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 0xffu;
+                    if (direct) c = (c & NS_HASHED) ? code_of(c, w.pos < nn ? PRE_NIB : 0u) : LINK_GENERIC;
                     if (c == LINK_FAST) {  // depth == pos and nibble == key nibble by construction of the stamp
                         ++used;
                         w.pos += 1;
@@ -935,8 +945,8 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                     for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
                 } else {
                     // stepped over node used - 1 (a canonical full branch): its slot for this key's nibble
-                    const uint32_t mp = a.meta[used - 1u];
-                    const uint8_t* rb = a.v.nodes + a.v.node_off[used - 1u] + (4u + 33u * ((mp >> 4) & 15u));
+                    const uint32_t nibp = direct ? key_nibble(key, w.pos - 1u) : (a.meta[used - 1u] >> 4) & 15u;
+                    const uint8_t* rb = a.v.nodes + a.v.node_off[used - 1u] + (4u + 33u * nibp);
                     const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
                     want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
                     want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
@@ -1039,7 +1049,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
         if (a.v.value_off) a.v.value_off[i] = voff;
         if (a.v.value_len) a.v.value_len[i] = vlen;
     }
-    // the verdict, while every status passes through this kernel anyway (fail_count was zeroed by plan_kernel)
+    // the verdict, while every status passes through this kernel anyway (fail_count was zeroed by zero_kernel)
     if (a.v.fail_count) {
         const bool bad = in && !(status == PHANT_PROOF_PRESENT || status == PHANT_PROOF_ABSENT || status == STATUS_NEEDS_SLOW);
         if (a.v.root_idx == nullptr || a.v.n_roots == 1) {
@@ -1334,11 +1344,8 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     hipError_t e = hipSuccess;
     {
         const size_t n16 = l.rep / 16;
-        hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(ws), n16);
-    }
-    if (v.fail_count && !total_nodes) {  // no plan_kernel will run: clear the verdict counters here
-        e = hipMemsetAsync(v.fail_count, 0, sizeof(uint32_t) * (size_t)v.n_roots, st);
-        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(ws), n16, v.fail_count,
+                           v.n_roots);
     }
     const uint32_t pg = (v.n + 255u) / 256u;
     if (total_nodes) {
@@ -1364,7 +1371,8 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         }
         // (plan_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep tier
         // fills every slot it is given the moment it starts -- one launch measures 2 % shorter this way round)
-        hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
+        // (S = 0: hash_deep_kernel and walk_kernel alone -- nothing reads a stamp or a link code)
+        if (a.shallow) hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
         hipLaunchKernelGGL(hash_deep_kernel, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl, deep_levels);
         if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
         if (a.shallow) {
@@ -1381,7 +1389,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
             hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), list_lds, st, a);
         }
         if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
+        if (a.shallow) hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(walk_kernel, dim3(pg), dim3(256), 0, st, a);
     return hipGetLastError();
