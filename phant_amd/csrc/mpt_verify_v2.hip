@@ -31,6 +31,11 @@
 //                         settled from the tables is verified from scratch by its lane (verify_one, a rare branch
 //                         of the same kernel: a kernel of its own cost 5 us per launch for nothing).
 //
+//   S = 0 (small batches: under 72 MB of nodes the chip hashes everything in a few rounds of waves, and the shallow tier's
+//   kernels cost more than they save): zero_kernel, hash_deep_kernel over every depth, walk_kernel -- which then reads the
+//   node states directly: the lane that hashed a node knew the proof's key and parent, the depth a stamp would carry is the
+//   walk's own position.  No stamps, tables, lists, link codes or helper stream.
+//
 // Soundness: rep[j] = r only if bytes(j) == bytes(r), checked byte for byte (so keccak(j) == digest[r]), and r
 // is only trusted when nstat[r] says r itself was hashed; the group key is only a hint where to look.  A copy
 // inherits a link result only if its parent is byte-identical to the representative's parent (same rep) and the
