@@ -683,6 +683,8 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
 // (deepest last: the leaves, the short chunks, fill the tail); a wave whose proofs are all shorter leaves at once.
 constexpr uint32_t DEEP_LEVELS = 8;  // at most; the launcher picks fewer when the batch's proofs are short (see there)
 
+// SOLO: the S = 0 form -- no plan_kernel runs, so this kernel is the one to notice a proof_first_node that is not monotone
+template <bool SOLO>
 __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const uint32_t waves_per_level, const uint32_t levels) {
     // the 32 reference bytes wait in LDS while the sponge has the registers ([dword][lane]: conflict-free)
     __shared__ uint32_t s_ref[8][256];
@@ -701,8 +703,10 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
             const uint32_t last = a.v.proof_first_node[p + 1];
             if (last >= first && last <= a.total_nodes) count = last - first;
             // (node ranges of other proofs may overlap then: what a lane finds out about a node holds for ITS proof's key
-            // and parent only -- the walk must not use it.  plan_kernel says the same when it runs; with S = 0 it does not)
-            if (last < first) a.hdr[HDR_PFN_BROKEN] = 1u;
+            // and parent only -- the walk must not use it.  plan_kernel says so when it runs)
+            if constexpr (SOLO) {
+                if (last < first) a.hdr[HDR_PFN_BROKEN] = 1u;
+            }
             if (a.v.root_idx) root = a.v.root_idx[p];
         }
         if (__ballot(d < count) == 0ull) break;
@@ -864,15 +868,19 @@ constexpr uint32_t WALK_KEY_BYTES = 32;
 constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  // odd stride: no bank pile-up
 
 // digest of node j as the pipeline knows it: the node's own, or its representative's (identical bytes)
+template <bool DIRECT>
 PHANT_DEV bool known_digest(const Args& a, uint32_t j, uint32_t& rj) {
     rj = j;
-    if (a.shallow != 0u) {  // (S = 0: no stamps, no representatives)
+    if constexpr (!DIRECT) {  // (S = 0: no stamps, no representatives)
         const uint32_t m = a.meta[j];
         if (m & PRE_GROUP) rj = a.rep[j];
     }
     return rj < a.total_nodes && (a.nstat[rj] & NS_HASHED);
 }
 
+// DIRECT: the S = 0 form (a kernel of its own: the two-tier form's code is then exactly what it was without it -- as one
+// kernel with a uniform branch the 100 000-proof launch measured 3 % longer, 0.2205 -> 0.2277 ms)
+template <bool DIRECT>
 __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
     __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
     beside_the_hashing();  // (see link_kernel)
@@ -919,7 +927,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
             // ---- the run of nodes link_kernel settled: one byte each, eight at a time.  With S = 0 there is neither
             // plan_kernel nor link_kernel: every node was hashed in place by a lane that knew the proof's key, its state byte
             // says it all, and the depth the stamp would carry is the walk's own position (it only steps over LINK_FAST) ----
-            const bool direct = a.shallow == 0u;
+            constexpr bool direct = DIRECT;
             bool hash_known = false;  // the node at `used` is already known to hash to its reference
             for (bool run = true; run && used < last;) {
                 const uint8_t* lp = (direct ? a.nstat : a.link) + used;  // both are followed by 8 readable bytes
@@ -928,7 +936,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                 for (int u = 0; u < 8; ++u) {
                     if (!run || used >= last) continue;
                     uint32_t c = ((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 0xffu;
-                    if (direct) c = (c & NS_HASHED) ? code_of(c, w.pos < nn ? PRE_NIB : 0u) : LINK_GENERIC;
+                    if constexpr (direct) c = (c & NS_HASHED) ? code_of(c, w.pos < nn ? PRE_NIB : 0u) : LINK_GENERIC;
                     if (c == LINK_FAST) {  // depth == pos and nibble == key nibble by construction of the stamp
                         ++used;
                         w.pos += 1;
@@ -950,7 +958,9 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                     for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
                 } else {
                     // stepped over node used - 1 (a canonical full branch): its slot for this key's nibble
-                    const uint32_t nibp = direct ? key_nibble(key, w.pos - 1u) : (a.meta[used - 1u] >> 4) & 15u;
+                    uint32_t nibp;
+                    if constexpr (direct) nibp = key_nibble(key, w.pos - 1u);
+                    else nibp = (a.meta[used - 1u] >> 4) & 15u;
                     const uint8_t* rb = a.v.nodes + a.v.node_off[used - 1u] + (4u + 33u * nibp);
                     const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
                     want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
@@ -982,7 +992,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                         hash_known = false;  // a hash lane compared the digest with the parent's reference
                     } else {
                         uint32_t rj;
-                        if (!known_digest(a, j, rj)) {
+                        if (!known_digest<DIRECT>(a, j, rj)) {
                             status = STATUS_NEEDS_SLOW;
                             break;
                         }
@@ -1378,7 +1388,8 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         // fills every slot it is given the moment it starts -- one launch measures 2 % shorter this way round)
         // (S = 0: hash_deep_kernel and walk_kernel alone -- nothing reads a stamp or a link code)
         if (a.shallow) hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(hash_deep_kernel, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl, deep_levels);
+        if (a.shallow) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl, deep_levels);
+        else hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl, deep_levels);
         if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
         if (a.shallow) {
             hipLaunchKernelGGL(dedup_kernel, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);
@@ -1396,7 +1407,8 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
         if (a.shallow) hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(walk_kernel, dim3(pg), dim3(256), 0, st, a);
+    if (a.shallow) hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(walk_kernel<true>, dim3(pg), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
