@@ -18,7 +18,12 @@ class Context:
 
     def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
                  verify_nodedup: bool = False, dedup_levels: int | None = None):
-        """verify_fused / verify_nodedup: the A/B forms of the verify pipeline (one lane per proof; every shipped
+        """use_torch_stream: the ctx works on torch's current stream of the device (its launches are ordered with the torch
+        operations around them: the default, and what every mirror function that takes or returns a tensor assumes).  False:
+        a private stream -- device-form calls are then asynchronous on THAT stream and not ordered with torch's; the caller
+        fences both ways (`torch.cuda.current_stream().synchronize()` before handing over tensors torch is still producing,
+        `ctx.sync()` before torch reads a result).
+        verify_fused / verify_nodedup: the A/B forms of the verify pipeline (one lane per proof; every shipped
         node hashed).  dedup_levels: how many trie levels from the root the two-tier pipeline deduplicates
         (None = chosen from the batch size; PHANT_CTX_DEDUP_LEVELS)."""
         lib = L.lib()

@@ -11,9 +11,11 @@
 #include <sanitizer/asan_interface.h>
 #define PHANT_ARENA_POISON(p, n) ASAN_POISON_MEMORY_REGION((p), (n))
 #define PHANT_ARENA_UNPOISON(p, n) ASAN_UNPOISON_MEMORY_REGION((p), (n))
+#define PHANT_ARENA_POISONS 1  // (a copy may then not span several sub-allocations: it would touch the padding)
 #else
 #define PHANT_ARENA_POISON(p, n) ((void)0)
 #define PHANT_ARENA_UNPOISON(p, n) ((void)0)
+#define PHANT_ARENA_POISONS 0
 #endif
 
 namespace phant {

@@ -42,6 +42,9 @@ struct phant_ctx {
         phant::DevArena io, dv;
         bool busy = false;
     } slots[PHANT_MAX_SLOTS];
+    // pinned staging of the host-form verify call for small batches: the caller's arrays are packed into it and cross the bus
+    // in ONE copy each way (pageable hipMemcpyAsync costs ~25 us a piece, a call has nine of them)
+    uint8_t* stage = nullptr;
     // stream-side timing of the last device-form call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -186,6 +189,7 @@ void phant_ctx_destroy(phant_ctx* c) {
     c->dv.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stage) (void)hipHostFree(c->stage);
     for (auto& sl : c->slots) {
         if (sl.stream) {
             (void)hipStreamSynchronize(sl.stream);
@@ -467,12 +471,26 @@ static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_
 
 // Stage a host witness into `io` on stream `s`, run the pipeline there and queue the copies of the results
 // back into the caller's buffers.  Does NOT wait.
+// Results of a call that went through the pinned staging buffer: where they wait for the stream to finish
+constexpr size_t STAGE_BYTES = 8u << 20;
+struct StagedResults {
+    const uint8_t *status = nullptr, *value_off = nullptr, *value_len = nullptr;  // inside c->stage (null: not staged)
+};
+static void deliver_staged(const StagedResults& r, uint32_t n, uint8_t* status, uint64_t* value_off, uint32_t* value_len) {
+    if (!r.status) return;
+    std::memcpy(status, r.status, n);
+    if (value_off) std::memcpy(value_off, r.value_off, (size_t)n * 8);
+    if (value_len) std::memcpy(value_len, r.value_len, (size_t)n * 4);
+}
+
 static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& io, phant::DevArena& dv,
                                  const phant::FlatSide* side, bool timed, const uint8_t* roots, uint32_t n_roots,
                                  const uint32_t* root_idx, const uint8_t* keys, uint32_t key_len, const uint8_t* nodes,
                                  uint64_t nodes_len, const uint64_t* node_off, const uint32_t* proof_first_node,
                                  uint32_t n, uint8_t* status, uint64_t* value_off, uint32_t* value_len,
-                                 uint32_t** d_fail_out = nullptr /* != null: the per-root verdict, left on the device */) {
+                                 uint32_t** d_fail_out = nullptr /* != null: the per-root verdict, left on the device */,
+                                 StagedResults* staged_out = nullptr /* != null: small batches may go through c->stage; the
+                                 caller then synchronises the stream and calls deliver_staged() */) {
     // The number of node offsets the caller provided is what the LAST entry of proof_first_node says
     // (include/phant_gpu.h): node_off has proof_first_node[n] + 1 entries.  An earlier entry that points
     // beyond it makes its proofs BAD_INPUT on the device; it never widens what is read from the caller.
@@ -496,14 +514,37 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
     uint64_t* d_voff = io.take<uint64_t>(n);
     uint32_t* d_vlen = io.take<uint32_t>(n);
     uint32_t* d_fail = io.take<uint32_t>(n_roots);
-    HIP_TRY(c, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 32, hipMemcpyHostToDevice, s));
-    if (root_idx) HIP_TRY(c, hipMemcpyAsync(d_ridx, root_idx, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
-    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nodes_len, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d_noff, node_off, ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d_pfn, proof_first_node, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+    // Small batches (the witness of an ordinary block): the arena's layout mirrored in pinned memory, one copy in, one out
+    const bool staged = staged_out != nullptr && need <= STAGE_BYTES;
+    if (staged && !c->stage) {
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->stage), STAGE_BYTES, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipHostMalloc(staging)", e);
+    }
+    auto put = [&](void* d_dst, const void* src, size_t bytes) -> hipError_t {
+        if (!bytes) return hipSuccess;
+        if (!staged) return hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s);
+        uint8_t* const h = c->stage + (static_cast<uint8_t*>(d_dst) - io.base);
+        std::memcpy(h, src, bytes);
+        // (sanitizer test builds poison the arena's padding: array by array there)
+        return PHANT_ARENA_POISONS ? hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+    };
+    HIP_TRY(c, put(d_roots, roots, (size_t)n_roots * 32));
+    if (root_idx) HIP_TRY(c, put(d_ridx, root_idx, (size_t)n * 4));
+    if (key_len) HIP_TRY(c, put(d_keys, keys, (size_t)n * key_len));
+    if (nodes_len) HIP_TRY(c, put(d_nodes, nodes, (size_t)nodes_len));
+    HIP_TRY(c, put(d_noff, node_off, ((size_t)total_nodes + 1) * 8));
+    HIP_TRY(c, put(d_pfn, proof_first_node, ((size_t)n + 1) * 4));
+    if (staged && !PHANT_ARENA_POISONS)  // [roots .. proof_first_node]: consecutive allocations of the arena
+        HIP_TRY(c, hipMemcpyAsync(io.base, c->stage, (size_t)(reinterpret_cast<uint8_t*>(d_pfn + n + 1) - io.base), hipMemcpyHostToDevice, s));
     phant::VerifyArgs a{d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
                         d_noff, d_pfn, n, d_status, d_voff, d_vlen};
+    if (staged) {
+        // the results are written straight into the pinned buffer (hipHostMalloc memory is mapped into the device's address
+        // space and coherent): no copy back, the caller's stream synchronisation makes them visible
+        a.status = c->stage + (d_status - io.base);
+        a.value_off = reinterpret_cast<uint64_t*>(c->stage + (reinterpret_cast<uint8_t*>(d_voff) - io.base));
+        a.value_len = reinterpret_cast<uint32_t*>(c->stage + (reinterpret_cast<uint8_t*>(d_vlen) - io.base));
+    }
     if (d_fail_out) {
         *d_fail_out = d_fail;
         if (c->verify_fused) {  // the one-lane-per-proof A/B kernel has no tail kernel to carry the verdict
@@ -518,6 +559,12 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
     } else {
         const int32_t vrc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
         if (vrc) return vrc;
+    }
+    if (staged) {  // [status .. value_len]: consecutive as well
+        staged_out->status = a.status;
+        staged_out->value_off = reinterpret_cast<const uint8_t*>(a.value_off);
+        staged_out->value_len = reinterpret_cast<const uint8_t*>(a.value_len);
+        return PHANT_OK;
     }
     HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
     if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
@@ -594,11 +641,13 @@ int32_t phant_mpt_verify_batch(phant_ctx* c, const uint8_t* roots, uint32_t n_ro
         const int32_t src = ensure_side(c);
         if (src) return src;
     }
+    StagedResults staged;
     const int32_t rc = verify_host_async(c, c->stream, c->ws.io, c->dv, &c->side, true, roots, n_roots, root_idx, keys,
                                          key_len, nodes, nodes_len, node_off, proof_first_node, n, status, value_off,
-                                         value_len);
+                                         value_len, nullptr, &staged);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    deliver_staged(staged, n, status, value_off, value_len);
     return PHANT_OK;
 }
 
