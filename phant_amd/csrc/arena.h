@@ -65,10 +65,26 @@ struct Workspaces {
     DevArena io;  // staged inputs / outputs of the current call
     DevArena t1;  // trie builder: per-key / per-boundary arrays
     DevArena t2;  // trie builder: slot tables + encoding scratch
+    // Pinned mirror of the first STAGE_BYTES of `io` for SMALL host-form calls: the caller's pageable arrays are packed into
+    // it at the offsets their device copies have in the arena and cross the bus in ONE copy (a pageable hipMemcpyAsync costs
+    // ~25 us a piece, and a call has five to nine); it is mapped into the device's address space, so small results can be
+    // written straight into it.  Only by calls that end with a stream synchronisation (the next call overwrites it).
+    static constexpr size_t STAGE_BYTES = 8u << 20;
+    uint8_t* stage = nullptr;
+    hipError_t ensure_stage() {
+        return stage ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&stage), STAGE_BYTES, hipHostMallocDefault);
+    }
+    // the pinned twin of a device address inside `io`
+    template <class T>
+    T* staged(T* d) const {
+        return reinterpret_cast<T*>(stage + (reinterpret_cast<const uint8_t*>(d) - io.base));
+    }
     void release() {
         io.release();
         t1.release();
         t2.release();
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr;
     }
 };
 

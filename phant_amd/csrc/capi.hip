@@ -42,9 +42,6 @@ struct phant_ctx {
         phant::DevArena io, dv;
         bool busy = false;
     } slots[PHANT_MAX_SLOTS];
-    // pinned staging of the host-form verify call for small batches: the caller's arrays are packed into it and cross the bus
-    // in ONE copy each way (pageable hipMemcpyAsync costs ~25 us a piece, a call has nine of them)
-    uint8_t* stage = nullptr;
     // stream-side timing of the last device-form call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -189,7 +186,6 @@ void phant_ctx_destroy(phant_ctx* c) {
     c->dv.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stage) (void)hipHostFree(c->stage);
     for (auto& sl : c->slots) {
         if (sl.stream) {
             (void)hipStreamSynchronize(sl.stream);
@@ -472,9 +468,8 @@ static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_
 // Stage a host witness into `io` on stream `s`, run the pipeline there and queue the copies of the results
 // back into the caller's buffers.  Does NOT wait.
 // Results of a call that went through the pinned staging buffer: where they wait for the stream to finish
-constexpr size_t STAGE_BYTES = 8u << 20;
 struct StagedResults {
-    const uint8_t *status = nullptr, *value_off = nullptr, *value_len = nullptr;  // inside c->stage (null: not staged)
+    const uint8_t *status = nullptr, *value_off = nullptr, *value_len = nullptr;  // inside c->ws.stage (null: not staged)
 };
 static void deliver_staged(const StagedResults& r, uint32_t n, uint8_t* status, uint64_t* value_off, uint32_t* value_len) {
     if (!r.status) return;
@@ -489,7 +484,7 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
                                  uint64_t nodes_len, const uint64_t* node_off, const uint32_t* proof_first_node,
                                  uint32_t n, uint8_t* status, uint64_t* value_off, uint32_t* value_len,
                                  uint32_t** d_fail_out = nullptr /* != null: the per-root verdict, left on the device */,
-                                 StagedResults* staged_out = nullptr /* != null: small batches may go through c->stage; the
+                                 StagedResults* staged_out = nullptr /* != null: small batches may go through c->ws.stage; the
                                  caller then synchronises the stream and calls deliver_staged() */) {
     // The number of node offsets the caller provided is what the LAST entry of proof_first_node says
     // (include/phant_gpu.h): node_off has proof_first_node[n] + 1 entries.  An earlier entry that points
@@ -515,15 +510,15 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
     uint32_t* d_vlen = io.take<uint32_t>(n);
     uint32_t* d_fail = io.take<uint32_t>(n_roots);
     // Small batches (the witness of an ordinary block): the arena's layout mirrored in pinned memory, one copy in, one out
-    const bool staged = staged_out != nullptr && need <= STAGE_BYTES;
-    if (staged && !c->stage) {
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->stage), STAGE_BYTES, hipHostMallocDefault);
+    const bool staged = staged_out != nullptr && &io == &c->ws.io && need <= phant::Workspaces::STAGE_BYTES;
+    if (staged) {
+        hipError_t e = c->ws.ensure_stage();
         if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipHostMalloc(staging)", e);
     }
     auto put = [&](void* d_dst, const void* src, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
         if (!staged) return hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, s);
-        uint8_t* const h = c->stage + (static_cast<uint8_t*>(d_dst) - io.base);
+        uint8_t* const h = c->ws.staged(static_cast<uint8_t*>(d_dst));
         std::memcpy(h, src, bytes);
         // (sanitizer test builds poison the arena's padding: array by array there)
         return PHANT_ARENA_POISONS ? hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
@@ -535,15 +530,15 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
     HIP_TRY(c, put(d_noff, node_off, ((size_t)total_nodes + 1) * 8));
     HIP_TRY(c, put(d_pfn, proof_first_node, ((size_t)n + 1) * 4));
     if (staged && !PHANT_ARENA_POISONS)  // [roots .. proof_first_node]: consecutive allocations of the arena
-        HIP_TRY(c, hipMemcpyAsync(io.base, c->stage, (size_t)(reinterpret_cast<uint8_t*>(d_pfn + n + 1) - io.base), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(io.base, c->ws.stage, (size_t)(reinterpret_cast<uint8_t*>(d_pfn + n + 1) - io.base), hipMemcpyHostToDevice, s));
     phant::VerifyArgs a{d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
                         d_noff, d_pfn, n, d_status, d_voff, d_vlen};
     if (staged) {
         // the results are written straight into the pinned buffer (hipHostMalloc memory is mapped into the device's address
         // space and coherent): no copy back, the caller's stream synchronisation makes them visible
-        a.status = c->stage + (d_status - io.base);
-        a.value_off = reinterpret_cast<uint64_t*>(c->stage + (reinterpret_cast<uint8_t*>(d_voff) - io.base));
-        a.value_len = reinterpret_cast<uint32_t*>(c->stage + (reinterpret_cast<uint8_t*>(d_vlen) - io.base));
+        a.status = c->ws.staged(d_status);
+        a.value_off = c->ws.staged(d_voff);
+        a.value_len = c->ws.staged(d_vlen);
     }
     if (d_fail_out) {
         *d_fail_out = d_fail;

@@ -791,17 +791,38 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
     uint32_t* d_enc_len = ws.io.take<uint32_t>(n_tries);
     const bool want_enc = root_enc_out && root_enc_len_out && root_enc_cap;
     if (want_enc) TB_TRY(hipMemsetAsync(d_enc_len, 0, (size_t)n_tries * 4, st));
-    std::vector<uint32_t> ko((size_t)n + 1, 0);
-    std::vector<uint64_t> vo((size_t)n + 1, 0);
-    for (uint32_t i = 0; i <= n && n; ++i) {
-        ko[i] = key_off[i] - key_off[0];
-        vo[i] = val_off[i] - val_off[0];
+    // Small calls (the tries of an ordinary block): the five input arrays are laid out in the pinned mirror of the arena and cross
+    // the bus in one copy; the offsets are rebased in place there (Workspaces::stage)
+    const size_t in_span = (size_t)(reinterpret_cast<uint8_t*>(d_seg + n_tries + 1) - ws.io.base);
+    const bool staged = !PHANT_ARENA_POISONS && in_span <= Workspaces::STAGE_BYTES;
+    if (staged) {
+        TB_TRY(ws.ensure_stage());
+        if (kb) std::memcpy(ws.staged(d_keys), keys + key_off[0], kb);
+        if (vb) std::memcpy(ws.staged(d_vals), vals + val_off[0], vb);
+        uint32_t* const ko = ws.staged(d_koff);
+        uint64_t* const vo = ws.staged(d_voff);
+        ko[0] = 0;
+        vo[0] = 0;
+        for (uint32_t i = 0; i <= n && n; ++i) {
+            ko[i] = key_off[i] - key_off[0];
+            vo[i] = val_off[i] - val_off[0];
+        }
+        std::memcpy(ws.staged(d_seg), seg_first, ((size_t)n_tries + 1) * 4);
+        TB_TRY(hipMemcpyAsync(ws.io.base, ws.stage, in_span, hipMemcpyHostToDevice, st));
+    } else {
+        std::vector<uint32_t> ko((size_t)n + 1, 0);
+        std::vector<uint64_t> vo((size_t)n + 1, 0);
+        for (uint32_t i = 0; i <= n && n; ++i) {
+            ko[i] = key_off[i] - key_off[0];
+            vo[i] = val_off[i] - val_off[0];
+        }
+        if (kb) TB_TRY(hipMemcpyAsync(d_keys, keys + key_off[0], kb, hipMemcpyHostToDevice, st));
+        if (vb) TB_TRY(hipMemcpyAsync(d_vals, vals + val_off[0], vb, hipMemcpyHostToDevice, st));
+        TB_TRY(hipMemcpyAsync(d_koff, ko.data(), ko.size() * 4, hipMemcpyHostToDevice, st));
+        TB_TRY(hipMemcpyAsync(d_voff, vo.data(), vo.size() * 8, hipMemcpyHostToDevice, st));
+        TB_TRY(hipMemcpyAsync(d_seg, seg_first, ((size_t)n_tries + 1) * 4, hipMemcpyHostToDevice, st));
+        // (pageable sources: hipMemcpyAsync has taken its copy of ko / vo when it returns)
     }
-    if (kb) TB_TRY(hipMemcpyAsync(d_keys, keys + key_off[0], kb, hipMemcpyHostToDevice, st));
-    if (vb) TB_TRY(hipMemcpyAsync(d_vals, vals + val_off[0], vb, hipMemcpyHostToDevice, st));
-    TB_TRY(hipMemcpyAsync(d_koff, ko.data(), ko.size() * 4, hipMemcpyHostToDevice, st));
-    TB_TRY(hipMemcpyAsync(d_voff, vo.data(), vo.size() * 8, hipMemcpyHostToDevice, st));
-    TB_TRY(hipMemcpyAsync(d_seg, seg_first, ((size_t)n_tries + 1) * 4, hipMemcpyHostToDevice, st));
     int32_t rc = forest_device(ws, st, d_keys, d_koff, d_vals, d_voff, n, kb, vb, d_seg, n_tries, d_roots, err,
                                want_enc ? d_enc : nullptr, want_enc ? d_enc_len : nullptr, want_enc ? root_enc_cap : 0u);
     if (rc) {
