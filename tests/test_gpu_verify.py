@@ -199,6 +199,28 @@ def test_garbage_committed_roots(M, oracle):
     _assert_same(got, want)
 
 
+@pytest.mark.parametrize("n", [1500, 2100])
+def test_host_form_on_both_sides_of_the_staging_limit(M, oracle, n):
+    """phant_mpt_verify_batch packs the arrays of a call of up to 8 MiB into one pinned buffer (one copy in, results written
+    straight into it), larger calls copy array by array: ~3.6 KB leaves make 1 500 proofs a 7.5 MB call, 2 100 proofs a 10.5 MB one.
+    Same statuses and value locations as the oracle on both sides, present and absent keys."""
+    if M.mode not in ("flat", "levels3"):
+        pytest.skip("one chosen and one forced tier split are enough here")
+    rng = np.random.default_rng(n)
+    keys, _ = random_kv(rng, n, 32, 1, 2, 0)
+    vals = [rng.integers(0, 256, 3500 + int(rng.integers(0, 200)), dtype=np.uint8).tobytes() for _ in keys]
+    t = oracle.Trie(keys, vals)
+    q = list(keys) + [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(50)]
+    proofs = [t.prove(k) for k in q]
+    nodes, _, _ = pack_proofs(proofs)
+    assert (nodes.size < (8 << 20) - (512 << 10)) == (n == 1500) and (nodes.size > (8 << 20)) == (n == 2100)
+    got, want = _both(M, oracle, [t.root()], None, q, 32, proofs)
+    _assert_same(got, want)
+    assert (got[0][:n] == M.PROOF_PRESENT).all() and (got[0][n:] == M.PROOF_ABSENT).all()
+    for i in (0, n // 2, n - 1):
+        assert nodes[int(got[1][i]):int(got[1][i]) + int(got[2][i])].tobytes() == vals[i]
+
+
 def test_bad_offsets_are_flagged(M, oracle):
     root = np.zeros(32, np.uint8)
     keys = np.zeros(64, np.uint8)
