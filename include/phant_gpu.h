@@ -84,7 +84,8 @@ typedef struct phant_ctx phant_ctx;
                                        batch carries byte-identical copies (A/B; = PHANT_CTX_DEDUP_LEVELS(0)) */
 /* flags: how many trie levels, counted from the root, the verify pipeline deduplicates across the proofs of a
  * batch (byte-compares copies instead of hashing them); deeper nodes are hashed in place.  Default (field 0):
- * chosen from the batch size -- levels with fewer groups than proofs.  Correctness does not depend on it. */
+ * chosen from the batch -- none for batches of less than 72 MB of nodes (the chip hashes those whole in a few rounds
+ * of waves), otherwise the levels with fewer groups than proofs.  Correctness does not depend on it. */
 #define PHANT_CTX_DEDUP_LEVELS_SHIFT 8
 #define PHANT_CTX_DEDUP_LEVELS_MASK 0x1f00u
 #define PHANT_CTX_DEDUP_LEVELS(n) ((((uint32_t)(n) + 1u) << PHANT_CTX_DEDUP_LEVELS_SHIFT) & PHANT_CTX_DEDUP_LEVELS_MASK)
