@@ -465,8 +465,6 @@ static int32_t verify_resident(phant_ctx* c, const phant::VerifyArgs& a, uint32_
     return verify_resident_on(c, a, total_nodes, c->stream, c->dv, &c->side, true);
 }
 
-// Stage a host witness into `io` on stream `s`, run the pipeline there and queue the copies of the results
-// back into the caller's buffers.  Does NOT wait.
 // Results of a call that went through the pinned staging buffer: where they wait for the stream to finish
 struct StagedResults {
     const uint8_t *status = nullptr, *value_off = nullptr, *value_len = nullptr;  // inside c->ws.stage (null: not staged)
@@ -478,6 +476,8 @@ static void deliver_staged(const StagedResults& r, uint32_t n, uint8_t* status, 
     if (value_len) std::memcpy(value_len, r.value_len, (size_t)n * 4);
 }
 
+// Stage a host witness into `io` on stream `s`, run the pipeline there and queue the copies of the results
+// back into the caller's buffers (or, staged_out given and the call small, leave them in the pinned buffer).  Does NOT wait.
 static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& io, phant::DevArena& dv,
                                  const phant::FlatSide* side, bool timed, const uint8_t* roots, uint32_t n_roots,
                                  const uint32_t* root_idx, const uint8_t* keys, uint32_t key_len, const uint8_t* nodes,
