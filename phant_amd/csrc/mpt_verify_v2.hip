@@ -691,6 +691,9 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t level = w / waves_per_level;  // 0 .. levels - 1
+    // (the grid is whole workgroups: up to three waves behind the last level would take "level = levels" -- the depths the
+    // first level's waves come back for -- and hash those nodes a second time)
+    if (level >= levels) return;
     const uint32_t p = (w % waves_per_level) * 64u + lane;
     const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
     const uint32_t nn = 2u * a.v.key_len;

@@ -29,7 +29,7 @@ def M(request):
 from tests.test_gpu_verify import (  # noqa: E402,F401
     test_reference_vector_tries, test_random_tries, test_embedded_nodes_and_branch_values,
     test_mutation_fuzz_matches_oracle, test_garbage_committed_roots, test_bad_offsets_are_flagged,
-    test_host_form_on_both_sides_of_the_staging_limit,
+    test_host_form_on_both_sides_of_the_staging_limit, test_which_nodes_get_hashed_per_tier_split,
     test_empty_trie_proves_absence, test_one_byte_off_in_a_duplicate_node,
     test_non_monotone_proof_first_node_matches_oracle, test_synthetic_depth8_small_vs_oracle,
     test_synthetic_other_depths, test_block_witness_accounts_and_storage)

@@ -221,6 +221,26 @@ def test_host_form_on_both_sides_of_the_staging_limit(M, oracle, n):
         assert nodes[int(got[1][i]):int(got[1][i]) + int(got[2][i])].tobytes() == vals[i]
 
 
+def test_which_nodes_get_hashed_per_tier_split(M, oracle):
+    """300 proofs through one 300-key trie share their upper nodes.  A small batch with the tier split chosen by the launcher is
+    hashed whole (S = 0: every shipped node), as with deduplication switched off; with a forced split the copies of the levels
+    above it are compared instead of hashed (phant_verify_stats)."""
+    if M.mode == "fused":
+        pytest.skip("the one-lane-per-proof kernel keeps no per-node statistics")
+    rng = np.random.default_rng(5)
+    keys, vals = random_kv(rng, 300, 32, 1, 60, 0)
+    t = oracle.Trie(keys, vals)
+    proofs = [t.prove(k) for k in keys]
+    got, want = _both(M, oracle, [t.root()], None, keys, 32, proofs)
+    _assert_same(got, want)
+    shipped = sum(len(p) for p in proofs)
+    hashed = sum(M._ctx.verify_stats())
+    if M.mode in ("flat", "nodedup"):
+        assert hashed == shipped
+    else:  # levels1 / levels3 / levels16: at least the 299 copies of the root node are not hashed
+        assert hashed <= shipped - 299, (M.mode, hashed, shipped)
+
+
 def test_bad_offsets_are_flagged(M, oracle):
     root = np.zeros(32, np.uint8)
     keys = np.zeros(64, np.uint8)
