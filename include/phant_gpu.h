@@ -211,7 +211,9 @@ PHANT_API int32_t phant_mpt_verify_verdict_dev(phant_ctx *ctx, const uint8_t *d_
                                                uint32_t *d_value_len, uint32_t *d_fail_count);
 /* One verdict per root: d_fail_count[r] = number of proofs against root r
  * whose status is not PRESENT/ABSENT (n_roots x u32, overwritten).  This is
- * the word each rank all-reduces in the multi-GPU path. */
+ * the word each rank all-reduces in the multi-GPU path.  A proof whose root
+ * index is out of range (its status is BAD_INPUT) is counted against root 0,
+ * so that an all-zero verdict always means "every proof passed". */
 PHANT_API int32_t phant_mpt_verdict_dev(phant_ctx *ctx, const uint8_t *d_status,
                                         const uint32_t *d_root_idx, uint32_t n, uint32_t n_roots,
                                         uint32_t *d_fail_count);
@@ -272,7 +274,8 @@ PHANT_API uint32_t phant_comm_owner(const phant_comm *comm, const uint8_t *key, 
  * caller's proof order, value_off into the caller's node blob) + fail_count[r] (n_roots, may be NULL) = proofs against
  * root r that are not PRESENT / ABSENT, summed over the devices by the all-reduce: the "one pass/fail per root".
  * The index arrays are read on the host here (the witness is re-packed per device): inconsistent proof_first_node /
- * node_off make the CALL fail with PHANT_E_INVALID_ARG instead of costing single proofs a BAD_INPUT. */
+ * node_off, or a root_idx entry >= n_roots, make the CALL fail with PHANT_E_INVALID_ARG instead of costing single
+ * proofs a BAD_INPUT. */
 PHANT_API int32_t phant_mpt_verify_sharded(phant_comm *comm, const uint8_t *roots, uint32_t n_roots,
                                            const uint32_t *root_idx, const uint8_t *keys, uint32_t key_len,
                                            const uint8_t *nodes, uint64_t nodes_len, const uint64_t *node_off,

@@ -430,6 +430,9 @@ int32_t phant_mpt_verify_sharded(phant_comm* c, const uint8_t* roots, uint32_t n
     for (uint32_t j = 0; j < total_nodes; ++j)
         if (node_off[j + 1] < node_off[j] || node_off[j + 1] > nodes_len || node_off[j + 1] - node_off[j] > 0x7fffffffull)
             return cfail(c, PHANT_E_INVALID_ARG, "mpt_verify_sharded: node_off is inconsistent");
+    if (root_idx)
+        for (uint32_t i = 0; i < n; ++i)
+            if (root_idx[i] >= n_roots) return cfail(c, PHANT_E_INVALID_ARG, "mpt_verify_sharded: root_idx out of range");
 
     // ---- deal the proofs out ----
     for (Shard& s : c->shards) {

@@ -64,9 +64,19 @@ struct VerifyTune {
     // 0.237 at 40 KiB, 0.250 at 52 KiB = 3 waves).  Alone, the deep tier is launched without it.
     uint32_t hash_lds = 40u * 1024u;
     bool serial = false;  // diagnostics: the tiers one after the other on the ctx stream (clean per-kernel durations in a trace)
+    uint32_t pipe = 3;    // A/B while both exist: 3 = mpt_verify_v3.hip (propose / elect / compare next to one hash kernel / walk),
+                          // 2 = round 2's seven-launch chain (mpt_verify_v2.hip)
 };
 hipError_t launch_mpt_verify(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
                              hipStream_t st, const FlatSide* side, const VerifyTune& tune);
+// round 3's pipeline (mpt_verify_v3.hip), same contract
+size_t verify_workspace_bytes_v3(uint32_t total_nodes);
+hipError_t launch_mpt_verify_v3(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
+                                hipStream_t st, const FlatSide* side, const VerifyTune& tune);
+void verify_stats_from_header_v3(const uint32_t* hdr, uint32_t hashed[8]);
+void verify_paths_from_header_v3(const uint32_t* hdr, uint32_t out[2]);
+size_t verify_nodeset_workspace_bytes_v3(uint32_t total_nodes);
+hipError_t launch_mpt_verify_nodeset_v3(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, hipStream_t st);
 // nodes hashed per rate-block class by the last launch, from a host copy of the workspace's first
 // VERIFY_HEADER_WORDS words
 constexpr uint32_t VERIFY_HEADER_WORDS = 160;

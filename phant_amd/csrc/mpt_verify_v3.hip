@@ -1,63 +1,71 @@
-// mpt_verify_v2.hip -- batched proof verification, two-tier pipeline.
+// mpt_verify_v3.hip -- batched proof verification, two-tier pipeline (round 3).
 //
-// A witness ships every proof as its own node list, so the upper trie levels arrive many times over
-// (BASELINE config 3: 800 k shipped nodes, ~354 k distinct), while the lower levels are all but unique.
-// Keccak-f is integer-VALU-bound on gfx950, comparing two nodes is a memory stream.
-// So the batch is cut at a depth S ("shallow levels", chosen on the host from the batch size):
+// A witness ships every proof as its own node list, so the upper trie levels arrive many times over (BASELINE config 3:
+// 800 k shipped nodes, ~354 k distinct), while the lower levels are all but unique.  Keccak-f is integer-VALU-bound on
+// gfx950, comparing two nodes is a memory stream.  So the batch is cut at a depth S ("shallow
+// levels", chosen on the host from the batch size):
 //
-//   deep tier (depth >= S): nothing to deduplicate.  hash_deep_kernel hashes these nodes in place -- wave =
-//        64 consecutive proofs at one depth, lane = proof -- with no planning, no lists and no table in front
-//        of it: it starts at once, on the helper stream, and is the VALU-bound bulk of the launch.
-//   shallow tier (depth < S), on the main stream, NEXT TO the deep tier (a memory stream beside VALU work):
-//        plan_kernel      one lane per proof: stamps every node with depth + key nibble, shallow nodes also
-//                         with the 64-bit key of their (root, depth, key-prefix) group; every multi-block
-//                         shallow node proposes itself as its group's representative in a 2-choice table
-//                         (plain stores, last writer wins -- correctness never depends on who wins).
-//        dedup_kernel     one lane per node looks its group up; a wave then reads the nodes that HAVE a
-//                         representative, 16 bytes per lane (coalesced), next to the representative's bytes
-//                         (L2 / Infinity-Cache hits).  Equal => rep[j] = representative (never hashed);
-//                         otherwise the node is listed for hashing, compacted per rate-block class.
-//        hash_list_kernel one lane per listed node, one 64-node chunk of one class per wave.
-//   Both hash kernels also settle, while the digest is still in registers, whether the node is what its
-//   parent commits to: the parent of node j inside a proof is node j - 1, and if that is a full 532-byte
-//   branch the reference for this key's nibble sits at a fixed place in its bytes (root nodes: the root
-//   table).  One status byte per hashed node (nstat[]): hashed / canonical full branch / link checked / ok.
-//        link_kernel      one lane per node: the walk's code for node j.  A hashed node reads its own nstat;
-//                         a copy inherits its representative's when their parents are the same bytes and the
-//                         same key nibble (cheap gathers from a few hot lines instead of 64 bytes per node).
-//        walk_kernel      one lane per proof steps over the run of nodes link_kernel settled and decodes the
-//                         rest (DESIGN.md section 3 order of checks) from an LDS copy -- for BASELINE's proofs
-//                         just the leaf; counts the per-root verdict; the (never seen) proof that cannot be
-//                         settled from the tables is verified from scratch by its lane (verify_one, a rare branch
-//                         of the same kernel: a kernel of its own cost 5 us per launch for nothing).
+//   shallow tier (node index d < S inside its proof): copies are COMPARED with one representative per
+//   (root, d, first d key nibbles) group instead of being hashed.
+//        propose_kernel   one lane per (proof, d < S): every multi-block node writes itself into its group's table slot
+//                         (plain stores, last writer wins -- no atomics, so a group of 100 000 members costs what a group
+//                         of one does); the kernel also clears the header, the node states and the verdict counters.
+//        elect_kernel     the same lanes read the slot back: the node found there is the group's representative.  It and
+//                         every node without a group are LISTED for hashing (per rate-block class, with the proof they
+//                         belong to); a copy goes to the compare list with its representative.  rep[j] for every node.
+//        compare_kernel   dense over the compare list: a half wave per 532-byte copy, 16 bytes per lane, coalesced, next
+//                         to the representative's bytes (L2 / Infinity-Cache hits).  A copy that differs gets rep[j] = j:
+//                         nobody hashed it, the walk that meets it hashes it itself (damaged proofs only).
+//   hash_kernel (helper stream, NEXT TO compare_kernel; it starts when the lists are complete): one kernel for everything
+//        that is hashed --
+//          list role      one 64-node chunk of one class list per wave (the shallow tier's representatives),
+//          deep role      wave = 64 consecutive proofs at one depth >= S, lane = proof: nothing is looked up, a proof's
+//                         node at depth d is node proof_first_node[p] + d, its key nibble comes from the key.
+//        Both settle, while the digest is still in registers, whether the node is what its parent commits to: the parent
+//        of node j inside a proof is node j - 1, and if that is a full 532-byte branch the reference for this key's nibble
+//        sits at byte 4 + 33 nibble (root nodes: the root table).  One status byte per hashed node (nstat[]).
+//   walk_kernel          one lane per proof.  Steps over the run of nodes whose state says "hash matches, canonical full
+//                         branch" -- a copy takes its representative's state when it was the same comparison (below) --
+//                         and decodes the rest (DESIGN.md section 3 order of checks) from an LDS copy: for BASELINE's
+//                         proofs just the leaf.  Counts the per-root verdict.
 //
-//   S = 0 (small batches: under 72 MB of nodes the chip hashes everything in a few rounds of waves, and the shallow tier's
-//   kernels cost more than they save): zero_kernel, hash_deep_kernel over every depth, walk_kernel -- which then reads the
-//   node states directly: the lane that hashed a node knew the proof's key and parent, the depth a stamp would carry is the
-//   walk's own position.  No stamps, tables, lists, link codes or helper stream.
+//   S = 0 (small batches: under 72 MB of nodes the chip hashes everything in a few rounds of waves): zero_kernel,
+//   hash_kernel with the deep role over every depth, walk_kernel reading the node states directly.
 //
-// Soundness: rep[j] = r only if bytes(j) == bytes(r), checked byte for byte (so keccak(j) == digest[r]), and r
-// is only trusted when nstat[r] says r itself was hashed; the group key is only a hint where to look.  A copy
-// inherits a link result only if its parent is byte-identical to the representative's parent (same rep) and the
-// key nibble is the same, which makes it the same comparison.  A stamp is only used by the proof that wrote it
-// (node ranges of proofs are disjoint when proof_first_node is monotone -- otherwise every proof is verified
-// from scratch).
+// Round 2's pipeline (mpt_verify_v2.hip) had seven launches on its critical chain: zero, plan, dedup, hash_list, link, walk
+// with hash_deep beside them.  plan's per-node stamps and group keys (12 MB of stores), link's pass over every node and the
+// list kernel's 4-permutation latency chain BEHIND the comparison are gone: the chain is propose, elect, compare, walk, and
+// all hashing is one pool of waves that starts the moment the lists exist.
 //
-// What it computes: the verifier missing at src/engine_api/execution_payload.zig:177-178, over the node
-// encodings of src/mpt/mpt.zig:187-193,216-231,254-261,285-314.
+// Soundness.  rep[j] = r != j only if (i) r was found in the slot of j's group and belongs to that group -- by construction
+// for the direct-mapped levels (the slot index is an injective function of (root, d, prefix)), by checking r's owner proof
+// for the hashed levels (entry_matches) --, (ii) bytes(j) == bytes(r), compared byte for byte.  Every member of a group
+// reads the same slot after propose_kernel has finished, so r's own lane sees itself there and lists r for hashing.  A copy
+// inherits its representative's link result only if the representative's parent is byte-identical to its own parent (same
+// representative one level up) -- the key nibble is the same by (i) --, which makes it the same comparison; otherwise the
+// walk compares the representative's digest with the reference in its own parent.  rep[] / nstat[] of a node are only used
+// by the proof that owns it (node ranges of proofs are disjoint when proof_first_node is monotone -- otherwise every proof
+// is verified from scratch).  Table slots are never cleared: a slot is only read by nodes that wrote to it in this launch
+// (direct levels) or its content is validated against the witness (hashed levels), whatever an earlier launch left there.
+//
+// What it computes: the verifier missing at src/engine_api/execution_payload.zig:177-178, over the node encodings of
+// src/mpt/mpt.zig:187-193,216-231,254-261,285-314.
 #include <cstdlib>
 
 #include "launch.h"
 #include "mpt_verify_one.hip.h"
 
 namespace phant {
-namespace v2 {
+namespace v3 {
 
 constexpr uint32_t N_CLASS = 8;        // class c = (c+1) rate blocks; last class = 8 or more
 constexpr uint32_t LIST_B532 = 8;      // list of the nodes that are exactly 532 bytes long
 constexpr uint32_t N_LIST = 9;
+constexpr uint32_t COPY_B532 = 9;      // compare list: 532-byte copies {node, representative}
+constexpr uint32_t COPY_OTHER = 10;    // compare list: other multi-block copies
+constexpr uint32_t N_CURSOR = 11;
 constexpr uint32_t CLASS_NONE = 0xffu;
-constexpr uint32_t MAX_SHALLOW = 16;   // key prefix of <= 16 nibbles fits the 64-bit group key
+constexpr uint32_t MAX_SHALLOW = 16;   // key prefix of <= 16 nibbles fits 64 bits
 constexpr uint32_t STATUS_NEEDS_SLOW = 0xffu;
 constexpr uint32_t BRANCH_LEN = 532u;  // f9 02 11 | 16 x (a0 + 32 bytes) | 80
 
@@ -65,16 +73,17 @@ constexpr uint32_t BRANCH_LEN = 532u;  // f9 02 11 | 16 x (a0 + 32 bytes) | 80
 constexpr uint32_t HDR_PFN_BROKEN = 9;   // some proof has last < first
 constexpr uint32_t HDR_SLOW = 10;        // proofs verified from scratch by their walk lane (reporting only)
 constexpr uint32_t HDR_OPENED = 11;      // nodes decoded by walks that decoded more than one (reporting only)
-constexpr uint32_t HDR_STAT = 16;        // + 16 x stripe + class: nodes hashed by the deep tier (reporting only)
+constexpr uint32_t HDR_COPY_B532 = 12;   // entries of the two compare lists
+constexpr uint32_t HDR_COPY_OTHER = 13;
+constexpr uint32_t HDR_INLINE = 14;      // nodes hashed by a walk lane: copies that differ from their representative (reporting only)
+constexpr uint32_t HDR_STAT = 16;        // + 16 x stripe + class: nodes hashed by the deep role (reporting only)
 constexpr uint32_t HDR_STAT_STRIPES = 16;
 constexpr size_t HEADER_BYTES = 2048;
 
+PHANT_DEV uint32_t cursor_word(uint32_t cls) { return cls < N_LIST ? cls : HDR_COPY_B532 + (cls - COPY_B532); }
+
 // nstat[] bits
 constexpr uint32_t NS_HASHED = 1u, NS_CANON = 2u, NS_LINK_CHECKED = 4u, NS_LINK_OK = 8u;
-
-// plan_kernel -> node-parallel kernels, in meta[] (zeroed per call, so an unstamped node reads 0):
-// PRE_STAMP | PRE_NIB (nibble valid) | PRE_GROUP (shallow: rep[] / gkey[] valid) | nibble << 4 | depth << 8
-constexpr uint32_t PRE_NIB = 2u, PRE_GROUP = 4u, PRE_STAMP = 8u;
 
 PHANT_DEV uint32_t node_list(uint32_t len) {
     if (len == BRANCH_LEN) return LIST_B532;
@@ -84,6 +93,7 @@ PHANT_DEV uint32_t node_list(uint32_t len) {
 
 struct __attribute__((packed, aligned(1))) U32x4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U32x3 { uint32_t x, y, z; };
+struct __attribute__((packed, aligned(1))) U32x2 { uint32_t x, y; };
 struct __attribute__((packed, aligned(1))) U32x1 { uint32_t x; };
 PHANT_DEV uint4 load16u(const uint8_t* p) {  // unaligned 16-byte global load
     const U32x4 v = *reinterpret_cast<const U32x4*>(p);
@@ -104,8 +114,9 @@ PHANT_DEV uint64_t key_prefix64(const uint8_t* __restrict__ key, uint32_t key_le
     for (uint32_t t = 0; t < take; ++t) kb |= (uint64_t)key[t] << (56u - 8u * t);
     return kb;
 }
-// 64-bit group key of (root, depth, first `d` key nibbles); murmur3 finaliser.
-PHANT_DEV uint64_t group_key(uint64_t kb, uint32_t root, uint32_t d) {
+PHANT_DEV bool same_prefix(uint64_t x, uint64_t y, uint32_t d) { return d == 0u || ((x ^ y) >> (64u - 4u * d)) == 0ull; }
+// slot hash of (root, depth, first `d` key nibbles); murmur3 finaliser.
+PHANT_DEV uint64_t group_hash(uint64_t kb, uint32_t root, uint32_t d) {
     const uint64_t pre = d ? (kb >> (64u - 4u * d)) : 0ull;
     uint64_t h = pre ^ ((uint64_t)(d + 1u) << 58) ^ ((uint64_t)root * 0x9E3779B97F4A7C15ull);
     h ^= h >> 33;
@@ -115,11 +126,9 @@ PHANT_DEV uint64_t group_key(uint64_t kb, uint32_t root, uint32_t d) {
     h ^= h >> 33;
     return h;
 }
-// Where a group's representative is proposed and looked up.  The levels next to the root -- few groups, each with
-// very many members: losing one of them to a collision would cost thousands of hashes -- are direct-mapped: level d
-// of root r has 16^d slots of its own, [n_roots (16^d - 1) / 15 + r 16^d, + 16^d), indexed by the key prefix.  The
-// levels below them share a hashed 2-choice table (a group that loses both its slots is hashed copy by copy).
-constexpr uint64_t GK_DIRECT = 1ull << 63;
+// Where a group's representative is proposed and looked up.  The levels next to the root are direct-mapped: level d of
+// root r has 16^d slots of its own, [n_roots (16^d - 1) / 15 + r 16^d, + 16^d), indexed by the key prefix.  The levels
+// below them share a hashed 2-choice table (a group that finds both its slots taken by others is hashed copy by copy).
 PHANT_DEV uint32_t direct_index(uint64_t kb, uint32_t root, uint32_t d, uint32_t n_roots) {
     uint32_t width = 1u, below = 0u;  // 16^d, (16^d - 1) / 15
     for (uint32_t t = 0; t < d; ++t) {
@@ -129,45 +138,32 @@ PHANT_DEV uint32_t direct_index(uint64_t kb, uint32_t root, uint32_t d, uint32_t
     const uint32_t pre = d ? (uint32_t)(kb >> (64u - 4u * d)) : 0u;
     return n_roots * below + root * width + pre;
 }
-PHANT_DEV uint32_t gk_fp(uint64_t h) { return (uint32_t)(h >> 32) | 1u; }
-PHANT_DEV uint32_t gk_slot_a(uint64_t h, uint32_t mask) { return (uint32_t)h & mask; }
-PHANT_DEV uint32_t gk_slot_b(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 20) & mask; }
+PHANT_DEV uint32_t slot_a(uint64_t h, uint32_t mask) { return (uint32_t)h & mask; }
+PHANT_DEV uint32_t slot_b(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 24) & mask; }
 
 struct Args {
     VerifyArgs v;
     uint32_t total_nodes;
-    uint32_t shallow;        // nodes of depth < shallow are deduplicated and hashed from the class lists; the
-                             // others are hashed in place by hash_deep_kernel.  0 = hash every shipped node (A/B)
-    uint32_t all_listed;     // node-set witnesses: every valid node goes to the lists (no stamps, no links)
+    uint32_t shallow;        // nodes of index < shallow in their proof are deduplicated and hashed from the class lists;
+                             // the others are hashed in place by the deep role.  0 = hash every shipped node
+    uint32_t ds_log;         // the shallow tier's kernels give every proof 2^ds_log lanes (>= shallow)
     uint32_t direct;         // levels [0, direct) of the shallow tier have a direct-mapped table, the others the hashed one
-    uint32_t* dtab;          // n_roots x (16^direct - 1) / 15 entries: node + 1 of a member of the group (0: none), zeroed per call
-    uint64_t* table;         // tmask + 1 entries {fp:32 | node:32}, zeroed per call
+    uint32_t* dtab;          // n_roots x (16^direct - 1) / 15 entries: node + 1 of a member of the group
+    uint64_t* table;         // tmask + 1 entries {owner proof:32 | node + 1:32}
     uint32_t tmask;
-    uint32_t* rep;           // total_nodes; meaningful where meta[] says PRE_GROUP
-    uint32_t* meta;          // total_nodes, zeroed per call
-    uint64_t* gkey;          // total_nodes; meaningful where meta[] says PRE_GROUP: GK_DIRECT | index into dtab, or the
-                             // 64-bit key of the group for the hashed table
-    uint32_t* ent;           // N_LIST x total_nodes: node ids to hash, per list
+    uint32_t* rep;           // total_nodes; written for the shallow tier's nodes
+    uint2* ent;              // N_LIST x total_nodes: {node, owner proof} to hash, per list
+    uint2* cpy;              // 2 x total_nodes: {node, representative} to compare
     uint32_t* hdr;           // header: [0..8] list counts, HDR_*; zeroed per call
     uint32_t* digest;        // total_nodes x 8
     uint8_t* nstat;          // total_nodes: NS_* of the node, written by the lane that hashed it; zeroed per call
-    uint8_t* link;           // total_nodes (+ 16 readable): LINK_* code of link_kernel
 };
 
-// ---------------------------------------------------------------- plan
-// One lane per proof.  Stamps every node of the proof (up to the deepest position a walk can reach) with what
-// the node-parallel kernels need to know about its owner -- depth and the key nibble at that depth, shallow
-// nodes also the 64-bit key of their (root, depth, key prefix) group -- so that they never search for the
-// owning proof or touch the keys.  Every multi-block shallow node also proposes itself as the representative of
-// its group.  Plain stores: the last writer of a table slot wins.
-constexpr uint32_t PLAN_BATCH = 8;  // even: a batch starts on a key byte
-
-// The memory-bound kernels of the shallow tier run NEXT TO hash waves that never stop issuing: a few instructions,
-// then a wait for memory -- at equal priority they would only get the leftover issue slots.
+// The memory-bound kernels run NEXT TO hash waves that never stop issuing: a few instructions, then a wait for memory -- at
+// equal priority they would only get the leftover issue slots.
 PHANT_DEV void beside_the_hashing() { __builtin_amdgcn_s_setprio(3); }
 
-// header, tables, stamps, node states: zeroed per call (16 bytes per lane; bytes = multiple of 256) -- and, as the first
-// kernel of the launch, the verdict counters the walk will add to
+// header + node states (S = 0 form; the two-tier form clears them in propose_kernel) and the verdict counters
 __global__ void __launch_bounds__(256) zero_kernel(uint4* p, size_t n16, uint32_t* fail_count, uint32_t n_roots) {
     beside_the_hashing();
     const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
@@ -176,76 +172,148 @@ __global__ void __launch_bounds__(256) zero_kernel(uint4* p, size_t n16, uint32_
         for (size_t r = i; r < n_roots; r += (size_t)gridDim.x * 256u) fail_count[r] = 0u;
 }
 
-__global__ void __launch_bounds__(256) plan_kernel(const Args a) {
-    beside_the_hashing();
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= a.v.n) return;
-    const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
+// ---------------------------------------------------------------- the shallow tier's lanes
+// Lane g of propose_kernel / elect_kernel: proof g >> ds_log, node index g & (2^ds_log - 1) inside it.
+struct ShallowLane {
+    uint32_t p, d, j, root, len;
+    uint64_t kb;
+    bool act;      // node (p, d) exists, d < S, and a walk can get there (a walk consumes >= one nibble per hashed node)
+    bool valid;    // its offsets are usable
+    bool group;    // it takes part in the deduplication: multi-block node of a proof with a usable root index
+    bool broken;   // the proof's node range goes backwards (d == 0 lane only)
+};
+PHANT_DEV ShallowLane shallow_lane(const Args& a, uint32_t g) {
+    ShallowLane L;
+    L.p = g >> a.ds_log;
+    L.d = g & ((1u << a.ds_log) - 1u);
+    L.j = 0;
+    L.root = 0;
+    L.len = 0;
+    L.kb = 0;
+    L.act = L.valid = L.group = L.broken = false;
+    if (L.p >= a.v.n || L.d >= a.shallow) return L;
+    const uint32_t first = a.v.proof_first_node[L.p], last = a.v.proof_first_node[L.p + 1];
     if (last < first) {
-        // proof_first_node is not monotone: node ranges of OTHER proofs may then overlap, and a node stamped
-        // by one proof would be read by another.  Tell the walk not to trust anything derived from stamps.
-        a.hdr[HDR_PFN_BROKEN] = 1u;
-        return;  // BAD_INPUT: the walk reports it
+        L.broken = L.d == 0u;
+        return L;
     }
-    if (last > a.total_nodes) return;  // BAD_INPUT: the walk reports it
-    const uint32_t root = a.v.root_idx ? a.v.root_idx[p] : 0u;
-    const uint8_t* key = a.v.keys + (uint64_t)a.v.key_len * p;
-    const uint64_t kb = key_prefix64(key, a.v.key_len);
-    const uint32_t nn = 2u * a.v.key_len;
-    uint32_t end = last - first;
-    end = end <= nn ? end : nn + 1u;  // a walk consumes at least one nibble per hashed node
-    // nodes [0, gend) get a group (a root index out of range -- the walk reports it -- must not index the direct map)
-    const uint32_t gend = root >= a.v.n_roots ? 0u : end < a.shallow ? end : a.shallow;
-    // the shallow nodes' offsets are all requested before the first store (the compiler may not move a load
-    // across the table / stamp stores itself -- they could alias)
-    for (uint32_t d0 = 0; d0 < end; d0 += PLAN_BATCH) {
-        uint64_t offs[PLAN_BATCH + 1];
-        uint32_t kb4 = 0;  // key bytes d0/2 .. d0/2 + 3 (PLAN_BATCH = 8 nibbles)
-        if (d0 < gend) {
-#pragma unroll
-            for (uint32_t u = 0; u <= PLAN_BATCH; ++u) {
-                const uint32_t d = d0 + u <= gend ? d0 + u : gend;
-                offs[u] = a.v.node_off[first + d];
-            }
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < PLAN_BATCH / 2u; ++u)
-            if (d0 / 2u + u < a.v.key_len) kb4 |= (uint32_t)key[d0 / 2u + u] << (8u * u);
-#pragma unroll
-        for (uint32_t u = 0; u < PLAN_BATCH; ++u) {
-            const uint32_t d = d0 + u;
-            if (d < end) {
-                const uint32_t j = first + d;
-                uint32_t pm = PRE_STAMP | (d << 8);
-                if (d < nn) {
-                    const uint32_t kbyte = (kb4 >> (8u * (u >> 1))) & 0xffu;
-                    pm |= PRE_NIB | (((u & 1u) ? (kbyte & 0x0fu) : (kbyte >> 4)) << 4);
-                }
-                if (d < gend) {
-                    const uint64_t b = offs[u], e = offs[u + 1];
-                    const bool multi = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull && e - b >= RATE;
-                    pm |= PRE_GROUP;
-                    if (d < a.direct) {
-                        const uint32_t at = direct_index(kb, root, d, a.v.n_roots);
-                        a.gkey[j] = GK_DIRECT | at;
-                        if (multi) a.dtab[at] = j + 1u;
-                    } else {
-                        const uint64_t h = group_key(kb, root, d) & ~GK_DIRECT;
-                        a.gkey[j] = h;
-                        if (multi) {
-                            const uint64_t entry = ((uint64_t)gk_fp(h) << 32) | j;
-                            a.table[gk_slot_a(h, a.tmask)] = entry;
-                            a.table[gk_slot_b(h, a.tmask)] = entry;
-                        }
-                    }
-                }
-                a.meta[j] = pm;
-            }
-        }
+    if (last > a.total_nodes) return L;  // BAD_INPUT: the walk reports it
+    const uint32_t nn = 2u * a.v.key_len, cnt = last - first;
+    const uint32_t end = cnt <= nn ? cnt : nn + 1u;
+    if (L.d >= end) return L;
+    L.act = true;
+    L.j = first + L.d;
+    L.root = a.v.root_idx ? a.v.root_idx[L.p] : 0u;
+    const uint64_t e = a.v.node_off[L.j + 1], b = a.v.node_off[L.j];
+    if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
+        L.valid = true;
+        L.len = (uint32_t)(e - b);
+    }
+    // (a root index out of range -- the walk reports it -- must not index the direct map)
+    L.group = L.valid && L.len >= RATE && L.root < a.v.n_roots;
+    if (L.group) L.kb = key_prefix64(a.v.keys + (uint64_t)a.v.key_len * L.p, a.v.key_len);
+    return L;
+}
+
+// ---------------------------------------------------------------- propose
+__global__ void __launch_bounds__(256) propose_kernel(const Args a, uint4* zero_p, size_t zero_n16) {
+    beside_the_hashing();
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    {   // header + node states + verdict counters (nothing else of this launch has started)
+        const size_t lanes = (size_t)gridDim.x * 256u;
+        for (size_t i = g; i < zero_n16; i += lanes) zero_p[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (a.v.fail_count)
+            for (size_t r = g; r < a.v.n_roots; r += lanes) a.v.fail_count[r] = 0u;
+    }
+    const ShallowLane L = shallow_lane(a, g);
+    if (!L.group) return;
+    if (L.d < a.direct) {
+        a.dtab[direct_index(L.kb, L.root, L.d, a.v.n_roots)] = L.j + 1u;
+    } else {
+        const uint64_t h = group_hash(L.kb, L.root, L.d);
+        const uint64_t entry = ((uint64_t)L.p << 32) | (uint64_t)(L.j + 1u);
+        a.table[slot_a(h, a.tmask)] = entry;
+        a.table[slot_b(h, a.tmask)] = entry;
     }
 }
 
-// ---------------------------------------------------------------- dedup
+// ---------------------------------------------------------------- elect
+// Does the hashed table's entry name a node of THIS lane's group?  Whatever the slot holds (another group of this launch,
+// something an earlier launch left): the entry's owner proof must exist, have a sane node range, the node must be its
+// node of index d, and root index and the first d key nibbles must be this lane's.
+PHANT_DEV bool entry_matches(const Args& a, uint64_t en, const ShallowLane& L, uint32_t& node) {
+    const uint32_t pr = (uint32_t)(en >> 32), j1 = (uint32_t)en;
+    if (j1 == 0u || pr >= a.v.n) return false;
+    node = j1 - 1u;
+    if (pr == L.p) return node == L.j;
+    const uint32_t f = a.v.proof_first_node[pr], l = a.v.proof_first_node[pr + 1];
+    if (l < f || l > a.total_nodes || node < f || node >= l || node - f != L.d) return false;
+    if ((a.v.root_idx ? a.v.root_idx[pr] : 0u) != L.root) return false;
+    return same_prefix(key_prefix64(a.v.keys + (uint64_t)a.v.key_len * pr, a.v.key_len), L.kb, L.d);
+}
+
+__global__ void __launch_bounds__(256) elect_kernel(const Args a) {
+    constexpr uint32_t WAVES = 4;
+    __shared__ uint32_t s_cnt[WAVES][N_CURSOR];
+    __shared__ uint32_t s_base[N_CURSOR];
+    beside_the_hashing();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t NT = a.total_nodes;
+    if (tid < WAVES * N_CURSOR) (&s_cnt[0][0])[tid] = 0u;
+    const ShallowLane L = shallow_lane(a, blockIdx.x * 256u + tid);
+    // proof_first_node is not monotone: node ranges of OTHER proofs may then overlap, and what one proof's lanes find out
+    // about a node would be read by another.  Tell the walk not to trust anything.
+    if (L.broken) a.hdr[HDR_PFN_BROKEN] = 1u;
+
+    uint32_t cand = L.j;
+    if (L.group) {
+        uint32_t c = L.j;
+        if (L.d < a.direct) {
+            const uint32_t t = a.dtab[direct_index(L.kb, L.root, L.d, a.v.n_roots)];
+            if (t) c = t - 1u;
+        } else {
+            const uint64_t h = group_hash(L.kb, L.root, L.d);
+            uint32_t node;
+            if (entry_matches(a, a.table[slot_a(h, a.tmask)], L, node)) c = node;
+            else if (entry_matches(a, a.table[slot_b(h, a.tmask)], L, node)) c = node;
+        }
+        if (c != L.j && c < NT) {
+            // a representative is only usable if it is a well-formed node of the same length
+            const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
+            if (c1 >= c0 && c1 <= a.v.nodes_len && c1 - c0 == L.len) cand = c;
+        }
+    }
+    if (L.act) a.rep[L.j] = cand;
+
+    // ---- lists: what must be hashed (with its owner proof), what must be compared (with its representative) ----
+    uint32_t cls = CLASS_NONE;
+    if (L.act && L.valid) cls = cand == L.j ? node_list(L.len) : (L.len == BRANCH_LEN ? COPY_B532 : COPY_OTHER);
+    uint32_t my_rank = 0;
+    __syncthreads();
+    unsigned long long todo = __ballot(cls != CLASS_NONE);
+    while (todo) {
+        const uint32_t c0 = lane_u32(cls, (uint32_t)__builtin_ctzll(todo));
+        const unsigned long long m = __ballot(cls == c0);
+        if (lane == 0) s_cnt[wave][c0] = (uint32_t)__popcll(m);
+        if (cls == c0) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    __syncthreads();
+    if (tid < N_CURSOR) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < WAVES; ++w) tot += s_cnt[w][tid];
+        s_base[tid] = tot ? atomicAdd(&a.hdr[cursor_word(tid)], tot) : 0u;
+    }
+    __syncthreads();
+    if (cls != CLASS_NONE) {
+        uint32_t at = s_base[cls] + my_rank;
+        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
+        if (cls < N_LIST) a.ent[(uint64_t)cls * NT + at] = make_uint2(L.j, L.p);
+        else a.cpy[(uint64_t)(cls - COPY_B532) * NT + at] = make_uint2(L.j, cand);
+    }
+}
+
+// ---------------------------------------------------------------- compare
 // all 64 lanes: are the `len` bytes at x and y equal?  16 bytes per lane per step.
 PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len, uint32_t lane) {
     uint32_t diff = 0;
@@ -258,161 +326,92 @@ PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len
     return __ballot(diff != 0) == 0ull;
 }
 
-constexpr int DEDUP_UNROLL = 4;  // nodes in flight per wave in the 532-byte path
-
-// Workgroups of 256 lanes = one wave per SIMD: such a workgroup finds room next to the deep tier's hash waves where
-// one of four waves per SIMD has to wait for all of them at once (measured: 0.250 -> 0.237 ms per launch).  The price
-// is one returning atomicAdd per workgroup and non-empty list on the SAME few cursors (served one at a time, ~11.6 ns
-// each, tools/ubench/atomic_rate.hip): ~3 000 of them for BASELINE config 3, spread over the kernel's run.
-constexpr uint32_t DEDUP_BLOCK = 256;
+constexpr int COMPARE_UNROLL = 4;  // steps in flight per wave: 2 x COMPARE_UNROLL nodes
 #ifdef PHANT_HOST_EMU
 #define PHANT_NUM_VGPR(n)  // (a register budget means nothing to a host compiler; clang rejects the attribute there)
 #else
 #define PHANT_NUM_VGPR(n) __attribute__((amdgpu_num_vgpr(n)))
 #endif
 
-__global__ void __launch_bounds__(DEDUP_BLOCK) PHANT_NUM_VGPR(48) dedup_kernel(const Args a) {
-    constexpr uint32_t WAVES = DEDUP_BLOCK / 64u;
-    __shared__ uint32_t s_cnt[WAVES][N_LIST];
-    __shared__ uint32_t s_base[N_LIST];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t NT = a.total_nodes;
-    const uint32_t j = blockIdx.x * DEDUP_BLOCK + tid;
+// One wave per 64 entries of a compare list.  532-byte copies: a half wave covers bytes [0, 512) of one copy (16 per lane),
+// so a trip of COMPARE_UNROLL steps compares 2 x COMPARE_UNROLL copies with all their loads issued before any is used; the
+// last 28 bytes lane per copy afterwards (they share their cache lines with bytes just read).  A short last chunk repeats
+// its last entry (idempotent), so the body has no conditionals.  Workgroups of 256 lanes = one wave per SIMD: such a
+// workgroup finds room next to the hash waves where four waves per SIMD would have to wait for all of them at once.
+__global__ void __launch_bounds__(256) PHANT_NUM_VGPR(48) compare_kernel(const Args a) {
     beside_the_hashing();
-
-    // ---- lane-per-node metadata (coalesced) ----
-    bool valid = false, listed = false;
-    uint64_t b = 0, cb = 0;
-    uint32_t len = 0, cand = j;
-    if (j < NT) {
-        const uint64_t e = a.v.node_off[j + 1];
-        b = a.v.node_off[j];
-        if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
-            valid = true;
-            len = (uint32_t)(e - b);
-            const uint32_t stamp = a.all_listed ? 0u : a.meta[j];
-            // shallow stamped nodes are this tier's; the deep ones are hashed in place, nodes no walk reaches never
-            listed = a.all_listed || ((stamp & PRE_STAMP) && (stamp >> 8) < a.shallow);
-            if (len >= RATE && (stamp & PRE_GROUP)) {
-                const uint64_t h = a.gkey[j];
-                uint32_t c = j;  // the group's proposed representative
-                if (h & GK_DIRECT) {
-                    const uint32_t t = a.dtab[(uint32_t)h];
-                    if (t) c = t - 1u;
-                } else {
-                    const uint32_t fp = gk_fp(h);
-                    uint64_t en = a.table[gk_slot_a(h, a.tmask)];
-                    if ((uint32_t)(en >> 32) != fp) en = a.table[gk_slot_b(h, a.tmask)];
-                    if ((uint32_t)(en >> 32) == fp) c = (uint32_t)en;
-                }
-                if (c < NT && c != j) {
-                    // a representative is only usable if it is a well-formed node of the same length
-                    const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
-                    if (c1 >= c0 && c1 <= a.v.nodes_len && c1 - c0 == len) {
-                        cand = c;
-                        cb = c0;
-                    }
-                }
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t NT = a.total_nodes;
+    const uint32_t cnt_a = a.hdr[HDR_COPY_B532], cnt_b = a.hdr[HDR_COPY_OTHER];
+    const uint32_t chunks_a = (cnt_a + 63u) / 64u, chunks_b = (cnt_b + 63u) / 64u;
+    if (q < chunks_a) {
+        const uint32_t idx = q * 64u + lane;
+        const uint2 en = a.cpy[idx < cnt_a ? idx : cnt_a - 1u];
+        const uint32_t j = en.x;
+        const uint64_t b = a.v.node_off[j], cb = a.v.node_off[en.y];
+        const uint32_t coff = 16u * (lane & 31u);
+        const bool upper = lane >= 32u;
+        // everything that selects a node below is wave-uniform: say so, or the compiler predicates per lane
+        const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32), cb_lo = (uint32_t)cb, cb_hi = (uint32_t)(cb >> 32);
+        bool differs = false;
+#pragma unroll 1
+        for (uint32_t t = 0; t < 64u; t += 2u * COMPARE_UNROLL) {
+            uint4 x[COMPARE_UNROLL], y[COMPARE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < COMPARE_UNROLL; ++u) {
+                const uint32_t i0 = t + 2u * u, i1 = i0 + 1u;
+                const uint64_t own0 = lane_u64(b_lo, b_hi, i0), own1 = lane_u64(b_lo, b_hi, i1);
+                const uint64_t oth0 = lane_u64(cb_lo, cb_hi, i0), oth1 = lane_u64(cb_lo, cb_hi, i1);
+                x[u] = load16u(a.v.nodes + (upper ? own1 : own0) + coff);
+                y[u] = load16u(a.v.nodes + (upper ? oth1 : oth0) + coff);
+            }
+#pragma unroll
+            for (int u = 0; u < COMPARE_UNROLL; ++u) {
+                const uint32_t i0 = t + 2u * u, i1 = i0 + 1u;
+                // acc | (x ^ y), dword by dword
+                uint32_t diff = x[u].x ^ y[u].x;
+                diff = __builtin_amdgcn_bitop3_b32(x[u].y, y[u].y, diff, 0xBE);
+                diff = __builtin_amdgcn_bitop3_b32(x[u].z, y[u].z, diff, 0xBE);
+                diff = __builtin_amdgcn_bitop3_b32(x[u].w, y[u].w, diff, 0xBE);
+                const unsigned long long m = __ballot(diff != 0);
+                if ((uint32_t)m != 0u && lane == i0) differs = true;
+                if ((uint32_t)(m >> 32) != 0u && lane == i1) differs = true;
             }
         }
+        {   // bytes [504, 532)
+            const uint8_t* const own = a.v.nodes + b + (BRANCH_LEN - 28u);
+            const uint8_t* const oth = a.v.nodes + cb + (BRANCH_LEN - 28u);
+            const uint4 p0 = load16u(own), p1 = load16u(own + 12), q0 = load16u(oth), q1 = load16u(oth + 12);
+            uint32_t diff = (p0.x ^ q0.x) | (p0.y ^ q0.y) | (p0.z ^ q0.z) | (p0.w ^ q0.w);
+            diff |= (p1.x ^ q1.x) | (p1.y ^ q1.y) | (p1.z ^ q1.z) | (p1.w ^ q1.w);
+            if (diff) differs = true;
+        }
+        if (differs) a.rep[j] = j;  // nobody hashed it: the walk that meets it does
+        return;
     }
-
-    uint32_t my_rep = j;
-    // ---- 532-byte nodes that have a representative.  A half wave covers bytes [0, 512) of one node (16 per lane), so
-    // a trip of DEDUP_UNROLL steps compares 2 * DEDUP_UNROLL nodes with all their loads issued before any is used; a
-    // short last trip repeats its last node (idempotent), so the body has no conditionals.  The last 28 bytes of
-    // every node that got this far are compared below, lane per node (they share their cache lines with bytes just
-    // read).  (A whole wave per node -- 34 useful lanes of 64 -- is twice the trips and the instructions.)  Nodes
-    // WITHOUT a representative are not opened here at all: the hash kernel reads them (once), and checks their form
-    // while it has them in registers. ----
-    const uint32_t coff = 16u * (lane & 31u);
-    const bool upper = lane >= 32u;
-    // everything that selects a node below is wave-uniform: say so, or the compiler predicates per lane
+    q -= chunks_a;
+    if (q >= chunks_b) return;
+    // ---- other multi-block copies (sparse branches >= 136 bytes): generic compare, one at a time ----
+    const uint32_t idx = q * 64u + lane;
+    const uint2 en = a.cpy[(uint64_t)NT + (idx < cnt_b ? idx : cnt_b - 1u)];
+    const uint32_t j = en.x;
+    const uint64_t b = a.v.node_off[j], cb = a.v.node_off[en.y];
+    const uint32_t len = (uint32_t)(a.v.node_off[j + 1] - b);  // (elect_kernel checked both nodes: same, sane length)
     const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32), cb_lo = (uint32_t)cb, cb_hi = (uint32_t)(cb >> 32);
-    const bool is532 = valid && len == BRANCH_LEN && cand != j;
-    unsigned long long todo = __ballot(is532);
-    while (todo) {
-        uint32_t i0[DEDUP_UNROLL], i1[DEDUP_UNROLL];
-        uint4 x[DEDUP_UNROLL], y[DEDUP_UNROLL];
-        uint32_t i = 0;
-#pragma unroll
-        for (int u = 0; u < DEDUP_UNROLL; ++u) {
-            if (todo) {
-                i = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
-            }
-            i0[u] = i;
-            if (todo) {
-                i = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
-            }
-            i1[u] = i;
-            const uint64_t own0 = lane_u64(b_lo, b_hi, i0[u]), own1 = lane_u64(b_lo, b_hi, i1[u]);
-            const uint64_t oth0 = lane_u64(cb_lo, cb_hi, i0[u]), oth1 = lane_u64(cb_lo, cb_hi, i1[u]);
-            x[u] = load16u(a.v.nodes + (upper ? own1 : own0) + coff);
-            y[u] = load16u(a.v.nodes + (upper ? oth1 : oth0) + coff);
-        }
-#pragma unroll
-        for (int u = 0; u < DEDUP_UNROLL; ++u) {
-            // acc | (x ^ y), dword by dword
-            uint32_t diff = x[u].x ^ y[u].x;
-            diff = __builtin_amdgcn_bitop3_b32(x[u].y, y[u].y, diff, 0xBE);
-            diff = __builtin_amdgcn_bitop3_b32(x[u].z, y[u].z, diff, 0xBE);
-            diff = __builtin_amdgcn_bitop3_b32(x[u].w, y[u].w, diff, 0xBE);
-            const unsigned long long m = __ballot(diff != 0);
-            if ((uint32_t)m == 0u && lane == i0[u]) my_rep = cand;
-            if ((uint32_t)(m >> 32) == 0u && lane == i1[u]) my_rep = cand;
-        }
-    }
-    if (is532 && my_rep != j) {  // bytes [504, 532)
-        const uint8_t* const own = a.v.nodes + b + (BRANCH_LEN - 28u);
-        const uint8_t* const oth = a.v.nodes + cb + (BRANCH_LEN - 28u);
-        const uint4 p0 = load16u(own), p1 = load16u(own + 12), q0 = load16u(oth), q1 = load16u(oth + 12);
-        uint32_t diff = (p0.x ^ q0.x) | (p0.y ^ q0.y) | (p0.z ^ q0.z) | (p0.w ^ q0.w);
-        diff |= (p1.x ^ q1.x) | (p1.y ^ q1.y) | (p1.z ^ q1.z) | (p1.w ^ q1.w);
-        if (diff) my_rep = j;
-    }
-
-    // ---- other multi-block nodes (sparse branches >= 136 bytes): generic compare, one at a time ----
-    todo = __ballot(valid && len >= RATE && len != BRANCH_LEN && cand != j);
-    while (todo) {
-        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
+    bool differs = false;
+    const uint32_t live = cnt_b - q * 64u < 64u ? cnt_b - q * 64u : 64u;
+    for (uint32_t i = 0; i < live; ++i) {
         const uint32_t ll = lane_u32(len, i);
-        const uint8_t* o = a.v.nodes + lane_u64(b_lo, b_hi, i);
-        const uint8_t* c = a.v.nodes + lane_u64(cb_lo, cb_hi, i);
-        const bool eq = wave_bytes_equal(o, c, ll, lane);
-        if (lane == i && eq) my_rep = cand;
+        const bool eq = wave_bytes_equal(a.v.nodes + lane_u64(b_lo, b_hi, i), a.v.nodes + lane_u64(cb_lo, cb_hi, i), ll, lane);
+        if (lane == i && !eq) differs = true;
     }
-
-    // ---- results + per-list compaction of the nodes that must be hashed ----
-    const bool need = listed && my_rep == j;
-    const uint32_t cls = valid ? node_list(len) : CLASS_NONE;
-    if (j < NT) a.rep[j] = my_rep;
-    uint32_t my_rank = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < N_LIST; ++c) {
-        const unsigned long long m = __ballot(need && cls == c);
-        if (lane == 0) s_cnt[wave][c] = (uint32_t)__popcll(m);
-        if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    }
-    __syncthreads();
-    if (tid < N_LIST) {
-        uint32_t tot = 0;
-        for (uint32_t w = 0; w < WAVES; ++w) tot += s_cnt[w][tid];
-        s_base[tid] = tot ? atomicAdd(&a.hdr[tid], tot) : 0u;
-    }
-    __syncthreads();
-    if (need) {
-        uint32_t at = s_base[cls] + my_rank;
-        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
-        a.ent[(uint64_t)cls * NT + at] = j;
-    }
+    if (differs) a.rep[j] = j;
 }
 
 // ---------------------------------------------------------------- canonical full branch, per rate block
 // f9 02 11 | 16 x (a0 + 32 bytes) | 80 = 532 bytes: what the marker bytes of rate block K (bytes
-// [136 K, 136 K + 136) of the node, as 34 little-endian dwords) must be.  The hash kernels hold exactly
+// [136 K, 136 K + 136) of the node, as 34 little-endian dwords) must be.  The hash waves hold exactly
 // these dwords in registers when they absorb the block, so checking the form of a node there costs ~10
 // VALU operations per block and no memory traffic.
 struct BranchMask {
@@ -448,19 +447,9 @@ PHANT_DEV uint32_t branch_block_bad_k(const uint32_t (&d)[RATE_DWORDS]) {
     return bad;
 }
 
-// ---------------------------------------------------------------- one node per lane through the sponge
-// What a hash lane knows about its node.
-struct LaneNode {
-    const uint8_t* ptr;     // first byte
-    uint32_t len;
-    bool active;
-};
-
 // One rate block of a 532-byte node into the sponge: K = which block (0..3), NDW = its message dwords (34, or 31 for
 // the last block: 124 message bytes, then the padding -- two constants, nothing masked per lane, nothing read beyond
 // the node's last byte).  Returns nonzero iff the block contradicts the canonical full branch.
-// (Tried and dropped, DESIGN.md section 7.5: absorbing in two halves behind a compiler fence to stay at <= 96 VGPRs / 5
-// waves per SIMD -- the second memory round trip per block cost more than the fifth wave gave.)
 template <int K, int NDW>
 PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
     uint32_t d[RATE_DWORDS];
@@ -490,18 +479,13 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 }
 
 // Keccak-256 of a node that is exactly 532 bytes long, for every lane of the wave (wave-uniform: all active lanes
-// have such a node; inactive lanes hash whatever `ptr` points at -- the launcher gives them a readable one).  Three
-// full rate blocks and a last one of 124 message bytes: the padding is two constants, nothing is masked per lane, and
-// nothing beyond the node's last byte is read.  Returns nonzero iff the node is NOT the canonical full branch.
+// have such a node; inactive lanes hash whatever `ptr` points at -- the launcher gives them a readable one).  Returns
+// nonzero iff the node is NOT the canonical full branch.
 // LADDER: the wave's issue priority falls as it gets on (2, 1, 1, 0 over the four blocks: below the memory-bound kernels' 3
-// throughout -- same-box A/B of ladders: 3,2,1,0 one launch 0.2251 ms, 2,1,1,0 0.2221, 1,1,1,0 0.2234; flatter ones
-// (2,1,0,0 / 1,1,0,0) gain 1.9 % with four launches in flight and lose 2.5 % one at a time).  VALU issue on a
-// SIMD is arbitrated by priority, then age -- left alone, the oldest of four co-resident hash waves takes ~60 % of the
-// slots, finishes first, and the youngest ends up running its last permutations alone at single-wave speed (6.9
-// instead of 9.8 G perm/s).  With the ladder a wave that is behind outranks the ones ahead: they advance block by
-// block together and finish together.  Measured on BASELINE config 3 (profiles/r2_a/sweep_ladder.jsonl): the deep
-// tier alone 7 us shorter, a launch 0.2515 -> 0.2449 ms.  The list kernel uses it as well (its other classes keep one
-// raised priority: few waves, on the critical path).
+// throughout).  VALU issue on a SIMD is arbitrated by priority, then age -- left alone, the oldest of four co-resident
+// hash waves takes ~60 % of the slots, finishes first, and the youngest ends up running its last permutations alone at
+// single-wave speed.  With the ladder a wave that is behind outranks the ones ahead: they advance block by block
+// together and finish together (ladders measured).
 template <bool LADDER>
 PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
     sponge_zero(s);
@@ -521,8 +505,7 @@ PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
 }
 
 // Keccak-256 of one node per lane, any lengths (exec-masked loop: the wave runs as many permutations as its longest
-// node needs).  `safe_end`: one past the last byte of the node blob.  No look at the node's form: 532-byte nodes go
-// through hash_b532.
+// node needs).  `safe_end`: one past the last byte of the node blob.
 PHANT_DEV void hash_any(Sponge& s, const uint8_t* __restrict__ p, uint32_t len, const uint8_t* __restrict__ safe_end) {
     sponge_zero(s);
     uint32_t left = len;
@@ -563,21 +546,10 @@ PHANT_DEV void hash_short_uniform(Sponge& s, const uint8_t* __restrict__ p, uint
     keccak_f1600(s);
 }
 
-// proof owning node j: pfn[p] <= j < pfn[p+1] (only root nodes ask)
-PHANT_DEV uint32_t find_proof(const uint32_t* __restrict__ pfn, uint32_t n, uint32_t j) {
-    uint32_t lo = 0, hi = n;  // invariant (for monotone pfn): pfn[lo] <= j < pfn[hi]
-    while (hi - lo > 1u) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (pfn[mid] <= j) lo = mid;
-        else hi = mid;
-    }
-    return lo;
-}
-
-// Where the 32 bytes node j must hash to are (nullptr: not known without decoding the parent).  `d`: depth of the
+// Where the 32 bytes node j must hash to are (nullptr: not known without decoding the parent).  `d`: index of the
 // node in its proof, `root`: the proof's root index, `nib_parent`: the key nibble at depth d - 1 (or >= 16: none),
 // `b`: byte offset of node j.  The parent of node j is node j - 1 = bytes [node_off[j-1], b); if that is 532 bytes
-// long, the reference of a full branch for that nibble starts at byte 4 + 33 nib (link_kernel only believes the
+// long, the reference of a full branch for that nibble starts at byte 4 + 33 nib (the walk only believes the
 // comparison when the parent turns out to be the canonical full branch).
 PHANT_DEV const uint8_t* ref_location(const Args& a, uint32_t j, uint32_t d, uint32_t root, uint32_t nib_parent, uint64_t b) {
     if (d == 0u) return root < a.v.n_roots ? a.v.roots + 32ull * root : nullptr;
@@ -608,17 +580,12 @@ PHANT_DEV void store_node_digest(const Args& a, uint32_t j, const Sponge& s) {
     o[1] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
 }
 
-// ---------------------------------------------------------------- hash, shallow tier: one list chunk per wave
-// Wave q hashes chunk q (64 nodes of one list, the lists with the most rate blocks first) and exits; the grid covers
-// the worst case and the dispatcher keeps every SIMD full until the lists run out.  A short last chunk repeats its
-// last node (same results stored twice) so that no lane is ever idle-masked.
-__global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
-    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const uint32_t lane = threadIdx.x & 63u;
+// ---------------------------------------------------------------- hash: the list role
+// Wave q hashes chunk q (64 nodes of one list, the lists with the most rate blocks first) and exits; the grid covers the
+// worst case and the dispatcher keeps every SIMD full.  A short last chunk repeats its last node (same results stored
+// twice) so that no lane is ever idle-masked.
+PHANT_DEV void list_role(const Args& a, uint32_t q, const uint32_t lane) {
     const uint32_t N = a.total_nodes;
-    // On the critical path (plan -> dedup -> this -> link -> walk) with fewer waves than the chip has SIMDs, while the
-    // deep tier's waves, which are many and in nobody's way, compete for the same issue slots: go first.
-    __builtin_amdgcn_s_setprio(2);
     // queue order: 8+ blocks, 7, 6, 5, [532-byte list], 4 (others), 3, 2, 1
     uint32_t cls = N_LIST, idx = 0;
 #pragma unroll
@@ -637,7 +604,8 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
         }
     }
     if (cls == N_LIST) return;
-    const uint32_t j = a.ent[(uint64_t)cls * N + idx];
+    const uint2 en = a.ent[(uint64_t)cls * N + idx];
+    const uint32_t j = en.x;
     const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
     const uint64_t b = a.v.node_off[j];
     const uint32_t len = (uint32_t)(a.v.node_off[j + 1] - b);
@@ -645,17 +613,13 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
 
     // the reference this node must hash to: requested now, compared after the last permutation
     const uint8_t* refp = nullptr;
-    if (!a.all_listed) {
-        const uint32_t m = a.meta[j];
-        const uint32_t d = m >> 8;
-        uint32_t root = 0, nibp = 16u;
-        if (d == 0u) {
-            if (a.v.root_idx) root = a.v.root_idx[find_proof(a.v.proof_first_node, a.v.n, j)];
-        } else {
-            const uint32_t mp = a.meta[j - 1u];
-            if ((mp & PRE_NIB) && (mp >> 8) == d - 1u) nibp = (mp >> 4) & 15u;
-        }
-        if (m & PRE_STAMP) refp = ref_location(a, j, d, root, nibp, b);
+    {
+        const uint32_t owner = en.y;
+        const uint32_t d = j - a.v.proof_first_node[owner];
+        const uint32_t root = a.v.root_idx ? a.v.root_idx[owner] : 0u;
+        uint32_t nibp = 16u;
+        if (d >= 1u && d - 1u < 2u * a.v.key_len) nibp = key_nibble(a.v.keys + (uint64_t)a.v.key_len * owner, d - 1u);
+        refp = ref_location(a, j, d, root, nibp, b);
     }
     const RefBytes ref = load_ref(refp);
 
@@ -663,9 +627,9 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
     uint32_t bad;
     const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
     if (cls == LIST_B532) {
-        bad = hash_b532<true>(s, p);  // (same-box A/B, three runs each: config 4 +1.8 %, one launch at a time -2 %)
+        bad = hash_b532<true>(s, p);
     } else if (cls == 0u && __ballot(len != len0 || p + RATE > safe_end) == 0ull) {
-        hash_short_uniform(s, p, len0);  // one length below the rate for the whole chunk: BASELINE's leaves
+        hash_short_uniform(s, p, len0);  // one length below the rate for the whole chunk
         bad = 1u;
     } else {
         hash_any(s, p, len, safe_end);
@@ -677,19 +641,15 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
     store_node_digest(a, j, s);
 }
 
-// ---------------------------------------------------------------- hash, deep tier: in place
-// Wave = 64 consecutive proofs at one depth, lane = proof.  Nothing is looked up: a proof's node at depth d is node
-// proof_first_node[p] + d, its key nibble comes from the key.  The grid's y covers DEEP_LEVELS depths per pass
-// (deepest last: the leaves, the short chunks, fill the tail); a wave whose proofs are all shorter leaves at once.
+// ---------------------------------------------------------------- hash: the deep role, in place
+// Wave = 64 consecutive proofs at one depth, lane = proof.  The deep waves cover `levels` depths per pass (deepest last:
+// the leaves, the short chunks, fill the tail); a wave whose proofs are all shorter leaves at once.
 constexpr uint32_t DEEP_LEVELS = 8;  // at most; the launcher picks fewer when the batch's proofs are short (see there)
 
-// SOLO: the S = 0 form -- no plan_kernel runs, so this kernel is the one to notice a proof_first_node that is not monotone
+// SOLO: the S = 0 form -- no elect_kernel runs, so this role is the one to notice a proof_first_node that is not monotone
 template <bool SOLO>
-__global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const uint32_t waves_per_level, const uint32_t levels) {
-    // the 32 reference bytes wait in LDS while the sponge has the registers ([dword][lane]: conflict-free)
-    __shared__ uint32_t s_ref[8][256];
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const uint32_t lane = threadIdx.x & 63u;
+PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, const uint32_t waves_per_level, const uint32_t levels,
+                         uint32_t (&s_ref)[8][256]) {
     const uint32_t level = w / waves_per_level;  // 0 .. levels - 1
     // (the grid is whole workgroups: up to three waves behind the last level would take "level = levels" -- the depths the
     // first level's waves come back for -- and hash those nodes a second time)
@@ -706,7 +666,7 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
             const uint32_t last = a.v.proof_first_node[p + 1];
             if (last >= first && last <= a.total_nodes) count = last - first;
             // (node ranges of other proofs may overlap then: what a lane finds out about a node holds for ITS proof's key
-            // and parent only -- the walk must not use it.  plan_kernel says so when it runs)
+            // and parent only -- the walk must not use it.  elect_kernel says so when it runs)
             if constexpr (SOLO) {
                 if (last < first) a.hdr[HDR_PFN_BROKEN] = 1u;
             }
@@ -783,85 +743,78 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
     }
 }
 
-// ---------------------------------------------------------------- link
-// One lane per node: the walk's code for node j.
-//   LINK_FAST     hash matches, node is a canonical full branch stamped with this key's nibble: step over
-//   LINK_HASH_OK  hash matches, node must be decoded (BASELINE: the account leaf)
-//   LINK_BAD_HASH / LINK_SLOW   settle the proof (DESIGN.md section 3 order: they come after BAD_INPUT)
-//   LINK_GENERIC  nothing established (parent not canonical, offsets bad, ...): the walk does it all
-// A code of a node at depth >= 1 is only ever consulted by a walk that stepped over the parent with LINK_FAST, i.e.
-// the parent IS a canonical full branch -- which is what makes "the 32 bytes at 4 + 33 nibble" its reference.
-enum : uint32_t { LINK_GENERIC = 0, LINK_FAST = 1, LINK_HASH_OK = 2, LINK_BAD_HASH = 3, LINK_SLOW = 4 };
-
-PHANT_DEV uint32_t code_of(uint32_t ns, uint32_t m) {
-    if (!(ns & NS_LINK_CHECKED)) return LINK_GENERIC;
-    if (!(ns & NS_LINK_OK)) return LINK_BAD_HASH;
-    return ((m & PRE_NIB) && (ns & NS_CANON)) ? LINK_FAST : LINK_HASH_OK;
+// Every wave that hashes.  Workgroups [0, list_wgs): the list role (upper bound; waves beyond the lists leave at once --
+// at the head of the grid that costs a microsecond of dispatch); the rest: the deep role.
+template <bool SOLO>
+__global__ void __launch_bounds__(256, 4) hash_kernel(const Args a, const uint32_t list_wgs, const uint32_t waves_per_level,
+                                                      const uint32_t levels) {
+    // the 32 reference bytes wait in LDS while the sponge has the registers ([dword][lane]: conflict-free)
+    __shared__ uint32_t s_ref[8][256];
+    const uint32_t lane = threadIdx.x & 63u;
+    if constexpr (!SOLO) {
+        if (blockIdx.x < list_wgs) {
+            // fewer waves than the chip has SIMDs, four permutations in a row each, and the walk waits for them: go first
+            __builtin_amdgcn_s_setprio(2);
+            list_role(a, (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), lane);
+            return;
+        }
+    }
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((blockIdx.x - list_wgs) * 4u + (threadIdx.x >> 6));
+    deep_role<SOLO>(a, w, lane, waves_per_level, levels, s_ref);
 }
 
-__global__ void __launch_bounds__(256) link_kernel(const Args a) {
-    // With several launches in flight this kernel and the walk run next to OTHER launches' hash waves: a few instructions
-    // between memory round trips at the end of a launch's dependency chain -- raised priority, like the shallow tier's
-    // kernels (same-box A/B, 4 launches in flight: +3.5-4.7 % proofs/s for this kernel, +1.5 % for the walk).
-    beside_the_hashing();
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= a.total_nodes) return;
-    uint32_t code = LINK_GENERIC;
-    const uint32_t m = a.meta[j];
-    if (m & PRE_STAMP) {
-        const uint32_t d = m >> 8;
-        const uint32_t r = (m & PRE_GROUP) ? a.rep[j] : j;
-        if (r == j) {
-            const uint32_t ns = a.nstat[j];
-            code = (ns & NS_HASHED) ? code_of(ns, m) : LINK_GENERIC;  // (not hashed: bad offsets; the walk reports it)
-        } else if (r >= a.total_nodes) {
-            code = LINK_SLOW;
-        } else {
-            const uint32_t ns = a.nstat[r];
-            const uint32_t mr = a.meta[r];
-            if (!(ns & NS_HASHED)) {
-                code = LINK_SLOW;  // a representative that was not hashed itself
-            } else if (d == 0u) {
-                // a copy of another proof's root node: compare the representative's digest with THIS proof's root
-                uint32_t root = 0;
-                if (a.v.root_idx) root = a.v.root_idx[find_proof(a.v.proof_first_node, a.v.n, j)];
-                if (root < a.v.n_roots) {
-                    const RefBytes want = load_ref(a.v.roots + 32ull * root);
-                    const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * r);
-                    const uint4 d0 = dg[0], d1 = dg[1];
-                    const uint32_t diff = (d0.x ^ want.lo.x) | (d0.y ^ want.lo.y) | (d0.z ^ want.lo.z) | (d0.w ^ want.lo.w) |
-                                          (d1.x ^ want.hi.x) | (d1.y ^ want.hi.y) | (d1.z ^ want.hi.z) | (d1.w ^ want.hi.w);
-                    code = diff ? LINK_BAD_HASH : (((m & PRE_NIB) && (ns & NS_CANON)) ? LINK_FAST : LINK_HASH_OK);
-                }
-            } else if ((mr & PRE_STAMP) && (mr >> 8) >= 1u && r >= 1u) {
-                // the representative's link result is this node's if it was the same comparison: the parents
-                // (nodes j - 1 and r - 1) are the same bytes -- same representative -- and the same key nibble
-                const uint32_t mp = a.meta[j - 1u], mq = a.meta[r - 1u];
-                const uint32_t pj = (mp & PRE_GROUP) ? a.rep[j - 1u] : j - 1u;
-                const uint32_t pr = (mq & PRE_GROUP) ? a.rep[r - 1u] : r - 1u;
-                if ((mp & PRE_NIB) && (mq & PRE_NIB) && (mp >> 8) == d - 1u && (mq >> 8) == (mr >> 8) - 1u &&
-                    ((mp >> 4) & 15u) == ((mq >> 4) & 15u) && pj == pr) {
-                    code = code_of(ns, m);
-                } else if ((mp & PRE_NIB) && (mp >> 8) == d - 1u) {
-                    // not the same comparison (the representative sits in a proof whose parent node differs, e.g. a
-                    // damaged one): compare the representative's digest with the reference in THIS proof's parent
-                    const uint8_t* refp = ref_location(a, j, d, 0u, (mp >> 4) & 15u, a.v.node_off[j]);
-                    if (refp) {
-                        const RefBytes want = load_ref(refp);
-                        const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * r);
-                        const uint4 d0 = dg[0], d1 = dg[1];
-                        const uint32_t diff = (d0.x ^ want.lo.x) | (d0.y ^ want.lo.y) | (d0.z ^ want.lo.z) | (d0.w ^ want.lo.w) |
-                                              (d1.x ^ want.hi.x) | (d1.y ^ want.hi.y) | (d1.z ^ want.hi.z) | (d1.w ^ want.hi.w);
-                        code = diff ? LINK_BAD_HASH : (((m & PRE_NIB) && (ns & NS_CANON)) ? LINK_FAST : LINK_HASH_OK);
-                    }
-                }
+// node-set witnesses: every node listed (classify_kernel), no owners, no references
+__global__ void __launch_bounds__(256, 4) hash_set_kernel(const Args a) {
+    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t N = a.total_nodes;
+    uint32_t cls = N_LIST, idx = 0;
+#pragma unroll
+    for (int o = 0; o < (int)N_LIST; ++o) {
+        const int c = o < 4 ? 7 - o : (o == 4 ? (int)LIST_B532 : 8 - o);
+        const uint32_t cnt = a.hdr[c];
+        const uint32_t chunks = (cnt + 63u) / 64u;
+        if (cls == N_LIST) {
+            if (q < chunks) {
+                cls = (uint32_t)c;
+                idx = q * 64u + lane;
+                idx = idx < cnt ? idx : cnt - 1u;
+            } else {
+                q -= chunks;
             }
         }
     }
-    a.link[j] = (uint8_t)code;
+    if (cls == N_LIST) return;
+    const uint32_t j = a.ent[(uint64_t)cls * N + idx].x;
+    const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
+    const uint64_t b = a.v.node_off[j];
+    const uint32_t len = (uint32_t)(a.v.node_off[j + 1] - b);
+    const uint8_t* const p = a.v.nodes + b;
+    Sponge s;
+    uint32_t bad = 1u;
+    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
+    if (cls == LIST_B532) bad = hash_b532<false>(s, p);
+    else if (cls == 0u && __ballot(len != len0 || p + RATE > safe_end) == 0ull) hash_short_uniform(s, p, len0);
+    else hash_any(s, p, len, safe_end);
+    a.nstat[j] = (uint8_t)(NS_HASHED | (bad == 0u ? NS_CANON : 0u));
+    store_node_digest(a, j, s);
 }
 
 // ---------------------------------------------------------------- walk
+//   LINK_FAST     hash matches, node is a canonical full branch and the key has a nibble for it: step over
+//   LINK_HASH_OK  hash matches, node must be decoded (BASELINE: the account leaf)
+//   LINK_BAD_HASH settles the proof (DESIGN.md section 3 order: after BAD_INPUT)
+//   LINK_GENERIC  nothing established (parent not canonical, offsets bad, ...): the walk does it all
+// A state of a node at index >= 1 is only ever consulted by a walk that stepped over the parent with LINK_FAST, i.e.
+// the parent IS a canonical full branch -- which is what makes "the 32 bytes at 4 + 33 nibble" its reference.
+enum : uint32_t { LINK_GENERIC = 0, LINK_FAST = 1, LINK_HASH_OK = 2, LINK_BAD_HASH = 3 };
+
+PHANT_DEV uint32_t code_of(uint32_t ns, bool has_nibble) {
+    if (!(ns & NS_HASHED) || !(ns & NS_LINK_CHECKED)) return LINK_GENERIC;
+    if (!(ns & NS_LINK_OK)) return LINK_BAD_HASH;
+    return (has_nibble && (ns & NS_CANON)) ? LINK_FAST : LINK_HASH_OK;
+}
+
 // Nodes the generic decoder opens (for BASELINE's proofs: the 112-byte account leaf) are first copied
 // into a per-lane LDS slot with 16-byte loads, together with the key: the RLP decoder and the path
 // comparison read single bytes one after the other, and from HBM/L2 every one of those ~100 dependent
@@ -870,26 +823,17 @@ constexpr uint32_t WALK_STAGE_BYTES = 192;  // nodes up to this size are staged;
 constexpr uint32_t WALK_KEY_BYTES = 32;
 constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  // odd stride: no bank pile-up
 
-// digest of node j as the pipeline knows it: the node's own, or its representative's (identical bytes)
-template <bool DIRECT>
-PHANT_DEV bool known_digest(const Args& a, uint32_t j, uint32_t& rj) {
-    rj = j;
-    if constexpr (!DIRECT) {  // (S = 0: no stamps, no representatives)
-        const uint32_t m = a.meta[j];
-        if (m & PRE_GROUP) rj = a.rep[j];
-    }
-    return rj < a.total_nodes && (a.nstat[rj] & NS_HASHED);
-}
-
-// DIRECT: the S = 0 form (a kernel of its own: the two-tier form's code is then exactly what it was without it -- as one
-// kernel with a uniform branch the 100 000-proof launch measured 3 % longer, 0.2205 -> 0.2277 ms)
+// DIRECT: the S = 0 form (no representatives: every node was hashed in place by a lane that knew the proof's key)
 template <bool DIRECT>
 __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
     __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
-    beside_the_hashing();  // (see link_kernel)
+    // With several launches in flight this kernel runs next to OTHER launches' hash waves: a few instructions between memory
+    // round trips at the end of a launch's dependency chain -- raised priority, like the shallow tier's kernels.
+    beside_the_hashing();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const bool in = i < a.v.n;
     uint32_t status = PHANT_PROOF_PRESENT;
+    uint32_t r = 0;
     if (in) {
         uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
         const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
@@ -897,7 +841,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
         uint64_t voff = 0;
         uint32_t vlen = 0;
         const uint32_t first = a.v.proof_first_node[i], last = a.v.proof_first_node[i + 1];
-        const uint32_t r = a.v.root_idx ? a.v.root_idx[i] : 0u;
+        r = a.v.root_idx ? a.v.root_idx[i] : 0u;
         if (last < first || last > a.total_nodes || r >= a.v.n_roots) {
             status = PHANT_PROOF_BAD_INPUT;
         } else if (last == first) {  // no nodes: only the empty trie is proven that way (absence)
@@ -907,10 +851,16 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
             for (int k = 0; k < 8; ++k) rw[k] = rb.u32(4 * k);
             status = is_empty_root(rw) ? PHANT_PROOF_ABSENT : PHANT_PROOF_INVALID_EMPTY;
         } else if (a.hdr[HDR_PFN_BROKEN] != 0u) {
-            status = STATUS_NEEDS_SLOW;  // stamps may be another proof's: nothing derived from them is used
+            status = STATUS_NEEDS_SLOW;  // node states may be another proof's: nothing derived from them is used
         } else {
             const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * i;
             const uint32_t nn = 2u * a.v.key_len;
+            // the nodes of this proof that have a representative entry: index < sx
+            uint32_t sx = 0;
+            if constexpr (!DIRECT) {
+                const uint32_t cnt = last - first, end = cnt <= nn ? cnt : nn + 1u;
+                sx = end < a.shallow ? end : a.shallow;
+            }
             // Two pointers, never merged into one variable: the compiler only emits ds_read for the LDS copies
             // if each access site sees where its pointer comes from (a pointer that may be either turns every
             // byte access into a flat load, which goes through the vector-memory path even when it hits LDS).
@@ -927,26 +877,65 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
             uint32_t used = first;
             status = 0xffffffffu;
 
-            // ---- the run of nodes link_kernel settled: one byte each, eight at a time.  With S = 0 there is neither
-            // plan_kernel nor link_kernel: every node was hashed in place by a lane that knew the proof's key, its state byte
-            // says it all, and the depth the stamp would carry is the walk's own position (it only steps over LINK_FAST) ----
-            constexpr bool direct = DIRECT;
+            // ---- the run of nodes the hash waves settled, eight at a time.  While every node so far was stepped over,
+            // a node's index in the proof is the number of key nibbles consumed.  A deep node's state is its own; a shallow
+            // node that is a copy takes its representative's state if that was the same comparison: root nodes always (same
+            // group = same root), below them when the two parents are the same bytes (same representative one level up; the
+            // key nibble is the same because the group is) ----
             bool hash_known = false;  // the node at `used` is already known to hash to its reference
+            uint32_t rprev = 0;       // representative of the node stepped over last
             for (bool run = true; run && used < last;) {
-                const uint8_t* lp = (direct ? a.nstat : a.link) + used;  // both are followed by 8 readable bytes
+                const uint32_t base = used, dbase = used - first;
+                const uint8_t* lp = a.nstat + base;  // followed by >= 8 readable bytes
                 const uint32_t c0 = load4u(lp), c1 = load4u(lp + 4);
+                uint32_t rj[8], nsr[8], rpar[8];
+                if constexpr (!DIRECT) {
+                    if (dbase < sx) {
+                        const uint8_t* rp = reinterpret_cast<const uint8_t*>(a.rep + base);  // (followed by readable words)
+                        const uint4 r0 = load16u(rp), r1 = load16u(rp + 16);
+                        rj[0] = r0.x; rj[1] = r0.y; rj[2] = r0.z; rj[3] = r0.w;
+                        rj[4] = r1.x; rj[5] = r1.y; rj[6] = r1.z; rj[7] = r1.w;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool sh = dbase + u < sx && base + u < last && rj[u] < a.total_nodes;
+                            rj[u] = sh ? rj[u] : base + u;
+                        }
+                        // the representatives' states and the representatives of THEIR parents: independent gathers
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool copy = rj[u] != base + u;
+                            nsr[u] = copy ? a.nstat[rj[u]] : 0u;
+                            rpar[u] = (copy && rj[u] >= 1u && dbase + u >= 1u) ? a.rep[rj[u] - 1u] : 0xffffffffu;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            rj[u] = base + u;
+                            nsr[u] = 0u;
+                            rpar[u] = 0xffffffffu;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (!run || used >= last) continue;
-                    uint32_t c = ((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 0xffu;
-                    if constexpr (direct) c = (c & NS_HASHED) ? code_of(c, w.pos < nn ? PRE_NIB : 0u) : LINK_GENERIC;
-                    if (c == LINK_FAST) {  // depth == pos and nibble == key nibble by construction of the stamp
+                    const uint32_t own = ((u < 4 ? c0 : c1) >> (8 * (u & 3))) & 0xffu;
+                    uint32_t c, me = used;
+                    if constexpr (DIRECT) {
+                        c = code_of(own, w.pos < nn);
+                    } else {
+                        me = rj[u];
+                        if (me == used) c = code_of(own, w.pos < nn);
+                        else if (used == first || rpar[u] == rprev) c = code_of(nsr[u], w.pos < nn);
+                        else c = LINK_GENERIC;  // another comparison: the generic step compares the digest with ITS reference
+                    }
+                    if (c == LINK_FAST) {
                         ++used;
                         w.pos += 1;
+                        rprev = me;
                     } else {
                         run = false;
                         if (c == LINK_BAD_HASH) status = PHANT_PROOF_BAD_HASH;
-                        else if (c == LINK_SLOW) status = STATUS_NEEDS_SLOW;
                         else hash_known = c == LINK_HASH_OK;
                     }
                 }
@@ -961,9 +950,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                     for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
                 } else {
                     // stepped over node used - 1 (a canonical full branch): its slot for this key's nibble
-                    uint32_t nibp;
-                    if constexpr (direct) nibp = key_nibble(key, w.pos - 1u);
-                    else nibp = (a.meta[used - 1u] >> 4) & 15u;
+                    const uint32_t nibp = key_nibble(key, w.pos - 1u);
                     const uint8_t* rb = a.v.nodes + a.v.node_off[used - 1u] + (4u + 33u * nibp);
                     const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
                     want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
@@ -975,7 +962,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
             uint32_t cur_len = 0, opened = 0;
             const uint8_t* staged_from = nullptr;  // global address of the node currently in the slot
             for (;;) {
-                if (status != 0xffffffffu) break;  // settled from the link codes
+                if (status != 0xffffffffu) break;  // settled from the node states
                 ++opened;
                 if (by_hash) {
                     if (used == last) {
@@ -994,15 +981,30 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                     if (hash_known) {
                         hash_known = false;  // a hash lane compared the digest with the parent's reference
                     } else {
-                        uint32_t rj;
-                        if (!known_digest<DIRECT>(a, j, rj)) {
-                            status = STATUS_NEEDS_SLOW;
-                            break;
+                        // digest of node j as the pipeline knows it: the node's own, or its representative's (identical bytes)
+                        uint32_t rj = j;
+                        if constexpr (!DIRECT) {
+                            if (j - first < sx) rj = a.rep[j];
                         }
-                        const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
-                        const uint4 d0 = dg[0], d1 = dg[1];
-                        const uint32_t diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
-                                              (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
+                        uint32_t diff;
+                        if (rj < a.total_nodes && (a.nstat[rj] & NS_HASHED)) {
+                            const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
+                            const uint4 d0 = dg[0], d1 = dg[1];
+                            diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
+                                   (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
+                        } else {
+                            // a copy that differs from its group's representative (a damaged node), or one whose group lost its
+                            // table slots: nobody hashed it -- this lane does
+                            atomicAdd(&a.hdr[HDR_INLINE], 1u);
+                            Sponge s;
+                            keccak256_global(s, cur, cur_len, nodes_end);
+                            diff = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                diff |= s.lo[k] ^ want[2 * k];
+                                diff |= s.hi[k] ^ want[2 * k + 1];
+                            }
+                        }
                         if (diff) {
                             status = PHANT_PROOF_BAD_HASH;
                             break;
@@ -1067,26 +1069,60 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
         if (a.v.value_off) a.v.value_off[i] = voff;
         if (a.v.value_len) a.v.value_len[i] = vlen;
     }
-    // the verdict, while every status passes through this kernel anyway (fail_count was zeroed by zero_kernel)
+    // the verdict, while every status passes through this kernel anyway (fail_count was zeroed by the launch's first
+    // kernel).  A proof whose root index is out of range counts against root 0: a zero verdict means every proof passed.
     if (a.v.fail_count) {
-        const bool bad = in && !(status == PHANT_PROOF_PRESENT || status == PHANT_PROOF_ABSENT || status == STATUS_NEEDS_SLOW);
+        const bool bad = in && !(status == PHANT_PROOF_PRESENT || status == PHANT_PROOF_ABSENT);
         if (a.v.root_idx == nullptr || a.v.n_roots == 1) {
             const unsigned long long m = __ballot(bad);
             if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&a.v.fail_count[0], (uint32_t)__popcll(m));
         } else if (bad) {
-            const uint32_t r = a.v.root_idx[i];
-            atomicAdd(&a.v.fail_count[r < a.v.n_roots ? r : 0u], 1u);  // (out of range: against root 0, never dropped)
+            atomicAdd(&a.v.fail_count[r < a.v.n_roots ? r : 0u], 1u);
         }
     }
 }
 
 // ---------------------------------------------------------------- node-set witnesses
 // A witness that ships every node ONCE, in any order (what a block builder that deduplicates its proofs
-// sends): references are resolved by hash.  Hash every node (the class lists + hash_list_kernel, nothing to
+// sends): references are resolved by hash.  Hash every node (classify_kernel + hash_set_kernel, nothing to
 // deduplicate, no links), put digest -> node into an open-addressing table, then one lane per key walks from its
 // root.  Semantics: DESIGN.md section 3 with "the node a 32-byte reference points to" = the node of the set with
 // that digest (none: MISSING_NODE; BAD_HASH / EXTRA_NODES / INVALID_EMPTY cannot occur).
 constexpr uint32_t SET_EMPTY = 0xffffffffu;
+
+// one lane per node: sort the well-formed nodes into the rate-block class lists
+__global__ void __launch_bounds__(256) classify_kernel(const Args a) {
+    constexpr uint32_t WAVES = 4;
+    __shared__ uint32_t s_cnt[WAVES][N_LIST];
+    __shared__ uint32_t s_base[N_LIST];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t NT = a.total_nodes;
+    const uint32_t j = blockIdx.x * 256u + tid;
+    uint32_t cls = CLASS_NONE;
+    if (j < NT) {
+        const uint64_t e = a.v.node_off[j + 1], b = a.v.node_off[j];
+        if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) cls = node_list((uint32_t)(e - b));
+    }
+    uint32_t my_rank = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < N_LIST; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (lane == 0) s_cnt[wave][c] = (uint32_t)__popcll(m);
+        if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (tid < N_LIST) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < WAVES; ++w) tot += s_cnt[w][tid];
+        s_base[tid] = tot ? atomicAdd(&a.hdr[tid], tot) : 0u;
+    }
+    __syncthreads();
+    if (cls != CLASS_NONE) {
+        uint32_t at = s_base[cls] + my_rank;
+        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
+        a.ent[(uint64_t)cls * NT + at] = make_uint2(j, 0u);
+    }
+}
 
 __global__ void __launch_bounds__(256) nodeset_insert_kernel(const Args a, uint32_t* tab, uint32_t tab_mask) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
@@ -1236,12 +1272,8 @@ static size_t rnd256(size_t x) { return (x + 255) / 256 * 256; }
 // 16^d groups per root at depth d against n proofs (keys are Keccak outputs: uniform).  Beyond that the table
 // lookups and the byte comparison cost more than hashing the rare duplicate.
 // A batch the chip can hash in a few rounds of waves is hashed whole: below ~530 000 Keccak-f (72 MB of nodes; eight per SIMD
-// lane slot) the shallow tier's extra kernels and the fork / join of the helper stream cost more than the hashing they save.
-// Measured (profiles/r2_d/small_batches_*.jsonl, block_witness_scale_vs_levels.jsonl), one launch / four in flight:
-//   depth-8 proofs, one root:  150 proofs 78 -> 56 us;  1 000  82 -> 59;  3 000  97 -> 61;  10 000 (39 MB) 103 -> 80, 171 -> 276 M
-//                              proofs/s;  16 000 (62 MB) 106 -> 85, 251 -> 293 M;  20 000 (77 MB) equal;  24 000 (92 MB): 339 vs 292 M
-//   block witnesses:           8 000 proofs (23 MB) 130 -> 276 M proofs/s;  16 000 (46 MB) 247 -> 352 M;  24 000 (69 MB) 310 -> 368 M;
-//                              32 000 (92 MB) equal;  40 000 (115 MB): 440 vs 377 M for the two tiers
+// lane slot) the shallow tier's extra kernels and the fork / join of the helper stream cost more than the hashing they save
+// (measured in round 2: profiles/r2_d/small_batches_*.jsonl, block_witness_scale_vs_levels.jsonl).
 constexpr uint64_t HASH_EVERYTHING_BELOW_BYTES = 72000000ull;
 
 static uint32_t shallow_levels(uint32_t n, uint32_t n_roots, uint64_t nodes_len, int32_t forced) {
@@ -1296,21 +1328,19 @@ static uint32_t table_entries(uint32_t n, uint32_t n_roots, uint32_t direct, uin
 }
 
 struct Layout {
-    size_t dtab, table, meta, nstat, rep, ent, digest, gkey, link, end;
+    size_t nstat, dtab, table, rep, ent, cpy, digest, end;
 };
 static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries) {
     const size_t tn = total_nodes;
     Layout l;
     size_t p = HEADER_BYTES;
+    l.nstat = p;  p += rnd256(tn + 16);   // header .. nstat: zeroed per call, contiguous
     l.dtab = p;   p += rnd256((size_t)direct_entries * 4);
     l.table = p;  p += rnd256((size_t)te * 8);
-    l.meta = p;   p += rnd256(tn * 4);
-    l.nstat = p;  p += rnd256(tn);        // header .. nstat: zeroed per call, contiguous
-    l.rep = p;    p += rnd256(tn * 4);
-    l.ent = p;    p += rnd256(tn * 4 * N_LIST);
+    l.rep = p;    p += rnd256(tn * 4 + 64);
+    l.ent = p;    p += rnd256(tn * 8 * N_LIST);
+    l.cpy = p;    p += rnd256(tn * 8 * 2);
     l.digest = p; p += rnd256(tn * 32);
-    l.gkey = p;   p += rnd256(tn * 8);
-    l.link = p;   p += rnd256(tn + 16);
     l.end = p + 1024;
     return l;
 }
@@ -1324,25 +1354,23 @@ size_t workspace_bytes(uint32_t total_nodes) {
 
 static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
     a.hdr = reinterpret_cast<uint32_t*>(ws);
+    a.nstat = ws + l.nstat;
     a.dtab = reinterpret_cast<uint32_t*>(ws + l.dtab);
     a.table = reinterpret_cast<uint64_t*>(ws + l.table);
     a.tmask = te - 1u;
-    a.meta = reinterpret_cast<uint32_t*>(ws + l.meta);
-    a.nstat = ws + l.nstat;
     a.rep = reinterpret_cast<uint32_t*>(ws + l.rep);
-    a.ent = reinterpret_cast<uint32_t*>(ws + l.ent);
+    a.ent = reinterpret_cast<uint2*>(ws + l.ent);
+    a.cpy = reinterpret_cast<uint2*>(ws + l.cpy);
     a.digest = reinterpret_cast<uint32_t*>(ws + l.digest);
-    a.gkey = reinterpret_cast<uint64_t*>(ws + l.gkey);
-    a.link = ws + l.link;
 }
 
-}  // namespace v2
+}  // namespace v3
 
-size_t verify_workspace_bytes(uint32_t total_nodes) { return v2::workspace_bytes(total_nodes); }
+size_t verify_workspace_bytes_v3(uint32_t total_nodes) { return v3::workspace_bytes(total_nodes); }
 
-hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
-                             hipStream_t st, const FlatSide* side, const VerifyTune& tune) {
-    using namespace v2;
+hipError_t launch_mpt_verify_v3(const VerifyArgs& v_in, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
+                                hipStream_t st, const FlatSide* side, const VerifyTune& tune) {
+    using namespace v3;
     VerifyArgs v = v_in;
     v.total_nodes = total_nodes;  // (verify_one bounds every proof's node range by it)
     if (v.n == 0) return hipSuccess;
@@ -1350,106 +1378,95 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     a.v = v;
     a.total_nodes = total_nodes;
     a.shallow = shallow_levels(v.n, v.n_roots, v.nodes_len, dedup_levels);
-    a.all_listed = 0;
+    a.ds_log = 0;
+    while ((1u << a.ds_log) < a.shallow) ++a.ds_log;
     uint64_t direct_entries = 0;
     a.direct = direct_levels(v.n_roots, a.shallow, direct_entries);
     const uint32_t te = table_entries(v.n, v.n_roots, a.direct, a.shallow, total_nodes);
     const Layout l = layout(total_nodes, te, direct_entries);
     bind(a, ws, l, te);
-    // header, tables, stamps and node states are contiguous: one clearing kernel (own kernel instead of hipMemsetAsync: with
-    // several launches in flight it runs next to other launches' hash waves at the head of this launch's chain -- raised
-    // priority is worth 1-1.5 % there)
     hipError_t e = hipSuccess;
-    {
-        const size_t n16 = l.rep / 16;
-        hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)((n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(ws), n16, v.fail_count,
-                           v.n_roots);
-    }
+    const size_t zero_n16 = l.dtab / 16;  // header + node states
     const uint32_t pg = (v.n + 255u) / 256u;
-    if (total_nodes) {
-        const uint32_t ng = (total_nodes + 255u) / 256u;
-        const uint32_t dg = (total_nodes + DEDUP_BLOCK - 1u) / DEDUP_BLOCK;
-        const uint32_t wpl = (v.n + 63u) / 64u;                       // waves per level of the deep tier
-        // One pass of the grid covers `levels` depths below the shallow tier, a wave whose proofs go deeper loops.  Sized
-        // from the batch's average proof length (+ 1): a wave of a level no proof reaches still has to be dispatched and
-        // read its proofs' lengths before it can leave -- with 8 levels for depth-8 proofs above a 5-level shallow tier
-        // that was 7 800 such waves next to 4 700 working ones.
-        const uint64_t avg_len = (total_nodes + v.n - 1u) / v.n;
-        const uint32_t deep_levels = avg_len + 1u <= a.shallow ? 1u
-                                     : (uint32_t)(avg_len + 1u - a.shallow < DEEP_LEVELS ? avg_len + 1u - a.shallow : DEEP_LEVELS);
-        const uint32_t deep_grid = (wpl * deep_levels + 3u) / 4u;
-        const bool two = side && side->stream && side->fork && side->join && a.shallow != 0u && !tune.serial;
-        // deep tier: no inputs but the witness, so it starts at once -- on the helper stream, next to the shallow tier
-        hipStream_t ds = st;
-        const uint32_t deep_lds = two ? tune.hash_lds : 0u;  // (alone, the deep tier takes every wave slot it can get)
-        if (two) {
-            if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
-            ds = side->stream;
-        }
-        // (plan_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep tier
-        // fills every slot it is given the moment it starts -- one launch measures 2 % shorter this way round)
-        // (S = 0: hash_deep_kernel and walk_kernel alone -- nothing reads a stamp or a link code)
-        if (a.shallow) hipLaunchKernelGGL(plan_kernel, dim3(pg), dim3(256), 0, st, a);
-        if (a.shallow) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl, deep_levels);
-        else hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_grid), dim3(256), deep_lds, ds, a, wpl, deep_levels);
-        if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
-        if (a.shallow) {
-            hipLaunchKernelGGL(dedup_kernel, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);
-            // grid bound: every shallow node listed (64-node chunks, 4 waves per workgroup) + one short chunk per list
-            const uint64_t listed = (uint64_t)v.n * a.shallow < total_nodes ? (uint64_t)v.n * a.shallow : total_nodes;
-            const uint32_t hg = (uint32_t)((listed + 255u) / 256u) + N_LIST;
-            // Next to the deep tier the list kernel's workgroups count against the same cap (same LDS footprint: any three
-            // hash workgroups per CU), so that a fourth hash wave never takes the registers the comparison, link and walk
-            // waves of this and other launches need -- for single-root batches, where the list is small next to the deep tier
-            // (same-box A/B, config 3: 4 in flight +1.5 %, one launch -1.8 %; config 4, whose list kernel is the longer one:
-            // 4 in flight +1.5 % but one launch +8 %: left alone there)
-            const uint32_t list_lds = (two && v.n_roots == 1u) ? tune.hash_lds + 8192u : 0u;
-            hipLaunchKernelGGL(hash_list_kernel, dim3(hg), dim3(256), list_lds, st, a);
-        }
-        if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
-        if (a.shallow) hipLaunchKernelGGL(link_kernel, dim3(ng), dim3(256), 0, st, a);
+    const uint32_t wpl = (v.n + 63u) / 64u;  // waves per level of the deep role
+    // One pass of the deep waves covers `levels` depths below the shallow tier, a wave whose proofs go deeper loops.  Sized
+    // from the batch's average proof length (+ 1): a wave of a level no proof reaches still has to be dispatched and read
+    // its proofs' lengths before it can leave.
+    const uint64_t avg_len = total_nodes ? (total_nodes + v.n - 1u) / v.n : 0u;
+    const uint32_t deep_levels = avg_len + 1u <= a.shallow ? 1u
+                                 : (uint32_t)(avg_len + 1u - a.shallow < DEEP_LEVELS ? avg_len + 1u - a.shallow : DEEP_LEVELS);
+    const uint32_t deep_wgs = (wpl * deep_levels + 3u) / 4u;
+    if (a.shallow == 0u || total_nodes == 0u) {
+        // S = 0: clear, hash every node in place, walk on the node states.  No lists, tables or helper stream.
+        a.shallow = 0;
+        hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)((zero_n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(ws),
+                           zero_n16, v.fail_count, v.n_roots);
+        if (total_nodes) hipLaunchKernelGGL(hash_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, 0u, wpl, deep_levels);
+        hipLaunchKernelGGL(walk_kernel<true>, dim3(pg), dim3(256), 0, st, a);
+        return hipGetLastError();
     }
-    if (a.shallow) hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(walk_kernel<true>, dim3(pg), dim3(256), 0, st, a);
+    // ---- two tiers ----
+    const uint64_t lanes = (uint64_t)v.n << a.ds_log;
+    const uint32_t sg = (uint32_t)((lanes + 255u) / 256u);
+    hipLaunchKernelGGL(propose_kernel, dim3(sg), dim3(256), 0, st, a, reinterpret_cast<uint4*>(ws), zero_n16);
+    hipLaunchKernelGGL(elect_kernel, dim3(sg), dim3(256), 0, st, a);
+    // everything that is hashed: on the helper stream, next to the comparison
+    const bool two = side && side->stream && side->fork && side->join && !tune.serial;
+    hipStream_t hs = st;
+    if (two) {
+        if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
+        hs = side->stream;
+    }
+    // grid bound of the list role: every shallow node listed (64-node chunks, 4 waves per workgroup) + one short chunk per list
+    const uint64_t listed = (uint64_t)v.n * a.shallow < total_nodes ? (uint64_t)v.n * a.shallow : total_nodes;
+    const uint32_t list_wgs = (uint32_t)((listed + 255u) / 256u) + (N_LIST + 3u) / 4u;
+    // An otherwise unused dynamic LDS allocation caps the hash workgroups per CU while the comparison runs next to them
+    // (VerifyTune::hash_lds): room for the memory-bound waves
+    hipLaunchKernelGGL(hash_kernel<false>, dim3(list_wgs + deep_wgs), dim3(256), two ? tune.hash_lds : 0u, hs, a, list_wgs, wpl, deep_levels);
+    if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+    {
+        // grid bound of the comparison: every shallow node a copy
+        const uint32_t cg = (uint32_t)((listed + 255u) / 256u) + 2u;
+        hipLaunchKernelGGL(compare_kernel, dim3(cg), dim3(256), 0, st, a);
+    }
+    if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
-static uint32_t nodeset_table_entries(uint32_t total_nodes) {
+static uint32_t nodeset_table_entries_v3(uint32_t total_nodes) {
     uint32_t t = 1024;
     while (t < 2u * total_nodes && t < (1u << 31)) t <<= 1;
     return t;
 }
 
-size_t verify_nodeset_workspace_bytes(uint32_t total_nodes) {
-    return v2::workspace_bytes(total_nodes) + v2::rnd256((size_t)nodeset_table_entries(total_nodes) * 4);
+size_t verify_nodeset_workspace_bytes_v3(uint32_t total_nodes) {
+    return v3::workspace_bytes(total_nodes) + v3::rnd256((size_t)nodeset_table_entries_v3(total_nodes) * 4);
 }
 
-hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, hipStream_t st) {
-    using namespace v2;
+hipError_t launch_mpt_verify_nodeset_v3(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, hipStream_t st) {
+    using namespace v3;
     if (v.n == 0) return hipSuccess;
     Args a;
     a.v = v;
     a.total_nodes = total_nodes;
     a.shallow = 0;
+    a.ds_log = 0;
     a.direct = 0;
-    a.all_listed = 1;
     const uint32_t te = 1024;
     const Layout l = layout(total_nodes, te, 0);
     bind(a, ws, l, te);
     uint32_t* tab = reinterpret_cast<uint32_t*>(ws + workspace_bytes(total_nodes));
-    const uint32_t tab_entries = nodeset_table_entries(total_nodes);
-    hipError_t e = hipMemsetAsync(ws, 0, HEADER_BYTES, st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.nstat, 0, total_nodes, st);
+    const uint32_t tab_entries = nodeset_table_entries_v3(total_nodes);
+    hipError_t e = hipMemsetAsync(ws, 0, l.dtab, st);  // header + node states
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tab, 0xff, (size_t)tab_entries * 4, st);
     if (e != hipSuccess) return e;
     if (total_nodes) {
         const uint32_t ng = (total_nodes + 255u) / 256u;
-        const uint32_t dg = (total_nodes + DEDUP_BLOCK - 1u) / DEDUP_BLOCK;
-        hipLaunchKernelGGL(dedup_kernel, dim3(dg), dim3(DEDUP_BLOCK), 0, st, a);  // class lists only
-        hipLaunchKernelGGL(hash_list_kernel, dim3(ng + N_LIST), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(classify_kernel, dim3(ng), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(hash_set_kernel, dim3(ng + (N_LIST + 3u) / 4u), dim3(256), 0, st, a);
         hipLaunchKernelGGL(nodeset_insert_kernel, dim3(ng), dim3(256), 0, st, a, tab, tab_entries - 1u);
     }
     hipLaunchKernelGGL(nodeset_walk_kernel, dim3((v.n + 255u) / 256u), dim3(256), 0, st, a, tab, tab_entries - 1u);
@@ -1457,17 +1474,17 @@ hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, 
 }
 
 // nodes hashed per rate-block class by the last launch on this workspace (host copy of the header)
-void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]) {
-    using namespace v2;
+void verify_stats_from_header_v3(const uint32_t* hdr, uint32_t hashed[8]) {
+    using namespace v3;
     for (uint32_t c = 0; c < N_CLASS; ++c) {
         hashed[c] = hdr[c];
         for (uint32_t s = 0; s < HDR_STAT_STRIPES; ++s) hashed[c] += hdr[HDR_STAT + N_CLASS * s + c];
     }
     hashed[BRANCH_LEN / RATE] += hdr[LIST_B532];
 }
-void verify_paths_from_header(const uint32_t* hdr, uint32_t out[2]) {
-    out[0] = hdr[v2::HDR_SLOW];
-    out[1] = hdr[v2::HDR_OPENED];
+void verify_paths_from_header_v3(const uint32_t* hdr, uint32_t out[2]) {
+    out[0] = hdr[v3::HDR_SLOW];
+    out[1] = hdr[v3::HDR_OPENED] + hdr[v3::HDR_INLINE];
 }
 
 }  // namespace phant

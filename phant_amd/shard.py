@@ -78,14 +78,17 @@ def partition(b: HostBatch, world: int) -> list[np.ndarray]:
 
 
 def fail_counts(status: np.ndarray, root_idx: np.ndarray | None, n_roots: int) -> np.ndarray:
-    """Host restatement of phant_mpt_verdict_dev: proofs per root that are neither PRESENT (1) nor ABSENT (2)."""
+    """Host restatement of phant_mpt_verdict_dev: proofs per root that are neither PRESENT (1) nor ABSENT (2); a root
+    index out of range counts against root 0 (an all-zero verdict means every proof passed)."""
     bad = ~((status == 1) | (status == 2))
     if root_idx is None:
         out = np.zeros(n_roots, np.int32)
         if n_roots:
             out[0] = int(bad.sum())
         return out
-    return np.bincount(np.asarray(root_idx, np.int64)[bad], minlength=n_roots).astype(np.int32)
+    ri = np.asarray(root_idx, np.int64)
+    ri = np.where((ri >= 0) & (ri < n_roots), ri, 0)
+    return np.bincount(ri[bad], minlength=n_roots).astype(np.int32)
 
 
 def gpu_verify(b: HostBatch):

@@ -3,11 +3,12 @@ import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "phant::" in r["Kernel_Name"] and "keccak256_fixed" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first = ("hash_deep", "plan_kernel") if any("hash_deep" in r["Kernel_Name"] for r in rows) else ("plan_kernel",)
+first = ("propose_kernel", "zero_kernel") if any("propose_kernel" in r["Kernel_Name"] for r in rows) else \
+    ("hash_deep", "plan_kernel") if any("hash_deep" in r["Kernel_Name"] for r in rows) else ("plan_kernel",)
 t0 = None
 cur = []
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("phant::v2::", "").replace("phant::", "")
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("phant::v2::", "").replace("phant::v3::", "").replace("phant::", "")
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if t0 is None or (any(x in name for x in first) and s - t0 > 100_000):
         if cur:
