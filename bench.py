@@ -654,8 +654,8 @@ def main():
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
 
     pipeline = ("two-tier verify pipeline = hash_deep_kernel (in-place hashing of the deep levels, helper stream) next to "
-                "plan_kernel + dedup_kernel + hash_list_kernel (deduplicated shallow levels), then link_kernel + "
-                "walk_kernel (one launch of the path, first kernel start to last kernel end; the hash kernels are "
+                "propose_kernel + dedup_kernel + hash_list_kernel (deduplicated shallow levels), then walk_kernel "
+                "(one launch of the path, first kernel start to last kernel end; the hash kernels are "
                 "integer-VALU-bound, see roofline.valu)")
     line = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
@@ -674,7 +674,7 @@ def main():
                                                         if args.workload == "config3" else None)) else None),
                      "traffic_detail": tr,
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
-                                "node-set pipeline = dedup_kernel (class lists) + hash_list_kernel + "
+                                "node-set pipeline = classify_kernel (class lists) + hash_set_kernel + "
                                 "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
                                 "trie hasher = lcp_kernel + tree_level_kernel x log n + identify_kernel + order_kernel + "
                                 "leaf_kernel + branch_kernel per depth (first start to last end, two counter read-backs "

@@ -160,7 +160,6 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         c->tune.hash_lds = (uint32_t)(kb < 0 ? 0 : kb > 63 ? 63 : kb) * 1024u;  // (< 64 KiB needs no opt-in)
     }
     if (const char* t = std::getenv("PHANT_VERIFY_SERIAL")) c->tune.serial = t[0] == '1';
-    if (const char* t = std::getenv("PHANT_VERIFY_PIPE")) c->tune.pipe = t[0] == '2' ? 2u : 3u;
     DeviceGuard g(dev);
     if (!own) {
         c->stream = (hipStream_t)stream;  // nullptr = the default stream
@@ -241,8 +240,7 @@ int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
     // list counts and the deep tier's striped counters, in the header of the verify workspace (mpt_verify_v2.hip)
     uint32_t hdr[phant::VERIFY_HEADER_WORDS];
     HIP_TRY(c, hipMemcpy(hdr, c->dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
-    if (c->tune.pipe == 2u) phant::verify_stats_from_header(hdr, hashed);
-    else phant::verify_stats_from_header_v3(hdr, hashed);
+    phant::verify_stats_from_header(hdr, hashed);
     return PHANT_OK;
 }
 
@@ -255,8 +253,7 @@ int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
     if (c->side.stream) HIP_TRY(c, hipStreamSynchronize(c->side.stream));
     uint32_t hdr[phant::VERIFY_HEADER_WORDS];
     HIP_TRY(c, hipMemcpy(hdr, c->dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
-    if (c->tune.pipe == 2u) phant::verify_paths_from_header(hdr, out);
-    else phant::verify_paths_from_header_v3(hdr, out);
+    phant::verify_paths_from_header(hdr, out);
     return PHANT_OK;
 }
 
@@ -445,8 +442,7 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
         }
         return PHANT_OK;
     }
-    const bool v2 = c->tune.pipe == 2u;
-    const size_t need = v2 ? phant::verify_workspace_bytes(total_nodes) : phant::verify_workspace_bytes_v3(total_nodes);
+    const size_t need = phant::verify_workspace_bytes(total_nodes);
     if (need > dv.cap) {
         HIP_TRY(c, hipStreamSynchronize(st));
         hipError_t e = dv.reset(need);
@@ -455,10 +451,7 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
         // correctness; it keeps the first launch on fresh memory deterministic)
         HIP_TRY(c, hipMemsetAsync(dv.base, 0, dv.cap, st));
     }
-    auto launch = [&]() {
-        return v2 ? phant::launch_mpt_verify(a, total_nodes, dv.base, c->dedup_levels, st, side, c->tune)
-                  : phant::launch_mpt_verify_v3(a, total_nodes, dv.base, c->dedup_levels, st, side, c->tune);
-    };
+    auto launch = [&]() { return phant::launch_mpt_verify(a, total_nodes, dv.base, c->dedup_levels, st, side, c->tune); };
     if (timed) {
         TimedRegion t(c);
         HIP_TRY(c, launch());
@@ -668,8 +661,7 @@ int32_t phant_mpt_verify_nodeset_dev(phant_ctx* c, const uint8_t* d_roots, uint3
     if (!d_roots || n_roots == 0 || !d_node_off || !d_status || (key_len && !d_keys) || key_len > 0x3fffffffu)
         return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset_dev: bad argument");
     DeviceGuard g(c->device);
-    const bool v2 = c->tune.pipe == 2u;
-    const size_t need = v2 ? phant::verify_nodeset_workspace_bytes(total_nodes) : phant::verify_nodeset_workspace_bytes_v3(total_nodes);
+    const size_t need = phant::verify_nodeset_workspace_bytes(total_nodes);
     if (need > c->dv.cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         hipError_t e = c->dv.reset(need);
@@ -678,8 +670,7 @@ int32_t phant_mpt_verify_nodeset_dev(phant_ctx* c, const uint8_t* d_roots, uint3
     phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len, d_node_off, nullptr, n,
                         d_status, d_value_off, d_value_len};
     TimedRegion t(c);
-    HIP_TRY(c, v2 ? phant::launch_mpt_verify_nodeset(a, total_nodes, c->dv.base, c->stream)
-                  : phant::launch_mpt_verify_nodeset_v3(a, total_nodes, c->dv.base, c->stream));
+    HIP_TRY(c, phant::launch_mpt_verify_nodeset(a, total_nodes, c->dv.base, c->stream));
     return PHANT_OK;
 }
 

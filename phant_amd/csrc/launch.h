@@ -46,8 +46,8 @@ struct VerifyArgs {
                                      // caller, capi.hip::verify_resident_on)
 };
 hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
-// Two-tier pipeline (mpt_verify_v2.hip): the trie levels that repeat across proofs are deduplicated (plan ->
-// dedup/compare -> class-sorted hashing of the distinct nodes), the deeper ones hashed in place, then link -> walk.
+// Two-tier pipeline (mpt_verify_v3.hip): the trie levels that repeat across proofs are deduplicated (propose ->
+// dedup/compare -> class-sorted hashing of the distinct nodes), the deeper ones hashed in place next to that, then walk.
 // ws = verify_workspace_bytes().  dedup_levels: how many levels from the root are deduplicated; < 0 = chosen from the
 // batch size, 0 = hash every shipped node (A/B).  `side` (may be null): helper stream + events owned by the ctx; with
 // it the deep tier runs NEXT TO the shallow tier (VALU-bound hashing beside a memory stream), without it in front.
@@ -59,27 +59,17 @@ size_t verify_workspace_bytes(uint32_t total_nodes);
 // The deep tier's occupancy cap and a diagnostics switch (fixed per ctx).
 struct VerifyTune {
     // An otherwise unused dynamic LDS allocation per workgroup of the deep tier caps how many of them a CU holds
-    // (160 KiB / it) WHILE the shallow tier's memory-bound kernels run next to it: 40 KiB -> 4 hash waves per SIMD,
-    // which leaves those kernels a slot per SIMD (measured on BASELINE config 3: 0.254 ms per launch uncapped,
-    // 0.237 at 40 KiB, 0.250 at 52 KiB = 3 waves).  Alone, the deep tier is launched without it.
+    // (160 KiB / (8 KiB + it)) WHILE the shallow tier's memory-bound kernels run next to it: 40 KiB -> 3 workgroups = 3 hash
+    // waves per SIMD = 360 of its 512 VGPRs, which leaves dedup_kernel (48) three waves per SIMD (measured on BASELINE
+    // config 3, round 3: one launch 0.262 ms uncapped, 0.234 at 40 KiB, 0.237 at 52 KiB).  Alone, the deep tier runs uncapped.
     uint32_t hash_lds = 40u * 1024u;
     bool serial = false;  // diagnostics: the tiers one after the other on the ctx stream (clean per-kernel durations in a trace)
-    uint32_t pipe = 3;    // A/B while both exist: 3 = mpt_verify_v3.hip (propose / elect / compare next to one hash kernel / walk),
-                          // 2 = round 2's seven-launch chain (mpt_verify_v2.hip)
 };
 hipError_t launch_mpt_verify(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
                              hipStream_t st, const FlatSide* side, const VerifyTune& tune);
-// round 3's pipeline (mpt_verify_v3.hip), same contract
-size_t verify_workspace_bytes_v3(uint32_t total_nodes);
-hipError_t launch_mpt_verify_v3(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
-                                hipStream_t st, const FlatSide* side, const VerifyTune& tune);
-void verify_stats_from_header_v3(const uint32_t* hdr, uint32_t hashed[8]);
-void verify_paths_from_header_v3(const uint32_t* hdr, uint32_t out[2]);
-size_t verify_nodeset_workspace_bytes_v3(uint32_t total_nodes);
-hipError_t launch_mpt_verify_nodeset_v3(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, hipStream_t st);
 // nodes hashed per rate-block class by the last launch, from a host copy of the workspace's first
 // VERIFY_HEADER_WORDS words
-constexpr uint32_t VERIFY_HEADER_WORDS = 160;
+constexpr uint32_t VERIFY_HEADER_WORDS = 2048;
 void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]);
 // out[0] = proofs the walk could not settle from the tables (verified from scratch by their lane), out[1] = nodes
 // decoded by walks that had to decode more than one

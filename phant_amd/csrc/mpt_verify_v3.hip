@@ -5,37 +5,38 @@
 // gfx950, comparing two nodes is a memory stream.  So the batch is cut at a depth S ("shallow
 // levels", chosen on the host from the batch size):
 //
-//   shallow tier (node index d < S inside its proof): copies are COMPARED with one representative per
-//   (root, d, first d key nibbles) group instead of being hashed.
+//   deep tier (node index d >= S inside its proof): nothing to deduplicate.  hash_deep_kernel hashes these nodes in
+//        place -- wave = 64 consecutive proofs at one depth, lane = proof; a proof's node at depth d is node
+//        proof_first_node[p] + d, its key nibble comes from the key -- with nothing in front of it: it starts at once, on
+//        the helper stream, and is the VALU-bound bulk of the launch.  It clears nothing and needs nothing cleared.
+//   shallow tier (d < S), on the main stream, NEXT TO it: copies are COMPARED with one representative per
+//        (root, d, first d key nibbles) group instead of being hashed.
 //        propose_kernel   one lane per (proof, d < S): every multi-block node writes itself into its group's table slot
 //                         (plain stores, last writer wins -- no atomics, so a group of 100 000 members costs what a group
-//                         of one does); the kernel also clears the header, the node states and the verdict counters.
-//        elect_kernel     the same lanes read the slot back: the node found there is the group's representative.  It and
-//                         every node without a group are LISTED for hashing (per rate-block class, with the proof they
-//                         belong to); a copy goes to the compare list with its representative.  rep[j] for every node.
-//        compare_kernel   dense over the compare list: a half wave per 532-byte copy, 16 bytes per lane, coalesced, next
-//                         to the representative's bytes (L2 / Infinity-Cache hits).  A copy that differs gets rep[j] = j:
-//                         nobody hashed it, the walk that meets it hashes it itself (damaged proofs only).
-//   hash_kernel (helper stream, NEXT TO compare_kernel; it starts when the lists are complete): one kernel for everything
-//        that is hashed --
-//          list role      one 64-node chunk of one class list per wave (the shallow tier's representatives),
-//          deep role      wave = 64 consecutive proofs at one depth >= S, lane = proof: nothing is looked up, a proof's
-//                         node at depth d is node proof_first_node[p] + d, its key nibble comes from the key.
-//        Both settle, while the digest is still in registers, whether the node is what its parent commits to: the parent
-//        of node j inside a proof is node j - 1, and if that is a full 532-byte branch the reference for this key's nibble
-//        sits at byte 4 + 33 nibble (root nodes: the root table).  One status byte per hashed node (nstat[]).
-//   walk_kernel          one lane per proof.  Steps over the run of nodes whose state says "hash matches, canonical full
+//                         of one does); the kernel also clears the header, the shallow nodes' states and the verdict.
+//        dedup_kernel     the same lanes read the slot back: the node found there is the group's representative.  A wave
+//                         byte-compares its copies with their representatives, a half wave per 532-byte copy, 16 bytes per
+//                         lane, coalesced (the representative's bytes: L2 / Infinity-Cache hits).  Equal => rep[j] =
+//                         representative (never hashed); the representatives, the nodes without a group and the copies
+//                         that differ are listed for hashing, compacted per rate-block class, with their owner proof.
+//        hash_list_kernel one 64-node chunk of one class list per wave.
+//   Both hash roles settle, while the digest is still in registers, whether the node is what its parent commits to: the
+//   parent of node j inside a proof is node j - 1, and if that is a full 532-byte branch the reference for this key's
+//   nibble sits at byte 4 + 33 nibble (root nodes: the root table).  One status byte per hashed node (nstat[]).
+//        walk_kernel      one lane per proof.  Steps over the run of nodes whose state says "hash matches, canonical full
 //                         branch" -- a copy takes its representative's state when it was the same comparison (below) --
 //                         and decodes the rest (DESIGN.md section 3 order of checks) from an LDS copy: for BASELINE's
 //                         proofs just the leaf.  Counts the per-root verdict.
 //
 //   S = 0 (small batches: under 72 MB of nodes the chip hashes everything in a few rounds of waves): zero_kernel,
-//   hash_kernel with the deep role over every depth, walk_kernel reading the node states directly.
+//   hash_deep_kernel over every depth, walk_kernel reading the node states directly.
 //
-// Round 2's pipeline (mpt_verify_v2.hip) had seven launches on its critical chain: zero, plan, dedup, hash_list, link, walk
-// with hash_deep beside them.  plan's per-node stamps and group keys (12 MB of stores), link's pass over every node and the
-// list kernel's 4-permutation latency chain BEHIND the comparison are gone: the chain is propose, elect, compare, walk, and
-// all hashing is one pool of waves that starts the moment the lists exist.
+// Against round 2's chain (zero, plan, dedup, hash_list, link, walk with hash_deep beside them): no per-node stamps and
+// group keys (plan's 12 MB of stores, read back by three kernels: the lanes of the node-parallel kernels are (proof, level)
+// pairs and know their owner), no link pass over every node (the walk gathers the few bytes it needs itself), no clearing
+// kernel and no table clearing at all.  What was measured and dropped on the way: the election
+// split from the comparison (so that the lists are complete early and ALL hashing is one pool of waves behind it; the
+// copies that differ then need a late pass), the comparison as a persistent grid, prefetched rate blocks.
 //
 // Soundness.  rep[j] = r != j only if (i) r was found in the slot of j's group and belongs to that group -- by construction
 // for the direct-mapped levels (the slot index is an injective function of (root, d, prefix)), by checking r's owner proof
@@ -61,10 +62,10 @@ namespace v3 {
 constexpr uint32_t N_CLASS = 8;        // class c = (c+1) rate blocks; last class = 8 or more
 constexpr uint32_t LIST_B532 = 8;      // list of the nodes that are exactly 532 bytes long
 constexpr uint32_t N_LIST = 9;
-constexpr uint32_t COPY_B532 = 9;      // compare list: 532-byte copies {node, representative}
-constexpr uint32_t COPY_OTHER = 10;    // compare list: other multi-block copies
-constexpr uint32_t N_CURSOR = 11;
 constexpr uint32_t CLASS_NONE = 0xffu;
+constexpr uint32_t STRIPES = 8;        // every class list is kept as STRIPES sub-lists (workgroup b appends to b mod STRIPES):
+                                       // returning atomics on ONE address are served one at a time, ~11.6 ns each
+                                       // (tools/ubench/atomic_rate.hip) -- thousands of workgroups on one cursor are tens of us
 constexpr uint32_t MAX_SHALLOW = 16;   // key prefix of <= 16 nibbles fits 64 bits
 constexpr uint32_t STATUS_NEEDS_SLOW = 0xffu;
 constexpr uint32_t BRANCH_LEN = 532u;  // f9 02 11 | 16 x (a0 + 32 bytes) | 80
@@ -73,14 +74,23 @@ constexpr uint32_t BRANCH_LEN = 532u;  // f9 02 11 | 16 x (a0 + 32 bytes) | 80
 constexpr uint32_t HDR_PFN_BROKEN = 9;   // some proof has last < first
 constexpr uint32_t HDR_SLOW = 10;        // proofs verified from scratch by their walk lane (reporting only)
 constexpr uint32_t HDR_OPENED = 11;      // nodes decoded by walks that decoded more than one (reporting only)
-constexpr uint32_t HDR_COPY_B532 = 12;   // entries of the two compare lists
-constexpr uint32_t HDR_COPY_OTHER = 13;
-constexpr uint32_t HDR_INLINE = 14;      // nodes hashed by a walk lane: copies that differ from their representative (reporting only)
-constexpr uint32_t HDR_STAT = 16;        // + 16 x stripe + class: nodes hashed by the deep role (reporting only)
+constexpr uint32_t HDR_PARITY = 15;      // which of the two statistics buffers this launch's deep role counts into.  The deep role may
+                                         // start before anything of the launch has cleared anything: propose_kernel clears the OTHER
+                                         // buffer (the next launch's), the walk flips the word when the launch is over.  Never cleared
+                                         // by the two-tier form.
+constexpr uint32_t HDR_STAT = 1024;      // + 128 x buffer + 8 x stripe + class: nodes hashed by the deep role (reporting only).  A page
+                                         // of their own: next to the list cursors, the thousands of atomics of the deep role's waves
+                                         // made dedup_kernel's reservations wait (measured: 117 -> 136 us next to the deep tier)
 constexpr uint32_t HDR_STAT_STRIPES = 16;
-constexpr size_t HEADER_BYTES = 2048;
+constexpr uint32_t HDR_STAT_WORDS = HDR_STAT_STRIPES * N_CLASS;            // per buffer
+constexpr uint32_t HDR_STAT_END = HDR_STAT + 2u * HDR_STAT_WORDS;          // 1280
+constexpr uint32_t HDR_CUR = 256;        // + 32 x stripe + class: the lists' counts (a 128-byte line per stripe)
+constexpr uint32_t HDR_WORDS = 512;      // flags and cursors; the statistics behind them
+constexpr size_t HEADER_BYTES = 8192;
+static_assert(HDR_STAT_END <= VERIFY_HEADER_WORDS && 4u * VERIFY_HEADER_WORDS <= HEADER_BYTES,
+              "capi.hip copies VERIFY_HEADER_WORDS words back for the statistics");
 
-PHANT_DEV uint32_t cursor_word(uint32_t cls) { return cls < N_LIST ? cls : HDR_COPY_B532 + (cls - COPY_B532); }
+PHANT_DEV uint32_t cursor_word(uint32_t cls, uint32_t stripe) { return HDR_CUR + 32u * stripe + cls; }
 
 // nstat[] bits
 constexpr uint32_t NS_HASHED = 1u, NS_CANON = 2u, NS_LINK_CHECKED = 4u, NS_LINK_OK = 8u;
@@ -146,17 +156,16 @@ struct Args {
     uint32_t total_nodes;
     uint32_t shallow;        // nodes of index < shallow in their proof are deduplicated and hashed from the class lists;
                              // the others are hashed in place by the deep role.  0 = hash every shipped node
-    uint32_t ds_log;         // the shallow tier's kernels give every proof 2^ds_log lanes (>= shallow)
     uint32_t direct;         // levels [0, direct) of the shallow tier have a direct-mapped table, the others the hashed one
     uint32_t* dtab;          // n_roots x (16^direct - 1) / 15 entries: node + 1 of a member of the group
     uint64_t* table;         // tmask + 1 entries {owner proof:32 | node + 1:32}
     uint32_t tmask;
     uint32_t* rep;           // total_nodes; written for the shallow tier's nodes
-    uint2* ent;              // N_LIST x total_nodes: {node, owner proof} to hash, per list
-    uint2* cpy;              // 2 x total_nodes: {node, representative} to compare
-    uint32_t* hdr;           // header: [0..8] list counts, HDR_*; zeroed per call
+    uint2* ent;              // N_LIST x STRIPES x stripe_cap: {node, owner proof} to hash, per list and stripe
+    uint32_t stripe_cap;     // entries per (class, stripe) = lanes of the workgroups that append there
+    uint32_t* hdr;           // header: HDR_*; cleared per call (propose_kernel / zero_kernel)
     uint32_t* digest;        // total_nodes x 8
-    uint8_t* nstat;          // total_nodes: NS_* of the node, written by the lane that hashed it; zeroed per call
+    uint8_t* nstat;          // total_nodes: NS_* of the node, written by the lane that hashed it
 };
 
 // The memory-bound kernels run NEXT TO hash waves that never stop issuing: a few instructions, then a wait for memory -- at
@@ -173,7 +182,8 @@ __global__ void __launch_bounds__(256) zero_kernel(uint4* p, size_t n16, uint32_
 }
 
 // ---------------------------------------------------------------- the shallow tier's lanes
-// Lane g of propose_kernel / elect_kernel: proof g >> ds_log, node index g & (2^ds_log - 1) inside it.
+// Lane g of propose_kernel / dedup_kernel: proof g / S, node index g mod S inside it (consecutive lanes = consecutive
+// nodes: the offset loads and the per-node stores are coalesced).
 struct ShallowLane {
     uint32_t p, d, j, root, len;
     uint64_t kb;
@@ -184,14 +194,14 @@ struct ShallowLane {
 };
 PHANT_DEV ShallowLane shallow_lane(const Args& a, uint32_t g) {
     ShallowLane L;
-    L.p = g >> a.ds_log;
-    L.d = g & ((1u << a.ds_log) - 1u);
+    L.p = g / a.shallow;
+    L.d = g - L.p * a.shallow;
     L.j = 0;
     L.root = 0;
     L.len = 0;
     L.kb = 0;
     L.act = L.valid = L.group = L.broken = false;
-    if (L.p >= a.v.n || L.d >= a.shallow) return L;
+    if (L.p >= a.v.n) return L;
     const uint32_t first = a.v.proof_first_node[L.p], last = a.v.proof_first_node[L.p + 1];
     if (last < first) {
         L.broken = L.d == 0u;
@@ -216,16 +226,27 @@ PHANT_DEV ShallowLane shallow_lane(const Args& a, uint32_t g) {
 }
 
 // ---------------------------------------------------------------- propose
-__global__ void __launch_bounds__(256) propose_kernel(const Args a, uint4* zero_p, size_t zero_n16) {
+// Also the launch's clearing kernel: the header (but for the deep role's statistics buffer, which may already be counting),
+// the verdict counters and the state byte of every shallow node (the deep role writes the state of every node it owns
+// itself, so nothing else of nstat[] is read before it is written).
+__global__ void __launch_bounds__(256) propose_kernel(const Args a) {
     beside_the_hashing();
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    {   // header + node states + verdict counters (nothing else of this launch has started)
+    {
         const size_t lanes = (size_t)gridDim.x * 256u;
-        for (size_t i = g; i < zero_n16; i += lanes) zero_p[i] = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t other = HDR_STAT + HDR_STAT_WORDS * ((a.hdr[HDR_PARITY] & 1u) ^ 1u);  // (the deep role may be counting in this launch's)
+        for (size_t i = g; i < HDR_WORDS + HDR_STAT_WORDS; i += lanes) {
+            if (i < HDR_WORDS) {
+                if (i != HDR_PARITY) a.hdr[i] = 0u;
+            } else {
+                a.hdr[other + (i - HDR_WORDS)] = 0u;
+            }
+        }
         if (a.v.fail_count)
             for (size_t r = g; r < a.v.n_roots; r += lanes) a.v.fail_count[r] = 0u;
     }
     const ShallowLane L = shallow_lane(a, g);
+    if (L.act) a.nstat[L.j] = 0u;
     if (!L.group) return;
     if (L.d < a.direct) {
         a.dtab[direct_index(L.kb, L.root, L.d, a.v.n_roots)] = L.j + 1u;
@@ -237,7 +258,7 @@ __global__ void __launch_bounds__(256) propose_kernel(const Args a, uint4* zero_
     }
 }
 
-// ---------------------------------------------------------------- elect
+// ---------------------------------------------------------------- dedup
 // Does the hashed table's entry name a node of THIS lane's group?  Whatever the slot holds (another group of this launch,
 // something an earlier launch left): the entry's owner proof must exist, have a sane node range, the node must be its
 // node of index d, and root index and the first d key nibbles must be this lane's.
@@ -252,68 +273,11 @@ PHANT_DEV bool entry_matches(const Args& a, uint64_t en, const ShallowLane& L, u
     return same_prefix(key_prefix64(a.v.keys + (uint64_t)a.v.key_len * pr, a.v.key_len), L.kb, L.d);
 }
 
-__global__ void __launch_bounds__(256) elect_kernel(const Args a) {
-    constexpr uint32_t WAVES = 4;
-    __shared__ uint32_t s_cnt[WAVES][N_CURSOR];
-    __shared__ uint32_t s_base[N_CURSOR];
-    beside_the_hashing();
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t NT = a.total_nodes;
-    if (tid < WAVES * N_CURSOR) (&s_cnt[0][0])[tid] = 0u;
-    const ShallowLane L = shallow_lane(a, blockIdx.x * 256u + tid);
-    // proof_first_node is not monotone: node ranges of OTHER proofs may then overlap, and what one proof's lanes find out
-    // about a node would be read by another.  Tell the walk not to trust anything.
-    if (L.broken) a.hdr[HDR_PFN_BROKEN] = 1u;
-
-    uint32_t cand = L.j;
-    if (L.group) {
-        uint32_t c = L.j;
-        if (L.d < a.direct) {
-            const uint32_t t = a.dtab[direct_index(L.kb, L.root, L.d, a.v.n_roots)];
-            if (t) c = t - 1u;
-        } else {
-            const uint64_t h = group_hash(L.kb, L.root, L.d);
-            uint32_t node;
-            if (entry_matches(a, a.table[slot_a(h, a.tmask)], L, node)) c = node;
-            else if (entry_matches(a, a.table[slot_b(h, a.tmask)], L, node)) c = node;
-        }
-        if (c != L.j && c < NT) {
-            // a representative is only usable if it is a well-formed node of the same length
-            const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
-            if (c1 >= c0 && c1 <= a.v.nodes_len && c1 - c0 == L.len) cand = c;
-        }
-    }
-    if (L.act) a.rep[L.j] = cand;
-
-    // ---- lists: what must be hashed (with its owner proof), what must be compared (with its representative) ----
-    uint32_t cls = CLASS_NONE;
-    if (L.act && L.valid) cls = cand == L.j ? node_list(L.len) : (L.len == BRANCH_LEN ? COPY_B532 : COPY_OTHER);
-    uint32_t my_rank = 0;
-    __syncthreads();
-    unsigned long long todo = __ballot(cls != CLASS_NONE);
-    while (todo) {
-        const uint32_t c0 = lane_u32(cls, (uint32_t)__builtin_ctzll(todo));
-        const unsigned long long m = __ballot(cls == c0);
-        if (lane == 0) s_cnt[wave][c0] = (uint32_t)__popcll(m);
-        if (cls == c0) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        todo &= ~m;
-    }
-    __syncthreads();
-    if (tid < N_CURSOR) {
-        uint32_t tot = 0;
-        for (uint32_t w = 0; w < WAVES; ++w) tot += s_cnt[w][tid];
-        s_base[tid] = tot ? atomicAdd(&a.hdr[cursor_word(tid)], tot) : 0u;
-    }
-    __syncthreads();
-    if (cls != CLASS_NONE) {
-        uint32_t at = s_base[cls] + my_rank;
-        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
-        if (cls < N_LIST) a.ent[(uint64_t)cls * NT + at] = make_uint2(L.j, L.p);
-        else a.cpy[(uint64_t)(cls - COPY_B532) * NT + at] = make_uint2(L.j, cand);
-    }
+// where entry `at` of list (class, stripe) lives
+PHANT_DEV uint64_t ent_index(const Args& a, uint32_t cls, uint32_t stripe, uint32_t at) {
+    return ((uint64_t)cls * STRIPES + stripe) * a.stripe_cap + at;
 }
 
-// ---------------------------------------------------------------- compare
 // all 64 lanes: are the `len` bytes at x and y equal?  16 bytes per lane per step.
 PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len, uint32_t lane) {
     uint32_t diff = 0;
@@ -333,80 +297,141 @@ constexpr int COMPARE_UNROLL = 4;  // steps in flight per wave: 2 x COMPARE_UNRO
 #define PHANT_NUM_VGPR(n) __attribute__((amdgpu_num_vgpr(n)))
 #endif
 
-// One wave per 64 entries of a compare list.  532-byte copies: a half wave covers bytes [0, 512) of one copy (16 per lane),
-// so a trip of COMPARE_UNROLL steps compares 2 x COMPARE_UNROLL copies with all their loads issued before any is used; the
-// last 28 bytes lane per copy afterwards (they share their cache lines with bytes just read).  A short last chunk repeats
-// its last entry (idempotent), so the body has no conditionals.  Workgroups of 256 lanes = one wave per SIMD: such a
-// workgroup finds room next to the hash waves where four waves per SIMD would have to wait for all of them at once.
-__global__ void __launch_bounds__(256) PHANT_NUM_VGPR(48) compare_kernel(const Args a) {
+// One lane per (proof, d < S), as propose_kernel.  The lane reads its group's slot back: the node found there is the
+// group's representative (every member reads the same slot after propose_kernel has finished, so the representative's
+// own lane finds itself).  A wave then byte-compares the copies among its lanes with their representatives: a half wave
+// covers bytes [0, 512) of one 532-byte copy (16 per lane, coalesced), so a trip of COMPARE_UNROLL steps compares
+// 2 x COMPARE_UNROLL copies with all their loads issued before any is used; a short last trip repeats its last copy
+// (idempotent), so the body has no conditionals; the last 28 bytes lane per copy afterwards (they share their cache lines
+// with bytes just read).  rep[j] for every node; the representatives, the nodes without a group and the copies that
+// differ (damaged nodes, or the representative is one) are LISTED for hashing, per rate-block class, compacted over the
+// workgroup, with one reservation per workgroup and class on the cursor of the workgroup's stripe.
+// Workgroups of 256 lanes = one wave per SIMD: such a workgroup finds room next to the hash waves where four waves per
+// SIMD would have to wait for all of them at once.
+__global__ void __launch_bounds__(256) PHANT_NUM_VGPR(48) dedup_kernel(const Args a) {
+    constexpr uint32_t WAVES = 4;
+    __shared__ uint32_t s_cnt[WAVES][N_LIST];
+    __shared__ uint32_t s_base[N_LIST];
     beside_the_hashing();
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t NT = a.total_nodes;
-    const uint32_t cnt_a = a.hdr[HDR_COPY_B532], cnt_b = a.hdr[HDR_COPY_OTHER];
-    const uint32_t chunks_a = (cnt_a + 63u) / 64u, chunks_b = (cnt_b + 63u) / 64u;
-    if (q < chunks_a) {
-        const uint32_t idx = q * 64u + lane;
-        const uint2 en = a.cpy[idx < cnt_a ? idx : cnt_a - 1u];
-        const uint32_t j = en.x;
-        const uint64_t b = a.v.node_off[j], cb = a.v.node_off[en.y];
-        const uint32_t coff = 16u * (lane & 31u);
-        const bool upper = lane >= 32u;
-        // everything that selects a node below is wave-uniform: say so, or the compiler predicates per lane
-        const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32), cb_lo = (uint32_t)cb, cb_hi = (uint32_t)(cb >> 32);
-        bool differs = false;
-#pragma unroll 1
-        for (uint32_t t = 0; t < 64u; t += 2u * COMPARE_UNROLL) {
-            uint4 x[COMPARE_UNROLL], y[COMPARE_UNROLL];
-#pragma unroll
-            for (int u = 0; u < COMPARE_UNROLL; ++u) {
-                const uint32_t i0 = t + 2u * u, i1 = i0 + 1u;
-                const uint64_t own0 = lane_u64(b_lo, b_hi, i0), own1 = lane_u64(b_lo, b_hi, i1);
-                const uint64_t oth0 = lane_u64(cb_lo, cb_hi, i0), oth1 = lane_u64(cb_lo, cb_hi, i1);
-                x[u] = load16u(a.v.nodes + (upper ? own1 : own0) + coff);
-                y[u] = load16u(a.v.nodes + (upper ? oth1 : oth0) + coff);
-            }
-#pragma unroll
-            for (int u = 0; u < COMPARE_UNROLL; ++u) {
-                const uint32_t i0 = t + 2u * u, i1 = i0 + 1u;
-                // acc | (x ^ y), dword by dword
-                uint32_t diff = x[u].x ^ y[u].x;
-                diff = __builtin_amdgcn_bitop3_b32(x[u].y, y[u].y, diff, 0xBE);
-                diff = __builtin_amdgcn_bitop3_b32(x[u].z, y[u].z, diff, 0xBE);
-                diff = __builtin_amdgcn_bitop3_b32(x[u].w, y[u].w, diff, 0xBE);
-                const unsigned long long m = __ballot(diff != 0);
-                if ((uint32_t)m != 0u && lane == i0) differs = true;
-                if ((uint32_t)(m >> 32) != 0u && lane == i1) differs = true;
+    if (tid < WAVES * N_LIST) (&s_cnt[0][0])[tid] = 0u;
+    const ShallowLane L = shallow_lane(a, blockIdx.x * 256u + tid);
+    // proof_first_node is not monotone: node ranges of OTHER proofs may then overlap, and what one proof's lanes find out
+    // about a node would be read by another.  Tell the walk not to trust anything.
+    if (L.broken) a.hdr[HDR_PFN_BROKEN] = 1u;
+
+    const uint32_t j = L.j;
+    uint32_t cand = j;
+    uint64_t b = 0, cb = 0;
+    if (L.group) {
+        uint32_t c = j;
+        if (L.d < a.direct) {
+            const uint32_t t = a.dtab[direct_index(L.kb, L.root, L.d, a.v.n_roots)];
+            if (t) c = t - 1u;
+        } else {
+            const uint64_t h = group_hash(L.kb, L.root, L.d);
+            uint32_t node;
+            if (entry_matches(a, a.table[slot_a(h, a.tmask)], L, node)) c = node;
+            else if (entry_matches(a, a.table[slot_b(h, a.tmask)], L, node)) c = node;
+        }
+        if (c != j && c < NT) {
+            // a representative is only usable if it is a well-formed node of the same length
+            const uint64_t c0 = a.v.node_off[c], c1 = a.v.node_off[c + 1];
+            if (c1 >= c0 && c1 <= a.v.nodes_len && c1 - c0 == L.len) {
+                cand = c;
+                cb = c0;
+                b = a.v.node_off[j];
             }
         }
-        {   // bytes [504, 532)
-            const uint8_t* const own = a.v.nodes + b + (BRANCH_LEN - 28u);
-            const uint8_t* const oth = a.v.nodes + cb + (BRANCH_LEN - 28u);
-            const uint4 p0 = load16u(own), p1 = load16u(own + 12), q0 = load16u(oth), q1 = load16u(oth + 12);
-            uint32_t diff = (p0.x ^ q0.x) | (p0.y ^ q0.y) | (p0.z ^ q0.z) | (p0.w ^ q0.w);
-            diff |= (p1.x ^ q1.x) | (p1.y ^ q1.y) | (p1.z ^ q1.z) | (p1.w ^ q1.w);
-            if (diff) differs = true;
-        }
-        if (differs) a.rep[j] = j;  // nobody hashed it: the walk that meets it does
-        return;
     }
-    q -= chunks_a;
-    if (q >= chunks_b) return;
-    // ---- other multi-block copies (sparse branches >= 136 bytes): generic compare, one at a time ----
-    const uint32_t idx = q * 64u + lane;
-    const uint2 en = a.cpy[(uint64_t)NT + (idx < cnt_b ? idx : cnt_b - 1u)];
-    const uint32_t j = en.x;
-    const uint64_t b = a.v.node_off[j], cb = a.v.node_off[en.y];
-    const uint32_t len = (uint32_t)(a.v.node_off[j + 1] - b);  // (elect_kernel checked both nodes: same, sane length)
+
+    // ---- the wave's 532-byte copies ----
+    const uint32_t coff = 16u * (lane & 31u);
+    const bool upper = lane >= 32u;
+    // everything that selects a node below is wave-uniform: say so, or the compiler predicates per lane
     const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32), cb_lo = (uint32_t)cb, cb_hi = (uint32_t)(cb >> 32);
     bool differs = false;
-    const uint32_t live = cnt_b - q * 64u < 64u ? cnt_b - q * 64u : 64u;
-    for (uint32_t i = 0; i < live; ++i) {
-        const uint32_t ll = lane_u32(len, i);
+    const bool is532 = cand != j && L.len == BRANCH_LEN;
+    unsigned long long todo = __ballot(is532);
+    while (todo) {
+        uint32_t i0[COMPARE_UNROLL], i1[COMPARE_UNROLL];
+        uint4 x[COMPARE_UNROLL], y[COMPARE_UNROLL];
+        uint32_t i = 0;
+#pragma unroll
+        for (int u = 0; u < COMPARE_UNROLL; ++u) {
+            if (todo) {
+                i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+            }
+            i0[u] = i;
+            if (todo) {
+                i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+            }
+            i1[u] = i;
+            const uint64_t own0 = lane_u64(b_lo, b_hi, i0[u]), own1 = lane_u64(b_lo, b_hi, i1[u]);
+            const uint64_t oth0 = lane_u64(cb_lo, cb_hi, i0[u]), oth1 = lane_u64(cb_lo, cb_hi, i1[u]);
+            x[u] = load16u(a.v.nodes + (upper ? own1 : own0) + coff);
+            y[u] = load16u(a.v.nodes + (upper ? oth1 : oth0) + coff);
+        }
+#pragma unroll
+        for (int u = 0; u < COMPARE_UNROLL; ++u) {
+            // acc | (x ^ y), dword by dword
+            uint32_t diff = x[u].x ^ y[u].x;
+            diff = __builtin_amdgcn_bitop3_b32(x[u].y, y[u].y, diff, 0xBE);
+            diff = __builtin_amdgcn_bitop3_b32(x[u].z, y[u].z, diff, 0xBE);
+            diff = __builtin_amdgcn_bitop3_b32(x[u].w, y[u].w, diff, 0xBE);
+            const unsigned long long m = __ballot(diff != 0);
+            if ((uint32_t)m != 0u && lane == i0[u]) differs = true;
+            if ((uint32_t)(m >> 32) != 0u && lane == i1[u]) differs = true;
+        }
+    }
+    if (is532 && !differs) {  // bytes [504, 532)
+        const uint8_t* const own = a.v.nodes + b + (BRANCH_LEN - 28u);
+        const uint8_t* const oth = a.v.nodes + cb + (BRANCH_LEN - 28u);
+        const uint4 p0 = load16u(own), p1 = load16u(own + 12), q0 = load16u(oth), q1 = load16u(oth + 12);
+        uint32_t diff = (p0.x ^ q0.x) | (p0.y ^ q0.y) | (p0.z ^ q0.z) | (p0.w ^ q0.w);
+        diff |= (p1.x ^ q1.x) | (p1.y ^ q1.y) | (p1.z ^ q1.z) | (p1.w ^ q1.w);
+        if (diff) differs = true;
+    }
+    // ---- other multi-block copies (sparse branches >= 136 bytes): generic compare, one at a time ----
+    todo = __ballot(cand != j && L.len != BRANCH_LEN);
+    while (todo) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t ll = lane_u32(L.len, i);
         const bool eq = wave_bytes_equal(a.v.nodes + lane_u64(b_lo, b_hi, i), a.v.nodes + lane_u64(cb_lo, cb_hi, i), ll, lane);
         if (lane == i && !eq) differs = true;
     }
-    if (differs) a.rep[j] = j;
+    if (differs) cand = j;
+    if (L.act) a.rep[j] = cand;
+
+    // ---- what must be hashed (with its owner proof) ----
+    const uint32_t cls = (L.act && L.valid && cand == j) ? node_list(L.len) : CLASS_NONE;
+    uint32_t my_rank = 0;
+    __syncthreads();
+    todo = __ballot(cls != CLASS_NONE);
+    while (todo) {
+        const uint32_t c0 = lane_u32(cls, (uint32_t)__builtin_ctzll(todo));
+        const unsigned long long m = __ballot(cls == c0);
+        if (lane == 0) s_cnt[wave][c0] = (uint32_t)__popcll(m);
+        if (cls == c0) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    __syncthreads();
+    const uint32_t stripe = blockIdx.x % STRIPES;
+    if (tid < N_LIST) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < WAVES; ++w) tot += s_cnt[w][tid];
+        s_base[tid] = tot ? atomicAdd(&a.hdr[cursor_word(tid, stripe)], tot) : 0u;
+    }
+    __syncthreads();
+    if (cls != CLASS_NONE) {
+        uint32_t at = s_base[cls] + my_rank;
+        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
+        a.ent[ent_index(a, cls, stripe, at)] = make_uint2(j, L.p);
+    }
 }
 
 // ---------------------------------------------------------------- canonical full branch, per rate block
@@ -581,30 +606,51 @@ PHANT_DEV void store_node_digest(const Args& a, uint32_t j, const Sponge& s) {
 }
 
 // ---------------------------------------------------------------- hash: the list role
-// Wave q hashes chunk q (64 nodes of one list, the lists with the most rate blocks first) and exits; the grid covers the
-// worst case and the dispatcher keeps every SIMD full.  A short last chunk repeats its last node (same results stored
-// twice) so that no lane is ever idle-masked.
-PHANT_DEV void list_role(const Args& a, uint32_t q, const uint32_t lane) {
-    const uint32_t N = a.total_nodes;
-    // queue order: 8+ blocks, 7, 6, 5, [532-byte list], 4 (others), 3, 2, 1
-    uint32_t cls = N_LIST, idx = 0;
-#pragma unroll
-    for (int o = 0; o < (int)N_LIST; ++o) {
-        const int c = o < 4 ? 7 - o : (o == 4 ? (int)LIST_B532 : 8 - o);
-        const uint32_t cnt = a.hdr[c];
-        const uint32_t chunks = (cnt + 63u) / 64u;
-        if (cls == N_LIST) {
-            if (q < chunks) {
-                cls = (uint32_t)c;
-                idx = q * 64u + lane;
-                idx = idx < cnt ? idx : cnt - 1u;
-            } else {
-                q -= chunks;
-            }
-        }
+// Wave q hashes chunk q (64 nodes of one list) and exits; the grid covers the worst case and the dispatcher keeps every
+// SIMD full.  A short last chunk repeats its last node (same results stored twice) so that no lane is ever idle-masked.
+// The chunk queue is the concatenation of the lists in this order: classes by falling rate-block count -- 8+ blocks, 7, 6,
+// 5, [532-byte list], 4 (others), 3, 2, 1 --, inside a class the stripes.
+constexpr uint32_t N_QUEUE = N_LIST * STRIPES;  // 72
+PHANT_DEV uint32_t queue_class(uint32_t li) {
+    const uint32_t o = li / STRIPES;
+    return o < 4u ? 7u - o : (o == 4u ? LIST_B532 : 8u - o);
+}
+PHANT_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t up = __shfl_up(v, o, 64);
+        if (lane >= o) v += up;
     }
-    if (cls == N_LIST) return;
-    const uint2 en = a.ent[(uint64_t)cls * N + idx];
+    return v;
+}
+
+PHANT_DEV void list_role(const Args& a, uint32_t q, const uint32_t lane) {
+    // which list chunk q is in: every lane reads the count of a list (two: there are 72), one prefix sum over the wave
+    // (72 dependent scalar loads per wave cost 12 us -- every wave of the grid, the real ones included)
+    static_assert(N_QUEUE > 64u && N_QUEUE <= 128u, "two lists per lane");
+    const uint32_t cnt_a = a.hdr[cursor_word(queue_class(lane), lane % STRIPES)];
+    const uint32_t cnt_b = lane + 64u < N_QUEUE ? a.hdr[cursor_word(queue_class(lane + 64u), (lane + 64u) % STRIPES)] : 0u;
+    const uint32_t ch_a = (cnt_a + 63u) / 64u, ch_b = (cnt_b + 63u) / 64u;
+    const uint32_t incl_a = wave_inclusive_scan(ch_a, lane);
+    uint32_t li, before, cnt;
+    const unsigned long long m_a = __ballot(q < incl_a);
+    if (m_a) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m_a);
+        li = l;
+        before = lane_u32(incl_a, l) - lane_u32(ch_a, l);
+        cnt = lane_u32(cnt_a, l);
+    } else {
+        const uint32_t incl_b = lane_u32(incl_a, 63u) + wave_inclusive_scan(ch_b, lane);
+        const unsigned long long m_b = __ballot(q < incl_b);
+        if (!m_b) return;
+        const uint32_t l = (uint32_t)__builtin_ctzll(m_b);
+        li = l + 64u;
+        before = lane_u32(incl_b, l) - lane_u32(ch_b, l);
+        cnt = lane_u32(cnt_b, l);
+    }
+    const uint32_t cls = queue_class(li), stripe = li % STRIPES;
+    uint32_t idx = (q - before) * 64u + lane;
+    idx = idx < cnt ? idx : cnt - 1u;
+    const uint2 en = a.ent[ent_index(a, cls, stripe, idx)];
     const uint32_t j = en.x;
     const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
     const uint64_t b = a.v.node_off[j];
@@ -657,6 +703,8 @@ PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, c
     const uint32_t p = (w % waves_per_level) * 64u + lane;
     const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
     const uint32_t nn = 2u * a.v.key_len;
+    uint32_t hashed[N_CLASS] = {0, 0, 0, 0, 0, 0, 0, 0};                    // (wave-uniform)
+    const uint32_t stat_buf = a.hdr[HDR_PARITY] & 1u;                      // (requested now, used when the wave is through)
     // (a wave normally makes one trip: everything about the proof is re-read per trip rather than kept in
     // registers across the sponge)
     for (uint32_t d = a.shallow + level;; d += levels) {
@@ -682,6 +730,7 @@ PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, c
             b = a.v.node_off[j];
             active = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull;
             len = active ? (uint32_t)(e - b) : 0u;
+            if (!active) a.nstat[j] = 0u;  // (nobody clears the deep nodes' states: "not hashed" is written like any other)
         }
         const bool roomy = a.v.nodes_len >= BRANCH_LEN;
         const uint8_t* const ptr = a.v.nodes + (active ? b : 0ull);
@@ -697,16 +746,10 @@ PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, c
             s_ref[0][t] = ref.lo.x; s_ref[1][t] = ref.lo.y; s_ref[2][t] = ref.lo.z; s_ref[3][t] = ref.lo.w;
             s_ref[4][t] = ref.hi.x; s_ref[5][t] = ref.hi.y; s_ref[6][t] = ref.hi.z; s_ref[7][t] = ref.hi.w;
         }
-        {   // reporting only: nodes hashed per rate-block class (striped counters, one add per wave and class)
+        {   // reporting only: nodes hashed per rate-block class, counted in wave-uniform registers until the wave is through
             const uint32_t cls = len / RATE < N_CLASS ? len / RATE : N_CLASS - 1u;
-            const unsigned long long any = __ballot(active);
-            const uint32_t c0 = any ? lane_u32(cls, (uint32_t)__builtin_ctzll(any)) : 0u;
-            const unsigned long long same = __ballot(active && cls == c0);
-            if (same == any) {
-                if (lane == 0 && any) atomicAdd(&a.hdr[HDR_STAT + N_CLASS * (w % HDR_STAT_STRIPES) + c0], (uint32_t)__popcll(any));
-            } else if (active) {
-                atomicAdd(&a.hdr[HDR_STAT + N_CLASS * (w % HDR_STAT_STRIPES) + cls], 1u);
-            }
+#pragma unroll
+            for (uint32_t c = 0; c < N_CLASS; ++c) hashed[c] += (uint32_t)__popcll(__ballot(active && cls == c));
         }
         // what must survive the sponge: one word of flags (and the lane's proof index)
         enum : uint32_t { F_ACTIVE = 1u, F_REF = 2u, F_CANON = 4u };
@@ -741,26 +784,32 @@ PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, c
             store_node_digest(a, j, s);
         }
     }
+    // The statistics, as the wave's last instructions: an atomic issued in front of the rate-block loads is waited for with
+    // them (gfx950 counts it in vmcnt), and with thousands of waves on a few counters that wait is microseconds per wave
+    // (measured: the deep tier alone 127 -> 138 us).
+    if (lane < N_CLASS) {
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < N_CLASS; ++c) mine = lane == c ? hashed[c] : mine;
+        if (mine) atomicAdd(&a.hdr[HDR_STAT + HDR_STAT_WORDS * stat_buf + N_CLASS * (w % HDR_STAT_STRIPES) + lane], mine);
+    }
 }
 
-// Every wave that hashes.  Workgroups [0, list_wgs): the list role (upper bound; waves beyond the lists leave at once --
-// at the head of the grid that costs a microsecond of dispatch); the rest: the deep role.
+// Two kernels (as one with two roles the register allocation is the union: 122 VGPRs = an allocation of 128, and next to
+// three such waves a SIMD has room for two of dedup_kernel's instead of three).
+// SOLO: the S = 0 form.
 template <bool SOLO>
-__global__ void __launch_bounds__(256, 4) hash_kernel(const Args a, const uint32_t list_wgs, const uint32_t waves_per_level,
-                                                      const uint32_t levels) {
+__global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const uint32_t waves_per_level, const uint32_t levels) {
     // the 32 reference bytes wait in LDS while the sponge has the registers ([dword][lane]: conflict-free)
     __shared__ uint32_t s_ref[8][256];
-    const uint32_t lane = threadIdx.x & 63u;
-    if constexpr (!SOLO) {
-        if (blockIdx.x < list_wgs) {
-            // fewer waves than the chip has SIMDs, four permutations in a row each, and the walk waits for them: go first
-            __builtin_amdgcn_s_setprio(2);
-            list_role(a, (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), lane);
-            return;
-        }
-    }
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((blockIdx.x - list_wgs) * 4u + (threadIdx.x >> 6));
-    deep_role<SOLO>(a, w, lane, waves_per_level, levels, s_ref);
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    deep_role<SOLO>(a, w, threadIdx.x & 63u, waves_per_level, levels, s_ref);
+}
+__global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
+    // On the critical path (propose -> dedup -> this -> walk) with fewer waves than the chip has SIMDs, four permutations in
+    // a row each, while the deep tier's waves, which are many and in nobody's way, compete for the same issue slots: go first.
+    __builtin_amdgcn_s_setprio(2);
+    list_role(a, (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), threadIdx.x & 63u);
 }
 
 // node-set witnesses: every node listed (classify_kernel), no owners, no references
@@ -927,7 +976,19 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                         me = rj[u];
                         if (me == used) c = code_of(own, w.pos < nn);
                         else if (used == first || rpar[u] == rprev) c = code_of(nsr[u], w.pos < nn);
-                        else c = LINK_GENERIC;  // another comparison: the generic step compares the digest with ITS reference
+                        else if (!(nsr[u] & NS_HASHED)) c = LINK_GENERIC;
+                        else {
+                            // Not the same comparison (the representative sits in a proof whose parent is other bytes, e.g. a
+                            // damaged one): its digest against the reference in THIS proof's parent -- node used - 1, which
+                            // this walk has just stepped over as a canonical full branch.
+                            const uint8_t* rb = a.v.nodes + a.v.node_off[used - 1u] + (4u + 33u * key_nibble(key, w.pos - 1u));
+                            const uint4 w0 = load16u(rb), w1 = load16u(rb + 16);
+                            const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * me);
+                            const uint4 d0 = dg[0], d1 = dg[1];
+                            const uint32_t diff = (d0.x ^ w0.x) | (d0.y ^ w0.y) | (d0.z ^ w0.z) | (d0.w ^ w0.w) |
+                                                  (d1.x ^ w1.x) | (d1.y ^ w1.y) | (d1.z ^ w1.z) | (d1.w ^ w1.w);
+                            c = diff ? LINK_BAD_HASH : ((w.pos < nn && (nsr[u] & NS_CANON)) ? LINK_FAST : LINK_HASH_OK);
+                        }
                     }
                     if (c == LINK_FAST) {
                         ++used;
@@ -986,28 +1047,27 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                         if constexpr (!DIRECT) {
                             if (j - first < sx) rj = a.rep[j];
                         }
-                        uint32_t diff;
-                        if (rj < a.total_nodes && (a.nstat[rj] & NS_HASHED)) {
-                            const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
-                            const uint4 d0 = dg[0], d1 = dg[1];
-                            diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
-                                   (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
-                        } else {
-                            // a copy that differs from its group's representative (a damaged node), or one whose group lost its
-                            // table slots: nobody hashed it -- this lane does
-                            atomicAdd(&a.hdr[HDR_INLINE], 1u);
-                            Sponge s;
-                            keccak256_global(s, cur, cur_len, nodes_end);
-                            diff = 0;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                diff |= s.lo[k] ^ want[2 * k];
-                                diff |= s.hi[k] ^ want[2 * k + 1];
-                            }
+                        if (!(rj < a.total_nodes && (a.nstat[rj] & NS_HASHED))) {
+                            status = STATUS_NEEDS_SLOW;  // (nobody hashed it: cannot happen while the lists are complete)
+                            break;
                         }
+                        const uint4* dg = reinterpret_cast<const uint4*>(a.digest + 8ull * rj);
+                        const uint4 d0 = dg[0], d1 = dg[1];
+                        const uint32_t diff = (d0.x ^ want[0]) | (d0.y ^ want[1]) | (d0.z ^ want[2]) | (d0.w ^ want[3]) |
+                                              (d1.x ^ want[4]) | (d1.y ^ want[5]) | (d1.z ^ want[6]) | (d1.w ^ want[7]);
                         if (diff) {
                             status = PHANT_PROOF_BAD_HASH;
                             break;
+                        }
+                        // a canonical full branch (checked by the wave that hashed it) and the key has a nibble for it: the
+                        // next reference is slot nib of the node, no decoding (byte-wise from HBM that is ~100 dependent loads)
+                        if ((a.nstat[rj] & NS_CANON) && w.pos < nn) {
+                            const uint8_t* rb = cur + (4u + 33u * key_nibble(key, w.pos));
+                            const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
+                            want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
+                            want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
+                            w.pos += 1;
+                            continue;
                         }
                     }
                     // a node reached through a hash: stage it (embedded children are decoded inside their
@@ -1069,6 +1129,7 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
         if (a.v.value_off) a.v.value_off[i] = voff;
         if (a.v.value_len) a.v.value_len[i] = vlen;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.hdr[HDR_PARITY] ^= 1u;  // (the next launch's deep role counts into the other buffer)
     // the verdict, while every status passes through this kernel anyway (fail_count was zeroed by the launch's first
     // kernel).  A proof whose root index is out of range counts against root 0: a zero verdict means every proof passed.
     if (a.v.fail_count) {
@@ -1328,28 +1389,34 @@ static uint32_t table_entries(uint32_t n, uint32_t n_roots, uint32_t direct, uin
 }
 
 struct Layout {
-    size_t nstat, dtab, table, rep, ent, cpy, digest, end;
+    size_t nstat, dtab, table, rep, ent, digest, end;
+    uint32_t stripe_cap;
 };
-static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries) {
+// `lanes`: the shallow tier's lanes (proofs x shallow levels; 0 for the forms without a shallow tier)
+static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries, uint64_t lanes) {
     const size_t tn = total_nodes;
     Layout l;
+    const uint64_t wgs = (lanes + 255u) / 256u;
+    l.stripe_cap = (uint32_t)((wgs + STRIPES - 1u) / STRIPES * 256u);
     size_t p = HEADER_BYTES;
-    l.nstat = p;  p += rnd256(tn + 16);   // header .. nstat: zeroed per call, contiguous
+    l.nstat = p;  p += rnd256(tn + 16);
     l.dtab = p;   p += rnd256((size_t)direct_entries * 4);
     l.table = p;  p += rnd256((size_t)te * 8);
     l.rep = p;    p += rnd256(tn * 4 + 64);
-    l.ent = p;    p += rnd256(tn * 8 * N_LIST);
-    l.cpy = p;    p += rnd256(tn * 8 * 2);
+    // the two-tier form's striped lists, or the node-set form's N_LIST x total_nodes
+    const size_t striped = (size_t)N_LIST * STRIPES * l.stripe_cap * 8u;
+    l.ent = p;    p += rnd256(striped > tn * 8 * N_LIST ? striped : tn * 8 * N_LIST);
     l.digest = p; p += rnd256(tn * 32);
     l.end = p + 1024;
     return l;
 }
 
 size_t workspace_bytes(uint32_t total_nodes) {
-    // sized for the largest tables any (n, n_roots) can ask for with this many nodes
+    // sized for the largest tables and lists any (n, n_roots) can ask for with this many nodes (the shallow tier has at
+    // most one lane per node: the launcher cuts a forced split back to that)
     uint32_t t = 1024;
     while (t < 4ull * total_nodes && t < (1u << 26)) t <<= 1;
-    return layout(total_nodes, t, DIRECT_MAX_ENTRIES).end;
+    return layout(total_nodes, t, DIRECT_MAX_ENTRIES, (uint64_t)total_nodes + 256u * STRIPES).end;
 }
 
 static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
@@ -1360,15 +1427,15 @@ static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
     a.tmask = te - 1u;
     a.rep = reinterpret_cast<uint32_t*>(ws + l.rep);
     a.ent = reinterpret_cast<uint2*>(ws + l.ent);
-    a.cpy = reinterpret_cast<uint2*>(ws + l.cpy);
+    a.stripe_cap = l.stripe_cap;
     a.digest = reinterpret_cast<uint32_t*>(ws + l.digest);
 }
 
 }  // namespace v3
 
-size_t verify_workspace_bytes_v3(uint32_t total_nodes) { return v3::workspace_bytes(total_nodes); }
+size_t verify_workspace_bytes(uint32_t total_nodes) { return v3::workspace_bytes(total_nodes); }
 
-hipError_t launch_mpt_verify_v3(const VerifyArgs& v_in, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
+hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
                                 hipStream_t st, const FlatSide* side, const VerifyTune& tune) {
     using namespace v3;
     VerifyArgs v = v_in;
@@ -1378,15 +1445,16 @@ hipError_t launch_mpt_verify_v3(const VerifyArgs& v_in, uint32_t total_nodes, ui
     a.v = v;
     a.total_nodes = total_nodes;
     a.shallow = shallow_levels(v.n, v.n_roots, v.nodes_len, dedup_levels);
-    a.ds_log = 0;
-    while ((1u << a.ds_log) < a.shallow) ++a.ds_log;
+    // the shallow tier has a lane per (proof, level) and lists sized by them: a forced split deeper than the proofs are
+    // long on average is cut back to what the workspace (sized from total_nodes) holds
+    while (a.shallow && (uint64_t)v.n * a.shallow > (uint64_t)total_nodes + 256u * STRIPES) --a.shallow;
     uint64_t direct_entries = 0;
     a.direct = direct_levels(v.n_roots, a.shallow, direct_entries);
     const uint32_t te = table_entries(v.n, v.n_roots, a.direct, a.shallow, total_nodes);
-    const Layout l = layout(total_nodes, te, direct_entries);
+    const uint64_t lanes = (uint64_t)v.n * a.shallow;
+    const Layout l = layout(total_nodes, te, direct_entries, lanes);
     bind(a, ws, l, te);
     hipError_t e = hipSuccess;
-    const size_t zero_n16 = l.dtab / 16;  // header + node states
     const uint32_t pg = (v.n + 255u) / 256u;
     const uint32_t wpl = (v.n + 63u) / 64u;  // waves per level of the deep role
     // One pass of the deep waves covers `levels` depths below the shallow tier, a wave whose proofs go deeper loops.  Sized
@@ -1399,66 +1467,63 @@ hipError_t launch_mpt_verify_v3(const VerifyArgs& v_in, uint32_t total_nodes, ui
     if (a.shallow == 0u || total_nodes == 0u) {
         // S = 0: clear, hash every node in place, walk on the node states.  No lists, tables or helper stream.
         a.shallow = 0;
+        const size_t zero_n16 = l.dtab / 16;  // header + node states
         hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)((zero_n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(ws),
                            zero_n16, v.fail_count, v.n_roots);
-        if (total_nodes) hipLaunchKernelGGL(hash_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, 0u, wpl, deep_levels);
+        if (total_nodes) hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, wpl, deep_levels);
         hipLaunchKernelGGL(walk_kernel<true>, dim3(pg), dim3(256), 0, st, a);
         return hipGetLastError();
     }
     // ---- two tiers ----
-    const uint64_t lanes = (uint64_t)v.n << a.ds_log;
     const uint32_t sg = (uint32_t)((lanes + 255u) / 256u);
-    hipLaunchKernelGGL(propose_kernel, dim3(sg), dim3(256), 0, st, a, reinterpret_cast<uint4*>(ws), zero_n16);
-    hipLaunchKernelGGL(elect_kernel, dim3(sg), dim3(256), 0, st, a);
-    // everything that is hashed: on the helper stream, next to the comparison
     const bool two = side && side->stream && side->fork && side->join && !tune.serial;
-    hipStream_t hs = st;
+    hipStream_t hs = two ? side->stream : st;
+    // grid bound of the list role: every shallow node listed (64-node chunks, 4 waves per workgroup) + a short chunk per list
+    const uint64_t listed = lanes < total_nodes ? lanes : total_nodes;
+    const uint32_t list_wgs = (uint32_t)((listed + 255u) / 256u) + (N_QUEUE + 3u) / 4u;
+    // An otherwise unused dynamic LDS allocation caps the hash workgroups per CU while the shallow tier's memory-bound
+    // kernels run next to them (VerifyTune::hash_lds): a fourth hash wave per SIMD would take the registers they need
+    const uint32_t hash_lds = two ? tune.hash_lds : 0u;
+    // the deep role: no inputs but the witness, so it starts at once -- on the helper stream, next to the shallow tier
     if (two) {
-        if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
+        if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;  // (behind the previous launch's walk)
         if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
-        hs = side->stream;
     }
-    // grid bound of the list role: every shallow node listed (64-node chunks, 4 waves per workgroup) + one short chunk per list
-    const uint64_t listed = (uint64_t)v.n * a.shallow < total_nodes ? (uint64_t)v.n * a.shallow : total_nodes;
-    const uint32_t list_wgs = (uint32_t)((listed + 255u) / 256u) + (N_LIST + 3u) / 4u;
-    // An otherwise unused dynamic LDS allocation caps the hash workgroups per CU while the comparison runs next to them
-    // (VerifyTune::hash_lds): room for the memory-bound waves
-    hipLaunchKernelGGL(hash_kernel<false>, dim3(list_wgs + deep_wgs), dim3(256), two ? tune.hash_lds : 0u, hs, a, list_wgs, wpl, deep_levels);
+    // (propose_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep
+    // role's waves fill every slot they are given the moment they start)
+    hipLaunchKernelGGL(propose_kernel, dim3(sg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
     if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
-    {
-        // grid bound of the comparison: every shallow node a copy
-        const uint32_t cg = (uint32_t)((listed + 255u) / 256u) + 2u;
-        hipLaunchKernelGGL(compare_kernel, dim3(cg), dim3(256), 0, st, a);
-    }
+    hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(hash_list_kernel, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, st, a);
     if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
-static uint32_t nodeset_table_entries_v3(uint32_t total_nodes) {
+static uint32_t nodeset_table_entries(uint32_t total_nodes) {
     uint32_t t = 1024;
     while (t < 2u * total_nodes && t < (1u << 31)) t <<= 1;
     return t;
 }
 
-size_t verify_nodeset_workspace_bytes_v3(uint32_t total_nodes) {
-    return v3::workspace_bytes(total_nodes) + v3::rnd256((size_t)nodeset_table_entries_v3(total_nodes) * 4);
+size_t verify_nodeset_workspace_bytes(uint32_t total_nodes) {
+    return v3::workspace_bytes(total_nodes) + v3::rnd256((size_t)nodeset_table_entries(total_nodes) * 4);
 }
 
-hipError_t launch_mpt_verify_nodeset_v3(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, hipStream_t st) {
+hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, hipStream_t st) {
     using namespace v3;
     if (v.n == 0) return hipSuccess;
     Args a;
     a.v = v;
     a.total_nodes = total_nodes;
     a.shallow = 0;
-    a.ds_log = 0;
     a.direct = 0;
     const uint32_t te = 1024;
-    const Layout l = layout(total_nodes, te, 0);
+    const Layout l = layout(total_nodes, te, 0, 0);
     bind(a, ws, l, te);
     uint32_t* tab = reinterpret_cast<uint32_t*>(ws + workspace_bytes(total_nodes));
-    const uint32_t tab_entries = nodeset_table_entries_v3(total_nodes);
+    const uint32_t tab_entries = nodeset_table_entries(total_nodes);
     hipError_t e = hipMemsetAsync(ws, 0, l.dtab, st);  // header + node states
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tab, 0xff, (size_t)tab_entries * 4, st);
@@ -1474,17 +1539,23 @@ hipError_t launch_mpt_verify_nodeset_v3(const VerifyArgs& v, uint32_t total_node
 }
 
 // nodes hashed per rate-block class by the last launch on this workspace (host copy of the header)
-void verify_stats_from_header_v3(const uint32_t* hdr, uint32_t hashed[8]) {
+void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]) {
     using namespace v3;
-    for (uint32_t c = 0; c < N_CLASS; ++c) {
-        hashed[c] = hdr[c];
-        for (uint32_t s = 0; s < HDR_STAT_STRIPES; ++s) hashed[c] += hdr[HDR_STAT + N_CLASS * s + c];
+    uint32_t lists[N_LIST];
+    for (uint32_t c = 0; c < N_LIST; ++c) {
+        lists[c] = hdr[c];  // (the node-set form's single cursors)
+        for (uint32_t s = 0; s < STRIPES; ++s) lists[c] += hdr[HDR_CUR + 32u * s + c];
     }
-    hashed[BRANCH_LEN / RATE] += hdr[LIST_B532];
+    const uint32_t buf = (hdr[HDR_PARITY] & 1u) ^ 1u;  // (the walk has flipped the word)
+    for (uint32_t c = 0; c < N_CLASS; ++c) {
+        hashed[c] = lists[c];
+        for (uint32_t s = 0; s < HDR_STAT_STRIPES; ++s) hashed[c] += hdr[HDR_STAT + HDR_STAT_WORDS * buf + N_CLASS * s + c];
+    }
+    hashed[BRANCH_LEN / RATE] += lists[LIST_B532];
 }
-void verify_paths_from_header_v3(const uint32_t* hdr, uint32_t out[2]) {
+void verify_paths_from_header(const uint32_t* hdr, uint32_t out[2]) {
     out[0] = hdr[v3::HDR_SLOW];
-    out[1] = hdr[v3::HDR_OPENED] + hdr[v3::HDR_INLINE];
+    out[1] = hdr[v3::HDR_OPENED];
 }
 
 }  // namespace phant

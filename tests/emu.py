@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "phant_amd", "csrc")
-SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v2.hip", "mpt_verify_v3.hip", "trie_build.hip", "state_root.hip", "radix_sort.hip",
+SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v3.hip", "trie_build.hip", "state_root.hip", "radix_sort.hip",
            "capi.hip", "comm.hip", "witness_json.cpp", "host_rlp.cpp"]
 OUT_DIR = os.path.join(ROOT, "tests", "native", "_build")
 

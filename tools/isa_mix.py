@@ -2,7 +2,7 @@
 """Static instruction mix of one kernel and of each of its loops, from the gfx950 assembly hipcc emits
 (compile-only, works without a GPU):
 
-    python tools/isa_mix.py phant_amd/csrc/mpt_verify_v2.hip hash_deep_kernel
+    python tools/isa_mix.py phant_amd/csrc/mpt_verify_v3.hip hash_deep_kernel
 
 Backs the "180 VALU per Keccak round, the instruction minimum" figure of DESIGN.md section 7.1 with something
 checkable: the round loop's VALU count by opcode, its scalar overhead, where the loads and waits sit."""

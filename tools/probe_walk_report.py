@@ -3,8 +3,7 @@ import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "phant::" in r["Kernel_Name"] and "keccak256_fixed" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first = ("propose_kernel", "zero_kernel") if any("propose_kernel" in r["Kernel_Name"] for r in rows) else \
-    ("hash_deep", "plan_kernel") if any("hash_deep" in r["Kernel_Name"] for r in rows) else ("plan_kernel",)
+first = ("propose_kernel", "zero_kernel")
 t0 = None
 cur = []
 for r in rows:
@@ -13,7 +12,7 @@ for r in rows:
     if t0 is None or (any(x in name for x in first) and s - t0 > 100_000):
         if cur:
             print("  ".join(cur))
-        cur = []
+        cur = [f"period={(s - t0) / 1e3:.0f}" if t0 is not None else "period=-"]
         t0 = s
     cur.append(f"{name[:9]}@{(s - t0) / 1e3:.0f}+{(e - s) / 1e3:.0f}")
 print("  ".join(cur))

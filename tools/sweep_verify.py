@@ -31,22 +31,36 @@ COMBOS = [
 KNOBS = ("PHANT_HASH_LDS_KB", "PHANT_VERIFY_SERIAL")
 
 
+def grid(spec):
+    """--grid "PHANT_VERIFY_ORDER=0,1;PHANT_COMPARE_WGS=256,768;PHANT_HASH_LDS_KB=0,40": the cross product, mode flat"""
+    import itertools
+    axes = []
+    for part in spec.split(";"):
+        k, vs = part.split("=")
+        axes.append([(k, v) for v in vs.split(",")])
+    return [("flat", None, dict(c)) for c in itertools.product(*axes)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--proofs", type=int, default=100_000)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--grid", default=None, help="cross product of environment knobs instead of the built-in list")
+    ap.add_argument("--corrupt", type=float, default=None, help="fraction of damaged / exclusion proofs in the witness")
     args = ap.parse_args()
+    combos = grid(args.grid) if args.grid else COMBOS
     import torch
     import phant_amd
     from phant_amd import mpt as M
 
     dev = torch.device("cuda", 0)
-    w = phant_amd.witness.account_witness(args.proofs, depth=8, seed=2, device=dev)
+    kw = {} if args.corrupt is None else {"corrupt_frac": args.corrupt}
+    w = phant_amd.witness.account_witness(args.proofs, depth=8, seed=2, device=dev, **kw)
     b = w.batch
     status = torch.empty(b.n, dtype=torch.uint8, device=dev)
     lines = []
-    for mode, levels, env in COMBOS:
+    for mode, levels, env in combos:
         for k in KNOBS:
             os.environ.pop(k, None)
         os.environ.update(env)
