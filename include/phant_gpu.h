@@ -268,7 +268,7 @@ PHANT_API int32_t phant_comm_create(const int32_t *devices, uint32_t n_devices, 
 PHANT_API void phant_comm_destroy(phant_comm *comm);
 PHANT_API uint32_t phant_comm_size(const phant_comm *comm);
 PHANT_API phant_ctx *phant_comm_ctx(phant_comm *comm, uint32_t rank); /* rank's ctx: for device-form calls on its device */
-PHANT_API const char *phant_comm_last_error(const phant_comm *comm);
+PHANT_API const char *phant_comm_last_error(const phant_comm *comm); /* NULL: why the last phant_comm_create on this thread failed */
 PHANT_API uint32_t phant_comm_owner(const phant_comm *comm, const uint8_t *key, uint32_t key_len);
 /* Host form of phant_mpt_verify_batch over all devices of the comm (same arguments and outputs, results in the
  * caller's proof order, value_off into the caller's node blob) + fail_count[r] (n_roots, may be NULL) = proofs against

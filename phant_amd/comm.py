@@ -28,7 +28,8 @@ class Comm:
             n_devices = len(devices)
         rc = self._lib.phant_comm_create(arr, n_devices, flags, C.byref(h))
         if rc != L.OK:
-            raise L.PhantError(rc, "phant_comm_create failed (needs gfx950 devices; RCCL for more than one)")
+            why = self._lib.phant_comm_last_error(None)
+            raise L.PhantError(rc, (why.decode() if why else "") or "phant_comm_create failed (needs gfx950 devices; RCCL for more than one)")
         self._h = h
 
     @property

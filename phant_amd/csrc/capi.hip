@@ -157,7 +157,9 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     // diagnostics / A/B, read once per ctx (tools/sweep_verify.py): the deep tier's occupancy cap, serial tiers
     if (const char* t = std::getenv("PHANT_HASH_LDS_KB")) {
         const long kb = std::strtol(t, nullptr, 10);
-        c->tune.hash_lds = (uint32_t)(kb < 0 ? 0 : kb > 63 ? 63 : kb) * 1024u;  // (< 64 KiB needs no opt-in)
+        // (on top of the hash kernels' 8 KiB of static LDS, and the list kernel is launched with 8 KiB more: the sum must stay
+        // within the 64 KiB a launch gets without opting in)
+        c->tune.hash_lds = (uint32_t)(kb < 0 ? 0 : kb > 47 ? 47 : kb) * 1024u;
     }
     if (const char* t = std::getenv("PHANT_VERIFY_SERIAL")) c->tune.serial = t[0] == '1';
     DeviceGuard g(dev);

@@ -25,8 +25,12 @@
 
 #include "../../include/phant_gpu.h"
 
-#ifndef PHANT_HOST_EMU
-#include <dlfcn.h>
+// RCCL's names and entry points (resolved at run time) and one host thread per device: comm_host.h.  The CPU test suite
+// compiles this file for the host against a stand-in of that header (an in-process sum, devices one after the other).
+#ifdef PHANT_HOST_EMU
+#include <hipemu/comm_host.h>
+#else
+#include "comm_host.h"
 #endif
 
 struct phant_ctx;
@@ -42,93 +46,9 @@ int ctx_device(const phant_ctx* c);
 
 namespace {
 
-// ---- the five RCCL entry points this file uses, resolved at run time ----
-typedef void* rccl_comm_t;
-struct Rccl {
-    int (*comm_init_all)(rccl_comm_t*, int, const int*) = nullptr;
-    int (*comm_destroy)(rccl_comm_t) = nullptr;
-    int (*all_reduce)(const void*, void*, size_t, int /*dtype*/, int /*op*/, rccl_comm_t, hipStream_t) = nullptr;
-    int (*group_start)() = nullptr;
-    int (*group_end)() = nullptr;
-    const char* (*error_string)(int) = nullptr;
-    bool ok() const { return comm_init_all && comm_destroy && all_reduce && group_start && group_end; }
-};
-constexpr int RCCL_UINT32 = 3, RCCL_SUM = 0;  // ncclUint32, ncclSum (rccl.h)
-
-#ifndef PHANT_HOST_EMU
-bool load_rccl(Rccl& r, std::string& err) {
-    void* h = nullptr;
-    // a copy the process already carries (PyTorch ships its own) wins: two RCCLs in one process is asking for trouble
-    void* probe = dlsym(RTLD_DEFAULT, "ncclCommInitAll");
-    if (!probe) {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (h) break;
-        }
-        if (!h) {
-            err = "RCCL not found (librccl.so.1)";
-            return false;
-        }
-    }
-    auto sym = [&](const char* n) -> void* { return h ? dlsym(h, n) : dlsym(RTLD_DEFAULT, n); };
-    r.comm_init_all = reinterpret_cast<decltype(r.comm_init_all)>(sym("ncclCommInitAll"));
-    r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(sym("ncclCommDestroy"));
-    r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(sym("ncclAllReduce"));
-    r.group_start = reinterpret_cast<decltype(r.group_start)>(sym("ncclGroupStart"));
-    r.group_end = reinterpret_cast<decltype(r.group_end)>(sym("ncclGroupEnd"));
-    r.error_string = reinterpret_cast<decltype(r.error_string)>(sym("ncclGetErrorString"));
-    if (!r.ok()) {
-        err = "RCCL lacks an entry point";
-        return false;
-    }
-    return true;
-}
-#else
-// Host-emulation test build (tests/emu.py): "devices" are the host, so the collective is a loop.  Same call pattern as
-// the real thing -- the all-reduce of every rank is noted between group_start and group_end and carried out at the end.
-struct EmuCall {
-    const uint32_t* send;
-    uint32_t* recv;
-    size_t count;
-};
-std::vector<EmuCall> g_emu_calls;
-int emu_init_all(rccl_comm_t* c, int n, const int*) {
-    for (int i = 0; i < n; ++i) c[i] = reinterpret_cast<rccl_comm_t>((uintptr_t)(i + 1));
-    return 0;
-}
-int emu_destroy(rccl_comm_t) { return 0; }
-int emu_all_reduce(const void* s, void* r, size_t count, int dtype, int op, rccl_comm_t, hipStream_t) {
-    if (dtype != RCCL_UINT32 || op != RCCL_SUM) return 1;
-    g_emu_calls.push_back({static_cast<const uint32_t*>(s), static_cast<uint32_t*>(r), count});
-    return 0;
-}
-int emu_group_start() {
-    g_emu_calls.clear();
-    return 0;
-}
-int emu_group_end() {
-    if (g_emu_calls.empty()) return 0;
-    const size_t count = g_emu_calls[0].count;
-    std::vector<uint32_t> sum(count, 0);
-    for (const EmuCall& c : g_emu_calls) {
-        if (c.count != count) return 1;
-        for (size_t i = 0; i < count; ++i) sum[i] += c.send[i];
-    }
-    for (const EmuCall& c : g_emu_calls) std::memcpy(c.recv, sum.data(), count * 4);
-    g_emu_calls.clear();
-    return 0;
-}
-const char* emu_error_string(int) { return "emulated RCCL error"; }
-bool load_rccl(Rccl& r, std::string&) {
-    r.comm_init_all = emu_init_all;
-    r.comm_destroy = emu_destroy;
-    r.all_reduce = emu_all_reduce;
-    r.group_start = emu_group_start;
-    r.group_end = emu_group_end;
-    r.error_string = emu_error_string;
-    return true;
-}
-#endif
+using phant::Rccl;
+using phant::for_each_device;
+using phant::load_rccl;
 
 // one device's shard of a witness, gathered on the host (proof order kept)
 struct Shard {
@@ -145,7 +65,7 @@ struct Shard {
 struct phant_comm {
     std::vector<phant_ctx*> ctx;
     std::vector<int> devices;
-    std::vector<rccl_comm_t> rccl;
+    std::vector<ncclComm_t> rccl;
     Rccl api;
     bool have_rccl = false;
     std::string err;
@@ -163,10 +83,10 @@ int32_t cfail(phant_comm* c, int32_t code, const std::string& what) {
 int32_t all_reduce_u32(phant_comm* c, const std::vector<uint32_t*>& bufs, size_t count) {
     const size_t n = c->ctx.size();
     if (n == 1 || count == 0) return PHANT_OK;
-    int rc = c->api.group_start();
+    ncclResult_t rc = c->api.group_start();
     for (size_t r = 0; r < n && rc == 0; ++r)
-        rc = c->api.all_reduce(bufs[r], bufs[r], count, RCCL_UINT32, RCCL_SUM, c->rccl[r], phant::ctx_stream(c->ctx[r]));
-    const int rc2 = c->api.group_end();
+        rc = c->api.all_reduce(bufs[r], bufs[r], count, ncclUint32, ncclSum, c->rccl[r], phant::ctx_stream(c->ctx[r]));
+    const ncclResult_t rc2 = c->api.group_end();
     if (rc == 0) rc = rc2;
     if (rc != 0)
         return cfail(c, PHANT_E_DEVICE, std::string("RCCL all-reduce: ") + (c->api.error_string ? c->api.error_string(rc) : "error"));
@@ -251,16 +171,7 @@ int32_t sharded_root(phant_comm* c, const std::vector<KeyList>& lists, uint8_t o
         }
         if (p.rc != PHANT_OK) p.err = phant_last_error(c->ctx[d]);
     };
-#ifndef PHANT_HOST_EMU
-    {
-        std::vector<std::thread> th;
-        for (uint32_t d = 1; d < W; ++d) th.emplace_back(work, d);
-        work(0);
-        for (std::thread& t : th) t.join();
-    }
-#else  // (the host emulation of the HIP runtime is single-threaded)
-    for (uint32_t d = 0; d < W; ++d) work(d);
-#endif
+    for_each_device(W, work);
     for (uint32_t d = 0; d < W; ++d)
         if (parts[d].rc != PHANT_OK) return cfail(c, parts[d].rc, std::string(who) + ": device " + std::to_string(d) + ": " + parts[d].err);
     // ---- the root branch from the sixteen child references ----
@@ -329,23 +240,31 @@ int32_t sharded_root(phant_comm* c, const std::vector<KeyList>& lists, uint8_t o
 
 }  // namespace
 
+// why the last phant_comm_create on this thread failed (the comm itself is gone by then): phant_comm_last_error(NULL)
+thread_local std::string g_create_err;
+
 extern "C" {
 
 int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t flags, phant_comm** out) {
     if (!out) return PHANT_E_INVALID_ARG;
     *out = nullptr;
+    g_create_err.clear();
+    auto refuse = [](int32_t code, const std::string& why) {
+        g_create_err = why;
+        return code;
+    };
     int have = 0;
-    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return PHANT_E_NO_DEVICE;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return refuse(PHANT_E_NO_DEVICE, "comm_create: no GPU visible");
     if (n_devices == 0) n_devices = (uint32_t)have;  // all of them
-    if (n_devices > 64) return PHANT_E_INVALID_ARG;
+    if (n_devices > 64) return refuse(PHANT_E_INVALID_ARG, "comm_create: more than 64 devices");
     phant_comm* c = new (std::nothrow) phant_comm();
-    if (!c) return PHANT_E_OOM;
+    if (!c) return refuse(PHANT_E_OOM, "comm_create: out of memory");
     for (uint32_t r = 0; r < n_devices; ++r) {
         const int d = devices ? devices[r] : (int)r;
         for (int prev : c->devices)
             if (prev == d) {  // (RCCL cannot put one device into a communicator twice)
                 phant_comm_destroy(c);
-                return PHANT_E_INVALID_ARG;
+                return refuse(PHANT_E_INVALID_ARG, "comm_create: device " + std::to_string(d) + " listed twice");
             }
         phant_opts o;
         o.struct_size = sizeof(o);
@@ -356,21 +275,24 @@ int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t f
         const int32_t rc = phant_ctx_create(&o, &x);
         if (rc != PHANT_OK) {
             phant_comm_destroy(c);
-            return rc;
+            return refuse(rc, "comm_create: no ctx on device " + std::to_string(d) + " (needs a gfx950 device)");
         }
         c->ctx.push_back(x);
         c->devices.push_back(d);
     }
     if (n_devices > 1) {
         if (!load_rccl(c->api, c->err)) {
+            const std::string why = "comm_create: " + c->err;
             phant_comm_destroy(c);
-            return PHANT_E_UNSUPPORTED;
+            return refuse(PHANT_E_UNSUPPORTED, why);
         }
         c->rccl.assign(n_devices, nullptr);
-        if (c->api.comm_init_all(c->rccl.data(), (int)n_devices, c->devices.data()) != 0) {
+        const ncclResult_t nrc = c->api.comm_init_all(c->rccl.data(), (int)n_devices, c->devices.data());
+        if (nrc != ncclSuccess) {
+            const std::string why = std::string("comm_create: ncclCommInitAll: ") + (c->api.error_string ? c->api.error_string(nrc) : "error");
             c->rccl.clear();
             phant_comm_destroy(c);
-            return PHANT_E_DEVICE;
+            return refuse(PHANT_E_DEVICE, why);
         }
         c->have_rccl = true;
     }
@@ -383,7 +305,7 @@ void phant_comm_destroy(phant_comm* c) {
     if (!c) return;
     for (phant_ctx* x : c->ctx) (void)phant_stream_sync(x);
     if (c->have_rccl)
-        for (rccl_comm_t k : c->rccl)
+        for (ncclComm_t k : c->rccl)
             if (k) (void)c->api.comm_destroy(k);
     for (phant_ctx* x : c->ctx) phant_ctx_destroy(x);
     delete c;
@@ -393,7 +315,7 @@ uint32_t phant_comm_size(const phant_comm* c) { return c ? (uint32_t)c->ctx.size
 
 phant_ctx* phant_comm_ctx(phant_comm* c, uint32_t rank) { return (c && rank < c->ctx.size()) ? c->ctx[rank] : nullptr; }
 
-const char* phant_comm_last_error(const phant_comm* c) { return c ? c->err.c_str() : "null comm"; }
+const char* phant_comm_last_error(const phant_comm* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 uint32_t phant_comm_owner(const phant_comm* c, const uint8_t* key, uint32_t key_len) {
     const uint32_t n = phant_comm_size(c);
@@ -477,17 +399,7 @@ int32_t phant_mpt_verify_sharded(phant_comm* c, const uint8_t* roots, uint32_t n
             c->ctx[r], roots, n_roots, root_idx ? s.root_idx.data() : nullptr, s.keys.data(), key_len, s.nodes.data(),
             s.nodes.size(), s.node_off.data(), s.pfn.data(), m, s.status.data(), s.value_off.data(), s.value_len.data(), &s.d_fail);
     };
-#ifndef PHANT_HOST_EMU
-    if (W == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (uint32_t r = 0; r < W; ++r) th.emplace_back(work, r);
-        for (std::thread& t : th) t.join();
-    }
-#else  // (the host emulation of the HIP runtime is single-threaded)
-    for (uint32_t r = 0; r < W; ++r) work(r);
-#endif
+    for_each_device(W, work);
     for (uint32_t r = 0; r < W; ++r)
         if (c->shards[r].rc != PHANT_OK) {
             for (phant_ctx* x : c->ctx) (void)phant_stream_sync(x);  // nothing of a failed call stays in flight
@@ -619,16 +531,7 @@ int32_t phant_state_root_sharded(phant_comm* c, const uint8_t* addrs, const uint
                                        s.vals.data(), s.vals.size(), s.val_off.data());
         if (s.rc != PHANT_OK) s.err = phant_last_error(c->ctx[d]);
     };
-#ifndef PHANT_HOST_EMU
-    {
-        std::vector<std::thread> th;
-        for (uint32_t d = 1; d < W; ++d) th.emplace_back(work, d);
-        work(0);
-        for (std::thread& t : th) t.join();
-    }
-#else
-    for (uint32_t d = 0; d < W; ++d) work(d);
-#endif
+    for_each_device(W, work);
     std::vector<KeyList> lists(W);
     for (uint32_t d = 0; d < W; ++d) {
         if (sh[d].rc != PHANT_OK) return cfail(c, sh[d].rc, "state_root_sharded: device " + std::to_string(d) + ": " + sh[d].err);

@@ -291,10 +291,10 @@ PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len
 }
 
 constexpr int COMPARE_UNROLL = 4;  // steps in flight per wave: 2 x COMPARE_UNROLL nodes
-#ifdef PHANT_HOST_EMU
-#define PHANT_NUM_VGPR(n)  // (a register budget means nothing to a host compiler; clang rejects the attribute there)
-#else
+#ifdef __HIPCC__
 #define PHANT_NUM_VGPR(n) __attribute__((amdgpu_num_vgpr(n)))
+#else
+#define PHANT_NUM_VGPR(n)  // (a register budget means nothing to a host compiler)
 #endif
 
 // One lane per (proof, d < S), as propose_kernel.  The lane reads its group's slot back: the node found there is the

@@ -76,7 +76,8 @@ struct TrieDev {
     unsigned long long scratch_cap;
 };
 
-enum : uint32_t { ERR_UNSORTED = 1u };
+enum : uint32_t { ERR_UNSORTED = 1u, ERR_KEY_RANGE = 2u };
+constexpr uint32_t MAX_KEY_BYTES = 255;  // nibble depths index MAX_DEPTH_BINS counters (LDS and global)
 
 PHANT_DEV uint32_t nib_len(const TrieDev& t, uint32_t i) { return 2u * (t.key_off[i + 1] - t.key_off[i]); }
 PHANT_DEV uint32_t nib_at(const TrieDev& t, uint32_t i, uint32_t j) {
@@ -97,7 +98,19 @@ __global__ void __launch_bounds__(256) lcp_kernel(TrieDev t) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i > t.n) return;
     int32_t v = -1;
-    if (i > 0 && i < t.n && !t.first_flag[i]) {
+    // The device-resident form cannot look at the offsets on the host: a key longer than 255 bytes, or offsets that go
+    // backwards (the difference wraps), would index the depth counters of the kernels behind this one out of bounds.  Such a
+    // key is reported and takes no part in the prefix computation, so every lcp stays below 2 x 255.
+    bool sane = true;
+    if (i < t.n) {
+        if (t.key_off[i + 1] - t.key_off[i] > MAX_KEY_BYTES) {
+            atomicOr(&t.counters[1], ERR_KEY_RANGE);
+            sane = false;
+        }
+        if (i > 0 && t.key_off[i] - t.key_off[i - 1] > MAX_KEY_BYTES) sane = false;
+    }
+    if (i > 0 && i < t.n && !t.first_flag[i] && !sane) v = 0;
+    if (i > 0 && i < t.n && !t.first_flag[i] && sane) {
         const uint32_t la = t.key_off[i] - t.key_off[i - 1], lb = t.key_off[i + 1] - t.key_off[i];
         const uint8_t* a = t.keys + t.key_off[i - 1];
         const uint8_t* b = t.keys + t.key_off[i];
@@ -707,6 +720,10 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     std::vector<uint32_t> cnt(8 + MAX_DEPTH_BINS);
     TB_TRY(hipMemcpyAsync(cnt.data(), t.counters, cnt.size() * 4, hipMemcpyDeviceToHost, st));
     TB_TRY(hipStreamSynchronize(st));
+    if (cnt[1] & ERR_KEY_RANGE) {
+        err = "key longer than 255 bytes, or key offsets not monotone";
+        return PHANT_E_INVALID_ARG;
+    }
     if (cnt[1] & ERR_UNSORTED) {
         err = "keys are not strictly increasing (mpt.zig:39)";
         return PHANT_E_UNSORTED;

@@ -5,9 +5,10 @@ the block witness as JSON -> packed arrays -> one batched verification on the GP
 Wire format: EIP-1186 `eth_getProof` result objects under a state root (include/phant_gpu.h, block
 witness section), hex per src/common/hexutils.zig:22-37.
 
-    w = ExecutionWitness.parse_json(text)       # host-only (no GPU needed)
-    status, n_failed = w.verify(ctx)            # PHANT_PROOF_* per proof, document order
-    ok = new_payload_witness_ok(text, ctx)      # what newPayloadV2Handler would ask before runBlock
+    w = ExecutionWitness.parse_json(text)                        # host-only (no GPU needed)
+    status, n_failed = w.verify(ctx, expected_state_root=root)   # PHANT_PROOF_* per proof, document order; `root` = the
+                                                                 # state root the CALLER trusts (the parent header's)
+    ok = new_payload_witness_ok(text, parent_state_root, ctx)    # what newPayloadV2Handler would ask before runBlock
 """
 from __future__ import annotations
 

@@ -63,7 +63,11 @@ def test_comm_create_arguments():
     try:
         h = C.c_void_p()
         assert lib.phant_comm_create(None, 3, 0, C.byref(h)) == L.E_NO_DEVICE          # more devices than there are
+        assert b"device 2" in lib.phant_comm_last_error(None)                          # (why: the comm itself is gone)
         assert lib.phant_comm_create((C.c_int32 * 2)(0, 0), 2, 0, C.byref(h)) == L.E_INVALID_ARG   # one device twice
+        assert b"listed twice" in lib.phant_comm_last_error(None)
+        with pytest.raises(L.PhantError, match="listed twice"):
+            phant_amd.comm.Comm(devices=[1, 1])
         assert lib.phant_comm_create(None, 0, 0, C.byref(h)) == 0 and lib.phant_comm_size(h) == 2  # 0 = all of them
         assert lib.phant_comm_ctx(h, 1) and not lib.phant_comm_ctx(h, 2)
         assert lib.phant_comm_owner(h, (C.c_uint8 * 1)(0x30), 1) == 1 and lib.phant_comm_owner(h, (C.c_uint8 * 1)(0x4f), 1) == 0

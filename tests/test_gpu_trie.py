@@ -73,6 +73,18 @@ def test_mptize_device_form_matches_host_form_and_oracle(P, oracle):
     with pytest.raises(L.PhantError) as e:
         dev_root([b"\x02", b"\x01"], [b"a", b"b"])
     assert e.value.code == L.E_UNSORTED
+    # what only the device can see in this form: a key longer than 255 bytes (its nibble depths would index the depth
+    # counters out of bounds), key offsets that go backwards
+    with pytest.raises(L.PhantError) as e:
+        dev_root([b"\x01" * 10, b"\x02" * 300, b"\x03"], [b"a", b"b", b"c"])
+    assert e.value.code == L.E_INVALID_ARG
+    kb = torch.from_numpy(np.arange(64, dtype=np.uint8)).cuda()
+    ko = torch.tensor([0, 40, 8, 64], dtype=torch.int32).cuda()
+    vb, vo = torch.zeros(3, dtype=torch.uint8).cuda(), torch.tensor([0, 1, 2, 3], dtype=torch.int64).cuda()
+    with pytest.raises(L.PhantError) as e:
+        P.mpt.mptize_dev(kb, ko, vb, vo)
+    assert e.value.code == L.E_INVALID_ARG
+    assert dev_root([b"\x01", b"\x02"], [b"a", b"b"]) == oracle.mptize([b"\x01", b"\x02"], [b"a", b"b"])  # (the ctx is fine)
 
 
 def test_mptize_variable_length_keys_and_branch_values(P, oracle):
