@@ -99,6 +99,14 @@ def parse():
     ap.add_argument("--streams", type=int, default=4,
                     help="config3: independent batches in flight, each on its own ctx + HIP stream (a validator "
                          "verifying consecutive witnesses); 1 = strictly one launch sequence after the other")
+    ap.add_argument("--allreduce-every", type=int, default=0,
+                    help="N > 1: a slot's per-root verdicts are exchanged once per this many passes, as one all-reduce of a "
+                         "(passes x roots) block on a stream of its own (default 0 = once per timed step = --inner passes)")
+    ap.add_argument("--comm", action="store_true",
+                    help="the in-process form of the multi-GPU path: ONE process, every visible device behind one phant_comm "
+                         "(phant_comm_ctx + phant_mpt_verify_verdict_dev per device, one phant_comm_allreduce_verdict per pass); "
+                         "prints config 4's strong-scaling line.  No torchrun")
+    ap.add_argument("--comm-devices", type=int, default=0, help="--comm: devices to use (default 0 = all visible)")
     ap.add_argument("--messages", type=int, default=1 << 20, help="config2: 136-byte messages per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -257,6 +265,108 @@ def cpu_baseline_mptize(keys_t, vals_t, n, root_t, target_seconds):
     return out
 
 
+def device_id_bytes(dev):
+    """16 bytes that identify the physical device behind `dev` (its UUID; PCI bus id + ordinal where the build has none)."""
+    import torch
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        u = getattr(p, "uuid", None)
+        raw = bytes.fromhex(str(u).replace("-", "")) if u is not None else b""
+    except Exception:
+        raw = b""
+    if len(raw) != 16:
+        import hashlib
+        raw = hashlib.sha256(f"{os.uname().nodename}:{getattr(dev, 'index', 0)}".encode()).digest()[:16]
+    return torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+
+
+# What strong scaling of ONE block witness can reach: at N = 8 a rank holds 10 000 of config 4's 80 000 proofs -- below the
+# size where the two tiers pay (72 MB of nodes), so it takes the S = 0 form, whose launch is latency-bound (one wave's
+# Keccak-f chain per node), and every pass ends in an all-reduce.  Measured on one MI355X (profiles/r2_d/
+# small_batches_direct_walk.jsonl): 10 000 depth-8 proofs 74.6 us per launch (134 M proofs/s), 282 M proofs/s with four
+# launches in flight.
+STRONG_EXPECTED = {"basis": "one GPU, 10 000 proofs per launch (what a rank of 8 holds): 74.6 us per launch one at a time, "
+                            "282 M proofs/s with four in flight (profiles/r2_d/small_batches_direct_walk.jsonl); one GPU, the "
+                            "whole 80 000-proof witness: ~0.20 ms per launch, ~515 M proofs/s with four in flight",
+                   "speedup_upper_bound_at_8_gpus": {"four_in_flight": round(8 * 282 / 515, 1), "one_at_a_time": round(8 * 134 / 400, 1)},
+                   "why": "a rank's share of one block falls under the latency floor of a launch (the S = 0 form); the verdict "
+                          "exchange (2 001 x 4 B) is latency-bound as well"}
+
+
+def run_comm_bench(args):
+    """--comm: ONE process, every visible device behind one phant_comm (what phant itself, a single process, would use).
+    Config 4's block witness split over the devices (device-resident shards), a pass = phant_mpt_verify_verdict_dev on
+    every device's ctx + one phant_comm_allreduce_verdict; prints the strong-scaling line."""
+    import torch
+    import phant_amd
+    from phant_amd import mpt as M
+    from phant_amd.comm import Comm
+
+    D = args.comm_devices or torch.cuda.device_count()
+    comm = Comm(n_devices=D)
+    D = comm.size
+    inner, steps, warmup = max(1, args.inner), args.steps, args.warmup
+    # ---- every device builds its shard.  The shared state root needs every rank's level-1 hashes: a first pass over the
+    # ranks collects them (its witnesses are thrown away), the second builds the shards against their sum
+    slots, contribs = [None] * D, []
+
+    def build(d, share):
+        torch.cuda.set_device(d)
+        dev = torch.device("cuda", d)
+        w = phant_amd.witness.block_witness(scale=args.block_scale, seed=4, device=dev, rank=d, world=D,
+                                            ctx=phant_amd.Context(d), share=share if D > 1 else None)
+        torch.cuda.synchronize()
+        return w, dev
+
+    if D > 1:
+        for d in range(D):
+            build(d, lambda c: (contribs.append(c.cpu().clone()), c)[1])
+        level1 = sum(contribs[1:], contribs[0].clone())
+    for d in range(D):
+        w, dev = build(d, lambda c: level1.to(c.device))
+        slots[d] = (w, torch.empty(w.batch.n, dtype=torch.uint8, device=dev),
+                    torch.zeros(w.batch.n_roots, dtype=torch.int32, device=dev), comm.ctx(d))
+    torch.cuda.set_device(0)
+    n_roots = slots[0][0].batch.n_roots
+    total = sum(s[0].batch.n for s in slots)
+
+    def one_pass():
+        for w, status, fails, c in slots:
+            M.verify_batch_dev(w.batch, status=status, ctx=c, fail_count=fails)
+        comm.allreduce_verdict([s[2] for s in slots], n_roots)
+
+    def sync():
+        for _, _, _, c in slots:
+            c.sync()
+
+    for _ in range(max(1, warmup) * inner):
+        one_pass()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps * inner):
+        one_pass()
+    sync()
+    elapsed = time.perf_counter() - t0
+    want = sum(s[0].n_invalid for s in slots)
+    for w, status, fails, _ in slots:
+        assert torch.equal(status, w.expected), "verify statuses differ from the constructed expectation"
+        assert int(fails.sum().item()) == want, (int(fails.sum().item()), want)
+    passes = steps * inner
+    line = {"metric": "mpt_proofs_verified_per_sec_block_witness", "value": total * passes / elapsed, "unit": "proofs/s",
+            "n_gpus": D, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / passes * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"config4 through phant_comm: one synthetic {int(10000 * args.block_scale)}-tx block witness "
+                                   f"({total} account + storage proofs, {n_roots} roots) split over {D} device(s) of ONE process, "
+                                   f"shards resident, one launch sequence per device and one phant_comm_allreduce_verdict per pass, "
+                                   f"{inner} back-to-back passes per timed step",
+                       "units_per_step": total, "parallelism": f"phant_comm x{D} (single process)",
+                       "passes_per_timed_step": inner, "timed_region_ms": elapsed * 1e3},
+            "devices": [bytes(device_id_bytes(torch.device("cuda", d)).cpu().tolist()).hex() for d in comm.devices],
+            "expected": STRONG_EXPECTED}
+    print(json.dumps(line), flush=True)
+    comm.close()
+
+
 def mk_ctx(args, local_rank, use_torch_stream=True):
     import phant_amd
     return phant_amd.Context(local_rank, use_torch_stream=use_torch_stream, verify_fused=(args.verify_mode == "fused"),
@@ -277,6 +387,7 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
 
     n_wit = max(S, 2)
     wits = [make_witness(k) for k in range(n_wit)]
+    K = max(1, args.allreduce_every or inner)  # passes per verdict exchange
     w0 = wits[0]
     n_units = w0.batch.n
     for w in wits:
@@ -294,17 +405,55 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
             st_ = _SLOT_STREAMS[k - 1]
             with torch.cuda.stream(st_):
                 c_ = mk_ctx(args, local_rank)
+        # the slot's verdicts: two blocks of K passes x n_roots counters -- pass i of a block writes row i, a full block is
+        # exchanged as ONE all-reduce while the passes of the other block go on
         slots.append((st_, c_, torch.empty(n_units, dtype=torch.uint8, device=dev),
-                      torch.zeros(w0.batch.n_roots, dtype=torch.int32, device=dev), wits[k]))
+                      torch.zeros((2, K, w0.batch.n_roots), dtype=torch.int32, device=dev), wits[k]))
     turn = {"k": 0}
+    # The exchange (RCCL) on a stream of its own, fed by events: a collective issued on a slot's stream would put RCCL's
+    # kernels and stream waits between that slot's launches -- and the hardware queues are a scarce resource here (DESIGN.md
+    # section 7.5: a ninth stream / a second set of slot streams cost 10-20 %).
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    filled = [0] * S                       # passes written into the slot's current block
+    block_of = [0] * S                     # which block that is
+    reduced_ev = [[None, None] for _ in range(S)]   # event behind the last exchange of block b of slot k
+    exchanged = {"n": 0}
+
+    def exchange(k):
+        st_, _, _, fails_, _ = slots[k]
+        b = block_of[k]
+        if world > 1 and filled[k]:
+            ready = torch.cuda.Event()
+            ready.record(st_)
+            comm_stream.wait_event(ready)
+            with torch.cuda.stream(comm_stream):
+                dist.all_reduce(fails_[b, :filled[k]])  # pass/fail words per root, over xGMI (RCCL)
+                done = torch.cuda.Event()
+                done.record(comm_stream)
+            reduced_ev[k][b] = done
+            exchanged["n"] += 1
+        block_of[k], filled[k] = b ^ 1, 0
+        if reduced_ev[k][b ^ 1] is not None:   # the block about to be overwritten: its exchange must be through
+            st_.wait_event(reduced_ev[k][b ^ 1])
+            reduced_ev[k][b ^ 1] = None
 
     def one_pass():
-        st_, c_, status_, fails_, w_ = slots[turn["k"] % S]
+        k = turn["k"] % S
+        st_, c_, status_, fails_, w_ = slots[k]
         turn["k"] += 1
         with torch.cuda.stream(st_):
-            M.verify_batch_dev(w_.batch, status=status_, ctx=c_, fail_count=fails_)  # statuses + per-root verdict
-            if world > 1:
-                dist.all_reduce(fails_)  # one pass/fail word per root, over xGMI (RCCL)
+            # statuses + per-root verdict of this pass
+            M.verify_batch_dev(w_.batch, status=status_, ctx=c_, fail_count=fails_[block_of[k], filled[k]])
+        filled[k] += 1
+        if filled[k] == K:
+            exchange(k)
+
+    def flush():
+        for k in range(S):
+            if filled[k]:
+                exchange(k)
+        if comm_stream is not None:
+            comm_stream.synchronize()
 
     def barrier():
         if world > 1:
@@ -322,25 +471,28 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     # the device); keep that out of the W warm-up steps and the K timed steps
     for _ in range(S):
         one_pass()
+    flush()
     torch.cuda.synchronize()
     for _ in range(warmup):
         one_pass()
+    flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps * inner):
         one_pass()
+    flush()  # (the last, possibly short, blocks: every verdict of the timed passes has been exchanged when the clock stops)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
-    # correctness of what was timed
-    exp_fail = torch.tensor([0], dtype=torch.int32, device=dev)
-    for _, _, status_, fails_, w_ in slots:
+    # correctness of what was timed: the statuses, and every row of the verdict blocks = the witness's failures over ALL ranks
+    for k, (_, _, status_, fails_, w_) in enumerate(slots):
         assert torch.equal(status_, w_.expected), "verify statuses differ from the constructed expectation"
         want = torch.tensor([w_.n_invalid], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(want)
-        assert int(fails_.sum().item()) == int(want.item()), (int(fails_.sum().item()), int(want.item()))
-    del exp_fail
+        rows = fails_.sum(dim=2).reshape(-1)
+        rows = rows[rows != 0] if int(want.item()) else rows[:0]
+        assert rows.numel() == 0 or bool((rows == int(want.item())).all()), (rows[:8].tolist(), int(want.item()))
 
     # the same number of passes strictly one after the other on ONE stream, alternating between two witnesses
     barrier()
@@ -348,9 +500,9 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     t1 = time.perf_counter()
     with torch.cuda.stream(st0):
         for k in range(steps * inner):
-            M.verify_batch_dev(wits[k % n_wit].batch, status=status0, ctx=c0, fail_count=fails0)
-            if world > 1:
-                dist.all_reduce(fails0)
+            M.verify_batch_dev(wits[k % n_wit].batch, status=status0, ctx=c0, fail_count=fails0[0, k % K])
+            if world > 1 and (k % K == K - 1 or k == steps * inner - 1):
+                dist.all_reduce(fails0[0, :k % K + 1])
     barrier()
     e1 = max_over_ranks(time.perf_counter() - t1)
 
@@ -381,7 +533,9 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     out = {"wits": wits, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
            "value": n_units * world * passes / elapsed,
            "single": {"value": n_units * world * passes / e1, "ms_per_step": e1 / passes * 1e3},
-           "k_avg_ms": k_evt_ms, "k_synced_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed}
+           "k_avg_ms": k_evt_ms, "k_synced_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed,
+           "verdict_exchange": {"passes_per_allreduce": K, "allreduces_on_this_rank": exchanged["n"],
+                                "stream": "own (event-fed)" if world > 1 else None}}
     for k, (st_, c_, _, _, _) in enumerate(slots):
         if c_ is not ctx:
             c_.close()
@@ -402,9 +556,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.comm:
+        if world != 1:
+            raise SystemExit("--comm is the single-process form: no torchrun")
+        return run_comm_bench(args)
+    rccl_world = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # who is in the job: every rank's device, gathered over the same backend the verdicts will take -- N distinct
+        # UUIDs = N GPUs really took part
+        mine = device_id_bytes(dev)
+        ids = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(ids, mine)
+        uu = [bytes(t.cpu().tolist()).hex() for t in ids]
+        rccl_world = {"ranks": world, "distinct_devices": len(set(uu)), "device_ids": uu, "backend": dist.get_backend()}
 
     import phant_amd
     from phant_amd import mpt as M
@@ -454,7 +620,7 @@ def main():
                         f"{w.nodes_per_proof:.2f} nodes, {w.bytes_per_proof:.0f} B and {w.perms_per_proof:.1f} "
                         f"Keccak-f per proof on average, 1% corrupted/exclusion); distinct witness per slot, "
                         f"{inner} back-to-back passes per timed step")
-        extra = {"kernel_synced_avg_ms": r["k_synced_ms"]}
+        extra = {"kernel_synced_avg_ms": r["k_synced_ms"], "verdict_exchange": r["verdict_exchange"]}
         if r["hashed"] is not None:
             hashed = r["hashed"]
             kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
@@ -486,7 +652,8 @@ def main():
                                         "ms_per_step": r4["single"]["ms_per_step"]},
                       "kernel_avg_ms": r4["k_avg_ms"],
                       "roofline_frac": w4.batch.algorithmic_bytes() / (r4["k_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "nodes_hashed": int(sum(r4["hashed"])), "nodes_shipped": int(w4.batch.node_off.numel() - 1)}
+                      "nodes_hashed": int(sum(r4["hashed"])), "nodes_shipped": int(w4.batch.node_off.numel() - 1),
+                      "verdict_exchange": r4["verdict_exchange"], "expected": STRONG_EXPECTED}
             del r4
     elif args.workload == "nodeset":
         w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
@@ -703,6 +870,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds)
         else:
             line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)
+    if rccl_world is not None:
+        line["rccl_world"] = rccl_world
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -31,10 +31,31 @@ class Comm:
             why = self._lib.phant_comm_last_error(None)
             raise L.PhantError(rc, (why.decode() if why else "") or "phant_comm_create failed (needs gfx950 devices; RCCL for more than one)")
         self._h = h
+        n = int(self._lib.phant_comm_size(h))
+        self.devices = list(devices) if devices is not None else list(range(n))
 
     @property
     def size(self) -> int:
         return int(self._lib.phant_comm_size(self._h))
+
+    def ctx(self, rank: int):
+        """The comm's ctx on its device `rank` (phant_comm_ctx), for device-form calls on that device: a borrowed
+        phant_amd.Context on a private stream."""
+        from .context import Context
+        h = self._lib.phant_comm_ctx(self._h, rank)
+        if not h:
+            raise L.PhantError(L.E_INVALID_ARG, f"no rank {rank} in a comm of {self.size}")
+        return Context.borrowed(C.c_void_p(h), self.devices[rank])
+
+    def allreduce_verdict(self, fail_counts, n_roots: int):
+        """phant_comm_allreduce_verdict: fail_counts[rank] = that device's n_roots x int32 / uint32 tensor (written by
+        verify_batch_dev(..., fail_count=) on comm.ctx(rank)); summed in place on every device, on the ranks' own streams,
+        not waited for."""
+        assert len(fail_counts) == self.size
+        ptrs = (C.c_void_p * self.size)(*[t.data_ptr() for t in fail_counts])
+        rc = self._lib.phant_comm_allreduce_verdict(self._h, ptrs, n_roots)
+        if rc != L.OK:
+            raise L.PhantError(rc, self._lib.phant_comm_last_error(self._h).decode())
 
     def owner(self, key: bytes) -> int:
         buf = (C.c_uint8 * max(1, len(key))).from_buffer_copy(bytes(key) or b"\0")

@@ -50,6 +50,17 @@ class Context:
         self._h = h
         self._lib = lib
 
+    @classmethod
+    def borrowed(cls, handle, device: int) -> "Context":
+        """A view of a phant_ctx somebody else owns (phant_comm_ctx: a comm's per-device ctx, on a PRIVATE stream -- see
+        use_torch_stream=False above for the fencing that asks of the caller); close() leaves the handle alone."""
+        self = cls.__new__(cls)
+        self.device = int(device)
+        self._lib = L.lib()
+        self._h = handle
+        self._borrowed = True
+        return self
+
     # -- plumbing --
     def check(self, rc: int):
         if rc != L.OK:
@@ -80,7 +91,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.phant_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.phant_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -61,7 +61,7 @@ def _rand_u8(shape, gen, device):
 
 def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_frac: float = 0.01,
                     rank: int = 0, world: int = 1, group=None, ctx=None, n_tries: int = 0,
-                    value: bytes | None = None, key_order: str = "random") -> Witness:
+                    value: bytes | None = None, key_order: str = "random", share=None) -> Witness:
     """key_order: "random" (BASELINE: the proofs arrive in no particular order) or "sorted" (ascending keys, as a producer
     that walks the trie would list them -- an A/B for how much the order matters to the verifier).
     n_tries = 0: one trie, shared by all ranks (the state trie).  n_tries >= 1: the n proofs are spread over
@@ -140,7 +140,10 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
             contrib = torch.zeros((16, 33), dtype=torch.int32, device=device)
             contrib[nib, :32] = child_hash.to(torch.int32)
             contrib[nib, 32] = 1
-            dist.all_reduce(contrib, group=group)
+            if share is not None:  # (several devices of ONE process: bench.py --comm sums the ranks' contributions itself)
+                contrib = share(contrib)
+            else:
+                dist.all_reduce(contrib, group=group)
             g0 = torch.Generator(device=device)
             g0.manual_seed(seed * 7919 + 17)  # same filler on every rank
             slots = _rand_u8((1, 16, 32), g0, device)
@@ -213,7 +216,7 @@ BLOCK_10K_TX = {"accounts": 20_000, "storage": [(3, 1500, 8), (5, 450, 40), (7, 
 
 
 def block_witness(shape: dict | None = None, seed: int = 4, device=None, corrupt_frac: float = 0.01, rank: int = 0,
-                  world: int = 1, group=None, ctx=None, scale: float = 1.0) -> Witness:
+                  world: int = 1, group=None, ctx=None, scale: float = 1.0, share=None) -> Witness:
     """One block's account + storage proofs as ONE multi-root batch (root 0 = the state root, then the storage
     roots).  `shape` = {"accounts": n, "storage": [(depth, contracts, slots_per_contract), ...]}, times `scale`.
 
@@ -225,7 +228,7 @@ def block_witness(shape: dict | None = None, seed: int = 4, device=None, corrupt
     shape = shape or BLOCK_10K_TX
     n_acc = max(2, int(shape["accounts"] * scale) // world)
     parts = [account_witness(n_acc, depth=8, seed=seed, device=device, corrupt_frac=corrupt_frac, rank=rank,
-                             world=world, group=group, ctx=ctx)]
+                             world=world, group=group, ctx=ctx, share=share)]
     slot_value = bytes(range(0xA0, 0xA0 + 32))  # a 32-byte storage value, RLP a0 || 32 bytes in the leaf
     part_roots = [1]  # roots each part contributes per rank
     for k, (depth, contracts, slots) in enumerate(shape["storage"]):

@@ -28,6 +28,15 @@ def _no_cuda():
     class _Stream:
         cuda_stream = 0
 
+        def wait_event(self, *a, **k):
+            pass
+
+        def wait_stream(self, *a, **k):
+            pass
+
+        def synchronize(self, *a, **k):
+            pass
+
     real_device = torch.device
     saved = (torch.device, torch.cuda.set_device, torch.cuda.current_stream, torch.cuda.Stream, torch.cuda.stream,
              phant_amd.Context, torch.cuda.Event)
@@ -35,6 +44,9 @@ def _no_cuda():
     class _Event:  # wall-clock stand-in for a HIP event (the emulated runtime executes at launch)
         def __init__(self, *a, **k):
             self.t = 0.0
+
+        def synchronize(self):
+            pass
 
         def record(self, *a, **k):
             import time
@@ -192,7 +204,9 @@ def _rank_main(rank, world, port, argv, q):
     ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4", "--inner", "1", "--no-strong"],
     ["--gpus", "2", "--workload", "config4", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--streams", "2",
      "--inner", "1"],
-], ids=["config3", "config3-fewer-steps-than-slots", "config4"])
+    ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "2", "--inner", "3", "--allreduce-every", "2",
+     "--block-scale", "0.01"],
+], ids=["config3", "config3-fewer-steps-than-slots", "config4", "config3-verdicts-every-2-passes"])
 def test_two_ranks_dry_run(argv):
     """The N > 1 path the driver launches with torchrun (never run on real GPUs this round): both ranks build their
     shard, agree on the state root, verify, all-reduce the verdict; rank 0 prints the one line."""
@@ -216,11 +230,31 @@ def test_two_ranks_dry_run(argv):
     assert isinstance(got[1], str)  # rank 1 printed no JSON line (that is what its assertion message says)
     assert line["n_gpus"] == 2 and "cpu_baseline" not in line and line["roofline"]["frac"] > 0
     assert line["config"]["parallelism"] == "key-sharded x2"
+    # who took part, gathered over the backend the verdicts take; the verdicts of K passes go as one all-reduce
+    assert line["rccl_world"]["ranks"] == 2 and len(line["rccl_world"]["device_ids"]) == 2
+    ex = line["roofline"]["verdict_exchange"]
+    inner = int(argv[argv.index("--inner") + 1])
+    assert ex["passes_per_allreduce"] == (2 if "--allreduce-every" in argv else inner) and ex["allreduces_on_this_rank"] > 0
     if "config4" in argv:
         assert line["scaling"] == "strong"
     elif "--no-strong" not in argv:
         # what a SCALE run reads: the strong-scaling config-4 figure next to the weak config-3 one
         assert line["strong"]["scaling"] == "strong" and line["strong"]["value"] > 0
+
+
+def test_comm_form_dry_run():
+    """bench.py --comm: ONE process, two (emulated) devices behind one phant_comm -- the shards built per device with the
+    shared state root summed in process, a pass = a verify per device + one phant_comm_allreduce_verdict."""
+    os.environ["HIPEMU_DEVICES"] = "2"
+    try:
+        line = _bench(["--comm", "--comm-devices", "2", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--inner", "2"])
+    finally:
+        os.environ.pop("HIPEMU_DEVICES", None)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["parallelism"] == "phant_comm x2 (single process)" and len(line["devices"]) == 2
+    assert line["expected"]["speedup_upper_bound_at_8_gpus"]["four_in_flight"] < 8
+    line = _bench(["--comm", "--comm-devices", "1", "--block-scale", "0.01", "--steps", "1", "--warmup", "0", "--inner", "1"])
+    assert line["n_gpus"] == 1 and line["config"]["units_per_step"] == 1080
 
 
 def test_smoke_dry_run(capsys):

@@ -168,3 +168,62 @@ def test_rccl_is_found_and_a_one_rank_allreduce_runs(comm1):
     assert lib.phant_comm_allreduce_verdict(comm1._h, arr, 3) == 0
     assert lib.phant_stream_sync(lib.phant_comm_ctx(comm1._h, 0)) == 0
     assert fc.tolist() == [3, 0, 7]
+
+
+# ---- every GPU of the node (what a SCALE box has and a gpurun box has not): min(device_count, 8) real devices, RCCL for real
+@pytest.fixture(scope="module")
+def comm_all():
+    import torch
+    import phant_amd
+    n = min(torch.cuda.device_count(), 8)
+    if n < 2:
+        pytest.skip("one GPU visible: the several-device forms run on the emulator (tests/test_emu_comm.py) and at N = 1 above")
+    c = phant_amd.comm.Comm(n_devices=n)
+    assert c.size == n
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_all_devices_comm_verify_sharded(comm_all, oracle):
+    body_sharded_matches_oracle_and_single_ctx(comm_all, oracle)
+    body_block_witness_per_root_verdict(comm_all, oracle)
+    body_rejects_inconsistent_index_arrays(comm_all, oracle)
+
+
+@pytest.mark.gpu
+def test_all_devices_comm_roots(comm_all, oracle):
+    body_sharded_mptize_matches_the_oracle(comm_all, oracle)
+    body_sharded_state_root(comm_all, oracle)
+
+
+@pytest.mark.gpu
+def test_all_devices_resident_shards_and_verdict_exchange(comm_all):
+    """The device-form of the exchange (what bench.py --comm times): every device verifies its resident shard of a block
+    witness on the comm's ctx, one phant_comm_allreduce_verdict sums the per-root verdicts in place on every device."""
+    import torch
+    import phant_amd
+    from phant_amd import mpt as M
+    D = comm_all.size
+    contribs, shards = [], []
+    for d in range(D):
+        phant_amd.witness.block_witness(scale=0.05, seed=4, device=f"cuda:{d}", rank=d, world=D, ctx=phant_amd.Context(d),
+                                        share=lambda c: (contribs.append(c.cpu().clone()), c)[1])
+    level1 = sum(contribs[1:], contribs[0].clone())
+    for d in range(D):
+        w = phant_amd.witness.block_witness(scale=0.05, seed=4, device=f"cuda:{d}", rank=d, world=D, ctx=phant_amd.Context(d),
+                                            share=lambda c: level1.to(c.device))
+        shards.append((w, torch.empty(w.batch.n, dtype=torch.uint8, device=f"cuda:{d}"),
+                       torch.zeros(w.batch.n_roots, dtype=torch.int32, device=f"cuda:{d}"), comm_all.ctx(d)))
+    for d in range(D):
+        torch.cuda.synchronize(d)
+    for w, status, fails, c in shards:
+        M.verify_batch_dev(w.batch, status=status, ctx=c, fail_count=fails)
+    comm_all.allreduce_verdict([s[2] for s in shards], shards[0][0].batch.n_roots)
+    for _, _, _, c in shards:
+        c.sync()
+    want = sum(s[0].n_invalid for s in shards)
+    for w, status, fails, _ in shards:
+        assert torch.equal(status, w.expected)
+        assert int(fails.sum().item()) == want
+    assert all(torch.equal(shards[0][2].cpu(), s[2].cpu()) for s in shards[1:])
