@@ -55,22 +55,40 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def csrc_sha256():
+    """The hash tools/pmc_traffic.py stamps its result with: one SHA-256 over the kernel sources (sorted by name)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "phant_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(mode, proofs):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-    their own runs and corrected as tools/pmc_traffic.py documents), or None.  The counters cannot be read
-    from inside this process; the newest profiles/*/pmc_traffic.json measured on this pipeline is quoted."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own runs and
+    corrected as tools/pmc_traffic.py documents).  The counters cannot be read from inside this process, so this is a quoted
+    file -- and only quoted while it is a measurement of THESE kernels: the newest profiles/*/pmc_traffic.json whose
+    `csrc_sha256` equals the hash of phant_amd/csrc as it is now.  Otherwise {"bytes": None, "stale": ...}."""
     import glob
     if proofs != 100_000:
         return None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), reverse=True):
+    now = csrc_sha256()
+    newest = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")), key=os.path.getmtime, reverse=True):
         try:
             t = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if mode in t:
+        if mode not in t:
+            continue
+        newest = newest or os.path.relpath(f, ROOT)
+        if t.get("csrc_sha256") == now:
             return {"bytes": t[mode]["total"], "read": t[mode]["read"], "write": t[mode]["write"],
-                    "source": os.path.relpath(f, ROOT)}
-    return None
+                    "source": f"static:{os.path.relpath(f, ROOT)}@csrc:{now[:12]}",
+                    "kernels": {k.split("::")[-1]: v["read"] + v["write"] for k, v in t[mode].get("kernels", {}).items()}}
+    return {"bytes": None, "stale": f"no profiles/*/pmc_traffic.json was measured on the kernel sources as they are now "
+                                    f"(csrc:{now[:12]}); newest: {newest}"}
 
 
 def parse():
@@ -367,6 +385,38 @@ def run_comm_bench(args):
     comm.close()
 
 
+def per_kernel_roofline(kernel_ms, tiers, n, w, valu_peak):
+    """roofline.kernels: every kernel of the two-tier pipeline ALONE on the chip (tiers serialised) against the roofline that
+    bounds it -- the hash kernels against the Keccak-f rate measured in this run, the memory-bound ones against HBM's 8 TB/s
+    with their algorithmic bytes (config 3: every shallow node is 532 bytes)."""
+    S = tiers["dedup_levels"]
+    shallow = n * S
+    copies = shallow - tiers["list_nodes"]
+    node_b, key_b = 532, 32
+    out = {"note": "tiers serialised (PHANT_VERIFY_SERIAL=1): HIP events around each kernel, alone on the chip; one launch "
+                   "overlaps hash_deep with propose + dedup + hash_list", "dedup_levels": S}
+
+    def hbm(ms, nbytes, what):
+        g = nbytes / (ms * 1e-3) / 1e9
+        return {"ms": ms, "bound": "hbm", "algorithmic_bytes": int(nbytes), "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": g / HBM_PEAK_GBS, "bytes": what}
+
+    def valu(ms, perms):
+        g = perms / (ms * 1e-3) / 1e9
+        return {"ms": ms, "bound": "valu", "keccak_f": int(perms), "achieved": g, "peak": valu_peak, "unit": "G Keccak-f/s",
+                "frac": g / valu_peak}
+
+    out["hash_deep_kernel"] = valu(kernel_ms["hash_deep"], tiers["deep_keccak_f"])
+    out["hash_list_kernel"] = valu(kernel_ms["hash_list"], tiers["list_keccak_f"])
+    out["dedup_kernel"] = hbm(kernel_ms["dedup"], copies * node_b + shallow * 16 + n * (key_b + 8),
+                              "the copies' own bytes once (their representatives are cache hits) + offsets + keys")
+    out["propose_kernel"] = hbm(kernel_ms["propose"], shallow * 16 + n * (key_b + 8) + tiers["list_nodes"] * 4,
+                                "offsets + keys + table stores")
+    out["walk_kernel"] = hbm(kernel_ms["walk"], n * (112 + key_b + 8 + 9) + w.nodes_per_proof * n * (1 + 4 * S // 8),
+                             "the leaf, the key, node states and representatives, one status byte")
+    return out
+
+
 def mk_ctx(args, local_rank, use_torch_stream=True):
     import phant_amd
     return phant_amd.Context(local_rank, use_torch_stream=use_torch_stream, verify_fused=(args.verify_mode == "fused"),
@@ -529,8 +579,33 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
         kms.append(ctx.last_kernel_ms())
     ctx.timing(False)
     hashed = ctx.verify_stats() if args.verify_mode != "fused" else None
+    # every kernel of the pipeline alone on the chip: a second ctx with the tiers serialised (PHANT_VERIFY_SERIAL is read at
+    # ctx creation), HIP events around each kernel (phant_verify_kernel_ms), averaged over a few launches
+    kernels = tiers = None
+    if args.verify_mode == "flat":
+        tiers = ctx.verify_tier_stats()
+        if tiers["dedup_levels"]:
+            saved = os.environ.get("PHANT_VERIFY_SERIAL")
+            os.environ["PHANT_VERIFY_SERIAL"] = "1"
+            try:
+                with torch.cuda.stream(st0):
+                    cs = mk_ctx(args, local_rank)
+            finally:
+                if saved is None:
+                    os.environ.pop("PHANT_VERIFY_SERIAL", None)
+                else:
+                    os.environ["PHANT_VERIFY_SERIAL"] = saved
+            acc, reps = {}, 8
+            with torch.cuda.stream(st0):
+                for k in range(reps + 2):
+                    M.verify_batch_dev(wits[0].batch, status=dstatus, ctx=cs)
+                    if k >= 2:
+                        for name, ms in cs.verify_kernel_ms().items():
+                            acc[name] = acc.get(name, 0.0) + ms / reps
+            kernels = acc
+            cs.close()
     passes = steps * inner
-    out = {"wits": wits, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
+    out = {"wits": wits, "kernels": kernels, "tiers": tiers, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
            "value": n_units * world * passes / elapsed,
            "single": {"value": n_units * world * passes / e1, "ms_per_step": e1 / passes * 1e3},
            "k_avg_ms": k_evt_ms, "k_synced_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed,
@@ -624,14 +699,23 @@ def main():
         if r["hashed"] is not None:
             hashed = r["hashed"]
             kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
-            # the second roofline of this path: Keccak-f is integer-VALU-bound.  Peak = what the product's round
-            # function sustains with nothing but permutations on the chip (tools/ubench/keccak_rate.hip,
-            # profiles/r1i/keccak_rate_ubench.txt: 10.3 G perm/s at 6 waves/SIMD)
+            # the second roofline of this path: Keccak-f is integer-VALU-bound.  Peak = what the product's round function
+            # sustains with nothing but permutations on THIS chip, measured in this run (phant_keccak_rate: 6 waves per SIMD,
+            # ~5 ms; 4 = what the 120-VGPR hash kernels can have).  Round 1's stand-alone figure: 10.3 G perm/s
+            # (profiles/r1i/keccak_rate_ubench.txt)
+            peak6 = ctx.keccak_rate(6, 200) / 1e9
+            peak4 = ctx.keccak_rate(4, 200) / 1e9
+            vpeak = max(peak6, peak4)
             extra = {**extra, "nodes_shipped": int(b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed)), "keccak_f_run": kf,
                      "keccak_f_if_every_node_hashed": int(round(w.perms_per_proof * n_units)),
-                     "valu": {"bound": "valu", "achieved": kf / (k_avg_ms * 1e-3) / 1e9, "peak": 10.3,
-                              "unit": "G Keccak-f/s", "frac": kf / (k_avg_ms * 1e-3) / 1e9 / 10.3,
+                     "valu": {"bound": "valu", "achieved": kf / (k_avg_ms * 1e-3) / 1e9, "peak": vpeak,
+                              "unit": "G Keccak-f/s", "frac": kf / (k_avg_ms * 1e-3) / 1e9 / vpeak,
+                              "peak_source": "phant_keccak_rate on this device, this run: permutations only, the better of 4 and 6 "
+                                             "waves per SIMD",
+                              "peak_at_6_waves_per_simd": peak6, "peak_at_4_waves_per_simd": peak4, "peak_round1_ubench": 10.3,
                               "note": "permutations actually run / whole-pipeline time of one launch"}}
+            if args.workload == "config3" and args.verify_mode == "flat" and r.get("kernels"):
+                extra["kernels"] = per_kernel_roofline(r["kernels"], r["tiers"], n_units, w, vpeak)
         if args.workload == "config3" and not args.no_strong and args.verify_mode != "fused":
             # BASELINE config 4 next to it: ONE block witness split over the same N GPUs (strong scaling): accounts by
             # top key nibble, contracts dealt out whole, one all-reduce of the per-root verdicts per pass
@@ -829,6 +913,11 @@ def main():
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong" if args.workload == "config4" else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}",
+                   **({"parity_basis": "derived: the reference has no verifier (TODO at src/engine_api/execution_payload.zig:177-178), "
+                                       "so no known answer exists; statuses are checked against the constructed expectation here and, "
+                                       "in tests/, against oracle/verify.c over proofs extracted from tries whose roots the "
+                                       "reference's own vectors pin (DESIGN.md section 5)"} if proofs_like or streamed or
+                      args.workload == "nodeset" else {}),
                    "verify_mode": args.verify_mode if proofs_like else None,
                    "dedup_levels": (args.dedup_levels if proofs_like else None),
                    "streams": (S if proofs_like else 1), "passes_per_timed_step": inner,
@@ -839,6 +928,7 @@ def main():
                      "throughput_frac": value / world * alg_bytes / n_units / 1e9 / HBM_PEAK_GBS,  # rate (launches overlap)
                      "traffic": (tr["bytes"] if (tr := (pmc_traffic(args.verify_mode, args.proofs)
                                                         if args.workload == "config3" else None)) else None),
+                     "traffic_source": (tr.get("source") or tr.get("stale")) if tr else None,
                      "traffic_detail": tr,
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
                                 "node-set pipeline = classify_kernel (class lists) + hash_set_kernel + "

@@ -442,7 +442,20 @@ PHANT_API int32_t phant_verify_stats(phant_ctx *ctx, uint32_t hashed[8]);
  * verified from scratch, out[1] = nodes decoded by walks that had to decode more than one node (both 0 for a witness
  * of full-branch paths ending in a leaf); synchronises the ctx stream.  Diagnostics, not part of a result. */
 PHANT_API int32_t phant_verify_path_stats(phant_ctx *ctx, uint32_t out[2]);
+/* The two tiers of the last verify call on this ctx: out[0] = trie levels deduplicated (0: every shipped node hashed in
+ * place), out[1] = nodes hashed from the class lists (representatives, nodes without a group, copies that differed) and
+ * out[2] = their Keccak-f, out[3] = nodes hashed in place by the deep tier and out[4] = their Keccak-f.  Diagnostics. */
+PHANT_API int32_t phant_verify_tier_stats(phant_ctx *ctx, uint32_t out[5]);
 PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
+/* Diagnostics, for a ctx created with PHANT_VERIFY_SERIAL=1 in the environment (the pipeline's tiers then run one after the
+ * other on the ctx stream): device time of each kernel of the last two-tier verify launch, alone on the chip -- ms[0..4] =
+ * propose, hash_deep, dedup, hash_list, walk.  Synchronises the ctx stream. */
+PHANT_API int32_t phant_verify_kernel_ms(phant_ctx *ctx, float ms[5]);
+/* Diagnostics: the Keccak-f[1600] rate of the device when it does nothing else -- waves_per_simd (1..8) waves per SIMD,
+ * every lane `perms` permutations of a register-resident state with the product's round function, timed with events on the
+ * ctx stream (synchronises it).  *perms_per_s = permutations per second over the whole chip: the VALU ceiling every hash
+ * kernel of this library is measured against (bench.py: roofline.valu.peak). */
+PHANT_API int32_t phant_keccak_rate(phant_ctx *ctx, uint32_t waves_per_simd, uint32_t perms, double *perms_per_s);
 
 #ifdef __cplusplus
 }

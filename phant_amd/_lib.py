@@ -81,8 +81,11 @@ SYMBOLS = {
     "phant_state_trie_leaves": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),
     "phant_timing": (_i32, [_vp, _i32]),
     "phant_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
+    "phant_keccak_rate": (_i32, [_vp, _u32, _u32, C.POINTER(C.c_double)]),
+    "phant_verify_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float * 5)]),
     "phant_verify_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 8)]),
     "phant_verify_path_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 2)]),
+    "phant_verify_tier_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 5)]),
     "phant_mpt_root_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _u32, _vp]),
     "phant_comm_create": (_i32, [_vp, _u32, _u32, C.POINTER(_vp)]),
     "phant_comm_destroy": (None, [_vp]),

@@ -77,11 +77,31 @@ class Context:
         self.check(self._lib.phant_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def keccak_rate(self, waves_per_simd: int = 6, perms: int = 100) -> float:
+        """Keccak-f per second of the whole device running nothing but permutations (phant_keccak_rate, ~5 ms): the VALU
+        ceiling of the sponge on THIS chip."""
+        out = C.c_double(0.0)
+        self.check(self._lib.phant_keccak_rate(self._h, waves_per_simd, perms, C.byref(out)))
+        return out.value
+
+    def verify_kernel_ms(self) -> dict[str, float]:
+        """Device time of each kernel of the last two-tier verify launch, tiers serialised (a ctx created while
+        PHANT_VERIFY_SERIAL=1 is in the environment): propose, hash_deep, dedup, hash_list, walk."""
+        out = (C.c_float * 5)()
+        self.check(self._lib.phant_verify_kernel_ms(self._h, C.byref(out)))
+        return dict(zip(("propose", "hash_deep", "dedup", "hash_list", "walk"), [float(x) for x in out]))
+
     def verify_stats(self) -> list[int]:
         """Nodes hashed by the last node-parallel verify call, per rate-block class."""
         out = (C.c_uint32 * 8)()
         self.check(self._lib.phant_verify_stats(self._h, C.byref(out)))
         return list(out)
+
+    def verify_tier_stats(self) -> dict[str, int]:
+        """The two tiers of the last verify call: levels deduplicated, nodes / Keccak-f of the class lists and of the deep tier."""
+        out = (C.c_uint32 * 5)()
+        self.check(self._lib.phant_verify_tier_stats(self._h, C.byref(out)))
+        return dict(zip(("dedup_levels", "list_nodes", "list_keccak_f", "deep_nodes", "deep_keccak_f"), [int(x) for x in out]))
 
     def verify_path_stats(self) -> tuple[int, int]:
         """(proofs verified from scratch by their walk lane, nodes decoded by walks that decoded more than one)."""

@@ -42,6 +42,9 @@ struct phant_ctx {
         phant::DevArena io, dv;
         bool busy = false;
     } slots[PHANT_MAX_SLOTS];
+    uint32_t last_shallow = 0;  // trie levels the last two-tier launch deduplicated (diagnostics)
+    hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // PHANT_VERIFY_SERIAL: per-kernel events
+    bool kev_valid = false;
     // stream-side timing of the last device-form call
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -176,6 +179,15 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         phant_ctx_destroy(c);
         return PHANT_E_DEVICE;
     }
+    c->tune.last_shallow = &c->last_shallow;
+    if (c->tune.serial) {  // diagnostics: events around every kernel of a two-tier launch (phant_verify_kernel_ms)
+        for (hipEvent_t& e : c->kev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                phant_ctx_destroy(c);
+                return PHANT_E_DEVICE;
+            }
+        c->tune.kernel_ev = c->kev;
+    }
     *out = c;
     return PHANT_OK;
 }
@@ -188,6 +200,8 @@ void phant_ctx_destroy(phant_ctx* c) {
     c->dv.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->kev)
+        if (e) (void)hipEventDestroy(e);
     for (auto& sl : c->slots) {
         if (sl.stream) {
             (void)hipStreamSynchronize(sl.stream);
@@ -246,6 +260,20 @@ int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
     return PHANT_OK;
 }
 
+int32_t phant_verify_tier_stats(phant_ctx* c, uint32_t out[5]) {
+    if (!c || !out) return PHANT_E_INVALID_ARG;
+    for (int i = 0; i < 5; ++i) out[i] = 0;
+    if (c->verify_fused || !c->dv.base) return PHANT_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->side.stream) HIP_TRY(c, hipStreamSynchronize(c->side.stream));
+    uint32_t hdr[phant::VERIFY_HEADER_WORDS];
+    HIP_TRY(c, hipMemcpy(hdr, c->dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
+    out[0] = c->last_shallow;
+    phant::verify_tier_stats_from_header(hdr, out + 1);
+    return PHANT_OK;
+}
+
 int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
     if (!c || !out) return PHANT_E_INVALID_ARG;
     out[0] = out[1] = 0;
@@ -259,12 +287,54 @@ int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
     return PHANT_OK;
 }
 
+int32_t phant_verify_kernel_ms(phant_ctx* c, float ms[5]) {
+    if (!c || !ms) return PHANT_E_INVALID_ARG;
+    if (!c->tune.kernel_ev) return fail(c, PHANT_E_UNSUPPORTED, "verify_kernel_ms: the ctx was not created under PHANT_VERIFY_SERIAL=1");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 5; ++i) {
+        ms[i] = 0.f;
+        // (a launch that took the S = 0 form, or none yet: the events were never recorded)
+        if (hipEventElapsedTime(&ms[i], c->kev[i], c->kev[i + 1]) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, PHANT_E_INVALID_ARG, "verify_kernel_ms: no two-tier launch on this ctx yet");
+        }
+    }
+    return PHANT_OK;
+}
+
 int32_t phant_last_kernel_ms(phant_ctx* c, float* ms) {
     if (!c || !ms) return PHANT_E_INVALID_ARG;
     if (!c->ev_pending) return fail(c, PHANT_E_INVALID_ARG, "no timed call pending");
     DeviceGuard g(c->device);
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PHANT_OK;
+}
+
+int32_t phant_keccak_rate(phant_ctx* c, uint32_t waves_per_simd, uint32_t perms, double* perms_per_s) {
+    if (!c || !perms_per_s || waves_per_simd == 0 || waves_per_simd > 8 || perms == 0) return PHANT_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    int cus = 0;
+    HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const uint32_t blocks = (uint32_t)cus * waves_per_simd;  // a 256-lane workgroup = one wave on each of a CU's four SIMDs
+    const int32_t rc = ws_reset(c, (size_t)blocks * 256 * 4 + 256);
+    if (rc) return rc;
+    uint32_t* d_out = ws_take<uint32_t>(c, (size_t)blocks * 256);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(c, hipEventCreate(&e0));
+    hipError_t e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = phant::launch_keccak_rate(d_out, blocks, perms, c->stream);  // (warm-up: code in the instruction caches)
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    if (e == hipSuccess) e = phant::launch_keccak_rate(d_out, blocks, perms, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(c, PHANT_E_DEVICE, "keccak_rate", e);
+    *perms_per_s = ms > 0.f ? (double)blocks * 256.0 * perms / (ms * 1e-3) : 0.0;
     return PHANT_OK;
 }
 

@@ -52,6 +52,28 @@ keccak256_fixed_kernel(const uint8_t* __restrict__ blob, uint32_t msg_len, uint6
     store_digest(s, out + 32ull * i);
 }
 
+// ---- diagnostics: nothing but permutations (the product's round function), `perms` per lane: the VALU ceiling of the
+// sponge on the chip that runs it (phant_keccak_rate; bench.py quotes it as roofline.valu.peak) ----
+__global__ void __launch_bounds__(256) keccak_rate_kernel(uint32_t* __restrict__ out, uint32_t perms) {
+    Sponge s;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        s.lo[i] = t * 2654435761u + (uint32_t)i;
+        s.hi[i] = t ^ (0x9e3779b9u * (uint32_t)(i + 1));
+    }
+    for (uint32_t p = 0; p < perms; ++p) keccak_f1600(s);
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) x ^= s.lo[i] ^ s.hi[i];
+    out[t] = x;
+}
+
+hipError_t launch_keccak_rate(uint32_t* d_out, uint32_t blocks, uint32_t perms, hipStream_t st) {
+    hipLaunchKernelGGL(keccak_rate_kernel, dim3(blocks), dim3(256), 0, st, d_out, perms);
+    return hipGetLastError();
+}
+
 hipError_t launch_keccak256_var(const uint8_t* d_blob, const uint64_t* d_off, uint32_t n,
                                 uint8_t* d_out, hipStream_t st) {
     if (n == 0) return hipSuccess;

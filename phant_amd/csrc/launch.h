@@ -11,6 +11,9 @@ hipError_t launch_keccak256_var(const uint8_t* d_blob, const uint64_t* d_off, ui
 hipError_t launch_keccak256_fixed(const uint8_t* d_blob, uint32_t msg_len, uint64_t stride,
                                   uint32_t n, uint8_t* d_out, hipStream_t st);
 
+// diagnostics: blocks x 256 lanes run `perms` Keccak-f each on a register-resident state; d_out: blocks x 256 words
+hipError_t launch_keccak_rate(uint32_t* d_out, uint32_t blocks, uint32_t perms, hipStream_t st);
+
 // bulk_keccak.hip: blooms n_receipts x 256 bytes (4-byte aligned, zeroed by the launcher); addresses n x 20 bytes
 // (4-byte aligned)
 hipError_t launch_logs_bloom(const uint8_t* d_items, const uint64_t* d_item_off, const uint32_t* d_item_receipt,
@@ -64,6 +67,9 @@ struct VerifyTune {
     // config 3, round 3: one launch 0.262 ms uncapped, 0.234 at 40 KiB, 0.237 at 52 KiB).  Alone, the deep tier runs uncapped.
     uint32_t hash_lds = 40u * 1024u;
     bool serial = false;  // diagnostics: the tiers one after the other on the ctx stream (clean per-kernel durations in a trace)
+    uint32_t* last_shallow = nullptr; // diagnostics: where the launcher notes the tier split it chose (phant_verify_tier_stats)
+    hipEvent_t* kernel_ev = nullptr;  // diagnostics, with `serial`: six events recorded around the five kernels of a two-tier
+                                      // launch (propose, hash_deep, dedup, hash_list, walk): phant_verify_kernel_ms
 };
 hipError_t launch_mpt_verify(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
                              hipStream_t st, const FlatSide* side, const VerifyTune& tune);
@@ -71,6 +77,9 @@ hipError_t launch_mpt_verify(const VerifyArgs& a, uint32_t total_nodes, uint8_t*
 // VERIFY_HEADER_WORDS words
 constexpr uint32_t VERIFY_HEADER_WORDS = 2048;
 void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]);
+// out[0] = nodes hashed from the class lists, [1] = their Keccak-f (class c = c + 1 permutations), [2] = nodes hashed in
+// place by the deep role, [3] = their Keccak-f
+void verify_tier_stats_from_header(const uint32_t* hdr, uint32_t out[4]);
 // out[0] = proofs the walk could not settle from the tables (verified from scratch by their lane), out[1] = nodes
 // decoded by walks that had to decode more than one
 void verify_paths_from_header(const uint32_t* hdr, uint32_t out[2]);

@@ -1448,6 +1448,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     // the shallow tier has a lane per (proof, level) and lists sized by them: a forced split deeper than the proofs are
     // long on average is cut back to what the workspace (sized from total_nodes) holds
     while (a.shallow && (uint64_t)v.n * a.shallow > (uint64_t)total_nodes + 256u * STRIPES) --a.shallow;
+    if (tune.last_shallow) *tune.last_shallow = total_nodes ? a.shallow : 0u;
     uint64_t direct_entries = 0;
     a.direct = direct_levels(v.n_roots, a.shallow, direct_entries);
     const uint32_t te = table_entries(v.n, v.n_roots, a.direct, a.shallow, total_nodes);
@@ -1491,13 +1492,24 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     }
     // (propose_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep
     // role's waves fill every slot they are given the moment they start)
+    hipEvent_t* const kev = (!two && tune.serial) ? tune.kernel_ev : nullptr;  // (diagnostics: every kernel alone on the chip)
+    auto mark = [&](int i) {
+        if (kev && e == hipSuccess) e = hipEventRecord(kev[i], st);
+    };
+    mark(0);
     hipLaunchKernelGGL(propose_kernel, dim3(sg), dim3(256), 0, st, a);
+    mark(1);
     hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+    mark(2);
     if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), 0, st, a);
+    mark(3);
     hipLaunchKernelGGL(hash_list_kernel, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, st, a);
+    mark(4);
     if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+    mark(5);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
@@ -1552,6 +1564,23 @@ void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]) {
         for (uint32_t s = 0; s < HDR_STAT_STRIPES; ++s) hashed[c] += hdr[HDR_STAT + HDR_STAT_WORDS * buf + N_CLASS * s + c];
     }
     hashed[BRANCH_LEN / RATE] += lists[LIST_B532];
+}
+void verify_tier_stats_from_header(const uint32_t* hdr, uint32_t out[4]) {
+    using namespace v3;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (uint32_t c = 0; c < N_LIST; ++c) {
+        uint32_t cnt = hdr[c];  // (the node-set form's single cursors)
+        for (uint32_t s = 0; s < STRIPES; ++s) cnt += hdr[HDR_CUR + 32u * s + c];
+        out[0] += cnt;
+        out[1] += cnt * (c == LIST_B532 ? BRANCH_LEN / RATE + 1u : c + 1u);
+    }
+    const uint32_t buf = (hdr[HDR_PARITY] & 1u) ^ 1u;
+    for (uint32_t c = 0; c < N_CLASS; ++c)
+        for (uint32_t s = 0; s < HDR_STAT_STRIPES; ++s) {
+            const uint32_t cnt = hdr[HDR_STAT + HDR_STAT_WORDS * buf + N_CLASS * s + c];
+            out[2] += cnt;
+            out[3] += cnt * (c + 1u);
+        }
 }
 void verify_paths_from_header(const uint32_t* hdr, uint32_t out[2]) {
     out[0] = hdr[v3::HDR_SLOW];

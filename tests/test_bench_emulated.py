@@ -131,6 +131,17 @@ def test_config3_forced_tier_split_dry_run():
                    "--dedup-levels", "3", "--no-strong"])
     _check_contract(line, 1, 0)
     assert line["config"]["dedup_levels"] == 3 and "strong" not in line
+    # the VALU peak is measured in the run; every kernel of the two-tier pipeline has its own roofline entry (tiers serialised)
+    r = line["roofline"]
+    assert r["valu"]["peak"] > 0 and "this run" in r["valu"]["peak_source"]
+    k = r["kernels"]
+    assert k["dedup_levels"] == 3 and all(k[n]["ms"] > 0 for n in ("propose_kernel", "hash_deep_kernel", "dedup_kernel",
+                                                                    "hash_list_kernel", "walk_kernel"))
+    assert k["hash_deep_kernel"]["bound"] == "valu" and k["dedup_kernel"]["bound"] == "hbm"
+    assert k["hash_deep_kernel"]["keccak_f"] + k["hash_list_kernel"]["keccak_f"] == r["keccak_f_run"]
+    assert "derived" in line["config"]["parity_basis"]
+    # (no committed PMC measurement is of a 200-proof batch: nothing is quoted)
+    assert r["traffic"] is None
 
 
 def test_config3_fewer_steps_than_slots():

@@ -11,15 +11,30 @@ correction factor used here is derived from a known byte count in the same acces
   * hash_deep_kernel in nodedup mode reads every shipped node once (one node per lane, unaligned 16 B
     loads): factor = known bytes / reported -> applied to both hash kernels in every mode;
   * fillBufferAligned (408 004 096 B written): WRITE_SIZE factor;
-  * the remaining kernels (plan, link, walk: scattered 4..32-byte accesses) are left at 1.0 and marked
+  * the remaining kernels (propose, walk: scattered 4..32-byte accesses) are left at 1.0 and marked
     uncalibrated -- a lower bound.
+The result carries a hash of the kernel sources it was measured on (`csrc_sha256`): bench.py quotes it only while
+phant_amd/csrc still hashes to that.
 The PMC passes run the pipeline's tiers one after the other (PHANT_VERIFY_SERIAL=1): counters are per dispatch.
 """
 import collections
 import csv
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha256():
+    """One hash over the kernel sources (sorted by name): what a traffic measurement is a measurement OF."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "phant_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
 
 d = sys.argv[1]
 UB_BYTES = 750000 * 544 + 4096  # load_align.hip buffer
@@ -49,7 +64,7 @@ known_hash = n * 3836 + 800000 * (16 + 8 + 1) + 100000 * 24
 hk = next(k for k in nd_f if "hash_deep_kernel" in k)  # (a template since the S = 0 form: "...hash_deep_kernel<true>")
 f_hash = known_hash / nd_f[hk]
 
-out = {"unit": "bytes per launch (100000 depth-8 proofs)", "factors": {
+out = {"unit": "bytes per launch (100000 depth-8 proofs)", "csrc_sha256": csrc_sha256(), "factors": {
     "stream_read_uint4": round(f_stream, 3), "node_read_16B_per_lane": round(f_node, 3),
     "node_read_half_wave_per_node": round(f_half, 3),
     "hash kernel (from nodedup known bytes)": round(f_hash, 3), "write": round(f_write, 3)}}
