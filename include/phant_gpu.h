@@ -384,6 +384,19 @@ PHANT_API int32_t phant_index_root_rlp(phant_ctx *ctx, const uint8_t *items,
 PHANT_API int32_t phant_index_root_be32(phant_ctx *ctx, const uint8_t *items,
                                         const uint64_t *item_off, uint32_t n, uint8_t out[32]);
 
+/* All index-keyed roots of one block in ONE pass -- what src/blockchain/blockchain.zig:198-204 computes with three
+ * calculateMPTRoot calls (transactions, receipts, withdrawals; key rlp(index) as phant_index_root_rlp).  The trie hasher
+ * works level by level, and at these sizes (<= a few hundred items) a level is pure latency: the lists go through it as one
+ * forest, so that latency is paid once per block instead of once per list.  List l = items[l][item_off[l][0] ..
+ * item_off[l][n[l]]) with n[l] + 1 offsets; n[l] == 0 (items[l] / item_off[l] may then be NULL) gives mpt.zig:10
+ * empty_mpt_root.  roots_out = n_lists x 32 bytes, in list order.
+ * Optionally the block's logs blooms in the same call (arguments as phant_logs_bloom; bloom_items == NULL: none). */
+PHANT_API int32_t phant_block_roots(phant_ctx *ctx, const uint8_t *const *items, const uint64_t *const *item_off,
+                                    const uint32_t *n, uint32_t n_lists, uint8_t *roots_out,
+                                    const uint8_t *bloom_items, const uint64_t *bloom_item_off,
+                                    const uint32_t *bloom_item_receipt, uint32_t n_bloom_items, uint32_t n_receipts,
+                                    uint8_t *blooms);
+
 /* ------------------------------------------- sharded trie roots (multi-GPU mptize)
  * a trie shards by the top key nibble -- 16 sub-tries, one exchange of <= 33-byte
  * child references, then the root branch.  A rank calls phant_mpt_root_nodes over its sub-tries (one

@@ -76,6 +76,7 @@ SYMBOLS = {
     "phant_mpt_root_nodes": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _u32, _vp]),
     "phant_mpt_strip_first_nibble": (_i32, [_vp, _u32, _vp, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     "phant_index_root_rlp": (_i32, [_vp, _vp, _vp, _u32, _vp]),
+    "phant_block_roots": (_i32, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "phant_index_root_be32": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "phant_state_root": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "phant_state_trie_leaves": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),

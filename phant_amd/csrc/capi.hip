@@ -1147,6 +1147,26 @@ int32_t phant_index_root_rlp(phant_ctx* c, const uint8_t* items, const uint64_t*
     return PHANT_OK;
 }
 
+int32_t phant_block_roots(phant_ctx* c, const uint8_t* const* items, const uint64_t* const* item_off, const uint32_t* n,
+                          uint32_t n_lists, uint8_t* roots_out, const uint8_t* bloom_items, const uint64_t* bloom_item_off,
+                          const uint32_t* bloom_item_receipt, uint32_t n_bloom_items, uint32_t n_receipts, uint8_t* blooms) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (n_lists && (!items || !item_off || !n || !roots_out)) return fail(c, PHANT_E_INVALID_ARG, "block_roots: null pointer");
+    for (uint32_t l = 0; l < n_lists; ++l)
+        if (n[l] && (!items[l] || !item_off[l])) return fail(c, PHANT_E_INVALID_ARG, "block_roots: null list");
+    DeviceGuard g(c->device);
+    if (n_lists) {
+        std::string err;
+        const int32_t rc = phant::index_roots_host(c->ws, c->stream, items, item_off, n, n_lists, roots_out, err);
+        if (rc) return fail(c, rc, err.c_str());
+    }
+    if (bloom_items || n_bloom_items) {
+        if (!blooms) return fail(c, PHANT_E_INVALID_ARG, "block_roots: blooms is null");
+        return phant_logs_bloom(c, bloom_items, bloom_item_off, bloom_item_receipt, n_bloom_items, n_receipts, blooms);
+    }
+    return PHANT_OK;
+}
+
 int32_t phant_index_root_be32(phant_ctx* c, const uint8_t* items, const uint64_t* item_off,
                               uint32_t n, uint8_t out[32]) {
     if (!c || !out) return PHANT_E_INVALID_ARG;

@@ -44,6 +44,10 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
 int32_t index_root_host(Workspaces& ws, hipStream_t st, const uint8_t* items, const uint64_t* item_off, uint32_t n,
                         bool be32, uint8_t out[32], std::string& err);
 
+// calculateMPTRoot of n_lists lists in one forest pass (blockchain.zig:198-204); roots_out = n_lists x 32 bytes
+int32_t index_roots_host(Workspaces& ws, hipStream_t st, const uint8_t* const* items, const uint64_t* const* item_off,
+                         const uint32_t* n, uint32_t n_lists, uint8_t* roots_out, std::string& err);
+
 // secure-trie state root over AccountState fields (src/state/types.zig:13-20)
 int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,
                         const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,

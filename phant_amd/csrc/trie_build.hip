@@ -909,6 +909,60 @@ static size_t rlp_index_key(uint64_t v, uint8_t* out) {
     return 1 + n;
 }
 
+// One list's items as the sorted (key, value) pairs of its index-keyed trie, appended to packed arrays: key = rlp(index)
+// (blockchain.zig:213-232: items 1..0x7f, then item 0 under key 0x80, then 0x80.. -- that insertion order is ascending key
+// order).  key_off / val_off hold one entry per pair appended so far + 1.
+static void append_rlp_index_pairs(const uint8_t* items, const uint64_t* item_off, uint32_t n, std::vector<uint8_t>& keys,
+                                   std::vector<uint32_t>& key_off, std::vector<uint8_t>& vals, std::vector<uint64_t>& val_off) {
+    auto push = [&](uint32_t idx, const uint8_t* key, size_t klen) {
+        keys.insert(keys.end(), key, key + klen);
+        vals.insert(vals.end(), items + item_off[idx], items + item_off[idx + 1]);
+        key_off.push_back((uint32_t)keys.size());
+        val_off.push_back(vals.size());
+    };
+    uint32_t i = 0;
+    while (i + 1 < n && i + 1 != 0x80) {
+        const uint8_t kb = (uint8_t)(i + 1);
+        push(i + 1, &kb, 1);
+        ++i;
+    }
+    if (n > 0) {
+        const uint8_t kb = 0x80;
+        push(0, &kb, 1);
+        ++i;
+    }
+    while (i < n) {
+        uint8_t kb[9];
+        const size_t kl = rlp_index_key(i, kb);
+        push(i, kb, kl);
+        ++i;
+    }
+}
+
+// calculateMPTRoot over several lists of one block at once (blockchain.zig:198-204: transactions, receipts, withdrawals):
+// ONE forest pass, so the level-by-level latency of the trie hasher is paid once for all of them.
+int32_t index_roots_host(Workspaces& ws, hipStream_t st, const uint8_t* const* items, const uint64_t* const* item_off,
+                         const uint32_t* n, uint32_t n_lists, uint8_t* roots_out, std::string& err) {
+    std::vector<uint8_t> keys, vals;
+    std::vector<uint32_t> key_off(1, 0), seg(1, 0);
+    std::vector<uint64_t> val_off(1, 0);
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        for (uint32_t i = 0; i < n[l]; ++i)
+            if (item_off[l][i + 1] < item_off[l][i]) {
+                err = "block_roots: item offsets not monotone";
+                return PHANT_E_INVALID_ARG;
+            }
+        if ((uint64_t)seg.back() + n[l] > 0xffffffffull) {
+            err = "block_roots: more than 2^32 items";
+            return PHANT_E_UNSUPPORTED;
+        }
+        append_rlp_index_pairs(items[l], item_off[l], n[l], keys, key_off, vals, val_off);
+        seg.push_back((uint32_t)(key_off.size() - 1));
+    }
+    return trie_forest_host(ws, st, keys.data(), key_off.data(), vals.data(), val_off.data(), seg.back(), seg.data(), n_lists,
+                            roots_out, err);
+}
+
 int32_t index_root_host(Workspaces& ws, hipStream_t st, const uint8_t* items, const uint64_t* item_off, uint32_t n,
                         bool be32, uint8_t out[32], std::string& err) {
     std::vector<uint8_t> keys;
@@ -934,35 +988,11 @@ int32_t index_root_host(Workspaces& ws, hipStream_t st, const uint8_t* items, co
         return trie_root_host(ws, st, keys.data(), key_off.data(), n ? items + item_off[0] : nullptr,
                               val_off.data(), n, out, err);
     }
-    // blockchain.zig:213-232: items 1..0x7f, then item 0 (key 0x80), then 0x80.. --
-    // that insertion order is ascending key order
     keys.reserve((size_t)n * 4);
     vals.reserve(n ? (size_t)(item_off[n] - item_off[0]) : 0);
-    uint32_t k = 0;
-    auto push = [&](uint32_t idx, const uint8_t* key, size_t klen) {
-        keys.insert(keys.end(), key, key + klen);
-        vals.insert(vals.end(), items + item_off[idx], items + item_off[idx + 1]);
-        ++k;
-        key_off[k] = (uint32_t)keys.size();
-        val_off[k] = vals.size();
-    };
-    uint32_t i = 0;
-    while (i + 1 < n && i + 1 != 0x80) {
-        const uint8_t kb = (uint8_t)(i + 1);
-        push(i + 1, &kb, 1);
-        ++i;
-    }
-    if (n > 0) {
-        const uint8_t kb = 0x80;
-        push(0, &kb, 1);
-        ++i;
-    }
-    while (i < n) {
-        uint8_t kb[9];
-        const size_t kl = rlp_index_key(i, kb);
-        push(i, kb, kl);
-        ++i;
-    }
+    key_off.assign(1, 0);
+    val_off.assign(1, 0);
+    append_rlp_index_pairs(items, item_off, n, keys, key_off, vals, val_off);
     return trie_root_host(ws, st, keys.data(), key_off.data(), vals.data(), val_off.data(), n, out, err);
 }
 

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -113,6 +115,22 @@ def index_root_rlp(items, ctx: Context | None = None) -> bytes:
     out = np.zeros(32, np.uint8)
     ctx.check(ctx._lib.phant_index_root_rlp(ctx.handle, _np_ptr(blob), _np_ptr(off), len(items), _np_ptr(out)))
     return out.tobytes()
+
+
+def block_roots(lists, ctx: Context | None = None) -> list[bytes]:
+    """Blockchain.validateBlock's roots (blockchain.zig:198-204: transactionsRoot, receiptsRoot, withdrawalsRoot) in ONE
+    call: `lists` = the encoded items of every index-keyed trie of the block (key rlp(index), as index_root_rlp); all of
+    them go through the trie hasher as one forest, so its level-by-level latency is paid once (phant_block_roots).
+    -> one 32-byte root per list (empty_mpt_root for an empty one)."""
+    ctx = ctx or default_context()
+    packed = [_pack([bytes(x) for x in items], np.uint64) for items in lists]
+    k = len(lists)
+    item_p = (C.c_void_p * max(k, 1))(*[_np_ptr(b).value if b.size else None for b, _ in packed])
+    off_p = (C.c_void_p * max(k, 1))(*[_np_ptr(o).value for _, o in packed])
+    n = (C.c_uint32 * max(k, 1))(*[len(x) for x in lists])
+    out = np.zeros(32 * max(k, 1), np.uint8)
+    ctx.check(ctx._lib.phant_block_roots(ctx.handle, item_p, off_p, n, k, _np_ptr(out), None, None, None, 0, 0, None))
+    return [out[32 * i:32 * i + 32].tobytes() for i in range(k)]
 
 
 def index_root_be32(items, ctx: Context | None = None) -> bytes:

@@ -112,6 +112,34 @@ def test_fixture_tx_and_withdrawal_roots(P):
     assert n == 87
 
 
+def test_block_roots_in_one_call(P, oracle):
+    """phant_block_roots: every index-keyed trie of a block through the trie hasher as ONE forest (blockchain.zig:198-204).
+    The reference's 87 transactionsTrie + 87 withdrawalsRoot fixture values, each block's pair from one call; then three
+    lists per block with receipts-shaped items in the middle (the fixtures' receiptTrie needs the EVM: not a stand-alone
+    vector) against the oracle, lists of 0 / 1 / 127 / 128 / 129 / 400 items (the rlp(index) keys cross 0x80), no list at all."""
+    fx = golden.fixtures()
+    n = 0
+    for c in fx["cases"]:
+        for b in c["blocks"]:
+            txs = [bytes.fromhex(x) for x in b["tx_values"]]
+            wds = [bytes.fromhex(x) for x in b.get("withdrawal_values", [])]
+            got = P.mpt.block_roots([txs, wds])
+            assert got[0].hex() == b["transactions_trie"], c["name"]
+            if "withdrawals_root" in b:
+                assert got[1].hex() == b["withdrawals_root"], c["name"]
+            else:
+                assert got[1] == P.mpt.empty_mpt_root
+            n += 1
+    assert n == 87
+    rng = np.random.default_rng(11)
+    mk = lambda k, lo, hi: [rng.integers(0, 256, int(rng.integers(lo, hi)), dtype=np.uint8).tobytes() for _ in range(k)]  # noqa: E731
+    for sizes in ((0, 0, 0), (1, 1, 0), (127, 127, 16), (128, 129, 1), (400, 400, 400), (3, 0, 129)):
+        lists = [mk(sizes[0], 100, 300), mk(sizes[1], 300, 700), mk(sizes[2], 40, 60)]
+        got = P.mpt.block_roots(lists)
+        assert got == [oracle.index_root_rlp(x) for x in lists], sizes
+    assert P.mpt.block_roots([]) == []
+
+
 def test_index_root_be32_vs_oracle(P, oracle):
     rng = np.random.default_rng(5)
     for n in (0, 1, 2, 17, 129, 400):

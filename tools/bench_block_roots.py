@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Latency of the block's index-keyed roots on the GPU: three phant_index_root_rlp calls (one per list, what three
+calculateMPTRoot calls would become) against ONE phant_block_roots (the lists as one forest).  Host form: the items are the
+caller's bytes, every call includes its copies.
+
+    python tools/bench_block_roots.py [--items 400]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--items", type=int, nargs="*", default=[10, 100, 400])
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import phant_amd
+    from phant_amd import mpt as M
+    rng = np.random.default_rng(3)
+    for n in args.items:
+        mk = lambda lo, hi: [rng.integers(0, 256, int(rng.integers(lo, hi)), dtype=np.uint8).tobytes() for _ in range(n)]  # noqa: E731
+        lists = [mk(100, 300), mk(300, 700), mk(40, 60)]  # txs, receipts, withdrawals
+        want = [M.index_root_rlp(x) for x in lists]
+        assert M.block_roots(lists) == want
+
+        def t(f, reps=30):
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                f()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        one = t(lambda: M.index_root_rlp(lists[1]))
+        three = t(lambda: [M.index_root_rlp(x) for x in lists])
+        forest = t(lambda: M.block_roots(lists))
+        print(json.dumps({"items_per_list": n, "one_root_ms": round(one, 4), "three_calls_ms": round(three, 4),
+                          "block_roots_ms": round(forest, 4), "block_roots_over_one_root": round(forest / one, 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
