@@ -429,6 +429,26 @@ PHANT_API int32_t phant_state_root(phant_ctx *ctx, const uint8_t *addrs, const u
                                    const uint8_t *slot_vals, const uint32_t *slot_first,
                                    uint32_t n, uint8_t out[32]);
 
+/* The same over DEVICE-resident struct-of-arrays (a node that keeps its state in HBM: nothing of it crosses the bus): offsets
+ * relative -- d_code_off[0] == 0, d_slot_first[0] == 0 --, code_bytes = d_code_off[n] and n_slots = d_slot_first[n] given by
+ * the caller who packed them (checked on the device: PHANT_E_INVALID_ARG); d_slot_vals, d_balances and d_root 4-byte aligned.
+ * The root is written to d_root (device, 32 bytes).  The call synchronises the ctx stream a few times (it reads counters back
+ * while it builds: live slots, leaf bytes, the tries' depth histograms). */
+PHANT_API int32_t phant_state_root_dev(phant_ctx *ctx, const uint8_t *d_addrs, const uint64_t *d_nonces,
+                                       const uint8_t *d_balances, const uint8_t *d_code, const uint64_t *d_code_off,
+                                       uint64_t code_bytes, const uint8_t *d_slot_keys, const uint8_t *d_slot_vals,
+                                       const uint32_t *d_slot_first, uint32_t n_slots, uint32_t n, uint8_t *d_root);
+/* One rank's share of a SHARDED state root (arguments as phant_state_root): the sub-tries of its accounts by the top nibble x
+ * of the hashed address, in one pass -- roots[32 x] = that sub-trie's mptize root, root_enc[root_enc_cap x ..] = the RLP of its
+ * root NODE (what phant_mpt_strip_first_nibble re-roots one nibble lower), root_enc_len[x] its length, 0 when the rank has no
+ * account under x.  The leaves stay on the device (phant_state_trie_leaves + phant_mpt_root_nodes is the same result with a
+ * round trip through host memory).  root_enc_cap <= 256; 200 bytes hold any state-trie root node. */
+PHANT_API int32_t phant_state_subtrie_nodes(phant_ctx *ctx, const uint8_t *addrs, const uint64_t *nonces,
+                                            const uint8_t *balances, const uint8_t *code, const uint64_t *code_off,
+                                            const uint8_t *slot_keys, const uint8_t *slot_vals, const uint32_t *slot_first,
+                                            uint32_t n, uint8_t *roots, uint8_t *root_enc, uint32_t root_enc_cap,
+                                            uint32_t *root_enc_len);
+
 /* The LEAVES of that state trie instead of its root -- what a rank of a multi-GPU state root (SURVEY.md
  * section 8e) computes for the accounts it owns before the top-nibble exchange of mptize_sharded: keys = n x 32,
  * keccak256(address) in ascending order; value i = vals[val_off[i] .. val_off[i+1]) =

@@ -80,6 +80,8 @@ SYMBOLS = {
     "phant_index_root_be32": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "phant_state_root": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "phant_state_trie_leaves": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u64, _vp]),
+    "phant_state_root_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "phant_state_subtrie_nodes": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _vp]),
     "phant_timing": (_i32, [_vp, _i32]),
     "phant_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "phant_keccak_rate": (_i32, [_vp, _u32, _u32, C.POINTER(C.c_double)]),

@@ -1193,6 +1193,39 @@ int32_t phant_state_root(phant_ctx* c, const uint8_t* addrs, const uint64_t* non
     return PHANT_OK;
 }
 
+int32_t phant_state_root_dev(phant_ctx* c, const uint8_t* d_addrs, const uint64_t* d_nonces, const uint8_t* d_balances,
+                             const uint8_t* d_code, const uint64_t* d_code_off, uint64_t code_bytes, const uint8_t* d_slot_keys,
+                             const uint8_t* d_slot_vals, const uint32_t* d_slot_first, uint32_t n_slots, uint32_t n, uint8_t* d_root) {
+    if (!c || !d_root) return PHANT_E_INVALID_ARG;
+    if (n && (!d_addrs || !d_nonces || !d_balances || !d_code_off || !d_slot_first || (code_bytes && !d_code) ||
+              (n_slots && (!d_slot_keys || !d_slot_vals))))
+        return fail(c, PHANT_E_INVALID_ARG, "state_root_dev: null pointer");
+    if (((uintptr_t)d_slot_vals & 3u) || ((uintptr_t)d_balances & 3u) || ((uintptr_t)d_root & 3u))
+        return fail(c, PHANT_E_INVALID_ARG, "state_root_dev: d_slot_vals / d_balances / d_root must be 4-byte aligned");
+    DeviceGuard g(c->device);
+    TimedRegion t(c);
+    std::string err;
+    const int32_t rc = phant::state_root_dev(c->ws, c->stream, d_addrs, d_nonces, d_balances, d_code, d_code_off, code_bytes, d_slot_keys,
+                                             d_slot_vals, d_slot_first, n_slots, n, d_root, err);
+    if (rc) return fail(c, rc, err.c_str());
+    return PHANT_OK;
+}
+
+int32_t phant_state_subtrie_nodes(phant_ctx* c, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
+                                  const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys, const uint8_t* slot_vals,
+                                  const uint32_t* slot_first, uint32_t n, uint8_t* roots, uint8_t* root_enc, uint32_t root_enc_cap,
+                                  uint32_t* root_enc_len) {
+    if (!c || !roots || !root_enc || !root_enc_len) return PHANT_E_INVALID_ARG;
+    if (n && (!addrs || !nonces || !balances || !code_off || !slot_first))
+        return fail(c, PHANT_E_INVALID_ARG, "state_subtrie_nodes: null pointer");
+    DeviceGuard g(c->device);
+    std::string err;
+    const int32_t rc = phant::state_subtrie_nodes_host(c->ws, c->stream, addrs, nonces, balances, code, code_off, slot_keys, slot_vals,
+                                                       slot_first, n, roots, root_enc, root_enc_cap, root_enc_len, err);
+    if (rc) return fail(c, rc, err.c_str());
+    return PHANT_OK;
+}
+
 int32_t phant_state_trie_leaves(phant_ctx* c, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
                                 const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys,
                                 const uint8_t* slot_vals, const uint32_t* slot_first, uint32_t n, uint8_t* keys,

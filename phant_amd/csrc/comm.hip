@@ -105,17 +105,21 @@ struct KeyList {
 // The root of the trie over the union of lists[d] (d = device), where device d hashes the sub-tries of the top nibbles x
 // with x mod W == d out of ITS list (keys of other nibbles in that list are ignored: phant_mpt_root_sharded hands every
 // device the same list, phant_state_root_sharded each its own).  Root branch formed on the host.
+// what a device contributes to a sharded root: for each top nibble it owns and has keys under, the sub-trie's root and the
+// RLP of its root node
+struct Part {
+    uint32_t first[17];
+    std::vector<uint32_t> nibbles;
+    std::vector<uint8_t> roots, enc;
+    std::vector<uint32_t> len;
+    uint32_t cap = 0;
+    int32_t rc = PHANT_OK;
+    std::string err;
+};
+int32_t root_from_parts(phant_comm* c, const std::vector<Part>& parts, uint8_t out[32], const char* who);
+
 int32_t sharded_root(phant_comm* c, const std::vector<KeyList>& lists, uint8_t out[32], const char* who) {
     const uint32_t W = (uint32_t)c->ctx.size();
-    struct Part {
-        uint32_t first[17];
-        std::vector<uint32_t> nibbles;
-        std::vector<uint8_t> roots, enc;
-        std::vector<uint32_t> len;
-        uint32_t cap = 0;
-        int32_t rc = PHANT_OK;
-        std::string err;
-    };
     std::vector<Part> parts(W);
     // the sixteen top-nibble ranges of each (sorted) list; order across ranges and key lengths are checked here because
     // the ranges are cut on the host (within a range the device checks the order: PHANT_E_UNSORTED)
@@ -172,6 +176,13 @@ int32_t sharded_root(phant_comm* c, const std::vector<KeyList>& lists, uint8_t o
         if (p.rc != PHANT_OK) p.err = phant_last_error(c->ctx[d]);
     };
     for_each_device(W, work);
+    return root_from_parts(c, parts, out, who);
+}
+
+// the root branch from the devices' sub-trie root nodes (single process: collecting the sixteen child references IS the
+// exchange)
+int32_t root_from_parts(phant_comm* c, const std::vector<Part>& parts, uint8_t out[32], const char* who) {
+    const uint32_t W = (uint32_t)c->ctx.size();
     for (uint32_t d = 0; d < W; ++d)
         if (parts[d].rc != PHANT_OK) return cfail(c, parts[d].rc, std::string(who) + ": device " + std::to_string(d) + ": " + parts[d].err);
     // ---- the root branch from the sixteen child references ----
@@ -490,11 +501,9 @@ int32_t phant_state_root_sharded(phant_comm* c, const uint8_t* addrs, const uint
         if (rc != PHANT_OK) return cfail(c, rc, std::string("state_root_sharded: ") + phant_last_error(c->ctx[0]));
     }
     struct Share {
-        std::vector<uint8_t> addrs, balances, code, slot_keys, slot_vals, keys, vals;
-        std::vector<uint64_t> nonces, code_off, val_off;
-        std::vector<uint32_t> slot_first, key_off;
-        int32_t rc = PHANT_OK;
-        std::string err;
+        std::vector<uint8_t> addrs, balances, code, slot_keys, slot_vals;
+        std::vector<uint64_t> nonces, code_off;
+        std::vector<uint32_t> slot_first;
     };
     std::vector<Share> sh(W);
     for (Share& s : sh) {
@@ -514,30 +523,41 @@ int32_t phant_state_root_sharded(phant_comm* c, const uint8_t* addrs, const uint
         }
         s.slot_first.push_back((uint32_t)(s.slot_keys.size() / 32));
     }
-    // ---- every device: its accounts -> state-trie leaves ----
+    // ---- every device: its accounts -> state-trie leaves -> the sub-tries of its top nibbles, all on the device: only the
+    // sub-tries' roots and root nodes come back (round 2 passed the leaves through host vectors in between) ----
+    constexpr uint32_t CAP = 200;  // a state-trie root node: <= 3 + 33 + 3 + 110 bytes as a leaf, 36 as an extension
+    std::vector<Part> parts(W);
     auto work = [&](uint32_t d) {
         Share& s = sh[d];
+        Part& p = parts[d];
         const uint32_t m = (uint32_t)s.nonces.size();
-        s.key_off.assign((size_t)m + 1, 0);
-        for (uint32_t i = 0; i <= m; ++i) s.key_off[i] = 32u * i;
-        s.val_off.assign((size_t)m + 1, 0);
         if (m == 0) return;
-        s.keys.resize((size_t)m * 32);
-        s.vals.resize((size_t)m * 112);
+        uint8_t roots[16 * 32], enc[16 * CAP];
+        uint32_t len[16];
         const uint8_t one = 0;
-        s.rc = phant_state_trie_leaves(c->ctx[d], s.addrs.data(), s.nonces.data(), s.balances.data(), s.code.empty() ? &one : s.code.data(),
-                                       s.code_off.data(), s.slot_keys.empty() ? &one : s.slot_keys.data(),
-                                       s.slot_vals.empty() ? &one : s.slot_vals.data(), s.slot_first.data(), m, s.keys.data(),
-                                       s.vals.data(), s.vals.size(), s.val_off.data());
-        if (s.rc != PHANT_OK) s.err = phant_last_error(c->ctx[d]);
+        p.rc = phant_state_subtrie_nodes(c->ctx[d], s.addrs.data(), s.nonces.data(), s.balances.data(), s.code.empty() ? &one : s.code.data(),
+                                         s.code_off.data(), s.slot_keys.empty() ? &one : s.slot_keys.data(),
+                                         s.slot_vals.empty() ? &one : s.slot_vals.data(), s.slot_first.data(), m, roots, enc, CAP, len);
+        if (p.rc != PHANT_OK) {
+            p.err = phant_last_error(c->ctx[d]);
+            return;
+        }
+        p.cap = CAP;
+        for (uint32_t x = 0; x < 16; ++x)
+            if (len[x]) {
+                if (x % W != d) {  // (cannot happen: the accounts were dealt out by this very nibble)
+                    p.rc = PHANT_E_DEVICE;
+                    p.err = "an account under a nibble of another device";
+                    return;
+                }
+                p.nibbles.push_back(x);
+                p.roots.insert(p.roots.end(), roots + 32 * x, roots + 32 * x + 32);
+                p.enc.insert(p.enc.end(), enc + (size_t)CAP * x, enc + (size_t)CAP * (x + 1));
+                p.len.push_back(len[x]);
+            }
     };
     for_each_device(W, work);
-    std::vector<KeyList> lists(W);
-    for (uint32_t d = 0; d < W; ++d) {
-        if (sh[d].rc != PHANT_OK) return cfail(c, sh[d].rc, "state_root_sharded: device " + std::to_string(d) + ": " + sh[d].err);
-        lists[d] = KeyList{sh[d].keys.data(), sh[d].key_off.data(), sh[d].vals.data(), sh[d].val_off.data(), (uint32_t)sh[d].nonces.size()};
-    }
-    return sharded_root(c, lists, out, "state_root_sharded");
+    return root_from_parts(c, parts, out, "state_root_sharded");
 }
 
 }  // extern "C"

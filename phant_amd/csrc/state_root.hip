@@ -243,58 +243,49 @@ struct DevLeaves {
     uint8_t* root = nullptr;      // 32 bytes for the caller's forest pass
 };
 
-int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
-                         const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys, const uint8_t* slot_vals,
-                         const uint32_t* slot_first, uint32_t n, DevLeaves& out, std::string& err) {
-    for (uint32_t a = 0; a < n; ++a) {
-        if (slot_first[a + 1] < slot_first[a]) {
-            err = "slot_first not monotone";
-            return PHANT_E_INVALID_ARG;
-        }
-        if (code_off[a + 1] < code_off[a]) {
-            err = "code_off not monotone";
-            return PHANT_E_INVALID_ARG;
-        }
-    }
-    const uint32_t m = slot_first[n] - slot_first[0];
-    if ((uint64_t)n * 112u > 0xffffffffull || (uint64_t)m * 33u > 0xffffffffull) {  // (leaf offsets are scanned as 32-bit counters)
-        err = "state root: more than 4 GiB of leaves in one call";
-        return PHANT_E_UNSUPPORTED;
-    }
-    const uint64_t code_bytes = code_off[n] - code_off[0];
+// the AccountState fields as device-resident struct-of-arrays, offsets relative (code_off[0] == 0, slot_first[0] == 0)
+struct StateIn {
+    const uint8_t* addrs;        // n x 20
+    const uint64_t* nonces;      // n
+    const uint8_t* bal;          // n x 32, big-endian
+    const uint8_t* code;         // code_bytes
+    const uint64_t* code_off;    // n + 1
+    const uint8_t* skeys;        // m x 32
+    const uint8_t* svals;        // m x 32 (4-byte aligned)
+    const uint32_t* slot_first;  // n + 1
+    uint32_t n, m;
+    uint64_t code_bytes;
+};
+
+size_t state_scratch_bytes(uint32_t n, uint32_t m) {
     const size_t n1 = (size_t)n + 1, m1 = (size_t)m + 1;
     auto R = [](size_t b) { return DevArena::round(b); };
     const size_t sort_ws = order_workspace_bytes(m > n ? m : n);
     const size_t scan_entries = scan_scratch_entries((m > n ? m : n) + 1u);
-    SR_TRY(ws.io.reset(R(20 * (size_t)n + 16) + R(8 * (size_t)n) + R(32 * (size_t)n) + R(code_bytes + 16) + R(8 * n1) + 2 * R(32 * (size_t)m + 16) +
-                       2 * R(4 * n1) + R(4 * m1) + R(32 * (size_t)m + 16) + 2 * R(4 * (size_t)m + 4) + R(32 * (size_t)m + 16) + R(sort_ws) +
-                       R(4 * m1) + R(32 * (size_t)m + 16) + R(4 * m1) + R(33 * (size_t)m + 16) + R(8 * m1) + R(32 * (size_t)n) +
-                       2 * R(32 * (size_t)n) + R(4 * n1) + R(32 * (size_t)n + 16) + R(4 * n1) + R(112 * (size_t)n + 16) + R(8 * n1) + R(4 * scan_entries) + 8192));
-    // ---- the caller's arrays, once ----
-    uint8_t* d_addrs = ws.io.take<uint8_t>(20 * (size_t)n + 16);
-    uint64_t* d_nonces = ws.io.take<uint64_t>(n);
-    uint8_t* d_bal = ws.io.take<uint8_t>(32 * (size_t)n);
-    uint8_t* d_code = ws.io.take<uint8_t>(code_bytes + 16);
-    uint64_t* d_code_off = ws.io.take<uint64_t>(n1);
-    uint8_t* d_skeys_in = ws.io.take<uint8_t>(32 * (size_t)m + 16);
-    uint8_t* d_svals_in = ws.io.take<uint8_t>(32 * (size_t)m + 16);
-    uint32_t* d_slot_first = ws.io.take<uint32_t>(n1);
-    SR_TRY(hipMemcpyAsync(d_addrs, addrs, 20 * (size_t)n, hipMemcpyHostToDevice, st));
-    SR_TRY(hipMemcpyAsync(d_nonces, nonces, 8 * (size_t)n, hipMemcpyHostToDevice, st));
-    SR_TRY(hipMemcpyAsync(d_bal, balances, 32 * (size_t)n, hipMemcpyHostToDevice, st));
-    if (code_bytes) SR_TRY(hipMemcpyAsync(d_code, code + code_off[0], code_bytes, hipMemcpyHostToDevice, st));
-    std::vector<uint64_t> rel_code(n1);
-    std::vector<uint32_t> rel_slot(n1);
-    for (size_t i = 0; i < n1; ++i) {
-        rel_code[i] = code_off[i] - code_off[0];
-        rel_slot[i] = slot_first[i] - slot_first[0];
+    return R(4 * n1) + R(4 * m1) + R(32 * (size_t)m + 16) + 2 * R(4 * (size_t)m + 4) + R(32 * (size_t)m + 16) + R(sort_ws) + R(4 * m1) +
+           R(32 * (size_t)m + 16) + R(4 * m1) + R(33 * (size_t)m + 16) + R(8 * m1) + R(32 * (size_t)n) + 2 * R(32 * (size_t)n) + R(4 * n1) +
+           R(32 * (size_t)n + 16) + R(4 * n1) + R(112 * (size_t)n + 16) + R(8 * n1) + R(4 * scan_entries) + R(17 * 4) + 8192;
+}
+
+// device-resident inputs -> the state trie's leaves in device memory (scratch from ws.io, which the caller has reset to
+// hold state_scratch_bytes on top of whatever it staged there)
+int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, DevLeaves& out, std::string& err) {
+    const uint32_t n = in.n, m = in.m;
+    if ((uint64_t)n * 112u > 0xffffffffull || (uint64_t)m * 33u > 0xffffffffull) {  // (leaf offsets are scanned as 32-bit counters)
+        err = "state root: more than 4 GiB of leaves in one call";
+        return PHANT_E_UNSUPPORTED;
     }
-    SR_TRY(hipMemcpyAsync(d_code_off, rel_code.data(), 8 * n1, hipMemcpyHostToDevice, st));
-    SR_TRY(hipMemcpyAsync(d_slot_first, rel_slot.data(), 4 * n1, hipMemcpyHostToDevice, st));
-    if (m) {
-        SR_TRY(hipMemcpyAsync(d_skeys_in, slot_keys + 32ull * slot_first[0], 32 * (size_t)m, hipMemcpyHostToDevice, st));
-        SR_TRY(hipMemcpyAsync(d_svals_in, slot_vals + 32ull * slot_first[0], 32 * (size_t)m, hipMemcpyHostToDevice, st));
-    }
+    const size_t n1 = (size_t)n + 1, m1 = (size_t)m + 1;
+    const size_t sort_ws = order_workspace_bytes(m > n ? m : n);
+    const size_t scan_entries = scan_scratch_entries((m > n ? m : n) + 1u);
+    const uint8_t* d_addrs = in.addrs;
+    const uint64_t* d_nonces = in.nonces;
+    const uint8_t* d_bal = in.bal;
+    const uint8_t* d_code = in.code;
+    const uint64_t* d_code_off = in.code_off;
+    const uint8_t* d_skeys_in = in.skeys;
+    const uint8_t* d_svals_in = in.svals;
+    const uint32_t* d_slot_first = in.slot_first;
 
     // ---- storage: live slots -> hashed keys -> per-account order -> leaves -> one forest pass ----
     uint32_t* d_acc_first = ws.io.take<uint32_t>(n1);
@@ -344,7 +335,7 @@ int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, c
     out.key_off = ws.io.take<uint32_t>(n1);
     out.vals = ws.io.take<uint8_t>(112 * (size_t)n + 16);
     out.val_off = ws.io.take<uint64_t>(n1);
-    out.seg = ws.io.take<uint32_t>(2);
+    out.seg = ws.io.take<uint32_t>(17);
     out.root = ws.io.take<uint8_t>(32);
     SR_TRY(launch_keccak256_fixed(d_addrs, 20, 20, n, d_ha, st));
     SR_TRY(launch_keccak256_var(d_code, d_code_off, n, d_hc, st));
@@ -359,10 +350,84 @@ int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, c
                        out.key_off, out.vals, out.val_off);
     const uint32_t seg[2] = {0u, n};
     SR_TRY(hipMemcpyAsync(out.seg, seg, sizeof seg, hipMemcpyHostToDevice, st));
-    SR_TRY(hipStreamSynchronize(st));  // avb, and `seg` / the rel_* vectors may go
+    SR_TRY(hipStreamSynchronize(st));  // avb, and `seg` may go
     out.val_bytes = avb;
     SR_TRY(hipGetLastError());
     return PHANT_OK;
+}
+
+// the caller's HOST arrays -> staged once -> state_leaves_core
+int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
+                         const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys, const uint8_t* slot_vals,
+                         const uint32_t* slot_first, uint32_t n, DevLeaves& out, std::string& err) {
+    for (uint32_t a = 0; a < n; ++a) {
+        if (slot_first[a + 1] < slot_first[a]) {
+            err = "slot_first not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+        if (code_off[a + 1] < code_off[a]) {
+            err = "code_off not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+    }
+    const uint32_t m = slot_first[n] - slot_first[0];
+    const uint64_t code_bytes = code_off[n] - code_off[0];
+    const size_t n1 = (size_t)n + 1;
+    auto R = [](size_t b) { return DevArena::round(b); };
+    SR_TRY(ws.io.reset(R(20 * (size_t)n + 16) + R(8 * (size_t)n) + R(32 * (size_t)n) + R(code_bytes + 16) + R(8 * n1) + 2 * R(32 * (size_t)m + 16) +
+                       R(4 * n1) + state_scratch_bytes(n, m)));
+    // ---- the caller's arrays, once ----
+    uint8_t* d_addrs = ws.io.take<uint8_t>(20 * (size_t)n + 16);
+    uint64_t* d_nonces = ws.io.take<uint64_t>(n);
+    uint8_t* d_bal = ws.io.take<uint8_t>(32 * (size_t)n);
+    uint8_t* d_code = ws.io.take<uint8_t>(code_bytes + 16);
+    uint64_t* d_code_off = ws.io.take<uint64_t>(n1);
+    uint8_t* d_skeys_in = ws.io.take<uint8_t>(32 * (size_t)m + 16);
+    uint8_t* d_svals_in = ws.io.take<uint8_t>(32 * (size_t)m + 16);
+    uint32_t* d_slot_first = ws.io.take<uint32_t>(n1);
+    SR_TRY(hipMemcpyAsync(d_addrs, addrs, 20 * (size_t)n, hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_nonces, nonces, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_bal, balances, 32 * (size_t)n, hipMemcpyHostToDevice, st));
+    if (code_bytes) SR_TRY(hipMemcpyAsync(d_code, code + code_off[0], code_bytes, hipMemcpyHostToDevice, st));
+    std::vector<uint64_t> rel_code(n1);
+    std::vector<uint32_t> rel_slot(n1);
+    for (size_t i = 0; i < n1; ++i) {
+        rel_code[i] = code_off[i] - code_off[0];
+        rel_slot[i] = slot_first[i] - slot_first[0];
+    }
+    SR_TRY(hipMemcpyAsync(d_code_off, rel_code.data(), 8 * n1, hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_slot_first, rel_slot.data(), 4 * n1, hipMemcpyHostToDevice, st));
+    if (m) {
+        SR_TRY(hipMemcpyAsync(d_skeys_in, slot_keys + 32ull * slot_first[0], 32 * (size_t)m, hipMemcpyHostToDevice, st));
+        SR_TRY(hipMemcpyAsync(d_svals_in, slot_vals + 32ull * slot_first[0], 32 * (size_t)m, hipMemcpyHostToDevice, st));
+    }
+    SR_TRY(hipStreamSynchronize(st));  // (the rel_* vectors may go; the core synchronises within microseconds anyway)
+    const StateIn in{d_addrs, d_nonces, d_bal, d_code, d_code_off, d_skeys_in, d_svals_in, d_slot_first, n, m, code_bytes};
+    return state_leaves_core(ws, st, in, out, err);
+}
+
+// device form: what only the device can see -- offsets that go backwards or do not span what the caller says
+__global__ void __launch_bounds__(256) state_offsets_check_kernel(const uint64_t* __restrict__ code_off, const uint32_t* __restrict__ slot_first,
+                                                                  uint32_t n, uint32_t m, uint64_t code_bytes, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i > n) return;
+    bool bad = false;
+    if (i == 0) bad = code_off[0] != 0ull || slot_first[0] != 0u || code_off[n] != code_bytes || slot_first[n] != m;
+    if (i < n) bad = bad || code_off[i + 1] < code_off[i] || slot_first[i + 1] < slot_first[i];
+    if (bad) *flag = 1u;
+}
+
+// sixteen sub-tries by the top nibble of the (sorted, 32-byte) keys: seg[x] = first key whose top nibble is >= x, seg[16] = n
+__global__ void __launch_bounds__(64) nibble_segments_kernel(const uint8_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ seg) {
+    const uint32_t x = threadIdx.x;
+    if (x > 16u) return;
+    uint32_t lo = 0, hi = n;  // first i with (keys[32 i] >> 4) >= x
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint32_t)(keys[32ull * mid] >> 4) < x) lo = mid + 1u;
+        else hi = mid;
+    }
+    seg[x] = x == 16u ? n : lo;
 }
 
 }  // namespace
@@ -388,6 +453,62 @@ int32_t state_leaves_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, 
     SR_TRY(hipMemcpyAsync(avoff.data(), l.val_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
     SR_TRY(hipStreamSynchronize(st));
     return PHANT_OK;
+}
+
+// StateDB.root() over DEVICE-resident struct-of-arrays: nothing of the state crosses the bus, the root stays on the device.
+int32_t state_root_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_addrs, const uint64_t* d_nonces, const uint8_t* d_balances,
+                       const uint8_t* d_code, const uint64_t* d_code_off, uint64_t code_bytes, const uint8_t* d_slot_keys,
+                       const uint8_t* d_slot_vals, const uint32_t* d_slot_first, uint32_t n_slots, uint32_t n, uint8_t* d_root,
+                       std::string& err) {
+    if (n == 0) {
+        uint8_t root[32];
+        const int32_t rc = trie_root_host(ws, st, nullptr, nullptr, nullptr, nullptr, 0, root, err);
+        if (rc) return rc;
+        SR_TRY(hipMemcpyAsync(d_root, root, 32, hipMemcpyHostToDevice, st));
+        SR_TRY(hipStreamSynchronize(st));
+        return PHANT_OK;
+    }
+    SR_TRY(ws.io.reset(state_scratch_bytes(n, n_slots) + 256));
+    uint32_t* d_flag = ws.io.take<uint32_t>(1);
+    SR_TRY(hipMemsetAsync(d_flag, 0, 4, st));
+    hipLaunchKernelGGL(state_offsets_check_kernel, dim3(blocks((uint64_t)n + 1)), dim3(256), 0, st, d_code_off, d_slot_first, n, n_slots, code_bytes, d_flag);
+    uint32_t flag = 0;
+    SR_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+    SR_TRY(hipStreamSynchronize(st));
+    if (flag) {
+        err = "state_root_dev: code_off / slot_first not monotone, not starting at 0 or not ending at code_bytes / n_slots";
+        return PHANT_E_INVALID_ARG;
+    }
+    const StateIn in{d_addrs, d_nonces, d_balances, d_code, d_code_off, d_slot_keys, d_slot_vals, d_slot_first, n, n_slots, code_bytes};
+    DevLeaves l;
+    int32_t rc = state_leaves_core(ws, st, in, l, err);
+    if (rc) return rc;
+    rc = trie_forest_dev(ws, st, l.keys, l.key_off, 32ull * n, l.vals, l.val_off, l.val_bytes, n, l.seg, 1, l.root, err);
+    if (rc) return rc;
+    SR_TRY(hipMemcpyAsync(d_root, l.root, 32, hipMemcpyDeviceToDevice, st));
+    return PHANT_OK;
+}
+
+// One device's share of a SHARDED state root (comm.hip): its accounts -> leaves (device-resident) -> the sixteen sub-tries by
+// top nibble as ONE forest pass -> per nibble the sub-trie's root and the RLP of its root node.  Only those (16 x (32 + cap +
+// 4) bytes) come back; the leaves never leave the device.  enc_len[x] == 0: no account of this share under nibble x.
+int32_t state_subtrie_nodes_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
+                                 const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys, const uint8_t* slot_vals,
+                                 const uint32_t* slot_first, uint32_t n, uint8_t* roots, uint8_t* enc, uint32_t cap, uint32_t* enc_len,
+                                 std::string& err) {
+    std::memset(enc_len, 0, 16 * sizeof(uint32_t));
+    if (n == 0) return PHANT_OK;
+    DevLeaves l;
+    int32_t rc = state_leaves_dev(ws, st, addrs, nonces, balances, code, code_off, slot_keys, slot_vals, slot_first, n, l, err);
+    if (rc) return rc;
+    if (cap > 256u) {
+        err = "state_subtrie_nodes: cap > 256";
+        return PHANT_E_INVALID_ARG;
+    }
+    hipLaunchKernelGGL(nibble_segments_kernel, dim3(1), dim3(64), 0, st, l.keys, n, l.seg);
+    uint8_t* d_out = ws.io.take<uint8_t>(16u * (36u + cap) + 64u);  // (inside the slack state_scratch_bytes leaves)
+    return trie_forest_nodes_dev(ws, st, l.keys, l.key_off, 32ull * n, l.vals, l.val_off, l.val_bytes, n, l.seg, 16, d_out, roots, enc, cap,
+                                 enc_len, err);
 }
 
 int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces,

@@ -28,6 +28,14 @@ int32_t trie_forest_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, c
                         const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n,
                         const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_roots, std::string& err);
 
+// ... and with every trie's root NODE (RLP, root_enc_cap bytes each; root_enc_len_out 0 for an empty trie); these small
+// results are delivered to HOST buffers (the call synchronises); d_out: n_tries x (36 + root_enc_cap) + 64 bytes of device
+// memory (4-byte aligned) they pass through
+int32_t trie_forest_nodes_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
+                              const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n,
+                              const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_out, uint8_t* roots_out, uint8_t* root_enc_out,
+                              uint32_t root_enc_cap, uint32_t* root_enc_len_out, std::string& err);
+
 // A forest of independent tries in one pass: trie t owns keys
 // [seg_first[t], seg_first[t+1]); roots_out = n_tries x 32 bytes.
 int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, const uint32_t* key_off,
@@ -53,6 +61,20 @@ int32_t state_root_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, co
                         const uint8_t* balances, const uint8_t* code, const uint64_t* code_off,
                         const uint8_t* slot_keys, const uint8_t* slot_vals,
                         const uint32_t* slot_first, uint32_t n, uint8_t out[32], std::string& err);
+
+// the same over DEVICE-resident struct-of-arrays (offsets relative: code_off[0] == 0, slot_first[0] == 0; code_bytes and
+// n_slots given by the caller who packed them), the root written to device memory
+int32_t state_root_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_addrs, const uint64_t* d_nonces, const uint8_t* d_balances,
+                       const uint8_t* d_code, const uint64_t* d_code_off, uint64_t code_bytes, const uint8_t* d_slot_keys,
+                       const uint8_t* d_slot_vals, const uint32_t* d_slot_first, uint32_t n_slots, uint32_t n, uint8_t* d_root,
+                       std::string& err);
+
+// one device's share of a sharded state root: its accounts' sub-tries by the top nibble of the hashed address -- roots
+// (16 x 32), root nodes (16 x cap) and their lengths (0: no account there); the leaves stay on the device
+int32_t state_subtrie_nodes_host(Workspaces& ws, hipStream_t st, const uint8_t* addrs, const uint64_t* nonces, const uint8_t* balances,
+                                 const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys, const uint8_t* slot_vals,
+                                 const uint32_t* slot_first, uint32_t n, uint8_t* roots, uint8_t* enc, uint32_t cap, uint32_t* enc_len,
+                                 std::string& err);
 
 // the sorted leaves of that trie (keys n x 32 = keccak256(address) ascending, values = account RLP, val_off
 // n + 1), storage roots included: what a rank of a sharded state root feeds to the top-nibble exchange

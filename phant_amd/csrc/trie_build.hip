@@ -865,6 +865,32 @@ int32_t trie_forest_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, c
     return rc;
 }
 
+// the forest pass over device-resident arrays that also delivers every trie's root NODE; results to HOST buffers (small)
+int32_t trie_forest_nodes_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
+                              const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n,
+                              const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_out, uint8_t* roots_out, uint8_t* root_enc_out,
+                              uint32_t root_enc_cap, uint32_t* root_enc_len_out, std::string& err) {
+    // d_out: n_tries x (32 + root_enc_cap + 4) + 64 bytes of device memory from the caller, 4-byte aligned
+    uint8_t* d_roots = d_out;
+    uint8_t* d_enc = d_out + (size_t)n_tries * 32;
+    uint32_t* d_len = reinterpret_cast<uint32_t*>(d_out + ((size_t)n_tries * 32 + (size_t)n_tries * root_enc_cap + 3) / 4 * 4);
+    TB_TRY(hipMemsetAsync(d_len, 0, (size_t)n_tries * 4, st));  // (an empty trie has no root node: nobody writes its length)
+    int32_t rc = forest_device(ws, st, d_keys, d_key_off, d_vals, d_val_off, n, key_bytes, val_bytes, d_seg_first, n_tries, d_roots, err,
+                               d_enc, d_len, root_enc_cap);
+    hipError_t e = hipSuccess;
+    if (rc == PHANT_OK) {
+        e = hipMemcpyAsync(roots_out, d_roots, (size_t)n_tries * 32, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(root_enc_out, d_enc, (size_t)n_tries * root_enc_cap, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(root_enc_len_out, d_len, (size_t)n_tries * 4, hipMemcpyDeviceToHost, st);
+    }
+    (void)hipStreamSynchronize(st);
+    if (rc == PHANT_OK && e != hipSuccess) {
+        err = std::string("trie_forest_nodes_dev: ") + hipGetErrorString(e);
+        rc = PHANT_E_DEVICE;
+    }
+    return rc;
+}
+
 int32_t trie_root_dev(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off, uint64_t key_bytes,
                       const uint8_t* d_vals, const uint64_t* d_val_off, uint64_t val_bytes, uint32_t n, uint8_t* d_root,
                       std::string& err) {

@@ -57,6 +57,45 @@ def state_root(accounts, ctx: Context | None = None) -> bytes:
     return out.tobytes()
 
 
+def state_root_dev(accounts, ctx: Context | None = None, out=None):
+    """The same with the state resident in HBM (phant_state_root_dev): the struct-of-arrays is put on the ctx's device once
+    (what a node that keeps its StateDB there has anyway) and nothing of it crosses the bus during the call; the root is a
+    device tensor.  `accounts` may also be the tuple of device tensors soa_dev() returned."""
+    import torch
+    ctx = ctx or default_context()
+    n, t = accounts if isinstance(accounts, tuple) and len(accounts) == 2 and isinstance(accounts[0], int) else soa_dev(accounts, ctx)
+    addrs, nonces, bal, code, code_off, skb, svb, fi, code_bytes, n_slots = t
+    if out is None:
+        out = torch.empty(32, dtype=torch.uint8, device=addrs.device)
+    ctx.check(ctx._lib.phant_state_root_dev(ctx.handle, addrs.data_ptr(), nonces.data_ptr(), bal.data_ptr(), code.data_ptr(),
+                                            code_off.data_ptr(), code_bytes, skb.data_ptr(), svb.data_ptr(), fi.data_ptr(), n_slots, n,
+                                            out.data_ptr()))
+    return out
+
+
+def soa_dev(accounts, ctx: Context | None = None):
+    """AccountState list -> (n, device tensors + the two byte / slot totals): the arguments of phant_state_root_dev."""
+    import torch
+    ctx = ctx or default_context()
+    n, (addrs, nonces, bal, code, code_off, skb, svb, fi) = _soa(accounts)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda(ctx.device)  # noqa: E731
+    return n, (up(addrs), up(nonces), up(bal), up(code), up(code_off), up(skb), up(svb), up(fi), int(code_off[-1]) if n else 0,
+               int(fi[-1]) if n else 0)
+
+
+def state_subtrie_nodes(accounts, ctx: Context | None = None, cap: int = 200):
+    """One rank's share of a sharded state root (phant_state_subtrie_nodes): {top nibble x: (sub-trie root, RLP of its root
+    node)} for the nibbles this account list has keys under; the leaves never leave the device."""
+    ctx = ctx or default_context()
+    n, arrays = _soa(accounts)
+    roots = np.zeros((16, 32), np.uint8)
+    enc = np.zeros((16, cap), np.uint8)
+    ln = np.zeros(16, np.uint32)
+    ctx.check(ctx._lib.phant_state_subtrie_nodes(ctx.handle, *[_np_ptr(a) for a in arrays], n, _np_ptr(roots), _np_ptr(enc), cap,
+                                                 _np_ptr(ln)))
+    return {x: (roots[x].tobytes(), enc[x, :int(ln[x])].tobytes()) for x in range(16) if ln[x]}
+
+
 def state_trie_leaves(accounts, ctx: Context | None = None):
     """The leaves of the state trie of `accounts` (phant_state_trie_leaves): -> (keys, vals), two lists of
     bytes, keys = keccak256(address) ascending, vals = rlp([nonce, balance, storageRoot, codeHash])."""

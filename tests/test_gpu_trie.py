@@ -283,6 +283,55 @@ def test_state_root_edge_cases(P, oracle):
     assert rc != L.OK
 
 
+def test_state_root_device_form_and_subtrie_nodes(P, oracle):
+    """phant_state_root_dev: the struct-of-arrays resident in HBM, root out in HBM -- the reference's fixture state roots, random
+    states, the edge cases above, no accounts; offsets that lie are refused.  phant_state_subtrie_nodes: a share's sixteen
+    sub-tries by top nibble without the leaves leaving the device = what phant_state_trie_leaves + phant_mpt_root_nodes give
+    through host memory."""
+    import torch
+    from phant_amd import _lib as L, shard
+    fx = golden.fixtures()
+    cases = sorted(fx["cases"], key=lambda c: -len(c["pre"]))
+    for c in cases[:5] + cases[-5:]:
+        acc = golden.accounts_of(c["pre"], fx["codes"])
+        got = P.state.state_root_dev(acc)
+        torch.cuda.synchronize()
+        assert bytes(got.cpu().numpy().tobytes()).hex() == c["genesis_state_root"], c["name"]
+    rng = np.random.default_rng(77)
+    acc = []
+    for _ in range(900):
+        st = {int(rng.integers(0, 2 ** 62)): int(rng.integers(0, 3)) * int(rng.integers(1, 2 ** 62)) for _ in range(int(rng.integers(0, 6)))}
+        acc.append(dict(addr=rng.integers(0, 256, 20, dtype=np.uint8).tobytes(), nonce=int(rng.integers(0, 1000)),
+                        balance=int(rng.integers(0, 2 ** 62)) ** 2,
+                        code=rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8).tobytes(), storage=st))
+    for part in (acc, acc[:1], acc[:2], []):
+        got = P.state.state_root_dev(part)
+        torch.cuda.synchronize()
+        assert bytes(got.cpu().numpy().tobytes()) == oracle.state_root(part), len(part)
+    # offsets only the device can see in this form
+    n, t = P.state.soa_dev(acc[:50])
+    for which in (4, 7):  # code_off, slot_first
+        bad = list(t)
+        raw = bad[which].clone()
+        words = raw.view(torch.int64 if which == 4 else torch.int32)
+        words[3] = words[5] + 1
+        bad[which] = raw
+        with pytest.raises(L.PhantError) as e:
+            P.state.state_root_dev((n, tuple(bad)))
+        assert e.value.code == L.E_INVALID_ARG
+    with pytest.raises(L.PhantError):
+        P.state.state_root_dev((n, tuple(list(t[:9]) + [t[9] + 1])))   # n_slots is not slot_first[n]
+    # a share's sub-tries, device-resident, against the same through host memory
+    nodes = P.state.state_subtrie_nodes(acc)
+    keys, vals = P.state.state_trie_leaves(acc)
+    first = [next((i for i, k in enumerate(keys) if (k[0] >> 4) >= x), len(keys)) for x in range(17)]
+    want = shard.gpu_root_nodes(keys, vals, first)
+    assert set(nodes) == {x for x in range(16) if first[x + 1] > first[x]}
+    for x, (root, enc) in nodes.items():
+        assert (root, enc) == want[x], x
+    assert P.state.state_subtrie_nodes([]) == {}
+
+
 def test_sharded_mptize_matches_the_single_gpu_root(oracle):
     """phant_mpt_root_nodes (forest pass with root-node RLP out) + strip + top-nibble exchange, world sizes
     1..8 played back in one process on one GPU, against mptize on the GPU and on the oracle."""

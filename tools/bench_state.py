@@ -43,5 +43,24 @@ for _ in range(args.reps + 1):
     t0 = time.perf_counter()
     ctx.check(ctx._lib.phant_state_root(ctx.handle, *[_np_ptr(a) for a in arrays], n, _np_ptr(out)))
     best = min(best, time.perf_counter() - t0)
-print(json.dumps({"workload": f"state root of {n} accounts x {k} live slots", "repo": args.repo, "seconds": round(best, 4),
-                  "leaves_per_s": round(n * (k + 1) / best), "root": out.tobytes().hex()}))
+line = {"workload": f"state root of {n} accounts x {k} live slots", "repo": args.repo, "seconds": round(best, 4),
+        "leaves_per_s": round(n * (k + 1) / best), "root": out.tobytes().hex()}
+if hasattr(ctx._lib, "phant_state_root_dev"):
+    # the device-resident form: the struct-of-arrays already in HBM, the root left there
+    import torch  # noqa: E402
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
+    d = [up(a) for a in arrays]
+    d_root = torch.empty(32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    best_dev = 1e9
+    for _ in range(args.reps + 1):
+        t0 = time.perf_counter()
+        ctx.check(ctx._lib.phant_state_root_dev(ctx.handle, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                                d[4].data_ptr(), 0, d[5].data_ptr(), d[6].data_ptr(), d[7].data_ptr(), n * k, n,
+                                                d_root.data_ptr()))
+        torch.cuda.synchronize()
+        best_dev = min(best_dev, time.perf_counter() - t0)
+    line["device_form_seconds"] = round(best_dev, 4)
+    line["device_form_leaves_per_s"] = round(n * (k + 1) / best_dev)
+    line["device_form_root_matches"] = bytes(d_root.cpu().numpy().tobytes()) == out.tobytes()
+print(json.dumps(line))
