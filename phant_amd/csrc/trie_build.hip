@@ -23,6 +23,7 @@
 #include "trie_build.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -93,10 +94,8 @@ __global__ void __launch_bounds__(256) first_flag_kernel(TrieDev t) {
     }
 }
 
-// lcp + strict-order check (mpt.zig:39 asserts sorted; distinct keys assumed)
-__global__ void __launch_bounds__(256) lcp_kernel(TrieDev t) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i > t.n) return;
+// lcp + strict-order check (mpt.zig:39 asserts sorted; distinct keys assumed), element i <= n
+PHANT_DEV void lcp_element(const TrieDev& t, const uint32_t i) {
     int32_t v = -1;
     // The device-resident form cannot look at the offsets on the host: a key longer than 255 bytes, or offsets that go
     // backwards (the difference wraps), would index the depth counters of the kernels behind this one out of bounds.  Such a
@@ -131,6 +130,10 @@ __global__ void __launch_bounds__(256) lcp_kernel(TrieDev t) {
     t.lcp[i] = v;
     t.tree[t.M + i] = v;
 }
+__global__ void __launch_bounds__(256) lcp_kernel(TrieDev t) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i <= t.n) lcp_element(t, i);
+}
 
 __global__ void __launch_bounds__(256) tree_pad_kernel(TrieDev t) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x + t.n + 1;
@@ -144,6 +147,33 @@ __global__ void __launch_bounds__(256) tree_level_kernel(int32_t* tree, uint32_t
         const int32_t a = tree[2 * v], b = tree[2 * v + 1];
         tree[v] = a < b ? a : b;
     }
+}
+
+// the levels of w <= 256 nodes in ONE launch (a workgroup barrier between them instead of a kernel boundary: up to nine
+// launches of a few lanes each at the head of every call)
+__global__ void __launch_bounds__(256) tree_top_kernel(int32_t* tree, uint32_t w_first) {
+    for (uint32_t w = w_first; w >= 1u; w >>= 1) {
+        const uint32_t k = threadIdx.x;
+        if (k < w) {
+            const uint32_t v = w + k;
+            const int32_t a = tree[2 * v], b = tree[2 * v + 1];
+            tree[v] = a < b ? a : b;
+        }
+        __syncthreads();
+    }
+}
+
+// what six hipMemsetAsync calls did at the head of every call: flags, markers and counters of the passes below
+__global__ void __launch_bounds__(256) trie_init_kernel(TrieDev t) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i <= t.n) {
+        t.first_flag[i] = 0;
+        t.value_key[i] = NONE;
+        t.dense[i] = NONE;
+    }
+    if (i < 8u + (uint32_t)MAX_DEPTH_BINS) t.counters[i] = 0u;
+    if (i < (uint32_t)MAX_DEPTH_BINS) t.depth_cursor[i] = 0u;
+    if (i == 0) *t.cursor = 0ull;
 }
 
 // largest j < i with lcp[j] < thr (exists: lcp[0] = -1 and thr >= 0)
@@ -180,23 +210,11 @@ PHANT_DEV uint32_t rep_of(const TrieDev& t, uint32_t x, int32_t lcp_x, int32_t p
     return next_less(t, PL, pd + 1);
 }
 
-// Workgroups of 1 024 lanes for the two kernels that count into a handful of global counters: atomics on one address
-// are served one at a time (~12 ns each, tools/ubench/atomic_rate.hip) whether they return a value or not, and a
-// million keys have their ~335 k branch nodes on three or four depths -- one atomic per WAVE and depth was 47 000
-// of them (0.55 ms in each of the two kernels); the counting now happens in LDS, one global atomic per WORKGROUP
-// and depth.
-constexpr uint32_t COUNT_BLOCK = 1024;
-
-__global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
-    __shared__ uint32_t s_hist[MAX_DEPTH_BINS];
-    __shared__ uint32_t s_wave_reps[COUNT_BLOCK / 64];
-    __shared__ uint32_t s_dense_base;
-    const uint32_t i = blockIdx.x * COUNT_BLOCK + threadIdx.x;
-    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK) s_hist[b] = 0u;
-    __syncthreads();
-    const bool in = i < t.n;
+// Key i as a leaf (or a branch value), boundary i as a branch node: -> is boundary i the representative of a branch node
+// (of depth d)?
+PHANT_DEV bool identify_element(const TrieDev& t, const uint32_t i, int32_t& d) {
     // --- key i as a leaf (or a branch value) ---
-    if (in) {
+    {
         const int32_t dl = t.lcp[i], dr = t.lcp[i + 1];
         const int32_t di = dl > dr ? dl : dr;
         if (di < 0) {
@@ -214,10 +232,8 @@ __global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
         }
     }
     // --- boundary i as a branch node ---
-    uint32_t dn = NONE;
-    bool is_rep = false;
-    const int32_t d = in ? t.lcp[i] : -1;
-    if (in && i >= 1 && d >= 0) {
+    d = t.lcp[i];
+    if (i >= 1 && d >= 0) {
         const uint32_t p = prev_less(t, i, d + 1);
         if (t.lcp[p] < d) {  // leftmost boundary of value d in its interval
             const uint32_t l = p;
@@ -227,9 +243,30 @@ __global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
             t.nd_l[i] = l;
             t.nd_pd[i] = pd;
             t.nd_parent[i] = pd < 0 ? NONE : rep_of(t, l, pl, pd);
-            is_rep = true;
+            return true;
         }
     }
+    return false;
+}
+
+// Workgroups of 1 024 lanes for the two kernels that count into a handful of global counters: atomics on one address
+// are served one at a time (~12 ns each, tools/ubench/atomic_rate.hip) whether they return a value or not, and a
+// million keys have their ~335 k branch nodes on three or four depths -- one atomic per WAVE and depth was 47 000
+// of them (0.55 ms in each of the two kernels); the counting now happens in LDS, one global atomic per WORKGROUP
+// and depth.
+constexpr uint32_t COUNT_BLOCK = 1024;
+
+__global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
+    __shared__ uint32_t s_hist[MAX_DEPTH_BINS];
+    __shared__ uint32_t s_wave_reps[COUNT_BLOCK / 64];
+    __shared__ uint32_t s_dense_base;
+    const uint32_t i = blockIdx.x * COUNT_BLOCK + threadIdx.x;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK) s_hist[b] = 0u;
+    __syncthreads();
+    const bool in = i < t.n;
+    uint32_t dn = NONE;
+    int32_t d = -1;
+    const bool is_rep = in && identify_element(t, i, d);
     // dense ids: ranks inside the workgroup (ballot + the waves' totals in LDS), one global reservation; the
     // per-depth histogram: LDS counters, one global add per depth the workgroup met
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -301,7 +338,21 @@ PHANT_DEV uint8_t* put_hdr(uint8_t* w, uint64_t len, uint32_t short_base, uint32
 }
 PHANT_DEV uint8_t* put_str(uint8_t* w, const uint8_t* s, uint64_t len) {
     if (!(len == 1 && s[0] < 0x80u)) w = put_hdr(w, len, 0x80u, 0xb7u);
-    for (uint64_t k = 0; k < len; ++k) w[k] = s[k];
+    // the payload: byte by byte up to a 4-byte boundary of the source, then a dword per load (a transaction or a receipt is
+    // hundreds of bytes: one load instruction per byte was most of the leaf kernel for such items), never beyond s + len
+    uint64_t k = 0;
+    while (k < len && ((uintptr_t)(s + k) & 3u)) {
+        w[k] = s[k];
+        ++k;
+    }
+    for (; k + 4 <= len; k += 4) {
+        const uint32_t q = *reinterpret_cast<const uint32_t*>(s + k);
+        w[k] = (uint8_t)q;
+        w[k + 1] = (uint8_t)(q >> 8);
+        w[k + 2] = (uint8_t)(q >> 16);
+        w[k + 3] = (uint8_t)(q >> 24);
+    }
+    for (; k < len; ++k) w[k] = s[k];
     return w + len;
 }
 
@@ -421,51 +472,78 @@ PHANT_DEV void deliver(const TrieDev& t, uint32_t parent, uint32_t nib, uint32_t
     }
 }
 
-// LeafNode, mpt.zig:54-56 / :254-261
-__global__ void __launch_bounds__(256) leaf_kernel(TrieDev t) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool live = i < t.n && t.leaf_ps[i] != BRANCH_VALUE;
-    uint32_t ps = 0, nl = 0, total = 0;
-    uint64_t vlen = 0, payload = 0;
-    const uint8_t* v = nullptr;
-    if (live) {
-        ps = t.leaf_ps[i];
-        nl = nib_len(t, i);
-        v = t.vals + t.val_off[i];
-        vlen = t.val_off[i + 1] - t.val_off[i];
-        payload = hp_rlp_size(nl - ps) + rlp_str_size(vlen, vlen ? v[0] : 0u);
-        total = (uint32_t)(rlp_list_hdr_size(payload) + payload);
+constexpr uint32_t BRANCH_STAGE_BYTES_ = 4u * RATE;        // (= BRANCH_STAGE_BYTES below)
+constexpr uint32_t BRANCH_STAGE_DW_ = 4u * RATE_DWORDS + 1u;  // (= BRANCH_STAGE_DW below)
+
+// LeafNode, mpt.zig:54-56 / :254-261: what key i's leaf looks like ...
+struct LeafPlan {
+    bool live;
+    uint32_t ps, nl, total;
+    uint64_t vlen, payload;
+    const uint8_t* v;
+};
+constexpr uint32_t LEAF_STAGE_DW = RATE_DWORDS + 1u;  // 35 (odd): one rate block of LDS per lane (a state-trie leaf is ~112 bytes)
+PHANT_DEV LeafPlan leaf_plan(const TrieDev& t, const uint32_t i) {
+    LeafPlan p;
+    p.live = i < t.n && t.leaf_ps[i] != BRANCH_VALUE;
+    p.ps = p.nl = p.total = 0;
+    p.vlen = p.payload = 0;
+    p.v = nullptr;
+    if (p.live) {
+        p.ps = t.leaf_ps[i];
+        p.nl = nib_len(t, i);
+        p.v = t.vals + t.val_off[i];
+        p.vlen = t.val_off[i + 1] - t.val_off[i];
+        p.payload = hp_rlp_size(p.nl - p.ps) + rlp_str_size(p.vlen, p.vlen ? p.v[0] : 0u);
+        p.total = (uint32_t)(rlp_list_hdr_size(p.payload) + p.payload);
     }
-    // one rate block of LDS per lane (a state-trie leaf is ~112 bytes); longer leaves go through the scratch blob
-    constexpr uint32_t STAGE_DW = RATE_DWORDS + 1u;  // 35: odd
-    __shared__ uint32_t s_stage[256 * STAGE_DW];
-    const bool staged = live && total < RATE;
-    const unsigned long long at = wave_alloc(t.cursor, (live && !staged) ? ((total + 3u) & ~3u) : 0u);
-    if (!live) return;
+    return p;
+}
+// ... built in the lane's LDS slot (STAGE_DW dwords: LEAF_STAGE_DW for total < RATE, four rate blocks for total <
+// LEAF_BIG_MAX), hashed from there, delivered
+template <uint32_t STAGE_DW>
+PHANT_DEV void leaf_emit_staged(const TrieDev& t, const uint32_t i, const LeafPlan& p, uint32_t* slot) {
     const uint32_t parent = t.leaf_parent[i];
-    const bool hashed = total >= 32u || parent == NONE;
+    const bool hashed = p.total >= 32u || parent == NONE;
     Sponge s;
-    if (staged) {
-        uint32_t* slot = s_stage + threadIdx.x * STAGE_DW;
-        stage_clear<STAGE_DW>(slot);
-        uint8_t* enc = reinterpret_cast<uint8_t*>(slot);
-        uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
-        w = put_hp(w, t, i, ps, nl, true);
-        w = put_str(w, v, vlen);
-        if (hashed) keccak256_staged(s, slot, total);
-        deliver(t, parent, ps ? nib_at(t, i, ps - 1) : 0u, i, enc, total, s, hashed);
-        return;
-    }
-    if (at + total > t.scratch_cap) {
+    stage_clear<STAGE_DW>(slot);
+    uint8_t* enc = reinterpret_cast<uint8_t*>(slot);
+    uint8_t* w = put_hdr(enc, p.payload, 0xc0u, 0xf7u);
+    w = put_hp(w, t, i, p.ps, p.nl, true);
+    w = put_str(w, p.v, p.vlen);
+    if (hashed) keccak256_staged(s, slot, p.total);
+    deliver(t, parent, p.ps ? nib_at(t, i, p.ps - 1) : 0u, i, enc, p.total, s, hashed);
+}
+// ... or, too long for the slot, at byte `at` of the scratch blob
+PHANT_DEV void leaf_emit_scratch(const TrieDev& t, const uint32_t i, const LeafPlan& p, const unsigned long long at) {
+    if (at + p.total > t.scratch_cap) {
         atomicOr(&t.counters[2], 1u);
         return;
     }
+    const uint32_t parent = t.leaf_parent[i];
+    const bool hashed = p.total >= 32u || parent == NONE;
+    Sponge s;
     uint8_t* enc = t.scratch + at;
-    uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
-    w = put_hp(w, t, i, ps, nl, true);
-    w = put_str(w, v, vlen);
-    if (hashed) keccak256_global(s, enc, total);
-    deliver(t, parent, ps ? nib_at(t, i, ps - 1) : 0u, i, enc, total, s, hashed);
+    uint8_t* w = put_hdr(enc, p.payload, 0xc0u, 0xf7u);
+    w = put_hp(w, t, i, p.ps, p.nl, true);
+    w = put_str(w, p.v, p.vlen);
+    if (hashed) keccak256_global(s, enc, p.total);
+    deliver(t, parent, p.ps ? nib_at(t, i, p.ps - 1) : 0u, i, enc, p.total, s, hashed);
+}
+
+// Three size classes: under one rate block (a state-trie leaf: 256 lanes per workgroup, 35 dwords of LDS each), under four
+// (a transaction, a receipt: leaf_big_kernel, 64 lanes per workgroup with the branch kernel's 137-dword slots), the rest
+// through the scratch blob (byte stores to global memory: slow, rare).
+constexpr uint32_t LEAF_BIG_MAX = BRANCH_STAGE_BYTES_;  // 4 x 136: the padding needs a byte
+__global__ void __launch_bounds__(256) leaf_kernel(TrieDev t) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const LeafPlan p = leaf_plan(t, i);
+    __shared__ uint32_t s_stage[256 * LEAF_STAGE_DW];
+    const bool staged = p.live && p.total < RATE;
+    const bool scratch = p.live && p.total >= LEAF_BIG_MAX;
+    const unsigned long long at = wave_alloc(t.cursor, scratch ? ((p.total + 3u) & ~3u) : 0u);
+    if (staged) leaf_emit_staged<LEAF_STAGE_DW>(t, i, p, s_stage + threadIdx.x * LEAF_STAGE_DW);
+    else if (scratch) leaf_emit_scratch(t, i, p, at);
 }
 
 // BranchNode (mpt.zig:216-231) at nibble depth d, plus the ExtensionNode above
@@ -530,103 +608,127 @@ constexpr uint32_t BRANCH_STAGE_BLOCKS = 4;
 constexpr uint32_t BRANCH_STAGE_DW = BRANCH_STAGE_BLOCKS * RATE_DWORDS + 1u;  // 137: odd
 constexpr uint32_t BRANCH_STAGE_BYTES = BRANCH_STAGE_BLOCKS * RATE;
 
+// what the branch node with representative boundary order[at] looks like (live: there is one)
+struct BranchPlan {
+    bool live, staged;
+    uint32_t i, dn, total, ext_len, l, ext_cap, need;
+    uint64_t payload, vlen;
+    const uint8_t* v;
+    int32_t d, pd;
+};
+PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t at, const bool live) {
+    BranchPlan p;
+    p.live = live;
+    p.i = p.dn = p.total = 0;
+    p.payload = p.vlen = 0;
+    p.v = nullptr;
+    if (live) {
+        p.i = t.order[at];
+        p.dn = t.dense[p.i];
+        // the 16 slot lengths: one aligned 16-byte load
+        const uint4 sl4 = *reinterpret_cast<const uint4*>(t.slot_len + (uint64_t)p.dn * 16u);
+        const uint32_t slw[4] = {sl4.x, sl4.y, sl4.z, sl4.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t sl = (slw[k >> 2] >> (8u * (k & 3u))) & 0xffu;
+            p.payload += sl == 0 ? 1u : (sl == 32u ? 33u : sl);
+        }
+        const uint32_t vk = t.value_key[p.i];
+        if (vk != NONE) {
+            p.v = t.vals + t.val_off[vk];
+            p.vlen = t.val_off[vk + 1] - t.val_off[vk];
+        }
+        p.payload += rlp_str_size(p.vlen, p.vlen ? p.v[0] : 0u);
+        p.total = (uint32_t)(rlp_list_hdr_size(p.payload) + p.payload);
+    }
+    p.d = live ? t.lcp[p.i] : 0;
+    p.pd = live ? t.nd_pd[p.i] : 0;
+    p.ext_len = live ? (uint32_t)(p.d - (p.pd + 1)) : 0u;
+    p.l = live ? t.nd_l[p.i] : 0u;
+    // extension size bound: list hdr (<=3) + HP string (<= 2 + ext_len/2 + 1) + ref (<= 33)
+    p.ext_cap = (live && p.ext_len) ? (40u + p.ext_len / 2u + 4u) : 0u;
+    // staged in LDS when the branch leaves room for the padding in its four blocks and the extension fits two
+    p.staged = live && p.payload < BRANCH_STAGE_BYTES - 8u && p.total < BRANCH_STAGE_BYTES && p.ext_cap < 2u * RATE;
+    // the others reserve room in the scratch blob
+    p.need = (live && !p.staged) ? (((p.total + 3u) & ~3u) + ((p.ext_cap + 3u) & ~3u)) : 0u;
+    return p;
+}
+// built in the lane's LDS slot (BRANCH_STAGE_DW dwords) / at byte `at` of the scratch blob, hashed, the extension above it
+// likewise, delivered to the parent's slot table
+PHANT_DEV void branch_emit(const TrieDev& t, const BranchPlan& p, uint32_t* slot, const unsigned long long at) {
+    const uint32_t parent = t.nd_parent[p.i];
+    const bool is_root = parent == NONE;
+    bool hashed = p.total >= 32u || (is_root && p.ext_len == 0);
+    Sponge s;
+    sponge_zero(s);
+    if (p.staged) {
+        stage_clear<BRANCH_STAGE_DW>(slot);
+        uint8_t* enc = reinterpret_cast<uint8_t*>(slot);
+        (void)put_branch(enc, t, p.dn, p.payload, p.v, p.vlen);
+        if (hashed) keccak256_staged(s, slot, p.total);
+        uint32_t out_len = p.total;
+        if (p.ext_len) {
+            // the extension gets a clean region: behind an embedded branch (shorter than 32 bytes), or the
+            // whole slot again once the branch is a digest in registers
+            uint32_t* xslot = slot + 2u * RATE_DWORDS;
+            if (hashed) {
+                stage_clear<BRANCH_STAGE_DW>(slot);
+                xslot = slot;
+            }
+            uint8_t* xenc = reinterpret_cast<uint8_t*>(xslot);
+            out_len = put_extension(xenc, t, p.l, (uint32_t)(p.pd + 1), (uint32_t)p.d, hashed, s, enc, p.total);
+            enc = xenc;
+            hashed = out_len >= 32u || is_root;
+            if (hashed) keccak256_staged(s, xslot, out_len);
+        }
+        deliver(t, parent, is_root ? 0u : nib_at(t, p.l, (uint32_t)p.pd), p.l, enc, out_len, s, hashed);
+        return;
+    }
+    if (at + p.total + p.ext_cap + 8 > t.scratch_cap) {
+        atomicOr(&t.counters[2], 1u);
+        return;
+    }
+    uint8_t* enc = t.scratch + at;
+    (void)put_branch(enc, t, p.dn, p.payload, p.v, p.vlen);
+    if (hashed) keccak256_global(s, enc, p.total);
+    uint32_t out_len = p.total;
+    if (p.ext_len) {
+        uint8_t* xenc = enc + ((p.total + 3u) & ~3u);
+        out_len = put_extension(xenc, t, p.l, (uint32_t)(p.pd + 1), (uint32_t)p.d, hashed, s, enc, p.total);
+        enc = xenc;
+        hashed = out_len >= 32u || is_root;
+        if (hashed) keccak256_global(s, enc, out_len);
+    }
+    deliver(t, parent, is_root ? 0u : nib_at(t, p.l, (uint32_t)p.pd), p.l, enc, out_len, s, hashed);
+}
+
 __global__ void __launch_bounds__(BRANCH_LANES) branch_kernel(TrieDev t, uint32_t begin, uint32_t count) {
     __shared__ uint32_t s_stage[BRANCH_LANES * BRANCH_STAGE_DW];
     __shared__ uint32_t s_total;
     __shared__ unsigned long long s_base;
     const uint32_t q = blockIdx.x * BRANCH_LANES + threadIdx.x;
-    const bool live = q < count;
-    uint32_t i = 0, dn = 0, total = 0, vk = NONE;
-    uint64_t payload = 0, vlen = 0;
-    const uint8_t* v = nullptr;
-    if (live) {
-        i = t.order[begin + q];
-        dn = t.dense[i];
-        // the 16 slot lengths: one aligned 16-byte load
-        const uint4 sl4 = *reinterpret_cast<const uint4*>(t.slot_len + (uint64_t)dn * 16u);
-        const uint32_t slw[4] = {sl4.x, sl4.y, sl4.z, sl4.w};
+    const BranchPlan p = branch_plan(t, begin + q, q < count);
+    // room in the scratch blob for the nodes that do not fit their slot: one reservation per workgroup (= wave)
+    uint32_t incl = p.need;
 #pragma unroll
-        for (uint32_t k = 0; k < 16; ++k) {
-            const uint32_t sl = (slw[k >> 2] >> (8u * (k & 3u))) & 0xffu;
-            payload += sl == 0 ? 1u : (sl == 32u ? 33u : sl);
-        }
-        vk = t.value_key[i];
-        if (vk != NONE) {
-            v = t.vals + t.val_off[vk];
-            vlen = t.val_off[vk + 1] - t.val_off[vk];
-        }
-        payload += rlp_str_size(vlen, vlen ? v[0] : 0u);
-        total = (uint32_t)(rlp_list_hdr_size(payload) + payload);
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if ((threadIdx.x & 63u) >= (uint32_t)o) incl += up;
     }
-    const int32_t d = live ? t.lcp[i] : 0;
-    const int32_t pd = live ? t.nd_pd[i] : 0;
-    const uint32_t ext_len = live ? (uint32_t)(d - (pd + 1)) : 0u;
-    const uint32_t l = live ? t.nd_l[i] : 0u;
-    // extension size bound: list hdr (<=3) + HP string (<= 2 + ext_len/2 + 1) + ref (<= 33)
-    const uint32_t ext_cap = (live && ext_len) ? (40u + ext_len / 2u + 4u) : 0u;
-    // staged in LDS when the branch leaves room for the padding in its four blocks and the extension fits two
-    const bool staged = live && payload < BRANCH_STAGE_BYTES - 8u && total < BRANCH_STAGE_BYTES && ext_cap < 2u * RATE;
-    // the others reserve room in the scratch blob: one reservation per workgroup (= wave)
-    {
-        const uint32_t need = (live && !staged) ? (((total + 3u) & ~3u) + ((ext_cap + 3u) & ~3u)) : 0u;
-        uint32_t incl = need;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if ((threadIdx.x & 63u) >= (uint32_t)o) incl += up;
-        }
-        if (threadIdx.x == BRANCH_LANES - 1u) s_total = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) s_base = s_total ? atomicAdd(t.cursor, (unsigned long long)s_total) : 0ull;
-        __syncthreads();
-        if (!live) return;
-        const uint32_t parent = t.nd_parent[i];
-        const bool is_root = parent == NONE;
-        bool hashed = total >= 32u || (is_root && ext_len == 0);
-        Sponge s;
-        sponge_zero(s);
-        if (staged) {
-            uint32_t* slot = s_stage + threadIdx.x * BRANCH_STAGE_DW;
-            stage_clear<BRANCH_STAGE_DW>(slot);
-            uint8_t* enc = reinterpret_cast<uint8_t*>(slot);
-            (void)put_branch(enc, t, dn, payload, v, vlen);
-            if (hashed) keccak256_staged(s, slot, total);
-            uint32_t out_len = total;
-            if (ext_len) {
-                // the extension gets a clean region: behind an embedded branch (shorter than 32 bytes), or the
-                // whole slot again once the branch is a digest in registers
-                uint32_t* xslot = slot + 2u * RATE_DWORDS;
-                if (hashed) {
-                    stage_clear<BRANCH_STAGE_DW>(slot);
-                    xslot = slot;
-                }
-                uint8_t* xenc = reinterpret_cast<uint8_t*>(xslot);
-                out_len = put_extension(xenc, t, l, (uint32_t)(pd + 1), (uint32_t)d, hashed, s, enc, total);
-                enc = xenc;
-                hashed = out_len >= 32u || is_root;
-                if (hashed) keccak256_staged(s, xslot, out_len);
-            }
-            deliver(t, parent, is_root ? 0u : nib_at(t, l, (uint32_t)pd), l, enc, out_len, s, hashed);
-            return;
-        }
-        const unsigned long long at = s_base + (incl - need);
-        if (at + total + ext_cap + 8 > t.scratch_cap) {
-            atomicOr(&t.counters[2], 1u);
-            return;
-        }
-        uint8_t* enc = t.scratch + at;
-        (void)put_branch(enc, t, dn, payload, v, vlen);
-        if (hashed) keccak256_global(s, enc, total);
-        uint32_t out_len = total;
-        if (ext_len) {
-            uint8_t* xenc = enc + ((total + 3u) & ~3u);
-            out_len = put_extension(xenc, t, l, (uint32_t)(pd + 1), (uint32_t)d, hashed, s, enc, total);
-            enc = xenc;
-            hashed = out_len >= 32u || is_root;
-            if (hashed) keccak256_global(s, enc, out_len);
-        }
-        deliver(t, parent, is_root ? 0u : nib_at(t, l, (uint32_t)pd), l, enc, out_len, s, hashed);
-    }
+    if (threadIdx.x == BRANCH_LANES - 1u) s_total = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_total ? atomicAdd(t.cursor, (unsigned long long)s_total) : 0ull;
+    __syncthreads();
+    if (!p.live) return;
+    branch_emit(t, p, s_stage + threadIdx.x * BRANCH_STAGE_DW, s_base + (incl - p.need));
+}
+
+static_assert(BRANCH_STAGE_BYTES_ == BRANCH_STAGE_BYTES && BRANCH_STAGE_DW_ == BRANCH_STAGE_DW, "one slot size for big leaves and branches");
+__global__ void __launch_bounds__(BRANCH_LANES) leaf_big_kernel(TrieDev t) {
+    __shared__ uint32_t s_stage[BRANCH_LANES * BRANCH_STAGE_DW];
+    const uint32_t i = blockIdx.x * BRANCH_LANES + threadIdx.x;
+    const LeafPlan p = leaf_plan(t, i);
+    if (p.live && p.total >= RATE && p.total < LEAF_BIG_MAX) leaf_emit_staged<BRANCH_STAGE_DW>(t, i, p, s_stage + threadIdx.x * BRANCH_STAGE_DW);
 }
 
 __global__ void __launch_bounds__(256) fill_empty_roots_kernel(uint8_t* roots, uint32_t n_tries) {
@@ -637,6 +739,126 @@ __global__ void __launch_bounds__(256) fill_empty_roots_kernel(uint8_t* roots, u
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n_tries)
         for (int k = 0; k < 32; ++k) roots[32ull * i + k] = E[k];
+}
+
+// ---- small forests: everything in ONE launch ----
+// The passes above are ~30 dependent launches and two counter read-backs: for the tries of an ordinary block (<= a few
+// hundred keys: blockchain.zig:198-204) that overhead is most of the call (0.40 ms for 400 keys, of which the sponges' own
+// latency chain is ~0.12).  Up to SMALL_MAX_KEYS keys the whole construction runs in one workgroup of 256 lanes: the same
+// element functions, the passes separated by workgroup barriers instead of kernel boundaries, the per-depth counters and the
+// dense ids kept in LDS, the branch levels as a loop inside the kernel -- one launch, and one read-back (the error flags)
+// at the end.  LDS: the branch stage of four waves (140 KB; the leaves use its first 35 KB) + 6 KB of counters.
+constexpr uint32_t SMALL_BLOCK = 256;
+constexpr uint32_t SMALL_MAX_KEYS = 256;  // one pass of the workgroup's lanes over the keys: beyond that its passes queue up behind each other
+
+__global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
+    __shared__ uint32_t s_stage[SMALL_BLOCK * BRANCH_STAGE_DW];
+    __shared__ uint32_t s_hist[MAX_DEPTH_BINS], s_begin[MAX_DEPTH_BINS], s_cur[MAX_DEPTH_BINS];
+    __shared__ uint32_t s_wave[SMALL_BLOCK / 64];
+    __shared__ uint32_t s_nrep, s_err;
+    constexpr uint32_t B = SMALL_BLOCK;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n = t.n;
+    // ---- what the launcher's memsets and fill_empty_roots_kernel do for the large form ----
+    for (uint32_t i = tid; i <= n; i += B) {
+        t.first_flag[i] = 0;
+        t.value_key[i] = NONE;
+        t.dense[i] = NONE;
+    }
+    for (uint32_t i = tid; i < 8u + (uint32_t)MAX_DEPTH_BINS; i += B) t.counters[i] = 0u;
+    for (uint32_t b = tid; b < (uint32_t)MAX_DEPTH_BINS; b += B) {
+        s_hist[b] = 0u;
+        s_cur[b] = 0u;
+    }
+    for (uint32_t i = tid; i < n * 4u; i += B) reinterpret_cast<uint32_t*>(t.slot_len)[i] = 0u;  // n x 16 bytes
+    {
+        const uint8_t E[32] = {0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 0xff, 0x83, 0x45, 0xe6, 0x92, 0xc0, 0xf8, 0x6e,
+                               0x5b, 0x48, 0xe0, 0x1b, 0x99, 0x6c, 0xad, 0xc0, 0x01, 0x62, 0x2f, 0xb5, 0xe3, 0x63, 0xb4, 0x21};
+        for (uint32_t i = tid; i < t.n_tries; i += B) {  // mpt.zig:10 empty_mpt_root = keccak256(0x80)
+            for (int k = 0; k < 32; ++k) t.roots[32ull * i + k] = E[k];
+            if (t.root_enc_len) t.root_enc_len[i] = 0u;
+        }
+    }
+    if (tid == 0) {
+        *t.cursor = 0ull;
+        s_nrep = 0u;
+    }
+    __syncthreads();
+    for (uint32_t sg = tid; sg < t.n_tries; sg += B) {
+        const uint32_t f = t.seg_first[sg];
+        if (f <= n) t.first_flag[f] = 1;
+    }
+    __syncthreads();
+    // ---- lcp, min-tree ----
+    for (uint32_t i = tid; i <= n; i += B) lcp_element(t, i);
+    for (uint32_t i = n + 1u + tid; i < t.M; i += B) t.tree[t.M + i] = INF_LCP;
+    __syncthreads();
+    for (uint32_t w = t.M / 2u; w >= 1u; w >>= 1) {
+        for (uint32_t k = tid; k < w; k += B) {
+            const uint32_t v = w + k;
+            const int32_t x = t.tree[2 * v], y = t.tree[2 * v + 1];
+            t.tree[v] = x < y ? x : y;
+        }
+        __syncthreads();
+    }
+    // ---- leaves' parents, branch nodes, their dense ids and the per-depth counts ----
+    for (uint32_t c0 = 0; c0 < n; c0 += B) {
+        const uint32_t i = c0 + tid;
+        int32_t d = -1;
+        const bool is_rep = i < n && identify_element(t, i, d);
+        const unsigned long long reps = __ballot(is_rep);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(reps);
+        if (is_rep) atomicAdd(&s_hist[d], 1u);
+        __syncthreads();
+        if (is_rep) {
+            uint32_t base = s_nrep;
+            for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+            t.dense[i] = base + (uint32_t)__popcll(reps & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (tid == 0) s_nrep += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        s_err = t.counters[1];
+        t.counters[0] = s_nrep;
+        uint32_t acc = 0;
+        for (int b = 0; b < MAX_DEPTH_BINS; ++b) {
+            s_begin[b] = acc;
+            acc += s_hist[b];
+        }
+    }
+    __syncthreads();
+    if (s_err) return;  // (unsorted keys, a key too long: the launcher reads the flags)
+    // ---- the branch nodes grouped by depth ----
+    for (uint32_t c0 = 0; c0 < n; c0 += B) {
+        const uint32_t i = c0 + tid;
+        if (i < n && i != 0u && t.dense[i] != NONE) {
+            const int32_t d = t.lcp[i];
+            t.order[s_begin[d] + atomicAdd(&s_cur[d], 1u)] = i;
+        }
+    }
+    __syncthreads();
+    // ---- leaves ----
+    for (uint32_t c0 = 0; c0 < n; c0 += B) {
+        const uint32_t i = c0 + tid;
+        const LeafPlan p = leaf_plan(t, i);
+        if (!p.live) continue;
+        if (p.total < LEAF_BIG_MAX) leaf_emit_staged<BRANCH_STAGE_DW>(t, i, p, s_stage + tid * BRANCH_STAGE_DW);
+        else leaf_emit_scratch(t, i, p, atomicAdd(t.cursor, (unsigned long long)((p.total + 3u) & ~3u)));
+    }
+    __syncthreads();
+    // ---- branch nodes, level by level from the deepest nibble depth up ----
+    for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
+        const uint32_t c = s_hist[d];
+        if (!c) continue;
+        for (uint32_t q0 = 0; q0 < c; q0 += B) {
+            const uint32_t q = q0 + tid;
+            const BranchPlan p = branch_plan(t, s_begin[d] + q, q < c);
+            if (p.live) branch_emit(t, p, s_stage + tid * BRANCH_STAGE_DW, p.need ? atomicAdd(t.cursor, (unsigned long long)p.need) : 0ull);
+        }
+        __syncthreads();  // the level's references sit in their parents' slot tables
+    }
 }
 
 // ---- host driver ----
@@ -702,18 +924,48 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     }
     uint32_t* d_depth_begin = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
 
-    TB_TRY(hipMemsetAsync(t.first_flag, 0, (size_t)n + 1, st));
-    TB_TRY(hipMemsetAsync(t.counters, 0, (8 + MAX_DEPTH_BINS) * 4, st));
-    TB_TRY(hipMemsetAsync(t.depth_cursor, 0, MAX_DEPTH_BINS * 4, st));
-    TB_TRY(hipMemsetAsync(t.value_key, 0xff, ((size_t)n + 1) * 4, st));
-    TB_TRY(hipMemsetAsync(t.dense, 0xff, ((size_t)n + 1) * 4, st));
-    TB_TRY(hipMemsetAsync(t.cursor, 0, 8, st));
+    static const uint32_t small_max = std::getenv("PHANT_TRIE_SMALL_MAX") ? (uint32_t)std::strtoul(std::getenv("PHANT_TRIE_SMALL_MAX"), nullptr, 10) : SMALL_MAX_KEYS;
+    if (n <= (small_max < SMALL_MAX_KEYS ? small_max : SMALL_MAX_KEYS)) {
+        // one launch, one read-back (see small_forest_kernel); tables sized for the most branch nodes n keys can have
+        const uint64_t cap = total_val_bytes + total_key_bytes + (uint64_t)n * 32 + (uint64_t)n * (3 + 16 * 33 + 16 + 48 + 255 / 2 + 16) + 4096;
+        TB_TRY(ws.t2.reset(DevArena::round((size_t)n * 16 * 32) + DevArena::round((size_t)n * 16) + DevArena::round(cap) + 1024));
+        t.slot_bytes = ws.t2.take<uint8_t>((size_t)n * 16 * 32);
+        t.slot_len = ws.t2.take<uint8_t>((size_t)n * 16);
+        t.scratch = ws.t2.take<uint8_t>(cap);
+        t.scratch_cap = cap;
+        hipLaunchKernelGGL(small_forest_kernel, dim3(1), dim3(SMALL_BLOCK), 0, st, t);
+        TB_TRY(hipGetLastError());
+        uint32_t flags[3];
+        TB_TRY(hipMemcpyAsync(flags, t.counters, sizeof flags, hipMemcpyDeviceToHost, st));
+        TB_TRY(hipStreamSynchronize(st));
+        if (flags[1] & ERR_KEY_RANGE) {
+            err = "key longer than 255 bytes, or key offsets not monotone";
+            return PHANT_E_INVALID_ARG;
+        }
+        if (flags[1] & ERR_UNSORTED) {
+            err = "keys are not strictly increasing (mpt.zig:39)";
+            return PHANT_E_UNSORTED;
+        }
+        if (flags[2]) {
+            err = "trie scratch overflow (internal bound too small)";
+            return PHANT_E_DEVICE;
+        }
+        return PHANT_OK;
+    }
+
+    {
+        const uint64_t lanes = (uint64_t)n + 1 > 8u + MAX_DEPTH_BINS ? (uint64_t)n + 1 : 8u + MAX_DEPTH_BINS;
+        hipLaunchKernelGGL(trie_init_kernel, dim3(blocks(lanes)), dim3(256), 0, st, t);
+    }
 
     hipLaunchKernelGGL(first_flag_kernel, dim3(blocks(n_tries)), dim3(256), 0, st, t);
     hipLaunchKernelGGL(lcp_kernel, dim3(blocks((uint64_t)n + 1)), dim3(256), 0, st, t);
     if (M > n + 1) hipLaunchKernelGGL(tree_pad_kernel, dim3(blocks(M - n - 1)), dim3(256), 0, st, t);
-    for (uint32_t w = M / 2; w >= 1; w >>= 1)
-        hipLaunchKernelGGL(tree_level_kernel, dim3(blocks(w)), dim3(256), 0, st, t.tree, w);
+    {
+        uint32_t w = M / 2;
+        for (; w > 256u; w >>= 1) hipLaunchKernelGGL(tree_level_kernel, dim3(blocks(w)), dim3(256), 0, st, t.tree, w);
+        if (w >= 1u) hipLaunchKernelGGL(tree_top_kernel, dim3(1), dim3(256), 0, st, t.tree, w);
+    }
     hipLaunchKernelGGL(identify_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
     TB_TRY(hipGetLastError());
 
@@ -752,6 +1004,9 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
 
     if (n_rep) hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t, d_depth_begin);
     hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t);
+    // (leaves of 136 .. 543 bytes; whether there are any the host does not know -- a grid of idle waves costs microseconds)
+    if (total_val_bytes + total_key_bytes + 8ull * n >= (uint64_t)RATE)
+        hipLaunchKernelGGL(leaf_big_kernel, dim3((n + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t);
     for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
         const uint32_t c = cnt[8 + d];
         if (!c) continue;
