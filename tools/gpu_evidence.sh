@@ -30,6 +30,16 @@ b config5 --workload config5 --steps 64 --cpu-seconds 3
 b config5_20k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 20000
 b config5_100k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 100000
 b mptize --workload mptize --cpu-seconds 8 --steps 10
+timeout 300 python bench.py --comm --steps 10 --inner 10 2>&1 | grep '^{' | tail -1 > "$OUT/bench_comm_one_process.json"; python -c "
+import json; d=json.load(open('$OUT/bench_comm_one_process.json')); print('comm (one process)', d['n_gpus'], 'device(s)', round(d['value']/1e6,1), 'M proofs/s', round(d['ms_per_step'],4), 'ms')"
+timeout 300 python tools/bench_block_roots.py --items 1 10 100 400 > "$OUT/block_roots.jsonl" 2>&1; tail -4 "$OUT/block_roots.jsonl"
+timeout 300 python tools/bench_state.py > "$OUT/state_root.jsonl" 2>&1; timeout 300 python tools/bench_state.py --accounts 1000000 --slots 0 >> "$OUT/state_root.jsonl" 2>&1; cut -c1-330 "$OUT/state_root.jsonl"
+timeout 300 python tools/sweep_verify.py --steps 40 --out "$OUT/sweep.jsonl" > "$OUT/sweep.log" 2>&1; python - <<PY
+import json
+for l in open("$OUT/sweep.jsonl"):
+    d = json.loads(l)
+    print(d["mode"], d["dedup_levels"], d["env"], "ok" if d["ok"] else "WRONG", "event", d["event_ms"], "min", d["event_min_ms"], "hashed", d["nodes_hashed"])
+PY
 timeout 600 python tools/stress_verify.py --seeds 20 --first-seed 3000 2>&1 | tail -1 | tee "$OUT/stress.log"
 timeout 300 python tools/stress_trie.py --seeds 10 2>&1 | tail -1 | tee "$OUT/stress_trie.log"
 prof() {  # tag, env..., (BARGS)
@@ -45,7 +55,8 @@ BARGS="--streams 4" prof streams4 X=1
 BARGS="--streams 1 --workload config4" prof config4 X=1
 ( cd /tmp && rm -rf /tmp/prof_t && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o p -- python $R/bench.py --workload mptize --no-cpu-baseline --steps 10 > "$OUT/prof_mptize.log" 2>&1 )
 f=$(find /tmp/prof_t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && (head -1 "$f"; grep "phant" "$f") > "$OUT/mptize_kernel_stats.csv"
-( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/ubench/hash_stage.hip -o /tmp/hash_stage && timeout 120 /tmp/hash_stage ) > "$OUT/hash_stage_ubench.txt" 2>&1; tail -12 "$OUT/hash_stage_ubench.txt"
+rm -rf /tmp/pw; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pw -o p -- python $R/tools/probe_walk.py > "$OUT/probe.log" 2>&1 )
+python tools/probe_walk_report.py /tmp/pw | tee "$OUT/timeline.txt" | cut -c1-260 | tail -6
 # ---- PMC passes: counters in their own runs, kernel trace only
 pmc() {  # name, counters, mode
   name=$1; ctr=$2; mode=$3

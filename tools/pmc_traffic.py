@@ -74,7 +74,7 @@ for mode in ("flat", "nodedup"):
     per = {}
     tot_r = tot_w = 0.0
     for k in fr:
-        if not k.startswith("phant::") or "keccak256_fixed" in k or "verdict" in k:
+        if not k.startswith("phant::") or "keccak256_fixed" in k or "keccak_rate" in k or "verdict" in k:
             continue
         fac = f_half if "dedup_kernel" in k else f_hash if "hash_" in k else 1.0
         r = fr[k] * fac
