@@ -48,8 +48,11 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--grid", default=None, help="cross product of environment knobs instead of the built-in list")
     ap.add_argument("--corrupt", type=float, default=None, help="fraction of damaged / exclusion proofs in the witness")
+    ap.add_argument("--levels", default=None, help="e.g. 4,5,4,5: the two-tier pipeline at these forced tier splits, in this order")
     args = ap.parse_args()
     combos = grid(args.grid) if args.grid else COMBOS
+    if args.levels:
+        combos = [("flat", int(x) if int(x) >= 0 else None, e) for x in args.levels.split(",") for _, _, e in (combos if args.grid else [("flat", None, {})])]
     import torch
     import phant_amd
     from phant_amd import mpt as M
@@ -85,6 +88,7 @@ def main():
         paths = ctx.verify_path_stats() if mode != "fused" else (0, 0)
         line = {"mode": mode, "dedup_levels": levels, "env": env, "ok": ok, "wall_ms": round(wall, 4), "event_ms": round(sum(kms) / len(kms), 4),
                 "event_min_ms": round(min(kms), 4), "proofs_per_s": round(b.n / (wall * 1e-3)),
+                "kernel_us": ({k: round(v * 1e3, 1) for k, v in ctx.verify_kernel_ms().items()} if env.get("PHANT_VERIFY_SERIAL") == "1" and mode == "flat" else None),
                 "nodes_hashed": int(sum(hashed)), "slow_proofs": paths[0], "walk_opened": paths[1], "keccak_f": int(sum((c + 1) * h for c, h in enumerate(hashed)))}
         print(json.dumps(line), flush=True)
         lines.append(line)
