@@ -71,6 +71,13 @@ struct Workspaces {
     hipError_t ensure_stage() {
         return stage ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&stage), STAGE_BYTES, hipHostMallocDefault);
     }
+    // A few pinned, device-visible words for what a pass reads back in the middle of a call (the trie builder's counters): a
+    // copy into pageable memory costs ~25 us, a kernel that stores its flags here costs nothing beyond the synchronisation.
+    static constexpr size_t MAILBOX_WORDS = 1024;
+    uint32_t* mailbox = nullptr;
+    hipError_t ensure_mailbox() {
+        return mailbox ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&mailbox), MAILBOX_WORDS * 4, hipHostMallocDefault);
+    }
     // the pinned twin of a device address inside `io`
     template <class T>
     T* staged(T* d) const {
@@ -82,6 +89,8 @@ struct Workspaces {
         t2.release();
         if (stage) (void)hipHostFree(stage);
         stage = nullptr;
+        if (mailbox) (void)hipHostFree(mailbox);
+        mailbox = nullptr;
     }
 };
 

@@ -66,7 +66,7 @@ struct TrieDev {
     // scratch blob for encodings
     uint8_t* scratch;
     unsigned long long* cursor;
-    // counters[0] = n_rep, [1] = error flags, [2] = scratch overflow, hist at [8..8+512)
+    // counters[0] = n_rep, [1] = error flags, [2] = scratch overflow, [3] = some leaf may reach a rate block, hist at [8..8+512)
     uint32_t* counters;
     uint32_t* order;      // rep boundaries grouped by depth
     uint32_t* depth_cursor;  // 512
@@ -75,6 +75,7 @@ struct TrieDev {
     uint32_t* root_enc_len;  // optional: its length (may exceed root_enc_cap: then only the length is valid)
     uint32_t root_enc_cap;
     unsigned long long scratch_cap;
+    uint32_t* flags_host;  // small_forest_kernel: where counters[0..2] go when the kernel ends (pinned host memory), or null
 };
 
 enum : uint32_t { ERR_UNSORTED = 1u, ERR_KEY_RANGE = 2u };
@@ -140,24 +141,35 @@ __global__ void __launch_bounds__(256) tree_pad_kernel(TrieDev t) {
     if (i < t.M) t.tree[t.M + i] = INF_LCP;
 }
 
-__global__ void __launch_bounds__(256) tree_level_kernel(int32_t* tree, uint32_t w) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k < w) {
-        const uint32_t v = w + k;
-        const int32_t a = tree[2 * v], b = tree[2 * v + 1];
-        tree[v] = a < b ? a : b;
+// The min-tree over the lcp array, up to eleven levels per launch: a workgroup takes a tile of T consecutive nodes of the level of
+// width w_in (T = 2 048, or the whole level when it is narrower) and writes every level above it down to the tile's one
+// ancestor -- the first from global memory, the rest out of LDS behind workgroup barriers.  A million keys: two launches (twelve
+// when every level was one: 80 us of launch gaps at the head of every call).
+constexpr uint32_t TREE_TILE = 2048;
+__global__ void __launch_bounds__(256) tree_tile_kernel(int32_t* tree, uint32_t w_in, uint32_t T) {
+    __shared__ int32_t s_min[TREE_TILE / 2];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    uint32_t half = T >> 1, w = w_in >> 1;  // this tile's nodes on the level being written, that level's width
+    for (uint32_t k = tid; k < half; k += 256u) {
+        const uint32_t v = w + b * half + k;
+        const int32_t x = tree[2 * v], y = tree[2 * v + 1];
+        const int32_t m = x < y ? x : y;
+        tree[v] = m;
+        s_min[k] = m;
     }
-}
-
-// the levels of w <= 256 nodes in ONE launch (a workgroup barrier between them instead of a kernel boundary: up to nine
-// launches of a few lanes each at the head of every call)
-__global__ void __launch_bounds__(256) tree_top_kernel(int32_t* tree, uint32_t w_first) {
-    for (uint32_t w = w_first; w >= 1u; w >>= 1) {
-        const uint32_t k = threadIdx.x;
-        if (k < w) {
-            const uint32_t v = w + k;
-            const int32_t a = tree[2 * v], b = tree[2 * v + 1];
-            tree[v] = a < b ? a : b;
+    __syncthreads();
+    while (half > 1u) {
+        half >>= 1;
+        w >>= 1;
+        int32_t m[2] = {0, 0};  // half <= 512: at most two nodes per lane
+        for (uint32_t k = tid, q = 0; k < half; k += 256u, ++q) {
+            const int32_t x = s_min[2 * k], y = s_min[2 * k + 1];
+            m[q] = x < y ? x : y;
+        }
+        __syncthreads();
+        for (uint32_t k = tid, q = 0; k < half; k += 256u, ++q) {
+            s_min[k] = m[q];
+            tree[w + b * half + k] = m[q];
         }
         __syncthreads();
     }
@@ -267,6 +279,12 @@ __global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
     uint32_t dn = NONE;
     int32_t d = -1;
     const bool is_rep = in && identify_element(t, i, d);
+    // could this key's leaf reach a rate block?  (list header <= 3, hex-prefix string <= key bytes + 3, value string <= bytes + 3:
+    // the host launches leaf_big_kernel only if some key says yes -- a state trie's 110-byte leaves never do)
+    {
+        const bool maybe_big = in && (uint64_t)(t.key_off[i + 1] - t.key_off[i]) + (t.val_off[i + 1] - t.val_off[i]) + 9u >= (uint64_t)RATE;
+        if (__ballot(maybe_big) != 0ull && (threadIdx.x & 63u) == 0u) t.counters[3] = 1u;  // (plain store: every writer writes 1)
+    }
     // dense ids: ranks inside the workgroup (ballot + the waves' totals in LDS), one global reservation; the
     // per-depth histogram: LDS counters, one global add per depth the workgroup met
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -290,22 +308,37 @@ __global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
     if (in) t.dense[i] = dn;
 }
 
-__global__ void __launch_bounds__(COUNT_BLOCK) order_kernel(TrieDev t, const uint32_t* depth_begin) {
+// Also: where a depth's bin starts (the exclusive prefix sum of identify_kernel's histogram: every workgroup forms it again in LDS
+// -- 512 counters, nine steps -- instead of the host sending it over), and the slot lengths cleared (16 bytes per node).
+__global__ void __launch_bounds__(COUNT_BLOCK) order_kernel(TrieDev t) {
     __shared__ uint32_t s_cnt[MAX_DEPTH_BINS];
     __shared__ uint32_t s_base[MAX_DEPTH_BINS];
+    __shared__ uint32_t s_begin[2][MAX_DEPTH_BINS];
+    static_assert(COUNT_BLOCK >= MAX_DEPTH_BINS, "one lane per depth bin");
     const uint32_t i = blockIdx.x * COUNT_BLOCK + threadIdx.x;
-    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK) s_cnt[b] = 0u;
+    const uint32_t tid = threadIdx.x;
+    if (tid < (uint32_t)MAX_DEPTH_BINS) {
+        s_cnt[tid] = 0u;
+        s_begin[0][tid] = t.counters[8 + tid];
+    }
+    if (i < t.counters[0]) reinterpret_cast<uint4*>(t.slot_len)[i] = make_uint4(0u, 0u, 0u, 0u);  // (n_rep <= n lanes)
     __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t o = 1; o < (uint32_t)MAX_DEPTH_BINS; o <<= 1) {  // inclusive scan, two buffers
+        if (tid < (uint32_t)MAX_DEPTH_BINS) s_begin[cur ^ 1u][tid] = s_begin[cur][tid] + (tid >= o ? s_begin[cur][tid - o] : 0u);
+        cur ^= 1u;
+        __syncthreads();
+    }
     const bool live = i < t.n && i != 0 && t.dense[i] != NONE;
-    const int32_t d = live ? t.lcp[i] : -1;
+    const uint32_t d = live ? (uint32_t)t.lcp[i] : 0u;
     // rank inside the workgroup's share of depth d (LDS), then one global reservation per workgroup and depth;
     // the order inside a depth bin is immaterial (it is a work list)
     const uint32_t local = live ? atomicAdd(&s_cnt[d], 1u) : 0u;
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK)
+    for (uint32_t b = tid; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK)
         if (s_cnt[b]) s_base[b] = atomicAdd(&t.depth_cursor[b], s_cnt[b]);
     __syncthreads();
-    if (live) t.order[depth_begin[d] + s_base[d] + local] = i;
+    if (live) t.order[(d ? s_begin[cur][d - 1u] : 0u) + s_base[d] + local] = i;
 }
 
 // ---- RLP helpers (row a10: canonical subset used at mpt.zig:127,198,236,268) ----
@@ -344,6 +377,13 @@ PHANT_DEV uint8_t* put_str(uint8_t* w, const uint8_t* s, uint64_t len) {
     while (k < len && ((uintptr_t)(s + k) & 3u)) {
         w[k] = s[k];
         ++k;
+    }
+    for (; k + 32 <= len; k += 32) {  // eight loads in flight: a loop of one load, one wait is a microsecond per 4 bytes
+        uint32_t q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const uint32_t*>(s + k + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) w[k + u] = (uint8_t)(q[u >> 2] >> (8 * (u & 3)));
     }
     for (; k + 4 <= len; k += 4) {
         const uint32_t q = *reinterpret_cast<const uint32_t*>(s + k);
@@ -409,9 +449,31 @@ PHANT_DEV uint8_t* put_hp(uint8_t* w, const TrieDev& t, uint32_t k, uint32_t ps,
     const uint32_t b0 = ((is_leaf ? 2u : 0u) + (odd ? 1u : 0u)) << 4 | (odd ? nib_at(t, k, ps) : 0u);
     if (hp > 1) w = put_hdr(w, hp, 0x80u, 0xb7u);
     *w++ = (uint8_t)b0;
-    for (uint32_t j = ps + (odd ? 1u : 0u); j < pe; j += 2)
-        *w++ = (uint8_t)((nib_at(t, k, j) << 4) | nib_at(t, k, j + 1));
-    return w;
+    // nibbles [s, pe), an even number, two per byte.  The key bytes are loaded eight (nine) at a time BEFORE any is stored: one
+    // load per nibble, each waited for in turn, was 10-15 us of a leaf's latency (57 nibbles of a 32-byte key).
+    const uint32_t s = ps + (odd ? 1u : 0u), nout = (pe - s) / 2u;
+    const uint8_t* const src = t.keys + t.key_off[k] + (s >> 1);
+    uint32_t m = 0;
+    if (!(s & 1u)) {  // byte-aligned: the key's own bytes
+        for (; m + 8u <= nout; m += 8u) {
+            uint8_t q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = src[m + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[m + u] = q[u];
+        }
+        for (; m < nout; ++m) w[m] = src[m];
+    } else {  // low nibble of byte m, high nibble of byte m + 1 (the last one read is the key's byte (pe - 1) / 2)
+        for (; m + 8u <= nout; m += 8u) {
+            uint8_t q[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) q[u] = src[m + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[m + u] = (uint8_t)((q[u] << 4) | (q[u + 1] >> 4));
+        }
+        for (; m < nout; ++m) w[m] = (uint8_t)((src[m] << 4) | (src[m + 1] >> 4));
+    }
+    return w + nout;
 }
 
 // ---- nodes staged in LDS ----
@@ -551,24 +613,39 @@ __global__ void __launch_bounds__(256) leaf_kernel(TrieDev t) {
 // Writes the 17-item list into `enc` (LDS slot or scratch blob: the caller's pointer decides what the stores are).
 PHANT_DEV uint8_t* put_branch(uint8_t* enc, const TrieDev& t, uint32_t dn, uint64_t payload, const uint8_t* v, uint64_t vlen) {
     uint8_t* w = put_hdr(enc, payload, 0xc0u, 0xf7u);
-    for (uint32_t k = 0; k < 16; ++k) {
-        const uint64_t slot = (uint64_t)dn * 16u + k;
-        const uint32_t sl = t.slot_len[slot];
-        const uint8_t* src = t.slot_bytes + slot * 32u;
-        if (sl == 0) {
-            *w++ = 0x80;
-        } else {
-            if (sl == 32u) {
+    // the 16 slot lengths: one aligned 16-byte load; the slots' bytes four children at a time, all eight 16-byte loads issued
+    // before the first byte is stored (the table has all 32 bytes of every slot, whatever its length says is used): sixteen
+    // load-wait-store rounds were 15-25 us of EVERY branch node's latency, which is what a depth bin with few nodes costs
+    const uint4 sl4 = *reinterpret_cast<const uint4*>(t.slot_len + (uint64_t)dn * 16u);
+    const uint32_t slw[4] = {sl4.x, sl4.y, sl4.z, sl4.w};
+    const uint4* const table = reinterpret_cast<const uint4*>(t.slot_bytes + (uint64_t)dn * 16u * 32u);
+#pragma unroll 1
+    for (uint32_t g = 0; g < 4; ++g) {
+        if (slw[g] == 0u) {  // four empty slots (most of a sparse branch): nothing to fetch
+            w[0] = w[1] = w[2] = w[3] = 0x80;
+            w += 4;
+            continue;
+        }
+        uint4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = table[8u * g + (uint32_t)u];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t sl = (slw[g] >> (8 * c)) & 0xffu;
+            const uint32_t qq[8] = {q[2 * c].x, q[2 * c].y, q[2 * c].z, q[2 * c].w, q[2 * c + 1].x, q[2 * c + 1].y, q[2 * c + 1].z, q[2 * c + 1].w};
+            if (sl == 0) {
+                *w++ = 0x80;
+            } else if (sl == 32u) {
                 *w++ = 0xa0;
-                // a 32-byte reference: two aligned 16-byte loads from the slot table, bytes out
-                const uint4 q0 = reinterpret_cast<const uint4*>(src)[0], q1 = reinterpret_cast<const uint4*>(src)[1];
-                const uint32_t qq[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
                 for (int b = 0; b < 32; ++b) w[b] = (uint8_t)(qq[b >> 2] >> (8 * (b & 3)));
-            } else {
-                for (uint32_t b = 0; b < sl; ++b) w[b] = src[b];
+                w += 32;
+            } else {  // an embedded child (< 32 bytes)
+#pragma unroll
+                for (int b = 0; b < 31; ++b)
+                    if ((uint32_t)b < sl) w[b] = (uint8_t)(qq[b >> 2] >> (8 * (b & 3)));
+                w += sl;
             }
-            w += sl;
         }
     }
     if (vlen)
@@ -829,7 +906,10 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
         }
     }
     __syncthreads();
-    if (s_err) return;  // (unsorted keys, a key too long: the launcher reads the flags)
+    if (s_err) {  // (unsorted keys, a key too long: the launcher reads the flags)
+        if (tid < 3u && t.flags_host) t.flags_host[tid] = tid == 0u ? s_nrep : tid == 1u ? s_err : 0u;
+        return;
+    }
     // ---- the branch nodes grouped by depth ----
     for (uint32_t c0 = 0; c0 < n; c0 += B) {
         const uint32_t i = c0 + tid;
@@ -859,6 +939,8 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
         }
         __syncthreads();  // the level's references sit in their parents' slot tables
     }
+    // what the launcher wants to know, straight into its pinned mailbox (no copy command, one synchronisation)
+    if (tid < 3u && t.flags_host) t.flags_host[tid] = atomicOr(&t.counters[tid], 0u);
 }
 
 // ---- host driver ----
@@ -882,6 +964,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
                              const uint32_t* d_seg_first, uint32_t n_tries, uint8_t* d_roots,
                              std::string& err, uint8_t* d_root_enc = nullptr, uint32_t* d_root_enc_len = nullptr,
                              uint32_t root_enc_cap = 0) {
+    TB_TRY(ws.ensure_mailbox());
     TrieDev t{};
     t.root_enc = d_root_enc;
     t.root_enc_len = d_root_enc_len;
@@ -922,7 +1005,6 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         t.depth_cursor = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
         t.cursor = ws.t1.take<unsigned long long>(1);
     }
-    uint32_t* d_depth_begin = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
 
     static const uint32_t small_max = std::getenv("PHANT_TRIE_SMALL_MAX") ? (uint32_t)std::strtoul(std::getenv("PHANT_TRIE_SMALL_MAX"), nullptr, 10) : SMALL_MAX_KEYS;
     if (n <= (small_max < SMALL_MAX_KEYS ? small_max : SMALL_MAX_KEYS)) {
@@ -933,11 +1015,11 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         t.slot_len = ws.t2.take<uint8_t>((size_t)n * 16);
         t.scratch = ws.t2.take<uint8_t>(cap);
         t.scratch_cap = cap;
+        t.flags_host = ws.mailbox;
         hipLaunchKernelGGL(small_forest_kernel, dim3(1), dim3(SMALL_BLOCK), 0, st, t);
         TB_TRY(hipGetLastError());
-        uint32_t flags[3];
-        TB_TRY(hipMemcpyAsync(flags, t.counters, sizeof flags, hipMemcpyDeviceToHost, st));
         TB_TRY(hipStreamSynchronize(st));
+        const uint32_t flags[3] = {ws.mailbox[0], ws.mailbox[1], ws.mailbox[2]};
         if (flags[1] & ERR_KEY_RANGE) {
             err = "key longer than 255 bytes, or key offsets not monotone";
             return PHANT_E_INVALID_ARG;
@@ -961,17 +1043,18 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     hipLaunchKernelGGL(first_flag_kernel, dim3(blocks(n_tries)), dim3(256), 0, st, t);
     hipLaunchKernelGGL(lcp_kernel, dim3(blocks((uint64_t)n + 1)), dim3(256), 0, st, t);
     if (M > n + 1) hipLaunchKernelGGL(tree_pad_kernel, dim3(blocks(M - n - 1)), dim3(256), 0, st, t);
-    {
-        uint32_t w = M / 2;
-        for (; w > 256u; w >>= 1) hipLaunchKernelGGL(tree_level_kernel, dim3(blocks(w)), dim3(256), 0, st, t.tree, w);
-        if (w >= 1u) hipLaunchKernelGGL(tree_top_kernel, dim3(1), dim3(256), 0, st, t.tree, w);
+    for (uint32_t w = M; w > 1u;) {  // M is a power of two
+        const uint32_t T = w < TREE_TILE ? w : TREE_TILE;
+        hipLaunchKernelGGL(tree_tile_kernel, dim3(w / T), dim3(256), 0, st, t.tree, w, T);
+        w /= T;
     }
     hipLaunchKernelGGL(identify_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
     TB_TRY(hipGetLastError());
 
-    std::vector<uint32_t> cnt(8 + MAX_DEPTH_BINS);
-    TB_TRY(hipMemcpyAsync(cnt.data(), t.counters, cnt.size() * 4, hipMemcpyDeviceToHost, st));
+    static_assert(8 + MAX_DEPTH_BINS <= Workspaces::MAILBOX_WORDS, "the counters fit the pinned mailbox");
+    TB_TRY(hipMemcpyAsync(ws.mailbox, t.counters, (8 + MAX_DEPTH_BINS) * 4, hipMemcpyDeviceToHost, st));
     TB_TRY(hipStreamSynchronize(st));
+    const std::vector<uint32_t> cnt(ws.mailbox, ws.mailbox + 8 + MAX_DEPTH_BINS);
     if (cnt[1] & ERR_KEY_RANGE) {
         err = "key longer than 255 bytes, or key offsets not monotone";
         return PHANT_E_INVALID_ARG;
@@ -987,7 +1070,6 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         depth_begin[d] = acc;
         acc += cnt[8 + d];
     }
-    TB_TRY(hipMemcpyAsync(d_depth_begin, depth_begin.data(), MAX_DEPTH_BINS * 4, hipMemcpyHostToDevice, st));
 
     // leaves: list hdr (<=9) + HP (<= 3 + key bytes + 1) + value (<= 9 + len), 4-byte rounded;
     // branches: <= 3 + 16*33 + value; extensions <= 48 + key bytes / 2
@@ -1000,12 +1082,12 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     t.slot_len = ws.t2.take<uint8_t>((size_t)n_rep * 16);
     t.scratch = ws.t2.take<uint8_t>(cap);
     t.scratch_cap = cap;
-    TB_TRY(hipMemsetAsync(t.slot_len, 0, (size_t)n_rep * 16, st));
-
-    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t, d_depth_begin);
+    // (order_kernel also clears the slot lengths and forms the bins' starts from the histogram it finds in t.counters)
+    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
     hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t);
-    // (leaves of 136 .. 543 bytes; whether there are any the host does not know -- a grid of idle waves costs microseconds)
-    if (total_val_bytes + total_key_bytes + 8ull * n >= (uint64_t)RATE)
+    // (leaves of 136 .. 543 bytes: identify_kernel said whether there can be any -- a grid of lanes that only find out that
+    // their leaf is small was 24 us per million keys)
+    if (cnt[3])
         hipLaunchKernelGGL(leaf_big_kernel, dim3((n + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t);
     for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
         const uint32_t c = cnt[8 + d];
@@ -1013,10 +1095,9 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         hipLaunchKernelGGL(branch_kernel, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t, depth_begin[d], c);
     }
     TB_TRY(hipGetLastError());
-    uint32_t flags[3];
-    TB_TRY(hipMemcpyAsync(flags, t.counters, sizeof flags, hipMemcpyDeviceToHost, st));
+    TB_TRY(hipMemcpyAsync(ws.mailbox, t.counters, 3 * 4, hipMemcpyDeviceToHost, st));
     TB_TRY(hipStreamSynchronize(st));
-    if (flags[2]) {
+    if (ws.mailbox[2]) {
         err = "trie scratch overflow (internal bound too small)";
         return PHANT_E_DEVICE;
     }
@@ -1062,13 +1143,24 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
     uint8_t* d_enc = ws.io.take<uint8_t>((size_t)n_tries * root_enc_cap + 4);
     uint32_t* d_enc_len = ws.io.take<uint32_t>(n_tries);
     const bool want_enc = root_enc_out && root_enc_len_out && root_enc_cap;
-    if (want_enc) TB_TRY(hipMemsetAsync(d_enc_len, 0, (size_t)n_tries * 4, st));
     // Small calls (the tries of an ordinary block): the five input arrays are laid out in the pinned mirror of the arena and cross
-    // the bus in one copy; the offsets are rebased in place there (Workspaces::stage)
+    // the bus in one copy; the offsets are rebased in place there (Workspaces::stage).  The results go the other way without a
+    // copy command at all: the kernels store roots (and root nodes) into the mirror -- it is device-visible --, and they are
+    // there when the pass's own synchronisation returns.
     const size_t in_span = (size_t)(reinterpret_cast<uint8_t*>(d_seg + n_tries + 1) - ws.io.base);
+    const size_t out_span = (size_t)(reinterpret_cast<uint8_t*>(d_enc_len + n_tries) - ws.io.base);
     const bool staged = !PHANT_ARENA_POISONS && in_span <= Workspaces::STAGE_BYTES;
+    const bool staged_out = staged && out_span <= Workspaces::STAGE_BYTES;
+    if (staged) TB_TRY(ws.ensure_stage());
+    if (staged_out) {
+        d_roots = ws.staged(d_roots);
+        d_enc = ws.staged(d_enc);
+        d_enc_len = ws.staged(d_enc_len);
+        if (want_enc) std::memset(d_enc_len, 0, (size_t)n_tries * 4);
+    } else if (want_enc) {
+        TB_TRY(hipMemsetAsync(d_enc_len, 0, (size_t)n_tries * 4, st));
+    }
     if (staged) {
-        TB_TRY(ws.ensure_stage());
         if (kb) std::memcpy(ws.staged(d_keys), keys + key_off[0], kb);
         if (vb) std::memcpy(ws.staged(d_vals), vals + val_off[0], vb);
         uint32_t* const ko = ws.staged(d_koff);
@@ -1100,6 +1192,15 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
     if (rc) {
         (void)hipStreamSynchronize(st);
         return rc;
+    }
+    if (staged_out) {
+        TB_TRY(hipStreamSynchronize(st));  // (forest_device has synchronised already unless there were no keys)
+        std::memcpy(roots_out, d_roots, (size_t)n_tries * 32);
+        if (want_enc) {
+            std::memcpy(root_enc_out, d_enc, (size_t)n_tries * root_enc_cap);
+            std::memcpy(root_enc_len_out, d_enc_len, (size_t)n_tries * 4);
+        }
+        return PHANT_OK;
     }
     TB_TRY(hipMemcpyAsync(roots_out, d_roots, (size_t)n_tries * 32, hipMemcpyDeviceToHost, st));
     if (want_enc) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# state root on the GPU: parity tests, throughput now and (if tools/_oldrepo exists) with round 1's host-side ordering
+# state root on the GPU: parity tests, throughput of the host form and the device-resident form
 OUT=$PWD/gpurun_out/${1:-state}
 mkdir -p "$OUT"; ulimit -c 0; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 timeout 100 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1 || { echo "smoke failed"; tail -5 "$OUT/smoke.log"; exit 1; }
@@ -7,5 +7,4 @@ timeout 600 python -m pytest tests/test_gpu_trie.py tests/test_gpu_x_state_shard
 for a in "200000 5" "1000000 0" "2000 500"; do
   set -- $a
   timeout 300 python tools/bench_state.py --accounts $1 --slots $2 | tee -a "$OUT/bench_state.jsonl"
-  [ -d tools/_oldrepo ] && timeout 300 python tools/bench_state.py --accounts $1 --slots $2 --repo tools/_oldrepo | tee -a "$OUT/bench_state.jsonl"
 done

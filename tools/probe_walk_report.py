@@ -9,7 +9,7 @@ first = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("propose_kernel
 t0 = None
 cur = []
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("phant::v2::", "").replace("phant::v3::", "").replace("phant::", "").replace("(anonymous namespace)::", "")
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("phant::v2::", "").replace("phant::v3::", "").replace("phant::", "").replace("(anonymous namespace)::", "")
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if t0 is None or (any(x in name for x in first) and s - t0 > 100_000):
         if cur:
