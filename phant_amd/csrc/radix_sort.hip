@@ -3,9 +3,10 @@
 // The secure tries of src/state (statedb.zig / types.zig:13-20 -> DESIGN.md section 9) are keyed by Keccak outputs, so
 // before a trie can be hashed its leaves have to be put in key order.  Round 1 did that on the host (std::sort with
 // 32-byte memcmp: ~0.2 s per million keys, behind a device-to-host copy of every digest).  Here: a stable LSD radix
-// sort of (64-bit key, 32-bit value) pairs, 8 bits per pass, three kernels per pass --
+// sort of (64-bit key, 32-bit value) pairs, 8 bits per pass, three launches per pass --
 //   radix_hist    per-workgroup digit histogram of a tile of 2 048 pairs (LDS atomics) -> hist[digit][workgroup]
-//   exclusive_scan of that table in place (256 x n / 2 048 entries; tiled, see below)
+//   radix_rows    the table's exclusive scan in digit-major order, one workgroup per digit (its row of per-tile counts behind
+//                 the totals of all smaller digits, which radix_hist summed on the way)
 //   radix_scatter every wave ranks its 512 pairs digit by digit in index order (a lane's rank among the lanes of its
 //                 wave with the same digit comes from eight ballots), the workgroup adds the waves' totals to the
 //                 scanned base, pairs go to their final place
@@ -29,18 +30,32 @@ constexpr uint32_t SORT_ITEMS = 8;                             // rounds of 64 p
 constexpr uint32_t SORT_TILE = SORT_THREADS * SORT_ITEMS;      // pairs per workgroup
 constexpr uint32_t SORT_WAVES = SORT_THREADS / 64u;
 
+// A workgroup counts HIST_TILES consecutive tiles (a column of the table each) and adds their sum to the digits' totals with one
+// atomic per digit: same-address atomics are served one at a time (~12 ns), so a workgroup per tile would put 512 of them on
+// every total of a million-key pass.
+constexpr uint32_t HIST_TILES = 2;
 __global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t shift,
-                                                                  uint32_t* __restrict__ hist, uint32_t n_tiles) {
+                                                                  uint32_t* __restrict__ hist, uint32_t n_tiles,
+                                                                  uint32_t* __restrict__ digit_total) {
     __shared__ uint32_t s_hist[256];
-    s_hist[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * SORT_TILE;
-    for (uint32_t r = 0; r < SORT_ITEMS; ++r) {
-        const uint32_t i = base + r * SORT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    uint32_t sum = 0;
+    for (uint32_t q = 0; q < HIST_TILES; ++q) {
+        const uint32_t tile = blockIdx.x * HIST_TILES + q;
+        if (tile >= n_tiles) break;
+        s_hist[threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t base = tile * SORT_TILE;
+        for (uint32_t r = 0; r < SORT_ITEMS; ++r) {
+            const uint32_t i = base + r * SORT_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const uint32_t c = s_hist[threadIdx.x];
+        hist[threadIdx.x * n_tiles + tile] = c;
+        sum += c;
+        __syncthreads();
     }
-    __syncthreads();
-    hist[threadIdx.x * n_tiles + blockIdx.x] = s_hist[threadIdx.x];
+    if (sum) atomicAdd(&digit_total[threadIdx.x], sum);
 }
 
 // ---- exclusive scan of 32-bit counters, in place.  Tiles of 2 048 counters (8 per lane, contiguous: a lane's two 16-byte
@@ -141,6 +156,30 @@ hipError_t exclusive_scan(uint32_t* d, uint32_t n, uint32_t* scratch, hipStream_
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(SCAN_THREADS), 0, st, d, n, (const uint32_t*)scratch);
     return hipGetLastError();
+}
+
+// The scan of a pass's digit table in ONE launch (the generic exclusive_scan above takes three for a table of this size, each a
+// few microseconds of launch latency around microseconds of work, eleven passes per state root): workgroup d owns digit d's row
+// of per-tile counts.  Where the row starts = the pairs of all smaller digits (radix_hist_kernel summed them per digit:
+// digit_total), then the row's own exclusive scan, 256 tiles at a time.  Workgroup 0 clears the totals of the NEXT pass (the two
+// buffers alternate; nothing reads that one before the next radix_hist_kernel, which this stream starts after this kernel).
+__global__ void __launch_bounds__(256) radix_rows_kernel(uint32_t* __restrict__ hist, uint32_t n_tiles, const uint32_t* __restrict__ digit_total,
+                                                         uint32_t* __restrict__ next_total) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x, d = blockIdx.x;
+    if (d == 0u) next_total[tid] = 0u;
+    uint32_t carry = 0;
+    (void)scan_block_exclusive(tid < d ? digit_total[tid] : 0u, tid, s_wave, &carry);
+    __syncthreads();
+    uint32_t* const row = hist + (size_t)d * n_tiles;
+    for (uint32_t c0 = 0; c0 < n_tiles; c0 += 256u) {
+        const uint32_t i = c0 + tid;
+        uint32_t total = 0;
+        const uint32_t ex = scan_block_exclusive(i < n_tiles ? row[i] : 0u, tid, s_wave, &total);
+        if (i < n_tiles) row[i] = carry + ex;
+        carry += total;
+        __syncthreads();  // (s_wave is reused by the next chunk)
+    }
 }
 
 __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
@@ -245,12 +284,14 @@ uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1u) / SORT_TILE; }
 // stable sort of the pairs by key bits [lo, hi) (multiples of 8); the result ends up in (keys, vals) -- the pointers are
 // swapped with their alternates after every pass
 hipError_t sort_pairs(uint64_t*& keys, uint32_t*& vals, uint64_t*& keys_alt, uint32_t*& vals_alt, uint32_t n, uint32_t lo, uint32_t hi,
-                      uint32_t* hist, uint32_t* scan_scratch, hipStream_t st) {
+                      uint32_t* hist, uint32_t* digit_totals /* 2 x 256; buffer `cur` is zero */, uint32_t& cur, hipStream_t st) {
     const uint32_t tiles = sort_tiles(n);
     for (uint32_t shift = lo; shift < hi; shift += 8u) {
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(tiles), dim3(SORT_THREADS), 0, st, keys, n, shift, hist, tiles);
-        const hipError_t e = exclusive_scan(hist, 256u * tiles, scan_scratch, st);
-        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3((tiles + HIST_TILES - 1u) / HIST_TILES), dim3(SORT_THREADS), 0, st, keys, n, shift, hist, tiles,
+                           digit_totals + 256u * cur);
+        hipLaunchKernelGGL(radix_rows_kernel, dim3(256), dim3(256), 0, st, hist, tiles, (const uint32_t*)(digit_totals + 256u * cur),
+                           digit_totals + 256u * (cur ^ 1u));
+        cur ^= 1u;
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(tiles), dim3(SORT_THREADS), 0, st, keys, vals, keys_alt, vals_alt, n, shift, hist, tiles);
         uint64_t* tk = keys; keys = keys_alt; keys_alt = tk;
         uint32_t* tv = vals; vals = vals_alt; vals_alt = tv;
@@ -271,7 +312,7 @@ size_t order_workspace_bytes(uint32_t n) {
     const size_t r = 256;
     auto rnd = [&](size_t b) { return (b + r - 1) / r * r; };
     return 2 * rnd((size_t)n * 8) + 2 * rnd((size_t)n * 4) + rnd((size_t)256 * sort_tiles(n) * 4) + rnd(4) +
-           rnd(4 * scan_scratch_entries(256u * sort_tiles(n))) + 6 * r;
+           rnd(2 * 256 * 4) + 6 * r;
 }
 
 // order[0..n): the items (digests d_digests[i], 32 bytes each) in ascending order of (seg_of[i], digest i); seg_of may be
@@ -290,8 +331,9 @@ hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_
     p += rnd((size_t)256 * sort_tiles(n) * 4);
     uint32_t* flag = reinterpret_cast<uint32_t*>(p);
     p += rnd(4);
-    uint32_t* scan_scratch = reinterpret_cast<uint32_t*>(p);
-    hipError_t e = hipMemsetAsync(flag, 0, 4, st);
+    uint32_t* digit_totals = reinterpret_cast<uint32_t*>(p);  // (directly behind the flag's 256 bytes: one memset for both)
+    uint32_t cur = 0;
+    hipError_t e = hipMemsetAsync(flag, 0, rnd(4) + 2 * 256 * 4, st);
     if (e != hipSuccess) return e;
     *d_flag_out = flag;
     if (n == 0) {
@@ -301,12 +343,12 @@ hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_
     const uint32_t g = (n + 255u) / 256u;
     hipLaunchKernelGGL(digest_prefix_kernel, dim3(g), dim3(256), 0, st, d_digests, n, keys, vals);
     const uint32_t bits = prefix_bits >= 64u ? 64u : (prefix_bits + 7u) / 8u * 8u;
-    if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 64u - bits, 64u, hist, scan_scratch, st)) != hipSuccess) return e;
+    if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 64u - bits, 64u, hist, digit_totals, cur, st)) != hipSuccess) return e;
     if (d_seg_of && n_seg > 1u) {
         uint32_t seg_bits = 8;
         while (seg_bits < 32u && ((uint64_t)1 << seg_bits) < n_seg) seg_bits += 8;
         hipLaunchKernelGGL(segment_key_kernel, dim3(g), dim3(256), 0, st, vals, d_seg_of, n, keys);
-        if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 0u, seg_bits, hist, scan_scratch, st)) != hipSuccess) return e;
+        if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 0u, seg_bits, hist, digit_totals, cur, st)) != hipSuccess) return e;
     }
     if (n > 1u) hipLaunchKernelGGL(order_check_kernel, dim3((n - 1u + 255u) / 256u), dim3(256), 0, st, d_digests, vals, d_seg_of, n, flag);
     *d_order_out = vals;

@@ -219,17 +219,15 @@ int32_t order_on_host(hipStream_t st, const uint8_t* d_digests, const uint32_t* 
     return PHANT_OK;
 }
 
-// digests (device) -> their order in device memory; the device sort, or the host's if that one reports ties
-int32_t order_digests(hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* d_sort_ws,
-                      uint32_t** d_order, std::string& err) {
-    uint32_t prefix_bits = 64;  // tests shrink it to reach the host fallback
+// digests (device) -> their order in device memory by the device sort, WITHOUT waiting for its verdict: the order is used at
+// once, *d_flag is read back by the caller together with whatever it reads back next anyway; a set flag (ties in the 64-bit
+// prefixes: never, unless someone ground keys for it) means order_on_host and the work since then again.
+int32_t order_digests_async(hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* d_sort_ws,
+                            uint32_t** d_order, uint32_t** d_flag, std::string& err) {
+    uint32_t prefix_bits = 64;
     if (const char* t = std::getenv("PHANT_SORT_PREFIX_BITS")) prefix_bits = (uint32_t)std::strtoul(t, nullptr, 10);
-    uint32_t* d_flag = nullptr;
-    SR_TRY(launch_order_digests(d_digests, d_seg_of, n, n_seg, d_sort_ws, d_order, &d_flag, prefix_bits, st));
-    uint32_t flag = 0;
-    SR_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
-    SR_TRY(hipStreamSynchronize(st));
-    return flag ? order_on_host(st, d_digests, d_seg_of, n, *d_order, err) : PHANT_OK;
+    SR_TRY(launch_order_digests(d_digests, d_seg_of, n, n_seg, d_sort_ws, d_order, d_flag, prefix_bits, st));
+    return PHANT_OK;
 }
 
 // the state trie's leaves in device memory (inside ws.io: valid until the next call that stages something there)
@@ -302,27 +300,37 @@ int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, Dev
     uint64_t* d_lvoff = ws.io.take<uint64_t>(m1);
     uint8_t* d_sroots = ws.io.take<uint8_t>(32 * (size_t)n);
     uint32_t* d_scan = ws.io.take<uint32_t>(scan_entries);
-    uint32_t L = 0;
+    // what the host reads back on the way goes through the ctx's pinned mailbox (a copy into pageable memory is ~25 us a piece);
+    // the words behind the trie builder's
+    SR_TRY(ws.ensure_mailbox());
+    volatile uint32_t* const mb = ws.mailbox + 640;
     hipLaunchKernelGGL(slot_live_kernel, dim3(blocks(m1)), dim3(256), 0, st, d_svals_in, m, d_pos);
     SR_TRY(launch_exclusive_scan_u32(d_pos, m + 1u, d_scan, st));
-    SR_TRY(hipMemcpyAsync(&L, d_pos + m, 4, hipMemcpyDeviceToHost, st));
+    SR_TRY(hipMemcpyAsync(const_cast<uint32_t*>(mb), d_pos + m, 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(acc_first_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_pos, d_slot_first, n, d_acc_first);
     if (m) hipLaunchKernelGGL(slot_compact_kernel, dim3(blocks(m)), dim3(256), 0, st, d_pos, d_skeys_in, d_slot_first, n, m, d_live_keys, d_live_src, d_seg_of);
-    SR_TRY(hipStreamSynchronize(st));  // L
+    SR_TRY(hipStreamSynchronize(st));
+    const uint32_t L = mb[0];
     uint64_t leaf_bytes = 0;
     if (L) {
         SR_TRY(launch_keccak256_fixed(d_live_keys, 32, 32, L, d_hk, st));
         uint32_t* d_order = nullptr;
-        const int32_t rc = order_digests(st, d_hk, d_seg_of, L, n, d_sort, &d_order, err);
+        uint32_t* d_flag = nullptr;
+        int32_t rc = order_digests_async(st, d_hk, d_seg_of, L, n, d_sort, &d_order, &d_flag, err);
         if (rc) return rc;
-        hipLaunchKernelGGL(slot_leaf_len_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, L, d_len);
-        SR_TRY(launch_exclusive_scan_u32(d_len, L + 1u, d_scan, st));
-        uint32_t vb = 0;
-        SR_TRY(hipMemcpyAsync(&vb, d_len + L, 4, hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(slot_leaf_write_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, d_hk, d_len, L,
-                           d_lkeys, d_lkoff, d_lvals, d_lvoff);
-        SR_TRY(hipStreamSynchronize(st));  // vb
-        leaf_bytes = vb;
+        for (int pass = 0; pass < 2; ++pass) {  // (a second time only behind the host's ordering)
+            hipLaunchKernelGGL(slot_leaf_len_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, L, d_len);
+            SR_TRY(launch_exclusive_scan_u32(d_len, L + 1u, d_scan, st));
+            SR_TRY(hipMemcpyAsync(const_cast<uint32_t*>(mb), d_len + L, 4, hipMemcpyDeviceToHost, st));
+            SR_TRY(hipMemcpyAsync(const_cast<uint32_t*>(mb + 1), d_flag, 4, hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(slot_leaf_write_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, d_hk, d_len, L,
+                               d_lkeys, d_lkoff, d_lvals, d_lvoff);
+            SR_TRY(hipStreamSynchronize(st));
+            leaf_bytes = mb[0];
+            if (pass || !mb[1]) break;
+            if ((rc = order_on_host(st, d_hk, d_seg_of, L, d_order, err)) != PHANT_OK) return rc;
+            SR_TRY(hipMemsetAsync(d_flag, 0, 4, st));
+        }
     }
     int32_t rc = trie_forest_dev(ws, st, d_lkeys, d_lkoff, 32ull * L, d_lvals, d_lvoff, leaf_bytes, L, d_acc_first, n, d_sroots, err);
     if (rc) return rc;
@@ -340,18 +348,24 @@ int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, Dev
     SR_TRY(launch_keccak256_fixed(d_addrs, 20, 20, n, d_ha, st));
     SR_TRY(launch_keccak256_var(d_code, d_code_off, n, d_hc, st));
     uint32_t* d_aorder = nullptr;
-    rc = order_digests(st, d_ha, nullptr, n, 1, d_sort, &d_aorder, err);
+    uint32_t* d_aflag = nullptr;
+    rc = order_digests_async(st, d_ha, nullptr, n, 1, d_sort, &d_aorder, &d_aflag, err);
     if (rc) return rc;
-    hipLaunchKernelGGL(account_len_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_aorder, d_nonces, d_bal, n, d_alen);
-    SR_TRY(launch_exclusive_scan_u32(d_alen, n + 1u, d_scan, st));
-    uint32_t avb = 0;
-    SR_TRY(hipMemcpyAsync(&avb, d_alen + n, 4, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(account_write_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_aorder, d_nonces, d_bal, d_sroots, d_hc, d_ha, d_alen, n, out.keys,
-                       out.key_off, out.vals, out.val_off);
     const uint32_t seg[2] = {0u, n};
     SR_TRY(hipMemcpyAsync(out.seg, seg, sizeof seg, hipMemcpyHostToDevice, st));
-    SR_TRY(hipStreamSynchronize(st));  // avb, and `seg` may go
-    out.val_bytes = avb;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(account_len_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_aorder, d_nonces, d_bal, n, d_alen);
+        SR_TRY(launch_exclusive_scan_u32(d_alen, n + 1u, d_scan, st));
+        SR_TRY(hipMemcpyAsync(const_cast<uint32_t*>(mb), d_alen + n, 4, hipMemcpyDeviceToHost, st));
+        SR_TRY(hipMemcpyAsync(const_cast<uint32_t*>(mb + 1), d_aflag, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(account_write_kernel, dim3(blocks(n1)), dim3(256), 0, st, d_aorder, d_nonces, d_bal, d_sroots, d_hc, d_ha, d_alen, n, out.keys,
+                           out.key_off, out.vals, out.val_off);
+        SR_TRY(hipStreamSynchronize(st));  // (and `seg` may go)
+        out.val_bytes = mb[0];
+        if (pass || !mb[1]) break;
+        if ((rc = order_on_host(st, d_ha, nullptr, n, d_aorder, err)) != PHANT_OK) return rc;
+        SR_TRY(hipMemsetAsync(d_aflag, 0, 4, st));
+    }
     SR_TRY(hipGetLastError());
     return PHANT_OK;
 }

@@ -255,6 +255,41 @@ def test_state_root_orders_its_leaves_on_the_gpu(P, oracle, monkeypatch):
     assert P.state.state_root(one) == oracle.state_root(one)
 
 
+def test_state_root_above_half_a_million_keys_per_sort(P, oracle):
+    """The radix sort's digit table has one row per digit and a column per tile of 2 048 keys; its scan (radix_rows_kernel)
+    walks a row 256 columns at a time.  More than 524 288 keys make that loop go round: 600 000 accounts without storage
+    (the account sort), 150 000 accounts x 4 slots (the slot sort and the regrouping by account), both forms, against the
+    oracle fed the same arrays."""
+    import torch
+    from phant_amd.context import default_context, _np_ptr
+    ctx = default_context()
+    rng = np.random.default_rng(2024)
+    for n, k in ((600_000, 0), (150_000, 4)):
+        addrs = rng.integers(0, 256, (n, 20), dtype=np.uint8)
+        nonces = rng.integers(0, 1000, n).astype(np.uint64)
+        bal = np.zeros((n, 32), np.uint8)
+        bal[:, 24:] = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+        code = np.zeros(1, np.uint8)
+        code_off = np.zeros(n + 1, np.uint64)
+        sk = rng.integers(0, 256, (max(n * k, 1), 32), dtype=np.uint8)
+        sv = np.zeros((max(n * k, 1), 32), np.uint8)
+        sv[:, 20:] = rng.integers(1, 256, (max(n * k, 1), 12), dtype=np.uint8)
+        first = (np.arange(n + 1) * k).astype(np.uint32)
+        arrays = (addrs, nonces, bal, code, code_off, sk, sv, first)
+        want = np.zeros(32, np.uint8)
+        assert oracle.lib().oracle_state_root(*[_np_ptr(a) for a in arrays], n, _np_ptr(want)) == 0
+        got = np.zeros(32, np.uint8)
+        ctx.check(ctx._lib.phant_state_root(ctx.handle, *[_np_ptr(a) for a in arrays], n, _np_ptr(got)))
+        assert got.tobytes() == want.tobytes(), (n, k)
+        d = [torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda() for a in arrays]
+        root = torch.empty(32, dtype=torch.uint8, device="cuda")
+        ctx.check(ctx._lib.phant_state_root_dev(ctx.handle, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                                d[4].data_ptr(), 0, d[5].data_ptr(), d[6].data_ptr(), d[7].data_ptr(), n * k, n,
+                                                root.data_ptr()))
+        torch.cuda.synchronize()
+        assert root.cpu().numpy().tobytes() == want.tobytes(), (n, k)
+
+
 def test_state_root_edge_cases(P, oracle):
     """Zero-valued slots do not exist (statedb.zig:112-119): an account whose slots are all zero has the empty storage
     root; accounts without code / with a zero balance / nonce; the same slot twice in one account is refused (the storage
