@@ -11,10 +11,10 @@
 //                 wave with the same digit comes from eight ballots), the workgroup adds the waves' totals to the
 //                 scanned base, pairs go to their final place
 // The key of a leaf is the first 8 bytes of its hashed key, big-endian; leaves of several tries (the storage slots of
-// many accounts) are then regrouped by a second, equally stable sort on the trie index.  Two leaves of one trie whose
-// hashed keys share 64 bits can end up in the wrong order -- order_check_kernel compares every neighbouring pair in full
-// and raises a flag; the caller then orders that batch on the host, as before.  (Finding such keys costs an attacker
-// 2^32 hashes: the fallback has to be correct, not fast.)
+// many accounts) are then regrouped by a second, equally stable sort on the trie index.  Round 3 sorts on the first 32 key
+// bits only (four passes instead of eight) and repairs the runs that tie (tie_fix_kernel below); order_check_kernel compares
+// every neighbouring pair in full and raises a flag if anything is still out of order (a run too long to have come about by
+// chance, duplicate keys); the caller then orders that batch on the host, as before.
 //
 // HBM-bound byte shuffling; nothing here is GEMM-shaped.  Per pass: 12 n bytes read twice, written once.
 #include <hip/hip_runtime.h>
@@ -279,6 +279,52 @@ __global__ void __launch_bounds__(256) order_check_kernel(const uint8_t* __restr
     if (cmp >= 0) *flag = 1u;
 }
 
+// The sort orders on the first SORT_PREFIX_BITS bits of a key only: keys are Keccak outputs, so among a million of them ~10^2
+// pairs share 32 leading bits (n^2 / 2^33) and every pass not run is 30 us.  What ties is repaired here: lane i, if position i
+// starts a run of equal (segment, prefix) -- the stable passes left such a run contiguous --, sorts the run by the full 32
+// bytes (two or three items; insertion sort in place).  A run longer than TIE_CAP was made, not found: the flag, i.e. the
+// host's ordering.  order_check_kernel then passes judgement on the result as before.
+constexpr uint32_t SORT_PREFIX_BITS = 32;
+constexpr uint32_t TIE_CAP = 16;
+__device__ __forceinline__ int digest_cmp(const uint8_t* __restrict__ digests, uint32_t x, uint32_t y) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(digests + 32ull * x);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(digests + 32ull * y);
+    for (int wd = 0; wd < 8; ++wd) {
+        const uint32_t a = __builtin_bswap32(p[wd]), b = __builtin_bswap32(q[wd]);
+        if (a != b) return a < b ? -1 : 1;
+    }
+    return 0;
+}
+__global__ void __launch_bounds__(256) tie_fix_kernel(const uint8_t* __restrict__ digests, uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ seg_of, uint32_t n, uint32_t prefix_mask,
+                                                      uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    auto seg = [&](uint32_t k) { return seg_of ? seg_of[order[k]] : 0u; };
+    auto pre = [&](uint32_t k) { return __builtin_bswap32(*reinterpret_cast<const uint32_t*>(digests + 32ull * order[k])) & prefix_mask; };
+    const uint32_t s0 = seg(i), p0 = pre(i);
+    if (i > 0u && seg(i - 1u) == s0 && pre(i - 1u) == p0) return;  // inside a run: its first position repairs it
+    uint32_t len = 1;
+    while (i + len < n && len <= TIE_CAP && seg(i + len) == s0 && pre(i + len) == p0) ++len;
+    if (len == 1u) return;
+    if (len > TIE_CAP) {
+        *flag = 1u;
+        return;
+    }
+    uint32_t v[TIE_CAP];
+    for (uint32_t k = 0; k < len; ++k) v[k] = order[i + k];
+    for (uint32_t k = 1; k < len; ++k) {
+        const uint32_t x = v[k];
+        uint32_t m = k;
+        while (m > 0u && digest_cmp(digests, v[m - 1u], x) > 0) {
+            v[m] = v[m - 1u];
+            --m;
+        }
+        v[m] = x;
+    }
+    for (uint32_t k = 0; k < len; ++k) order[i + k] = v[k];
+}
+
 uint32_t sort_tiles(uint32_t n) { return (n + SORT_TILE - 1u) / SORT_TILE; }
 
 // stable sort of the pairs by key bits [lo, hi) (multiples of 8); the result ends up in (keys, vals) -- the pointers are
@@ -317,7 +363,7 @@ size_t order_workspace_bytes(uint32_t n) {
 
 // order[0..n): the items (digests d_digests[i], 32 bytes each) in ascending order of (seg_of[i], digest i); seg_of may be
 // null (one segment).  *d_flag (device, zeroed here) becomes nonzero if the result is NOT in that order (64-bit prefix
-// ties, duplicate keys): the caller must then order the batch another way.  prefix_bits < 64 (tests): sort on fewer bits.
+// ties, duplicate keys): the caller must then order the batch another way.  prefix_bits: 0 = the product's choice (see the launcher); tests pass other values.
 hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* ws,
                                 uint32_t** d_order_out, uint32_t** d_flag_out, uint32_t prefix_bits, hipStream_t st) {
     auto rnd = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -342,6 +388,12 @@ hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_
     }
     const uint32_t g = (n + 255u) / 256u;
     hipLaunchKernelGGL(digest_prefix_kernel, dim3(g), dim3(256), 0, st, d_digests, n, keys, vals);
+    // prefix_bits = 0: the product's choice, SORT_PREFIX_BITS with the ties repaired; anything else (tests): that many bits, ties left
+    // to the order check
+    // (top bit set -- tests again: that many bits WITH the repair, so that small states exercise it)
+    const bool repair = prefix_bits == 0u || (prefix_bits & 0x80000000u);
+    prefix_bits &= 0x7fffffffu;
+    if (prefix_bits == 0u) prefix_bits = SORT_PREFIX_BITS;
     const uint32_t bits = prefix_bits >= 64u ? 64u : (prefix_bits + 7u) / 8u * 8u;
     if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 64u - bits, 64u, hist, digit_totals, cur, st)) != hipSuccess) return e;
     if (d_seg_of && n_seg > 1u) {
@@ -350,6 +402,9 @@ hipError_t launch_order_digests(const uint8_t* d_digests, const uint32_t* d_seg_
         hipLaunchKernelGGL(segment_key_kernel, dim3(g), dim3(256), 0, st, vals, d_seg_of, n, keys);
         if ((e = sort_pairs(keys, vals, keys_alt, vals_alt, n, 0u, seg_bits, hist, digit_totals, cur, st)) != hipSuccess) return e;
     }
+    if (n > 1u && repair)
+        hipLaunchKernelGGL(tie_fix_kernel, dim3(g), dim3(256), 0, st, d_digests, vals, n_seg > 1u ? d_seg_of : (const uint32_t*)nullptr, n,
+                           bits >= 32u ? 0xffffffffu : ~(0xffffffffu >> bits), flag);
     if (n > 1u) hipLaunchKernelGGL(order_check_kernel, dim3((n - 1u + 255u) / 256u), dim3(256), 0, st, d_digests, vals, d_seg_of, n, flag);
     *d_order_out = vals;
     return hipGetLastError();

@@ -224,8 +224,9 @@ int32_t order_on_host(hipStream_t st, const uint8_t* d_digests, const uint32_t* 
 // prefixes: never, unless someone ground keys for it) means order_on_host and the work since then again.
 int32_t order_digests_async(hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* d_sort_ws,
                             uint32_t** d_order, uint32_t** d_flag, std::string& err) {
-    uint32_t prefix_bits = 64;
+    uint32_t prefix_bits = 0;  // (the sort's own choice; a number -- tests -- means that many bits and no repair of ties)
     if (const char* t = std::getenv("PHANT_SORT_PREFIX_BITS")) prefix_bits = (uint32_t)std::strtoul(t, nullptr, 10);
+    if (const char* t = std::getenv("PHANT_SORT_REPAIR_BITS")) prefix_bits = (uint32_t)std::strtoul(t, nullptr, 10) | 0x80000000u;  // (tests: few bits, ties repaired)
     SR_TRY(launch_order_digests(d_digests, d_seg_of, n, n_seg, d_sort_ws, d_order, d_flag, prefix_bits, st));
     return PHANT_OK;
 }

@@ -236,8 +236,8 @@ def _random_accounts(rng, n, max_slots):
 def test_state_root_orders_its_leaves_on_the_gpu(P, oracle, monkeypatch):
     """phant_state_root sorts hashed addresses and hashed slot keys on the device (radix_sort.hip: 64-bit prefixes, then a
     regrouping by account): accounts with many slots (several sort tiles, every digit pass populated) and many accounts,
-    against the oracle; and the same state with the device sort reduced to 8 / 16 key bits, where nearly every neighbour
-    ties, the order check raises its flag and the host orders the batch (the path a 64-bit prefix collision takes)."""
+    against the oracle; and the same state with the device sort reduced to 8 / 16 key bits and no repair of ties, where nearly
+    every neighbour ties, the order check raises its flag and the host orders the batch (the path an unrepairable collision takes)."""
     rng = np.random.default_rng(77)
     acc = _random_accounts(rng, 40, 700) + _random_accounts(rng, 2500, 3)
     want = oracle.state_root(acc)
@@ -251,6 +251,16 @@ def test_state_root_orders_its_leaves_on_the_gpu(P, oracle, monkeypatch):
         monkeypatch.setenv("PHANT_SORT_PREFIX_BITS", bits)
         assert P.state.state_root(acc) == want
     monkeypatch.delenv("PHANT_SORT_PREFIX_BITS")
+    # the product sorts on 32 prefix bits and repairs what ties (tie_fix_kernel): at 32 bits nothing in a test ever ties, so the
+    # repair is driven with 8 bits -- a few hundred slots per account and a few dozen accounts make runs of two to ten everywhere --
+    # and the device's order must still be the one that gives the oracle's root (no fallback allowed)
+    tied = _random_accounts(rng, 60, 300) + _random_accounts(rng, 40, 0)
+    monkeypatch.setenv("PHANT_SORT_NO_FALLBACK", "1")
+    monkeypatch.setenv("PHANT_SORT_REPAIR_BITS", "8")
+    assert P.state.state_root(tied) == oracle.state_root(tied)
+    monkeypatch.delenv("PHANT_SORT_NO_FALLBACK")
+    assert P.state.state_root(acc) == want                # runs longer than the repair takes on (2 540 accounts on 8 bits): fallback
+    monkeypatch.delenv("PHANT_SORT_REPAIR_BITS")
     one = _random_accounts(rng, 1, 5000)   # one account, one big storage trie
     assert P.state.state_root(one) == oracle.state_root(one)
 
