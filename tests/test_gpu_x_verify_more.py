@@ -94,3 +94,52 @@ def test_small_batches_are_hashed_whole_large_ones_in_two_tiers():
             assert (hashed == shipped) if whole else (hashed < shipped // 2), (n, hashed, shipped)
     finally:
         ctx.close()
+
+
+def _reordered(b, perm):
+    """The same proofs listed in another order (and possibly more than once): the node blob stays where it is, the
+    proofs' node indices are renumbered -- proof k of the new batch is proof perm[k] of the old one."""
+    from phant_amd.mpt import ProofBatch
+    pfn = b.proof_first_node.to(torch.int64)
+    cnt = (pfn[1:] - pfn[:-1])[perm]
+    new_pfn = torch.zeros(perm.numel() + 1, dtype=torch.int64, device=perm.device)
+    new_pfn[1:] = torch.cumsum(cnt, 0)
+    total = int(new_pfn[-1])
+    owner = torch.repeat_interleave(torch.arange(perm.numel(), device=perm.device), cnt)     # new proof of every new node
+    within = torch.arange(total, device=perm.device) - new_pfn[:-1][owner]
+    old_node = pfn[:-1][perm][owner] + within
+    # node_off is a prefix array over the nodes IN ORDER; a reordered batch needs explicit (begin, end) pairs, which the C-ABI
+    # does not have -- so the nodes are copied into the new order (bytes unchanged, offsets rebuilt)
+    lens = (b.node_off[1:] - b.node_off[:-1])[old_node]
+    new_off = torch.zeros(total + 1, dtype=torch.int64, device=perm.device)
+    new_off[1:] = torch.cumsum(lens, 0)
+    src = torch.repeat_interleave(b.node_off[:-1][old_node] - new_off[:-1], lens) + torch.arange(int(new_off[-1]), device=perm.device)
+    nodes = b.nodes[src]
+    root_idx = None if b.root_idx is None else b.root_idx[perm].contiguous()
+    return ProofBatch(b.roots, root_idx, b.keys[perm].contiguous(), nodes, new_off, new_pfn.to(torch.int32))
+
+
+def test_full_size_batches_in_another_order_and_twice(M):
+    """Size-independent properties at BASELINE's full sizes (no oracle needed: the first verification of each witness is
+    checked against the constructed expectation): the statuses of a batch do not depend on the ORDER its proofs are listed
+    in -- the deduplication elects whichever member of a group wrote its table slot last, a damaged copy included -- nor on
+    how often a proof is listed: config 3 (100 000 proofs, one root) and config 4's block witness (80 000 proofs, 2 001
+    roots), each shuffled, reversed, and config 3 with every proof listed twice (200 000 proofs; every deep node then has
+    a twin)."""
+    import phant_amd
+    if M.mode not in ("flat", "levels3", "nodedup"):
+        pytest.skip("the default pipeline, a forced tier split and the form without deduplication cover it")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+    for w in (phant_amd.witness.account_witness(100_000, depth=8, seed=2), phant_amd.witness.block_witness(seed=4)):
+        b = w.batch
+        n = b.n
+        base = M.verify_batch_dev(b).clone()
+        assert torch.equal(base, w.expected)
+        for perm in (torch.randperm(n, device="cuda", generator=g), torch.arange(n - 1, -1, -1, device="cuda")):
+            st = M.verify_batch_dev(_reordered(b, perm))
+            assert torch.equal(st, base[perm])
+        if b.n_roots == 1:
+            twice = torch.cat([torch.arange(n, device="cuda"), torch.randperm(n, device="cuda", generator=g)])
+            st = M.verify_batch_dev(_reordered(b, twice))
+            assert torch.equal(st, base[twice])
