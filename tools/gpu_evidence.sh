@@ -21,7 +21,8 @@ PY
 b config3 --cpu-seconds 8
 b config3_nodedup --no-cpu-baseline --no-strong --verify-mode nodedup
 b config3_fused --no-cpu-baseline --no-strong --verify-mode fused --steps 5
-b config3_1M --no-cpu-baseline --no-strong --proofs 1000000 --steps 5 --inner 4 --streams 2
+b config3_1M --no-cpu-baseline --no-strong --proofs 1000000 --steps 5 --inner 4
+b config3_four_in_flight --no-cpu-baseline --no-strong --streams 4
 b config4 --workload config4 --cpu-seconds 5
 b config4_nodedup --workload config4 --no-cpu-baseline --verify-mode nodedup
 b config2 --workload config2 --cpu-seconds 3
@@ -51,6 +52,7 @@ prof() {  # tag, env..., (BARGS)
 }
 BARGS="--streams 1" prof concurrent X=1
 BARGS="--streams 1" prof serial PHANT_VERIFY_SERIAL=1
+BARGS="--streams 2" prof streams2 X=1
 BARGS="--streams 4" prof streams4 X=1
 BARGS="--streams 1 --workload config4" prof config4 X=1
 ( cd /tmp && rm -rf /tmp/prof_t && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o p -- python $R/bench.py --workload mptize --no-cpu-baseline --steps 10 > "$OUT/prof_mptize.log" 2>&1 )
