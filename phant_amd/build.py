@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for s in SOURCES:
         o = os.path.join(obj_dir, s.replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(o)
-        cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -5,15 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// The CPU test suite compiles these sources for the host and, under AddressSanitizer, poisons the padding behind every
-// sub-allocation (its stand-in header); the library's own build has no hooks.
-#ifdef PHANT_HOST_EMU
-#include <hipemu/arena_hooks.h>
-#else
-#define PHANT_ARENA_POISON(p, n) ((void)(p), (void)(n))
-#define PHANT_ARENA_UNPOISON(p, n) ((void)(p), (void)(n))
-#define PHANT_ARENA_POISONS 0
-#endif
+#include <phant_platform.h>  // PHANT_ARENA_POISON / _UNPOISON: nothing in the library's own build
 
 namespace phant {
 

@@ -25,13 +25,10 @@
 
 #include "../../include/phant_gpu.h"
 
-// RCCL's names and entry points (resolved at run time) and one host thread per device: comm_host.h.  The CPU test suite
-// compiles this file for the host against a stand-in of that header (an in-process sum, devices one after the other).
-#ifdef PHANT_HOST_EMU
-#include <hipemu/comm_host.h>
-#else
-#include "comm_host.h"
-#endif
+// RCCL's names and entry points (resolved at run time) and one host thread per device: comm_host.h (the CPU test suite's
+// phant_platform.h names a stand-in: an in-process sum, devices one after the other).
+#include <phant_platform.h>
+#include PHANT_COMM_HOST_HEADER
 
 struct phant_ctx;
 namespace phant {

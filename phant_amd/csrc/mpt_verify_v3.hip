@@ -53,6 +53,8 @@
 // src/mpt/mpt.zig:187-193,216-231,254-261,285-314.
 #include <cstdlib>
 
+#include <phant_platform.h>
+
 #include "launch.h"
 #include "mpt_verify_one.hip.h"
 
@@ -291,11 +293,6 @@ PHANT_DEV bool wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint32_t len
 }
 
 constexpr int COMPARE_UNROLL = 4;  // steps in flight per wave: 2 x COMPARE_UNROLL nodes
-#ifdef __HIPCC__
-#define PHANT_NUM_VGPR(n) __attribute__((amdgpu_num_vgpr(n)))
-#else
-#define PHANT_NUM_VGPR(n)  // (a register budget means nothing to a host compiler)
-#endif
 
 // One lane per (proof, d < S), as propose_kernel.  The lane reads its group's slot back: the node found there is the
 // group's representative (every member reads the same slot after propose_kernel has finished, so the representative's

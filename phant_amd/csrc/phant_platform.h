@@ -1,0 +1,28 @@
+// phant_platform.h -- the few places where the kernel sources name the compiler or the build they are part of, in ONE
+// header.  libphant_gpu.so is built with this file (hipcc, gfx950; `-I phant_amd/csrc`, included as <phant_platform.h>).
+// The CPU test suite compiles the same sources for the host and puts its own header of this name first on the include
+// path (tests/native/shim/phant_platform.h): no source under csrc/ tests a macro to find out which build it is in.
+#pragma once
+
+// a register budget for a kernel (dedup_kernel runs next to hash waves: its allocation decides how many of its waves fit)
+#define PHANT_NUM_VGPR(n) __attribute__((amdgpu_num_vgpr(n)))
+
+// "this value is needed HERE": without it the scheduler sinks a cheap computation past a Keccak-f and keeps its inputs
+// (a rate block's marker dwords) in registers across the permutation -- 13 VGPRs in the hash kernels.
+#define PHANT_PIN_SGPR(x) asm volatile("" : "+s"(x))
+#define PHANT_PIN_VGPR(x) asm volatile("" : "+v"(x))
+
+// arena.h: hooks for a sanitizer build (none here)
+#define PHANT_ARENA_POISON(p, n) ((void)(p), (void)(n))
+#define PHANT_ARENA_UNPOISON(p, n) ((void)(p), (void)(n))
+#define PHANT_ARENA_POISONS 0
+
+// comm.hip: RCCL's names and entry points and one host thread per device
+#define PHANT_COMM_HOST_HEADER "comm_host.h"
+
+// LDS-DMA: 16 bytes per lane from a global address of the lane's own straight into LDS at `lds_wave_base` + 16 x (lane of the
+// wave) (global_load_lds_dwordx4: no VGPRs; `lds_wave_base` wave-uniform), and the wait for everything a wave has in flight.
+#define PHANT_LDS_DMA16(gsrc, lds_wave_base)                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),             \
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+#define PHANT_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")

@@ -21,7 +21,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         s_path = os.path.join(d, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I",
-                               os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", s_path, src],
+                               os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "phant_amd", "csrc"), "-S", "--cuda-device-only", "-o", s_path, src],
                               stderr=subprocess.DEVNULL)
         lines = open(s_path).read().splitlines()
     start = [i for i, l in enumerate(lines) if re.match(r"^_Z\w*%s\w*:" % re.escape(kernel), l)][0]
