@@ -55,6 +55,8 @@
 
 #include <phant_platform.h>
 
+#include <phant_platform.h>
+
 #include "launch.h"
 #include "mpt_verify_one.hip.h"
 
