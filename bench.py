@@ -45,6 +45,7 @@ stream) and, at N = 1, `cpu_baseline` (the CPU oracle timed on this host).
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -119,9 +120,11 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="config3: independent batches in flight, each on its own ctx + HIP stream (a validator "
                          "verifying consecutive witnesses); 1 = strictly one launch sequence after the other")
-    ap.add_argument("--allreduce-every", type=int, default=0,
+    ap.add_argument("--allreduce-every", type=int, default=1,
                     help="N > 1: a slot's per-root verdicts are exchanged once per this many passes, as one all-reduce of a "
-                         "(passes x roots) block on a stream of its own (default 0 = once per timed step = --inner passes)")
+                         "(passes x roots) block on a stream of its own (default 1: a verdict per witness, what a validator needs; "
+                         "rounds 1-3 of this repository batched --inner = 30 passes per exchange: their N > 1 figures are not "
+                         "comparable)")
     ap.add_argument("--comm", action="store_true",
                     help="the in-process form of the multi-GPU path: ONE process, every visible device behind one phant_comm "
                          "(phant_comm_ctx + phant_mpt_verify_verdict_dev per device, one phant_comm_allreduce_verdict per pass); "
@@ -129,11 +132,15 @@ def parse():
     ap.add_argument("--comm-devices", type=int, default=0, help="--comm: devices to use (default 0 = all visible)")
     ap.add_argument("--messages", type=int, default=1 << 20, help="config2: 136-byte messages per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-seconds", type=int, default=1500,
+                    help="wall-clock guard: past this the process prints a JSON line with \"error\" (rank 0) and exits with rc 4 "
+                         "instead of hanging (a rendezvous or RCCL initialisation that never completes)")
+    ap.add_argument("--rendezvous-seconds", type=int, default=180, help="N > 1: timeout of the process-group rendezvous and of every collective")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def cpu_baseline_config3(w, target_seconds):
+def cpu_baseline_config3(w, target_seconds, gpu_status=None):
     """The CPU oracle (restatement of the reference's scalar path) on a bounded sample of the same
     workload, 1 core -- phant's MPT code is single-threaded."""
     import numpy as np
@@ -167,10 +174,16 @@ def cpu_baseline_config3(w, target_seconds):
             ok = ok and bool((st2 == st).all())
             dt += dt2
             passes += 1
+    # the checker's statuses against what the TIMED launches wrote (slot 0's last pass over this witness), not only
+    # against the generator's expectation
+    gpu_ok = None
+    if gpu_status is not None:
+        gpu_ok = bool((st == gpu_status[:cnt]).all())
     out = {"value": cnt * passes / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
            "sample": f"first {cnt} of the {n} config-3 proofs{' x %d passes' % passes if passes > 1 else ''}, "
                      f"oracle/verify.c single-threaded, {dt:.1f} s",
-           "host_cpus": os.cpu_count(), "statuses_match_gpu_expected": ok}
+           "host_cpus": os.cpu_count(), "statuses_match_gpu_expected": ok, "oracle_checked": gpu_ok is not None,
+           "oracle_matches_timed_gpu_statuses": gpu_ok, "oracle_checked_proofs": cnt if gpu_ok is not None else 0}
     # the same scalar code on all host cores, one slice of proofs per thread (ctypes releases the GIL);
     # phant itself is single-threaded, so this is the generous reading of "the CPU path"
     try:
@@ -296,7 +309,7 @@ def device_id_bytes(dev):
         raw = b""
     if len(raw) != 16:
         import hashlib
-        raw = hashlib.sha256(f"{os.uname().nodename}:{getattr(dev, 'index', 0)}".encode()).digest()[:16]
+        raw = hashlib.sha256(f"{os.uname().nodename}:{getattr(dev, 'index', 0)}:{os.environ.get('LOCAL_RANK', '0')}".encode()).digest()[:16]
     return torch.tensor(list(raw), dtype=torch.uint8, device=dev)
 
 
@@ -311,6 +324,31 @@ STRONG_EXPECTED = {"basis": "one GPU, 10 000 proofs per launch (what a rank of 8
                    "speedup_upper_bound_at_8_gpus": {"four_in_flight": round(8 * 282 / 515, 1), "one_at_a_time": round(8 * 134 / 400, 1)},
                    "why": "a rank's share of one block falls under the latency floor of a launch (the S = 0 form); the verdict "
                           "exchange (2 001 x 4 B) is latency-bound as well"}
+
+
+# one GPU's measured rate (M proofs/s, launches in flight) at the number of block-witness proofs a rank holds: profiles/r2_d/
+# small_batches_direct_walk.jsonl, block_witness_scale_vs_levels.jsonl, profiles/r3_final/bench_config4.json
+_RATE_POINTS = [(8_000, 276e6), (10_000, 282e6), (16_000, 352e6), (24_000, 368e6), (80_000, 520e6)]
+
+
+def strong_predicted(total_proofs, world, value):
+    """What N GPUs can reach on ONE block witness if nothing but the per-launch latency floor limits a rank: N x the
+    single-GPU rate at total / N proofs per launch (piecewise linear between the measured points)."""
+    per = total_proofs / world
+    pts = _RATE_POINTS
+    if per <= pts[0][0]:
+        rate = pts[0][1] * per / pts[0][0]
+    elif per >= pts[-1][0]:
+        rate = pts[-1][1]
+    else:
+        for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+            if x0 <= per <= x1:
+                rate = y0 + (y1 - y0) * (per - x0) / (x1 - x0)
+                break
+    ceiling = rate * world
+    return {"n_gpus": world, "proofs_per_rank": per, "ceiling_proofs_per_s": ceiling, "value_over_ceiling": value / ceiling,
+            "note": "ceiling = n_gpus x (one GPU's measured rate at proofs_per_rank per launch); read `value` against THIS, not "
+                    "against n_gpus x the N = 1 value: a rank's share of one block falls under the latency floor of a launch"}
 
 
 def run_comm_bench(args):
@@ -373,7 +411,7 @@ def run_comm_bench(args):
         assert int(fails.sum().item()) == want, (int(fails.sum().item()), want)
     passes = steps * inner
     line = {"metric": "mpt_proofs_verified_per_sec_block_witness", "value": total * passes / elapsed, "unit": "proofs/s",
-            "n_gpus": D, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / passes * 1e3, "higher_is_better": True,
+            "n_gpus": D, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "ms_per_pass": elapsed / passes * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"config4 through phant_comm: one synthetic {int(10000 * args.block_scale)}-tx block witness "
                                    f"({total} account + storage proofs, {n_roots} roots) split over {D} device(s) of ONE process, "
@@ -439,7 +477,7 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
 
     n_wit = max(S, 2)
     wits = [make_witness(k) for k in range(n_wit)]
-    K = max(1, args.allreduce_every or inner)  # passes per verdict exchange
+    K = max(1, min(args.allreduce_every, inner))  # passes per verdict exchange (1: a verdict per witness, what a validator needs)
     w0 = wits[0]
     n_units = w0.batch.n
     for w in wits:
@@ -466,6 +504,7 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     # kernels and stream waits between that slot's launches -- and the hardware queues are a scarce resource here (DESIGN.md
     # section 7.5: a ninth stream / a second set of slot streams cost 10-20 %).
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    wrote = [[[False] * K for _ in range(2)] for _ in range(S)]   # rows of the verdict blocks a pass has written
     filled = [0] * S                       # passes written into the slot's current block
     block_of = [0] * S                     # which block that is
     reduced_ev = [[None, None] for _ in range(S)]   # event behind the last exchange of block b of slot k
@@ -496,6 +535,7 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
         with torch.cuda.stream(st_):
             # statuses + per-root verdict of this pass
             M.verify_batch_dev(w_.batch, status=status_, ctx=c_, fail_count=fails_[block_of[k], filled[k]])
+        wrote[k][block_of[k]][filled[k]] = True
         filled[k] += 1
         if filled[k] == K:
             exchange(k)
@@ -542,9 +582,14 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
         want = torch.tensor([w_.n_invalid], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(want)
+        # every row a pass wrote holds exactly the witness's failures (zero included); nothing else was touched
+        mask = torch.tensor(wrote[k], dtype=torch.bool, device=dev).reshape(-1)
         rows = fails_.sum(dim=2).reshape(-1)
-        rows = rows[rows != 0] if int(want.item()) else rows[:0]
-        assert rows.numel() == 0 or bool((rows == int(want.item())).all()), (rows[:8].tolist(), int(want.item()))
+        assert bool(mask.any()), "no verdict row was written"
+        assert bool((rows[mask] == int(want.item())).all()), (rows[mask][:8].tolist(), int(want.item()))
+        assert bool((rows[~mask] == 0).all()), "a verdict row nobody wrote is not zero"
+
+    timed_status0 = slots[0][2].cpu().numpy().copy()  # slot 0's last timed pass over wits[0] (the buffer is reused below)
 
     # the same number of passes strictly one after the other on ONE stream, alternating between two witnesses
     barrier()
@@ -607,9 +652,9 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
             kernels = acc
             cs.close()
     passes = steps * inner
-    out = {"wits": wits, "kernels": kernels, "tiers": tiers, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
+    out = {"wits": wits, "status0": timed_status0, "kernels": kernels, "tiers": tiers, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
            "value": n_units * world * passes / elapsed,
-           "single": {"value": n_units * world * passes / e1, "ms_per_step": e1 / passes * 1e3},
+           "single": {"value": n_units * world * passes / e1, "ms_per_pass": e1 / passes * 1e3, "ms_per_step": e1 / steps * 1e3},
            "k_avg_ms": k_evt_ms, "k_synced_ms": sum(kms) / len(kms), "k_min_ms": min(kms), "hashed": hashed,
            "verdict_exchange": {"passes_per_allreduce": K, "allreduces_on_this_rank": exchanged["n"],
                                 "stream": "own (event-fed)" if world > 1 else None}}
@@ -627,6 +672,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def give_up(msg, rc):
+        # never a hang, never a silent death: the driver gets a line it can parse and a non-zero exit code
+        if rank == 0:  # (straight to fd 1: nothing buffered is lost by the _exit below)
+            os.write(1, (json.dumps({"metric": "mpt_proofs_verified_per_sec_depth%d" % args.depth, "value": None, "unit": "proofs/s",
+                                     "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "error": msg}) + "\n").encode())
+        sys.stderr.write(f"bench.py rank {rank}: {msg}\n")
+        sys.stderr.flush()
+        os._exit(rc)
+
+    if args.max_seconds > 0:
+        # a thread, not SIGALRM: a Python signal handler does not run while the main thread sits inside a blocking C call
+        # (a collective that never completes, a stream synchronisation on a hung device)
+        import threading
+        guard = threading.Timer(args.max_seconds, lambda: give_up(f"wall-clock guard: not finished after {args.max_seconds} s", 4))
+        guard.daemon = True
+        guard.start()
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if world != args.gpus:
@@ -640,12 +702,19 @@ def main():
     rccl_world = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        # who is in the job: every rank's device, gathered over the same backend the verdicts will take -- N distinct
-        # UUIDs = N GPUs really took part
-        mine = device_id_bytes(dev)
-        ids = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(ids, mine)
+        try:
+            # (RCCL; the CPU test suite drives the same code over gloo with torch.cuda stubbed out: tests/test_bench_emulated.py)
+            backend = os.environ.get("PHANT_BENCH_BACKEND", "nccl")
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=args.rendezvous_seconds),
+                                    **({"device_id": dev} if backend == "nccl" else {}))
+            # who is in the job: every rank's device, gathered over the same backend the verdicts will take -- N distinct
+            # UUIDs = N GPUs really took part (the first collective: RCCL builds its communicator here)
+            mine = device_id_bytes(dev)
+            ids = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(ids, mine)
+            torch.cuda.synchronize()
+        except Exception as e:  # rendezvous timed out, RCCL could not build the communicator, ...
+            give_up(f"process group / RCCL initialisation failed: {type(e).__name__}: {e}", 3)
         uu = [bytes(t.cpu().tolist()).hex() for t in ids]
         rccl_world = {"ranks": world, "distinct_devices": len(set(uu)), "device_ids": uu, "backend": dist.get_backend()}
 
@@ -680,7 +749,9 @@ def main():
         b = w.batch
         n_units, elapsed, value, single, k_avg_ms = r["n_units"], r["elapsed"], r["value"], r["single"], r["k_avg_ms"]
         alg_bytes = b.algorithmic_bytes()
-        ms_per_step = r["ms_per_pass"]
+        ms_per_pass = r["ms_per_pass"]
+        ms_per_step = ms_per_pass * inner
+        timed_status0 = r["status0"]
         if args.workload == "config3":
             metric, unit = "mpt_proofs_verified_per_sec_depth%d" % args.depth, "proofs/s"
             workload = (f"config3: {args.proofs} synthetic depth-{args.depth} account proofs per GPU against one "
@@ -733,13 +804,14 @@ def main():
                                   f"({total_proofs} account + storage proofs, {w4.batch.n_roots} roots) split over "
                                   f"{world} GPU(s)", "scaling": "strong", "metric": "mpt_proofs_verified_per_sec_block_witness",
                       "value": total_proofs * r4["passes"] / r4["elapsed"], "unit": "proofs/s",
-                      "ms_per_step": r4["ms_per_pass"], "proofs_on_rank0": r4["n_units"],
-                      "single_stream": {"value": total_proofs * r4["passes"] / (r4["single"]["ms_per_step"] * 1e-3 * r4["passes"]),
-                                        "ms_per_step": r4["single"]["ms_per_step"]},
+                      "ms_per_pass": r4["ms_per_pass"], "ms_per_step": r4["ms_per_pass"] * inner, "proofs_on_rank0": r4["n_units"],
+                      "single_stream": {"value": total_proofs * r4["passes"] / (r4["single"]["ms_per_pass"] * 1e-3 * r4["passes"]),
+                                        "ms_per_pass": r4["single"]["ms_per_pass"]},
                       "kernel_avg_ms": r4["k_avg_ms"],
                       "roofline_frac": w4.batch.algorithmic_bytes() / (r4["k_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "nodes_hashed": int(sum(r4["hashed"])), "nodes_shipped": int(w4.batch.node_off.numel() - 1),
                       "verdict_exchange": r4["verdict_exchange"], "expected": STRONG_EXPECTED}
+            strong["predicted"] = strong_predicted(total_proofs, world, strong["value"])
             del r4
     elif args.workload == "nodeset":
         w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
@@ -877,7 +949,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         value = n_units * world * args.steps * inner / elapsed
-        ms_per_step = elapsed / (args.steps * inner) * 1e3
+        ms_per_pass = elapsed / (args.steps * inner) * 1e3
+        ms_per_step = ms_per_pass * inner
 
         # correctness of what was timed
         if args.workload == "nodeset":
@@ -912,7 +985,7 @@ def main():
                 "integer-VALU-bound, see roofline.valu)")
     line = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_pass": ms_per_pass, "higher_is_better": True,
         "scaling": "strong" if args.workload == "config4" else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload, "units_per_gpu_per_step": n_units, "parallelism": f"key-sharded x{world}",
                    **({"parity_basis": "derived: the reference has no verifier (TODO at src/engine_api/execution_payload.zig:177-178), "
@@ -923,7 +996,9 @@ def main():
                    "verify_mode": args.verify_mode if proofs_like else None,
                    "dedup_levels": (args.dedup_levels if proofs_like else None),
                    "streams": (S if proofs_like else 1), "passes_per_timed_step": inner,
-                   "timed_region_ms": ms_per_step * args.steps * inner},
+                   "timed_region_ms": ms_per_step * args.steps,
+                   "step": f"a timed step = {inner} back-to-back pass(es) of the path over a resident batch; ms_per_step x steps = the "
+                           "timed region, ms_per_pass = one pass (`value` = units per pass / ms_per_pass)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "throughput_GBps": value / world * alg_bytes / n_units / 1e9,  # algorithmic bytes x the measured
@@ -959,7 +1034,7 @@ def main():
         elif args.workload == "config5" and not args.stream_proofs:
             line["cpu_baseline"] = cpu_baseline_block(w, args.cpu_seconds)
         elif args.workload in ("config3", "config5", "nodeset"):
-            line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds, timed_status0 if args.workload == "config3" else None)
         else:
             line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)
     if rccl_world is not None:

@@ -12,6 +12,7 @@ namespace phant {
 struct DevArena {
     uint8_t* base = nullptr;
     size_t cap = 0, used = 0;
+    bool overflowed = false;  // a take() beyond what reset() made room for (answered with nullptr)
 
     static size_t round(size_t n) { return (n + 255) / 256 * 256; }
 
@@ -19,6 +20,7 @@ struct DevArena {
     // Contents are dropped; the caller guarantees no kernel still uses them.
     hipError_t reset(size_t total) {
         used = 0;
+        overflowed = false;
         if (base) PHANT_ARENA_UNPOISON(base, cap);
         if (total <= cap) return hipSuccess;
         if (base) {
@@ -33,10 +35,16 @@ struct DevArena {
         cap = want;
         return hipSuccess;
     }
+    // nullptr when the arena was not reset for this much (a sizing bug upstream: the caller turns it into PHANT_E_DEVICE
+    // instead of handing a kernel memory behind the allocation)
     template <class T>
     T* take(size_t count) {
-        T* p = reinterpret_cast<T*>(base + used);
         const size_t bytes = count * sizeof(T), dwords = (bytes + 3) / 4 * 4;  // (device loads are dword-granular)
+        if (!base || round(bytes) > cap - used) {
+            overflowed = true;
+            return nullptr;
+        }
+        T* p = reinterpret_cast<T*>(base + used);
         PHANT_ARENA_POISON(base + used + dwords, round(bytes) - dwords);
         used += round(bytes);
         return p;

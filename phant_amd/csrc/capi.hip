@@ -290,11 +290,12 @@ int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
 int32_t phant_verify_kernel_ms(phant_ctx* c, float ms[5]) {
     if (!c || !ms) return PHANT_E_INVALID_ARG;
     if (!c->tune.kernel_ev) return fail(c, PHANT_E_UNSUPPORTED, "verify_kernel_ms: the ctx was not created under PHANT_VERIFY_SERIAL=1");
+    // (the events hold the LAST launch that recorded them: if the latest verify took the S = 0 form they are an earlier one's)
+    if (!c->kev_valid) return fail(c, PHANT_E_INVALID_ARG, "verify_kernel_ms: the last verify launch on this ctx was not a two-tier one");
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 5; ++i) {
         ms[i] = 0.f;
-        // (a launch that took the S = 0 form, or none yet: the events were never recorded)
         if (hipEventElapsedTime(&ms[i], c->kev[i], c->kev[i + 1]) != hipSuccess) {
             (void)hipGetLastError();
             return fail(c, PHANT_E_INVALID_ARG, "verify_kernel_ms: no two-tier launch on this ctx yet");
@@ -530,6 +531,9 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
     } else {
         HIP_TRY(c, launch());
     }
+    // phant_verify_kernel_ms reads the per-kernel events of THIS launch or nothing: a launch that took the S = 0 form (or ran
+    // the tiers next to each other) recorded none
+    if (&dv == &c->dv) c->kev_valid = c->tune.serial && c->tune.kernel_ev && c->last_shallow != 0u;
     return PHANT_OK;
 }
 

@@ -5,7 +5,26 @@
 // links and loads without it, a single-device comm never needs it.
 #pragma once
 #include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>  // ncclComm_t, ncclResult_t, ncclUint32, ncclSum ... (no symbol of it is linked)
+#else
+// A ROCm installation without RCCL's development headers still builds the library (a single-device comm never needs RCCL):
+// the handful of names comm.hip uses, as rccl.h 2.x declares them.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
+                           hipStream_t stream);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <string>
 #include <thread>

@@ -256,6 +256,10 @@ struct StateIn {
     uint64_t code_bytes;
 };
 
+// what state_subtrie_nodes_host takes on top: 16 x (root 32 + length 4 + encoding <= SUBTRIE_CAP_MAX) bytes and a flag line
+constexpr uint32_t SUBTRIE_CAP_MAX = 256;
+constexpr size_t SUBTRIE_OUT_BYTES = 16u * (36u + SUBTRIE_CAP_MAX) + 64u;
+
 size_t state_scratch_bytes(uint32_t n, uint32_t m) {
     const size_t n1 = (size_t)n + 1, m1 = (size_t)m + 1;
     auto R = [](size_t b) { return DevArena::round(b); };
@@ -263,7 +267,8 @@ size_t state_scratch_bytes(uint32_t n, uint32_t m) {
     const size_t scan_entries = scan_scratch_entries((m > n ? m : n) + 1u);
     return R(4 * n1) + R(4 * m1) + R(32 * (size_t)m + 16) + 2 * R(4 * (size_t)m + 4) + R(32 * (size_t)m + 16) + R(sort_ws) + R(4 * m1) +
            R(32 * (size_t)m + 16) + R(4 * m1) + R(33 * (size_t)m + 16) + R(8 * m1) + R(32 * (size_t)n) + 2 * R(32 * (size_t)n) + R(4 * n1) +
-           R(32 * (size_t)n + 16) + R(4 * n1) + R(112 * (size_t)n + 16) + R(8 * n1) + R(4 * scan_entries) + R(17 * 4) + 8192;
+           R(32 * (size_t)n + 16) + R(4 * n1) + R(112 * (size_t)n + 16) + R(8 * n1) + R(4 * scan_entries) + R(17 * 4) +
+           R(SUBTRIE_OUT_BYTES) + 8192;
 }
 
 // device-resident inputs -> the state trie's leaves in device memory (scratch from ws.io, which the caller has reset to
@@ -511,17 +516,21 @@ int32_t state_subtrie_nodes_host(Workspaces& ws, hipStream_t st, const uint8_t* 
                                  const uint8_t* code, const uint64_t* code_off, const uint8_t* slot_keys, const uint8_t* slot_vals,
                                  const uint32_t* slot_first, uint32_t n, uint8_t* roots, uint8_t* enc, uint32_t cap, uint32_t* enc_len,
                                  std::string& err) {
+    if (cap > SUBTRIE_CAP_MAX) {  // (before anything is done or written)
+        err = "state_subtrie_nodes: cap > 256";
+        return PHANT_E_INVALID_ARG;
+    }
     std::memset(enc_len, 0, 16 * sizeof(uint32_t));
     if (n == 0) return PHANT_OK;
     DevLeaves l;
     int32_t rc = state_leaves_dev(ws, st, addrs, nonces, balances, code, code_off, slot_keys, slot_vals, slot_first, n, l, err);
     if (rc) return rc;
-    if (cap > 256u) {
-        err = "state_subtrie_nodes: cap > 256";
-        return PHANT_E_INVALID_ARG;
-    }
     hipLaunchKernelGGL(nibble_segments_kernel, dim3(1), dim3(64), 0, st, l.keys, n, l.seg);
-    uint8_t* d_out = ws.io.take<uint8_t>(16u * (36u + cap) + 64u);  // (inside the slack state_scratch_bytes leaves)
+    uint8_t* d_out = ws.io.take<uint8_t>(16u * (36u + cap) + 64u);  // (SUBTRIE_OUT_BYTES of state_scratch_bytes)
+    if (!d_out) {
+        err = "state_subtrie_nodes: scratch arena too small";
+        return PHANT_E_DEVICE;
+    }
     return trie_forest_nodes_dev(ws, st, l.keys, l.key_off, 32ull * n, l.vals, l.val_off, l.val_bytes, n, l.seg, 16, d_out, roots, enc, cap,
                                  enc_len, err);
 }

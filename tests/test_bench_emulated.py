@@ -78,7 +78,7 @@ def _no_cuda():
          phant_amd.Context, torch.cuda.Event) = saved
 
 
-def _bench(argv):
+def _bench(argv, allow_no_line=False):
     sys.path.insert(0, ROOT)
     import bench
     old = sys.argv
@@ -90,15 +90,22 @@ def _bench(argv):
     finally:
         sys.argv = old
     lines = [ln for ln in out.getvalue().splitlines() if ln.startswith("{")]
+    if allow_no_line and not lines:  # (a rank other than 0)
+        return None
     assert len(lines) == 1, out.getvalue()
     return json.loads(lines[0])
 
 
 def _check_contract(line, steps, warmup):
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_pass", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["steps"] == steps and line["warmup"] == warmup
+    # ms_per_step is what its name says: steps x ms_per_step = the timed region; a step is `passes_per_timed_step` passes
+    c = line["config"]
+    assert abs(line["ms_per_step"] * steps - c["timed_region_ms"]) <= 1e-9 * max(1.0, c["timed_region_ms"])
+    assert abs(line["ms_per_pass"] * c["passes_per_timed_step"] - line["ms_per_step"]) <= 1e-9 * max(1.0, line["ms_per_step"])
+    assert abs(line["value"] - c["units_per_gpu_per_step"] / (line["ms_per_pass"] * 1e-3)) <= 1e-6 * line["value"]
     assert line["vs_baseline"] is None and line["higher_is_better"] is True and "workload" in line["config"]
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
@@ -115,6 +122,9 @@ def test_config3_dry_run(mode, streams, inner):
     assert line["scaling"] == "weak" and line["config"]["streams"] == streams
     assert line["config"]["passes_per_timed_step"] == inner
     assert line["cpu_baseline"]["statuses_match_gpu_expected"] is True
+    # the checker's statuses against what the TIMED launches wrote, over the whole batch
+    cb = line["cpu_baseline"]
+    assert cb["oracle_checked"] is True and cb["oracle_matches_timed_gpu_statuses"] is True and cb["oracle_checked_proofs"] == 300
     assert line["single_stream"]["value"] > 0
     if mode != "fused":
         assert 0 < line["roofline"]["nodes_hashed"] <= line["roofline"]["nodes_shipped"] == 300 * 8
@@ -122,6 +132,9 @@ def test_config3_dry_run(mode, streams, inner):
         st = line["strong"]
         assert st["scaling"] == "strong" and st["value"] > 0 and st["proofs_on_rank0"] == 1080
         assert 0 < st["nodes_hashed"] <= st["nodes_shipped"]
+        # the predicted ceiling a SCALE reader should hold `value` against sits next to it
+        pr = st["predicted"]
+        assert pr["n_gpus"] == 1 and pr["ceiling_proofs_per_s"] > 0 and abs(pr["value_over_ceiling"] - st["value"] / pr["ceiling_proofs_per_s"]) < 1e-9
     else:
         assert "strong" not in line
 
@@ -245,12 +258,15 @@ def test_two_ranks_dry_run(argv):
     assert line["rccl_world"]["ranks"] == 2 and len(line["rccl_world"]["device_ids"]) == 2
     ex = line["roofline"]["verdict_exchange"]
     inner = int(argv[argv.index("--inner") + 1])
-    assert ex["passes_per_allreduce"] == (2 if "--allreduce-every" in argv else inner) and ex["allreduces_on_this_rank"] > 0
+    # a verdict per witness by default (rounds 1-3 batched `inner` passes per exchange)
+    assert ex["passes_per_allreduce"] == (min(2, inner) if "--allreduce-every" in argv else 1) and ex["allreduces_on_this_rank"] > 0
     if "config4" in argv:
         assert line["scaling"] == "strong"
     elif "--no-strong" not in argv:
         # what a SCALE run reads: the strong-scaling config-4 figure next to the weak config-3 one
         assert line["strong"]["scaling"] == "strong" and line["strong"]["value"] > 0
+        # ... with the ceiling two GPUs can reach on ONE block witness next to it
+        assert line["strong"]["predicted"]["n_gpus"] == 2 and line["strong"]["predicted"]["ceiling_proofs_per_s"] > 0
 
 
 def test_comm_form_dry_run():
@@ -281,3 +297,46 @@ def test_smoke_dry_run(capsys):
     finally:
         torch.cuda.is_available, torch.cuda.current_device = saved
     assert "smoke OK" in capsys.readouterr().out
+
+
+# ---------------------------------------------------------------- N > 1 without the hardware
+_RANK_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+from tests import emu
+import tests.test_bench_emulated as T
+g = emu.emulated_backend()
+next(g)
+line = None
+try:
+    line = T._bench({argv!r}, allow_no_line=True)
+finally:
+    try:
+        next(g)
+    except StopIteration:
+        pass
+if line is not None:
+    print("LINE " + json.dumps(line), flush=True)
+"""
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_a_rank_that_never_shows_up_ends_in_an_error_line_not_a_hang():
+    """WORLD_SIZE=2 with only rank 0 started: the rendezvous times out, rank 0 prints a JSON line with "error" and exits non-zero."""
+    import subprocess
+    port = _free_port()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               PHANT_BENCH_BACKEND="gloo")
+    argv = ["--gpus", "2", "--proofs", "100", "--steps", "1", "--warmup", "0", "--rendezvous-seconds", "5", "--max-seconds", "60",
+            "--no-cpu-baseline", "--no-strong"]
+    p = subprocess.run([sys.executable, "-c", _RANK_SCRIPT.format(root=ROOT, argv=argv)], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode in (3, 4), (p.returncode, p.stderr[-2000:])
+    err_lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(err_lines) == 1 and err_lines[0]["error"] and err_lines[0]["value"] is None and err_lines[0]["n_gpus"] == 2
