@@ -30,7 +30,7 @@ try:
     d=json.load(open(f'gpurun_out/ab/{l}.json')); r=d.get('roofline',{}); k=r.get('kernels',{})
     ks=' '.join(f"{n.split('_kernel')[0]}={v['ms']*1e3:.0f}" for n,v in k.items() if isinstance(v,dict) and 'ms' in v)
     ss=d.get('single_stream',{})
-    print(f"{l:28s} {d['value']/1e6:7.1f} M/s  step {d.get("ms_per_pass", d["ms_per_step"]):.4f}  one-launch {r.get('kernel_avg_ms',0):.4f}  single {ss.get("ms_per_pass", ss.get("ms_per_step", 0)):.4f} | {ks}")
+    print(f"{l:28s} {d['value']/1e6:7.1f} M/s  step {d.get('ms_per_pass', d['ms_per_step']):.4f}  one-launch {r.get('kernel_avg_ms',0):.4f}  single {ss.get('ms_per_pass', ss.get('ms_per_step', 0)):.4f} | {ks}")
 except Exception as e:
     print(l, 'FAILED', e); print(open(f'gpurun_out/ab/{l}.err').read()[-600:])
 P
