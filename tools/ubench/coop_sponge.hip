@@ -1,0 +1,133 @@
+// coop_sponge.hip -- a LOW-LATENCY Keccak-f for launches that cannot fill the chip: one state spread over
+// 25 lanes (lane = x + 5 y holds one 64-bit word as two VGPRs), two states per wave (lanes 0..24 and 32..56), the cross-lane
+// steps by ds_bpermute:
+//   theta  column parity = XOR over the five lanes of a column (two dependent levels of fetches), D from the x-1 / x+1 columns
+//   rho    a per-lane rotation amount (variable v_alignbit)
+//   pi     one fixed lane permutation
+//   chi    the x+1 / x+2 neighbours
+// ~16 ds_bpermute + ~30 VALU per round instead of 180 VALU -- but five DEPENDENT trips through the LDS crossbar per round.
+// Measured against the product's lane-per-state round function at <= 1 wave per SIMD: latency of one permutation per wave,
+// and states per second of the chip at that occupancy.  Checks both against each other first.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/ubench/coop_sponge.hip -o tools/ubench/coop_sponge
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../phant_amd/csrc/keccak_f1600.hip.h"
+using namespace phant;
+
+__device__ __forceinline__ uint32_t fetch(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src_lane), (int)v); }
+
+constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5 y]
+
+// `perms` permutations of the wave's two states; in/out: 25 x u64 per state
+__global__ void __launch_bounds__(64) coop_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int perms) {
+    const uint32_t lane = threadIdx.x & 63u, g = lane >> 5, l = lane & 31u;
+    const bool live = l < 25u;
+    const uint32_t ll = live ? l : 0u, x = ll % 5u, y = ll / 5u, base = 32u * g;
+    const uint32_t up5 = base + (ll + 5u) % 25u, up10 = base + (ll + 10u) % 25u, up20 = base + (ll + 20u) % 25u;
+    const uint32_t xm1 = base + (x + 4u) % 5u + 5u * y, xp1 = base + (x + 1u) % 5u + 5u * y, xp2 = base + (x + 2u) % 5u + 5u * y;
+    // pi: B[y][2x + 3y] = A[x][y]  <=>  the lane (x', y') takes from ((x' + 3 y') mod 5, x')
+    const uint32_t pis = base + (x + 3u * y) % 5u + 5u * x;
+    uint32_t rho = 0;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) rho = ll == (uint32_t)i ? (uint32_t)RHO[i] : rho;
+    const bool swap = rho >= 32u, norot = (rho & 31u) == 0u;
+    const uint32_t sh = 32u - (rho & 31u);
+    const size_t st = ((size_t)blockIdx.x * 2u + g) * 25u + ll;
+    uint64_t a64 = in[st];
+    uint32_t lo = (uint32_t)a64, hi = (uint32_t)(a64 >> 32);
+    for (int p = 0; p < perms; ++p) {
+        for (int r = 0; r < 24; ++r) {
+            // theta
+            uint32_t tl = lo ^ fetch(lo, up5), th = hi ^ fetch(hi, up5);
+            const uint32_t fl = fetch(lo, up20), fh = fetch(hi, up20);
+            const uint32_t cl = xor3(tl, fetch(tl, up10), fl), ch = xor3(th, fetch(th, up10), fh);
+            const uint32_t ml = fetch(cl, xm1), mh = fetch(ch, xm1), pl = fetch(cl, xp1), ph = fetch(ch, xp1);
+            lo = xor3(lo, ml, alignbit(pl, ph, 31));
+            hi = xor3(hi, mh, alignbit(ph, pl, 31));
+            // rho: rotl64 by the lane's amount
+            const uint32_t sl = swap ? hi : lo, shh = swap ? lo : hi;
+            const uint32_t rl = norot ? sl : alignbit(sl, shh, sh), rh = norot ? shh : alignbit(shh, sl, sh);
+            // pi
+            const uint32_t bl = fetch(rl, pis), bh = fetch(rh, pis);
+            // chi
+            lo = chi(bl, fetch(bl, xp1), fetch(bl, xp2));
+            hi = chi(bh, fetch(bh, xp1), fetch(bh, xp2));
+            // iota
+            if (ll == 0u) {
+                lo ^= KECCAK_RC[r][0];
+                hi ^= KECCAK_RC[r][1];
+            }
+        }
+    }
+    if (live) out[st] = ((uint64_t)hi << 32) | lo;
+}
+
+// the product's form: a state per lane
+__global__ void __launch_bounds__(64) lane_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int perms) {
+    const size_t st = ((size_t)blockIdx.x * 64u + threadIdx.x) * 25u;
+    Sponge s;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        s.lo[i] = (uint32_t)in[st + i];
+        s.hi[i] = (uint32_t)(in[st + i] >> 32);
+    }
+    for (int p = 0; p < perms; ++p) keccak_f1600(s);
+#pragma unroll
+    for (int i = 0; i < 25; ++i) out[st + i] = ((uint64_t)s.hi[i] << 32) | s.lo[i];
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <class K>
+double time_ms(K k, uint32_t blocks, const uint64_t* in, uint64_t* out, int perms) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64), 0, 0, in, out, perms);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64), 0, 0, in, out, perms);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const uint32_t simds = (uint32_t)prop.multiProcessorCount * 4u;
+    const size_t max_states = (size_t)simds * 4u * 64u;
+    std::vector<uint64_t> h(max_states * 25u);
+    uint64_t z = 0x9E3779B97F4A7C15ull;
+    for (auto& v : h) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = z; }
+    uint64_t *in, *o1, *o2;
+    CK(hipMalloc(&in, h.size() * 8));
+    CK(hipMalloc(&o1, h.size() * 8));
+    CK(hipMalloc(&o2, h.size() * 8));
+    CK(hipMemcpy(in, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    // same states through both forms: 128 states = 2 lane-form waves = 64 cooperative waves
+    hipLaunchKernelGGL(lane_kernel, dim3(2), dim3(64), 0, 0, in, o1, 3);
+    hipLaunchKernelGGL(coop_kernel, dim3(64), dim3(64), 0, 0, in, o2, 3);
+    CK(hipDeviceSynchronize());
+    std::vector<uint64_t> r1(128 * 25), r2(128 * 25);
+    CK(hipMemcpy(r1.data(), o1, r1.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(r2.data(), o2, r2.size() * 8, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < r1.size(); ++i) bad += r1[i] != r2[i];
+    printf("cooperative vs lane-per-state, 128 states x 3 permutations: %zu words differ\n", bad);
+    const int perms = 64;
+    printf("%u SIMDs; %d permutations per wave, HIP events\n", simds, perms);
+    printf("%-44s %10s %14s %16s\n", "form, waves", "ms", "us / perm", "M states x perm / s");
+    for (double occ : {0.25, 0.5, 1.0, 2.0, 4.0}) {
+        const uint32_t waves = (uint32_t)(simds * occ);
+        const double t1 = time_ms(lane_kernel, waves, in, o1, perms), t2 = time_ms(coop_kernel, waves, in, o2, perms);
+        printf("lane per state (64 / wave), %5.2f waves/SIMD %10.3f %14.2f %16.1f\n", occ, t1, t1 * 1e3 / perms, 64.0 * waves * perms / (t1 * 1e-3) / 1e6);
+        printf("25 lanes per state (2 / wave), %5.2f waves/SIMD %7.3f %14.2f %16.1f\n", occ, t2, t2 * 1e3 / perms, 2.0 * waves * perms / (t2 * 1e-3) / 1e6);
+    }
+    return bad ? 1 : 0;
+}
