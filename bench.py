@@ -298,6 +298,55 @@ def cpu_baseline_mptize(keys_t, vals_t, n, root_t, target_seconds):
     return out
 
 
+def trie_keccak_f(keys32, value_len):
+    """Keccak-f the trie hasher must run for sorted distinct 32-byte keys with fixed-length values: one per node and rate
+    block, from the trie's SHAPE (mpt.zig:47-119): a leaf per key, a branch wherever the keys under a nibble prefix go on
+    with two or more different nibbles (its length from the number of children: every child of such a trie is a 32-byte
+    reference), an extension where a shared run of nibbles ends in a branch.  Exact while 15 nibbles tell all keys apart."""
+    import torch
+    n = keys32.shape[0]
+    be = torch.zeros(n, dtype=torch.int64, device=keys32.device)
+    for t in range(7):  # the first 60 bits (15 nibbles) as a non-negative integer
+        be = (be << 8) | keys32[:, t].to(torch.int64)
+    be = (be << 4) | (keys32[:, 7].to(torch.int64) >> 4)
+    # a leaf: list header + hex-prefix path + value; all of them one block here (the caller's values are short)
+    leaf_len = 3 + 33 + 2 + value_len
+    perms = n * (leaf_len // 136 + 1)
+    nodes = {"leaves": n, "branches": 0, "extensions": 0}
+    prev_single = None  # per group of depth d - 1: did it go on with ONE nibble (part of an extension's run)?
+    for d in range(0, 15):
+        pre = be >> (60 - 4 * d) if d else torch.zeros_like(be)
+        nxt = be >> (60 - 4 * (d + 1))
+        groups, inv, cnt = torch.unique_consecutive(pre, return_inverse=True, return_counts=True)
+        multi = cnt >= 2
+        if not bool(multi.any()):
+            break
+        kids = torch.unique_consecutive(nxt)
+        kid_parent = kids >> 4
+        _, kid_cnt = torch.unique_consecutive(kid_parent, return_counts=True)  # children per group (all groups, in order)
+        c = kid_cnt[multi]
+        br = c[c >= 2]
+        blen = 32 * br + 17
+        blen = blen + torch.where(blen > 255, 3, torch.where(blen > 55, 2, 1))
+        perms += int((blen // 136 + 1).sum().item())
+        nodes["branches"] += int(br.numel())
+        # an extension sits on top of every maximal run of single-child groups: count the runs' heads = single-child
+        # groups whose parent group was a branch (or the root)
+        single = multi & (kid_cnt == 1)
+        if bool(single.any()):
+            if d == 0:
+                heads = int(single.sum().item())
+            else:
+                parent = groups >> 4
+                ppre, pinv = torch.unique_consecutive(parent, return_inverse=True)
+                parent_single = prev_single[pinv] if prev_single is not None else torch.zeros_like(single)
+                heads = int((single & ~parent_single).sum().item())
+            perms += heads
+            nodes["extensions"] += heads
+        prev_single = single
+    return perms, nodes
+
+
 def device_id_bytes(dev):
     """16 bytes that identify the physical device behind `dev` (its UUID; PCI bus id + ordinal where the build has none)."""
     import torch
@@ -865,6 +914,7 @@ def main():
             M.mptize_dev(keys_t, key_off, vals_t, val_off, out=root, ctx=ctx)
 
         kernel_only = step
+        trie_perms, trie_nodes = trie_keccak_f(kb, 78)
         metric, unit = "mpt_trie_keys_hashed_per_sec", "keys/s"
         workload = (f"mptize: root of the trie of {n_units} sorted random 32-byte keys with 78-byte values per GPU, arrays "
                     f"resident in HBM (phant_mpt_root_dev; {alg_bytes} B = keys + values + root)")
@@ -977,6 +1027,19 @@ def main():
         if streamed and args.verify_mode != "fused":
             hashed = ctx.verify_stats()
             extra = {"nodes_shipped": int(b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed))}
+        if args.workload == "mptize":
+            # the roofline that bounds a trie hasher: every node is hashed once, Keccak-f is integer-VALU-bound (110 MB of keys and
+            # values are 1.6 % of HBM's rate at these times: the wrong ceiling).  Peak as for the verify line: measured in this run
+            peak6 = ctx.keccak_rate(6, 200) / 1e9
+            peak4 = ctx.keccak_rate(4, 200) / 1e9
+            vpeak = max(peak6, peak4)
+            extra = {"keccak_f_run": int(trie_perms), "trie_nodes": trie_nodes,
+                     "valu": {"bound": "valu", "achieved": trie_perms / (k_avg_ms * 1e-3) / 1e9, "peak": vpeak, "unit": "G Keccak-f/s",
+                              "frac": trie_perms / (k_avg_ms * 1e-3) / 1e9 / vpeak,
+                              "peak_source": "phant_keccak_rate on this device, this run: permutations only, the better of 4 and 6 "
+                                             "waves per SIMD",
+                              "note": "one Keccak-f per node and rate block, counted from the trie's shape (bench.trie_keccak_f) / "
+                                      "device time of one call (first kernel start to last kernel end)"}}
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
 
     pipeline = ("two-tier verify pipeline = hash_deep_kernel (in-place hashing of the deep levels, helper stream) next to "
