@@ -36,7 +36,7 @@ except Exception as e:
 P
 }
 [ -n "$AB_TESTS" ] && { cp tools/_ab/new.so phant_amd/libphant_gpu.so; timeout 900 python -m pytest $AB_TESTS -x -q 2>&1 | tail -3; }
-for round in 1 2; do
+for round in 1 2 3 4; do
   while read -r line; do [ -z "$line" ] && continue; case "$line" in \#*) continue;; esac; one $line; done < tools/_ab/cases.txt
 done
 R
