@@ -15,7 +15,7 @@ cp phant_amd/libphant_gpu.so tools/_ab/new.so
 cat > tools/_ab/run.sh <<'R'
 ulimit -c 0
 one() { timeout 300 python bench.py --no-cpu-baseline $2 2>&1 | grep "^{" | tail -1 > /tmp/b.json; python -c "
-import json; d=json.load(open('/tmp/b.json')); r=d['roofline']; print('$1', round(d['value']/1e6,1), 'M/s', round(d.get("ms_per_pass", d["ms_per_step"]),4), 'one launch', round(r['kernel_avg_ms'],4), 'single stream', round(d['single_stream']['ms_per_step'],4))"; }
+import json; d=json.load(open('/tmp/b.json')); r=d['roofline']; print('$1', round(d['value']/1e6,1), 'M/s', round(d.get('ms_per_pass', d['ms_per_step']),4), 'one launch', round(r['kernel_avg_ms'],4), 'single stream', round(d['single_stream'].get('ms_per_pass'),4))"; }
 for v in old new old new old new; do cp tools/_ab/$v.so phant_amd/libphant_gpu.so; one $v "--no-strong"; done
 for v in old new; do cp tools/_ab/$v.so phant_amd/libphant_gpu.so; one "$v-config4" "--workload config4 --no-strong"; done
 R

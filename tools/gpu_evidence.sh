@@ -13,7 +13,7 @@ b() { tag=$1; shift; timeout 400 python bench.py "$@" 2>&1 | grep '^{' | tail -1
 import json
 try:
     d = json.load(open("$OUT/bench_$tag.json"))
-    print("$tag", round(d["value"] / 1e6, 1), "M/s", "ms", round(d.get("ms_per_pass", d["ms_per_step"]), 4), "kernel", round(d["roofline"]["kernel_avg_ms"], 4), "frac", round(d["roofline"]["frac"], 3), "single", d.get("single_stream", {}).get("ms_per_step"), "strong", (d.get("strong") or {}).get("value"))
+    print("$tag", round(d["value"] / 1e6, 1), "M/s", "ms", round(d.get("ms_per_pass", d["ms_per_step"]), 4), "kernel", round(d["roofline"]["kernel_avg_ms"], 4), "frac", round(d["roofline"]["frac"], 3), "single", d.get("single_stream", {}).get("ms_per_pass"), "strong", (d.get("strong") or {}).get("value"))
 except Exception as e:
     print("$tag FAILED", e)
 PY
@@ -32,7 +32,7 @@ b config5_20k_account_proofs --workload config5 --no-cpu-baseline --stream-proof
 b config5_100k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 100000
 b mptize --workload mptize --cpu-seconds 8 --steps 10
 timeout 300 python bench.py --comm --steps 10 --inner 10 2>&1 | grep '^{' | tail -1 > "$OUT/bench_comm_one_process.json"; python -c "
-import json; d=json.load(open('$OUT/bench_comm_one_process.json')); print('comm (one process)', d['n_gpus'], 'device(s)', round(d['value']/1e6,1), 'M proofs/s', round(d.get("ms_per_pass", d["ms_per_step"]),4), 'ms')"
+import json; d=json.load(open('$OUT/bench_comm_one_process.json')); print('comm (one process)', d['n_gpus'], 'device(s)', round(d['value']/1e6,1), 'M proofs/s', round(d.get('ms_per_pass', d['ms_per_step']),4), 'ms')"
 timeout 300 python tools/bench_block_roots.py --items 1 10 100 400 > "$OUT/block_roots.jsonl" 2>&1; tail -4 "$OUT/block_roots.jsonl"
 timeout 300 python tools/bench_state.py > "$OUT/state_root.jsonl" 2>&1; timeout 300 python tools/bench_state.py --accounts 1000000 --slots 0 >> "$OUT/state_root.jsonl" 2>&1; cut -c1-330 "$OUT/state_root.jsonl"
 timeout 300 python tools/sweep_verify.py --steps 40 --out "$OUT/sweep.jsonl" > "$OUT/sweep.log" 2>&1; python - <<PY

@@ -17,6 +17,6 @@ PY
 timeout 300 python bench.py --no-cpu-baseline --no-strong 2>&1 | grep '^{' | tail -1 > "$OUT/bench_config3.json"
 python -c "
 import json; d = json.load(open('$OUT/bench_config3.json'))
-print('config3', round(d['value'] / 1e6, 1), 'M/s ms', round(d['ms_per_step'], 4), 'kernel', round(d['roofline']['kernel_avg_ms'], 4), 'single', d.get('single_stream', {}).get('ms_per_step'))"
+print('config3', round(d['value'] / 1e6, 1), 'M/s ms', round(d['ms_per_step'], 4), 'kernel', round(d['roofline']['kernel_avg_ms'], 4), 'single', d.get('single_stream', {}).get('ms_per_pass'))"
 rm -rf /tmp/pw; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pw -o p -- python $R/tools/probe_walk.py > "$OUT/probe.log" 2>&1 )
 python tools/probe_walk_report.py /tmp/pw | tee "$OUT/timeline.txt" | cut -c1-260 | tail -6
