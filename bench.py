@@ -30,7 +30,7 @@ collective is the all-reduce of the per-root failure count (RCCL).  value =
 proofs of ALL ranks / max-over-ranks time.  --streams S (default 2) keeps S independent launch
 sequences in flight per GPU (a sequence is two HIP streams -- the tiers run next to each other --, and two of them are the four
 hardware queues ROCm gives a process: with more in flight, streams share queues and wait for each other; measured 2 / 3 / 4 / 6:
-530 / 484 / 518 / 507 M proofs/s), each on its own ctx + HIP stream and each over a DIFFERENT witness (other seed: a
+530 / 484 / 518 / 507 M proofs/s, profiles/EXPERIMENTS.md), each on its own ctx + HIP stream and each over a DIFFERENT witness (other seed: a
 validator verifying consecutive witnesses; no step re-reads the bytes the previous step on its slot left in
 L2 / Infinity Cache): every step is still a full pass over a full batch; `single_stream` in the JSON line is
 the same number of passes strictly one after the other (alternating witnesses), and `roofline.achieved` always

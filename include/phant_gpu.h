@@ -339,7 +339,7 @@ PHANT_API int32_t phant_witness_parse_json_mt(const char *json, uint64_t len, ui
  * stay in the JSON text -- the witness notes where they are and BORROWS `json` until it has been verified and
  * freed.  phant_witness_verify then ships the text instead of the decoded nodes, decodes the digits on the GPU
  * and fetches only the proven values back.  On the host this leaves the structural scan (one `memchr` per
- * string; DESIGN.md section 9 has the measured rates of both forms);
+ * string; profiles/ROWS_NEXT_TO_THE_PATH.md has the measured rates of both forms);
  * the price is 2 bytes over PCIe per node byte.  A node whose
  * digits are not hex is found by the GPU: phant_witness_verify returns PHANT_E_INVALID_ARG (message: which
  * node).  phant_witness_get reports nodes = NULL for this form. */

@@ -34,7 +34,7 @@
 // Against round 2's chain (zero, plan, dedup, hash_list, link, walk with hash_deep beside them): no per-node stamps and
 // group keys (plan's 12 MB of stores, read back by three kernels: the lanes of the node-parallel kernels are (proof, level)
 // pairs and know their owner), no link pass over every node (the walk gathers the few bytes it needs itself), no clearing
-// kernel and no table clearing at all.  What was measured and dropped on the way: the election
+// kernel and no table clearing at all.  What was measured and dropped on the way (profiles/EXPERIMENTS.md): the election
 // split from the comparison (so that the lists are complete early and ALL hashing is one pool of waves behind it; the
 // copies that differ then need a late pass), the comparison as a persistent grid, prefetched rate blocks.
 //
@@ -509,7 +509,7 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 // throughout).  VALU issue on a SIMD is arbitrated by priority, then age -- left alone, the oldest of four co-resident
 // hash waves takes ~60 % of the slots, finishes first, and the youngest ends up running its last permutations alone at
 // single-wave speed.  With the ladder a wave that is behind outranks the ones ahead: they advance block by block
-// together and finish together (ladders measured).
+// together and finish together (profiles/EXPERIMENTS.md: ladders measured).
 template <bool LADDER>
 PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
     sponge_zero(s);

@@ -1,6 +1,6 @@
 // radix_sort.hip -- ordering hashed keys on the GPU (internal; used by state_root.hip).
 //
-// The secure tries of src/state (statedb.zig / types.zig:13-20 -> DESIGN.md section 9) are keyed by Keccak outputs, so
+// The secure tries of src/state (statedb.zig / types.zig:13-20 -> profiles/ROWS_NEXT_TO_THE_PATH.md) are keyed by Keccak outputs, so
 // before a trie can be hashed its leaves have to be put in key order.  Round 1 did that on the host (std::sort with
 // 32-byte memcmp: ~0.2 s per million keys, behind a device-to-host copy of every digest).  Here: a stable LSD radix
 // sort of (64-bit key, 32-bit value) pairs, 8 bits per pass, three launches per pass --

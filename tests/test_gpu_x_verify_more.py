@@ -80,7 +80,7 @@ def test_keys_longer_than_the_lds_staging(M, oracle):
 def test_small_batches_are_hashed_whole_large_ones_in_two_tiers():
     """The tier split chosen from the batch (no forced level): a batch the chip hashes in a few rounds of waves -- under 72 MB
     of nodes -- skips the deduplicating tier (every shipped node is hashed: fewer kernels, no helper stream), BASELINE
-    config 3's 387 MB does not (DESIGN.md section 7.2; the measurements behind the threshold: profiles/r2_d/).  Statuses as
+    config 3's 387 MB does not (DESIGN.md section 7; the measurements behind the threshold: profiles/r2_d/).  Statuses as
     constructed either way."""
     import phant_amd
     ctx = phant_amd.Context()

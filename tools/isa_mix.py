@@ -4,7 +4,7 @@
 
     python tools/isa_mix.py phant_amd/csrc/mpt_verify_v3.hip hash_deep_kernel
 
-Backs the "180 VALU per Keccak round, the instruction minimum" figure of DESIGN.md section 7.1 with something
+Backs the "180 VALU per Keccak round, the instruction minimum" figure of DESIGN.md section 7 with something
 checkable: the round loop's VALU count by opcode, its scalar overhead, where the loads and waits sit."""
 import collections
 import os

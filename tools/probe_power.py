@@ -6,7 +6,7 @@ sysfs (hwmon freq1_input / power1_average, pp_dpm_sclk) and, if that is not ther
     python tools/probe_power.py [--seconds 3] [--out gpurun_out/power.jsonl]
 
 Why: three rounds of scheduling experiments fit an ADDITIVE model -- a launch takes its Keccak-f at the VALU ceiling plus its
-bytes at ~10 TB/s, however the two are interleaved (DESIGN.md section 7.2).  A board that runs into its power limit behaves
+bytes at ~10 TB/s, however the two are interleaved (DESIGN.md section 7).  A board that runs into its power limit behaves
 exactly like that (time = energy / cap); this says whether it does.
 """
 import argparse
