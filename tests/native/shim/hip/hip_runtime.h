@@ -95,6 +95,15 @@ static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline void __threadfence() {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
+// (workgroups run one after the other here: a scoped atomic load / store is the plain one, the device's 100 MHz clock a counter)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+static inline long long wall_clock64() {
+    static long long ticks = 0;
+    return ++ticks;
+}
 
 // ------------------------------------------------------------------------------------------------ the emulator
 // Fiber switch: save the callee-saved registers on the current stack, publish its stack pointer, adopt the other
@@ -444,6 +453,7 @@ static __forceinline__ T __shfl_up(T v, unsigned delta, int width = 64) {
 // ------------------------------------------------------------------------------------------------ atomics
 #define HIPEMU_ATOMICS(T)                                                  \
     static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; } \
+    static inline T atomicSub(T* p, T v) { const T o = *p; *p = o - v; return o; } \
     static inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }  \
     static inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; } \
     static inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; } \
