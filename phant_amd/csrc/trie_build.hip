@@ -38,6 +38,8 @@ constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t BRANCH_VALUE = 0xfffffffeu;  // leaf_ps marker: key is a branch's value
 constexpr int MAX_DEPTH_BINS = 512;             // nibble depth <= 2*255
 constexpr int INF_LCP = 0x7fffffff;
+constexpr uint32_t FAN = 16;      // fan-out of the min-tree: a group of children is one 64-byte line
+constexpr int MAX_LEVELS = 8;      // 16^8 boundaries
 
 struct TrieDev {
     const uint8_t* keys;
@@ -48,14 +50,15 @@ struct TrieDev {
     const uint32_t* seg_first;
     uint32_t n_tries;
     uint8_t* first_flag;  // n+1: key i starts a trie
-    int32_t* lcp;         // n+1
-    int32_t* tree;        // 2*M min-tree over lcp
-    uint32_t M;
+    int32_t* lcp;         // n+1, padded with INF_LCP to lvl_size[0]: level 0 of the min-tree
+    int32_t* tree;        // its levels 1 .. n_lvl - 1 (level k at tree + lvl_off[k]): a node = the minimum of its FAN children
+    uint32_t lvl_size[MAX_LEVELS], lvl_off[MAX_LEVELS], n_lvl;  // sizes are multiples of FAN; the top level is ONE group
     // per boundary index (n+1)
     uint32_t* dense;      // dense node id of a representative boundary, else NONE
     uint32_t* nd_l;       // first key of the interval
     int32_t* nd_pd;       // parent depth (-1: root)
     uint32_t* nd_parent;  // parent's representative boundary, NONE: root
+    uint32_t* nd_rep;     // every boundary's interval representative (identify_element), NONE where there is no interval
     uint32_t* value_key;  // key whose value sits in this branch's value slot, or NONE
     // per key (n)
     uint32_t* leaf_parent;
@@ -109,8 +112,9 @@ PHANT_DEV void lcp_element(const TrieDev& t, const uint32_t i) {
         }
         if (i > 0 && t.key_off[i] - t.key_off[i - 1] > MAX_KEY_BYTES) sane = false;
     }
-    if (i > 0 && i < t.n && !t.first_flag[i] && !sane) v = 0;
-    if (i > 0 && i < t.n && !t.first_flag[i] && sane) {
+    const bool inner = i > 0 && i < t.n && !(t.first_flag && t.first_flag[i]);  // (first_flag null: ONE trie, no start but key 0)
+    if (inner && !sane) v = 0;
+    if (inner && sane) {
         const uint32_t la = t.key_off[i] - t.key_off[i - 1], lb = t.key_off[i + 1] - t.key_off[i];
         const uint8_t* a = t.keys + t.key_off[i - 1];
         const uint8_t* b = t.keys + t.key_off[i];
@@ -129,136 +133,191 @@ PHANT_DEV void lcp_element(const TrieDev& t, const uint32_t i) {
         if (!ok) atomicOr(&t.counters[1], ERR_UNSORTED);
     }
     t.lcp[i] = v;
-    t.tree[t.M + i] = v;
 }
+// ... for every boundary, together with the markers the passes below expect (no key is a branch value yet, no boundary has a
+// dense id) and the padding of the min-tree's leaf level: what trie_init_kernel and tree_pad_kernel did in launches of their own
 __global__ void __launch_bounds__(256) lcp_kernel(TrieDev t) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i <= t.n) lcp_element(t, i);
-}
-
-__global__ void __launch_bounds__(256) tree_pad_kernel(TrieDev t) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x + t.n + 1;
-    if (i < t.M) t.tree[t.M + i] = INF_LCP;
-}
-
-// The min-tree over the lcp array, up to eleven levels per launch: a workgroup takes a tile of T consecutive nodes of the level of
-// width w_in (T = 2 048, or the whole level when it is narrower) and writes every level above it down to the tile's one
-// ancestor -- the first from global memory, the rest out of LDS behind workgroup barriers.  A million keys: two launches (twelve
-// when every level was one: 80 us of launch gaps at the head of every call).
-constexpr uint32_t TREE_TILE = 2048;
-__global__ void __launch_bounds__(256) tree_tile_kernel(int32_t* tree, uint32_t w_in, uint32_t T) {
-    __shared__ int32_t s_min[TREE_TILE / 2];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    uint32_t half = T >> 1, w = w_in >> 1;  // this tile's nodes on the level being written, that level's width
-    for (uint32_t k = tid; k < half; k += 256u) {
-        const uint32_t v = w + b * half + k;
-        const int32_t x = tree[2 * v], y = tree[2 * v + 1];
-        const int32_t m = x < y ? x : y;
-        tree[v] = m;
-        s_min[k] = m;
-    }
-    __syncthreads();
-    while (half > 1u) {
-        half >>= 1;
-        w >>= 1;
-        int32_t m[2] = {0, 0};  // half <= 512: at most two nodes per lane
-        for (uint32_t k = tid, q = 0; k < half; k += 256u, ++q) {
-            const int32_t x = s_min[2 * k], y = s_min[2 * k + 1];
-            m[q] = x < y ? x : y;
-        }
-        __syncthreads();
-        for (uint32_t k = tid, q = 0; k < half; k += 256u, ++q) {
-            s_min[k] = m[q];
-            tree[w + b * half + k] = m[q];
-        }
-        __syncthreads();
-    }
-}
-
-// what six hipMemsetAsync calls did at the head of every call: flags, markers and counters of the passes below
-__global__ void __launch_bounds__(256) trie_init_kernel(TrieDev t) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i <= t.n) {
-        t.first_flag[i] = 0;
         t.value_key[i] = NONE;
         t.dense[i] = NONE;
+        lcp_element(t, i);
+    } else if (i < t.lvl_size[0]) {
+        t.lcp[i] = INF_LCP;
     }
+}
+
+// The min-tree over the lcp array has fan-out 16: a node is the minimum of sixteen children, which are ONE aligned 64-byte line.
+// The queries below are chains of dependent loads -- up from boundary i until a sibling answers, down again to the boundary it
+// stands for -- and the kernel that asks them takes as long as its longest chain (a boundary of a shallow node looks far: 40
+// loads in a binary tree over a million keys, which is what identify_kernel's 75 us were).  Sixteen children per load make
+// the chain a quarter as long: five levels for a million keys instead of twenty.
+PHANT_DEV const int32_t* lvl(const TrieDev& t, uint32_t k) { return k ? t.tree + t.lvl_off[k] : t.lcp; }
+PHANT_DEV void load_group(const int32_t* p, int32_t (&v)[FAN]) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);  // (64-byte aligned: level starts are, groups are FAN ints)
+#pragma unroll
+    for (uint32_t c = 0; c < FAN / 4u; ++c) {
+        const uint4 x = q[c];
+        v[4 * c] = (int32_t)x.x;
+        v[4 * c + 1] = (int32_t)x.y;
+        v[4 * c + 2] = (int32_t)x.z;
+        v[4 * c + 3] = (int32_t)x.w;
+    }
+}
+PHANT_DEV int32_t group_min(const int32_t* p) {
+    int32_t v[FAN];
+    load_group(p, v);
+    int32_t m = v[0];
+#pragma unroll
+    for (uint32_t c = 1; c < FAN; ++c) m = v[c] < m ? v[c] : m;
+    return m;
+}
+// Three levels per launch: a workgroup takes FAN^3 nodes of level `base` and writes their ancestors on levels base + 1 (one per
+// lane, from global memory), base + 2 and base + 3 (out of LDS).  Positions beyond a level's children are INF_LCP up to its
+// padded size.  A million keys: two launches.
+__global__ void __launch_bounds__(256) tree_levels_kernel(TrieDev t, uint32_t base) {
+    __shared__ int32_t s_a[FAN * FAN], s_b[FAN];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const int32_t* const src = lvl(t, base);
+    {
+        const uint32_t g = b * 256u + tid;
+        const int32_t m = (uint64_t)g * FAN < t.lvl_size[base] ? group_min(src + (uint64_t)g * FAN) : INF_LCP;
+        s_a[tid] = m;
+        if (g < t.lvl_size[base + 1u]) t.tree[t.lvl_off[base + 1u] + g] = m;
+    }
+    __syncthreads();
+    if (base + 2u >= t.n_lvl) return;
+    if (tid < FAN) {
+        int32_t m = s_a[FAN * tid];
+        for (uint32_t c = 1; c < FAN; ++c) m = s_a[FAN * tid + c] < m ? s_a[FAN * tid + c] : m;
+        s_b[tid] = m;
+        const uint32_t g = b * FAN + tid;
+        if (g < t.lvl_size[base + 2u]) t.tree[t.lvl_off[base + 2u] + g] = m;
+    }
+    __syncthreads();
+    if (base + 3u >= t.n_lvl) return;
+    if (tid == 0 && b < t.lvl_size[base + 3u]) {
+        int32_t m = s_b[0];
+        for (uint32_t c = 1; c < FAN; ++c) m = s_b[c] < m ? s_b[c] : m;
+        t.tree[t.lvl_off[base + 3u] + b] = m;
+    }
+}
+
+// The head of every large call, one launch: every root = empty_mpt_root (mpt.zig:10; a trie with keys overwrites its own), the
+// counters of the passes below cleared (lcp_kernel already reports into counters[1]), and -- for a forest -- the start flags
+// cleared for first_flag_kernel.
+PHANT_DEV void store_empty_root(uint8_t* out) {
+    const uint8_t E[32] = {0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 0xff, 0x83, 0x45, 0xe6, 0x92, 0xc0, 0xf8, 0x6e,
+                           0x5b, 0x48, 0xe0, 0x1b, 0x99, 0x6c, 0xad, 0xc0, 0x01, 0x62, 0x2f, 0xb5, 0xe3, 0x63, 0xb4, 0x21};
+    for (int k = 0; k < 32; ++k) out[k] = E[k];
+}
+__global__ void __launch_bounds__(256) head_kernel(TrieDev t) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < t.n_tries) store_empty_root(t.roots + 32ull * i);
+    if (t.first_flag && i <= t.n) t.first_flag[i] = 0;
     if (i < 8u + (uint32_t)MAX_DEPTH_BINS) t.counters[i] = 0u;
     if (i < (uint32_t)MAX_DEPTH_BINS) t.depth_cursor[i] = 0u;
     if (i == 0) *t.cursor = 0ull;
 }
 
+// which of a group's sixteen values are below thr, as a bit mask
+PHANT_DEV uint32_t below_mask(const int32_t* p, int32_t thr) {
+    int32_t v[FAN];
+    load_group(p, v);
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < FAN; ++c) m |= (v[c] < thr ? 1u : 0u) << c;
+    return m;
+}
 // largest j < i with lcp[j] < thr (exists: lcp[0] = -1 and thr >= 0)
 PHANT_DEV uint32_t prev_less(const TrieDev& t, uint32_t i, int32_t thr) {
-    uint32_t v = t.M + i;
-    while (v > 1) {
-        if ((v & 1u) && t.tree[v - 1] < thr) {
-            v = v - 1;
-            while (v < t.M) v = (t.tree[2 * v + 1] < thr) ? 2 * v + 1 : 2 * v;
-            return v - t.M;
+    uint32_t pos = i, k = 0;
+    for (;;) {  // up: the siblings to the LEFT of pos inside its group, then of its parent, ...
+        const uint32_t m = below_mask(lvl(t, k) + (pos & ~(FAN - 1u)), thr) & ((1u << (pos & (FAN - 1u))) - 1u);
+        if (m) {
+            pos = (pos & ~(FAN - 1u)) + (31u - (uint32_t)__builtin_clz(m));
+            break;
         }
-        v >>= 1;
+        if (k + 1u == t.n_lvl) return 0;
+        pos /= FAN;
+        ++k;
     }
-    return 0;
+    while (k > 0) {  // down: the rightmost child below thr
+        --k;
+        const uint32_t m = below_mask(lvl(t, k) + (uint64_t)pos * FAN, thr);
+        pos = pos * FAN + (31u - (uint32_t)__builtin_clz(m | 1u));
+    }
+    return pos;
 }
 // smallest j > i with lcp[j] < thr (exists: lcp[n] = -1)
 PHANT_DEV uint32_t next_less(const TrieDev& t, uint32_t i, int32_t thr) {
-    uint32_t v = t.M + i;
-    while (v > 1) {
-        if (!(v & 1u) && t.tree[v + 1] < thr) {
-            v = v + 1;
-            while (v < t.M) v = (t.tree[2 * v] < thr) ? 2 * v : 2 * v + 1;
-            return v - t.M;
+    uint32_t pos = i, k = 0;
+    for (;;) {
+        const uint32_t m = below_mask(lvl(t, k) + (pos & ~(FAN - 1u)), thr) & ~((2u << (pos & (FAN - 1u))) - 1u);
+        if (m) {
+            pos = (pos & ~(FAN - 1u)) + (uint32_t)__builtin_ctz(m);
+            break;
         }
-        v >>= 1;
+        if (k + 1u == t.n_lvl) return t.n;
+        pos /= FAN;
+        ++k;
     }
-    return t.n;
-}
-
-// representative boundary of the interval at depth pd that contains key x,
-// given lcp[x] <= pd
-PHANT_DEV uint32_t rep_of(const TrieDev& t, uint32_t x, int32_t lcp_x, int32_t pd) {
-    const uint32_t PL = (lcp_x < pd) ? x : prev_less(t, x, pd);
-    return next_less(t, PL, pd + 1);
+    while (k > 0) {  // down: the leftmost child below thr
+        --k;
+        const uint32_t m = below_mask(lvl(t, k) + (uint64_t)pos * FAN, thr);
+        pos = pos * FAN + (uint32_t)__builtin_ctz(m | 0x10000u);
+    }
+    return pos;
 }
 
 // Key i as a leaf (or a branch value), boundary i as a branch node: -> is boundary i the representative of a branch node
-// (of depth d)?
+// (of depth d)?  Two queries for every boundary -- the left edge PL of its interval (the nearest smaller lcp to the left) and the
+// interval's representative R (the first boundary behind PL that is not deeper) -- answer both questions: key i hangs under
+// boundary i + 1 when the lcp rises there, else under R; boundary i is a node iff R == i.  A node asks a third (its right edge)
+// and knows its parent's depth; the parent is the right edge itself when that is the shallower side, else the representative of
+// the LEFT edge's interval -- which the left edge's own lane is computing: noted as VIA | l and resolved out of nd_rep by the next
+// pass (resolve_parent).  (Before: up to six queries in a lane, each a chain of dependent loads; the kernel is as long as the
+// slowest lane of its slowest wave.)
+constexpr uint32_t VIA = 0x80000000u;  // (boundaries stay below 2^31 - 1: forest_device checks)
 PHANT_DEV bool identify_element(const TrieDev& t, const uint32_t i, int32_t& d) {
+    const int32_t dl = t.lcp[i], dr = t.lcp[i + 1];
+    d = dl;
+    uint32_t PL = 0, R = NONE;
+    if (i >= 1 && dl >= 0) {
+        PL = prev_less(t, i, dl);
+        R = next_less(t, PL, dl + 1);
+    }
+    t.nd_rep[i] = R;
     // --- key i as a leaf (or a branch value) ---
-    {
-        const int32_t dl = t.lcp[i], dr = t.lcp[i + 1];
-        const int32_t di = dl > dr ? dl : dr;
-        if (di < 0) {
-            t.leaf_parent[i] = NONE;  // single-key trie: the leaf is the root
-            t.leaf_ps[i] = 0;
+    const int32_t di = dl > dr ? dl : dr;
+    if (di < 0) {
+        t.leaf_parent[i] = NONE;  // single-key trie: the leaf is the root
+        t.leaf_ps[i] = 0;
+    } else {
+        const uint32_t rep = dr > dl ? i + 1u : R;
+        t.leaf_parent[i] = rep;
+        if (nib_len(t, i) == (uint32_t)di) {
+            t.value_key[rep] = i;  // mpt.zig:65-69
+            t.leaf_ps[i] = BRANCH_VALUE;
         } else {
-            const uint32_t rep = rep_of(t, i, dl, di);
-            t.leaf_parent[i] = rep;
-            if (nib_len(t, i) == (uint32_t)di) {
-                t.value_key[rep] = i;  // mpt.zig:65-69
-                t.leaf_ps[i] = BRANCH_VALUE;
-            } else {
-                t.leaf_ps[i] = (uint32_t)di + 1u;
-            }
+            t.leaf_ps[i] = (uint32_t)di + 1u;
         }
     }
     // --- boundary i as a branch node ---
-    d = t.lcp[i];
-    if (i >= 1 && d >= 0) {
-        const uint32_t p = prev_less(t, i, d + 1);
-        if (t.lcp[p] < d) {  // leftmost boundary of value d in its interval
-            const uint32_t l = p;
-            const uint32_t r1 = next_less(t, i, d);  // r + 1
-            const int32_t pl = t.lcp[l], pr = t.lcp[r1];
-            const int32_t pd = pl > pr ? pl : pr;
-            t.nd_l[i] = l;
-            t.nd_pd[i] = pd;
-            t.nd_parent[i] = pd < 0 ? NONE : rep_of(t, l, pl, pd);
-            return true;
-        }
-    }
-    return false;
+    if (R != i) return false;
+    const uint32_t l = PL;
+    const uint32_t r1 = next_less(t, i, dl);  // r + 1
+    const int32_t pl = t.lcp[l], pr = t.lcp[r1];
+    const int32_t pd = pl > pr ? pl : pr;
+    t.nd_l[i] = l;
+    t.nd_pd[i] = pd;
+    t.nd_parent[i] = pd < 0 ? NONE : (pl >= pr ? (VIA | l) : r1);
+    return true;
+}
+// the parent of node i, final (for the pass behind identify: every lane's nd_rep is in memory)
+PHANT_DEV void resolve_parent(const TrieDev& t, const uint32_t i) {
+    const uint32_t np = t.nd_parent[i];
+    if (np != NONE && (np & VIA)) t.nd_parent[i] = t.nd_rep[np & ~VIA];
 }
 
 // Workgroups of 1 024 lanes for the two kernels that count into a handful of global counters: atomics on one address
@@ -330,6 +389,7 @@ __global__ void __launch_bounds__(COUNT_BLOCK) order_kernel(TrieDev t) {
         __syncthreads();
     }
     const bool live = i < t.n && i != 0 && t.dense[i] != NONE;
+    if (live) resolve_parent(t, i);
     const uint32_t d = live ? (uint32_t)t.lcp[i] : 0u;
     // rank inside the workgroup's share of depth d (LDS), then one global reservation per workgroup and depth;
     // the order inside a depth bin is immaterial (it is a work list)
@@ -809,13 +869,8 @@ __global__ void __launch_bounds__(BRANCH_LANES) leaf_big_kernel(TrieDev t) {
 }
 
 __global__ void __launch_bounds__(256) fill_empty_roots_kernel(uint8_t* roots, uint32_t n_tries) {
-    // mpt.zig:10 empty_mpt_root = keccak256(0x80)
-    const uint8_t E[32] = {0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 0xff, 0x83, 0x45,
-                           0xe6, 0x92, 0xc0, 0xf8, 0x6e, 0x5b, 0x48, 0xe0, 0x1b, 0x99, 0x6c,
-                           0xad, 0xc0, 0x01, 0x62, 0x2f, 0xb5, 0xe3, 0x63, 0xb4, 0x21};
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n_tries)
-        for (int k = 0; k < 32; ++k) roots[32ull * i + k] = E[k];
+    if (i < n_tries) store_empty_root(roots + 32ull * i);
 }
 
 // ---- small forests: everything in ONE launch ----
@@ -848,13 +903,9 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
         s_cur[b] = 0u;
     }
     for (uint32_t i = tid; i < n * 4u; i += B) reinterpret_cast<uint32_t*>(t.slot_len)[i] = 0u;  // n x 16 bytes
-    {
-        const uint8_t E[32] = {0x56, 0xe8, 0x1f, 0x17, 0x1b, 0xcc, 0x55, 0xa6, 0xff, 0x83, 0x45, 0xe6, 0x92, 0xc0, 0xf8, 0x6e,
-                               0x5b, 0x48, 0xe0, 0x1b, 0x99, 0x6c, 0xad, 0xc0, 0x01, 0x62, 0x2f, 0xb5, 0xe3, 0x63, 0xb4, 0x21};
-        for (uint32_t i = tid; i < t.n_tries; i += B) {  // mpt.zig:10 empty_mpt_root = keccak256(0x80)
-            for (int k = 0; k < 32; ++k) t.roots[32ull * i + k] = E[k];
-            if (t.root_enc_len) t.root_enc_len[i] = 0u;
-        }
+    for (uint32_t i = tid; i < t.n_tries; i += B) {  // mpt.zig:10 empty_mpt_root = keccak256(0x80)
+        store_empty_root(t.roots + 32ull * i);
+        if (t.root_enc_len) t.root_enc_len[i] = 0u;
     }
     if (tid == 0) {
         *t.cursor = 0ull;
@@ -868,14 +919,11 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
     __syncthreads();
     // ---- lcp, min-tree ----
     for (uint32_t i = tid; i <= n; i += B) lcp_element(t, i);
-    for (uint32_t i = n + 1u + tid; i < t.M; i += B) t.tree[t.M + i] = INF_LCP;
+    for (uint32_t i = n + 1u + tid; i < t.lvl_size[0]; i += B) t.lcp[i] = INF_LCP;
     __syncthreads();
-    for (uint32_t w = t.M / 2u; w >= 1u; w >>= 1) {
-        for (uint32_t k = tid; k < w; k += B) {
-            const uint32_t v = w + k;
-            const int32_t x = t.tree[2 * v], y = t.tree[2 * v + 1];
-            t.tree[v] = x < y ? x : y;
-        }
+    for (uint32_t k = 1; k < t.n_lvl; ++k) {
+        for (uint32_t g = tid; g < t.lvl_size[k]; g += B)
+            t.tree[t.lvl_off[k] + g] = g * FAN < t.lvl_size[k - 1u] ? group_min(lvl(t, k - 1u) + g * FAN) : INF_LCP;
         __syncthreads();
     }
     // ---- leaves' parents, branch nodes, their dense ids and the per-depth counts ----
@@ -915,6 +963,7 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
         const uint32_t i = c0 + tid;
         if (i < n && i != 0u && t.dense[i] != NONE) {
             const int32_t d = t.lcp[i];
+            resolve_parent(t, i);
             t.order[s_begin[d] + atomicAdd(&s_cur[d], 1u)] = i;
         }
     }
@@ -977,26 +1026,44 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     t.seg_first = d_seg_first;
     t.n_tries = n_tries;
     t.roots = d_roots;
-    hipLaunchKernelGGL(fill_empty_roots_kernel, dim3(blocks(n_tries)), dim3(256), 0, st, d_roots, n_tries);
-    TB_TRY(hipGetLastError());
-    if (n == 0) return PHANT_OK;
+    if (n >= 0x7fffffffu) {  // (identify_element keeps a bit of a boundary index for itself)
+        err = "more than 2^31 - 2 keys in one call";
+        return PHANT_E_UNSUPPORTED;
+    }
+    if (n == 0) {
+        hipLaunchKernelGGL(fill_empty_roots_kernel, dim3(blocks(n_tries)), dim3(256), 0, st, d_roots, n_tries);
+        TB_TRY(hipGetLastError());
+        return PHANT_OK;
+    }
 
-    uint32_t M = 1;
-    while (M < n + 1) M <<= 1;
-    t.M = M;
+    // the min-tree's levels: level 0 = the n + 1 lcp values, every level padded to whole groups, the top level ONE group
+    size_t tree_ints = 0;
+    {
+        auto pad = [](uint64_t v) { return (uint32_t)((v + FAN - 1u) / FAN * FAN); };
+        t.lvl_size[0] = pad((uint64_t)n + 1);
+        t.lvl_off[0] = 0;
+        t.n_lvl = 1;
+        while (t.lvl_size[t.n_lvl - 1u] > FAN) {
+            t.lvl_size[t.n_lvl] = pad(t.lvl_size[t.n_lvl - 1u] / FAN);
+            t.lvl_off[t.n_lvl] = (uint32_t)tree_ints;
+            tree_ints += t.lvl_size[t.n_lvl];
+            ++t.n_lvl;
+        }
+    }
     {
         const size_t n1 = (size_t)n + 1;
-        const size_t total = DevArena::round(n1) + DevArena::round(n1 * 4) * 6 + DevArena::round((size_t)2 * M * 4) +
+        const size_t total = DevArena::round(n1) + DevArena::round(n1 * 4 + 64) * 7 + DevArena::round(tree_ints * 4 + 64) +
                              DevArena::round((size_t)n * 4) * 3 + DevArena::round((8 + MAX_DEPTH_BINS) * 4) +
                              DevArena::round(MAX_DEPTH_BINS * 4) * 2 + 256 + 4096;
         TB_TRY(ws.t1.reset(total));
         t.first_flag = ws.t1.take<uint8_t>(n1);
-        t.lcp = ws.t1.take<int32_t>(n1);
-        t.tree = ws.t1.take<int32_t>((size_t)2 * M);
+        t.lcp = ws.t1.take<int32_t>(t.lvl_size[0]);
+        t.tree = ws.t1.take<int32_t>(tree_ints + FAN);
         t.dense = ws.t1.take<uint32_t>(n1);
         t.nd_l = ws.t1.take<uint32_t>(n1);
         t.nd_pd = ws.t1.take<int32_t>(n1);
         t.nd_parent = ws.t1.take<uint32_t>(n1);
+        t.nd_rep = ws.t1.take<uint32_t>(n1);
         t.value_key = ws.t1.take<uint32_t>(n1);
         t.leaf_parent = ws.t1.take<uint32_t>(n);
         t.leaf_ps = ws.t1.take<uint32_t>(n);
@@ -1035,18 +1102,22 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         return PHANT_OK;
     }
 
+    // head (roots, counters, a forest's start flags) -> [first_flag] -> lcp (+ markers, + the min-tree's padding): three or two
+    // launches where there were five.  ONE trie has no start but key 0 and goes without the flags.
+    if (n_tries == 1) t.first_flag = nullptr;
     {
-        const uint64_t lanes = (uint64_t)n + 1 > 8u + MAX_DEPTH_BINS ? (uint64_t)n + 1 : 8u + MAX_DEPTH_BINS;
-        hipLaunchKernelGGL(trie_init_kernel, dim3(blocks(lanes)), dim3(256), 0, st, t);
+        uint64_t lanes = 8u + MAX_DEPTH_BINS;
+        if (n_tries > lanes) lanes = n_tries;
+        if (t.first_flag && (uint64_t)n + 1 > lanes) lanes = (uint64_t)n + 1;
+        hipLaunchKernelGGL(head_kernel, dim3(blocks(lanes)), dim3(256), 0, st, t);
     }
-
-    hipLaunchKernelGGL(first_flag_kernel, dim3(blocks(n_tries)), dim3(256), 0, st, t);
-    hipLaunchKernelGGL(lcp_kernel, dim3(blocks((uint64_t)n + 1)), dim3(256), 0, st, t);
-    if (M > n + 1) hipLaunchKernelGGL(tree_pad_kernel, dim3(blocks(M - n - 1)), dim3(256), 0, st, t);
-    for (uint32_t w = M; w > 1u;) {  // M is a power of two
-        const uint32_t T = w < TREE_TILE ? w : TREE_TILE;
-        hipLaunchKernelGGL(tree_tile_kernel, dim3(w / T), dim3(256), 0, st, t.tree, w, T);
-        w /= T;
+    if (t.first_flag) hipLaunchKernelGGL(first_flag_kernel, dim3(blocks(n_tries)), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(lcp_kernel, dim3(blocks(t.lvl_size[0])), dim3(256), 0, st, t);
+    for (uint32_t base = 0; base + 1u < t.n_lvl; base += 3u) {  // (the grid covers the widest of the three levels it writes)
+        uint32_t g = (t.lvl_size[base + 1u] + 255u) / 256u;
+        if (base + 2u < t.n_lvl && (t.lvl_size[base + 2u] + FAN - 1u) / FAN > g) g = (t.lvl_size[base + 2u] + FAN - 1u) / FAN;
+        if (base + 3u < t.n_lvl && t.lvl_size[base + 3u] > g) g = t.lvl_size[base + 3u];
+        hipLaunchKernelGGL(tree_levels_kernel, dim3(g), dim3(256), 0, st, t, base);
     }
     hipLaunchKernelGGL(identify_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
     TB_TRY(hipGetLastError());
