@@ -73,7 +73,7 @@ struct Workspaces {
     }
     // A few pinned, device-visible words for what a pass reads back in the middle of a call (the trie builder's counters): a
     // copy into pageable memory costs ~25 us, a kernel that stores its flags here costs nothing beyond the synchronisation.
-    static constexpr size_t MAILBOX_WORDS = 1024;
+    static constexpr size_t MAILBOX_WORDS = 2048;
     uint32_t* mailbox = nullptr;
     hipError_t ensure_mailbox() {
         return mailbox ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&mailbox), MAILBOX_WORDS * 4, hipHostMallocDefault);

@@ -40,6 +40,7 @@ constexpr int MAX_DEPTH_BINS = 512;             // nibble depth <= 2*255
 constexpr int INF_LCP = 0x7fffffff;
 constexpr uint32_t FAN = 16;      // fan-out of the min-tree: a group of children is one 64-byte line
 constexpr int MAX_LEVELS = 8;      // 16^8 boundaries
+constexpr uint32_t N_COUNTERS = 8u + 2u * (uint32_t)MAX_DEPTH_BINS;
 
 struct TrieDev {
     const uint8_t* keys;
@@ -69,9 +70,12 @@ struct TrieDev {
     // scratch blob for encodings
     uint8_t* scratch;
     unsigned long long* cursor;
-    // counters[0] = n_rep, [1] = error flags, [2] = scratch overflow, [3] = some leaf may reach a rate block, hist at [8..8+512)
+    // counters[0] = n_rep, [1] = error flags, [2] = scratch overflow, [3] = some leaf may reach a rate block, branch nodes per depth
+    // at [8..8+512), their children (leaves and nodes) per depth at [8+512..8+1024)
     uint32_t* counters;
     uint32_t* order;      // rep boundaries grouped by depth
+    uint32_t* order2;     // per depth bin, from its start: the nodes that did not fit the slot class the bin was run in
+    uint32_t* misfit;     // 512: how many of those
     uint32_t* depth_cursor;  // 512
     uint8_t* roots;       // n_tries x 32
     uint8_t* root_enc;    // optional: n_tries x root_enc_cap, the RLP of every trie's root node
@@ -215,8 +219,11 @@ __global__ void __launch_bounds__(256) head_kernel(TrieDev t) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < t.n_tries) store_empty_root(t.roots + 32ull * i);
     if (t.first_flag && i <= t.n) t.first_flag[i] = 0;
-    if (i < 8u + (uint32_t)MAX_DEPTH_BINS) t.counters[i] = 0u;
-    if (i < (uint32_t)MAX_DEPTH_BINS) t.depth_cursor[i] = 0u;
+    if (i < N_COUNTERS) t.counters[i] = 0u;
+    if (i < (uint32_t)MAX_DEPTH_BINS) {
+        t.depth_cursor[i] = 0u;
+        t.misfit[i] = 0u;
+    }
     if (i == 0) *t.cursor = 0ull;
 }
 
@@ -279,9 +286,10 @@ PHANT_DEV uint32_t next_less(const TrieDev& t, uint32_t i, int32_t thr) {
 // pass (resolve_parent).  (Before: up to six queries in a lane, each a chain of dependent loads; the kernel is as long as the
 // slowest lane of its slowest wave.)
 constexpr uint32_t VIA = 0x80000000u;  // (boundaries stay below 2^31 - 1: forest_device checks)
-PHANT_DEV bool identify_element(const TrieDev& t, const uint32_t i, int32_t& d) {
+PHANT_DEV bool identify_element(const TrieDev& t, const uint32_t i, int32_t& d, int32_t& leaf_under, int32_t& node_under) {
     const int32_t dl = t.lcp[i], dr = t.lcp[i + 1];
     d = dl;
+    leaf_under = node_under = -1;  // the depth of the node that gets key i's leaf / node i as a child (statistics)
     uint32_t PL = 0, R = NONE;
     if (i >= 1 && dl >= 0) {
         PL = prev_less(t, i, dl);
@@ -301,6 +309,7 @@ PHANT_DEV bool identify_element(const TrieDev& t, const uint32_t i, int32_t& d) 
             t.leaf_ps[i] = BRANCH_VALUE;
         } else {
             t.leaf_ps[i] = (uint32_t)di + 1u;
+            leaf_under = di;
         }
     }
     // --- boundary i as a branch node ---
@@ -312,6 +321,7 @@ PHANT_DEV bool identify_element(const TrieDev& t, const uint32_t i, int32_t& d) 
     t.nd_l[i] = l;
     t.nd_pd[i] = pd;
     t.nd_parent[i] = pd < 0 ? NONE : (pl >= pr ? (VIA | l) : r1);
+    node_under = pd;
     return true;
 }
 // the parent of node i, final (for the pass behind identify: every lane's nd_rep is in memory)
@@ -329,15 +339,18 @@ constexpr uint32_t COUNT_BLOCK = 1024;
 
 __global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
     __shared__ uint32_t s_hist[MAX_DEPTH_BINS];
+    __shared__ uint32_t s_child[MAX_DEPTH_BINS];  // children per depth: the host picks a bin's LDS slot size from the bin's mean fan-out
     __shared__ uint32_t s_wave_reps[COUNT_BLOCK / 64];
     __shared__ uint32_t s_dense_base;
     const uint32_t i = blockIdx.x * COUNT_BLOCK + threadIdx.x;
-    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK) s_hist[b] = 0u;
+    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK) s_hist[b] = s_child[b] = 0u;
     __syncthreads();
     const bool in = i < t.n;
     uint32_t dn = NONE;
-    int32_t d = -1;
-    const bool is_rep = in && identify_element(t, i, d);
+    int32_t d = -1, leaf_under = -1, node_under = -1;
+    const bool is_rep = in && identify_element(t, i, d, leaf_under, node_under);
+    if (leaf_under >= 0) atomicAdd(&s_child[leaf_under], 1u);
+    if (node_under >= 0) atomicAdd(&s_child[node_under], 1u);
     // could this key's leaf reach a rate block?  (list header <= 3, hex-prefix string <= key bytes + 3, value string <= bytes + 3:
     // the host launches leaf_big_kernel only if some key says yes -- a state trie's 110-byte leaves never do)
     {
@@ -356,8 +369,10 @@ __global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
         for (uint32_t w = 0; w < COUNT_BLOCK / 64u; ++w) tot += s_wave_reps[w];
         s_dense_base = tot ? atomicAdd(&t.counters[0], tot) : 0u;
     }
-    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK)
+    for (uint32_t b = threadIdx.x; b < (uint32_t)MAX_DEPTH_BINS; b += COUNT_BLOCK) {
         if (s_hist[b]) atomicAdd(&t.counters[8 + b], s_hist[b]);
+        if (s_child[b]) atomicAdd(&t.counters[8 + MAX_DEPTH_BINS + b], s_child[b]);
+    }
     __syncthreads();
     if (is_rep) {
         uint32_t base = s_dense_base;
@@ -753,14 +768,14 @@ struct BranchPlan {
     const uint8_t* v;
     int32_t d, pd;
 };
-PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t at, const bool live) {
+PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t* list, const uint32_t at, const bool live) {
     BranchPlan p;
     p.live = live;
     p.i = p.dn = p.total = 0;
     p.payload = p.vlen = 0;
     p.v = nullptr;
     if (live) {
-        p.i = t.order[at];
+        p.i = list[at];
         p.dn = t.dense[p.i];
         // the 16 slot lengths: one aligned 16-byte load
         const uint4 sl4 = *reinterpret_cast<const uint4*>(t.slot_len + (uint64_t)p.dn * 16u);
@@ -792,6 +807,9 @@ PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t at, const bool
 }
 // built in the lane's LDS slot (BRANCH_STAGE_DW dwords) / at byte `at` of the scratch blob, hashed, the extension above it
 // likewise, delivered to the parent's slot table
+// (STAGE_DW: the lane's slot.  With less than four rate blocks the caller has checked fits_slot: node and extension fit the
+// slot and an extension sits on a HASHED branch)
+template <uint32_t STAGE_DW>
 PHANT_DEV void branch_emit(const TrieDev& t, const BranchPlan& p, uint32_t* slot, const unsigned long long at) {
     const uint32_t parent = t.nd_parent[p.i];
     const bool is_root = parent == NONE;
@@ -799,7 +817,7 @@ PHANT_DEV void branch_emit(const TrieDev& t, const BranchPlan& p, uint32_t* slot
     Sponge s;
     sponge_zero(s);
     if (p.staged) {
-        stage_clear<BRANCH_STAGE_DW>(slot);
+        stage_clear<STAGE_DW>(slot);
         uint8_t* enc = reinterpret_cast<uint8_t*>(slot);
         (void)put_branch(enc, t, p.dn, p.payload, p.v, p.vlen);
         if (hashed) keccak256_staged(s, slot, p.total);
@@ -809,7 +827,7 @@ PHANT_DEV void branch_emit(const TrieDev& t, const BranchPlan& p, uint32_t* slot
             // whole slot again once the branch is a digest in registers
             uint32_t* xslot = slot + 2u * RATE_DWORDS;
             if (hashed) {
-                stage_clear<BRANCH_STAGE_DW>(slot);
+                stage_clear<STAGE_DW>(slot);
                 xslot = slot;
             }
             uint8_t* xenc = reinterpret_cast<uint8_t*>(xslot);
@@ -839,25 +857,66 @@ PHANT_DEV void branch_emit(const TrieDev& t, const BranchPlan& p, uint32_t* slot
     deliver(t, parent, is_root ? 0u : nib_at(t, p.l, (uint32_t)p.pd), p.l, enc, out_len, s, hashed);
 }
 
-__global__ void __launch_bounds__(BRANCH_LANES) branch_kernel(TrieDev t, uint32_t begin, uint32_t count) {
-    __shared__ uint32_t s_stage[BRANCH_LANES * BRANCH_STAGE_DW];
+// A depth bin, in one of three slot classes.  A lane's node is staged in LDS whole, and what a workgroup may hold of LDS decides
+// how many waves share a SIMD: four-block slots (any node up to a full branch with an extension) = ONE; but the crowded bins of a
+// big trie are the sparse ones below its last full level (a million random keys: 250 000 nodes of two or three children on one
+// depth -- 133 us at one wave per SIMD), and a forest's tries of a handful of keys.  BLOCKS = 1 / 2: 256 / 128 lanes share the
+// same 35 KB (four / two waves per SIMD); a node that does not fit its lane's slot goes to the bin's fallback list
+// (order2 from the bin's start, misfit[depth]), which the launcher runs through the four-block class behind it
+// (`dev_count`: the count comes from the device).  The launcher picks the class from the bin's mean fan-out (identify_kernel).
+template <uint32_t BLOCKS>
+PHANT_DEV bool fits_slot(const BranchPlan& p) {
+    if (BLOCKS == BRANCH_STAGE_BLOCKS) return p.staged;
+    return p.live && p.payload + 8u < BLOCKS * RATE && p.total < BLOCKS * RATE && (p.ext_len == 0u || (p.total >= 32u && p.ext_cap < BLOCKS * RATE));
+}
+template <uint32_t BLOCKS>
+__global__ void __launch_bounds__(256 / BLOCKS) branch_kernel(TrieDev t, const uint32_t* list, uint32_t begin, uint32_t count,
+                                                              const uint32_t* dev_count, uint32_t* misfit_count) {
+    constexpr uint32_t LANES = 256u / BLOCKS, STAGE_DW = BLOCKS * RATE_DWORDS + 1u;
+    __shared__ uint32_t s_stage[LANES * STAGE_DW];
     __shared__ uint32_t s_total;
     __shared__ unsigned long long s_base;
-    const uint32_t q = blockIdx.x * BRANCH_LANES + threadIdx.x;
-    const BranchPlan p = branch_plan(t, begin + q, q < count);
-    // room in the scratch blob for the nodes that do not fit their slot: one reservation per workgroup (= wave)
+    if (dev_count) count = *dev_count;
+    const uint32_t q = blockIdx.x * LANES + threadIdx.x;
+    if (blockIdx.x * LANES >= count) return;  // (the fallback pass is launched for the whole bin: most of its workgroups find nothing)
+    BranchPlan p = branch_plan(t, list, begin + q, q < count);
+    if (BLOCKS < BRANCH_STAGE_BLOCKS) {
+        const bool fits = fits_slot<BLOCKS>(p);
+        if (fits) branch_emit<STAGE_DW>(t, p, s_stage + threadIdx.x * STAGE_DW, 0ull);
+        // the misfits, behind the work and with ONE reservation per workgroup: returning atomics on one address are served one
+        // at a time (~12 ns: per wave they were 47 us of a 250 000-node bin, each in front of its wave's Keccak-f)
+        __shared__ uint32_t s_mis[LANES / 64u + 1u];
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const bool mis = p.live && !fits;
+        const unsigned long long m = __ballot(mis);
+        if (lane == 0) s_mis[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < LANES / 64u; ++w) tot += s_mis[w];
+            s_mis[LANES / 64u] = tot ? atomicAdd(misfit_count, tot) : 0u;
+        }
+        __syncthreads();
+        if (mis) {
+            uint32_t base = s_mis[LANES / 64u];
+            for (uint32_t w = 0; w < wave; ++w) base += s_mis[w];
+            t.order2[begin + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p.i;
+        }
+        return;
+    }
+    // room in the scratch blob for the nodes that do not fit even four blocks: one reservation per workgroup (= wave)
     uint32_t incl = p.need;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_up(incl, o, 64);
         if ((threadIdx.x & 63u) >= (uint32_t)o) incl += up;
     }
-    if (threadIdx.x == BRANCH_LANES - 1u) s_total = incl;
+    if (threadIdx.x == LANES - 1u) s_total = incl;
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_total ? atomicAdd(t.cursor, (unsigned long long)s_total) : 0ull;
     __syncthreads();
     if (!p.live) return;
-    branch_emit(t, p, s_stage + threadIdx.x * BRANCH_STAGE_DW, s_base + (incl - p.need));
+    branch_emit<STAGE_DW>(t, p, s_stage + threadIdx.x * STAGE_DW, s_base + (incl - p.need));
 }
 
 static_assert(BRANCH_STAGE_BYTES_ == BRANCH_STAGE_BYTES && BRANCH_STAGE_DW_ == BRANCH_STAGE_DW, "one slot size for big leaves and branches");
@@ -897,7 +956,7 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
         t.value_key[i] = NONE;
         t.dense[i] = NONE;
     }
-    for (uint32_t i = tid; i < 8u + (uint32_t)MAX_DEPTH_BINS; i += B) t.counters[i] = 0u;
+    for (uint32_t i = tid; i < N_COUNTERS; i += B) t.counters[i] = 0u;
     for (uint32_t b = tid; b < (uint32_t)MAX_DEPTH_BINS; b += B) {
         s_hist[b] = 0u;
         s_cur[b] = 0u;
@@ -929,8 +988,8 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
     // ---- leaves' parents, branch nodes, their dense ids and the per-depth counts ----
     for (uint32_t c0 = 0; c0 < n; c0 += B) {
         const uint32_t i = c0 + tid;
-        int32_t d = -1;
-        const bool is_rep = i < n && identify_element(t, i, d);
+        int32_t d = -1, leaf_under, node_under;
+        const bool is_rep = i < n && identify_element(t, i, d, leaf_under, node_under);
         const unsigned long long reps = __ballot(is_rep);
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(reps);
         if (is_rep) atomicAdd(&s_hist[d], 1u);
@@ -983,8 +1042,8 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
         if (!c) continue;
         for (uint32_t q0 = 0; q0 < c; q0 += B) {
             const uint32_t q = q0 + tid;
-            const BranchPlan p = branch_plan(t, s_begin[d] + q, q < c);
-            if (p.live) branch_emit(t, p, s_stage + tid * BRANCH_STAGE_DW, p.need ? atomicAdd(t.cursor, (unsigned long long)p.need) : 0ull);
+            const BranchPlan p = branch_plan(t, t.order, s_begin[d] + q, q < c);
+            if (p.live) branch_emit<BRANCH_STAGE_DW>(t, p, s_stage + tid * BRANCH_STAGE_DW, p.need ? atomicAdd(t.cursor, (unsigned long long)p.need) : 0ull);
         }
         __syncthreads();  // the level's references sit in their parents' slot tables
     }
@@ -1005,6 +1064,8 @@ __global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
 inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
 
 }  // namespace
+
+constexpr uint32_t CROWDED_BIN = 4u * 256u * 64u;  // nodes: above it a bin in four-block slots (one wave per SIMD) no longer fits the chip at once
 
 // Device-side forest build; all pointers device memory, except roots_host.
 static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off,
@@ -1053,8 +1114,8 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     {
         const size_t n1 = (size_t)n + 1;
         const size_t total = DevArena::round(n1) + DevArena::round(n1 * 4 + 64) * 7 + DevArena::round(tree_ints * 4 + 64) +
-                             DevArena::round((size_t)n * 4) * 3 + DevArena::round((8 + MAX_DEPTH_BINS) * 4) +
-                             DevArena::round(MAX_DEPTH_BINS * 4) * 2 + 256 + 4096;
+                             DevArena::round((size_t)n * 4) * 4 + DevArena::round(N_COUNTERS * 4) +
+                             DevArena::round(MAX_DEPTH_BINS * 4) * 3 + 256 + 4096;
         TB_TRY(ws.t1.reset(total));
         t.first_flag = ws.t1.take<uint8_t>(n1);
         t.lcp = ws.t1.take<int32_t>(t.lvl_size[0]);
@@ -1068,7 +1129,9 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         t.leaf_parent = ws.t1.take<uint32_t>(n);
         t.leaf_ps = ws.t1.take<uint32_t>(n);
         t.order = ws.t1.take<uint32_t>(n);
-        t.counters = ws.t1.take<uint32_t>(8 + MAX_DEPTH_BINS);
+        t.order2 = ws.t1.take<uint32_t>(n);
+        t.misfit = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
+        t.counters = ws.t1.take<uint32_t>(N_COUNTERS);
         t.depth_cursor = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
         t.cursor = ws.t1.take<unsigned long long>(1);
     }
@@ -1106,7 +1169,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     // launches where there were five.  ONE trie has no start but key 0 and goes without the flags.
     if (n_tries == 1) t.first_flag = nullptr;
     {
-        uint64_t lanes = 8u + MAX_DEPTH_BINS;
+        uint64_t lanes = N_COUNTERS;
         if (n_tries > lanes) lanes = n_tries;
         if (t.first_flag && (uint64_t)n + 1 > lanes) lanes = (uint64_t)n + 1;
         hipLaunchKernelGGL(head_kernel, dim3(blocks(lanes)), dim3(256), 0, st, t);
@@ -1122,10 +1185,10 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     hipLaunchKernelGGL(identify_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
     TB_TRY(hipGetLastError());
 
-    static_assert(8 + MAX_DEPTH_BINS <= Workspaces::MAILBOX_WORDS, "the counters fit the pinned mailbox");
-    TB_TRY(hipMemcpyAsync(ws.mailbox, t.counters, (8 + MAX_DEPTH_BINS) * 4, hipMemcpyDeviceToHost, st));
+    static_assert(N_COUNTERS <= Workspaces::MAILBOX_WORDS, "the counters fit the pinned mailbox");
+    TB_TRY(hipMemcpyAsync(ws.mailbox, t.counters, N_COUNTERS * 4, hipMemcpyDeviceToHost, st));
     TB_TRY(hipStreamSynchronize(st));
-    const std::vector<uint32_t> cnt(ws.mailbox, ws.mailbox + 8 + MAX_DEPTH_BINS);
+    const std::vector<uint32_t> cnt(ws.mailbox, ws.mailbox + N_COUNTERS);
     if (cnt[1] & ERR_KEY_RANGE) {
         err = "key longer than 255 bytes, or key offsets not monotone";
         return PHANT_E_INVALID_ARG;
@@ -1160,10 +1223,31 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     // their leaf is small was 24 us per million keys)
     if (cnt[3])
         hipLaunchKernelGGL(leaf_big_kernel, dim3((n + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t);
+    // A bin's slot class (branch_kernel): four blocks unless the bin is crowded (more workgroups than the chip holds at once) and
+    // its mean fan-out says that most of its nodes fit less; what does not fit is run through the four-block class behind it.
+    static const int force_blocks = std::getenv("PHANT_TRIE_SLOT_BLOCKS") ? std::atoi(std::getenv("PHANT_TRIE_SLOT_BLOCKS")) : 0;  // (A/B)
     for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
         const uint32_t c = cnt[8 + d];
         if (!c) continue;
-        hipLaunchKernelGGL(branch_kernel, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t, depth_begin[d], c);
+        const uint64_t children = cnt[8 + MAX_DEPTH_BINS + d];
+        uint32_t blocks = BRANCH_STAGE_BLOCKS;
+        if (c >= CROWDED_BIN) {
+            static const bool no_one = std::getenv("PHANT_TRIE_NO_ONE_BLOCK") != nullptr;  // (A/B)
+            if (children <= 3ull * c && !no_one) blocks = 1;        // (<= 3 children of 33 bytes: one rate block)
+            else if (children <= 6ull * c) blocks = 2;   // (<= 7: two)
+        }
+        if (force_blocks == 1 || force_blocks == 2 || force_blocks == 4) blocks = (uint32_t)force_blocks;
+        uint32_t* const mis = t.misfit + d;
+        if (blocks == 1)
+            hipLaunchKernelGGL(branch_kernel<1>, dim3((c + 255u) / 256u), dim3(256), 0, st, t, t.order, depth_begin[d], c, nullptr, mis);
+        else if (blocks == 2)
+            hipLaunchKernelGGL(branch_kernel<2>, dim3((c + 127u) / 128u), dim3(128), 0, st, t, t.order, depth_begin[d], c, nullptr, mis);
+        if (blocks != BRANCH_STAGE_BLOCKS)
+            hipLaunchKernelGGL(branch_kernel<BRANCH_STAGE_BLOCKS>, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t, t.order2,
+                               depth_begin[d], 0u, mis, nullptr);
+        else
+            hipLaunchKernelGGL(branch_kernel<BRANCH_STAGE_BLOCKS>, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t, t.order,
+                               depth_begin[d], c, nullptr, nullptr);
     }
     TB_TRY(hipGetLastError());
     TB_TRY(hipMemcpyAsync(ws.mailbox, t.counters, 3 * 4, hipMemcpyDeviceToHost, st));
