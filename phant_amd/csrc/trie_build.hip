@@ -877,48 +877,51 @@ __global__ void __launch_bounds__(256 / BLOCKS) branch_kernel(TrieDev t, const u
     __shared__ uint32_t s_total;
     __shared__ unsigned long long s_base;
     if (dev_count) count = *dev_count;
-    const uint32_t q = blockIdx.x * LANES + threadIdx.x;
-    if (blockIdx.x * LANES >= count) return;  // (the fallback pass is launched for the whole bin: most of its workgroups find nothing)
-    BranchPlan p = branch_plan(t, list, begin + q, q < count);
-    if (BLOCKS < BRANCH_STAGE_BLOCKS) {
-        const bool fits = fits_slot<BLOCKS>(p);
-        if (fits) branch_emit<STAGE_DW>(t, p, s_stage + threadIdx.x * STAGE_DW, 0ull);
-        // the misfits, behind the work and with ONE reservation per workgroup: returning atomics on one address are served one
-        // at a time (~12 ns: per wave they were 47 us of a 250 000-node bin, each in front of its wave's Keccak-f)
-        __shared__ uint32_t s_mis[LANES / 64u + 1u];
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const bool mis = p.live && !fits;
-        const unsigned long long m = __ballot(mis);
-        if (lane == 0) s_mis[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (uint32_t w = 0; w < LANES / 64u; ++w) tot += s_mis[w];
-            s_mis[LANES / 64u] = tot ? atomicAdd(misfit_count, tot) : 0u;
+    // (the fallback pass does not know its count when it is launched: a grid of at most FALLBACK_GRID workgroups strides over the
+    // list -- dispatching a workgroup per 64 nodes of the whole bin, nearly all of them to find nothing, was 35 us of a 250 000-node bin)
+    for (uint32_t first = blockIdx.x * LANES; first < count; first += gridDim.x * LANES) {
+        const uint32_t q = first + threadIdx.x;
+        BranchPlan p = branch_plan(t, list, begin + q, q < count);
+        if (BLOCKS < BRANCH_STAGE_BLOCKS) {
+            const bool fits = fits_slot<BLOCKS>(p);
+            if (fits) branch_emit<STAGE_DW>(t, p, s_stage + threadIdx.x * STAGE_DW, 0ull);
+            // the misfits, behind the work and with ONE reservation per workgroup: returning atomics on one address are served one
+            // at a time (~12 ns: per wave they were 47 us of a 250 000-node bin, each in front of its wave's Keccak-f)
+            __shared__ uint32_t s_mis[LANES / 64u + 1u];
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            const bool mis = p.live && !fits;
+            const unsigned long long m = __ballot(mis);
+            if (lane == 0) s_mis[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tot = 0;
+                for (uint32_t w = 0; w < LANES / 64u; ++w) tot += s_mis[w];
+                s_mis[LANES / 64u] = tot ? atomicAdd(misfit_count, tot) : 0u;
+            }
+            __syncthreads();
+            if (mis) {
+                uint32_t base = s_mis[LANES / 64u];
+                for (uint32_t w = 0; w < wave; ++w) base += s_mis[w];
+                t.order2[begin + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p.i;
+            }
+            __syncthreads();
+            continue;
         }
-        __syncthreads();
-        if (mis) {
-            uint32_t base = s_mis[LANES / 64u];
-            for (uint32_t w = 0; w < wave; ++w) base += s_mis[w];
-            t.order2[begin + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p.i;
-        }
-        return;
-    }
-    // room in the scratch blob for the nodes that do not fit even four blocks: one reservation per workgroup (= wave)
-    uint32_t incl = p.need;
+        // room in the scratch blob for the nodes that do not fit even four blocks: one reservation per workgroup (= wave)
+        uint32_t incl = p.need;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if ((threadIdx.x & 63u) >= (uint32_t)o) incl += up;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if ((threadIdx.x & 63u) >= (uint32_t)o) incl += up;
+        }
+        if (threadIdx.x == LANES - 1u) s_total = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_total ? atomicAdd(t.cursor, (unsigned long long)s_total) : 0ull;
+        __syncthreads();
+        if (p.live) branch_emit<STAGE_DW>(t, p, s_stage + threadIdx.x * STAGE_DW, s_base + (incl - p.need));
+        __syncthreads();
     }
-    if (threadIdx.x == LANES - 1u) s_total = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = s_total ? atomicAdd(t.cursor, (unsigned long long)s_total) : 0ull;
-    __syncthreads();
-    if (!p.live) return;
-    branch_emit<STAGE_DW>(t, p, s_stage + threadIdx.x * STAGE_DW, s_base + (incl - p.need));
 }
-
 static_assert(BRANCH_STAGE_BYTES_ == BRANCH_STAGE_BYTES && BRANCH_STAGE_DW_ == BRANCH_STAGE_DW, "one slot size for big leaves and branches");
 __global__ void __launch_bounds__(BRANCH_LANES) leaf_big_kernel(TrieDev t) {
     __shared__ uint32_t s_stage[BRANCH_LANES * BRANCH_STAGE_DW];
@@ -1065,6 +1068,7 @@ inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
 
 }  // namespace
 
+constexpr uint32_t FALLBACK_GRID = 1024;           // workgroups of a bin's fallback pass (its count is on the device)
 constexpr uint32_t CROWDED_BIN = 4u * 256u * 64u;  // nodes: above it a bin in four-block slots (one wave per SIMD) no longer fits the chip at once
 
 // Device-side forest build; all pointers device memory, except roots_host.
@@ -1225,6 +1229,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         hipLaunchKernelGGL(leaf_big_kernel, dim3((n + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t);
     // A bin's slot class (branch_kernel): four blocks unless the bin is crowded (more workgroups than the chip holds at once) and
     // its mean fan-out says that most of its nodes fit less; what does not fit is run through the four-block class behind it.
+    static const uint32_t fallback_grid = std::getenv("PHANT_TRIE_FALLBACK_GRID") ? (uint32_t)std::max(1, std::atoi(std::getenv("PHANT_TRIE_FALLBACK_GRID"))) : FALLBACK_GRID;  // (test knob)
     static const int force_blocks = std::getenv("PHANT_TRIE_SLOT_BLOCKS") ? std::atoi(std::getenv("PHANT_TRIE_SLOT_BLOCKS")) : 0;  // (A/B)
     for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
         const uint32_t c = cnt[8 + d];
@@ -1243,8 +1248,8 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         else if (blocks == 2)
             hipLaunchKernelGGL(branch_kernel<2>, dim3((c + 127u) / 128u), dim3(128), 0, st, t, t.order, depth_begin[d], c, nullptr, mis);
         if (blocks != BRANCH_STAGE_BLOCKS)
-            hipLaunchKernelGGL(branch_kernel<BRANCH_STAGE_BLOCKS>, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t, t.order2,
-                               depth_begin[d], 0u, mis, nullptr);
+            hipLaunchKernelGGL(branch_kernel<BRANCH_STAGE_BLOCKS>, dim3(std::min((c + BRANCH_LANES - 1u) / BRANCH_LANES, fallback_grid)), dim3(BRANCH_LANES), 0,
+                               st, t, t.order2, depth_begin[d], 0u, mis, nullptr);
         else
             hipLaunchKernelGGL(branch_kernel<BRANCH_STAGE_BLOCKS>, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t, t.order,
                                depth_begin[d], c, nullptr, nullptr);

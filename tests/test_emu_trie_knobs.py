@@ -1,0 +1,21 @@
+"""The trie hasher's launch-time choices, forced: a depth bin's slot class is picked from the bin's size and mean fan-out, which
+only a big trie on the GPU reaches.  Here every bin of small tries runs in the one- / two-block class (what does not fit takes the
+fallback list), with a fallback grid of ONE workgroup (the grid-stride loop), against the oracle -- the test bodies of
+tests/test_gpu_trie.py over the emulated kernels (tests/emu.py), each setting in a process of its own (the knobs are read once)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUBSET = "random_vs_oracle or variable_length or state_root_random or block_roots or receipt_trie"
+
+
+@pytest.mark.parametrize("env", [{"PHANT_TRIE_SLOT_BLOCKS": "1", "PHANT_TRIE_FALLBACK_GRID": "1"},
+                                 {"PHANT_TRIE_SLOT_BLOCKS": "2", "PHANT_TRIE_FALLBACK_GRID": "1"}],
+                         ids=["one_block_slots", "two_block_slots"])
+def test_slot_classes_and_fallback_lists(env):
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_emu_trie.py", "-x", "-q", "-p", "no:cacheprovider", "-k", SUBSET],
+                       cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and " passed" in r.stdout and " failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
