@@ -22,6 +22,8 @@
 // at once: trie starts are just lcp = -1 boundaries.
 #include "trie_build.h"
 
+#include <utility>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -762,7 +764,7 @@ constexpr uint32_t BRANCH_STAGE_BYTES = BRANCH_STAGE_BLOCKS * RATE;
 
 // what the branch node with representative boundary order[at] looks like (live: there is one)
 struct BranchPlan {
-    bool live, staged;
+    bool live, staged, full;  // full: sixteen 32-byte children and no value (f9 02 11 ...: 532 bytes)
     uint32_t i, dn, total, ext_len, l, ext_cap, need;
     uint64_t payload, vlen;
     const uint8_t* v;
@@ -774,6 +776,7 @@ PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t* list, const u
     p.i = p.dn = p.total = 0;
     p.payload = p.vlen = 0;
     p.v = nullptr;
+    p.full = false;
     if (live) {
         p.i = list[at];
         p.dn = t.dense[p.i];
@@ -785,8 +788,10 @@ PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t* list, const u
             const uint32_t sl = (slw[k >> 2] >> (8u * (k & 3u))) & 0xffu;
             p.payload += sl == 0 ? 1u : (sl == 32u ? 33u : sl);
         }
+        p.full = slw[0] == 0x20202020u && slw[1] == 0x20202020u && slw[2] == 0x20202020u && slw[3] == 0x20202020u;
         const uint32_t vk = t.value_key[p.i];
         if (vk != NONE) {
+            p.full = false;
             p.v = t.vals + t.val_off[vk];
             p.vlen = t.val_off[vk + 1] - t.val_off[vk];
         }
@@ -857,6 +862,89 @@ PHANT_DEV void branch_emit(const TrieDev& t, const BranchPlan& p, uint32_t* slot
     deliver(t, parent, is_root ? 0u : nib_at(t, p.l, (uint32_t)p.pd), p.l, enc, out_len, s, hashed);
 }
 
+// ---- the full branch, built in registers ----
+// f9 02 11 | 16 x (a0 | 32-byte reference) | 80 = 532 bytes (mpt.zig:216-231 with sixteen hashed children and no value): what
+// every node of a big trie's dense levels is.  Byte q of the node is a constant (q < 3, q = 531, q = 3 + 33 c) or byte
+// (q - 4) mod 33 of child (q - 3) / 33 -- all known at compile time, so a rate block is 34 dwords funnelled out of the slot table's
+// dwords (v_alignbyte; four bytes apiece where a marker sits) and absorbed from registers: no LDS slot (the 35 KiB of
+// branch_kernel's workgroups leave a SIMD ONE wave either way), no byte stores, the sixteen children in four round trips of
+// eight loads.  branch_kernel takes this way when EVERY node of the wave is such a node (the top levels of a big trie).
+constexpr uint32_t FULL_BRANCH_LEN = 3u + 16u * 33u + 1u;  // 532
+constexpr bool full_is_child(int q) { return q >= 3 && q < 531 && (q - 3) % 33 != 0; }
+constexpr int full_const(int q) { return q == 0 ? 0xf9 : q == 1 ? 0x02 : q == 2 ? 0x11 : q == 531 ? 0x80 : 0xa0; }
+constexpr int full_src_byte(int q) { return ((q - 3) / 33) * 32 + ((q - 3) % 33 - 1); }  // byte of the 512-byte slot row
+// first / one-past-last 16-byte piece of the slot row that rate block K needs
+constexpr int full_u4_lo(int k) { return k == 0 ? 0 : full_src_byte(136 * k + (full_is_child(136 * k) ? 0 : 1)) / 16; }
+constexpr int full_u4_hi(int k) { return full_src_byte(k == 3 ? 530 : (full_is_child(136 * k + 135) ? 136 * k + 135 : 136 * k + 134)) / 16 + 1; }
+template <int I>
+PHANT_DEV uint32_t u4_dword(const uint4* q) {
+    if constexpr (I % 4 == 0) return q[I / 4].x;
+    else if constexpr (I % 4 == 1) return q[I / 4].y;
+    else if constexpr (I % 4 == 2) return q[I / 4].z;
+    else return q[I / 4].w;
+}
+// dword J of rate block K; q[] = pieces full_u4_lo(K) .. of the node's slot row
+template <int K, int J>
+PHANT_DEV uint32_t full_dword(const uint4* q) {
+    constexpr int Q = 136 * K + 4 * J, BASE = 4 * full_u4_lo(K);
+    if constexpr (Q >= (int)FULL_BRANCH_LEN) {  // behind the message (block 3): pad10*1
+        return Q == (int)FULL_BRANCH_LEN ? 0x00000001u : (J == 33 ? 0x80000000u : 0u);
+    } else if constexpr (full_is_child(Q) && full_is_child(Q + 3) && full_src_byte(Q + 3) == full_src_byte(Q) + 3) {
+        constexpr int B = full_src_byte(Q);  // four consecutive bytes of one child
+        if constexpr (B % 4 == 0) {
+            return u4_dword<B / 4 - BASE>(q);
+        } else {
+            const uint64_t two = ((uint64_t)u4_dword<B / 4 + 1 - BASE>(q) << 32) | u4_dword<B / 4 - BASE>(q);
+            return (uint32_t)(two >> (8 * (B % 4)));
+        }
+    } else {
+        uint32_t v = 0;
+#define PHANT_FULL_BYTE(b)                                                                                         \
+    if constexpr (Q + b < (int)FULL_BRANCH_LEN) {                                                                  \
+        if constexpr (full_is_child(Q + b)) {                                                                      \
+            constexpr int B = full_src_byte(Q + b);                                                                \
+            v |= ((u4_dword<B / 4 - BASE>(q) >> (8 * (B % 4))) & 0xffu) << (8 * b);                                \
+        } else {                                                                                                   \
+            v |= (uint32_t)full_const(Q + b) << (8 * b);                                                           \
+        }                                                                                                          \
+    } else if constexpr (Q + b == (int)FULL_BRANCH_LEN) {                                                          \
+        v |= 0x01u << (8 * b);                                                                                     \
+    }
+        PHANT_FULL_BYTE(0)
+        PHANT_FULL_BYTE(1)
+        PHANT_FULL_BYTE(2)
+        PHANT_FULL_BYTE(3)
+#undef PHANT_FULL_BYTE
+        return v;
+    }
+}
+template <int K, int... J>
+PHANT_DEV void full_absorb_block(Sponge& s, const uint4* __restrict__ row, std::integer_sequence<int, J...>) {
+    constexpr int LO = full_u4_lo(K), N = full_u4_hi(K) - LO;
+    uint4 q[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) q[u] = row[LO + u];
+    const uint32_t d[RATE_DWORDS] = {full_dword<K, J>(q)...};
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        s.lo[i] ^= d[2 * i];
+        s.hi[i] ^= d[2 * i + 1];
+    }
+}
+// Keccak-256 of the full branch over the 16 x 32 bytes at `row` (16-byte aligned)
+PHANT_DEV void keccak256_full_branch(Sponge& s, const uint4* __restrict__ row) {
+    using Seq = std::make_integer_sequence<int, (int)RATE_DWORDS>;
+    sponge_zero(s);
+    full_absorb_block<0>(s, row, Seq{});
+    keccak_f1600(s);
+    full_absorb_block<1>(s, row, Seq{});
+    keccak_f1600(s);
+    full_absorb_block<2>(s, row, Seq{});
+    keccak_f1600(s);
+    full_absorb_block<3>(s, row, Seq{});
+    keccak_f1600(s);
+}
+
 // A depth bin, in one of three slot classes.  A lane's node is staged in LDS whole, and what a workgroup may hold of LDS decides
 // how many waves share a SIMD: four-block slots (any node up to a full branch with an extension) = ONE; but the crowded bins of a
 // big trie are the sparse ones below its last full level (a million random keys: 250 000 nodes of two or three children on one
@@ -906,6 +994,18 @@ __global__ void __launch_bounds__(256 / BLOCKS) branch_kernel(TrieDev t, const u
             }
             __syncthreads();
             continue;
+        }
+        {  // every node of the wave a full branch without an extension (and nobody wants the root's bytes): from registers
+            const uint32_t parent = p.live ? t.nd_parent[p.i] : NONE;
+            const bool fast = p.live && p.full && p.ext_len == 0u && !(parent == NONE && t.root_enc);
+            if (__ballot(p.live && !fast) == 0ull) {
+                if (fast) {
+                    Sponge s;
+                    keccak256_full_branch(s, reinterpret_cast<const uint4*>(t.slot_bytes + (uint64_t)p.dn * 16u * 32u));
+                    deliver(t, parent, parent == NONE ? 0u : nib_at(t, p.l, (uint32_t)p.pd), p.l, nullptr, FULL_BRANCH_LEN, s, true);
+                }
+                continue;
+            }
         }
         // room in the scratch blob for the nodes that do not fit even four blocks: one reservation per workgroup (= wave)
         uint32_t incl = p.need;
