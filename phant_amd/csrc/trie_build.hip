@@ -126,6 +126,17 @@ PHANT_DEV void lcp_element(const TrieDev& t, const uint32_t i) {
         const uint8_t* b = t.keys + t.key_off[i];
         const uint32_t m = la < lb ? la : lb;
         uint32_t k = 0;
+        // eight bytes per load while both keys have them (a byte per load and round trip was most of lcp_kernel: a million random
+        // keys agree in their first two or three bytes); the first byte that differs is the lowest set byte of the difference
+        struct __attribute__((packed, aligned(1))) U64 { unsigned long long v; };
+        while (k + 8u <= m) {
+            const unsigned long long x = reinterpret_cast<const U64*>(a + k)->v ^ reinterpret_cast<const U64*>(b + k)->v;
+            if (x) {
+                k += (uint32_t)__builtin_ctzll(x) >> 3;
+                break;
+            }
+            k += 8u;
+        }
         while (k < m && a[k] == b[k]) ++k;
         bool ok;
         if (k == m) {
