@@ -78,6 +78,16 @@ struct Workspaces {
     hipError_t ensure_mailbox() {
         return mailbox ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&mailbox), MAILBOX_WORDS * 4, hipHostMallocDefault);
     }
+    // a helper stream + events for the trie builder's deepest bins, which run next to the bulk of the leaves
+    hipStream_t side = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
+    hipError_t ensure_side() {
+        if (side) return hipSuccess;
+        hipError_t e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&side_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&side_join, hipEventDisableTiming);
+        return e;
+    }
     // the pinned twin of a device address inside `io`
     template <class T>
     T* staged(T* d) const {
@@ -91,6 +101,11 @@ struct Workspaces {
         stage = nullptr;
         if (mailbox) (void)hipHostFree(mailbox);
         mailbox = nullptr;
+        if (side_fork) (void)hipEventDestroy(side_fork);
+        if (side_join) (void)hipEventDestroy(side_join);
+        if (side) (void)hipStreamDestroy(side);
+        side = nullptr;
+        side_fork = side_join = nullptr;
     }
 };
 

@@ -78,6 +78,11 @@ struct TrieDev {
     uint32_t* order;      // rep boundaries grouped by depth
     uint32_t* order2;     // per depth bin, from its start: the nodes that did not fit the slot class the bin was run in
     uint32_t* misfit;     // 512: how many of those
+    // the keys whose leaves hang under a node of depth >= deep_from (and how many): hashed FIRST, so that the few nodes of the deepest
+    // bins can be hashed next to the bulk of the leaves (forest_device); deep_from < 0: no such split
+    uint32_t* deep_leaves;
+    uint32_t* deep_count;
+    int32_t deep_from;
     uint32_t* depth_cursor;  // 512
     uint8_t* roots;       // n_tries x 32
     uint8_t* root_enc;    // optional: n_tries x root_enc_cap, the RLP of every trie's root node
@@ -237,7 +242,10 @@ __global__ void __launch_bounds__(256) head_kernel(TrieDev t) {
         t.depth_cursor[i] = 0u;
         t.misfit[i] = 0u;
     }
-    if (i == 0) *t.cursor = 0ull;
+    if (i == 0) {
+        *t.cursor = 0ull;
+        *t.deep_count = 0u;
+    }
 }
 
 // which of a group's sixteen values are below thr, as a bit mask
@@ -427,6 +435,30 @@ __global__ void __launch_bounds__(COUNT_BLOCK) order_kernel(TrieDev t) {
         if (s_cnt[b]) s_base[b] = atomicAdd(&t.depth_cursor[b], s_cnt[b]);
     __syncthreads();
     if (live) t.order[(d ? s_begin[cur][d - 1u] : 0u) + s_base[d] + local] = i;
+    // the keys under the deepest nodes, as a list (one reservation per workgroup)
+    if (t.deep_from >= 0) {
+        __shared__ uint32_t s_deep[COUNT_BLOCK / 64u + 1u];
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        bool deep = false;
+        if (i < t.n) {
+            const uint32_t ps = t.leaf_ps[i];
+            deep = ps != BRANCH_VALUE && t.leaf_parent[i] != NONE && (int32_t)ps - 1 >= t.deep_from;
+        }
+        const unsigned long long m = __ballot(deep);
+        if (lane == 0) s_deep[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+            for (uint32_t w = 0; w < COUNT_BLOCK / 64u; ++w) tot += s_deep[w];
+            s_deep[COUNT_BLOCK / 64u] = tot ? atomicAdd(t.deep_count, tot) : 0u;
+        }
+        __syncthreads();
+        if (deep) {
+            uint32_t base = s_deep[COUNT_BLOCK / 64u];
+            for (uint32_t w = 0; w < wave; ++w) base += s_deep[w];
+            t.deep_leaves[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+        }
+    }
 }
 
 // ---- RLP helpers (row a10: canonical subset used at mpt.zig:127,198,236,268) ----
@@ -685,15 +717,23 @@ PHANT_DEV void leaf_emit_scratch(const TrieDev& t, const uint32_t i, const LeafP
 // (a transaction, a receipt: leaf_big_kernel, 64 lanes per workgroup with the branch kernel's 137-dword slots), the rest
 // through the scratch blob (byte stores to global memory: slow, rare).
 constexpr uint32_t LEAF_BIG_MAX = BRANCH_STAGE_BYTES_;  // 4 x 136: the padding needs a byte
-__global__ void __launch_bounds__(256) leaf_kernel(TrieDev t) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const LeafPlan p = leaf_plan(t, i);
+// `list` (with its count on the device: a grid that strides) = the keys under the deepest nodes, which go first when the deepest
+// bins are hashed next to the other leaves; that pass (no list) then skips them (t.deep_from).
+__global__ void __launch_bounds__(256) leaf_kernel(TrieDev t, const uint32_t* list, const uint32_t* dev_count) {
     __shared__ uint32_t s_stage[256 * LEAF_STAGE_DW];
-    const bool staged = p.live && p.total < RATE;
-    const bool scratch = p.live && p.total >= LEAF_BIG_MAX;
-    const unsigned long long at = wave_alloc(t.cursor, scratch ? ((p.total + 3u) & ~3u) : 0u);
-    if (staged) leaf_emit_staged<LEAF_STAGE_DW>(t, i, p, s_stage + threadIdx.x * LEAF_STAGE_DW);
-    else if (scratch) leaf_emit_scratch(t, i, p, at);
+    const uint32_t count = list ? *dev_count : t.n;
+    for (uint32_t first = blockIdx.x * 256u; first < count; first += gridDim.x * 256u) {
+        const uint32_t q = first + threadIdx.x;
+        const uint32_t i = list ? (q < count ? list[q] : t.n) : q;
+        LeafPlan p = leaf_plan(t, i);
+        if (!list && t.deep_from >= 0 && p.live && (int32_t)p.ps - 1 >= t.deep_from && t.leaf_parent[i] != NONE) p.live = false;
+        const bool staged = p.live && p.total < RATE;
+        const bool scratch = p.live && p.total >= LEAF_BIG_MAX;
+        const unsigned long long at = wave_alloc(t.cursor, scratch ? ((p.total + 3u) & ~3u) : 0u);
+        if (staged) leaf_emit_staged<LEAF_STAGE_DW>(t, i, p, s_stage + threadIdx.x * LEAF_STAGE_DW);
+        else if (scratch) leaf_emit_scratch(t, i, p, at);
+        __syncthreads();
+    }
 }
 
 // BranchNode (mpt.zig:216-231) at nibble depth d, plus the ExtensionNode above
@@ -1179,6 +1219,10 @@ inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
 
 }  // namespace
 
+constexpr uint32_t SIDE_MIN_KEYS = 400000;    // below it the leaves are too few to hide the deepest bins behind (200 000 keys: 0.497 vs 0.491 ms without)
+constexpr uint32_t SIDE_MAX_NODES = 65536;    // nodes in the bins that run beside the leaves (one generation of four-block workgroups)
+constexpr uint32_t SIDE_LEAF_LDS = 20480;     // bytes of unused dynamic LDS per leaf workgroup meanwhile: TWO of them per CU instead of four (with three,
+                                              // 5 or 6 KB, the bins beside them still starved: 146-162 us for a bin of 116 nodes)
 constexpr uint32_t FALLBACK_GRID = 1024;           // workgroups of a bin's fallback pass (its count is on the device)
 constexpr uint32_t CROWDED_BIN = 4u * 256u * 64u;  // nodes: above it a bin in four-block slots (one wave per SIMD) no longer fits the chip at once
 
@@ -1229,7 +1273,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     {
         const size_t n1 = (size_t)n + 1;
         const size_t total = DevArena::round(n1) + DevArena::round(n1 * 4 + 64) * 7 + DevArena::round(tree_ints * 4 + 64) +
-                             DevArena::round((size_t)n * 4) * 4 + DevArena::round(N_COUNTERS * 4) +
+                             DevArena::round((size_t)n * 4) * 5 + DevArena::round(N_COUNTERS * 4) + 256 +
                              DevArena::round(MAX_DEPTH_BINS * 4) * 3 + 256 + 4096;
         TB_TRY(ws.t1.reset(total));
         t.first_flag = ws.t1.take<uint8_t>(n1);
@@ -1246,6 +1290,9 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         t.order = ws.t1.take<uint32_t>(n);
         t.order2 = ws.t1.take<uint32_t>(n);
         t.misfit = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
+        t.deep_leaves = ws.t1.take<uint32_t>(n);
+        t.deep_count = ws.t1.take<uint32_t>(1);
+        t.deep_from = -1;
         t.counters = ws.t1.take<uint32_t>(N_COUNTERS);
         t.depth_cursor = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
         t.cursor = ws.t1.take<unsigned long long>(1);
@@ -1332,38 +1379,74 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     t.scratch = ws.t2.take<uint8_t>(cap);
     t.scratch_cap = cap;
     // (order_kernel also clears the slot lengths and forms the bins' starts from the histogram it finds in t.counters)
-    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
-    hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t);
-    // (leaves of 136 .. 543 bytes: identify_kernel said whether there can be any -- a grid of lanes that only find out that
-    // their leaf is small was 24 us per million keys)
-    if (cnt[3])
-        hipLaunchKernelGGL(leaf_big_kernel, dim3((n + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t);
     // A bin's slot class (branch_kernel): four blocks unless the bin is crowded (more workgroups than the chip holds at once) and
     // its mean fan-out says that most of its nodes fit less; what does not fit is run through the four-block class behind it.
     static const uint32_t fallback_grid = std::getenv("PHANT_TRIE_FALLBACK_GRID") ? (uint32_t)std::max(1, std::atoi(std::getenv("PHANT_TRIE_FALLBACK_GRID"))) : FALLBACK_GRID;  // (test knob)
     static const int force_blocks = std::getenv("PHANT_TRIE_SLOT_BLOCKS") ? std::atoi(std::getenv("PHANT_TRIE_SLOT_BLOCKS")) : 0;  // (A/B)
-    for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
+    auto launch_bin = [&](int d, hipStream_t on) {
         const uint32_t c = cnt[8 + d];
-        if (!c) continue;
+        if (!c) return;
         const uint64_t children = cnt[8 + MAX_DEPTH_BINS + d];
         uint32_t blocks = BRANCH_STAGE_BLOCKS;
         if (c >= CROWDED_BIN) {
-            static const bool no_one = std::getenv("PHANT_TRIE_NO_ONE_BLOCK") != nullptr;  // (A/B)
-            if (children <= 3ull * c && !no_one) blocks = 1;        // (<= 3 children of 33 bytes: one rate block)
-            else if (children <= 6ull * c) blocks = 2;   // (<= 7: two)
+            if (children <= 3ull * c) blocks = 1;       // (<= 3 children of 33 bytes: one rate block)
+            else if (children <= 6ull * c) blocks = 2;  // (<= 7: two)
         }
         if (force_blocks == 1 || force_blocks == 2 || force_blocks == 4) blocks = (uint32_t)force_blocks;
         uint32_t* const mis = t.misfit + d;
         if (blocks == 1)
-            hipLaunchKernelGGL(branch_kernel<1>, dim3((c + 255u) / 256u), dim3(256), 0, st, t, t.order, depth_begin[d], c, nullptr, mis);
+            hipLaunchKernelGGL(branch_kernel<1>, dim3((c + 255u) / 256u), dim3(256), 0, on, t, t.order, depth_begin[d], c, nullptr, mis);
         else if (blocks == 2)
-            hipLaunchKernelGGL(branch_kernel<2>, dim3((c + 127u) / 128u), dim3(128), 0, st, t, t.order, depth_begin[d], c, nullptr, mis);
+            hipLaunchKernelGGL(branch_kernel<2>, dim3((c + 127u) / 128u), dim3(128), 0, on, t, t.order, depth_begin[d], c, nullptr, mis);
         if (blocks != BRANCH_STAGE_BLOCKS)
             hipLaunchKernelGGL(branch_kernel<BRANCH_STAGE_BLOCKS>, dim3(std::min((c + BRANCH_LANES - 1u) / BRANCH_LANES, fallback_grid)), dim3(BRANCH_LANES), 0,
-                               st, t, t.order2, depth_begin[d], 0u, mis, nullptr);
+                               on, t, t.order2, depth_begin[d], 0u, mis, nullptr);
         else
-            hipLaunchKernelGGL(branch_kernel<BRANCH_STAGE_BLOCKS>, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t, t.order,
+            hipLaunchKernelGGL(branch_kernel<BRANCH_STAGE_BLOCKS>, dim3((c + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, on, t, t.order,
                                depth_begin[d], c, nullptr, nullptr);
+    };
+    // The deepest bins of a big trie hold a handful of nodes each and cost a node's latency apiece (~30 us: launch, nine dependent
+    // round trips, the Keccak-f) -- time in which the chip does nothing else.  They only need the leaves that hang under THEM: so
+    // those leaves go first (order_kernel lists them), and then the deepest bins run on a stream of their own NEXT TO the bulk of
+    // the leaves, which keeps a workgroup's worth of LDS per CU free for them.
+    int deep_from = -1;
+    {
+        static const bool no_side = std::getenv("PHANT_TRIE_NO_SIDE") != nullptr;  // (A/B)
+        static const uint32_t side_min = std::getenv("PHANT_TRIE_SIDE_MIN_KEYS") ? (uint32_t)std::atoi(std::getenv("PHANT_TRIE_SIDE_MIN_KEYS")) : SIDE_MIN_KEYS;  // (test knob)
+        if (!no_side && !cnt[3] && n >= side_min) {
+            uint64_t nodes = 0;
+            int bins = 0, from = -1;
+            for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
+                const uint32_t c = cnt[8 + d];
+                if (!c) continue;
+                if (c >= CROWDED_BIN || nodes + c > SIDE_MAX_NODES) break;
+                nodes += c;
+                ++bins;
+                from = d;
+            }
+            if (bins >= 2 && from > 0) deep_from = from;
+        }
+    }
+    t.deep_from = deep_from;
+    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
+    if (deep_from >= 0) {
+        TB_TRY(ws.ensure_side());
+        static const uint32_t side_lds = std::getenv("PHANT_TRIE_SIDE_LDS") ? (uint32_t)std::atoi(std::getenv("PHANT_TRIE_SIDE_LDS")) : SIDE_LEAF_LDS;
+        hipLaunchKernelGGL(leaf_kernel, dim3(std::min(blocks(n), 256u)), dim3(256), 0, st, t, t.deep_leaves, t.deep_count);
+        TB_TRY(hipEventRecord(ws.side_fork, st));
+        TB_TRY(hipStreamWaitEvent(ws.side, ws.side_fork, 0));
+        for (int d = MAX_DEPTH_BINS - 1; d >= deep_from; --d) launch_bin(d, ws.side);
+        TB_TRY(hipEventRecord(ws.side_join, ws.side));
+        hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), side_lds, st, t, nullptr, nullptr);
+        TB_TRY(hipStreamWaitEvent(st, ws.side_join, 0));
+        for (int d = deep_from - 1; d >= 0; --d) launch_bin(d, st);
+    } else {
+        hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t, nullptr, nullptr);
+        // (leaves of 136 .. 543 bytes: identify_kernel said whether there can be any -- a grid of lanes that only find out that
+        // their leaf is small was 24 us per million keys)
+        if (cnt[3])
+            hipLaunchKernelGGL(leaf_big_kernel, dim3((n + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t);
+        for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) launch_bin(d, st);
     }
     TB_TRY(hipGetLastError());
     TB_TRY(hipMemcpyAsync(ws.mailbox, t.counters, 3 * 4, hipMemcpyDeviceToHost, st));

@@ -57,7 +57,7 @@ BARGS="--streams 4" prof streams4 X=1
 BARGS="--streams 1 --workload config4" prof config4 X=1
 ( cd /tmp && rm -rf /tmp/prof_t && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o p -- python $R/bench.py --workload mptize --no-cpu-baseline --steps 10 > "$OUT/prof_mptize.log" 2>&1 )
 f=$(find /tmp/prof_t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && (head -1 "$f"; grep "phant" "$f") > "$OUT/mptize_kernel_stats.csv"
-python tools/probe_walk_report.py /tmp/prof_t trie_init_kernel | tail -1 | tr ' ' '\n' | grep -v '^$' > "$OUT/mptize_timeline.txt"
+python tools/probe_walk_report.py /tmp/prof_t head_kernel | tail -1 | tr ' ' '\n' | grep -v '^$' > "$OUT/mptize_timeline.txt"
 bash tools/gpu_prof.sh "${1:-evidence}/state_root_prof" state_offsets_check_kernel python $R/tools/bench_state.py --accounts 200000 --slots 5 > /dev/null 2>&1
 [ -x tools/ubench/overlap ] && timeout 60 tools/ubench/overlap > "$OUT/overlap_ubench.txt" 2>&1; grep -c overlap "$OUT/overlap_ubench.txt"
 timeout 200 python tools/probe_power.py --seconds 2 --out "$OUT/power_and_clock_per_phase.jsonl" > "$OUT/probe_power.log" 2>&1

@@ -13,4 +13,4 @@ PY
 f=$(find /tmp/prof_t -name '*kernel_stats.csv' | head -1); (head -1 "$f"; grep "phant" "$f") > "$OUT/mptize_kernel_stats.csv"
 cut -d, -f1-4 "$OUT/mptize_kernel_stats.csv" | cut -c1-120
 # one call kernel by kernel (the last of the run)
-python tools/probe_walk_report.py /tmp/prof_t trie_init_kernel | tail -1 | tr ' ' '\n' | grep -v '^$' > "$OUT/mptize_timeline.txt"; tr '\n' ' ' < "$OUT/mptize_timeline.txt" | cut -c1-1500; echo
+python tools/probe_walk_report.py /tmp/prof_t head_kernel | tail -1 | tr ' ' '\n' | grep -v '^$' > "$OUT/mptize_timeline.txt"; tr '\n' ' ' < "$OUT/mptize_timeline.txt" | cut -c1-1500; echo
