@@ -1073,7 +1073,7 @@ def main():
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
                                 "node-set pipeline = classify_kernel (class lists) + hash_set_kernel + "
                                 "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
-                                "trie hasher = lcp_kernel + tree_level_kernel x log n + identify_kernel + order_kernel + "
+                                "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + branch_kernel<1|2|4> per depth (first start to last end; one counter read-back in between, one at the end)"
                                 "leaf_kernel + branch_kernel per depth (first start to last end, two counter read-backs "
                                 "in between)" if args.workload == "mptize" else
                                 "mpt_verify_fused_kernel" if args.verify_mode == "fused" else pipeline),
