@@ -87,6 +87,33 @@ def test_mptize_device_form_matches_host_form_and_oracle(P, oracle):
     assert dev_root([b"\x01", b"\x02"], [b"a", b"b"]) == oracle.mptize([b"\x01", b"\x02"], [b"a", b"b"])  # (the ctx is fine)
 
 
+@pytest.mark.parametrize("n", [1_000_000, 3_000_000])
+def test_mptize_big_tries_vs_oracle(P, oracle, n):
+    """What only a big trie reaches in trie_build.hip: a crowded sparse depth bin in the one-block slot class with its fallback
+    list (a million random keys: 250 000 nodes of two or three children on depth 5, 7 % of them bigger), in the two-block class
+    (three million: mean fan-out 3.5), the deepest bins on the helper stream beside the leaves -- the root against oracle/mpt.c,
+    host form (which packs and copies) and device-resident form."""
+    import torch
+    rng = np.random.default_rng(n)
+    raw = rng.integers(0, 1 << 63, (n + n // 64, 4), dtype=np.int64).astype(">u8")  # big-endian words: byte order = key order
+    order = np.lexsort((raw[:, 3], raw[:, 2], raw[:, 1], raw[:, 0]))
+    raw = raw[order]
+    keep = np.ones(len(raw), bool)
+    keep[1:] = (raw[1:] != raw[:-1]).any(axis=1)
+    keys = np.ascontiguousarray(raw[keep][:n]).view(np.uint8).reshape(-1)
+    assert keys.size == 32 * n
+    vlen = rng.integers(1, 90, n)  # (below the 95 bytes from which a leaf could reach a rate block: that disables the helper stream)
+    val_off = np.concatenate([[0], np.cumsum(vlen)]).astype(np.uint64)
+    vals = rng.integers(0, 256, int(val_off[-1]), dtype=np.uint8)
+    key_off = (np.arange(n + 1, dtype=np.uint64) * 32).astype(np.uint32)
+    want = oracle.mptize_packed(keys, key_off, vals, val_off)
+    assert P.mpt.mptize_packed(keys, key_off, vals, val_off) == want
+    dev = lambda a, dt: torch.from_numpy(a.astype(dt)).cuda()
+    out = P.mpt.mptize_dev(dev(keys, np.uint8), dev(key_off, np.int32), dev(vals, np.uint8), dev(val_off, np.int64))
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == want
+
+
 def test_mptize_variable_length_keys_and_branch_values(P, oracle):
     rng = np.random.default_rng(77)
     keys = set()
