@@ -438,6 +438,10 @@ static __forceinline__ T __shfl(T v, int src, int width = 64) {
     std::memcpy(&r, &raw, sizeof(T));
     return r;
 }
+// ds_bpermute: the lane reads `v` of lane addr / 4
+static __forceinline__ int __builtin_amdgcn_ds_bpermute(int addr, int v) {
+    return (int)(uint32_t)hipemu::wave_op(hipemu::OP_SHFL, (uint32_t)v, (uint32_t)addr / 4u);
+}
 template <class T>
 static __forceinline__ T __shfl_up(T v, unsigned delta, int width = 64) {
     static_assert(sizeof(T) <= 8, "shuffle of at most 8 bytes");
