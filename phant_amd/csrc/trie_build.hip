@@ -1078,10 +1078,10 @@ __global__ void __launch_bounds__(256 / BLOCKS) branch_kernel(TrieDev t, const u
 // idle the chip is (one wave cannot issue faster), a full branch needs four in a row.  Here 32 lanes share a node: sixteen copy a
 // child each into the node's LDS buffer (their offsets a prefix sum over the sixteen lengths), and 25 hold one 64-bit word of the
 // sponge each (lane = x + 5 y; theta, pi and chi fetch their neighbours with ds_bpermute: tools/ubench/coop_sponge.hip, 5.8 us per
-// permutation).  A twentieth of the states per second of the lane-per-node kernels -- for bins of at most COOP_MAX_NODES nodes:
-// the three or four levels at the top of every trie, the sparse ones at its bottom.  A node with a value, under an extension, or
+// permutation).  A twentieth of the states per second of the lane-per-node kernels -- for bins of at most COOP_MAX_NODES nodes
+// (two waves per SIMD): the three or four levels at the top of every trie, the sparse ones at its bottom.  A node with a value, under an extension, or
 // whose bytes the caller wants (a sharded trie's root) takes the general way, on the half wave's first lane.
-constexpr uint32_t COOP_MAX_NODES = 512;
+constexpr uint32_t COOP_MAX_NODES = 4096;  // (512 / 2 048 / 4 096 / 8 192 measured: 10 000 keys 0.288 / 0.267 / 0.247 / 0.250 ms, a million 0.669 / 0.663 / 0.651 / 0.654)
 PHANT_DEV uint32_t coop_fetch(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src_lane), (int)v); }
 constexpr int COOP_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5 y]
 
@@ -1549,7 +1549,8 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         const uint32_t c = cnt[8 + d];
         if (!c) return;
         static const bool no_coop = std::getenv("PHANT_TRIE_NO_COOP") != nullptr;  // (A/B)
-        if (c <= COOP_MAX_NODES && !no_coop && !force_blocks) {
+        static const uint32_t coop_max = std::getenv("PHANT_TRIE_COOP_MAX") ? (uint32_t)std::atoi(std::getenv("PHANT_TRIE_COOP_MAX")) : COOP_MAX_NODES;  // (A/B)
+        if (c <= coop_max && !no_coop && !force_blocks) {
             hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 7u) / 8u), dim3(256), 0, on, t, depth_begin[d], c);
             return;
         }
