@@ -12,11 +12,11 @@
 //      O(log n) per element, with no recursion (mpt.zig:62-116 scans groups;
 //      mpt.zig:83-99 is the longest-common-prefix scan => the extension).
 //   3. Leaves (one lane per key), then branch nodes level by level from the
-//      deepest nibble depth up: each lane RLP-encodes its node into a scratch
-//      blob (wave prefix-sum + one atomic bump per wave to place the
-//      variable-length encodings), hashes it with its sponge in registers and
-//      drops the <= 32-byte reference into its parent's slot table
-//      (embed-if-shorter-than-32 rule mpt.zig:104,112; root always hashed :42).
+//      deepest nibble depth up: a lane RLP-encodes its node in an LDS slot,
+//      hashes it from there with its sponge in registers and drops the
+//      <= 32-byte reference into its parent's slot table (embed-if-shorter-
+//      than-32 rule mpt.zig:104,112; root always hashed :42).  A level with few
+//      nodes gives 32 lanes to a node instead (branch_coop_kernel).
 //
 // A forest of tries (one per account's storage) goes through the same passes
 // at once: trie starts are just lcp = -1 boundaries.
@@ -89,7 +89,6 @@ struct TrieDev {
     uint32_t* root_enc_len;  // optional: its length (may exceed root_enc_cap: then only the length is valid)
     uint32_t root_enc_cap;
     unsigned long long scratch_cap;
-    uint32_t* flags_host;  // small_forest_kernel: where counters[0..2] go when the kernel ends (pinned host memory), or null
 };
 
 enum : uint32_t { ERR_UNSORTED = 1u, ERR_KEY_RANGE = 2u };
@@ -225,7 +224,7 @@ __global__ void __launch_bounds__(256) tree_levels_kernel(TrieDev t, uint32_t ba
     }
 }
 
-// The head of every large call, one launch: every root = empty_mpt_root (mpt.zig:10; a trie with keys overwrites its own), the
+// The head of every call, one launch: every root = empty_mpt_root (mpt.zig:10; a trie with keys overwrites its own), the
 // counters of the passes below cleared (lcp_kernel already reports into counters[1]), and -- for a forest -- the start flags
 // cleared for first_flag_kernel.
 PHANT_DEV void store_empty_root(uint8_t* out) {
@@ -1248,125 +1247,6 @@ __global__ void __launch_bounds__(256) fill_empty_roots_kernel(uint8_t* roots, u
     if (i < n_tries) store_empty_root(roots + 32ull * i);
 }
 
-// ---- small forests: everything in ONE launch ----
-// The passes above are ~30 dependent launches and two counter read-backs: for the tries of an ordinary block (<= a few
-// hundred keys: blockchain.zig:198-204) that overhead is most of the call (0.40 ms for 400 keys, of which the sponges' own
-// latency chain is ~0.12).  Up to SMALL_MAX_KEYS keys the whole construction runs in one workgroup of 256 lanes: the same
-// element functions, the passes separated by workgroup barriers instead of kernel boundaries, the per-depth counters and the
-// dense ids kept in LDS, the branch levels as a loop inside the kernel -- one launch, and one read-back (the error flags)
-// at the end.  LDS: the branch stage of four waves (140 KB; the leaves use its first 35 KB) + 6 KB of counters.
-constexpr uint32_t SMALL_BLOCK = 256;
-constexpr uint32_t SMALL_MAX_KEYS = 256;  // one pass of the workgroup's lanes over the keys: beyond that its passes queue up behind each other
-
-__global__ void __launch_bounds__(SMALL_BLOCK) small_forest_kernel(TrieDev t) {
-    __shared__ uint32_t s_stage[SMALL_BLOCK * BRANCH_STAGE_DW];
-    __shared__ uint32_t s_hist[MAX_DEPTH_BINS], s_begin[MAX_DEPTH_BINS], s_cur[MAX_DEPTH_BINS];
-    __shared__ uint32_t s_wave[SMALL_BLOCK / 64];
-    __shared__ uint32_t s_nrep, s_err;
-    constexpr uint32_t B = SMALL_BLOCK;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n = t.n;
-    // ---- what the launcher's memsets and fill_empty_roots_kernel do for the large form ----
-    for (uint32_t i = tid; i <= n; i += B) {
-        t.first_flag[i] = 0;
-        t.value_key[i] = NONE;
-        t.dense[i] = NONE;
-    }
-    for (uint32_t i = tid; i < N_COUNTERS; i += B) t.counters[i] = 0u;
-    for (uint32_t b = tid; b < (uint32_t)MAX_DEPTH_BINS; b += B) {
-        s_hist[b] = 0u;
-        s_cur[b] = 0u;
-    }
-    for (uint32_t i = tid; i < n * 4u; i += B) reinterpret_cast<uint32_t*>(t.slot_len)[i] = 0u;  // n x 16 bytes
-    for (uint32_t i = tid; i < t.n_tries; i += B) {  // mpt.zig:10 empty_mpt_root = keccak256(0x80)
-        store_empty_root(t.roots + 32ull * i);
-        if (t.root_enc_len) t.root_enc_len[i] = 0u;
-    }
-    if (tid == 0) {
-        *t.cursor = 0ull;
-        s_nrep = 0u;
-    }
-    __syncthreads();
-    for (uint32_t sg = tid; sg < t.n_tries; sg += B) {
-        const uint32_t f = t.seg_first[sg];
-        if (f <= n) t.first_flag[f] = 1;
-    }
-    __syncthreads();
-    // ---- lcp, min-tree ----
-    for (uint32_t i = tid; i <= n; i += B) lcp_element(t, i);
-    for (uint32_t i = n + 1u + tid; i < t.lvl_size[0]; i += B) t.lcp[i] = INF_LCP;
-    __syncthreads();
-    for (uint32_t k = 1; k < t.n_lvl; ++k) {
-        for (uint32_t g = tid; g < t.lvl_size[k]; g += B)
-            t.tree[t.lvl_off[k] + g] = g * FAN < t.lvl_size[k - 1u] ? group_min(lvl(t, k - 1u) + g * FAN) : INF_LCP;
-        __syncthreads();
-    }
-    // ---- leaves' parents, branch nodes, their dense ids and the per-depth counts ----
-    for (uint32_t c0 = 0; c0 < n; c0 += B) {
-        const uint32_t i = c0 + tid;
-        int32_t d = -1, leaf_under, node_under;
-        const bool is_rep = i < n && identify_element(t, i, d, leaf_under, node_under);
-        const unsigned long long reps = __ballot(is_rep);
-        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(reps);
-        if (is_rep) atomicAdd(&s_hist[d], 1u);
-        __syncthreads();
-        if (is_rep) {
-            uint32_t base = s_nrep;
-            for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
-            t.dense[i] = base + (uint32_t)__popcll(reps & ((1ull << lane) - 1ull));
-        }
-        __syncthreads();
-        if (tid == 0) s_nrep += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        s_err = t.counters[1];
-        t.counters[0] = s_nrep;
-        uint32_t acc = 0;
-        for (int b = 0; b < MAX_DEPTH_BINS; ++b) {
-            s_begin[b] = acc;
-            acc += s_hist[b];
-        }
-    }
-    __syncthreads();
-    if (s_err) {  // (unsorted keys, a key too long: the launcher reads the flags)
-        if (tid < 3u && t.flags_host) t.flags_host[tid] = tid == 0u ? s_nrep : tid == 1u ? s_err : 0u;
-        return;
-    }
-    // ---- the branch nodes grouped by depth ----
-    for (uint32_t c0 = 0; c0 < n; c0 += B) {
-        const uint32_t i = c0 + tid;
-        if (i < n && i != 0u && t.dense[i] != NONE) {
-            const int32_t d = t.lcp[i];
-            resolve_parent(t, i);
-            t.order[s_begin[d] + atomicAdd(&s_cur[d], 1u)] = i;
-        }
-    }
-    __syncthreads();
-    // ---- leaves ----
-    for (uint32_t c0 = 0; c0 < n; c0 += B) {
-        const uint32_t i = c0 + tid;
-        const LeafPlan p = leaf_plan(t, i);
-        if (!p.live) continue;
-        if (p.total < LEAF_BIG_MAX) leaf_emit_staged<BRANCH_STAGE_DW>(t, i, p, s_stage + tid * BRANCH_STAGE_DW);
-        else leaf_emit_scratch(t, i, p, atomicAdd(t.cursor, (unsigned long long)((p.total + 3u) & ~3u)));
-    }
-    __syncthreads();
-    // ---- branch nodes, level by level from the deepest nibble depth up ----
-    for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
-        const uint32_t c = s_hist[d];
-        if (!c) continue;
-        for (uint32_t q0 = 0; q0 < c; q0 += B) {
-            const uint32_t q = q0 + tid;
-            const BranchPlan p = branch_plan(t, t.order, s_begin[d] + q, q < c);
-            if (p.live) branch_emit<BRANCH_STAGE_DW>(t, p, s_stage + tid * BRANCH_STAGE_DW, p.need ? atomicAdd(t.cursor, (unsigned long long)p.need) : 0ull);
-        }
-        __syncthreads();  // the level's references sit in their parents' slot tables
-    }
-    // what the launcher wants to know, straight into its pinned mailbox (no copy command, one synchronisation)
-    if (tid < 3u && t.flags_host) t.flags_host[tid] = atomicOr(&t.counters[tid], 0u);
-}
-
 // ---- host driver ----
 #define TB_TRY(call)                                    \
     do {                                                \
@@ -1458,35 +1338,6 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         t.counters = ws.t1.take<uint32_t>(N_COUNTERS);
         t.depth_cursor = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
         t.cursor = ws.t1.take<unsigned long long>(1);
-    }
-
-    static const uint32_t small_max = std::getenv("PHANT_TRIE_SMALL_MAX") ? (uint32_t)std::strtoul(std::getenv("PHANT_TRIE_SMALL_MAX"), nullptr, 10) : SMALL_MAX_KEYS;
-    if (n <= (small_max < SMALL_MAX_KEYS ? small_max : SMALL_MAX_KEYS)) {
-        // one launch, one read-back (see small_forest_kernel); tables sized for the most branch nodes n keys can have
-        const uint64_t cap = total_val_bytes + total_key_bytes + (uint64_t)n * 32 + (uint64_t)n * (3 + 16 * 33 + 16 + 48 + 255 / 2 + 16) + 4096;
-        TB_TRY(ws.t2.reset(DevArena::round((size_t)n * 16 * 32) + DevArena::round((size_t)n * 16) + DevArena::round(cap) + 1024));
-        t.slot_bytes = ws.t2.take<uint8_t>((size_t)n * 16 * 32);
-        t.slot_len = ws.t2.take<uint8_t>((size_t)n * 16);
-        t.scratch = ws.t2.take<uint8_t>(cap);
-        t.scratch_cap = cap;
-        t.flags_host = ws.mailbox;
-        hipLaunchKernelGGL(small_forest_kernel, dim3(1), dim3(SMALL_BLOCK), 0, st, t);
-        TB_TRY(hipGetLastError());
-        TB_TRY(hipStreamSynchronize(st));
-        const uint32_t flags[3] = {ws.mailbox[0], ws.mailbox[1], ws.mailbox[2]};
-        if (flags[1] & ERR_KEY_RANGE) {
-            err = "key longer than 255 bytes, or key offsets not monotone";
-            return PHANT_E_INVALID_ARG;
-        }
-        if (flags[1] & ERR_UNSORTED) {
-            err = "keys are not strictly increasing (mpt.zig:39)";
-            return PHANT_E_UNSORTED;
-        }
-        if (flags[2]) {
-            err = "trie scratch overflow (internal bound too small)";
-            return PHANT_E_DEVICE;
-        }
-        return PHANT_OK;
     }
 
     // head (roots, counters, a forest's start flags) -> [first_flag] -> lcp (+ markers, + the min-tree's padding): three or two
