@@ -59,6 +59,7 @@
 
 #include "launch.h"
 #include "mpt_verify_one.hip.h"
+#include "coop_sponge.hip.h"
 
 namespace phant {
 namespace v3 {
@@ -804,6 +805,110 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     deep_role<SOLO>(a, w, threadIdx.x & 63u, waves_per_level, levels, s_ref);
 }
+// ---- the S = 0 form of a SMALL batch: a node per HALF WAVE ----
+// The witness of an ordinary block is a few hundred proofs: far fewer nodes than the chip has lanes, and the launch is as long as
+// ONE lane's four sequential permutations over a 532-byte node (~9 us each: a wave cannot issue faster, however idle the chip).
+// Here 32 lanes share a node: lane l < 17 fetches word l of every rate block (eight bytes of the node; padding and the
+// canonical-branch markers checked on exactly those bytes), 25 lanes hold a word of the sponge each (coop_sponge.hip.h: ~6 us
+// per permutation).  Same node states, digests and statistics as deep_role<true>; up to COOP_MAX_NODES nodes per batch.
+constexpr uint32_t COOP_MAX_NODES = 2048;  // (one wave per SIMD: beyond it the shared sponge is no faster than a lane's)
+__global__ void __launch_bounds__(256) hash_coop_kernel(const Args a, const uint32_t levels) {
+    // (The two halves of a wave walk their loops TOGETHER -- as many trips and rate blocks as the longer one needs, the other half's
+    // surplus predicated off: every cross-lane operation runs with the whole wave, and a wave is as long as its longer half anyway.)
+    const uint32_t tid = threadIdx.x, l = tid & 31u, base = tid & 32u;
+    const uint32_t h = blockIdx.x * 8u + (tid >> 5);
+    const uint32_t p = h / levels, level = h % levels;
+    uint32_t first = 0, count = 0, root = 0;
+    if (p < a.v.n) {
+        first = a.v.proof_first_node[p];
+        const uint32_t last = a.v.proof_first_node[p + 1];
+        if (last >= first && last <= a.total_nodes) count = last - first;
+        if (last < first && l == 0) a.hdr[HDR_PFN_BROKEN] = 1u;  // (no elect_kernel in this form: see deep_role<true>)
+        if (a.v.root_idx) root = a.v.root_idx[p];
+    }
+    const uint32_t nn = 2u * a.v.key_len;
+    const uint32_t stat_buf = a.hdr[HDR_PARITY] & 1u;
+    const CoopLane c = coop_lane(l, base);
+    struct __attribute__((packed, aligned(1))) U64 { unsigned long long v; };
+    for (uint32_t d = level;; d += levels) {
+        if (__ballot(d < count) == 0ull) break;
+        const uint32_t j = first + d;
+        bool active = false;
+        uint32_t len = 0;
+        uint64_t b = 0;
+        if (d < count) {
+            const uint64_t e = a.v.node_off[j + 1];
+            b = a.v.node_off[j];
+            active = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull;
+            len = active ? (uint32_t)(e - b) : 0u;
+            if (!active && l == 0) a.nstat[j] = 0u;
+        }
+        const uint8_t* const ptr = a.v.nodes + (active ? b : 0ull);
+        const uint8_t* refp = nullptr;
+        if (active) {
+            const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * p;
+            refp = ref_location(a, j, d, root, (d >= 1u && d - 1u < nn) ? key_nibble(key, d - 1u) : 16u, b);
+        }
+        const uint32_t nb = active ? len / RATE + 1u : 0u;
+        const uint32_t nb_other = __shfl(nb, (int)(base ^ 32u), 64);
+        const uint32_t nb_max = nb > nb_other ? nb : nb_other;
+        const bool branch = active && len == BRANCH_LEN;
+        uint32_t lo = 0, hi = 0, dlo = 0, dhi = 0, bad = 0;
+        for (uint32_t k = 0; k < nb_max; ++k) {
+            if (k < nb && l < 17u) {
+                const uint32_t off = k * RATE + 8u * l;
+                unsigned long long w = 0;
+                if (off + 8u <= len) {
+                    w = reinterpret_cast<const U64*>(ptr + off)->v;
+                } else {
+#pragma unroll
+                    for (uint32_t t = 0; t < 8u; ++t) {
+                        const uint32_t q = off + t;
+                        if (q < len) w |= (unsigned long long)ptr[q] << (8u * t);
+                        else if (q == len) w |= 0x01ull << (8u * t);  // Keccak-256's domain byte
+                    }
+                }
+                if (k + 1u == nb && l == 16u) w |= 0x80ull << 56;  // the end of pad10*1: the rate's last byte
+                if (branch) {  // f9 02 11 | 16 x (a0 | 32 bytes) | 80: the markers among this lane's bytes
+#pragma unroll
+                    for (uint32_t t = 0; t < 8u; ++t) {
+                        const uint32_t q = off + t;
+                        const uint32_t byte = (uint32_t)(w >> (8u * t)) & 0xffu;
+                        const int want = q == 0u ? 0xf9 : q == 1u ? 0x02 : q == 2u ? 0x11 : q == BRANCH_LEN - 1u ? 0x80 : (q < BRANCH_LEN && (q - 3u) % 33u == 0u) ? 0xa0 : -1;
+                        if (want >= 0 && byte != (uint32_t)want) bad = 1u;
+                    }
+                }
+                lo ^= (uint32_t)w;
+                hi ^= (uint32_t)(w >> 32);
+            }
+            coop_permute(c, lo, hi);
+            if (k + 1u == nb) {  // this half's digest (the other half may need more blocks)
+                dlo = lo;
+                dhi = hi;
+            }
+        }
+        bool ne = false;
+        if (refp && l < 4u) {
+            const unsigned long long r = reinterpret_cast<const U64*>(refp + 8u * l)->v;
+            ne = (uint32_t)r != dlo || (uint32_t)(r >> 32) != dhi;
+        }
+        const uint32_t any_bad = (uint32_t)(__ballot(bad != 0u) >> base), any_ne = (uint32_t)(__ballot(ne) >> base);
+        if (active) {
+            uint32_t ns = NS_HASHED | ((branch && any_bad == 0u) ? NS_CANON : 0u);
+            if (refp) ns |= NS_LINK_CHECKED | (any_ne == 0u ? NS_LINK_OK : 0u);
+            if (l < 4u) {
+                a.digest[8ull * j + 2u * l] = dlo;
+                a.digest[8ull * j + 2u * l + 1u] = dhi;
+            }
+            if (l == 0) {
+                a.nstat[j] = (uint8_t)ns;
+                const uint32_t cls = len / RATE < N_CLASS ? len / RATE : N_CLASS - 1u;  // (reporting only, as deep_role)
+                atomicAdd(&a.hdr[HDR_STAT + HDR_STAT_WORDS * stat_buf + N_CLASS * (h % HDR_STAT_STRIPES) + cls], 1u);
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
     // On the critical path (propose -> dedup -> this -> walk) with fewer waves than the chip has SIMDs, four permutations in
     // a row each, while the deep tier's waves, which are many and in nobody's way, compete for the same issue slots: go first.
@@ -1470,7 +1575,12 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         const size_t zero_n16 = l.dtab / 16;  // header + node states
         hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)((zero_n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(ws),
                            zero_n16, v.fail_count, v.n_roots);
-        if (total_nodes) hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, wpl, deep_levels);
+        static const bool no_coop = std::getenv("PHANT_VERIFY_NO_COOP") != nullptr;  // (A/B)
+        static const uint32_t coop_max = std::getenv("PHANT_VERIFY_COOP_MAX") ? (uint32_t)std::atoi(std::getenv("PHANT_VERIFY_COOP_MAX")) : COOP_MAX_NODES;  // (A/B)
+        if (total_nodes && total_nodes <= coop_max && !no_coop)
+            hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)(((uint64_t)v.n * deep_levels + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);
+        else if (total_nodes)
+            hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, wpl, deep_levels);
         hipLaunchKernelGGL(walk_kernel<true>, dim3(pg), dim3(256), 0, st, a);
         return hipGetLastError();
     }

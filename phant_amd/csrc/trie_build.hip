@@ -31,6 +31,7 @@
 
 #include "../../include/phant_gpu.h"
 #include "absorb.hip.h"
+#include "coop_sponge.hip.h"
 #include "launch.h"
 
 namespace phant {
@@ -1076,82 +1077,57 @@ __global__ void __launch_bounds__(256 / BLOCKS) branch_kernel(TrieDev t, const u
 // A bin of a handful of nodes costs its node's latency, and most of that is the sponge: a lane runs one Keccak-f in ~9 us however
 // idle the chip is (one wave cannot issue faster), a full branch needs four in a row.  Here 32 lanes share a node: sixteen copy a
 // child each into the node's LDS buffer (their offsets a prefix sum over the sixteen lengths), and 25 hold one 64-bit word of the
-// sponge each (lane = x + 5 y; theta, pi and chi fetch their neighbours with ds_bpermute: tools/ubench/coop_sponge.hip, 5.8 us per
-// permutation).  A twentieth of the states per second of the lane-per-node kernels -- for bins of at most COOP_MAX_NODES nodes
+// sponge each (coop_sponge.hip.h: 5.8 us per permutation).  A twentieth of the states per second of the lane-per-node kernels -- for bins of at most COOP_MAX_NODES nodes
 // (two waves per SIMD): the three or four levels at the top of every trie, the sparse ones at its bottom.  A node with a value, under an extension, or
 // whose bytes the caller wants (a sharded trie's root) takes the general way, on the half wave's first lane.
 constexpr uint32_t COOP_MAX_NODES = 4096;  // (512 / 2 048 / 4 096 / 8 192 measured: 10 000 keys 0.288 / 0.267 / 0.247 / 0.250 ms, a million 0.669 / 0.663 / 0.651 / 0.654)
-PHANT_DEV uint32_t coop_fetch(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * src_lane), (int)v); }
-constexpr int COOP_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5 y]
-
-// the lanes' constants of the shared sponge, and Keccak-256 over the `nb` padded rate blocks at `buf` (digest: lanes 0 .. 3 of the half)
-struct CoopLane {
-    uint32_t l, ll, up5, up10, up20, xm1, xp1, xp2, pis, sh;
-    bool swap, norot;
-};
-PHANT_DEV CoopLane coop_lane(uint32_t l, uint32_t base) {
-    CoopLane c;
-    c.l = l;
-    c.ll = l < 25u ? l : 0u;
-    const uint32_t x = c.ll % 5u, y = c.ll / 5u;
-    c.up5 = base + (c.ll + 5u) % 25u;
-    c.up10 = base + (c.ll + 10u) % 25u;
-    c.up20 = base + (c.ll + 20u) % 25u;
-    c.xm1 = base + (x + 4u) % 5u + 5u * y;
-    c.xp1 = base + (x + 1u) % 5u + 5u * y;
-    c.xp2 = base + (x + 2u) % 5u + 5u * y;
-    c.pis = base + (x + 3u * y) % 5u + 5u * x;  // pi: the lane (x', y') takes from ((x' + 3 y') mod 5, x')
-    uint32_t rho = 0;
-#pragma unroll
-    for (int i = 0; i < 25; ++i) rho = c.ll == (uint32_t)i ? (uint32_t)COOP_RHO[i] : rho;
-    c.swap = rho >= 32u;
-    c.norot = (rho & 31u) == 0u;
-    c.sh = 32u - (rho & 31u);
-    return c;
-}
-PHANT_DEV void coop_keccak256(const CoopLane& c, const uint32_t* buf, uint32_t nb, uint32_t& lo, uint32_t& hi) {
-    lo = hi = 0;
-    for (uint32_t k = 0; k < nb; ++k) {
-        if (c.l < 17u) {
+// Keccak-256 over the `nb` padded rate blocks at `buf` (digest: the words of lanes 0 .. 3 of the half).  The two halves of a wave
+// go through the loop together, `nb_max` trips (the longer one's): the shorter half keeps its digest from its own last block.
+PHANT_DEV void coop_keccak256(const CoopLane& c, const uint32_t* buf, uint32_t nb, uint32_t nb_max, uint32_t& dlo, uint32_t& dhi) {
+    uint32_t lo = 0, hi = 0;
+    for (uint32_t k = 0; k < nb_max; ++k) {
+        if (k < nb && c.l < 17u) {
             lo ^= buf[k * RATE_DWORDS + 2u * c.l];
             hi ^= buf[k * RATE_DWORDS + 2u * c.l + 1u];
         }
-        for (int r = 0; r < 24; ++r) {
-            const uint32_t tl = lo ^ coop_fetch(lo, c.up5), th = hi ^ coop_fetch(hi, c.up5);  // theta
-            const uint32_t fl = coop_fetch(lo, c.up20), fh = coop_fetch(hi, c.up20);
-            const uint32_t cl = xor3(tl, coop_fetch(tl, c.up10), fl), ch = xor3(th, coop_fetch(th, c.up10), fh);
-            const uint32_t ml = coop_fetch(cl, c.xm1), mh = coop_fetch(ch, c.xm1), pl = coop_fetch(cl, c.xp1), ph = coop_fetch(ch, c.xp1);
-            lo = xor3(lo, ml, alignbit(pl, ph, 31));
-            hi = xor3(hi, mh, alignbit(ph, pl, 31));
-            const uint32_t s0 = c.swap ? hi : lo, s1 = c.swap ? lo : hi;  // rho: rotl64 by the lane's amount
-            const uint32_t rl = c.norot ? s0 : alignbit(s0, s1, c.sh), rh = c.norot ? s1 : alignbit(s1, s0, c.sh);
-            const uint32_t bl = coop_fetch(rl, c.pis), bh = coop_fetch(rh, c.pis);  // pi
-            lo = chi(bl, coop_fetch(bl, c.xp1), coop_fetch(bl, c.xp2));             // chi
-            hi = chi(bh, coop_fetch(bh, c.xp1), coop_fetch(bh, c.xp2));
-            if (c.ll == 0u) {  // iota
-                lo ^= KECCAK_RC[r][0];
-                hi ^= KECCAK_RC[r][1];
-            }
+        coop_permute(c, lo, hi);
+        if (k + 1u == nb) {
+            dlo = lo;
+            dhi = hi;
         }
     }
 }
+PHANT_DEV uint32_t coop_wave_max(uint32_t v, uint32_t base) {
+    const uint32_t other = __shfl(v, (int)(base ^ 32u), 64);
+    return v > other ? v : other;
+}
 
 __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t begin, uint32_t count) {
+    // (Every cross-lane operation below runs with the whole wave: the halves take the same branches and loop trips -- the longer
+    // half's -- with the other half's surplus predicated off.  A wave is as long as its longer half anyway.)
     __shared__ uint32_t s_node[8][BRANCH_STAGE_DW];
     const uint32_t tid = threadIdx.x, hw = tid >> 5, l = tid & 31u, base = tid & 32u;  // (base: the half's first lane in its wave)
     const uint32_t q = blockIdx.x * 8u + hw;
-    if (q >= count) return;
-    const uint32_t node = t.order[begin + q];
-    const uint32_t dn = t.dense[node], parent = t.nd_parent[node], lkey = t.nd_l[node];
-    const int32_t d = t.lcp[node], pd = t.nd_pd[node];
-    const uint32_t ext_len = (uint32_t)(d - (pd + 1));
+    const bool live = q < count;
+    const uint32_t node = live ? t.order[begin + q] : 0u;
+    uint32_t dn = 0, parent = NONE, lkey = 0, ext_len = 0, vk = NONE;
+    int32_t d = 0, pd = -1;
+    if (live) {
+        dn = t.dense[node];
+        parent = t.nd_parent[node];
+        lkey = t.nd_l[node];
+        d = t.lcp[node];
+        pd = t.nd_pd[node];
+        ext_len = (uint32_t)(d - (pd + 1));
+        vk = t.value_key[node];
+    }
     const bool is_root = parent == NONE;
     uint32_t* const buf = s_node[hw];
     uint8_t* const b = reinterpret_cast<uint8_t*>(buf);
     // ---- the 17-item list (mpt.zig:216-231), sixteen lanes a child each ----
     for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 32u) buf[k] = 0u;  // (in front of the shuffles below: they order it before the lanes' bytes)
-    const uint32_t sl = l < 16u ? t.slot_len[(uint64_t)dn * 16u + l] : 0u;
-    const uint32_t mine = l < 16u ? (sl == 0u ? 1u : (sl == 32u ? 33u : sl)) : 0u;
+    const uint32_t sl = (live && l < 16u) ? t.slot_len[(uint64_t)dn * 16u + l] : 0u;
+    const uint32_t mine = (live && l < 16u) ? (sl == 0u ? 1u : (sl == 32u ? 33u : sl)) : 0u;
     uint32_t incl = mine;
 #pragma unroll
     for (uint32_t o = 1; o < 16u; o <<= 1) {
@@ -1164,19 +1140,19 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
     // A value in the branch, a root whose bytes the caller wants, an extension over a branch too short to be hashed, an extension
     // longer than the buffer: the general way, on the half wave's first lane -- for BOTH halves of the wave (a wave that takes both
     // ways takes them one after the other).
-    const bool plain = t.value_key[node] == NONE && !(is_root && t.root_enc) && (ext_len == 0u || (total >= 32u && 44u + ext_len / 2u < BRANCH_STAGE_BYTES));
+    const bool plain = !live || (vk == NONE && !(is_root && t.root_enc) && (ext_len == 0u || (total >= 32u && 44u + ext_len / 2u < BRANCH_STAGE_BYTES)));
     if (__ballot(!plain) != 0ull) {
-        if (l == 0) {
+        if (live && l == 0) {
             const BranchPlan p = branch_plan(t, t.order, begin + q, true);
             branch_emit<BRANCH_STAGE_DW>(t, p, buf, p.need ? atomicAdd(t.cursor, (unsigned long long)p.need) : 0ull);
         }
         return;
     }
-    if (l == 16u) {
+    if (live && l == 16u) {
         (void)put_hdr(b, payload, 0xc0u, 0xf7u);
         b[hdr + children] = 0x80;
     }
-    if (l < 16u) {
+    if (live && l < 16u) {
         uint8_t* w = b + hdr + (incl - mine);
         if (sl == 0u) {
             w[0] = 0x80;
@@ -1190,24 +1166,25 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
                 if ((uint32_t)k < sl) w[k] = (uint8_t)(qq[k >> 2] >> (8 * (k & 3)));
         }
     }
-    uint32_t nb = __shfl(blocks_of(total), (int)base, 64);  // (also: every lane's bytes are in the buffer)
-    if (l == 0) {
+    const bool embedded = live && total < 32u && !is_root;  // (mpt.zig:104,:112; no extension above it: see `plain`)
+    const bool hashed = live && !embedded;
+    uint32_t nb = coop_wave_max(0u, base);  // (a shuffle: every lane's bytes are in the buffer)
+    nb = hashed ? blocks_of(total) : 0u;
+    if (hashed && l == 0) {
         b[total] = 0x01;  // Keccak-256's domain byte and the end of pad10*1
         b[nb * RATE - 1u] |= 0x80;
     }
-    const uint64_t slot = is_root ? 0ull : (uint64_t)t.dense[parent] * 16u + nib_at(t, lkey, (uint32_t)pd);
-    if (total < 32u && !is_root) {  // embedded in its parent (mpt.zig:104,:112; no extension: see `plain`)
-        if (l == 0) {
-            for (uint32_t k = 0; k < total; ++k) t.slot_bytes[slot * 32u + k] = b[k];
-            t.slot_len[slot] = (uint8_t)total;
-        }
-        return;
+    const uint64_t slot = (live && !is_root) ? (uint64_t)t.dense[parent] * 16u + nib_at(t, lkey, (uint32_t)pd) : 0ull;
+    if (embedded && l == 0) {
+        for (uint32_t k = 0; k < total; ++k) t.slot_bytes[slot * 32u + k] = b[k];
+        t.slot_len[slot] = (uint8_t)total;
     }
     const CoopLane c = coop_lane(l, base);
-    uint32_t lo, hi;
-    nb = __shfl(nb, (int)base, 64);  // (lane 0's padding bytes are in the buffer)
-    coop_keccak256(c, buf, nb, lo, hi);
-    if (ext_len) {  // ---- the ExtensionNode above it (mpt.zig:187-193): [HP(path), digest], built by the first lane, hashed by all ----
+    uint32_t lo = 0, hi = 0;
+    coop_keccak256(c, buf, nb, coop_wave_max(nb, base), lo, hi);  // (the shuffle inside: lane 0's padding bytes are in the buffer)
+    // ---- the ExtensionNode above it (mpt.zig:187-193): [HP(path), digest], built by the first lane, hashed by all ----
+    const bool ext = hashed && ext_len != 0u;
+    if (__ballot(ext) != 0ull) {
         Sponge s;
         sponge_zero(s);
 #pragma unroll
@@ -1215,23 +1192,30 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
             s.lo[k] = __shfl(lo, (int)(base + (uint32_t)k), 64);
             s.hi[k] = __shfl(hi, (int)(base + (uint32_t)k), 64);
         }
-        for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 32u) buf[k] = 0u;
-        uint32_t out_len = __shfl(0u, (int)base, 64);  // (the buffer is clear)
-        if (l == 0) {
+        if (ext)
+            for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 32u) buf[k] = 0u;
+        uint32_t out_len = coop_wave_max(0u, base);  // (a shuffle: the buffer is clear)
+        if (ext && l == 0) {
             out_len = put_extension(b, t, lkey, (uint32_t)(pd + 1), (uint32_t)d, true, s, nullptr, 0u);
             b[out_len] = 0x01;
             b[blocks_of(out_len) * RATE - 1u] |= 0x80;
         }
-        nb = __shfl(blocks_of(out_len), (int)base, 64);
-        coop_keccak256(c, buf, nb, lo, hi);
+        out_len = __shfl(out_len, (int)base, 64);
+        const uint32_t nbx = ext ? blocks_of(out_len) : 0u;
+        uint32_t xlo = 0, xhi = 0;
+        coop_keccak256(c, buf, nbx, coop_wave_max(nbx, base), xlo, xhi);
+        if (ext) {
+            lo = xlo;
+            hi = xhi;
+        }
     }
     // ---- the digest: words 0 .. 3 ----
-    if (l < 4u) {
+    if (hashed && l < 4u) {
         uint32_t* const dst = reinterpret_cast<uint32_t*>(is_root ? t.roots + 32ull * trie_of(t, lkey) : t.slot_bytes + slot * 32u);
         dst[2u * l] = lo;
         dst[2u * l + 1u] = hi;
     }
-    if (l == 0 && !is_root) t.slot_len[slot] = 32;
+    if (hashed && l == 0 && !is_root) t.slot_len[slot] = 32;
 }
 
 static_assert(BRANCH_STAGE_BYTES_ == BRANCH_STAGE_BYTES && BRANCH_STAGE_DW_ == BRANCH_STAGE_DW, "one slot size for big leaves and branches");
