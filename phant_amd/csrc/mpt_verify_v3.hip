@@ -1575,7 +1575,8 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         const size_t zero_n16 = l.dtab / 16;  // header + node states
         hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)((zero_n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(ws),
                            zero_n16, v.fail_count, v.n_roots);
-        static const bool no_coop = std::getenv("PHANT_VERIFY_NO_COOP") != nullptr;  // (A/B)
+        const bool no_coop = std::getenv("PHANT_VERIFY_NO_COOP") != nullptr;  // (A/B; read per launch: the dry runs of bench.py in the CPU
+                                                                              // suite switch it off -- 32 emulated lanes per node are slow there)
         static const uint32_t coop_max = std::getenv("PHANT_VERIFY_COOP_MAX") ? (uint32_t)std::atoi(std::getenv("PHANT_VERIFY_COOP_MAX")) : COOP_MAX_NODES;  // (A/B)
         if (total_nodes && total_nodes <= coop_max && !no_coop)
             hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)(((uint64_t)v.n * deep_levels + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);

@@ -17,7 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module", autouse=True)
 def _emulated_backend():
-    yield from emu.emulated_backend()
+    # (these runs are about bench.py's plumbing: the node-per-half-wave hash kernel that small batches take -- 32 emulated lanes
+    # and ~400 cross-lane operations per permutation -- makes them four times as long; tests/test_emu_verify.py is where it is tested)
+    os.environ["PHANT_VERIFY_NO_COOP"] = "1"
+    try:
+        yield from emu.emulated_backend()
+    finally:
+        os.environ.pop("PHANT_VERIFY_NO_COOP", None)
 
 
 @contextlib.contextmanager
