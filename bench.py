@@ -121,7 +121,7 @@ def parse():
                     help="config3: independent batches in flight, each on its own ctx + HIP stream (a validator "
                          "verifying consecutive witnesses); 1 = strictly one launch sequence after the other")
     ap.add_argument("--allreduce-every", type=int, default=1,
-                    help="N > 1: a slot's per-root verdicts are exchanged once per this many passes, as one all-reduce of a "
+                    help="N > 1 (>= 1): a slot's per-root verdicts are exchanged once per this many passes, as one all-reduce of a "
                          "(passes x roots) block on a stream of its own (default 1: a verdict per witness, what a validator needs; "
                          "rounds 1-3 of this repository batched --inner = 30 passes per exchange: their N > 1 figures are not "
                          "comparable)")
@@ -132,12 +132,19 @@ def parse():
     ap.add_argument("--comm-devices", type=int, default=0, help="--comm: devices to use (default 0 = all visible)")
     ap.add_argument("--messages", type=int, default=1 << 20, help="config2: 136-byte messages per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="config3 at N = 1: skip the short extra legs (config 2, mptize, config 5 at 8 blocks) that the default run "
+                         "appends to the line as `extra` so that the driver's record carries them")
+    ap.add_argument("--extra-seconds", type=int, default=420, help="wall-clock budget of all extra legs together")
     ap.add_argument("--max-seconds", type=int, default=1500,
                     help="wall-clock guard: past this the process prints a JSON line with \"error\" (rank 0) and exits with rc 4 "
                          "instead of hanging (a rendezvous or RCCL initialisation that never completes)")
     ap.add_argument("--rendezvous-seconds", type=int, default=180, help="N > 1: timeout of the process-group rendezvous and of every collective")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.allreduce_every < 1:
+        ap.error("--allreduce-every must be >= 1 (1 = a verdict per pass; --inner = one exchange per timed step)")
+    return args
 
 
 def cpu_baseline_config3(w, target_seconds, gpu_status=None):
@@ -474,33 +481,44 @@ def run_comm_bench(args):
     comm.close()
 
 
-def per_kernel_roofline(kernel_ms, tiers, n, w, valu_peak):
-    """roofline.kernels: every kernel of the two-tier pipeline ALONE on the chip (tiers serialised) against the roofline that
-    bounds it -- the hash kernels against the Keccak-f rate measured in this run, the memory-bound ones against HBM's 8 TB/s
-    with their algorithmic bytes (config 3: every shallow node is 532 bytes)."""
+def per_kernel_roofline(kernel_ms, tiers, n, w, valu_peak, form):
+    """roofline.kernels: every stage of the verify launch against ITS roofline, from the serialised launch's events."""
     S = tiers["dedup_levels"]
-    shallow = n * S
+    shallow = n * min(S, w.nodes_per_proof)  # nodes of the shallow tier
     copies = shallow - tiers["list_nodes"]
     node_b, key_b = 532, 32
-    out = {"note": "tiers serialised (PHANT_VERIFY_SERIAL=1): HIP events around each kernel, alone on the chip; one launch "
-                   "overlaps hash_deep with propose + dedup + hash_list", "dedup_levels": S}
+    out = {"note": "tiers serialised (PHANT_VERIFY_SERIAL=1): HIP events around each stage, alone on the chip; in one launch the deep "
+                   "tier, the hashing of the group heads and the comparison run next to each other", "dedup_levels": S, "form": form}
 
     def hbm(ms, nbytes, what):
-        g = nbytes / (ms * 1e-3) / 1e9
+        g = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"ms": ms, "bound": "hbm", "algorithmic_bytes": int(nbytes), "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": g / HBM_PEAK_GBS, "bytes": what}
 
     def valu(ms, perms):
-        g = perms / (ms * 1e-3) / 1e9
+        g = perms / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"ms": ms, "bound": "valu", "keccak_f": int(perms), "achieved": g, "peak": valu_peak, "unit": "G Keccak-f/s",
                 "frac": g / valu_peak}
 
     out["hash_deep_kernel"] = valu(kernel_ms["hash_deep"], tiers["deep_keccak_f"])
-    out["hash_list_kernel"] = valu(kernel_ms["hash_list"], tiers["list_keccak_f"])
-    out["dedup_kernel"] = hbm(kernel_ms["dedup"], copies * node_b + shallow * 16 + n * (key_b + 8),
-                              "the copies' own bytes once (their representatives are cache hits) + offsets + keys")
-    out["propose_kernel"] = hbm(kernel_ms["propose"], shallow * 16 + n * (key_b + 8) + tiers["list_nodes"] * 4,
-                                "offsets + keys + table stores")
+    if form == "table":
+        out["hash_list_kernel"] = valu(kernel_ms["hash_late"], tiers["list_keccak_f"])
+        out["dedup_kernel"] = hbm(kernel_ms["compare"], copies * node_b + shallow * 16 + n * (key_b + 8),
+                                  "the copies' own bytes once (their representatives are cache hits) + offsets + keys")
+        out["propose_kernel"] = hbm(kernel_ms["order"], shallow * 16 + n * (key_b + 8) + tiers["list_nodes"] * 4,
+                                    "offsets + keys + table stores")
+    else:
+        # (the two hash_list launches share one statistic: the heads' share of the Keccak-f is what the late launch did not run --
+        # the late list is short, its time is latency)
+        out["hash_list_kernel<heads>"] = valu(kernel_ms["hash_heads"], tiers["list_keccak_f"])
+        out["hash_list_kernel<late>"] = {"ms": kernel_ms["hash_late"], "bound": "latency",
+                                          "note": "the copies that differ: a few chunks of four sequential Keccak-f"}
+        out["compare_kernel"] = hbm(kernel_ms["compare"], shallow * node_b + shallow * 16 + n * (key_b + 8),
+                                    "every shallow node once + offsets + keys")
+        out["heads_kernel"] = hbm(kernel_ms["heads"], shallow * 16 + n * (key_b + 8) + tiers["list_nodes"] * 8,
+                                  "offsets + keys + list entries")
+        out["order_pass"] = hbm(kernel_ms["order"], n * (2 * key_b + 12) + 3 * 4 * 65536,
+                                "keys twice + counters + the order (order_hist + order_scan + order_scatter, or clear_kernel)")
     out["walk_kernel"] = hbm(kernel_ms["walk"], n * (112 + key_b + 8 + 9) + w.nodes_per_proof * n * (1 + 4 * S // 8),
                              "the leaf, the key, node states and representatives, one status byte")
     return out
@@ -699,6 +717,7 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
                         for name, ms in cs.verify_kernel_ms().items():
                             acc[name] = acc.get(name, 0.0) + ms / reps
             kernels = acc
+            kernels["form"] = cs.verify_form()
             cs.close()
     passes = steps * inner
     out = {"wits": wits, "status0": timed_status0, "kernels": kernels, "tiers": tiers, "n_units": n_units, "elapsed": elapsed, "passes": passes, "ms_per_pass": elapsed / passes * 1e3,
@@ -710,6 +729,50 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
     for k, (st_, c_, _, _, _) in enumerate(slots):
         if c_ is not ctx:
             c_.close()
+    return out
+
+
+def relaunch_under_torchrun(args):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.environ.get("PHANT_BENCH_ENTRY", os.path.abspath(__file__)), *sys.argv[1:]]
+    # (PHANT_BENCH_ENTRY: the CPU test suite's entry script -- this file's main() with torch.cuda stubbed out and gloo for RCCL)
+    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: re-executing as `%s`\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    try:
+        rc = subprocess.run(cmd, timeout=(args.max_seconds + 120) if args.max_seconds > 0 else None).returncode
+    except subprocess.TimeoutExpired:
+        print(json.dumps({"metric": "mpt_proofs_verified_per_sec_depth%d" % args.depth, "value": None, "unit": "proofs/s",
+                          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "error": "the torch.distributed.run launch did not finish in time"}), flush=True)
+        rc = 4
+    sys.exit(rc)
+
+
+def extra_legs(args):
+    """The default run's short extra legs, each a bench.py process of its own (own ctx, own JSON line with its own `roofline`
+    and oracle check), so that the driver's record of the default command carries more than config 3."""
+    import subprocess
+    legs = [("config2", ["--workload", "config2", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
+            ("mptize_1M_keys", ["--workload", "mptize", "--keys", "1000000", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
+            ("config5_8_blocks", ["--workload", "config5", "--steps", "2", "--warmup", "1", "--cpu-seconds", "3"])]
+    out, t_end = {}, time.time() + args.extra_seconds
+    for name, argv in legs:
+        left = t_end - time.time()
+        if left < 30:
+            out[name] = {"error": "skipped: the extra legs' wall-clock budget is spent"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extra", "--max-seconds", str(int(left)), *argv]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=left + 30)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[name] = json.loads(lines[-1]) if lines else {"error": f"no JSON line (rc {r.returncode})", "stderr_tail": r.stderr[-400:]}
+        except Exception as e:  # a leg must never cost the headline its line
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -738,8 +801,10 @@ def main():
         guard = threading.Timer(args.max_seconds, lambda: give_up(f"wall-clock guard: not finished after {args.max_seconds} s", 4))
         guard.daemon = True
         guard.start()
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.comm:
+        # started the way the N = 1 run is (`python bench.py --gpus N`): become the launcher -- one rank per GPU under
+        # torch.distributed.run, same arguments; its rank 0 prints the line, this process hands on the exit code
+        return relaunch_under_torchrun(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
@@ -837,7 +902,7 @@ def main():
                               "peak_at_6_waves_per_simd": peak6, "peak_at_4_waves_per_simd": peak4, "peak_round1_ubench": 10.3,
                               "note": "permutations actually run / whole-pipeline time of one launch"}}
             if args.workload == "config3" and args.verify_mode == "flat" and r.get("kernels"):
-                extra["kernels"] = per_kernel_roofline(r["kernels"], r["tiers"], n_units, w, vpeak)
+                extra["kernels"] = per_kernel_roofline(r["kernels"], r["tiers"], n_units, w, vpeak, r["kernels"].get("form"))
         if args.workload == "config3" and not args.no_strong and args.verify_mode != "fused":
             # BASELINE config 4 next to it: ONE block witness split over the same N GPUs (strong scaling): accounts by
             # top key nibble, contracts dealt out whole, one all-reduce of the per-root verdicts per pass
@@ -1042,10 +1107,11 @@ def main():
                                       "device time of one call (first kernel start to last kernel end)"}}
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
 
-    pipeline = ("two-tier verify pipeline = hash_deep_kernel (in-place hashing of the deep levels, helper stream) next to "
-                "propose_kernel + dedup_kernel + hash_list_kernel (deduplicated shallow levels), then walk_kernel "
-                "(one launch of the path, first kernel start to last kernel end; the hash kernels are "
-                "integer-VALU-bound, see roofline.valu)")
+    pipeline = ("two-tier verify pipeline = hash_deep_kernel (in-place hashing of the deep levels, helper stream) next to the "
+                "shallow tier (one root: order_hist / order_scan / order_scatter kernels, then heads_kernel + hash_list_kernel<0> on "
+                "a second helper stream next to compare_kernel + hash_list_kernel<1>; several roots: propose_kernel + dedup_kernel + "
+                "hash_list_kernel), then walk_kernel (one launch of the path, first kernel start to last kernel end; the hash "
+                "kernels are integer-VALU-bound, see roofline.valu)")
     line = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_pass": ms_per_pass, "higher_is_better": True,
@@ -1073,9 +1139,8 @@ def main():
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
                                 "node-set pipeline = classify_kernel (class lists) + hash_set_kernel + "
                                 "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
-                                "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + branch_kernel<1|2|4> per depth (first start to last end; one counter read-back in between, one at the end)"
-                                "leaf_kernel + branch_kernel per depth (first start to last end, two counter read-backs "
-                                "in between)" if args.workload == "mptize" else
+                                "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + per depth bin branch_kernel<1|2|4> or, for a thin bin, branch_coop_kernel (first start to last end)"
+                                if args.workload == "mptize" else
                                 "mpt_verify_fused_kernel" if args.verify_mode == "fused" else pipeline),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
@@ -1102,6 +1167,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)
     if rccl_world is not None:
         line["rccl_world"] = rccl_world
+    if rank == 0 and world == 1 and args.workload == "config3" and not args.no_extra and args.proofs == 100_000:
+        # (only the default-sized headline run: the sweeps and A/B scripts call with other sizes or --no-extra)
+        line["extra"] = extra_legs(args)
+        line["extra_keys"] = sorted(line["extra"])
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -86,6 +86,14 @@ typedef struct phant_ctx phant_ctx;
  * batch (byte-compares copies instead of hashing them); deeper nodes are hashed in place.  Default (field 0):
  * chosen from the batch -- none for batches of less than 72 MB of nodes (the chip hashes those whole in a few rounds
  * of waves), otherwise the levels with fewer groups than proofs.  Correctness does not depend on it. */
+#define PHANT_CTX_VERIFY_KEY_ORDERED 8u /* flags: the caller's word that every batch lists its proofs in (root index, key)
+                                          order -- as a witness producer that walks the tries emits them.  The verifier then
+                                          finds byte-identical copies of the upper trie levels among NEIGHBOURS for batches
+                                          against any number of roots (for one root it orders the proofs itself and needs no
+                                          such promise).  Nothing is trusted: an unordered batch is verified just the same, with
+                                          less deduplication (more hashing).  INTEGRATION.md section 5 */
+#define PHANT_CTX_VERIFY_TABLE 16u /* flags (A/B): the two-tier pipeline finds the copies of the upper trie levels through its
+                                     group tables whatever the batch (the form every batch took before the ordered one) */
 #define PHANT_CTX_DEDUP_LEVELS_SHIFT 8
 #define PHANT_CTX_DEDUP_LEVELS_MASK 0x1f00u
 #define PHANT_CTX_DEDUP_LEVELS(n) ((((uint32_t)(n) + 1u) << PHANT_CTX_DEDUP_LEVELS_SHIFT) & PHANT_CTX_DEDUP_LEVELS_MASK)
@@ -481,9 +489,15 @@ PHANT_API int32_t phant_verify_path_stats(phant_ctx *ctx, uint32_t out[2]);
 PHANT_API int32_t phant_verify_tier_stats(phant_ctx *ctx, uint32_t out[5]);
 PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
 /* Diagnostics, for a ctx created with PHANT_VERIFY_SERIAL=1 in the environment (the pipeline's tiers then run one after the
- * other on the ctx stream): device time of each kernel of the last two-tier verify launch, alone on the chip -- ms[0..4] =
- * propose, hash_deep, dedup, hash_list, walk.  Synchronises the ctx stream. */
-PHANT_API int32_t phant_verify_kernel_ms(phant_ctx *ctx, float ms[5]);
+ * other on the ctx stream): device time of each stage of the last two-tier verify launch, alone on the chip -- ms[0..6] =
+ * the order pass (order_hist + order_scan + order_scatter kernels; table form: propose_kernel), hash_deep_kernel, heads_kernel,
+ * the hashing of the group heads (hash_list_kernel, set 0), compare_kernel (table form: dedup_kernel), the hashing of what
+ * the comparison left (hash_list_kernel, set 1; table form: of everything listed), walk_kernel.  Stages a form does not have
+ * read 0.  form (may be NULL): 1 = table form, 2 = ordered form on the library's own order, 3 = on the caller's.
+ * Synchronises the ctx stream. */
+#define PHANT_VERIFY_KERNEL_STAGES 7
+PHANT_API int32_t phant_verify_kernel_ms(phant_ctx *ctx, float ms[PHANT_VERIFY_KERNEL_STAGES]);
+PHANT_API int32_t phant_verify_form(phant_ctx *ctx, uint32_t *form);
 /* Diagnostics: the Keccak-f[1600] rate of the device when it does nothing else -- waves_per_simd (1..8) waves per SIMD,
  * every lane `perms` permutations of a register-resident state with the product's round function, timed with events on the
  * ctx stream (synchronises it).  *perms_per_s = permutations per second over the whole chip: the VALU ceiling every hash

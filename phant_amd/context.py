@@ -17,7 +17,7 @@ class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
     def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
-                 verify_nodedup: bool = False, dedup_levels: int | None = None):
+                 verify_nodedup: bool = False, dedup_levels: int | None = None, key_ordered: bool = False, verify_table: bool = False):
         """use_torch_stream: the ctx works on torch's current stream of the device (its launches are ordered with the torch
         operations around them: the default, and what every mirror function that takes or returns a tensor assumes).  False:
         a private stream -- device-form calls are then asynchronous on THAT stream and not ordered with torch's; the caller
@@ -40,6 +40,10 @@ class Context:
             flags |= 2  # PHANT_CTX_VERIFY_FUSED
         if verify_nodedup:
             flags |= 4  # PHANT_CTX_VERIFY_NODEDUP
+        if verify_table:
+            flags |= 16  # PHANT_CTX_VERIFY_TABLE (A/B: the shallow tier through its group tables whatever the batch)
+        if key_ordered:
+            flags |= 8  # PHANT_CTX_VERIFY_KEY_ORDERED: every batch lists its proofs in (root index, key) order
         if dedup_levels is not None:
             flags |= ((int(dedup_levels) + 1) << 8) & 0x1F00  # PHANT_CTX_DEDUP_LEVELS(n)
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
@@ -84,12 +88,23 @@ class Context:
         self.check(self._lib.phant_keccak_rate(self._h, waves_per_simd, perms, C.byref(out)))
         return out.value
 
+    VERIFY_STAGES = ("order", "hash_deep", "heads", "hash_heads", "compare", "hash_late", "walk")
+    VERIFY_FORMS = {0: "hash_everything", 1: "table", 2: "ordered", 3: "ordered_by_caller"}
+
     def verify_kernel_ms(self) -> dict[str, float]:
-        """Device time of each kernel of the last two-tier verify launch, tiers serialised (a ctx created while
-        PHANT_VERIFY_SERIAL=1 is in the environment): propose, hash_deep, dedup, hash_list, walk."""
-        out = (C.c_float * 5)()
+        """Device time of each stage of the last two-tier verify launch, tiers serialised (a ctx created while
+        PHANT_VERIFY_SERIAL=1 is in the environment): the order pass (table form: propose_kernel), hash_deep_kernel,
+        heads_kernel, the hashing of the group heads, compare_kernel (table form: dedup_kernel), the hashing of what the
+        comparison left (table form: of everything listed), walk_kernel."""
+        out = (C.c_float * 7)()
         self.check(self._lib.phant_verify_kernel_ms(self._h, C.byref(out)))
-        return dict(zip(("propose", "hash_deep", "dedup", "hash_list", "walk"), [float(x) for x in out]))
+        return dict(zip(self.VERIFY_STAGES, [float(x) for x in out]))
+
+    def verify_form(self) -> str:
+        """The form the last verify launch on this ctx took (diagnostics)."""
+        out = C.c_uint32(0)
+        self.check(self._lib.phant_verify_form(self._h, C.byref(out)))
+        return self.VERIFY_FORMS.get(int(out.value), "?")
 
     def verify_stats(self) -> list[int]:
         """Nodes hashed by the last node-parallel verify call, per rate-block class."""

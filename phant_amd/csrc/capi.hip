@@ -43,7 +43,8 @@ struct phant_ctx {
         bool busy = false;
     } slots[PHANT_MAX_SLOTS];
     uint32_t last_shallow = 0;  // trie levels the last two-tier launch deduplicated (diagnostics)
-    hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // PHANT_VERIFY_SERIAL: per-kernel events
+    uint32_t last_form = 0;     // the shallow tier's form in the last launch (VerifyTune::last_form)
+    hipEvent_t kev[phant::VERIFY_KERNEL_STAGES + 1] = {};  // PHANT_VERIFY_SERIAL: events around the stages of a launch
     bool kev_valid = false;
     // stream-side timing of the last device-form call
     bool timing = false;
@@ -165,6 +166,17 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         c->tune.hash_lds = (uint32_t)(kb < 0 ? 0 : kb > 47 ? 47 : kb) * 1024u;
     }
     if (const char* t = std::getenv("PHANT_VERIFY_SERIAL")) c->tune.serial = t[0] == '1';
+    // the shallow tier's form (A/B): through the group tables whatever the batch; the caller's proofs are in (root, key) order
+    c->tune.table_form = opts && (opts->flags & PHANT_CTX_VERIFY_TABLE);
+    if (const char* t = std::getenv("PHANT_VERIFY_TABLE")) c->tune.table_form = t[0] == '1';
+    c->tune.key_ordered = opts && (opts->flags & PHANT_CTX_VERIFY_KEY_ORDERED);
+    if (const char* t = std::getenv("PHANT_VERIFY_KEY_ORDERED")) c->tune.key_ordered = t[0] == '1';
+    // the S = 0 form's node-per-half-wave kernel (A/B): never / up to this many nodes
+    c->tune.no_coop = std::getenv("PHANT_VERIFY_NO_COOP") != nullptr;
+    if (const char* t = std::getenv("PHANT_VERIFY_COOP_MAX")) {
+        const long v = std::strtol(t, nullptr, 10);
+        c->tune.coop_max = (uint32_t)(v < 0 ? 0 : v > (1 << 20) ? (1 << 20) : v);
+    }
     DeviceGuard g(dev);
     if (!own) {
         c->stream = (hipStream_t)stream;  // nullptr = the default stream
@@ -180,6 +192,7 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         return PHANT_E_DEVICE;
     }
     c->tune.last_shallow = &c->last_shallow;
+    c->tune.last_form = &c->last_form;
     if (c->tune.serial) {  // diagnostics: events around every kernel of a two-tier launch (phant_verify_kernel_ms)
         for (hipEvent_t& e : c->kev)
             if (hipEventCreate(&e) != hipSuccess) {
@@ -211,9 +224,13 @@ void phant_ctx_destroy(phant_ctx* c) {
         sl.dv.release();
     }
     if (c->side.stream) (void)hipStreamSynchronize(c->side.stream);
+    if (c->side.stream2) (void)hipStreamSynchronize(c->side.stream2);
     if (c->side.fork) (void)hipEventDestroy(c->side.fork);
     if (c->side.join) (void)hipEventDestroy(c->side.join);
+    if (c->side.sorted) (void)hipEventDestroy(c->side.sorted);
+    if (c->side.join2) (void)hipEventDestroy(c->side.join2);
     if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
+    if (c->side.stream2) (void)hipStreamDestroy(c->side.stream2);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -274,6 +291,12 @@ int32_t phant_verify_tier_stats(phant_ctx* c, uint32_t out[5]) {
     return PHANT_OK;
 }
 
+int32_t phant_verify_form(phant_ctx* c, uint32_t* form) {
+    if (!c || !form) return PHANT_E_INVALID_ARG;
+    *form = c->verify_fused ? 0u : c->last_form;
+    return PHANT_OK;
+}
+
 int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
     if (!c || !out) return PHANT_E_INVALID_ARG;
     out[0] = out[1] = 0;
@@ -287,14 +310,15 @@ int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
     return PHANT_OK;
 }
 
-int32_t phant_verify_kernel_ms(phant_ctx* c, float ms[5]) {
+int32_t phant_verify_kernel_ms(phant_ctx* c, float ms[PHANT_VERIFY_KERNEL_STAGES]) {
     if (!c || !ms) return PHANT_E_INVALID_ARG;
     if (!c->tune.kernel_ev) return fail(c, PHANT_E_UNSUPPORTED, "verify_kernel_ms: the ctx was not created under PHANT_VERIFY_SERIAL=1");
     // (the events hold the LAST launch that recorded them: if the latest verify took the S = 0 form they are an earlier one's)
     if (!c->kev_valid) return fail(c, PHANT_E_INVALID_ARG, "verify_kernel_ms: the last verify launch on this ctx was not a two-tier one");
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 5; ++i) {
+    static_assert(PHANT_VERIFY_KERNEL_STAGES == phant::VERIFY_KERNEL_STAGES, "one stage list");
+    for (int i = 0; i < PHANT_VERIFY_KERNEL_STAGES; ++i) {
         ms[i] = 0.f;
         if (hipEventElapsedTime(&ms[i], c->kev[i], c->kev[i + 1]) != hipSuccess) {
             (void)hipGetLastError();
@@ -497,6 +521,10 @@ static int32_t ensure_side(phant_ctx* c) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
+    // (the ordered form: the group heads are hashed on a helper stream of their own, next to the comparison)
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream2, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->side.sorted, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->side.join2, hipEventDisableTiming));
     return PHANT_OK;
 }
 

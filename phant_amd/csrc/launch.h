@@ -55,8 +55,11 @@ hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
 // batch size, 0 = hash every shipped node (A/B).  `side` (may be null): helper stream + events owned by the ctx; with
 // it the deep tier runs NEXT TO the shallow tier (VALU-bound hashing beside a memory stream), without it in front.
 struct FlatSide {
-    hipStream_t stream;       // non-blocking helper stream owned by the ctx
+    hipStream_t stream;       // non-blocking helper stream owned by the ctx: the deep tier
     hipEvent_t fork, join;    // timing-disabled events
+    // the ordered form's second helper stream: the group heads' hashing next to the comparison (null: on the ctx stream)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t sorted = nullptr, join2 = nullptr;
 };
 size_t verify_workspace_bytes(uint32_t total_nodes);
 // The deep tier's occupancy cap and a diagnostics switch (fixed per ctx).
@@ -68,9 +71,22 @@ struct VerifyTune {
     uint32_t hash_lds = 40u * 1024u;
     bool serial = false;  // diagnostics: the tiers one after the other on the ctx stream (clean per-kernel durations in a trace)
     uint32_t* last_shallow = nullptr; // diagnostics: where the launcher notes the tier split it chose (phant_verify_tier_stats)
-    hipEvent_t* kernel_ev = nullptr;  // diagnostics, with `serial`: six events recorded around the five kernels of a two-tier
-                                      // launch (propose, hash_deep, dedup, hash_list, walk): phant_verify_kernel_ms
+    hipEvent_t* kernel_ev = nullptr;  // diagnostics, with `serial`: VERIFY_KERNEL_STAGES + 1 events recorded around the stages of a
+                                      // two-tier launch (phant_verify_kernel_ms)
+    // The shallow tier's form.  table_form: always through the group tables (A/B; PHANT_VERIFY_TABLE=1).  Otherwise the ORDERED form
+    // (key-bucketed neighbour comparison, mpt_verify_v3.hip) for a batch against one root -- the library orders the proofs
+    // itself -- and, with key_ordered (PHANT_CTX_VERIFY_KEY_ORDERED: the caller says the proofs are in (root index, key) order),
+    // for any batch, on the caller's order as it is.
+    bool table_form = false;
+    bool key_ordered = false;
+    uint32_t coop_max = 2048;      // S = 0 form: batches of up to this many nodes take the node-per-half-wave hash kernel
+    bool no_coop = false;
+    uint32_t* last_form = nullptr; // diagnostics: 0 = S = 0, 1 = table form, 2 = ordered (own order), 3 = ordered (caller's order)
 };
+// stages of a two-tier launch, in the order of phant_verify_kernel_ms: the order pass (table form: propose_kernel), hash_deep,
+// heads_kernel (table form: nothing), the hashing of list set 0 (the group heads; table form: everything listed), the
+// comparison (table form: dedup_kernel), the hashing of list set 1 (table form: nothing), the walk
+constexpr int VERIFY_KERNEL_STAGES = 7;
 hipError_t launch_mpt_verify(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
                              hipStream_t st, const FlatSide* side, const VerifyTune& tune);
 // nodes hashed per rate-block class by the last launch, from a host copy of the workspace's first

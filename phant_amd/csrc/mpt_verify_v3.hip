@@ -55,8 +55,6 @@
 
 #include <phant_platform.h>
 
-#include <phant_platform.h>
-
 #include "launch.h"
 #include "mpt_verify_one.hip.h"
 #include "coop_sponge.hip.h"
@@ -89,13 +87,15 @@ constexpr uint32_t HDR_STAT = 1024;      // + 128 x buffer + 8 x stripe + class:
 constexpr uint32_t HDR_STAT_STRIPES = 16;
 constexpr uint32_t HDR_STAT_WORDS = HDR_STAT_STRIPES * N_CLASS;            // per buffer
 constexpr uint32_t HDR_STAT_END = HDR_STAT + 2u * HDR_STAT_WORDS;          // 1280
-constexpr uint32_t HDR_CUR = 256;        // + 32 x stripe + class: the lists' counts (a 128-byte line per stripe)
-constexpr uint32_t HDR_WORDS = 512;      // flags and cursors; the statistics behind them
+constexpr uint32_t HDR_CUR = 256;        // + 256 x list set + 32 x stripe + class: the lists' counts (a 128-byte line per stripe)
+constexpr uint32_t LIST_SETS = 2;        // set 0: what the table form lists / the ordered form's group heads (known from the keys:
+                                         // hashed early); set 1: the ordered form's copies that differ (known after the comparison)
+constexpr uint32_t HDR_WORDS = 768;      // flags and cursors; the statistics behind them
 constexpr size_t HEADER_BYTES = 8192;
 static_assert(HDR_STAT_END <= VERIFY_HEADER_WORDS && 4u * VERIFY_HEADER_WORDS <= HEADER_BYTES,
               "capi.hip copies VERIFY_HEADER_WORDS words back for the statistics");
 
-PHANT_DEV uint32_t cursor_word(uint32_t cls, uint32_t stripe) { return HDR_CUR + 32u * stripe + cls; }
+PHANT_DEV uint32_t cursor_word(uint32_t cls, uint32_t stripe, uint32_t set = 0u) { return HDR_CUR + 256u * set + 32u * stripe + cls; }
 
 // nstat[] bits
 constexpr uint32_t NS_HASHED = 1u, NS_CANON = 2u, NS_LINK_CHECKED = 4u, NS_LINK_OK = 8u;
@@ -168,6 +168,12 @@ struct Args {
     uint32_t* rep;           // total_nodes; written for the shallow tier's nodes
     uint2* ent;              // N_LIST x STRIPES x stripe_cap: {node, owner proof} to hash, per list and stripe
     uint32_t stripe_cap;     // entries per (class, stripe) = lanes of the workgroups that append there
+    // the ordered form (key-bucketed neighbour comparison instead of the group tables)
+    uint2* ent2;             // list set 1, N_LIST x STRIPES x stripe_cap2
+    uint32_t stripe_cap2;
+    const uint32_t* ord;     // n: proof at position i of the order by (root,) key prefix; null: the caller's order IS that order
+    const uint32_t* bstart;  // buckets + 1: first position of bucket b (ord given)
+    uint32_t bucket_bits;    // a proof's bucket = the top bucket_bits bits of its key (ord given)
     uint32_t* hdr;           // header: HDR_*; cleared per call (propose_kernel / zero_kernel)
     uint32_t* digest;        // total_nodes x 8
     uint8_t* nstat;          // total_nodes: NS_* of the node, written by the lane that hashed it
@@ -197,10 +203,10 @@ struct ShallowLane {
     bool group;    // it takes part in the deduplication: multi-block node of a proof with a usable root index
     bool broken;   // the proof's node range goes backwards (d == 0 lane only)
 };
-PHANT_DEV ShallowLane shallow_lane(const Args& a, uint32_t g) {
+PHANT_DEV ShallowLane shallow_node(const Args& a, uint32_t p, uint32_t d) {
     ShallowLane L;
-    L.p = g / a.shallow;
-    L.d = g - L.p * a.shallow;
+    L.p = p;
+    L.d = d;
     L.j = 0;
     L.root = 0;
     L.len = 0;
@@ -229,27 +235,32 @@ PHANT_DEV ShallowLane shallow_lane(const Args& a, uint32_t g) {
     if (L.group) L.kb = key_prefix64(a.v.keys + (uint64_t)a.v.key_len * L.p, a.v.key_len);
     return L;
 }
+PHANT_DEV ShallowLane shallow_lane(const Args& a, uint32_t g) {
+    const uint32_t p = g / a.shallow;
+    return shallow_node(a, p, g - p * a.shallow);
+}
 
 // ---------------------------------------------------------------- propose
 // Also the launch's clearing kernel: the header (but for the deep role's statistics buffer, which may already be counting),
 // the verdict counters and the state byte of every shallow node (the deep role writes the state of every node it owns
 // itself, so nothing else of nstat[] is read before it is written).
+PHANT_DEV void clear_launch_state(const Args& a, uint32_t g, size_t lanes) {
+    const uint32_t other = HDR_STAT + HDR_STAT_WORDS * ((a.hdr[HDR_PARITY] & 1u) ^ 1u);  // (the deep role may be counting in this launch's)
+    for (size_t i = g; i < HDR_WORDS + HDR_STAT_WORDS; i += lanes) {
+        if (i < HDR_WORDS) {
+            if (i != HDR_PARITY) a.hdr[i] = 0u;
+        } else {
+            a.hdr[other + (i - HDR_WORDS)] = 0u;
+        }
+    }
+    if (a.v.fail_count)
+        for (size_t r = g; r < a.v.n_roots; r += lanes) a.v.fail_count[r] = 0u;
+}
+
 __global__ void __launch_bounds__(256) propose_kernel(const Args a) {
     beside_the_hashing();
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    {
-        const size_t lanes = (size_t)gridDim.x * 256u;
-        const uint32_t other = HDR_STAT + HDR_STAT_WORDS * ((a.hdr[HDR_PARITY] & 1u) ^ 1u);  // (the deep role may be counting in this launch's)
-        for (size_t i = g; i < HDR_WORDS + HDR_STAT_WORDS; i += lanes) {
-            if (i < HDR_WORDS) {
-                if (i != HDR_PARITY) a.hdr[i] = 0u;
-            } else {
-                a.hdr[other + (i - HDR_WORDS)] = 0u;
-            }
-        }
-        if (a.v.fail_count)
-            for (size_t r = g; r < a.v.n_roots; r += lanes) a.v.fail_count[r] = 0u;
-    }
+    clear_launch_state(a, g, (size_t)gridDim.x * 256u);
     const ShallowLane L = shallow_lane(a, g);
     if (L.act) a.nstat[L.j] = 0u;
     if (!L.group) return;
@@ -281,6 +292,9 @@ PHANT_DEV bool entry_matches(const Args& a, uint64_t en, const ShallowLane& L, u
 // where entry `at` of list (class, stripe) lives
 PHANT_DEV uint64_t ent_index(const Args& a, uint32_t cls, uint32_t stripe, uint32_t at) {
     return ((uint64_t)cls * STRIPES + stripe) * a.stripe_cap + at;
+}
+PHANT_DEV uint64_t ent2_index(const Args& a, uint32_t cls, uint32_t stripe, uint32_t at) {
+    return ((uint64_t)cls * STRIPES + stripe) * a.stripe_cap2 + at;
 }
 
 // all 64 lanes: are the `len` bytes at x and y equal?  16 bytes per lane per step.
@@ -432,6 +446,297 @@ __global__ void __launch_bounds__(256) PHANT_NUM_VGPR(48) dedup_kernel(const Arg
         for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
         a.ent[ent_index(a, cls, stripe, at)] = make_uint2(j, L.p);
     }
+}
+
+
+// ================================================================ the shallow tier, ORDERED form
+// The table form above finds a group's representative through a table slot and reads every representative a second time.
+// When the proofs are visited in the order of their (root, key prefix), the members of a group are NEIGHBOURS: a copy is
+// compared with the node the wave has just streamed, every copy passes through the memory path once, and which nodes head a
+// group -- and will have to be hashed whatever the comparison says -- is known from the keys alone, before a single node byte
+// is read: their hashing starts at once (list set 0, hash_list_kernel on a helper stream) NEXT TO the comparison, and what is
+// left behind the comparison are the copies that differ (list set 1: damaged nodes and their successors).
+//
+//   one root (the state trie): the library orders the proofs itself -- a counting sort on the top 4 (S - 1) key bits:
+//        order_hist_kernel (also the launch's clearing kernel) -> order_scan_kernel -> order_scatter_kernel
+//   several roots: only when the caller says the batch IS in (root, key) order (PHANT_CTX_VERIFY_KEY_ORDERED); otherwise the
+//        table form.  Nothing is trusted about that claim: an unordered batch only loses deduplication.
+//   heads_kernel     lane = (position, level): lists what the keys alone say must be hashed -- nodes that take no part in the
+//                    deduplication (single-block nodes, oversized ones) and KEY HEADS: the first position of a run of equal
+//                    (root, level, key prefix); without an order of the library's own also the first position of every chunk.
+//   compare_kernel   wave = (chunk of 63 consecutive positions, level).  Lane l >= 1 fetches what describes position
+//                    63 chunk + l - 1 (proof, node offsets, key prefix); lane 0 the node the chunk's first run continues: the
+//                    key head of its group, found through the bucket table.  Then the wave streams the 64 nodes one after the
+//                    other, 12 bytes per lane: a node that does not open a run is compared with the run's REFERENCE (in
+//                    registers: the key head, or the last copy that differed); equal => rep[] = the reference's node, never
+//                    hashed; different => listed (set 1) and the new reference: a damaged head costs its group one extra hash
+//                    per chunk, a damaged copy two.
+// Soundness is the table form's: rep[j] = r != j only if r is a node of j's group (same root, level and key prefix, checked
+// on the keys, not taken from the order) and bytes(j) == bytes(r), compared byte for byte; every r is listed -- by
+// heads_kernel when it is a key head (the same rule, evaluated on the same keys), by compare_kernel itself otherwise.
+constexpr uint32_t CHUNK = 63;            // positions per comparison wave (lane 0 carries the first run's reference)
+constexpr uint32_t CMP_MAX_LEN = 768;     // 64 lanes x 12 bytes: longer nodes take no part (a branch is at most 532 + its value)
+constexpr uint32_t ORDER_MAX_BITS = 16;   // buckets <= 65 536: the scan is one launch (levels beyond 4 nibbles: see the launcher)
+constexpr uint32_t SCAN_TILE = 2048;
+
+PHANT_DEV uint32_t bucket_of(uint64_t kb, uint32_t bits) { return bits ? (uint32_t)(kb >> (64u - bits)) : 0u; }
+
+// one lane per proof: how many proofs per bucket (bcnt zeroed by the launcher); the launch's clearing kernel
+__global__ void __launch_bounds__(256) order_hist_kernel(const Args a, uint32_t* bcnt) {
+    beside_the_hashing();
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    clear_launch_state(a, p, (size_t)gridDim.x * 256u);
+    if (p >= a.v.n) return;
+    atomicAdd(&bcnt[bucket_of(key_prefix64(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len), a.bucket_bits)], 1u);
+}
+
+// bstart[b] = bcur[b] = proofs in buckets < b; bstart[buckets] = n.  One launch: workgroup w scans tile w (2 048 buckets) on top
+// of the sum of everything in front of it, which it adds up itself (<= 62 coalesced 16-byte loads per lane out of L2).
+__global__ void __launch_bounds__(256) order_scan_kernel(const uint32_t* __restrict__ bcnt, uint32_t* __restrict__ bstart,
+                                                         uint32_t* __restrict__ bcur, uint32_t buckets, uint32_t n) {
+    __shared__ uint32_t s_wave[4], s_wave2[4];
+    beside_the_hashing();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tile0 = blockIdx.x * SCAN_TILE;
+    uint32_t before = 0;
+    for (uint32_t i = 4u * tid; i < tile0; i += 1024u) {  // (tile0 is a multiple of 2 048)
+        const uint4 v = *reinterpret_cast<const uint4*>(bcnt + i);
+        before += v.x + v.y + v.z + v.w;
+    }
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t up = __shfl_up(before, o, 64);
+        if (lane >= o) before += up;
+    }
+    if (lane == 63u) s_wave[wave] = before;
+    uint32_t v[8];
+    const uint32_t at = tile0 + 8u * tid;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) v[k] = at + k < buckets ? bcnt[at + k] : 0u;
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) mine += v[k];
+    uint32_t inc = mine;
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63u) s_wave2[wave] = inc;
+    __syncthreads();
+    uint32_t run = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3] + inc - mine;
+    for (uint32_t w = 0; w < wave; ++w) run += s_wave2[w];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        if (at + k < buckets) {
+            bstart[at + k] = run;
+            bcur[at + k] = run;
+        }
+        run += v[k];
+    }
+    if (blockIdx.x == 0 && tid == 0) bstart[buckets] = n;
+}
+
+// one lane per proof: its position in the order
+__global__ void __launch_bounds__(256) order_scatter_kernel(const Args a, uint32_t* bcur, uint32_t* ord) {
+    beside_the_hashing();
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= a.v.n) return;
+    const uint32_t b = bucket_of(key_prefix64(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len), a.bucket_bits);
+    ord[atomicAdd(&bcur[b], 1u)] = p;
+}
+
+// the launch's clearing kernel when the caller's order is taken as it is (no order pass)
+__global__ void __launch_bounds__(256) clear_kernel(const Args a) {
+    beside_the_hashing();
+    clear_launch_state(a, blockIdx.x * 256u + threadIdx.x, (size_t)gridDim.x * 256u);
+}
+
+// (root, first d key nibbles) of two proofs equal?  (the key prefixes zero-padded: key_len is one per batch)
+PHANT_DEV bool same_key_group(uint32_t root_x, uint64_t kb_x, uint32_t root_y, uint64_t kb_y, uint32_t d) {
+    return root_x == root_y && same_prefix(kb_x, kb_y, d);
+}
+// Does position i open a run at level d?  The rule both kernels of the ordered form evaluate, on the keys alone.
+PHANT_DEV bool key_head(const Args& a, uint32_t i, uint32_t d, uint32_t root, uint64_t kb) {
+    if (i == 0u) return true;
+    if (!a.ord && i % CHUNK == 0u) return true;  // (no bucket table to find a run's head through: every chunk opens its own)
+    const uint32_t pp = a.ord ? a.ord[i - 1u] : i - 1u;
+    const uint32_t rp = a.v.root_idx ? a.v.root_idx[pp] : 0u;
+    return !same_key_group(rp, key_prefix64(a.v.keys + (uint64_t)a.v.key_len * pp, a.v.key_len), root, kb, d);
+}
+
+// appends the lanes' nodes (cls != CLASS_NONE) to the class lists of `set`, compacted over the workgroup: one reservation per
+// workgroup and class on the cursor of the workgroup's stripe
+template <uint32_t SET>
+PHANT_DEV void list_append(const Args& a, uint32_t cls, uint32_t j, uint32_t owner, uint32_t (&s_cnt)[4][N_LIST], uint32_t (&s_base)[N_LIST]) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t my_rank = 0;
+    __syncthreads();  // (s_cnt cleared by the caller at the kernel's head)
+    unsigned long long todo = __ballot(cls != CLASS_NONE);
+    while (todo) {
+        const uint32_t c0 = lane_u32(cls, (uint32_t)__builtin_ctzll(todo));
+        const unsigned long long m = __ballot(cls == c0);
+        if (lane == 0) s_cnt[wave][c0] = (uint32_t)__popcll(m);
+        if (cls == c0) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    __syncthreads();
+    const uint32_t stripe = blockIdx.x % STRIPES;
+    if (tid < N_LIST) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < 4u; ++w) tot += s_cnt[w][tid];
+        s_base[tid] = tot ? atomicAdd(&a.hdr[cursor_word(tid, stripe, SET)], tot) : 0u;
+    }
+    __syncthreads();
+    if (cls != CLASS_NONE) {
+        uint32_t at = s_base[cls] + my_rank;
+        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
+        if (SET == 0u) a.ent[ent_index(a, cls, stripe, at)] = make_uint2(j, owner);
+        else a.ent2[ent2_index(a, cls, stripe, at)] = make_uint2(j, owner);
+    }
+}
+
+PHANT_DEV bool takes_part(const ShallowLane& L) { return L.group && L.len <= CMP_MAX_LEN; }
+
+// lane = (position, level), as the table form's lanes: consecutive lanes = consecutive nodes of one proof
+__global__ void __launch_bounds__(256) heads_kernel(const Args a) {
+    __shared__ uint32_t s_cnt[4][N_LIST];
+    __shared__ uint32_t s_base[N_LIST];
+    beside_the_hashing();
+    const uint32_t tid = threadIdx.x;
+    if (tid < 4u * N_LIST) (&s_cnt[0][0])[tid] = 0u;
+    const uint32_t g = blockIdx.x * 256u + tid;
+    const uint32_t i = g / a.shallow, d = g - i * a.shallow;
+    uint32_t cls = CLASS_NONE, j = 0, p = 0;
+    if (i < a.v.n) {
+        p = a.ord ? a.ord[i] : i;
+        if (p < a.v.n) {  // (whatever the order array holds)
+            ShallowLane L = shallow_node(a, p, d);
+            j = L.j;
+            if (L.act && L.valid) {
+                bool listed = !takes_part(L);
+                if (!listed) listed = key_head(a, i, d, L.root, L.kb);
+                if (listed) cls = node_list(L.len);
+            }
+        }
+    }
+    list_append<0>(a, cls, j, p, s_cnt, s_base);
+}
+
+// wave = (chunk, level); see the head of this section
+__global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const Args a, const uint32_t chunks) {
+    __shared__ uint32_t s_cnt[4][N_LIST];
+    __shared__ uint32_t s_base[N_LIST];
+    beside_the_hashing();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid < 4u * N_LIST) (&s_cnt[0][0])[tid] = 0u;
+    const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (tid >> 6));
+    const uint32_t chunk = unit / a.shallow, d = unit - chunk * a.shallow;
+    const uint32_t i = chunk * CHUNK + lane - 1u;  // the lane's position (lanes >= 1)
+
+    // ---- what the lane's position is: meta = len (<= 768) | takes part | opens a run ----
+    enum : uint32_t { M_LEN = 0xffffu, M_PART = 1u << 16, M_HEAD = 1u << 17 };
+    uint32_t meta = 0, j = 0, p = 0, root = 0, len = 0;
+    uint64_t b = 0, kb = 0;
+    bool real = false, act = false;
+    if (chunk < chunks && lane >= 1u && i < a.v.n) {
+        p = a.ord ? a.ord[i] : i;
+        if (p < a.v.n) {  // (whatever the order array holds)
+            const ShallowLane L = shallow_node(a, p, d);
+            real = true;
+            act = L.act;
+            j = L.j;
+            len = L.len;
+            if (L.broken) a.hdr[HDR_PFN_BROKEN] = 1u;  // (node ranges of other proofs may overlap: the walk trusts nothing then)
+            if (L.act && !L.valid) a.nstat[j] = 0u;     // never hashed: says so (nobody else writes this node's state)
+            root = a.v.root_idx ? a.v.root_idx[p] : 0u;
+            kb = key_prefix64(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len);
+            if (key_head(a, i, d, root, kb)) meta |= M_HEAD;
+            if (takes_part(L)) {
+                meta |= M_PART | L.len;
+                b = a.v.node_off[j];
+            }
+        }
+    }
+    // ---- lane 0: the node the chunk's first run continues -- the key head of position 1's group, through the bucket table ----
+    {
+        const uint32_t m1 = (uint32_t)__shfl((int)meta, 1, 64), r1 = (uint32_t)__shfl((int)root, 1, 64);
+        const uint32_t k1lo = (uint32_t)__shfl((int)(uint32_t)kb, 1, 64), k1hi = (uint32_t)__shfl((int)(uint32_t)(kb >> 32), 1, 64);
+        if (lane == 0u && a.ord && (m1 & M_PART) && !(m1 & M_HEAD) && 4u * d <= a.bucket_bits) {
+            const uint64_t kb1 = ((uint64_t)k1hi << 32) | k1lo;
+            const uint32_t sh = a.bucket_bits - 4u * d;
+            const uint32_t gs = a.bstart[(bucket_of(kb1, a.bucket_bits) >> sh) << sh];
+            if (gs < chunk * CHUNK) {  // (in front of this chunk: a head inside it is met on the way)
+                const uint32_t h = a.ord[gs];
+                if (h < a.v.n) {
+                    const ShallowLane L = shallow_node(a, h, d);
+                    // usable only if it is what heads_kernel lists: a node that takes part, of this group, opening its run
+                    if (takes_part(L) && same_key_group(L.root, L.kb, r1, kb1, d) && key_head(a, gs, d, L.root, L.kb)) {
+                        meta = M_PART | M_HEAD | L.len;
+                        j = L.j;
+                        b = a.v.node_off[j];
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- the stream: node by node, 12 bytes per lane, two trips of four loads in flight ----
+    const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32);
+    const uint32_t off12 = 12u * lane;
+    uint32_t my_ref = 64u;  // the lane whose node this lane's node is a copy of (64: none)
+    bool late = false;      // differs from its run's reference (or found none): to be hashed, says this kernel
+    const unsigned long long parts = __ballot((meta & M_PART) != 0u);
+    if (parts) {
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(parts);  // (nothing to do behind the last node that takes part)
+        U32x3 ref{0u, 0u, 0u};
+        uint32_t ref_len = 0, ref_lane = 64u;
+        auto fetch = [&](uint32_t l) __attribute__((always_inline)) -> U32x3 {
+            const uint32_t m = lane_u32(meta, l);
+            const bool part = (m & M_PART) != 0u;
+            const uint32_t ln = part ? (m & M_LEN) : 12u;                 // (a node that takes no part: the blob's first bytes,
+            const uint64_t base = part ? lane_u64(b_lo, b_hi, l) : 0ull;  //  readable because some node of >= 136 bytes exists)
+            const uint32_t o = off12 < ln - 12u ? off12 : ln - 12u;       // (lanes behind the node's end repeat its last 12 bytes)
+            return *reinterpret_cast<const U32x3*>(a.v.nodes + base + o);
+        };
+        auto step = [&](uint32_t l, const U32x3& cur) __attribute__((always_inline)) {
+            const uint32_t m = lane_u32(meta, l);
+            if (m & M_HEAD) ref_lane = 64u;  // a run ends here, whatever this node is
+            if (!(m & M_PART)) return;
+            const uint32_t ln = m & M_LEN;
+            bool same = false;
+            if (ref_lane < 64u && ln == ref_len) {
+                uint32_t diff = cur.x ^ ref.x;
+                diff = __builtin_amdgcn_bitop3_b32(cur.y, ref.y, diff, 0xBE);  // acc | (x ^ y)
+                diff = __builtin_amdgcn_bitop3_b32(cur.z, ref.z, diff, 0xBE);
+                same = __ballot(diff != 0u) == 0ull;
+            }
+            if (same) {
+                if (lane == l) my_ref = ref_lane;
+            } else {
+                if (!(m & M_HEAD) && lane == l) late = true;
+                ref = cur;
+                ref_len = ln;
+                ref_lane = l;
+            }
+        };
+        constexpr uint32_t U = 4;
+        U32x3 A[U], B[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) A[u] = fetch(u);
+        for (uint32_t t = 0; t <= last; t += 2u * U) {
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) B[u] = fetch((t + U + u) & 63u);
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) step(t + u, A[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) A[u] = fetch((t + 2u * U + u) & 63u);
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) step(t + U + u, B[u]);
+        }
+    }
+    // ---- results: the representative of every node, and what is left to hash ----
+    const uint32_t rj = (uint32_t)__shfl((int)j, (int)(my_ref & 63u), 64);
+    if (real && act) a.rep[j] = my_ref < 64u ? rj : j;
+    list_append<1>(a, (real && late) ? node_list(len) : CLASS_NONE, j, p, s_cnt, s_base);
 }
 
 // ---------------------------------------------------------------- canonical full branch, per rate block
@@ -623,12 +928,14 @@ PHANT_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
-PHANT_DEV void list_role(const Args& a, uint32_t q, const uint32_t lane) {
+// -> false: no chunk q (the queue is shorter)
+template <uint32_t SET>
+PHANT_DEV bool list_role(const Args& a, uint32_t q, const uint32_t lane) {
     // which list chunk q is in: every lane reads the count of a list (two: there are 72), one prefix sum over the wave
     // (72 dependent scalar loads per wave cost 12 us -- every wave of the grid, the real ones included)
     static_assert(N_QUEUE > 64u && N_QUEUE <= 128u, "two lists per lane");
-    const uint32_t cnt_a = a.hdr[cursor_word(queue_class(lane), lane % STRIPES)];
-    const uint32_t cnt_b = lane + 64u < N_QUEUE ? a.hdr[cursor_word(queue_class(lane + 64u), (lane + 64u) % STRIPES)] : 0u;
+    const uint32_t cnt_a = a.hdr[cursor_word(queue_class(lane), lane % STRIPES, SET)];
+    const uint32_t cnt_b = lane + 64u < N_QUEUE ? a.hdr[cursor_word(queue_class(lane + 64u), (lane + 64u) % STRIPES, SET)] : 0u;
     const uint32_t ch_a = (cnt_a + 63u) / 64u, ch_b = (cnt_b + 63u) / 64u;
     const uint32_t incl_a = wave_inclusive_scan(ch_a, lane);
     uint32_t li, before, cnt;
@@ -641,7 +948,7 @@ PHANT_DEV void list_role(const Args& a, uint32_t q, const uint32_t lane) {
     } else {
         const uint32_t incl_b = lane_u32(incl_a, 63u) + wave_inclusive_scan(ch_b, lane);
         const unsigned long long m_b = __ballot(q < incl_b);
-        if (!m_b) return;
+        if (!m_b) return false;
         const uint32_t l = (uint32_t)__builtin_ctzll(m_b);
         li = l + 64u;
         before = lane_u32(incl_b, l) - lane_u32(ch_b, l);
@@ -650,7 +957,7 @@ PHANT_DEV void list_role(const Args& a, uint32_t q, const uint32_t lane) {
     const uint32_t cls = queue_class(li), stripe = li % STRIPES;
     uint32_t idx = (q - before) * 64u + lane;
     idx = idx < cnt ? idx : cnt - 1u;
-    const uint2 en = a.ent[ent_index(a, cls, stripe, idx)];
+    const uint2 en = SET == 0u ? a.ent[ent_index(a, cls, stripe, idx)] : a.ent2[ent2_index(a, cls, stripe, idx)];
     const uint32_t j = en.x;
     const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
     const uint64_t b = a.v.node_off[j];
@@ -685,6 +992,7 @@ PHANT_DEV void list_role(const Args& a, uint32_t q, const uint32_t lane) {
     if (refp) ns |= NS_LINK_CHECKED | (digest_equals(s, ref) ? NS_LINK_OK : 0u);
     a.nstat[j] = (uint8_t)ns;
     store_node_digest(a, j, s);
+    return true;
 }
 
 // ---------------------------------------------------------------- hash: the deep role, in place
@@ -692,7 +1000,7 @@ PHANT_DEV void list_role(const Args& a, uint32_t q, const uint32_t lane) {
 // the leaves, the short chunks, fill the tail); a wave whose proofs are all shorter leaves at once.
 constexpr uint32_t DEEP_LEVELS = 8;  // at most; the launcher picks fewer when the batch's proofs are short (see there)
 
-// SOLO: the S = 0 form -- no elect_kernel runs, so this role is the one to notice a proof_first_node that is not monotone
+// SOLO: the S = 0 form -- no shallow tier runs, so this role is the one to notice a proof_first_node that is not monotone
 template <bool SOLO>
 PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, const uint32_t waves_per_level, const uint32_t levels,
                          uint32_t (&s_ref)[8][256]) {
@@ -714,7 +1022,7 @@ PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, c
             const uint32_t last = a.v.proof_first_node[p + 1];
             if (last >= first && last <= a.total_nodes) count = last - first;
             // (node ranges of other proofs may overlap then: what a lane finds out about a node holds for ITS proof's key
-            // and parent only -- the walk must not use it.  elect_kernel says so when it runs)
+            // and parent only -- the walk must not use it.  The shallow tier's kernels say so when they run)
             if constexpr (SOLO) {
                 if (last < first) a.hdr[HDR_PFN_BROKEN] = 1u;
             }
@@ -823,7 +1131,7 @@ __global__ void __launch_bounds__(256) hash_coop_kernel(const Args a, const uint
         first = a.v.proof_first_node[p];
         const uint32_t last = a.v.proof_first_node[p + 1];
         if (last >= first && last <= a.total_nodes) count = last - first;
-        if (last < first && l == 0) a.hdr[HDR_PFN_BROKEN] = 1u;  // (no elect_kernel in this form: see deep_role<true>)
+        if (last < first && l == 0) a.hdr[HDR_PFN_BROKEN] = 1u;  // (no shallow tier in this form: see deep_role<true>)
         if (a.v.root_idx) root = a.v.root_idx[p];
     }
     const uint32_t nn = 2u * a.v.key_len;
@@ -909,11 +1217,20 @@ __global__ void __launch_bounds__(256) hash_coop_kernel(const Args a, const uint
     }
 }
 
+// SET: which of the two list sets (the ordered form hashes its group heads -- set 0 -- next to the comparison and what the
+// comparison leaves -- set 1 -- behind it)
+template <uint32_t SET>
 __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
     // On the critical path (propose -> dedup -> this -> walk) with fewer waves than the chip has SIMDs, four permutations in
     // a row each, while the deep tier's waves, which are many and in nobody's way, compete for the same issue slots: go first.
     __builtin_amdgcn_s_setprio(2);
-    list_role(a, (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), threadIdx.x & 63u);
+    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (SET == 0u) {
+        (void)list_role<SET>(a, q, threadIdx.x & 63u);  // (the grid covers the worst case, the dispatcher keeps every SIMD full)
+    } else {
+        // set 1 is short (the copies that differ): a bounded grid whose waves stride over the queue
+        while (list_role<SET>(a, q, threadIdx.x & 63u)) q += gridDim.x * 4u;
+    }
 }
 
 // node-set witnesses: every node listed (classify_kernel), no owners, no references
@@ -1493,15 +1810,20 @@ static uint32_t table_entries(uint32_t n, uint32_t n_roots, uint32_t direct, uin
 }
 
 struct Layout {
-    size_t nstat, dtab, table, rep, ent, digest, end;
-    uint32_t stripe_cap;
+    size_t nstat, dtab, table, rep, ent, digest, ord, bcnt, bstart, bcur, ent2, end;
+    uint32_t stripe_cap, stripe_cap2;
 };
-// `lanes`: the shallow tier's lanes (proofs x shallow levels; 0 for the forms without a shallow tier)
-static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries, uint64_t lanes) {
+// lanes of the comparison kernel of the ordered form: a wave per (chunk of CHUNK positions, level)
+static uint64_t compare_units(uint64_t n, uint32_t shallow) { return (n + CHUNK - 1u) / CHUNK * shallow; }
+// `lanes`: the shallow tier's lanes (proofs x shallow levels; 0 for the forms without a shallow tier); `ord_n`, `units`: proofs
+// ordered and comparison waves of the ordered form (0: another form)
+static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries, uint64_t lanes, uint64_t ord_n, uint64_t units) {
     const size_t tn = total_nodes;
     Layout l;
     const uint64_t wgs = (lanes + 255u) / 256u;
     l.stripe_cap = (uint32_t)((wgs + STRIPES - 1u) / STRIPES * 256u);
+    const uint64_t wgs2 = (units + 3u) / 4u;
+    l.stripe_cap2 = (uint32_t)((wgs2 + STRIPES - 1u) / STRIPES * 256u);
     size_t p = HEADER_BYTES;
     l.nstat = p;  p += rnd256(tn + 16);
     l.dtab = p;   p += rnd256((size_t)direct_entries * 4);
@@ -1511,6 +1833,12 @@ static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries,
     const size_t striped = (size_t)N_LIST * STRIPES * l.stripe_cap * 8u;
     l.ent = p;    p += rnd256(striped > tn * 8 * N_LIST ? striped : tn * 8 * N_LIST);
     l.digest = p; p += rnd256(tn * 32);
+    const size_t buckets = ord_n ? (size_t)1 << ORDER_MAX_BITS : 0;
+    l.ord = p;    p += rnd256((size_t)ord_n * 4);
+    l.bcnt = p;   p += rnd256(buckets * 4);
+    l.bstart = p; p += rnd256((buckets + 1) * 4);
+    l.bcur = p;   p += rnd256(buckets * 4);
+    l.ent2 = p;   p += rnd256((size_t)N_LIST * STRIPES * l.stripe_cap2 * 8u);
     l.end = p + 1024;
     return l;
 }
@@ -1520,7 +1848,9 @@ size_t workspace_bytes(uint32_t total_nodes) {
     // most one lane per node: the launcher cuts a forced split back to that)
     uint32_t t = 1024;
     while (t < 4ull * total_nodes && t < (1u << 26)) t <<= 1;
-    return layout(total_nodes, t, DIRECT_MAX_ENTRIES, (uint64_t)total_nodes + 256u * STRIPES).end;
+    const uint64_t lanes = (uint64_t)total_nodes + 256u * STRIPES;
+    // (n x S <= lanes and S >= 1: at most `lanes` proofs are ordered, and ceil(n / CHUNK) S <= n S / CHUNK + S comparison waves)
+    return layout(total_nodes, t, DIRECT_MAX_ENTRIES, lanes, lanes, lanes / CHUNK + MAX_SHALLOW + 1u).end;
 }
 
 static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
@@ -1533,6 +1863,11 @@ static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
     a.ent = reinterpret_cast<uint2*>(ws + l.ent);
     a.stripe_cap = l.stripe_cap;
     a.digest = reinterpret_cast<uint32_t*>(ws + l.digest);
+    a.ent2 = reinterpret_cast<uint2*>(ws + l.ent2);
+    a.stripe_cap2 = l.stripe_cap2;
+    a.ord = nullptr;
+    a.bstart = nullptr;
+    a.bucket_bits = 0;
 }
 
 }  // namespace v3
@@ -1549,6 +1884,13 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     a.v = v;
     a.total_nodes = total_nodes;
     a.shallow = shallow_levels(v.n, v.n_roots, v.nodes_len, dedup_levels);
+    // Which form the shallow tier takes: the ordered one wherever an order by (root, key prefix) is to be had -- one root: the
+    // library's own counting sort; the caller's word for it otherwise --, the group tables for the rest.
+    const bool own_order = !tune.table_form && !tune.key_ordered && v.n_roots == 1u;
+    const bool ordered = own_order || (!tune.table_form && tune.key_ordered);
+    // (the counting sort is on <= ORDER_MAX_BITS key bits: levels beyond that many nibbles would find their groups scattered
+    // over a bucket -- sound, but nothing deduplicated: left to the deep tier unless the split is forced)
+    if (own_order && dedup_levels < 0 && a.shallow > ORDER_MAX_BITS / 4u + 1u) a.shallow = ORDER_MAX_BITS / 4u + 1u;
     // the shallow tier has a lane per (proof, level) and lists sized by them: a forced split deeper than the proofs are
     // long on average is cut back to what the workspace (sized from total_nodes) holds
     while (a.shallow && (uint64_t)v.n * a.shallow > (uint64_t)total_nodes + 256u * STRIPES) --a.shallow;
@@ -1557,7 +1899,8 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     a.direct = direct_levels(v.n_roots, a.shallow, direct_entries);
     const uint32_t te = table_entries(v.n, v.n_roots, a.direct, a.shallow, total_nodes);
     const uint64_t lanes = (uint64_t)v.n * a.shallow;
-    const Layout l = layout(total_nodes, te, direct_entries, lanes);
+    const uint64_t units = ordered ? compare_units(v.n, a.shallow) : 0u;
+    const Layout l = layout(total_nodes, te, direct_entries, lanes, own_order ? v.n : 0u, units);
     bind(a, ws, l, te);
     hipError_t e = hipSuccess;
     const uint32_t pg = (v.n + 255u) / 256u;
@@ -1569,17 +1912,18 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     const uint32_t deep_levels = avg_len + 1u <= a.shallow ? 1u
                                  : (uint32_t)(avg_len + 1u - a.shallow < DEEP_LEVELS ? avg_len + 1u - a.shallow : DEEP_LEVELS);
     const uint32_t deep_wgs = (wpl * deep_levels + 3u) / 4u;
+    if (tune.last_form) *tune.last_form = (a.shallow == 0u || total_nodes == 0u) ? 0u : !ordered ? 1u : own_order ? 2u : 3u;
     if (a.shallow == 0u || total_nodes == 0u) {
         // S = 0: clear, hash every node in place, walk on the node states.  No lists, tables or helper stream.
         a.shallow = 0;
         const size_t zero_n16 = l.dtab / 16;  // header + node states
         hipLaunchKernelGGL(zero_kernel, dim3((uint32_t)((zero_n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint4*>(ws),
                            zero_n16, v.fail_count, v.n_roots);
-        const bool no_coop = std::getenv("PHANT_VERIFY_NO_COOP") != nullptr;  // (A/B; read per launch: the dry runs of bench.py in the CPU
-                                                                              // suite switch it off -- 32 emulated lanes per node are slow there)
-        static const uint32_t coop_max = std::getenv("PHANT_VERIFY_COOP_MAX") ? (uint32_t)std::atoi(std::getenv("PHANT_VERIFY_COOP_MAX")) : COOP_MAX_NODES;  // (A/B)
-        if (total_nodes && total_nodes <= coop_max && !no_coop)
-            hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)(((uint64_t)v.n * deep_levels + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);
+        // a node per half wave for the witness of an ordinary block: 32 lanes per (proof, level), so only where the proofs are
+        // about as long as the levels walked (a batch of many empty or short proofs would be mostly idle half waves)
+        const uint64_t halves = (uint64_t)v.n * deep_levels;
+        if (total_nodes && total_nodes <= tune.coop_max && !tune.no_coop && halves <= 4ull * COOP_MAX_NODES)
+            hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);
         else if (total_nodes)
             hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, wpl, deep_levels);
         hipLaunchKernelGGL(walk_kernel<true>, dim3(pg), dim3(256), 0, st, a);
@@ -1600,25 +1944,80 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;  // (behind the previous launch's walk)
         if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
     }
-    // (propose_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep
-    // role's waves fill every slot they are given the moment they start)
-    hipEvent_t* const kev = (!two && tune.serial) ? tune.kernel_ev : nullptr;  // (diagnostics: every kernel alone on the chip)
+    hipEvent_t* const kev = (!two && tune.serial) ? tune.kernel_ev : nullptr;  // (diagnostics: every stage alone on the chip)
     auto mark = [&](int i) {
         if (kev && e == hipSuccess) e = hipEventRecord(kev[i], st);
     };
+    if (!ordered) {
+        // (propose_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep
+        // role's waves fill every slot they are given the moment they start)
+        mark(0);
+        hipLaunchKernelGGL(propose_kernel, dim3(sg), dim3(256), 0, st, a);
+        mark(1);
+        hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+        mark(2);
+        mark(3);  // (no heads_kernel and nothing hashed ahead of the comparison in this form: stages 2 and 3 are empty)
+        mark(4);
+        if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), 0, st, a);
+        mark(5);
+        hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, st, a);
+        mark(6);
+        if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+        mark(7);
+        if (e != hipSuccess) return e;
+        return hipGetLastError();
+    }
+    // ---- ordered form ----
+    const bool three = two && side->stream2 && side->sorted && side->join2;
+    hipStream_t h2 = three ? side->stream2 : st;
     mark(0);
-    hipLaunchKernelGGL(propose_kernel, dim3(sg), dim3(256), 0, st, a);
+    if (own_order) {
+        a.bucket_bits = 4u * (a.shallow - 1u) < ORDER_MAX_BITS ? 4u * (a.shallow - 1u) : ORDER_MAX_BITS;
+        const uint32_t buckets = 1u << a.bucket_bits;
+        uint32_t* const bcnt = reinterpret_cast<uint32_t*>(ws + l.bcnt);
+        uint32_t* const bstart = reinterpret_cast<uint32_t*>(ws + l.bstart);
+        uint32_t* const bcur = reinterpret_cast<uint32_t*>(ws + l.bcur);
+        uint32_t* const ord = reinterpret_cast<uint32_t*>(ws + l.ord);
+        if ((e = hipMemsetAsync(bcnt, 0, (size_t)buckets * 4u, st)) != hipSuccess) return e;
+        // (the first kernel of the chain is handed to the device first, then the deep role, whose waves fill every slot they are
+        // given the moment they start; with the tiers serialised for per-stage times the deep role runs behind the order pass)
+        hipLaunchKernelGGL(order_hist_kernel, dim3(pg), dim3(256), 0, st, a, bcnt);
+        if (!kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+        hipLaunchKernelGGL(order_scan_kernel, dim3((buckets + SCAN_TILE - 1u) / SCAN_TILE), dim3(256), 0, st, bcnt, bstart, bcur, buckets, v.n);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(pg), dim3(256), 0, st, a, bcur, ord);
+        a.ord = ord;
+        a.bstart = bstart;
+    } else {
+        hipLaunchKernelGGL(clear_kernel, dim3(4), dim3(256), 0, st, a);
+        if (!kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+    }
     mark(1);
-    hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+    if (kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
     mark(2);
     if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), 0, st, a);
+    if (three) {
+        if ((e = hipEventRecord(side->sorted, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side->stream2, side->sorted, 0)) != hipSuccess) return e;
+    }
+    // the group heads: listed from the keys alone and hashed NEXT TO the comparison
+    hipLaunchKernelGGL(heads_kernel, dim3(sg), dim3(256), 0, h2, a);
     mark(3);
-    hipLaunchKernelGGL(hash_list_kernel, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, st, a);
+    hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, h2, a);
     mark(4);
-    if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+    if (three && (e = hipEventRecord(side->join2, side->stream2)) != hipSuccess) return e;
+    const uint32_t cg = (uint32_t)((units + 3u) / 4u);
+    hipLaunchKernelGGL(compare_kernel, dim3(cg), dim3(256), 0, st, a, (uint32_t)((v.n + CHUNK - 1u) / CHUNK));
     mark(5);
+    // what the comparison left: a thin list (damaged copies and their successors) -- a bounded grid that strides over it
+    const uint32_t late_wgs = list_wgs < 256u ? list_wgs : 256u;
+    hipLaunchKernelGGL(hash_list_kernel<1>, dim3(late_wgs), dim3(256), 0, st, a);
+    mark(6);
+    if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
+    if (three && (e = hipStreamWaitEvent(st, side->join2, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+    mark(7);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
@@ -1642,7 +2041,7 @@ hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, 
     a.shallow = 0;
     a.direct = 0;
     const uint32_t te = 1024;
-    const Layout l = layout(total_nodes, te, 0, 0);
+    const Layout l = layout(total_nodes, te, 0, 0, 0, 0);
     bind(a, ws, l, te);
     uint32_t* tab = reinterpret_cast<uint32_t*>(ws + workspace_bytes(total_nodes));
     const uint32_t tab_entries = nodeset_table_entries(total_nodes);
@@ -1666,7 +2065,8 @@ void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]) {
     uint32_t lists[N_LIST];
     for (uint32_t c = 0; c < N_LIST; ++c) {
         lists[c] = hdr[c];  // (the node-set form's single cursors)
-        for (uint32_t s = 0; s < STRIPES; ++s) lists[c] += hdr[HDR_CUR + 32u * s + c];
+        for (uint32_t t = 0; t < LIST_SETS; ++t)
+            for (uint32_t s = 0; s < STRIPES; ++s) lists[c] += hdr[HDR_CUR + 256u * t + 32u * s + c];
     }
     const uint32_t buf = (hdr[HDR_PARITY] & 1u) ^ 1u;  // (the walk has flipped the word)
     for (uint32_t c = 0; c < N_CLASS; ++c) {
@@ -1680,7 +2080,8 @@ void verify_tier_stats_from_header(const uint32_t* hdr, uint32_t out[4]) {
     out[0] = out[1] = out[2] = out[3] = 0;
     for (uint32_t c = 0; c < N_LIST; ++c) {
         uint32_t cnt = hdr[c];  // (the node-set form's single cursors)
-        for (uint32_t s = 0; s < STRIPES; ++s) cnt += hdr[HDR_CUR + 32u * s + c];
+        for (uint32_t t = 0; t < LIST_SETS; ++t)
+            for (uint32_t s = 0; s < STRIPES; ++s) cnt += hdr[HDR_CUR + 256u * t + 32u * s + c];
         out[0] += cnt;
         out[1] += cnt * (c == LIST_B532 ? BRANCH_LEN / RATE + 1u : c + 1u);
     }

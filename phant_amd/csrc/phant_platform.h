@@ -26,3 +26,14 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),             \
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #define PHANT_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// A wave's lanes hand bytes to each other through LDS (the node-per-half-wave kernels: sixteen lanes store a child each, all
+// lanes then read rate words): the stores of every lane are visible to every lane of the SAME wave behind this point.  The
+// hardware's LDS queue is in order per wave; this is what tells the compiler (release fence, wave barrier, acquire fence at
+// wavefront scope: no instruction on the hardware beyond an s_waitcnt).
+#define PHANT_WAVE_LDS_SYNC()                                       \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+    } while (0)

@@ -1125,7 +1125,8 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
     uint32_t* const buf = s_node[hw];
     uint8_t* const b = reinterpret_cast<uint8_t*>(buf);
     // ---- the 17-item list (mpt.zig:216-231), sixteen lanes a child each ----
-    for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 32u) buf[k] = 0u;  // (in front of the shuffles below: they order it before the lanes' bytes)
+    for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 32u) buf[k] = 0u;
+    PHANT_WAVE_LDS_SYNC();  // (the buffer is clear before any lane's bytes go in)
     const uint32_t sl = (live && l < 16u) ? t.slot_len[(uint64_t)dn * 16u + l] : 0u;
     const uint32_t mine = (live && l < 16u) ? (sl == 0u ? 1u : (sl == 32u ? 33u : sl)) : 0u;
     uint32_t incl = mine;
@@ -1168,8 +1169,8 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
     }
     const bool embedded = live && total < 32u && !is_root;  // (mpt.zig:104,:112; no extension above it: see `plain`)
     const bool hashed = live && !embedded;
-    uint32_t nb = coop_wave_max(0u, base);  // (a shuffle: every lane's bytes are in the buffer)
-    nb = hashed ? blocks_of(total) : 0u;
+    PHANT_WAVE_LDS_SYNC();  // (every lane's bytes are in the buffer)
+    const uint32_t nb = hashed ? blocks_of(total) : 0u;
     if (hashed && l == 0) {
         b[total] = 0x01;  // Keccak-256's domain byte and the end of pad10*1
         b[nb * RATE - 1u] |= 0x80;
@@ -1181,7 +1182,8 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
     }
     const CoopLane c = coop_lane(l, base);
     uint32_t lo = 0, hi = 0;
-    coop_keccak256(c, buf, nb, coop_wave_max(nb, base), lo, hi);  // (the shuffle inside: lane 0's padding bytes are in the buffer)
+    PHANT_WAVE_LDS_SYNC();  // (lane 0's padding bytes and the embedded node's copy-out are through)
+    coop_keccak256(c, buf, nb, coop_wave_max(nb, base), lo, hi);
     // ---- the ExtensionNode above it (mpt.zig:187-193): [HP(path), digest], built by the first lane, hashed by all ----
     const bool ext = hashed && ext_len != 0u;
     if (__ballot(ext) != 0ull) {
@@ -1192,14 +1194,17 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
             s.lo[k] = __shfl(lo, (int)(base + (uint32_t)k), 64);
             s.hi[k] = __shfl(hi, (int)(base + (uint32_t)k), 64);
         }
+        PHANT_WAVE_LDS_SYNC();  // (every lane has absorbed the branch's last block out of the buffer)
         if (ext)
             for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 32u) buf[k] = 0u;
-        uint32_t out_len = coop_wave_max(0u, base);  // (a shuffle: the buffer is clear)
+        PHANT_WAVE_LDS_SYNC();  // (the buffer is clear)
+        uint32_t out_len = 0;
         if (ext && l == 0) {
             out_len = put_extension(b, t, lkey, (uint32_t)(pd + 1), (uint32_t)d, true, s, nullptr, 0u);
             b[out_len] = 0x01;
             b[blocks_of(out_len) * RATE - 1u] |= 0x80;
         }
+        PHANT_WAVE_LDS_SYNC();  // (the extension's bytes and padding are in the buffer)
         out_len = __shfl(out_len, (int)base, 64);
         const uint32_t nbx = ext ? blocks_of(out_len) : 0u;
         uint32_t xlo = 0, xhi = 0;

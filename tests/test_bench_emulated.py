@@ -346,3 +346,42 @@ def test_a_rank_that_never_shows_up_ends_in_an_error_line_not_a_hang():
     assert p.returncode in (3, 4), (p.returncode, p.stderr[-2000:])
     err_lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(err_lines) == 1 and err_lines[0]["error"] and err_lines[0]["value"] is None and err_lines[0]["n_gpus"] == 2
+
+
+_ENTRY_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+from tests import emu
+import tests.test_bench_emulated as T
+g = emu.emulated_backend()
+next(g)
+line = None
+try:
+    line = T._bench(sys.argv[1:], allow_no_line=True)
+finally:
+    try:
+        next(g)
+    except StopIteration:
+        pass
+if line is not None:
+    print(json.dumps(line), flush=True)
+"""
+
+
+def test_gpus_2_without_torchrun_relaunches_itself(tmp_path):
+    """`python bench.py --gpus 2` the way the driver starts the N = 1 run (no WORLD_SIZE): bench.py becomes the launcher --
+    torch.distributed.run, one rank per GPU -- and the job prints ONE line with two ranks in it (gloo and the emulated
+    library stand in for RCCL and the GPUs through the test-only PHANT_BENCH_ENTRY script)."""
+    import subprocess
+    entry = tmp_path / "bench_entry.py"
+    entry.write_text(_ENTRY_SCRIPT.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PHANT_BENCH_BACKEND="gloo", PHANT_BENCH_ENTRY=str(entry), PHANT_VERIFY_NO_COOP="1")
+    argv = ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--inner", "1", "--no-strong", "--no-cpu-baseline",
+            "--max-seconds", "600"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, (p.returncode, p.stderr[-3000:])
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    assert lines[0]["n_gpus"] == 2 and lines[0]["rccl_world"]["ranks"] == 2 and lines[0]["value"] > 0

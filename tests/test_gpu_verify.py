@@ -26,11 +26,16 @@ class _Mode:
         return self._mod.verify_batch_dev(*a, ctx=self._ctx, **k)
 
 
-@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused"])
+# "+table" / "+caller": the shallow tier through its group tables whatever the batch / the ordered form on the caller's order as it
+# is (PHANT_CTX_VERIFY_KEY_ORDERED) -- which these batches are NOT in: nothing may depend on the promise
+@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+table", "levels16+table",
+                                        "levels3+caller", "levels16+caller"])
 def M(request):
     import phant_amd
-    ctx = phant_amd.Context(verify_fused=(request.param == "fused"), verify_nodedup=(request.param == "nodedup"),
-                            dedup_levels=(int(request.param[6:]) if request.param.startswith("levels") else None))
+    mode, _, form = request.param.partition("+")
+    ctx = phant_amd.Context(verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"),
+                            dedup_levels=(int(mode[6:]) if mode.startswith("levels") else None),
+                            key_ordered=(form == "caller"), verify_table=(form == "table"))
     yield _Mode(phant_amd.mpt, ctx, request.param)
     ctx.close()
 
@@ -237,6 +242,8 @@ def test_which_nodes_get_hashed_per_tier_split(M, oracle):
     hashed = sum(M._ctx.verify_stats())
     if M.mode in ("flat", "nodedup"):
         assert hashed == shipped
+    elif M.mode.endswith("+caller"):  # (the caller's order as it is: every chunk of 63 positions opens its own runs)
+        assert hashed <= shipped - 299 + 300 // 63, (M.mode, hashed, shipped)
     else:  # levels1 / levels3 / levels16: at least the 299 copies of the root node are not hashed
         assert hashed <= shipped - 299, (M.mode, hashed, shipped)
 
@@ -280,7 +287,7 @@ def test_one_byte_off_in_a_duplicate_node(M, oracle):
     node_off = b.node_off.cpu().numpy()
     pfn = b.proof_first_node.cpu().numpy()
     rng = np.random.default_rng(5)
-    offsets = [0, 3, 15, 16, 255, 256, 503, 504, 511, 512, 515, 516, 519, 520, 527, 528, 531]
+    offsets = [0, 3, 11, 12, 15, 16, 23, 24, 255, 256, 503, 504, 511, 512, 515, 516, 519, 520, 527, 528, 531]
     proofs = rng.choice(b.n, size=len(offsets) * 3, replace=False)
     for t, p in enumerate(proofs):
         level = t % 3  # a node of depth 0 / 1 / 2: all shared by many proofs

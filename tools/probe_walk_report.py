@@ -5,7 +5,7 @@ import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "phant::" in r["Kernel_Name"] and "keccak256_fixed" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-first = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("propose_kernel", "zero_kernel")
+first = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("propose_kernel", "zero_kernel", "order_hist_kernel", "clear_kernel")
 t0 = None
 cur = []
 for r in rows:
@@ -16,5 +16,5 @@ for r in rows:
             print("  ".join(cur))
         cur = [f"period={(s - t0) / 1e3:.0f}" if t0 is not None else "period=-"]
         t0 = s
-    cur.append(f"{name[:9]}@{(s - t0) / 1e3:.0f}+{(e - s) / 1e3:.0f}")
+    cur.append(f"{name[:15]}@{(s - t0) / 1e3:.0f}+{(e - s) / 1e3:.0f}")
 print("  ".join(cur))
