@@ -498,6 +498,16 @@ PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
 #define PHANT_VERIFY_KERNEL_STAGES 7
 PHANT_API int32_t phant_verify_kernel_ms(phant_ctx *ctx, float ms[PHANT_VERIFY_KERNEL_STAGES]);
 PHANT_API int32_t phant_verify_form(phant_ctx *ctx, uint32_t *form);
+/* Diagnostics: what the chip can overlap at best on THIS witness (arguments of phant_mpt_verify_batch_dev).  One complete
+ * verification first; then, `reps` times each on the ctx's streams, out_ms[0] = only the hashing that launch did (the deep tier
+ * and everything listed, next to each other: the integer-VALU side), out_ms[1] = only a coalesced read of the node bytes (the
+ * memory side, a clean stream), out_ms[2] = both next to each other.  A verify launch cannot be shorter than out_ms[2]; how
+ * far it is above it is what its own kernels' shape costs.  bench.py: roofline.bound_experiment.  Synchronises. */
+PHANT_API int32_t phant_verify_bound_experiment(phant_ctx *ctx, const uint8_t *d_roots, uint32_t n_roots,
+                                                const uint32_t *d_root_idx, const uint8_t *d_keys, uint32_t key_len,
+                                                const uint8_t *d_nodes, uint64_t nodes_len, const uint64_t *d_node_off,
+                                                uint32_t total_nodes, const uint32_t *d_proof_first_node, uint32_t n,
+                                                uint8_t *d_status, uint32_t reps, float out_ms[3]);
 /* Diagnostics: the Keccak-f[1600] rate of the device when it does nothing else -- waves_per_simd (1..8) waves per SIMD,
  * every lane `perms` permutations of a register-resident state with the product's round function, timed with events on the
  * ctx stream (synchronises it).  *perms_per_s = permutations per second over the whole chip: the VALU ceiling every hash

@@ -87,6 +87,8 @@ SYMBOLS = {
     "phant_keccak_rate": (_i32, [_vp, _u32, _u32, C.POINTER(C.c_double)]),
     "phant_verify_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float * 7)]),
     "phant_verify_form": (_i32, [_vp, C.POINTER(C.c_uint32)]),
+    "phant_verify_bound_experiment": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp, _u32,
+                                            C.POINTER(C.c_float * 3)]),
     "phant_verify_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 8)]),
     "phant_verify_path_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 2)]),
     "phant_verify_tier_stats": (_i32, [_vp, C.POINTER(C.c_uint32 * 5)]),

@@ -100,6 +100,18 @@ class Context:
         self.check(self._lib.phant_verify_kernel_ms(self._h, C.byref(out)))
         return dict(zip(self.VERIFY_STAGES, [float(x) for x in out]))
 
+    def verify_bound_experiment(self, batch, reps: int = 20) -> dict[str, float]:
+        """phant_verify_bound_experiment on a device-resident ProofBatch: ms of the launch's hashing alone, of a clean read of
+        the witness alone, of both next to each other."""
+        import torch
+        st = torch.empty(batch.n, dtype=torch.uint8, device=batch.nodes.device)
+        out = (C.c_float * 3)()
+        self.check(self._lib.phant_verify_bound_experiment(
+            self._h, batch.roots.data_ptr(), batch.n_roots, None if batch.root_idx is None else batch.root_idx.data_ptr(),
+            batch.keys.data_ptr(), batch.key_len, batch.nodes.data_ptr(), batch.nodes.numel(), batch.node_off.data_ptr(),
+            batch.node_off.numel() - 1, batch.proof_first_node.data_ptr(), batch.n, st.data_ptr(), reps, C.byref(out)))
+        return {"hash_only_ms": float(out[0]), "stream_only_ms": float(out[1]), "together_ms": float(out[2])}
+
     def verify_form(self) -> str:
         """The form the last verify launch on this ctx took (diagnostics)."""
         out = C.c_uint32(0)

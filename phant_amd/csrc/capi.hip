@@ -692,6 +692,44 @@ int32_t phant_mpt_verify_batch_dev(phant_ctx* c, const uint8_t* d_roots, uint32_
     return verify_resident(c, a, total_nodes);
 }
 
+int32_t phant_verify_bound_experiment(phant_ctx* c, const uint8_t* d_roots, uint32_t n_roots, const uint32_t* d_root_idx,
+                                      const uint8_t* d_keys, uint32_t key_len, const uint8_t* d_nodes, uint64_t nodes_len,
+                                      const uint64_t* d_node_off, uint32_t total_nodes, const uint32_t* d_proof_first_node,
+                                      uint32_t n, uint8_t* d_status, uint32_t reps, float out_ms[3]) {
+    if (!c || !out_ms || reps == 0) return PHANT_E_INVALID_ARG;
+    out_ms[0] = out_ms[1] = out_ms[2] = 0.f;
+    if (c->verify_fused || c->tune.serial) return fail(c, PHANT_E_UNSUPPORTED, "bound_experiment: needs the two-tier pipeline with its tiers next to each other");
+    if (((uintptr_t)d_nodes & 15u) != 0) return fail(c, PHANT_E_INVALID_ARG, "bound_experiment: the node blob must be 16-byte aligned");
+    // one complete launch: its lists and counts are what the hashing-only launches below work from
+    int32_t rc = phant_mpt_verify_batch_dev(c, d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len, d_node_off,
+                                            total_nodes, d_proof_first_node, n, d_status, nullptr, nullptr);
+    if (rc) return rc;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->last_form == 0u) return fail(c, PHANT_E_INVALID_ARG, "bound_experiment: the batch is hashed whole (no shallow tier)");
+    phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len,
+                        d_node_off, d_proof_first_node, n, d_status, nullptr, nullptr};
+    a.total_nodes = total_nodes;
+    phant::VerifyTune tune = c->tune;
+    tune.last_shallow = nullptr;
+    tune.last_form = nullptr;
+    tune.diag_sink = reinterpret_cast<uint32_t*>(c->dv.base + 4096);  // (header words nothing of these launches reads)
+    for (uint32_t what = 1; what <= 3u; ++what) {
+        tune.diag = what;
+        // (a warm-up, then `reps` back-to-back, events around them on the ctx stream)
+        HIP_TRY(c, phant::launch_mpt_verify(a, total_nodes, c->dv.base, c->dedup_levels, c->stream, &c->side, tune));
+        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        for (uint32_t k = 0; k < reps; ++k)
+            HIP_TRY(c, phant::launch_mpt_verify(a, total_nodes, c->dv.base, c->dedup_levels, c->stream, &c->side, tune));
+        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        out_ms[what - 1u] = ms / (float)reps;
+    }
+    return PHANT_OK;
+}
+
 int32_t phant_mpt_verify_verdict_dev(phant_ctx* c, const uint8_t* d_roots, uint32_t n_roots,
                                      const uint32_t* d_root_idx, const uint8_t* d_keys,
                                      uint32_t key_len, const uint8_t* d_nodes, uint64_t nodes_len,

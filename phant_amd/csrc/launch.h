@@ -82,6 +82,11 @@ struct VerifyTune {
     uint32_t coop_max = 2048;      // S = 0 form: batches of up to this many nodes take the node-per-half-wave hash kernel
     bool no_coop = false;
     uint32_t* last_form = nullptr; // diagnostics: 0 = S = 0, 1 = table form, 2 = ordered (own order), 3 = ordered (caller's order)
+    // diagnostics (phant_verify_bound_experiment), on a workspace a complete launch over the same witness has just left: 1 = only
+    // the hashing of that launch (deep tier + everything listed, next to each other), 2 = only a coalesced read of the witness's
+    // bytes (a clean stream with next to no VALU), 3 = both next to each other -- what the chip can overlap at best
+    uint32_t diag = 0;
+    uint32_t* diag_sink = nullptr;  // device words the read stream leaves its checksum in (so that the loads are not dead)
 };
 // stages of a two-tier launch, in the order of phant_verify_kernel_ms: the order pass (table form: propose_kernel), hash_deep,
 // heads_kernel (table form: nothing), the hashing of list set 0 (the group heads; table form: everything listed), the

@@ -129,6 +129,12 @@ PHANT_DEV uint64_t key_prefix64(const uint8_t* __restrict__ key, uint32_t key_le
     for (uint32_t t = 0; t < take; ++t) kb |= (uint64_t)key[t] << (56u - 8u * t);
     return kb;
 }
+// the same from one unaligned 8-byte load (keys of >= 8 bytes: every trie key of Ethereum is 32)
+PHANT_DEV uint64_t key_prefix64_wide(const uint8_t* __restrict__ key, uint32_t key_len) {
+    if (key_len < 8u) return key_prefix64(key, key_len);
+    struct __attribute__((packed, aligned(1))) U64u { unsigned long long v; };
+    return __builtin_bswap64(reinterpret_cast<const U64u*>(key)->v);
+}
 PHANT_DEV bool same_prefix(uint64_t x, uint64_t y, uint32_t d) { return d == 0u || ((x ^ y) >> (64u - 4u * d)) == 0ull; }
 // slot hash of (root, depth, first `d` key nibbles); murmur3 finaliser.
 PHANT_DEV uint64_t group_hash(uint64_t kb, uint32_t root, uint32_t d) {
@@ -171,9 +177,10 @@ struct Args {
     // the ordered form (key-bucketed neighbour comparison instead of the group tables)
     uint2* ent2;             // list set 1, N_LIST x STRIPES x stripe_cap2
     uint32_t stripe_cap2;
-    const uint32_t* ord;     // n: proof at position i of the order by (root,) key prefix; null: the caller's order IS that order
+    const struct PosInfo* pos;  // n records: what the ordered form needs to know about the proof at position i of the order
     const uint32_t* bstart;  // buckets + 1: first position of bucket b (ord given)
     uint32_t bucket_bits;    // a proof's bucket = the top bucket_bits bits of its key (ord given)
+    uint32_t dbg;            // EXPLORATION ONLY (PHANT_VERIFY_DBG): parts of compare_kernel switched off, for their cost
     uint32_t* hdr;           // header: HDR_*; cleared per call (propose_kernel / zero_kernel)
     uint32_t* digest;        // total_nodes x 8
     uint8_t* nstat;          // total_nodes: NS_* of the node, written by the lane that hashed it
@@ -481,37 +488,106 @@ constexpr uint32_t SCAN_TILE = 2048;
 
 PHANT_DEV uint32_t bucket_of(uint64_t kb, uint32_t bits) { return bits ? (uint32_t)(kb >> (64u - bits)) : 0u; }
 
+// What the kernels of the ordered form need to know about the proof at a position, in ONE 32-byte record per position: written
+// once by a lane that reads its proof's entries of the caller's arrays coalesced, read by consecutive lanes for consecutive
+// positions -- instead of every (position, level) lane of two kernels gathering the same five arrays through the order.
+struct PosInfo {
+    uint32_t p;      // the proof
+    uint32_t first;  // its first node
+    uint32_t end;    // its nodes a walk can reach (d < end: node first + d exists and is reachable); POS_BROKEN: the node range goes backwards
+    uint32_t root;   // its root index
+    uint32_t kb_lo, kb_hi;  // its first 8 key bytes, big-endian
+    uint32_t pad[2];
+};
+static_assert(sizeof(PosInfo) == 32, "two 16-byte loads");
+constexpr uint32_t POS_BROKEN = 0xffffffffu;
+PHANT_DEV PosInfo pos_info_of(const Args& a, uint32_t p, uint64_t kb) {
+    PosInfo r;
+    r.p = p;
+    r.first = 0;
+    r.end = 0;
+    r.root = a.v.root_idx ? a.v.root_idx[p] : 0u;
+    r.kb_lo = (uint32_t)kb;
+    r.kb_hi = (uint32_t)(kb >> 32);
+    r.pad[0] = r.pad[1] = 0u;
+    const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
+    if (last < first) {
+        r.end = POS_BROKEN;
+    } else if (last <= a.total_nodes) {  // (beyond: BAD_INPUT, the walk reports it)
+        const uint32_t nn = 2u * a.v.key_len, cnt = last - first;
+        r.first = first;
+        r.end = cnt <= nn ? cnt : nn + 1u;  // (a walk consumes >= one nibble per hashed node)
+    }
+    return r;
+}
+PHANT_DEV void store_pos_info(PosInfo* dst, const PosInfo& r) {
+    uint4* o = reinterpret_cast<uint4*>(dst);
+    o[0] = make_uint4(r.p, r.first, r.end, r.root);
+    o[1] = make_uint4(r.kb_lo, r.kb_hi, 0u, 0u);
+}
+PHANT_DEV PosInfo load_pos_info(const PosInfo* src) {
+    const uint4* i = reinterpret_cast<const uint4*>(src);
+    const uint4 x = i[0], y = i[1];
+    PosInfo r;
+    r.p = x.x; r.first = x.y; r.end = x.z; r.root = x.w;
+    r.kb_lo = y.x; r.kb_hi = y.y;
+    r.pad[0] = r.pad[1] = 0u;
+    return r;
+}
+PHANT_DEV uint64_t kb_of(const PosInfo& r) { return ((uint64_t)r.kb_hi << 32) | r.kb_lo; }
+
 // one lane per proof: how many proofs per bucket (bcnt zeroed by the launcher); the launch's clearing kernel
 __global__ void __launch_bounds__(256) order_hist_kernel(const Args a, uint32_t* bcnt) {
     beside_the_hashing();
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     clear_launch_state(a, p, (size_t)gridDim.x * 256u);
     if (p >= a.v.n) return;
-    atomicAdd(&bcnt[bucket_of(key_prefix64(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len), a.bucket_bits)], 1u);
+    atomicAdd(&bcnt[bucket_of(key_prefix64_wide(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len), a.bucket_bits)], 1u);
 }
 
-// bstart[b] = bcur[b] = proofs in buckets < b; bstart[buckets] = n.  One launch: workgroup w scans tile w (2 048 buckets) on top
-// of the sum of everything in front of it, which it adds up itself (<= 62 coalesced 16-byte loads per lane out of L2).
-__global__ void __launch_bounds__(256) order_scan_kernel(const uint32_t* __restrict__ bcnt, uint32_t* __restrict__ bstart,
-                                                         uint32_t* __restrict__ bcur, uint32_t buckets, uint32_t n) {
-    __shared__ uint32_t s_wave[4], s_wave2[4];
+// bstart[b] = bcur[b] = proofs in buckets < b; bstart[buckets] = n.  Two launches: the tiles' sums (2 048 buckets per
+// workgroup), then every tile's own scan on top of the sums in front of it (<= 32 of them: one load, one wave sum).
+__global__ void __launch_bounds__(256) order_sums_kernel(const uint32_t* __restrict__ bcnt, uint32_t* __restrict__ sums, uint32_t buckets) {
+    __shared__ uint32_t s_wave[4];
     beside_the_hashing();
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t tile0 = blockIdx.x * SCAN_TILE;
-    uint32_t before = 0;
-    for (uint32_t i = 4u * tid; i < tile0; i += 1024u) {  // (tile0 is a multiple of 2 048)
-        const uint4 v = *reinterpret_cast<const uint4*>(bcnt + i);
-        before += v.x + v.y + v.z + v.w;
+    const uint32_t at = blockIdx.x * SCAN_TILE + 8u * tid;
+    uint32_t mine = 0;
+    if (at + 8u <= buckets) {
+        const uint4 x = *reinterpret_cast<const uint4*>(bcnt + at), y = *reinterpret_cast<const uint4*>(bcnt + at + 4u);
+        mine = x.x + x.y + x.z + x.w + y.x + y.y + y.z + y.w;
+    } else {
+        for (uint32_t k = 0; k < 8u; ++k) mine += at + k < buckets ? bcnt[at + k] : 0u;
     }
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t up = __shfl_up(mine, o, 64);
+        if (lane >= o) mine += up;
+    }
+    if (lane == 63u) s_wave[wave] = mine;
+    __syncthreads();
+    if (tid == 0) sums[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+__global__ void __launch_bounds__(256) order_scan_kernel(const uint32_t* __restrict__ bcnt, const uint32_t* __restrict__ sums,
+                                                         uint32_t* __restrict__ bstart, uint32_t* __restrict__ bcur, uint32_t buckets, uint32_t n) {
+    __shared__ uint32_t s_wave[4];
+    beside_the_hashing();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    static_assert((1u << ORDER_MAX_BITS) / SCAN_TILE <= 64u, "the tiles in front of one fit a wave");
+    uint32_t before = lane < blockIdx.x ? sums[lane] : 0u;  // (every wave: no barrier for it)
     for (uint32_t o = 1; o < 64u; o <<= 1) {
         const uint32_t up = __shfl_up(before, o, 64);
         if (lane >= o) before += up;
     }
-    if (lane == 63u) s_wave[wave] = before;
+    before = (uint32_t)__shfl((int)before, 63, 64);
     uint32_t v[8];
-    const uint32_t at = tile0 + 8u * tid;
+    const uint32_t at = blockIdx.x * SCAN_TILE + 8u * tid;
+    if (at + 8u <= buckets) {
+        const uint4 x = *reinterpret_cast<const uint4*>(bcnt + at), y = *reinterpret_cast<const uint4*>(bcnt + at + 4u);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+    } else {
 #pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k) v[k] = at + k < buckets ? bcnt[at + k] : 0u;
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = at + k < buckets ? bcnt[at + k] : 0u;
+    }
     uint32_t mine = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 8u; ++k) mine += v[k];
@@ -520,10 +596,10 @@ __global__ void __launch_bounds__(256) order_scan_kernel(const uint32_t* __restr
         const uint32_t up = __shfl_up(inc, o, 64);
         if (lane >= o) inc += up;
     }
-    if (lane == 63u) s_wave2[wave] = inc;
+    if (lane == 63u) s_wave[wave] = inc;
     __syncthreads();
-    uint32_t run = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3] + inc - mine;
-    for (uint32_t w = 0; w < wave; ++w) run += s_wave2[w];
+    uint32_t run = before + inc - mine;
+    for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
 #pragma unroll
     for (uint32_t k = 0; k < 8u; ++k) {
         if (at + k < buckets) {
@@ -535,19 +611,23 @@ __global__ void __launch_bounds__(256) order_scan_kernel(const uint32_t* __restr
     if (blockIdx.x == 0 && tid == 0) bstart[buckets] = n;
 }
 
-// one lane per proof: its position in the order
-__global__ void __launch_bounds__(256) order_scatter_kernel(const Args a, uint32_t* bcur, uint32_t* ord) {
+// one lane per proof: its position in the order, and the position's record
+__global__ void __launch_bounds__(256) order_scatter_kernel(const Args a, uint32_t* bcur, PosInfo* pos) {
     beside_the_hashing();
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= a.v.n) return;
-    const uint32_t b = bucket_of(key_prefix64(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len), a.bucket_bits);
-    ord[atomicAdd(&bcur[b], 1u)] = p;
+    const uint64_t kb = key_prefix64_wide(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len);
+    const PosInfo r = pos_info_of(a, p, kb);
+    store_pos_info(pos + atomicAdd(&bcur[bucket_of(kb, a.bucket_bits)], 1u), r);
 }
 
-// the launch's clearing kernel when the caller's order is taken as it is (no order pass)
-__global__ void __launch_bounds__(256) clear_kernel(const Args a) {
+// the caller's order taken as it is (no order pass): position = proof.  Also the launch's clearing kernel.
+__global__ void __launch_bounds__(256) order_identity_kernel(const Args a, PosInfo* pos) {
     beside_the_hashing();
-    clear_launch_state(a, blockIdx.x * 256u + threadIdx.x, (size_t)gridDim.x * 256u);
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    clear_launch_state(a, p, (size_t)gridDim.x * 256u);
+    if (p >= a.v.n) return;
+    store_pos_info(pos + p, pos_info_of(a, p, key_prefix64_wide(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len)));
 }
 
 // (root, first d key nibbles) of two proofs equal?  (the key prefixes zero-padded: key_len is one per batch)
@@ -555,12 +635,33 @@ PHANT_DEV bool same_key_group(uint32_t root_x, uint64_t kb_x, uint32_t root_y, u
     return root_x == root_y && same_prefix(kb_x, kb_y, d);
 }
 // Does position i open a run at level d?  The rule both kernels of the ordered form evaluate, on the keys alone.
-PHANT_DEV bool key_head(const Args& a, uint32_t i, uint32_t d, uint32_t root, uint64_t kb) {
+// `me`, `prev`: the records of positions i and i - 1 (prev: anything for i = 0).
+PHANT_DEV bool key_head(const Args& a, uint32_t i, uint32_t d, const PosInfo& me, const PosInfo& prev) {
     if (i == 0u) return true;
-    if (!a.ord && i % CHUNK == 0u) return true;  // (no bucket table to find a run's head through: every chunk opens its own)
-    const uint32_t pp = a.ord ? a.ord[i - 1u] : i - 1u;
-    const uint32_t rp = a.v.root_idx ? a.v.root_idx[pp] : 0u;
-    return !same_key_group(rp, key_prefix64(a.v.keys + (uint64_t)a.v.key_len * pp, a.v.key_len), root, kb, d);
+    if (!a.bstart && i % CHUNK == 0u) return true;  // (no bucket table to find a run's head through: every chunk opens its own)
+    return !same_key_group(prev.root, kb_of(prev), me.root, kb_of(me), d);
+}
+// the node of level d of the proof at a position, as shallow_node() describes it
+PHANT_DEV ShallowLane ordered_node(const Args& a, const PosInfo& r, uint32_t d) {
+    ShallowLane L;
+    L.p = r.p;
+    L.d = d;
+    L.j = 0;
+    L.root = r.root;
+    L.len = 0;
+    L.kb = kb_of(r);
+    L.act = L.valid = L.group = false;
+    L.broken = r.end == POS_BROKEN && d == 0u;
+    if (r.end == POS_BROKEN || d >= r.end) return L;
+    L.act = true;
+    L.j = r.first + d;
+    const uint64_t e = a.v.node_off[L.j + 1], b = a.v.node_off[L.j];
+    if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
+        L.valid = true;
+        L.len = (uint32_t)(e - b);
+    }
+    L.group = L.valid && L.len >= RATE && L.root < a.v.n_roots;
+    return L;
 }
 
 // appends the lanes' nodes (cls != CLASS_NONE) to the class lists of `set`, compacted over the workgroup: one reservation per
@@ -607,16 +708,11 @@ __global__ void __launch_bounds__(256) heads_kernel(const Args a) {
     const uint32_t i = g / a.shallow, d = g - i * a.shallow;
     uint32_t cls = CLASS_NONE, j = 0, p = 0;
     if (i < a.v.n) {
-        p = a.ord ? a.ord[i] : i;
-        if (p < a.v.n) {  // (whatever the order array holds)
-            ShallowLane L = shallow_node(a, p, d);
-            j = L.j;
-            if (L.act && L.valid) {
-                bool listed = !takes_part(L);
-                if (!listed) listed = key_head(a, i, d, L.root, L.kb);
-                if (listed) cls = node_list(L.len);
-            }
-        }
+        const PosInfo me = load_pos_info(a.pos + i), prev = load_pos_info(a.pos + (i ? i - 1u : 0u));
+        p = me.p;
+        const ShallowLane L = ordered_node(a, me, d);
+        j = L.j;
+        if (L.act && L.valid && (!takes_part(L) || key_head(a, i, d, me, prev))) cls = node_list(L.len);
     }
     list_append<0>(a, cls, j, p, s_cnt, s_base);
 }
@@ -630,48 +726,44 @@ __global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const A
     if (tid < 4u * N_LIST) (&s_cnt[0][0])[tid] = 0u;
     const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (tid >> 6));
     const uint32_t chunk = unit / a.shallow, d = unit - chunk * a.shallow;
-    const uint32_t i = chunk * CHUNK + lane - 1u;  // the lane's position (lanes >= 1)
+    // the lane's position; lane 0 looks at lane 1's: it carries the node that position's run continues, if it is not a head itself
+    const uint32_t i = chunk * CHUNK + (lane ? lane - 1u : 0u);
 
     // ---- what the lane's position is: meta = len (<= 768) | takes part | opens a run ----
     enum : uint32_t { M_LEN = 0xffffu, M_PART = 1u << 16, M_HEAD = 1u << 17 };
-    uint32_t meta = 0, j = 0, p = 0, root = 0, len = 0;
-    uint64_t b = 0, kb = 0;
+    uint32_t meta = 0, j = 0, p = 0, len = 0;
+    uint64_t b = 0;
     bool real = false, act = false;
-    if (chunk < chunks && lane >= 1u && i < a.v.n) {
-        p = a.ord ? a.ord[i] : i;
-        if (p < a.v.n) {  // (whatever the order array holds)
-            const ShallowLane L = shallow_node(a, p, d);
+    if (chunk < chunks && i < a.v.n) {
+        const PosInfo me = load_pos_info(a.pos + i), prev = load_pos_info(a.pos + (i ? i - 1u : 0u));
+        const ShallowLane L = ordered_node(a, me, d);
+        p = me.p;
+        j = L.j;
+        len = L.len;
+        if (key_head(a, i, d, me, prev)) meta |= M_HEAD;
+        if (takes_part(L)) {
+            meta |= M_PART | L.len;
+            b = a.v.node_off[j];
+        }
+        if (lane >= 1u) {
             real = true;
             act = L.act;
-            j = L.j;
-            len = L.len;
             if (L.broken) a.hdr[HDR_PFN_BROKEN] = 1u;  // (node ranges of other proofs may overlap: the walk trusts nothing then)
             if (L.act && !L.valid) a.nstat[j] = 0u;     // never hashed: says so (nobody else writes this node's state)
-            root = a.v.root_idx ? a.v.root_idx[p] : 0u;
-            kb = key_prefix64(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len);
-            if (key_head(a, i, d, root, kb)) meta |= M_HEAD;
-            if (takes_part(L)) {
-                meta |= M_PART | L.len;
-                b = a.v.node_off[j];
-            }
-        }
-    }
-    // ---- lane 0: the node the chunk's first run continues -- the key head of position 1's group, through the bucket table ----
-    {
-        const uint32_t m1 = (uint32_t)__shfl((int)meta, 1, 64), r1 = (uint32_t)__shfl((int)root, 1, 64);
-        const uint32_t k1lo = (uint32_t)__shfl((int)(uint32_t)kb, 1, 64), k1hi = (uint32_t)__shfl((int)(uint32_t)(kb >> 32), 1, 64);
-        if (lane == 0u && a.ord && (m1 & M_PART) && !(m1 & M_HEAD) && 4u * d <= a.bucket_bits) {
-            const uint64_t kb1 = ((uint64_t)k1hi << 32) | k1lo;
-            const uint32_t sh = a.bucket_bits - 4u * d;
-            const uint32_t gs = a.bstart[(bucket_of(kb1, a.bucket_bits) >> sh) << sh];
-            if (gs < chunk * CHUNK) {  // (in front of this chunk: a head inside it is met on the way)
-                const uint32_t h = a.ord[gs];
-                if (h < a.v.n) {
-                    const ShallowLane L = shallow_node(a, h, d);
+        } else {
+            // the key head of position 1's group, through the bucket table
+            const bool wanted = a.bstart && (meta & M_PART) && !(meta & M_HEAD) && 4u * d <= a.bucket_bits && !(a.dbg & 2u);
+            meta = 0;
+            if (wanted) {
+                const uint32_t sh = a.bucket_bits - 4u * d;
+                const uint32_t gs = a.bstart[(bucket_of(L.kb, a.bucket_bits) >> sh) << sh];
+                if (gs < i) {  // (in front of this chunk: a head inside it is met on the way)
+                    const PosInfo h = load_pos_info(a.pos + gs), hprev = load_pos_info(a.pos + (gs ? gs - 1u : 0u));
+                    const ShallowLane H = ordered_node(a, h, d);
                     // usable only if it is what heads_kernel lists: a node that takes part, of this group, opening its run
-                    if (takes_part(L) && same_key_group(L.root, L.kb, r1, kb1, d) && key_head(a, gs, d, L.root, L.kb)) {
-                        meta = M_PART | M_HEAD | L.len;
-                        j = L.j;
+                    if (takes_part(H) && same_key_group(H.root, H.kb, L.root, L.kb, d) && key_head(a, gs, d, h, hprev)) {
+                        meta = M_PART | M_HEAD | H.len;
+                        j = H.j;
                         b = a.v.node_off[j];
                     }
                 }
@@ -685,7 +777,7 @@ __global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const A
     uint32_t my_ref = 64u;  // the lane whose node this lane's node is a copy of (64: none)
     bool late = false;      // differs from its run's reference (or found none): to be hashed, says this kernel
     const unsigned long long parts = __ballot((meta & M_PART) != 0u);
-    if (parts) {
+    if (parts && !(a.dbg & 1u)) {
         const uint32_t last = 63u - (uint32_t)__builtin_clzll(parts);  // (nothing to do behind the last node that takes part)
         U32x3 ref{0u, 0u, 0u};
         uint32_t ref_len = 0, ref_lane = 64u;
@@ -736,6 +828,7 @@ __global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const A
     // ---- results: the representative of every node, and what is left to hash ----
     const uint32_t rj = (uint32_t)__shfl((int)j, (int)(my_ref & 63u), 64);
     if (real && act) a.rep[j] = my_ref < 64u ? rj : j;
+    if (a.dbg & 4u) return;
     list_append<1>(a, (real && late) ? node_list(len) : CLASS_NONE, j, p, s_cnt, s_base);
 }
 
@@ -817,20 +910,20 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 // single-wave speed.  With the ladder a wave that is behind outranks the ones ahead: they advance block by block
 // together and finish together (profiles/EXPERIMENTS.md: ladders measured).
 template <bool LADDER>
-PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
+PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p, const bool noperm = false /* EXPLORATION */) {
     sponge_zero(s);
     if (LADDER) __builtin_amdgcn_s_setprio(2);
     uint32_t bad = absorb_b532_block<0, 34>(s, p);
-    keccak_f1600(s);
+    if (!noperm) keccak_f1600(s);
     if (LADDER) __builtin_amdgcn_s_setprio(1);
     bad |= absorb_b532_block<1, 34>(s, p + RATE);
-    keccak_f1600(s);
+    if (!noperm) keccak_f1600(s);
     if (LADDER) __builtin_amdgcn_s_setprio(1);
     bad |= absorb_b532_block<2, 34>(s, p + 2u * RATE);
-    keccak_f1600(s);
+    if (!noperm) keccak_f1600(s);
     if (LADDER) __builtin_amdgcn_s_setprio(0);
     bad |= absorb_b532_block<3, 31>(s, p + 3u * RATE);
-    keccak_f1600(s);
+    if (!noperm) keccak_f1600(s);
     return bad;
 }
 
@@ -1066,7 +1159,7 @@ PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, c
         const bool is532 = active && len == BRANCH_LEN;
         if (roomy && __ballot(is532) != 0ull) {
             // the lanes with a 532-byte node (the others run along on a readable address: the blob's first bytes)
-            const uint32_t bad = hash_b532<true>(s, is532 ? ptr : a.v.nodes);
+            const uint32_t bad = hash_b532<true>(s, (is532 && !(a.dbg & 8u)) ? ptr : a.v.nodes, (a.dbg & 16u) != 0u);
             if (is532 && bad == 0u) flags |= F_CANON;
         }
         const bool rest = active && !(roomy && is532);
@@ -1564,6 +1657,36 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
     }
 }
 
+// ---------------------------------------------------------------- diagnostics: a clean read stream
+// The witness's bytes, coalesced, 16 bytes per lane, eight loads in flight per lane, XORed into one word per workgroup:
+// what the memory system can deliver when nothing but ~60 VALU instructions per KB stands in the way.
+__global__ void __launch_bounds__(256) stream_read_kernel(const uint4* __restrict__ p, size_t n16, uint32_t* sink) {
+    const size_t stride = (size_t)gridDim.x * 256u;
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+    for (; i + 7u * stride < n16; i += 8u * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[i + (size_t)u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc.x ^= v[u].x;
+            acc.y ^= v[u].y;
+            acc.z ^= v[u].z;
+            acc.w ^= v[u].w;
+        }
+    }
+    for (; i < n16; i += stride) {
+        const uint4 v = p[i];
+        acc.x ^= v.x;
+        acc.y ^= v.y;
+        acc.z ^= v.z;
+        acc.w ^= v.w;
+    }
+    const uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (x == 0x9e3779b9u && sink) sink[blockIdx.x & 255u] = x;  // (never, in effect: the result only has to be wanted)
+}
+
 // ---------------------------------------------------------------- node-set witnesses
 // A witness that ships every node ONCE, in any order (what a block builder that deduplicates its proofs
 // sends): references are resolved by hash.  Hash every node (classify_kernel + hash_set_kernel, nothing to
@@ -1810,7 +1933,7 @@ static uint32_t table_entries(uint32_t n, uint32_t n_roots, uint32_t direct, uin
 }
 
 struct Layout {
-    size_t nstat, dtab, table, rep, ent, digest, ord, bcnt, bstart, bcur, ent2, end;
+    size_t nstat, dtab, table, rep, ent, digest, pos, bcnt, bstart, bcur, bsums, ent2, end;
     uint32_t stripe_cap, stripe_cap2;
 };
 // lanes of the comparison kernel of the ordered form: a wave per (chunk of CHUNK positions, level)
@@ -1834,10 +1957,11 @@ static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries,
     l.ent = p;    p += rnd256(striped > tn * 8 * N_LIST ? striped : tn * 8 * N_LIST);
     l.digest = p; p += rnd256(tn * 32);
     const size_t buckets = ord_n ? (size_t)1 << ORDER_MAX_BITS : 0;
-    l.ord = p;    p += rnd256((size_t)ord_n * 4);
+    l.pos = p;    p += rnd256((size_t)ord_n * sizeof(PosInfo));
     l.bcnt = p;   p += rnd256(buckets * 4);
     l.bstart = p; p += rnd256((buckets + 1) * 4);
     l.bcur = p;   p += rnd256(buckets * 4);
+    l.bsums = p;  p += rnd256(ord_n ? 256 : 0);
     l.ent2 = p;   p += rnd256((size_t)N_LIST * STRIPES * l.stripe_cap2 * 8u);
     l.end = p + 1024;
     return l;
@@ -1865,9 +1989,10 @@ static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
     a.digest = reinterpret_cast<uint32_t*>(ws + l.digest);
     a.ent2 = reinterpret_cast<uint2*>(ws + l.ent2);
     a.stripe_cap2 = l.stripe_cap2;
-    a.ord = nullptr;
+    a.pos = nullptr;
     a.bstart = nullptr;
     a.bucket_bits = 0;
+    a.dbg = std::getenv("PHANT_VERIFY_DBG") ? (uint32_t)std::atoi(std::getenv("PHANT_VERIFY_DBG")) : 0u;
 }
 
 }  // namespace v3
@@ -1900,7 +2025,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     const uint32_t te = table_entries(v.n, v.n_roots, a.direct, a.shallow, total_nodes);
     const uint64_t lanes = (uint64_t)v.n * a.shallow;
     const uint64_t units = ordered ? compare_units(v.n, a.shallow) : 0u;
-    const Layout l = layout(total_nodes, te, direct_entries, lanes, own_order ? v.n : 0u, units);
+    const Layout l = layout(total_nodes, te, direct_entries, lanes, ordered ? v.n : 0u, units);
     bind(a, ws, l, te);
     hipError_t e = hipSuccess;
     const uint32_t pg = (v.n + 255u) / 256u;
@@ -1948,6 +2073,35 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     auto mark = [&](int i) {
         if (kev && e == hipSuccess) e = hipEventRecord(kev[i], st);
     };
+    const bool three = two && side->stream2 && side->sorted && side->join2;
+    hipStream_t h2 = three ? side->stream2 : st;
+    if (tune.diag) {
+        // the workspace holds what a complete launch over this witness left (lists, counts): its hashing alone, a clean read of
+        // its bytes alone, or both next to each other -- the deep tier uncapped when nothing memory-bound runs beside it
+        if (two) {
+            if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
+            if (three && (e = hipStreamWaitEvent(side->stream2, side->fork, 0)) != hipSuccess) return e;
+        }
+        const uint32_t lds = tune.diag == 3u ? hash_lds : 0u;
+        if (tune.diag & 1u) {
+            hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), lds, hs, a, wpl, deep_levels);
+            hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), lds ? lds + 8192u : 0u, st, a);
+            if (ordered) hipLaunchKernelGGL(hash_list_kernel<1>, dim3(list_wgs < 256u ? list_wgs : 256u), dim3(256), 0, st, a);
+        }
+        if (tune.diag & 2u)
+            hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, h2, reinterpret_cast<const uint4*>(v.nodes),
+                               (size_t)(v.nodes_len / 16u), tune.diag_sink);
+        if (two) {
+            if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
+            if (three) {
+                if ((e = hipEventRecord(side->join2, side->stream2)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(st, side->join2, 0)) != hipSuccess) return e;
+            }
+        }
+        return hipGetLastError();
+    }
     if (!ordered) {
         // (propose_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep
         // role's waves fill every slot they are given the moment they start)
@@ -1970,27 +2124,27 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         return hipGetLastError();
     }
     // ---- ordered form ----
-    const bool three = two && side->stream2 && side->sorted && side->join2;
-    hipStream_t h2 = three ? side->stream2 : st;
     mark(0);
+    PosInfo* const pos = reinterpret_cast<PosInfo*>(ws + l.pos);
+    a.pos = pos;
     if (own_order) {
         a.bucket_bits = 4u * (a.shallow - 1u) < ORDER_MAX_BITS ? 4u * (a.shallow - 1u) : ORDER_MAX_BITS;
-        const uint32_t buckets = 1u << a.bucket_bits;
+        const uint32_t buckets = 1u << a.bucket_bits, tiles = (buckets + SCAN_TILE - 1u) / SCAN_TILE;
         uint32_t* const bcnt = reinterpret_cast<uint32_t*>(ws + l.bcnt);
         uint32_t* const bstart = reinterpret_cast<uint32_t*>(ws + l.bstart);
         uint32_t* const bcur = reinterpret_cast<uint32_t*>(ws + l.bcur);
-        uint32_t* const ord = reinterpret_cast<uint32_t*>(ws + l.ord);
+        uint32_t* const bsums = reinterpret_cast<uint32_t*>(ws + l.bsums);
         if ((e = hipMemsetAsync(bcnt, 0, (size_t)buckets * 4u, st)) != hipSuccess) return e;
         // (the first kernel of the chain is handed to the device first, then the deep role, whose waves fill every slot they are
         // given the moment they start; with the tiers serialised for per-stage times the deep role runs behind the order pass)
         hipLaunchKernelGGL(order_hist_kernel, dim3(pg), dim3(256), 0, st, a, bcnt);
         if (!kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
-        hipLaunchKernelGGL(order_scan_kernel, dim3((buckets + SCAN_TILE - 1u) / SCAN_TILE), dim3(256), 0, st, bcnt, bstart, bcur, buckets, v.n);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(pg), dim3(256), 0, st, a, bcur, ord);
-        a.ord = ord;
+        if (tiles > 1u) hipLaunchKernelGGL(order_sums_kernel, dim3(tiles), dim3(256), 0, st, bcnt, bsums, buckets);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(tiles), dim3(256), 0, st, bcnt, bsums, bstart, bcur, buckets, v.n);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(pg), dim3(256), 0, st, a, bcur, pos);
         a.bstart = bstart;
     } else {
-        hipLaunchKernelGGL(clear_kernel, dim3(4), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(order_identity_kernel, dim3(pg), dim3(256), 0, st, a, pos);
         if (!kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
     }
     mark(1);
@@ -2004,7 +2158,11 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     // the group heads: listed from the keys alone and hashed NEXT TO the comparison
     hipLaunchKernelGGL(heads_kernel, dim3(sg), dim3(256), 0, h2, a);
     mark(3);
-    hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, h2, a);
+    {
+        static const int list_kb = std::getenv("PHANT_LIST_LDS_KB") ? std::atoi(std::getenv("PHANT_LIST_LDS_KB")) : -1;  // EXPLORATION
+        const uint32_t list_lds = list_kb >= 0 ? (uint32_t)list_kb * 1024u : (hash_lds ? hash_lds + 8192u : 0u);
+        hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), two ? list_lds : 0u, h2, a);
+    }
     mark(4);
     if (three && (e = hipEventRecord(side->join2, side->stream2)) != hipSuccess) return e;
     const uint32_t cg = (uint32_t)((units + 3u) / 4u);
