@@ -86,14 +86,15 @@ typedef struct phant_ctx phant_ctx;
  * batch (byte-compares copies instead of hashing them); deeper nodes are hashed in place.  Default (field 0):
  * chosen from the batch -- none for batches of less than 72 MB of nodes (the chip hashes those whole in a few rounds
  * of waves), otherwise the levels with fewer groups than proofs.  Correctness does not depend on it. */
-#define PHANT_CTX_VERIFY_KEY_ORDERED 8u /* flags: the caller's word that every batch lists its proofs in (root index, key)
-                                          order -- as a witness producer that walks the tries emits them.  The verifier then
-                                          finds byte-identical copies of the upper trie levels among NEIGHBOURS for batches
-                                          against any number of roots (for one root it orders the proofs itself and needs no
-                                          such promise).  Nothing is trusted: an unordered batch is verified just the same, with
-                                          less deduplication (more hashing).  INTEGRATION.md section 5 */
-#define PHANT_CTX_VERIFY_TABLE 16u /* flags (A/B): the two-tier pipeline finds the copies of the upper trie levels through its
-                                     group tables whatever the batch (the form every batch took before the ordered one) */
+#define PHANT_CTX_VERIFY_KEY_ORDERED 8u /* flags (A/B): the caller's word that every batch lists its proofs in (root index, key)
+                                          order -- as a witness producer that walks the tries emits them.  The two-tier pipeline
+                                          then finds the byte-identical copies of the upper trie levels among NEIGHBOURS (the
+                                          "ordered form": every copy read once, the group heads hashed next to the comparison)
+                                          instead of through its group tables.  Nothing is trusted: an unordered batch is
+                                          verified just the same, with less deduplication (more hashing).  Measured on MI355X:
+                                          slower than the tables at every batch size (profiles/r5_explore/NOTES.md), hence A/B */
+#define PHANT_CTX_VERIFY_ORDERED 16u   /* flags (A/B): the ordered form for batches against ONE root, on the library's own order
+                                          (a counting sort on the top key bits in front of the comparison) */
 #define PHANT_CTX_DEDUP_LEVELS_SHIFT 8
 #define PHANT_CTX_DEDUP_LEVELS_MASK 0x1f00u
 #define PHANT_CTX_DEDUP_LEVELS(n) ((((uint32_t)(n) + 1u) << PHANT_CTX_DEDUP_LEVELS_SHIFT) & PHANT_CTX_DEDUP_LEVELS_MASK)

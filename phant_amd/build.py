@@ -18,8 +18,8 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libphant_gpu.so")
 SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v3.hip", "trie_build.hip", "state_root.hip", "radix_sort.hip", "capi.hip", "comm.hip",
            "witness_json.cpp", "host_rlp.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-fvisibility=hidden", "-fno-exceptions",
-         "-Wall", "-Wno-unused-function"]
+# (host exceptions ON: the generated extern "C" wrappers -- csrc/capi_guard_*.inc -- turn a std::bad_alloc into PHANT_E_OOM)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:
@@ -42,6 +42,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     hipcc = _hipcc()
+    # the extern "C" wrappers of the C-ABI, generated from the header
+    gen = os.path.join(os.path.dirname(_HERE), "tools", "gen_capi_guard.py")
+    r = subprocess.run([sys.executable, gen], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode:
+        raise RuntimeError(f"gen_capi_guard.py failed:\n{r.stdout}")
     objs = []
     obj_dir = os.path.join(_HERE, "build")
     os.makedirs(obj_dir, exist_ok=True)

@@ -17,7 +17,7 @@ class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
     def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
-                 verify_nodedup: bool = False, dedup_levels: int | None = None, key_ordered: bool = False, verify_table: bool = False):
+                 verify_nodedup: bool = False, dedup_levels: int | None = None, key_ordered: bool = False, verify_ordered: bool = False):
         """use_torch_stream: the ctx works on torch's current stream of the device (its launches are ordered with the torch
         operations around them: the default, and what every mirror function that takes or returns a tensor assumes).  False:
         a private stream -- device-form calls are then asynchronous on THAT stream and not ordered with torch's; the caller
@@ -40,8 +40,8 @@ class Context:
             flags |= 2  # PHANT_CTX_VERIFY_FUSED
         if verify_nodedup:
             flags |= 4  # PHANT_CTX_VERIFY_NODEDUP
-        if verify_table:
-            flags |= 16  # PHANT_CTX_VERIFY_TABLE (A/B: the shallow tier through its group tables whatever the batch)
+        if verify_ordered:
+            flags |= 16  # PHANT_CTX_VERIFY_ORDERED (A/B: one root: the ordered form on the library's own order)
         if key_ordered:
             flags |= 8  # PHANT_CTX_VERIFY_KEY_ORDERED: every batch lists its proofs in (root index, key) order
         if dedup_levels is not None:

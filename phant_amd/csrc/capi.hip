@@ -117,7 +117,22 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 }  // namespace
 
-extern "C" {
+// The functions of include/phant_gpu.h are implemented in namespace phant_impl; the exported `extern "C"` symbols are generated
+// wrappers (capi_guard_capi.inc, tools/gen_capi_guard.py) that call them inside a try block: host memory running out in a
+// std::vector / std::string comes back as PHANT_E_OOM, nothing unwinds or aborts across the C boundary.
+namespace phant_impl {
+int32_t guard_failed(phant_ctx* c, int32_t code) noexcept {
+    if (c) {
+        try {
+            c->err = code == PHANT_E_OOM ? "out of host memory" : "unexpected exception";
+        } catch (...) {
+        }
+    }
+    return code;
+}
+}  // namespace phant_impl
+
+namespace phant_impl {
 
 const char* phant_version(void) { return "phant_gpu 0.1 (gfx950)"; }
 
@@ -166,9 +181,9 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         c->tune.hash_lds = (uint32_t)(kb < 0 ? 0 : kb > 47 ? 47 : kb) * 1024u;
     }
     if (const char* t = std::getenv("PHANT_VERIFY_SERIAL")) c->tune.serial = t[0] == '1';
-    // the shallow tier's form (A/B): through the group tables whatever the batch; the caller's proofs are in (root, key) order
-    c->tune.table_form = opts && (opts->flags & PHANT_CTX_VERIFY_TABLE);
-    if (const char* t = std::getenv("PHANT_VERIFY_TABLE")) c->tune.table_form = t[0] == '1';
+    // the shallow tier's form (A/B): one of the ordered forms instead of the group tables
+    c->tune.own_order = opts && (opts->flags & PHANT_CTX_VERIFY_ORDERED);
+    if (const char* t = std::getenv("PHANT_VERIFY_ORDERED")) c->tune.own_order = t[0] == '1';
     c->tune.key_ordered = opts && (opts->flags & PHANT_CTX_VERIFY_KEY_ORDERED);
     if (const char* t = std::getenv("PHANT_VERIFY_KEY_ORDERED")) c->tune.key_ordered = t[0] == '1';
     // the S = 0 form's node-per-half-wave kernel (A/B): never / up to this many nodes
@@ -416,7 +431,7 @@ int32_t phant_keccak256_batch(phant_ctx* c, const uint8_t* blob, const uint64_t*
 
 int32_t phant_keccak256(phant_ctx* c, const uint8_t* data, uint64_t len, uint8_t out[32]) {
     const uint64_t off[2] = {0, len};
-    return phant_keccak256_batch(c, data, off, 1, out);
+    return phant_impl::phant_keccak256_batch(c, data, off, 1, out);
 }
 
 int32_t phant_keccak256_with_prefix(phant_ctx* c, const uint8_t* prefix, uint64_t prefix_len,
@@ -430,7 +445,7 @@ int32_t phant_keccak256_with_prefix(phant_ctx* c, const uint8_t* prefix, uint64_
     if (prefix_len) std::memcpy(cat, prefix, (size_t)prefix_len);
     if (len) std::memcpy(cat + prefix_len, data, (size_t)len);
     const uint64_t off[2] = {0, prefix_len + len};
-    const int32_t rc = phant_keccak256_batch(c, cat, off, 1, out);
+    const int32_t rc = phant_impl::phant_keccak256_batch(c, cat, off, 1, out);
     std::free(cat);
     return rc;
 }
@@ -701,7 +716,7 @@ int32_t phant_verify_bound_experiment(phant_ctx* c, const uint8_t* d_roots, uint
     if (c->verify_fused || c->tune.serial) return fail(c, PHANT_E_UNSUPPORTED, "bound_experiment: needs the two-tier pipeline with its tiers next to each other");
     if (((uintptr_t)d_nodes & 15u) != 0) return fail(c, PHANT_E_INVALID_ARG, "bound_experiment: the node blob must be 16-byte aligned");
     // one complete launch: its lists and counts are what the hashing-only launches below work from
-    int32_t rc = phant_mpt_verify_batch_dev(c, d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len, d_node_off,
+    int32_t rc = phant_impl::phant_mpt_verify_batch_dev(c, d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len, d_node_off,
                                             total_nodes, d_proof_first_node, n, d_status, nullptr, nullptr);
     if (rc) return rc;
     DeviceGuard g(c->device);
@@ -844,7 +859,7 @@ int32_t phant_mpt_verify_nodeset(phant_ctx* c, const uint8_t* roots, uint32_t n_
     if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
     if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nodes_len, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_noff, node_off, ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
-    rc = phant_mpt_verify_nodeset_dev(c, d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
+    rc = phant_impl::phant_mpt_verify_nodeset_dev(c, d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
                                       d_noff, total_nodes, n, d_status, d_voff, d_vlen);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
@@ -908,7 +923,7 @@ int32_t phant_wait(phant_ctx* c, uint32_t slot) {
     return PHANT_OK;
 }
 
-}  // extern "C"
+}  // namespace phant_impl
 
 /* ------------------------------------------------- internal: what comm.hip (several devices in one process) builds on */
 namespace phant {
@@ -921,10 +936,10 @@ int32_t ctx_verify_host_async_verdict(phant_ctx* c, const uint8_t* roots, uint32
                                       uint8_t* status, uint64_t* value_off, uint32_t* value_len, uint32_t** d_fail) {
     DeviceGuard g(c->device);
     {
-        const int32_t src = ensure_side(c);
+        const int32_t src = phant_impl::ensure_side(c);
         if (src) return src;
     }
-    return verify_host_async(c, c->stream, c->ws.io, c->dv, &c->side, false, roots, n_roots, root_idx, keys, key_len, nodes,
+    return phant_impl::verify_host_async(c, c->stream, c->ws.io, c->dv, &c->side, false, roots, n_roots, root_idx, keys, key_len, nodes,
                              nodes_len, node_off, proof_first_node, n, status, value_off, value_len, d_fail);
 }
 // a device array of n_roots zeroed counters owned by the ctx (a rank without proofs still takes part in the reduction)
@@ -941,7 +956,7 @@ int ctx_device(const phant_ctx* c) { return c->device; }
 
 }  // namespace phant
 
-extern "C" {
+namespace phant_impl {
 
 /* ------------------------------------------------------------------ block witness */
 
@@ -1232,7 +1247,7 @@ int32_t phant_block_roots(phant_ctx* c, const uint8_t* const* items, const uint6
     }
     if (bloom_items || n_bloom_items) {
         if (!blooms) return fail(c, PHANT_E_INVALID_ARG, "block_roots: blooms is null");
-        return phant_logs_bloom(c, bloom_items, bloom_item_off, bloom_item_receipt, n_bloom_items, n_receipts, blooms);
+        return phant_impl::phant_logs_bloom(c, bloom_items, bloom_item_off, bloom_item_receipt, n_bloom_items, n_receipts, blooms);
     }
     return PHANT_OK;
 }
@@ -1319,4 +1334,6 @@ int32_t phant_state_trie_leaves(phant_ctx* c, const uint8_t* addrs, const uint64
     return PHANT_OK;
 }
 
-}  // extern "C"
+}  // namespace phant_impl
+
+#include "capi_guard_capi.inc"

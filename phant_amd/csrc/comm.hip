@@ -251,7 +251,9 @@ int32_t root_from_parts(phant_comm* c, const std::vector<Part>& parts, uint8_t o
 // why the last phant_comm_create on this thread failed (the comm itself is gone by then): phant_comm_last_error(NULL)
 thread_local std::string g_create_err;
 
-extern "C" {
+namespace phant_impl {
+int32_t guard_failed(phant_ctx* c, int32_t code) noexcept;  // (capi.hip)
+
 
 int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t flags, phant_comm** out) {
     if (!out) return PHANT_E_INVALID_ARG;
@@ -326,7 +328,7 @@ phant_ctx* phant_comm_ctx(phant_comm* c, uint32_t rank) { return (c && rank < c-
 const char* phant_comm_last_error(const phant_comm* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 uint32_t phant_comm_owner(const phant_comm* c, const uint8_t* key, uint32_t key_len) {
-    const uint32_t n = phant_comm_size(c);
+    const uint32_t n = phant_impl::phant_comm_size(c);
     if (n <= 1 || key_len == 0 || !key) return 0;
     return (uint32_t)(key[0] >> 4) % n;
 }
@@ -371,7 +373,7 @@ int32_t phant_mpt_verify_sharded(phant_comm* c, const uint8_t* roots, uint32_t n
         s.rc = PHANT_OK;
     }
     for (uint32_t i = 0; i < n; ++i)
-        c->shards[phant_comm_owner(c, keys ? keys + (size_t)key_len * i : nullptr, key_len)].proofs.push_back(i);
+        c->shards[phant_impl::phant_comm_owner(c, keys ? keys + (size_t)key_len * i : nullptr, key_len)].proofs.push_back(i);
 
     // ---- per device, on a host thread of its own: gather the shard, stage it, verify (asynchronous) ----
     auto work = [&](uint32_t r) {
@@ -557,4 +559,6 @@ int32_t phant_state_root_sharded(phant_comm* c, const uint8_t* addrs, const uint
     return root_from_parts(c, parts, out, "state_root_sharded");
 }
 
-}  // extern "C"
+}  // namespace phant_impl
+
+#include "capi_guard_comm.inc"

@@ -73,11 +73,12 @@ struct VerifyTune {
     uint32_t* last_shallow = nullptr; // diagnostics: where the launcher notes the tier split it chose (phant_verify_tier_stats)
     hipEvent_t* kernel_ev = nullptr;  // diagnostics, with `serial`: VERIFY_KERNEL_STAGES + 1 events recorded around the stages of a
                                       // two-tier launch (phant_verify_kernel_ms)
-    // The shallow tier's form.  table_form: always through the group tables (A/B; PHANT_VERIFY_TABLE=1).  Otherwise the ORDERED form
-    // (key-bucketed neighbour comparison, mpt_verify_v3.hip) for a batch against one root -- the library orders the proofs
-    // itself -- and, with key_ordered (PHANT_CTX_VERIFY_KEY_ORDERED: the caller says the proofs are in (root index, key) order),
-    // for any batch, on the caller's order as it is.
-    bool table_form = false;
+    // The shallow tier's form: the group tables, unless one of the ORDERED forms (key-bucketed neighbour comparison,
+    // mpt_verify_v3.hip) is asked for -- A/B, measured slower on this chip at every batch size (profiles/r5_explore/NOTES.md):
+    // own_order (PHANT_CTX_VERIFY_ORDERED): a batch against ONE root is ordered by the library's own counting sort;
+    // key_ordered (PHANT_CTX_VERIFY_KEY_ORDERED: the caller says the proofs are in (root index, key) order): any batch, on the
+    // caller's order as it is.
+    bool own_order = false;
     bool key_ordered = false;
     uint32_t coop_max = 2048;      // S = 0 form: batches of up to this many nodes take the node-per-half-wave hash kernel
     bool no_coop = false;

@@ -180,6 +180,9 @@ struct Args {
     const struct PosInfo* pos;  // n records: what the ordered form needs to know about the proof at position i of the order
     const uint32_t* bstart;  // buckets + 1: first position of bucket b (ord given)
     uint32_t bucket_bits;    // a proof's bucket = the top bucket_bits bits of its key (ord given)
+    uint4* leafres;          // total_nodes: for the LAST node j of a proof {status or LEAF_NONE, value_len, value_off lo, hi}: what the
+                             // walk ends in if every node in front of j turns out to be a canonical full branch whose hash matches
+                             // (leaf_kernel; read by walk_kernel<.., true>)
     uint32_t dbg;            // EXPLORATION ONLY (PHANT_VERIFY_DBG): parts of compare_kernel switched off, for their cost
     uint32_t* hdr;           // header: HDR_*; cleared per call (propose_kernel / zero_kernel)
     uint32_t* digest;        // total_nodes x 8
@@ -717,78 +720,120 @@ __global__ void __launch_bounds__(256) heads_kernel(const Args a) {
     list_append<0>(a, cls, j, p, s_cnt, s_base);
 }
 
-// wave = (chunk, level); see the head of this section
-__global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const Args a, const uint32_t chunks) {
-    __shared__ uint32_t s_cnt[4][N_LIST];
-    __shared__ uint32_t s_base[N_LIST];
+// wave = a chunk of CHUNK consecutive positions, its S levels one after the other; see the head of this section.
+// One stream of S x 64 node loads per wave, RING of them in flight and never drained: while the last steps of a level are compared,
+// the first nodes of the next level are already on their way (their offsets were requested when the level began).  No barrier, no
+// LDS: a wave runs on its own, whatever its neighbours do.
+constexpr uint32_t RING = 8;
+static_assert(64u % RING == 0u, "a level is a whole number of ring turns");
+// `per_wave`: levels a wave takes (groups = ceil(S / per_wave) waves per chunk): more waves in flight against fewer set-ups
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) compare_kernel(const Args a, const uint32_t chunks, const uint32_t per_wave,
+                                                                                               const uint32_t groups) {
     beside_the_hashing();
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    if (tid < 4u * N_LIST) (&s_cnt[0][0])[tid] = 0u;
-    const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (tid >> 6));
-    const uint32_t chunk = unit / a.shallow, d = unit - chunk * a.shallow;
-    // the lane's position; lane 0 looks at lane 1's: it carries the node that position's run continues, if it is not a head itself
-    const uint32_t i = chunk * CHUNK + (lane ? lane - 1u : 0u);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t chunk = unit / groups;
+    if (chunk >= chunks) return;
+    const uint32_t S = a.shallow, i1 = chunk * CHUNK;
+    const uint32_t d_from = (unit - chunk * groups) * per_wave, d_to = d_from + per_wave < S ? d_from + per_wave : S;
+    // the lane's position; lane 0 carries, level by level, the node position i1's run continues (if i1 does not open one itself)
+    const uint32_t i = i1 + (lane ? lane - 1u : 0u);
+    const bool real = lane >= 1u && i < a.v.n;
+    enum : uint32_t { M_LEN = 0xffffu, M_PART = 1u << 16, M_HEAD = 1u << 17, M_ACT = 1u << 18 };
 
-    // ---- what the lane's position is: meta = len (<= 768) | takes part | opens a run ----
-    enum : uint32_t { M_LEN = 0xffffu, M_PART = 1u << 16, M_HEAD = 1u << 17 };
-    uint32_t meta = 0, j = 0, p = 0, len = 0;
-    uint64_t b = 0;
-    bool real = false, act = false;
-    if (chunk < chunks && i < a.v.n) {
+    // ---- the position's record, boiled down: first node; info = levels that open a run | reachable levels << 16 | root index usable << 24 ----
+    enum : uint32_t { I_END_SHIFT = 16, I_ROOT_OK = 1u << 24 };
+    uint32_t first = 0, info = 0;
+    if (real) {
         const PosInfo me = load_pos_info(a.pos + i), prev = load_pos_info(a.pos + (i ? i - 1u : 0u));
-        const ShallowLane L = ordered_node(a, me, d);
-        p = me.p;
-        j = L.j;
-        len = L.len;
-        if (key_head(a, i, d, me, prev)) meta |= M_HEAD;
-        if (takes_part(L)) {
-            meta |= M_PART | L.len;
-            b = a.v.node_off[j];
-        }
-        if (lane >= 1u) {
-            real = true;
-            act = L.act;
-            if (L.broken) a.hdr[HDR_PFN_BROKEN] = 1u;  // (node ranges of other proofs may overlap: the walk trusts nothing then)
-            if (L.act && !L.valid) a.nstat[j] = 0u;     // never hashed: says so (nobody else writes this node's state)
-        } else {
-            // the key head of position 1's group, through the bucket table
-            const bool wanted = a.bstart && (meta & M_PART) && !(meta & M_HEAD) && 4u * d <= a.bucket_bits && !(a.dbg & 2u);
-            meta = 0;
-            if (wanted) {
-                const uint32_t sh = a.bucket_bits - 4u * d;
-                const uint32_t gs = a.bstart[(bucket_of(L.kb, a.bucket_bits) >> sh) << sh];
-                if (gs < i) {  // (in front of this chunk: a head inside it is met on the way)
-                    const PosInfo h = load_pos_info(a.pos + gs), hprev = load_pos_info(a.pos + (gs ? gs - 1u : 0u));
-                    const ShallowLane H = ordered_node(a, h, d);
-                    // usable only if it is what heads_kernel lists: a node that takes part, of this group, opening its run
-                    if (takes_part(H) && same_key_group(H.root, H.kb, L.root, L.kb, d) && key_head(a, gs, d, h, hprev)) {
-                        meta = M_PART | M_HEAD | H.len;
-                        j = H.j;
-                        b = a.v.node_off[j];
-                    }
+        first = me.first;
+        if (me.end == POS_BROKEN) a.hdr[HDR_PFN_BROKEN] = 1u;  // (node ranges of other proofs may overlap: the walk trusts nothing then)
+        else info = (me.end < S ? me.end : S) << I_END_SHIFT;
+        if (me.root < a.v.n_roots) info |= I_ROOT_OK;
+        for (uint32_t d = 0; d < S; ++d)
+            if (key_head(a, i, d, me, prev)) info |= 1u << d;
+    }
+    // ---- lane d < S: the key head of position i1's group at level d, through the bucket table (h_meta = 0: none) ----
+    uint32_t h_meta = 0, h_j = 0;
+    uint64_t h_b = 0;
+    if (lane >= d_from && lane < d_to && a.bstart && i1 < a.v.n && 4u * lane <= a.bucket_bits && !(a.dbg & 2u)) {
+        const uint32_t d = lane;
+        const PosInfo one = load_pos_info(a.pos + i1), oprev = load_pos_info(a.pos + (i1 ? i1 - 1u : 0u));
+        if (!key_head(a, i1, d, one, oprev)) {
+            const uint32_t sh = a.bucket_bits - 4u * d;
+            const uint32_t gs = a.bstart[(bucket_of(kb_of(one), a.bucket_bits) >> sh) << sh];
+            if (gs < i1) {  // (in front of this chunk: a head inside it is met on the way)
+                const PosInfo h = load_pos_info(a.pos + gs), hprev = load_pos_info(a.pos + (gs ? gs - 1u : 0u));
+                const ShallowLane H = ordered_node(a, h, d);
+                // usable only if it is what heads_kernel lists: a node that takes part, of this group, opening its run
+                if (takes_part(H) && same_key_group(H.root, H.kb, one.root, kb_of(one), d) && key_head(a, gs, d, h, hprev)) {
+                    h_meta = M_PART | M_HEAD | H.len;
+                    h_j = H.j;
+                    h_b = a.v.node_off[H.j];
                 }
             }
         }
     }
+    const uint32_t hb_lo = (uint32_t)h_b, hb_hi = (uint32_t)(h_b >> 32);
 
-    // ---- the stream: node by node, 12 bytes per lane, two trips of four loads in flight ----
-    const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32);
+    // the lane's node of level d from its two offsets (e = node_off[first + d + 1], b = node_off[first + d]); lane 0: the level's head
+    auto describe = [&](uint32_t d, uint64_t e, uint64_t b, uint32_t& meta, uint32_t& b_lo, uint32_t& b_hi) __attribute__((always_inline)) {
+        meta = 0;
+        b_lo = (uint32_t)b;
+        b_hi = (uint32_t)(b >> 32);
+        if (d < (info >> I_END_SHIFT & 0xffu)) {  // (lane 0 and the lanes behind the batch's end: 0 levels)
+            meta = M_ACT;
+            if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
+                const uint32_t len = (uint32_t)(e - b);
+                if ((info & I_ROOT_OK) && len >= RATE && len <= CMP_MAX_LEN) meta |= M_PART | len;
+            } else {
+                a.nstat[first + d] = 0u;  // never hashed: says so (nobody else writes this node's state)
+            }
+        }
+        if (info >> d & 1u) meta |= M_HEAD;
+        // (wave-uniform lane index d: the level's head travels from lane d to lane 0)
+        const uint32_t m0 = lane_u32(h_meta, d), l0 = lane_u32(hb_lo, d), u0 = lane_u32(hb_hi, d);
+        if (lane == 0u) {
+            meta = m0;
+            b_lo = l0;
+            b_hi = u0;
+        }
+    };
+    auto offsets = [&](uint32_t d, uint64_t& e, uint64_t& b) __attribute__((always_inline)) {
+        e = b = 0;
+        if (d < (info >> I_END_SHIFT & 0xffu)) {
+            b = a.v.node_off[first + d];
+            e = a.v.node_off[first + d + 1u];
+        }
+    };
+
     const uint32_t off12 = 12u * lane;
-    uint32_t my_ref = 64u;  // the lane whose node this lane's node is a copy of (64: none)
-    bool late = false;      // differs from its run's reference (or found none): to be hashed, says this kernel
-    const unsigned long long parts = __ballot((meta & M_PART) != 0u);
-    if (parts && !(a.dbg & 1u)) {
-        const uint32_t last = 63u - (uint32_t)__builtin_clzll(parts);  // (nothing to do behind the last node that takes part)
+    uint32_t meta, b_lo, b_hi;  // this level
+    {
+        uint64_t e, b;
+        offsets(d_from, e, b);
+        describe(d_from, e, b, meta, b_lo, b_hi);
+    }
+    // a node that takes no part is "read" as the blob's first 12 bytes: readable whenever some node takes part (>= 136 bytes)
+    auto fetch = [&](uint32_t l, uint32_t fm, uint32_t flo, uint32_t fhi) __attribute__((always_inline)) -> U32x3 {
+        const uint32_t m = lane_u32(fm, l);
+        const bool part = (m & M_PART) != 0u;
+        const uint32_t ln = part ? (m & M_LEN) : 12u;
+        const uint64_t base = part ? lane_u64(flo, fhi, l) : 0ull;
+        const uint32_t o = off12 < ln - 12u ? off12 : ln - 12u;  // (lanes behind the node's end repeat its last 12 bytes)
+        return *reinterpret_cast<const U32x3*>(a.v.nodes + base + o);
+    };
+    const bool readable = a.v.nodes_len >= 12u && !(a.dbg & 1u);
+    U32x3 ring[RING];
+#pragma unroll
+    for (uint32_t u = 0; u < RING; ++u) ring[u] = readable ? fetch(u, meta, b_lo, b_hi) : U32x3{0u, 0u, 0u};
+
+    for (uint32_t d = d_from; d < d_to; ++d) {
+        const bool more = d + 1u < d_to;
         U32x3 ref{0u, 0u, 0u};
         uint32_t ref_len = 0, ref_lane = 64u;
-        auto fetch = [&](uint32_t l) __attribute__((always_inline)) -> U32x3 {
-            const uint32_t m = lane_u32(meta, l);
-            const bool part = (m & M_PART) != 0u;
-            const uint32_t ln = part ? (m & M_LEN) : 12u;                 // (a node that takes no part: the blob's first bytes,
-            const uint64_t base = part ? lane_u64(b_lo, b_hi, l) : 0ull;  //  readable because some node of >= 136 bytes exists)
-            const uint32_t o = off12 < ln - 12u ? off12 : ln - 12u;       // (lanes behind the node's end repeat its last 12 bytes)
-            return *reinterpret_cast<const U32x3*>(a.v.nodes + base + o);
-        };
+        uint32_t my_ref = 64u;  // the lane whose node this lane's node is a copy of (64: none)
+        bool late = false;      // differs from its run's reference (or found none): to be hashed, says this kernel
         auto step = [&](uint32_t l, const U32x3& cur) __attribute__((always_inline)) {
             const uint32_t m = lane_u32(meta, l);
             if (m & M_HEAD) ref_lane = 64u;  // a run ends here, whatever this node is
@@ -810,26 +855,45 @@ __global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const A
                 ref_lane = l;
             }
         };
-        constexpr uint32_t U = 4;
-        U32x3 A[U], B[U];
+        auto turns = [&](uint32_t from, uint32_t to) __attribute__((always_inline)) {
+            for (uint32_t t = from; t < to; t += RING) {
 #pragma unroll
-        for (uint32_t u = 0; u < U; ++u) A[u] = fetch(u);
-        for (uint32_t t = 0; t <= last; t += 2u * U) {
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) B[u] = fetch((t + U + u) & 63u);
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) step(t + u, A[u]);
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) A[u] = fetch((t + 2u * U + u) & 63u);
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) step(t + U + u, B[u]);
+                for (uint32_t u = 0; u < RING; ++u) {
+                    step(t + u, ring[u]);
+                    ring[u] = fetch(t + RING + u, meta, b_lo, b_hi);
+                }
+            }
+        };
+        // The next level's offsets are requested when this level begins and turned into its description half way through (they
+        // have long arrived: no wait), so that the level's last ring turn can fetch ahead into the next level.
+        uint32_t nmeta = 0, nb_lo = 0, nb_hi = 0;
+        {
+            uint64_t ne = 0, nb = 0;
+            if (more) offsets(d + 1u, ne, nb);
+            if (readable) turns(0u, 32u);
+            if (more) describe(d + 1u, ne, nb, nmeta, nb_lo, nb_hi);
         }
+        if (readable) {
+            turns(32u, 64u - RING);
+#pragma unroll
+            for (uint32_t u = 0; u < RING; ++u) {
+                step(64u - RING + u, ring[u]);
+                if (more) ring[u] = fetch(u, nmeta, nb_lo, nb_hi);
+            }
+        }
+        // ---- the level's results: the representative of every node, and what is left to hash ----
+        const uint32_t hj = lane_u32(h_j, d);
+        const uint32_t j = lane ? first + d : hj;
+        const uint32_t rj = (uint32_t)__shfl((int)j, (int)(my_ref & 63u), 64);
+        if (meta & M_ACT) a.rep[j] = my_ref < 64u ? rj : j;  // (M_ACT: a real position's existing node -- never lane 0)
+        if (late && !(a.dbg & 4u)) {  // (rare: damaged copies and their successors -- a reservation each)
+            const uint32_t cls = node_list(meta & M_LEN), stripe = chunk % STRIPES;
+            a.ent2[ent2_index(a, cls, stripe, atomicAdd(&a.hdr[cursor_word(cls, stripe, 1u)], 1u))] = make_uint2(j, a.pos[i].p);
+        }
+        meta = nmeta;
+        b_lo = nb_lo;
+        b_hi = nb_hi;
     }
-    // ---- results: the representative of every node, and what is left to hash ----
-    const uint32_t rj = (uint32_t)__shfl((int)j, (int)(my_ref & 63u), 64);
-    if (real && act) a.rep[j] = my_ref < 64u ? rj : j;
-    if (a.dbg & 4u) return;
-    list_append<1>(a, (real && late) ? node_list(len) : CLASS_NONE, j, p, s_cnt, s_base);
 }
 
 // ---------------------------------------------------------------- canonical full branch, per rate block
@@ -910,20 +974,20 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 // single-wave speed.  With the ladder a wave that is behind outranks the ones ahead: they advance block by block
 // together and finish together (profiles/EXPERIMENTS.md: ladders measured).
 template <bool LADDER>
-PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p, const bool noperm = false /* EXPLORATION */) {
+PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p, const bool ladder = true /* EXPLORATION */) {
     sponge_zero(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(2);
+    if (LADDER && ladder) __builtin_amdgcn_s_setprio(2);
     uint32_t bad = absorb_b532_block<0, 34>(s, p);
-    if (!noperm) keccak_f1600(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(1);
+    keccak_f1600(s);
+    if (LADDER && ladder) __builtin_amdgcn_s_setprio(1);
     bad |= absorb_b532_block<1, 34>(s, p + RATE);
-    if (!noperm) keccak_f1600(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(1);
+    keccak_f1600(s);
+    if (LADDER && ladder) __builtin_amdgcn_s_setprio(1);
     bad |= absorb_b532_block<2, 34>(s, p + 2u * RATE);
-    if (!noperm) keccak_f1600(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(0);
+    keccak_f1600(s);
+    if (LADDER && ladder) __builtin_amdgcn_s_setprio(0);
     bad |= absorb_b532_block<3, 31>(s, p + 3u * RATE);
-    if (!noperm) keccak_f1600(s);
+    keccak_f1600(s);
     return bad;
 }
 
@@ -1073,7 +1137,7 @@ PHANT_DEV bool list_role(const Args& a, uint32_t q, const uint32_t lane) {
     uint32_t bad;
     const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
     if (cls == LIST_B532) {
-        bad = hash_b532<true>(s, p);
+        bad = hash_b532<true>(s, p, !(a.dbg & 64u));
     } else if (cls == 0u && __ballot(len != len0 || p + RATE > safe_end) == 0ull) {
         hash_short_uniform(s, p, len0);  // one length below the rate for the whole chunk
         bad = 1u;
@@ -1159,7 +1223,7 @@ PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, c
         const bool is532 = active && len == BRANCH_LEN;
         if (roomy && __ballot(is532) != 0ull) {
             // the lanes with a 532-byte node (the others run along on a readable address: the blob's first bytes)
-            const uint32_t bad = hash_b532<true>(s, (is532 && !(a.dbg & 8u)) ? ptr : a.v.nodes, (a.dbg & 16u) != 0u);
+            const uint32_t bad = hash_b532<true>(s, (is532 && !(a.dbg & 8u)) ? ptr : a.v.nodes, !(a.dbg & 64u));
             if (is532 && bad == 0u) flags |= F_CANON;
         }
         const bool rest = active && !(roomy && is532);
@@ -1213,9 +1277,90 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
 // canonical-branch markers checked on exactly those bytes), 25 lanes hold a word of the sponge each (coop_sponge.hip.h: ~6 us
 // per permutation).  Same node states, digests and statistics as deep_role<true>; up to COOP_MAX_NODES nodes per batch.
 constexpr uint32_t COOP_MAX_NODES = 2048;  // (one wave per SIMD: beyond it the shared sponge is no faster than a lane's)
+// One node per half wave (the halves of a wave together: as many rate blocks as the longer node needs, the other half's surplus
+// predicated off -- every cross-lane operation runs with the whole wave).  `present`: this half has a node -- node j, index d in
+// proof p against root `root`.  stat_word: where the half's first lane counts the node (the in-place forms' statistics), or none.
+constexpr uint32_t NO_STAT = 0xffffffffu;
+PHANT_DEV void coop_node(const Args& a, const CoopLane& c, const uint32_t l, const uint32_t base, const bool present, const uint32_t p,
+                         const uint32_t j, const uint32_t d, const uint32_t root, const uint32_t stat_word) {
+    struct __attribute__((packed, aligned(1))) U64 { unsigned long long v; };
+    const uint32_t nn = 2u * a.v.key_len;
+    bool active = false;
+    uint32_t len = 0;
+    uint64_t b = 0;
+    if (present) {
+        const uint64_t e = a.v.node_off[j + 1];
+        b = a.v.node_off[j];
+        active = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull;
+        len = active ? (uint32_t)(e - b) : 0u;
+        if (!active && l == 0) a.nstat[j] = 0u;
+    }
+    const uint8_t* const ptr = a.v.nodes + (active ? b : 0ull);
+    const uint8_t* refp = nullptr;
+    if (active) {
+        const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * p;
+        refp = ref_location(a, j, d, root, (d >= 1u && d - 1u < nn) ? key_nibble(key, d - 1u) : 16u, b);
+    }
+    const uint32_t nb = active ? len / RATE + 1u : 0u;
+    const uint32_t nb_other = __shfl(nb, (int)(base ^ 32u), 64);
+    const uint32_t nb_max = nb > nb_other ? nb : nb_other;
+    const bool branch = active && len == BRANCH_LEN;
+    uint32_t lo = 0, hi = 0, dlo = 0, dhi = 0, bad = 0;
+    for (uint32_t k = 0; k < nb_max; ++k) {
+        if (k < nb && l < 17u) {
+            const uint32_t off = k * RATE + 8u * l;
+            unsigned long long w = 0;
+            if (off + 8u <= len) {
+                w = reinterpret_cast<const U64*>(ptr + off)->v;
+            } else {
+#pragma unroll
+                for (uint32_t t = 0; t < 8u; ++t) {
+                    const uint32_t q = off + t;
+                    if (q < len) w |= (unsigned long long)ptr[q] << (8u * t);
+                    else if (q == len) w |= 0x01ull << (8u * t);  // Keccak-256's domain byte
+                }
+            }
+            if (k + 1u == nb && l == 16u) w |= 0x80ull << 56;  // the end of pad10*1: the rate's last byte
+            if (branch) {  // f9 02 11 | 16 x (a0 | 32 bytes) | 80: the markers among this lane's bytes
+#pragma unroll
+                for (uint32_t t = 0; t < 8u; ++t) {
+                    const uint32_t q = off + t;
+                    const uint32_t byte = (uint32_t)(w >> (8u * t)) & 0xffu;
+                    const int want = q == 0u ? 0xf9 : q == 1u ? 0x02 : q == 2u ? 0x11 : q == BRANCH_LEN - 1u ? 0x80 : (q < BRANCH_LEN && (q - 3u) % 33u == 0u) ? 0xa0 : -1;
+                    if (want >= 0 && byte != (uint32_t)want) bad = 1u;
+                }
+            }
+            lo ^= (uint32_t)w;
+            hi ^= (uint32_t)(w >> 32);
+        }
+        coop_permute(c, lo, hi);
+        if (k + 1u == nb) {  // this half's digest (the other half may need more blocks)
+            dlo = lo;
+            dhi = hi;
+        }
+    }
+    bool ne = false;
+    if (refp && l < 4u) {
+        const unsigned long long r = reinterpret_cast<const U64*>(refp + 8u * l)->v;
+        ne = (uint32_t)r != dlo || (uint32_t)(r >> 32) != dhi;
+    }
+    const uint32_t any_bad = (uint32_t)(__ballot(bad != 0u) >> base), any_ne = (uint32_t)(__ballot(ne) >> base);
+    if (active) {
+        uint32_t ns = NS_HASHED | ((branch && any_bad == 0u) ? NS_CANON : 0u);
+        if (refp) ns |= NS_LINK_CHECKED | (any_ne == 0u ? NS_LINK_OK : 0u);
+        if (l < 4u) {
+            a.digest[8ull * j + 2u * l] = dlo;
+            a.digest[8ull * j + 2u * l + 1u] = dhi;
+        }
+        if (l == 0) {
+            a.nstat[j] = (uint8_t)ns;
+            const uint32_t cls = len / RATE < N_CLASS ? len / RATE : N_CLASS - 1u;  // (reporting only, as deep_role)
+            if (stat_word != NO_STAT) atomicAdd(&a.hdr[stat_word + cls], 1u);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) hash_coop_kernel(const Args a, const uint32_t levels) {
-    // (The two halves of a wave walk their loops TOGETHER -- as many trips and rate blocks as the longer one needs, the other half's
-    // surplus predicated off: every cross-lane operation runs with the whole wave, and a wave is as long as its longer half anyway.)
     const uint32_t tid = threadIdx.x, l = tid & 31u, base = tid & 32u;
     const uint32_t h = blockIdx.x * 8u + (tid >> 5);
     const uint32_t p = h / levels, level = h % levels;
@@ -1227,86 +1372,11 @@ __global__ void __launch_bounds__(256) hash_coop_kernel(const Args a, const uint
         if (last < first && l == 0) a.hdr[HDR_PFN_BROKEN] = 1u;  // (no shallow tier in this form: see deep_role<true>)
         if (a.v.root_idx) root = a.v.root_idx[p];
     }
-    const uint32_t nn = 2u * a.v.key_len;
-    const uint32_t stat_buf = a.hdr[HDR_PARITY] & 1u;
+    const uint32_t stat_word = HDR_STAT + HDR_STAT_WORDS * (a.hdr[HDR_PARITY] & 1u) + N_CLASS * (h % HDR_STAT_STRIPES);
     const CoopLane c = coop_lane(l, base);
-    struct __attribute__((packed, aligned(1))) U64 { unsigned long long v; };
     for (uint32_t d = level;; d += levels) {
         if (__ballot(d < count) == 0ull) break;
-        const uint32_t j = first + d;
-        bool active = false;
-        uint32_t len = 0;
-        uint64_t b = 0;
-        if (d < count) {
-            const uint64_t e = a.v.node_off[j + 1];
-            b = a.v.node_off[j];
-            active = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull;
-            len = active ? (uint32_t)(e - b) : 0u;
-            if (!active && l == 0) a.nstat[j] = 0u;
-        }
-        const uint8_t* const ptr = a.v.nodes + (active ? b : 0ull);
-        const uint8_t* refp = nullptr;
-        if (active) {
-            const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * p;
-            refp = ref_location(a, j, d, root, (d >= 1u && d - 1u < nn) ? key_nibble(key, d - 1u) : 16u, b);
-        }
-        const uint32_t nb = active ? len / RATE + 1u : 0u;
-        const uint32_t nb_other = __shfl(nb, (int)(base ^ 32u), 64);
-        const uint32_t nb_max = nb > nb_other ? nb : nb_other;
-        const bool branch = active && len == BRANCH_LEN;
-        uint32_t lo = 0, hi = 0, dlo = 0, dhi = 0, bad = 0;
-        for (uint32_t k = 0; k < nb_max; ++k) {
-            if (k < nb && l < 17u) {
-                const uint32_t off = k * RATE + 8u * l;
-                unsigned long long w = 0;
-                if (off + 8u <= len) {
-                    w = reinterpret_cast<const U64*>(ptr + off)->v;
-                } else {
-#pragma unroll
-                    for (uint32_t t = 0; t < 8u; ++t) {
-                        const uint32_t q = off + t;
-                        if (q < len) w |= (unsigned long long)ptr[q] << (8u * t);
-                        else if (q == len) w |= 0x01ull << (8u * t);  // Keccak-256's domain byte
-                    }
-                }
-                if (k + 1u == nb && l == 16u) w |= 0x80ull << 56;  // the end of pad10*1: the rate's last byte
-                if (branch) {  // f9 02 11 | 16 x (a0 | 32 bytes) | 80: the markers among this lane's bytes
-#pragma unroll
-                    for (uint32_t t = 0; t < 8u; ++t) {
-                        const uint32_t q = off + t;
-                        const uint32_t byte = (uint32_t)(w >> (8u * t)) & 0xffu;
-                        const int want = q == 0u ? 0xf9 : q == 1u ? 0x02 : q == 2u ? 0x11 : q == BRANCH_LEN - 1u ? 0x80 : (q < BRANCH_LEN && (q - 3u) % 33u == 0u) ? 0xa0 : -1;
-                        if (want >= 0 && byte != (uint32_t)want) bad = 1u;
-                    }
-                }
-                lo ^= (uint32_t)w;
-                hi ^= (uint32_t)(w >> 32);
-            }
-            coop_permute(c, lo, hi);
-            if (k + 1u == nb) {  // this half's digest (the other half may need more blocks)
-                dlo = lo;
-                dhi = hi;
-            }
-        }
-        bool ne = false;
-        if (refp && l < 4u) {
-            const unsigned long long r = reinterpret_cast<const U64*>(refp + 8u * l)->v;
-            ne = (uint32_t)r != dlo || (uint32_t)(r >> 32) != dhi;
-        }
-        const uint32_t any_bad = (uint32_t)(__ballot(bad != 0u) >> base), any_ne = (uint32_t)(__ballot(ne) >> base);
-        if (active) {
-            uint32_t ns = NS_HASHED | ((branch && any_bad == 0u) ? NS_CANON : 0u);
-            if (refp) ns |= NS_LINK_CHECKED | (any_ne == 0u ? NS_LINK_OK : 0u);
-            if (l < 4u) {
-                a.digest[8ull * j + 2u * l] = dlo;
-                a.digest[8ull * j + 2u * l + 1u] = dhi;
-            }
-            if (l == 0) {
-                a.nstat[j] = (uint8_t)ns;
-                const uint32_t cls = len / RATE < N_CLASS ? len / RATE : N_CLASS - 1u;  // (reporting only, as deep_role)
-                atomicAdd(&a.hdr[HDR_STAT + HDR_STAT_WORDS * stat_buf + N_CLASS * (h % HDR_STAT_STRIPES) + cls], 1u);
-            }
-        }
+        coop_node(a, c, l, base, d < count, p, first + d, d, root, stat_word);
     }
 }
 
@@ -1323,6 +1393,62 @@ __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
     } else {
         // set 1 is short (the copies that differ): a bounded grid whose waves stride over the queue
         while (list_role<SET>(a, q, threadIdx.x & 63u)) q += gridDim.x * 4u;
+    }
+}
+
+// What the comparison of the ordered form left (list set 1: copies that differ, and their successors).  Few: a node per HALF
+// WAVE then (four sequential permutations at the shared sponge's ~6 us instead of a lane's ~9-11: this kernel sits between the
+// comparison and the walk, on the launch's critical chain); a witness with much damage is hashed a lane per node as any list.
+__global__ void __launch_bounds__(256) hash_late_kernel(const Args a) {
+    __builtin_amdgcn_s_setprio(2);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // the 72 lists' counts, as list_role reads them; entry e of the queue = entry (e - before) of its list
+    static_assert(N_QUEUE > 64u && N_QUEUE <= 128u, "two lists per lane");
+    const uint32_t cnt_a = a.hdr[cursor_word(queue_class(lane), lane % STRIPES, 1u)];
+    const uint32_t cnt_b = lane + 64u < N_QUEUE ? a.hdr[cursor_word(queue_class(lane + 64u), (lane + 64u) % STRIPES, 1u)] : 0u;
+    const uint32_t incl_a = wave_inclusive_scan(cnt_a, lane);
+    const uint32_t incl_b = lane_u32(incl_a, 63u) + wave_inclusive_scan(cnt_b, lane);
+    const uint32_t total = lane_u32(incl_b, 63u);
+    if (total > COOP_MAX_NODES) {
+        uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (tid >> 6));
+        while (list_role<1>(a, q, lane)) q += gridDim.x * 4u;
+        return;
+    }
+    const uint32_t l = tid & 31u, base = tid & 32u;
+    const CoopLane c = coop_lane(l, base);
+    for (uint32_t h0 = (blockIdx.x * 4u + (tid >> 6)) * 2u;; h0 += gridDim.x * 8u) {  // (h0: the wave's first half's entry)
+        if (h0 >= total) break;
+        const uint32_t e = h0 + (base >> 5);
+        // which list: the first one whose inclusive count exceeds e (wave-wide search, each half for its own entry)
+        const uint32_t e0 = h0, e1 = h0 + 1u;
+        const unsigned long long a0 = __ballot(e0 < incl_a), b0 = __ballot(e0 < incl_b);
+        const unsigned long long a1 = __ballot(e1 < incl_a), b1 = __ballot(e1 < incl_b);
+        const unsigned long long ma = base ? a1 : a0, mb = base ? b1 : b0;
+        const bool present = e < total;
+        uint32_t li = 0, before = 0;
+        {
+            // (readlane wants a wave-uniform index: both halves' candidates are fetched, each half keeps its own)
+            const uint32_t la0 = a0 ? (uint32_t)__builtin_ctzll(a0) : 0u, lb0 = b0 ? (uint32_t)__builtin_ctzll(b0) : 0u;
+            const uint32_t la1 = a1 ? (uint32_t)__builtin_ctzll(a1) : 0u, lb1 = b1 ? (uint32_t)__builtin_ctzll(b1) : 0u;
+            const uint32_t bef_a0 = lane_u32(incl_a, la0) - lane_u32(cnt_a, la0), bef_b0 = lane_u32(incl_b, lb0) - lane_u32(cnt_b, lb0);
+            const uint32_t bef_a1 = lane_u32(incl_a, la1) - lane_u32(cnt_a, la1), bef_b1 = lane_u32(incl_b, lb1) - lane_u32(cnt_b, lb1);
+            if (ma) {
+                li = base ? la1 : la0;
+                before = base ? bef_a1 : bef_a0;
+            } else if (mb) {
+                li = 64u + (base ? lb1 : lb0);
+                before = base ? bef_b1 : bef_b0;
+            }
+        }
+        uint32_t j = 0, owner = 0, d = 0, root = 0;
+        if (present) {
+            const uint2 en = a.ent2[ent2_index(a, queue_class(li), li % STRIPES, e - before)];
+            j = en.x;
+            owner = en.y;
+            d = j - a.v.proof_first_node[owner];
+            root = a.v.root_idx ? a.v.root_idx[owner] : 0u;
+        }
+        coop_node(a, c, l, base, present, owner, j, d, root, NO_STAT);
     }
 }
 
@@ -1386,8 +1512,69 @@ constexpr uint32_t WALK_STAGE_BYTES = 192;  // nodes up to this size are staged;
 constexpr uint32_t WALK_KEY_BYTES = 32;
 constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  // odd stride: no bank pile-up
 
+// ---- the leaf, decoded ahead of time ----
+// What a proof's walk does once the hashes are known is all but fixed for a well-formed witness: step over the full branches, decode
+// the LAST node -- ~100 dependent byte reads of RLP and hex-prefix -- and compare the rest of the key.  That decoding needs nothing the
+// pipeline computes: leaf_kernel does it when the launch starts, next to everything else, for the case that every node in front of
+// the last one is stepped over (pos = nodes - 1 nibbles consumed), and the walk, at the end of the launch's critical chain, only looks
+// at node states and takes the prepared result -- or does it all itself when the proof turns out to be anything else.
+constexpr uint32_t LEAF_NONE = 0xffu;
+constexpr uint32_t LEAF_LANES = 256;
+__global__ void __launch_bounds__(LEAF_LANES) leaf_kernel(const Args a) {
+    __shared__ uint32_t s_stage[LEAF_LANES * WALK_SLOT_DW];
+    beside_the_hashing();
+    const uint32_t i = blockIdx.x * LEAF_LANES + threadIdx.x;
+    if (i >= a.v.n) return;
+    const uint32_t first = a.v.proof_first_node[i], last = a.v.proof_first_node[i + 1];
+    if (last <= first || last > a.total_nodes) return;  // (nothing to prepare: the walk settles these itself)
+    const uint32_t j = last - 1u, cnt = last - first, nn = 2u * a.v.key_len;
+    uint32_t status = LEAF_NONE, vlen = 0;
+    uint64_t voff = 0;
+    const uint64_t b = a.v.node_off[j], e = a.v.node_off[j + 1];
+    const uint32_t padded = (uint32_t)((e - b + 15u) & ~15ull);
+    if (cnt - 1u <= nn && e >= b && e <= a.v.nodes_len && e - b <= WALK_STAGE_BYTES && b + padded <= a.v.nodes_len &&
+        a.v.key_len <= WALK_KEY_BYTES) {
+        uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
+        const uint8_t* const cur = a.v.nodes + b;
+        for (uint32_t o = 0; o < padded; o += 16u) {
+            const uint4 q = load16u(cur + o);
+            slot[o / 4u] = q.x;
+            slot[o / 4u + 1u] = q.y;
+            slot[o / 4u + 2u] = q.z;
+            slot[o / 4u + 3u] = q.w;
+        }
+        uint8_t* const kdst = reinterpret_cast<uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+        const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * i;
+        for (uint32_t t = 0; t < a.v.key_len; ++t) kdst[t] = key[t];
+        const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
+        const uint8_t* const slot_key = reinterpret_cast<const uint8_t*>(slot + WALK_STAGE_BYTES / 4);
+        WalkState w;
+        w.pos = cnt - 1u;
+        w.status = PHANT_PROOF_BAD_INPUT;
+        w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
+        uint32_t at = 0, len = (uint32_t)(e - b);  // the node being decoded: the last node, or a node embedded in it
+        for (;;) {
+            GlobalBytes nd{slot_node + at};
+            const uint32_t st = walk_node(nd, len, slot_key, nn, w);
+            if (st == STEP_DONE) {
+                status = w.status;
+                if (status == PHANT_PROOF_PRESENT) {
+                    voff = b + at + w.value_pay;
+                    vlen = w.value_len;
+                }
+                break;
+            }
+            if (st == STEP_HASH) break;  // (the proof goes on behind its last node: MISSING_NODE, the walk's business)
+            at += w.ref_pay;
+            len = w.ref_total;
+        }
+    }
+    a.leafres[j] = make_uint4(status, vlen, (uint32_t)voff, (uint32_t)(voff >> 32));
+}
+
 // DIRECT: the S = 0 form (no representatives: every node was hashed in place by a lane that knew the proof's key)
-template <bool DIRECT>
+// LEAF: leaf_kernel has run
+template <bool DIRECT, bool LEAF>
 __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
     __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
     // With several launches in flight this kernel runs next to OTHER launches' hash waves: a few instructions between memory
@@ -1439,6 +1626,9 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
             w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
             uint32_t used = first;
             status = 0xffffffffu;
+            // what leaf_kernel prepared for this proof's last node (requested now, looked at when the run gets there)
+            uint4 leaf = make_uint4(LEAF_NONE, 0u, 0u, 0u);
+            if constexpr (LEAF) leaf = a.leafres[last - 1u];
 
             // ---- the run of nodes the hash waves settled, eight at a time.  While every node so far was stepped over,
             // a node's index in the proof is the number of key nibbles consumed.  A deep node's state is its own; a shallow
@@ -1512,6 +1702,17 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                         run = false;
                         if (c == LINK_BAD_HASH) status = PHANT_PROOF_BAD_HASH;
                         else hash_known = c == LINK_HASH_OK;
+                        if constexpr (LEAF) {
+                            // the last node, reached over full branches only, its hash as the parent commits to it: exactly the
+                            // case leaf_kernel decoded it for
+                            if (hash_known && used + 1u == last && leaf.x != LEAF_NONE) {
+                                status = leaf.x;
+                                if (status == PHANT_PROOF_PRESENT) {
+                                    voff = ((uint64_t)leaf.w << 32) | leaf.z;
+                                    vlen = leaf.y;
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -1660,14 +1861,15 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
 // ---------------------------------------------------------------- diagnostics: a clean read stream
 // The witness's bytes, coalesced, 16 bytes per lane, eight loads in flight per lane, XORed into one word per workgroup:
 // what the memory system can deliver when nothing but ~60 VALU instructions per KB stands in the way.
-__global__ void __launch_bounds__(256) stream_read_kernel(const uint4* __restrict__ p, size_t n16, uint32_t* sink) {
+// `mask`: the index is taken modulo mask + 1 (EXPLORATION: the same loads out of a region that stays in L2 / Infinity Cache)
+__global__ void __launch_bounds__(256) stream_read_kernel(const uint4* __restrict__ p, size_t n16, uint32_t* sink, size_t mask) {
     const size_t stride = (size_t)gridDim.x * 256u;
     size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     uint4 acc = make_uint4(0u, 0u, 0u, 0u);
     for (; i + 7u * stride < n16; i += 8u * stride) {
         uint4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[i + (size_t)u * stride];
+        for (int u = 0; u < 8; ++u) v[u] = p[(i + (size_t)u * stride) & mask];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             acc.x ^= v[u].x;
@@ -1677,7 +1879,7 @@ __global__ void __launch_bounds__(256) stream_read_kernel(const uint4* __restric
         }
     }
     for (; i < n16; i += stride) {
-        const uint4 v = p[i];
+        const uint4 v = p[i & mask];
         acc.x ^= v.x;
         acc.y ^= v.y;
         acc.z ^= v.z;
@@ -1933,7 +2135,7 @@ static uint32_t table_entries(uint32_t n, uint32_t n_roots, uint32_t direct, uin
 }
 
 struct Layout {
-    size_t nstat, dtab, table, rep, ent, digest, pos, bcnt, bstart, bcur, bsums, ent2, end;
+    size_t nstat, dtab, table, rep, ent, digest, pos, bcnt, bstart, bcur, bsums, ent2, leafres, end;
     uint32_t stripe_cap, stripe_cap2;
 };
 // lanes of the comparison kernel of the ordered form: a wave per (chunk of CHUNK positions, level)
@@ -1945,8 +2147,9 @@ static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries,
     Layout l;
     const uint64_t wgs = (lanes + 255u) / 256u;
     l.stripe_cap = (uint32_t)((wgs + STRIPES - 1u) / STRIPES * 256u);
-    const uint64_t wgs2 = (units + 3u) / 4u;
-    l.stripe_cap2 = (uint32_t)((wgs2 + STRIPES - 1u) / STRIPES * 256u);
+    // (list set 1: a comparison wave -- one per chunk of positions -- appends at most CHUNK x levels entries to ITS stripe's lists;
+    // `units` = chunks x levels)
+    l.stripe_cap2 = (uint32_t)((units + STRIPES - 1u) / STRIPES * CHUNK + (uint64_t)CHUNK * MAX_SHALLOW);
     size_t p = HEADER_BYTES;
     l.nstat = p;  p += rnd256(tn + 16);
     l.dtab = p;   p += rnd256((size_t)direct_entries * 4);
@@ -1963,6 +2166,7 @@ static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries,
     l.bcur = p;   p += rnd256(buckets * 4);
     l.bsums = p;  p += rnd256(ord_n ? 256 : 0);
     l.ent2 = p;   p += rnd256((size_t)N_LIST * STRIPES * l.stripe_cap2 * 8u);
+    l.leafres = p; p += rnd256(lanes ? tn * 16 : 0);  // (the two-tier forms)
     l.end = p + 1024;
     return l;
 }
@@ -1987,6 +2191,7 @@ static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
     a.ent = reinterpret_cast<uint2*>(ws + l.ent);
     a.stripe_cap = l.stripe_cap;
     a.digest = reinterpret_cast<uint32_t*>(ws + l.digest);
+    a.leafres = reinterpret_cast<uint4*>(ws + l.leafres);
     a.ent2 = reinterpret_cast<uint2*>(ws + l.ent2);
     a.stripe_cap2 = l.stripe_cap2;
     a.pos = nullptr;
@@ -2009,10 +2214,9 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     a.v = v;
     a.total_nodes = total_nodes;
     a.shallow = shallow_levels(v.n, v.n_roots, v.nodes_len, dedup_levels);
-    // Which form the shallow tier takes: the ordered one wherever an order by (root, key prefix) is to be had -- one root: the
-    // library's own counting sort; the caller's word for it otherwise --, the group tables for the rest.
-    const bool own_order = !tune.table_form && !tune.key_ordered && v.n_roots == 1u;
-    const bool ordered = own_order || (!tune.table_form && tune.key_ordered);
+    // Which form the shallow tier takes: the group tables, or -- asked for -- an ordered one (VerifyTune).
+    const bool own_order = tune.own_order && !tune.key_ordered && v.n_roots == 1u;
+    const bool ordered = own_order || tune.key_ordered;
     // (the counting sort is on <= ORDER_MAX_BITS key bits: levels beyond that many nibbles would find their groups scattered
     // over a bucket -- sound, but nothing deduplicated: left to the deep tier unless the split is forced)
     if (own_order && dedup_levels < 0 && a.shallow > ORDER_MAX_BITS / 4u + 1u) a.shallow = ORDER_MAX_BITS / 4u + 1u;
@@ -2051,7 +2255,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
             hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);
         else if (total_nodes)
             hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, wpl, deep_levels);
-        hipLaunchKernelGGL(walk_kernel<true>, dim3(pg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((walk_kernel<true, false>), dim3(pg), dim3(256), 0, st, a);
         return hipGetLastError();
     }
     // ---- two tiers ----
@@ -2064,6 +2268,8 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     // An otherwise unused dynamic LDS allocation caps the hash workgroups per CU while the shallow tier's memory-bound
     // kernels run next to them (VerifyTune::hash_lds): a fourth hash wave per SIMD would take the registers they need
     const uint32_t hash_lds = two ? tune.hash_lds : 0u;
+    // An otherwise unused dynamic LDS allocation caps the hash workgroups per CU while the shallow tier's memory-bound
+    // kernels run next to them (VerifyTune::hash_lds): a fourth hash wave per SIMD would take the registers they need
     // the deep role: no inputs but the witness, so it starts at once -- on the helper stream, next to the shallow tier
     if (two) {
         if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;  // (behind the previous launch's walk)
@@ -2083,15 +2289,25 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
             if (three && (e = hipStreamWaitEvent(side->stream2, side->fork, 0)) != hipSuccess) return e;
         }
-        const uint32_t lds = tune.diag == 3u ? hash_lds : 0u;
         if (tune.diag & 1u) {
+            const uint32_t lds = (tune.diag == 3u || std::getenv("PHANT_DIAG_CAP")) ? hash_lds : 0u;  // (capped only where something memory-bound runs beside it)
             hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), lds, hs, a, wpl, deep_levels);
             hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), lds ? lds + 8192u : 0u, st, a);
-            if (ordered) hipLaunchKernelGGL(hash_list_kernel<1>, dim3(list_wgs < 256u ? list_wgs : 256u), dim3(256), 0, st, a);
+            if (ordered) hipLaunchKernelGGL(hash_late_kernel, dim3(list_wgs < 256u ? list_wgs : 256u), dim3(256), 0, st, a);
         }
-        if (tune.diag & 2u)
-            hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 0, h2, reinterpret_cast<const uint4*>(v.nodes),
-                               (size_t)(v.nodes_len / 16u), tune.diag_sink);
+        if (tune.diag & 2u) {
+            // (PHANT_DIAG_STREAM_WGS: how much the stream keeps in flight -- 256 lanes x 8 loads x 16 bytes per workgroup)
+            static const uint32_t wgs = std::getenv("PHANT_DIAG_STREAM_WGS") ? (uint32_t)std::atoi(std::getenv("PHANT_DIAG_STREAM_WGS")) : 2048u;
+            static const uint32_t region_mb = std::getenv("PHANT_DIAG_STREAM_MB") ? (uint32_t)std::atoi(std::getenv("PHANT_DIAG_STREAM_MB")) : 0u;
+            size_t mask = ~(size_t)0;
+            if (region_mb) {
+                size_t r16 = (size_t)region_mb << 16;  // 16-byte elements
+                while (r16 > v.nodes_len / 16u) r16 >>= 1;
+                mask = r16 ? r16 - 1u : 0u;
+            }
+            hipLaunchKernelGGL(stream_read_kernel, dim3(wgs ? wgs : 1u), dim3(256), 0, h2, reinterpret_cast<const uint4*>(v.nodes),
+                               (size_t)(v.nodes_len / 16u), tune.diag_sink, mask);
+        }
         if (two) {
             if ((e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
@@ -2102,6 +2318,9 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         }
         return hipGetLastError();
     }
+    // the ordered forms: the leaves, decoded ahead of the walk, on the deep tier's stream, behind it (the staging -- 58 KB of LDS per
+    // 256 lanes -- would wait for room next to the hash workgroups anyway; the hashing of the listed nodes outlasts the deep tier)
+    auto leaf_launch = [&](hipStream_t s) { hipLaunchKernelGGL(leaf_kernel, dim3((v.n + LEAF_LANES - 1u) / LEAF_LANES), dim3(LEAF_LANES), 0, s, a); };
     if (!ordered) {
         // (propose_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep
         // role's waves fill every slot they are given the moment they start)
@@ -2113,12 +2332,18 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         mark(3);  // (no heads_kernel and nothing hashed ahead of the comparison in this form: stages 2 and 3 are empty)
         mark(4);
         if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), 0, st, a);
+        {
+            static const uint32_t dedup_lds = std::getenv("PHANT_DEDUP_LDS_KB") ? (uint32_t)std::atoi(std::getenv("PHANT_DEDUP_LDS_KB")) * 1024u : 0u;  // EXPLORATION
+            hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), two ? dedup_lds : 0u, st, a);
+        }
         mark(5);
         hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, st, a);
         mark(6);
         if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+        // (the walk decodes the leaves itself here: decoded ahead -- leaf_kernel, as in the ordered forms -- the walk is 8 us
+        // shorter and the launch no shorter, and the extra kernel costs 2.5 % of the throughput with two launches in flight:
+        // profiles/r5_explore/NOTES.md)
+        hipLaunchKernelGGL((walk_kernel<false, false>), dim3(pg), dim3(256), 0, st, a);
         mark(7);
         if (e != hipSuccess) return e;
         return hipGetLastError();
@@ -2138,14 +2363,20 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         // (the first kernel of the chain is handed to the device first, then the deep role, whose waves fill every slot they are
         // given the moment they start; with the tiers serialised for per-stage times the deep role runs behind the order pass)
         hipLaunchKernelGGL(order_hist_kernel, dim3(pg), dim3(256), 0, st, a, bcnt);
-        if (!kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+        if (!kev) {
+            hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+            if (two) leaf_launch(hs);
+        }
         if (tiles > 1u) hipLaunchKernelGGL(order_sums_kernel, dim3(tiles), dim3(256), 0, st, bcnt, bsums, buckets);
         hipLaunchKernelGGL(order_scan_kernel, dim3(tiles), dim3(256), 0, st, bcnt, bsums, bstart, bcur, buckets, v.n);
         hipLaunchKernelGGL(order_scatter_kernel, dim3(pg), dim3(256), 0, st, a, bcur, pos);
         a.bstart = bstart;
     } else {
         hipLaunchKernelGGL(order_identity_kernel, dim3(pg), dim3(256), 0, st, a, pos);
-        if (!kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+        if (!kev) {
+            hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+            if (two) leaf_launch(hs);
+        }
     }
     mark(1);
     if (kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
@@ -2158,23 +2389,22 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     // the group heads: listed from the keys alone and hashed NEXT TO the comparison
     hipLaunchKernelGGL(heads_kernel, dim3(sg), dim3(256), 0, h2, a);
     mark(3);
-    {
-        static const int list_kb = std::getenv("PHANT_LIST_LDS_KB") ? std::atoi(std::getenv("PHANT_LIST_LDS_KB")) : -1;  // EXPLORATION
-        const uint32_t list_lds = list_kb >= 0 ? (uint32_t)list_kb * 1024u : (hash_lds ? hash_lds + 8192u : 0u);
-        hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), two ? list_lds : 0u, h2, a);
-    }
+    hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, h2, a);
     mark(4);
     if (three && (e = hipEventRecord(side->join2, side->stream2)) != hipSuccess) return e;
-    const uint32_t cg = (uint32_t)((units + 3u) / 4u);
-    hipLaunchKernelGGL(compare_kernel, dim3(cg), dim3(256), 0, st, a, (uint32_t)((v.n + CHUNK - 1u) / CHUNK));
+    const uint32_t n_chunks = (uint32_t)((v.n + CHUNK - 1u) / CHUNK);
+    static const uint32_t cmp_levels = std::getenv("PHANT_CMP_LEVELS") ? (uint32_t)std::atoi(std::getenv("PHANT_CMP_LEVELS")) : 1u;  // EXPLORATION
+    const uint32_t per_wave = cmp_levels ? cmp_levels : 1u, groups = (a.shallow + per_wave - 1u) / per_wave;
+    hipLaunchKernelGGL(compare_kernel, dim3((uint32_t)(((uint64_t)n_chunks * groups + 3u) / 4u)), dim3(256), 0, st, a, n_chunks, per_wave, groups);
     mark(5);
     // what the comparison left: a thin list (damaged copies and their successors) -- a bounded grid that strides over it
     const uint32_t late_wgs = list_wgs < 256u ? list_wgs : 256u;
-    hipLaunchKernelGGL(hash_list_kernel<1>, dim3(late_wgs), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(hash_late_kernel, dim3(late_wgs), dim3(256), 0, st, a);
     mark(6);
     if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
     if (three && (e = hipStreamWaitEvent(st, side->join2, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+    if (!two) leaf_launch(st);
+    hipLaunchKernelGGL((walk_kernel<false, true>), dim3(pg), dim3(256), 0, st, a);
     mark(7);
     if (e != hipSuccess) return e;
     return hipGetLastError();

@@ -26,6 +26,8 @@
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),             \
                                      (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #define PHANT_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// every LDS read of the wave has delivered (a buffer the wave has read may be handed to the DMA engine again)
+#define PHANT_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // A wave's lanes hand bytes to each other through LDS (the node-per-half-wave kernels: sixteen lanes store a child each, all
 // lanes then read rate words): the stores of every lane are visible to every lane of the SAME wave behind this point.  The
@@ -37,3 +39,7 @@
         __builtin_amdgcn_wave_barrier();                            \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
     } while (0)
+
+// LDS whose size the LAUNCH names (the compiler must not know it: a kernel's register budget follows from its launch bounds, not
+// from how many workgroups its LDS lets a CU hold)
+#define PHANT_DYNAMIC_LDS(type, name) extern __shared__ type name[]

@@ -115,12 +115,12 @@ def LEVELS(n):  # PHANT_CTX_DEDUP_LEVELS(n): the two-tier pipeline with the firs
 
 # "flat" = the two-tier pipeline with its tier split chosen from the batch size; levelsN force the split (1: only the
 # root nodes are deduplicated, 16: every level, nothing left for the in-place tier)
-# "+table": the shallow tier through its group tables whatever the batch (the form a multi-root batch takes anyway);
-# "+caller": PHANT_CTX_VERIFY_KEY_ORDERED -- the ordered form on the caller's order as it is, which the tests' batches
-# are NOT in: nothing may depend on the promise
-KEY_ORDERED, TABLE = 8, 16
+# "+ordered" / "+caller": the ordered forms of the shallow tier (A/B) -- on the library's own order (batches against one root; the
+# others take the tables) / on the caller's order as it is (PHANT_CTX_VERIFY_KEY_ORDERED), which the tests' batches are NOT in:
+# nothing may depend on the promise
+KEY_ORDERED, ORDERED = 8, 16
 MODES = {"flat": 0, "nodedup": NODEDUP, "fused": FUSED, "levels1": LEVELS(1), "levels3": LEVELS(3), "levels16": LEVELS(16),
-         "levels3+table": LEVELS(3) | TABLE, "levels16+table": LEVELS(16) | TABLE, "levels3+caller": LEVELS(3) | KEY_ORDERED,
+         "levels3+ordered": LEVELS(3) | ORDERED, "levels16+ordered": LEVELS(16) | ORDERED, "levels3+caller": LEVELS(3) | KEY_ORDERED,
          "levels16+caller": LEVELS(16) | KEY_ORDERED}
 
 

@@ -10,6 +10,9 @@
 #include <cstring>
 #define PHANT_LDS_DMA16(gsrc, lds_wave_base) std::memcpy((uint8_t*)(lds_wave_base) + 16u * (threadIdx.x & 63u), (gsrc), 16)
 #define PHANT_WAIT_VMEM() ((void)0)
+#define PHANT_WAIT_LDS() ((void)0)
 // lanes are fibers here and meet at cross-lane operations only: a ballot is the rendezvous (every lane's LDS stores are done
 // before any lane goes on)
 #define PHANT_WAVE_LDS_SYNC() ((void)__ballot(1))
+// (workgroups run one after the other here: one static buffer of the largest size any launch asks for)
+#define PHANT_DYNAMIC_LDS(type, name) static type name[65536 / sizeof(type)]

@@ -154,12 +154,11 @@ def test_config3_forced_tier_split_dry_run():
     r = line["roofline"]
     assert r["valu"]["peak"] > 0 and "this run" in r["valu"]["peak_source"]
     k = r["kernels"]
-    # (one root: the ordered form -- the library's own order pass, the group heads hashed next to the comparison)
-    assert k["form"] == "ordered"
-    assert k["dedup_levels"] == 3 and all(k[n]["ms"] > 0 for n in ("order_pass", "hash_deep_kernel", "heads_kernel", "compare_kernel",
-                                                                    "hash_list_kernel<heads>", "walk_kernel"))
-    assert k["hash_deep_kernel"]["bound"] == "valu" and k["compare_kernel"]["bound"] == "hbm"
-    assert k["hash_deep_kernel"]["keccak_f"] + k["hash_list_kernel<heads>"]["keccak_f"] == r["keccak_f_run"]
+    assert k["form"] == "table"
+    assert k["dedup_levels"] == 3 and all(k[n]["ms"] > 0 for n in ("propose_kernel", "hash_deep_kernel", "dedup_kernel",
+                                                                    "hash_list_kernel", "walk_kernel"))
+    assert k["hash_deep_kernel"]["bound"] == "valu" and k["dedup_kernel"]["bound"] == "hbm"
+    assert k["hash_deep_kernel"]["keccak_f"] + k["hash_list_kernel"]["keccak_f"] == r["keccak_f_run"]
     assert "derived" in line["config"]["parity_basis"]
     # (no committed PMC measurement is of a 200-proof batch: nothing is quoted)
     assert r["traffic"] is None

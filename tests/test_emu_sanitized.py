@@ -72,3 +72,27 @@ def test_ctx_and_witness_lifecycles_do_not_leak(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and "no leaks expected" in r.stdout, (r.stdout + r.stderr)[-4000:]
+
+
+def test_host_allocation_failures_come_back_as_oom(tmp_path):
+    """tests/native/oom_check.cpp against the sanitized emulated library: with the k-th host allocation failing, for every k, the
+    entry points whose host side grows std::vector / std::string answer PHANT_E_OOM -- no abort, no exception across the C
+    boundary, nothing half built left behind (LeakSanitizer) -- and the library goes on working."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    try:
+        lib = emu.build(sanitize=True)
+    except RuntimeError as e:
+        pytest.skip(str(e)[-200:])
+    lib_dir = os.path.dirname(lib)
+    exe = str(tmp_path / "oom_check")
+    r = subprocess.run(["g++", "-std=c++17", "-g", "-fsanitize=address,undefined", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "native", "oom_check.cpp"), "-L", lib_dir, "-lphant_emu_san",
+                        "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:allocator_may_return_null=1", HIPEMU_DEVICES="2"))
+    assert r.returncode == 0 and "none aborted" in r.stdout, (r.stdout + r.stderr)[-4000:]

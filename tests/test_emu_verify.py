@@ -17,7 +17,7 @@ def _emulated_backend():
 
 # levelsN = the two-tier pipeline with its tier split forced (tests/emu.py): 1 = only root nodes deduplicated, 16 = every
 # level (nothing left for the in-place tier); "flat" chooses it from the batch size
-@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+table", "levels16+table",
+@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+ordered", "levels16+ordered",
                                         "levels3+caller", "levels16+caller"])
 def M(request):
     import phant_amd

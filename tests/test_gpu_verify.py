@@ -26,16 +26,16 @@ class _Mode:
         return self._mod.verify_batch_dev(*a, ctx=self._ctx, **k)
 
 
-# "+table" / "+caller": the shallow tier through its group tables whatever the batch / the ordered form on the caller's order as it
-# is (PHANT_CTX_VERIFY_KEY_ORDERED) -- which these batches are NOT in: nothing may depend on the promise
-@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+table", "levels16+table",
+# "+ordered" / "+caller": the ordered forms of the shallow tier (A/B) -- on the library's own order (one root) / on the caller's order
+# as it is (PHANT_CTX_VERIFY_KEY_ORDERED), which these batches are NOT in: nothing may depend on the promise
+@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+ordered", "levels16+ordered",
                                         "levels3+caller", "levels16+caller"])
 def M(request):
     import phant_amd
     mode, _, form = request.param.partition("+")
     ctx = phant_amd.Context(verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"),
                             dedup_levels=(int(mode[6:]) if mode.startswith("levels") else None),
-                            key_ordered=(form == "caller"), verify_table=(form == "table"))
+                            key_ordered=(form == "caller"), verify_ordered=(form == "ordered"))
     yield _Mode(phant_amd.mpt, ctx, request.param)
     ctx.close()
 

@@ -22,15 +22,15 @@ except Exception as e:
 P
 }
 for round in 1 2; do
-  line ordered_$round -- --no-cpu-baseline --no-strong
-  line table_$round PHANT_VERIFY_TABLE=1 -- --no-cpu-baseline --no-strong
+  line table_$round -- --no-cpu-baseline --no-strong
+  line ordered_$round PHANT_VERIFY_ORDERED=1 -- --no-cpu-baseline --no-strong
   line sorted_caller_$round PHANT_VERIFY_KEY_ORDERED=1 -- --no-cpu-baseline --no-strong --proof-order sorted
 done
-line ordered_streams1 -- --no-cpu-baseline --no-strong --streams 1
-line ordered_streams4 -- --no-cpu-baseline --no-strong --streams 4
+line ordered_streams1 PHANT_VERIFY_ORDERED=1 -- --no-cpu-baseline --no-strong --streams 1
+line ordered_streams4 PHANT_VERIFY_ORDERED=1 -- --no-cpu-baseline --no-strong --streams 4
 line config4_default -- --no-cpu-baseline --workload config4
 k=0
-for setting in "A=1" "PHANT_VERIFY_TABLE=1" "PHANT_VERIFY_SERIAL=1"; do
+for setting in "A=1" "PHANT_VERIFY_ORDERED=1" "PHANT_VERIFY_ORDERED=1 PHANT_VERIFY_SERIAL=1"; do
   k=$((k+1)); rm -rf /tmp/pw$k
   ( cd /tmp && timeout 200 env $setting rocprofv3 --kernel-trace --output-format csv -d /tmp/pw$k -o p -- python $R/tools/probe_walk.py > "$OUT/probe$k.log" 2>&1 )
   echo "== $setting"; python tools/probe_walk_report.py /tmp/pw$k | tee "$OUT/timeline$k.txt" | cut -c1-420 | tail -3
