@@ -765,7 +765,7 @@ def extra_legs(args):
     import subprocess
     legs = [("config2", ["--workload", "config2", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
             ("mptize_1M_keys", ["--workload", "mptize", "--keys", "1000000", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
-            ("config5_8_blocks", ["--workload", "config5", "--steps", "2", "--warmup", "1", "--cpu-seconds", "3"])]
+            ("config5_16_blocks", ["--workload", "config5", "--steps", "4", "--warmup", "2", "--cpu-seconds", "3"])]
     out, t_end = {}, time.time() + args.extra_seconds
     for name, argv in legs:
         left = t_end - time.time()

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -142,6 +143,7 @@ int32_t phant_device_count(void) {
     return n;
 }
 
+void phant_ctx_destroy(phant_ctx* c);
 int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     if (!out) return PHANT_E_INVALID_ARG;
     *out = nullptr;
@@ -170,6 +172,12 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PHANT_E_NO_DEVICE;
     phant_ctx* c = new (std::nothrow) phant_ctx();
     if (!c) return PHANT_E_OOM;
+    struct Holder {  // (destroyed on every way out but the last: also when something below runs out of host memory)
+        phant_ctx* c;
+        ~Holder() {
+            if (c) phant_impl::phant_ctx_destroy(c);
+        }
+    } holder{c};
     c->device = dev;
     c->verify_fused = fused;
     c->dedup_levels = dedup_levels;
@@ -197,25 +205,20 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         c->stream = (hipStream_t)stream;  // nullptr = the default stream
     } else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete c;
+            c->stream = nullptr;
             return PHANT_E_DEVICE;
         }
         c->own_stream = true;
     }
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
-        phant_ctx_destroy(c);
-        return PHANT_E_DEVICE;
-    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return PHANT_E_DEVICE;
     c->tune.last_shallow = &c->last_shallow;
     c->tune.last_form = &c->last_form;
     if (c->tune.serial) {  // diagnostics: events around every kernel of a two-tier launch (phant_verify_kernel_ms)
         for (hipEvent_t& e : c->kev)
-            if (hipEventCreate(&e) != hipSuccess) {
-                phant_ctx_destroy(c);
-                return PHANT_E_DEVICE;
-            }
+            if (hipEventCreate(&e) != hipSuccess) return PHANT_E_DEVICE;
         c->tune.kernel_ev = c->kev;
     }
+    holder.c = nullptr;
     *out = c;
     return PHANT_OK;
 }
@@ -974,8 +977,8 @@ int32_t phant_witness_parse_json_mt(const char* json, uint64_t len, uint32_t thr
     if (err && err_cap) err[0] = 0;
     if (!out || (!json && len)) return PHANT_E_INVALID_ARG;
     *out = nullptr;
-    phant_witness* w = new (std::nothrow) phant_witness();
-    if (!w) return PHANT_E_OOM;
+    std::unique_ptr<phant_witness> w(new (std::nothrow) phant_witness());  // (owned here until handed out: a parse that runs out of
+    if (!w) return PHANT_E_OOM;                                            //  memory half way unwinds through this function)
     std::string msg;
     const bool parsed = threads == 1 ? phant::witness_parse_json(json, (size_t)len, w->w, msg)
                                      : phant::witness_parse_json_mt(json, (size_t)len, threads, w->w, msg);
@@ -984,10 +987,9 @@ int32_t phant_witness_parse_json_mt(const char* json, uint64_t len, uint32_t thr
             std::strncpy(err, msg.c_str(), err_cap - 1);
             err[err_cap - 1] = 0;
         }
-        delete w;
         return PHANT_E_INVALID_ARG;
     }
-    *out = w;
+    *out = w.release();
     return PHANT_OK;
 }
 
@@ -995,7 +997,7 @@ int32_t phant_witness_index_json(const char* json, uint64_t len, uint32_t thread
                                  uint32_t err_cap) {
     if (!out || (!json && len)) return PHANT_E_INVALID_ARG;
     *out = nullptr;
-    phant_witness* w = new (std::nothrow) phant_witness();
+    std::unique_ptr<phant_witness> w(new (std::nothrow) phant_witness());
     if (!w) return PHANT_E_OOM;
     std::string msg;
     if (!phant::witness_index_json(json, (size_t)len, threads, w->w, msg)) {
@@ -1003,10 +1005,9 @@ int32_t phant_witness_index_json(const char* json, uint64_t len, uint32_t thread
             std::strncpy(err, msg.c_str(), err_cap - 1);
             err[err_cap - 1] = 0;
         }
-        delete w;
         return PHANT_E_INVALID_ARG;
     }
-    *out = w;
+    *out = w.release();
     return PHANT_OK;
 }
 

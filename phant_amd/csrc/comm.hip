@@ -255,6 +255,7 @@ namespace phant_impl {
 int32_t guard_failed(phant_ctx* c, int32_t code) noexcept;  // (capi.hip)
 
 
+void phant_comm_destroy(phant_comm* c);
 int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t flags, phant_comm** out) {
     if (!out) return PHANT_E_INVALID_ARG;
     *out = nullptr;
@@ -269,11 +270,18 @@ int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t f
     if (n_devices > 64) return refuse(PHANT_E_INVALID_ARG, "comm_create: more than 64 devices");
     phant_comm* c = new (std::nothrow) phant_comm();
     if (!c) return refuse(PHANT_E_OOM, "comm_create: out of memory");
+    struct Holder {  // (destroyed on every way out but the last: also when something below runs out of host memory)
+        phant_comm* c;
+        ~Holder() {
+            if (c) phant_impl::phant_comm_destroy(c);
+        }
+    } holder{c};
+    c->ctx.reserve(n_devices);  // (a ctx that exists is in the list: nothing can fail between its creation and its push_back)
+    c->devices.reserve(n_devices);
     for (uint32_t r = 0; r < n_devices; ++r) {
         const int d = devices ? devices[r] : (int)r;
         for (int prev : c->devices)
             if (prev == d) {  // (RCCL cannot put one device into a communicator twice)
-                phant_comm_destroy(c);
                 return refuse(PHANT_E_INVALID_ARG, "comm_create: device " + std::to_string(d) + " listed twice");
             }
         phant_opts o;
@@ -284,7 +292,6 @@ int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t f
         phant_ctx* x = nullptr;
         const int32_t rc = phant_ctx_create(&o, &x);
         if (rc != PHANT_OK) {
-            phant_comm_destroy(c);
             return refuse(rc, "comm_create: no ctx on device " + std::to_string(d) + " (needs a gfx950 device)");
         }
         c->ctx.push_back(x);
@@ -293,7 +300,6 @@ int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t f
     if (n_devices > 1) {
         if (!load_rccl(c->api, c->err)) {
             const std::string why = "comm_create: " + c->err;
-            phant_comm_destroy(c);
             return refuse(PHANT_E_UNSUPPORTED, why);
         }
         c->rccl.assign(n_devices, nullptr);
@@ -301,12 +307,12 @@ int32_t phant_comm_create(const int32_t* devices, uint32_t n_devices, uint32_t f
         if (nrc != ncclSuccess) {
             const std::string why = std::string("comm_create: ncclCommInitAll: ") + (c->api.error_string ? c->api.error_string(nrc) : "error");
             c->rccl.clear();
-            phant_comm_destroy(c);
             return refuse(PHANT_E_DEVICE, why);
         }
         c->have_rccl = true;
     }
     c->shards.resize(n_devices);
+    holder.c = nullptr;
     *out = c;
     return PHANT_OK;
 }

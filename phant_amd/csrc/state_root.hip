@@ -306,6 +306,10 @@ int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, Dev
     uint64_t* d_lvoff = ws.io.take<uint64_t>(m1);
     uint8_t* d_sroots = ws.io.take<uint8_t>(32 * (size_t)n);
     uint32_t* d_scan = ws.io.take<uint32_t>(scan_entries);
+    if (ws.io.overflowed) {  // (a sizing bug upstream: never a kernel or a copy on memory behind the allocation)
+        err = "state-root arena sized too small (internal)";
+        return PHANT_E_DEVICE;
+    }
     // what the host reads back on the way goes through the ctx's pinned mailbox (a copy into pageable memory is ~25 us a piece);
     // the words behind the trie builder's
     SR_TRY(ws.ensure_mailbox());
@@ -351,6 +355,10 @@ int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, Dev
     out.val_off = ws.io.take<uint64_t>(n1);
     out.seg = ws.io.take<uint32_t>(17);
     out.root = ws.io.take<uint8_t>(32);
+    if (ws.io.overflowed) {  // (a sizing bug upstream: never a kernel or a copy on memory behind the allocation)
+        err = "state-root arena sized too small (internal)";
+        return PHANT_E_DEVICE;
+    }
     SR_TRY(launch_keccak256_fixed(d_addrs, 20, 20, n, d_ha, st));
     SR_TRY(launch_keccak256_var(d_code, d_code_off, n, d_hc, st));
     uint32_t* d_aorder = nullptr;
@@ -405,6 +413,10 @@ int32_t state_leaves_dev(Workspaces& ws, hipStream_t st, const uint8_t* addrs, c
     uint8_t* d_skeys_in = ws.io.take<uint8_t>(32 * (size_t)m + 16);
     uint8_t* d_svals_in = ws.io.take<uint8_t>(32 * (size_t)m + 16);
     uint32_t* d_slot_first = ws.io.take<uint32_t>(n1);
+    if (ws.io.overflowed) {  // (a sizing bug upstream: never a kernel or a copy on memory behind the allocation)
+        err = "state-root arena sized too small (internal)";
+        return PHANT_E_DEVICE;
+    }
     SR_TRY(hipMemcpyAsync(d_addrs, addrs, 20 * (size_t)n, hipMemcpyHostToDevice, st));
     SR_TRY(hipMemcpyAsync(d_nonces, nonces, 8 * (size_t)n, hipMemcpyHostToDevice, st));
     SR_TRY(hipMemcpyAsync(d_bal, balances, 32 * (size_t)n, hipMemcpyHostToDevice, st));

@@ -1327,6 +1327,10 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         t.counters = ws.t1.take<uint32_t>(N_COUNTERS);
         t.depth_cursor = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
         t.cursor = ws.t1.take<unsigned long long>(1);
+        if (ws.t1.overflowed || !t.cursor) {  // (a sizing bug upstream: never a kernel on memory behind the allocation)
+            err = "trie workspace sized too small (internal)";
+            return PHANT_E_DEVICE;
+        }
     }
 
     // head (roots, counters, a forest's start flags) -> [first_flag] -> lcp (+ markers, + the min-tree's padding): three or two
@@ -1380,6 +1384,10 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     t.slot_len = ws.t2.take<uint8_t>((size_t)n_rep * 16);
     t.scratch = ws.t2.take<uint8_t>(cap);
     t.scratch_cap = cap;
+    if (ws.t2.overflowed || !t.scratch) {
+        err = "trie slot tables sized too small (internal)";
+        return PHANT_E_DEVICE;
+    }
     // (order_kernel also clears the slot lengths and forms the bins' starts from the histogram it finds in t.counters)
     // A bin's slot class (branch_kernel): four blocks unless the bin is crowded (more workgroups than the chip holds at once) and
     // its mean fan-out says that most of its nodes fit less; what does not fit is run through the four-block class behind it.
@@ -1389,7 +1397,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         const uint32_t c = cnt[8 + d];
         if (!c) return;
         static const bool no_coop = std::getenv("PHANT_TRIE_NO_COOP") != nullptr;  // (A/B)
-        static const uint32_t coop_max = std::getenv("PHANT_TRIE_COOP_MAX") ? (uint32_t)std::atoi(std::getenv("PHANT_TRIE_COOP_MAX")) : COOP_MAX_NODES;  // (A/B)
+        static const uint32_t coop_max = std::getenv("PHANT_TRIE_COOP_MAX") ? (uint32_t)std::min(std::max(std::atoi(std::getenv("PHANT_TRIE_COOP_MAX")), 0), 1 << 20) : COOP_MAX_NODES;  // (A/B)
         if (c <= coop_max && !no_coop && !force_blocks) {
             hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 7u) / 8u), dim3(256), 0, on, t, depth_begin[d], c);
             return;
@@ -1437,12 +1445,21 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     }
     t.deep_from = deep_from;
     if (n_rep) hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
+    // (whatever fails behind the fork: the helper stream is waited for before the arenas can be handed to another call)
+    struct SideGuard {
+        hipStream_t s = nullptr;
+        ~SideGuard() {
+            if (s) (void)hipStreamSynchronize(s);
+        }
+    } side_guard;
     if (deep_from >= 0) {
         TB_TRY(ws.ensure_side());
-        static const uint32_t side_lds = std::getenv("PHANT_TRIE_SIDE_LDS") ? (uint32_t)std::atoi(std::getenv("PHANT_TRIE_SIDE_LDS")) : SIDE_LEAF_LDS;
+        // (a leaf workgroup's static LDS + this must stay within the 64 KiB a launch gets without opting in)
+        static const uint32_t side_lds = std::getenv("PHANT_TRIE_SIDE_LDS") ? (uint32_t)std::min(std::max(std::atoi(std::getenv("PHANT_TRIE_SIDE_LDS")), 0), 65536 - 4 * 256 * (int)LEAF_STAGE_DW) : SIDE_LEAF_LDS;
         hipLaunchKernelGGL(leaf_kernel, dim3(std::min(blocks(n), 256u)), dim3(256), 0, st, t, t.deep_leaves, t.deep_count);
         TB_TRY(hipEventRecord(ws.side_fork, st));
         TB_TRY(hipStreamWaitEvent(ws.side, ws.side_fork, 0));
+        side_guard.s = ws.side;
         for (int d = MAX_DEPTH_BINS - 1; d >= deep_from; --d) launch_bin(d, ws.side);
         TB_TRY(hipEventRecord(ws.side_join, ws.side));
         hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), side_lds, st, t, nullptr, nullptr);
@@ -1504,6 +1521,10 @@ int32_t trie_forest_host(Workspaces& ws, hipStream_t st, const uint8_t* keys, co
     uint8_t* d_roots = ws.io.take<uint8_t>((size_t)n_tries * 32);
     uint8_t* d_enc = ws.io.take<uint8_t>((size_t)n_tries * root_enc_cap + 4);
     uint32_t* d_enc_len = ws.io.take<uint32_t>(n_tries);
+    if (ws.io.overflowed) {  // (a sizing bug upstream: never a kernel or a copy on memory behind the allocation)
+        err = "trie staging arena sized too small (internal)";
+        return PHANT_E_DEVICE;
+    }
     const bool want_enc = root_enc_out && root_enc_len_out && root_enc_cap;
     // Small calls (the tries of an ordinary block): the five input arrays are laid out in the pinned mirror of the arena and cross
     // the bus in one copy; the offsets are rebased in place there (Workspaces::stage).  The results go the other way without a
