@@ -1185,7 +1185,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)
     if rccl_world is not None:
         line["rccl_world"] = rccl_world
-    if rank == 0 and world == 1 and args.workload == "config3" and not args.no_extra and args.proofs == 100_000:
+    if (rank == 0 and world == 1 and args.workload == "config3" and not args.no_extra and args.proofs == 100_000 and
+            args.verify_mode == "flat" and not args.no_strong and not args.no_cpu_baseline and args.proof_order == "random"):
         # (only the default-sized headline run: the sweeps and A/B scripts call with other sizes or --no-extra)
         line["extra"] = extra_legs(args)
         line["extra_keys"] = sorted(line["extra"])

@@ -183,7 +183,6 @@ struct Args {
     uint4* leafres;          // total_nodes: for the LAST node j of a proof {status or LEAF_NONE, value_len, value_off lo, hi}: what the
                              // walk ends in if every node in front of j turns out to be a canonical full branch whose hash matches
                              // (leaf_kernel; read by walk_kernel<.., true>)
-    uint32_t dbg;            // EXPLORATION ONLY (PHANT_VERIFY_DBG): parts of compare_kernel switched off, for their cost
     uint32_t* hdr;           // header: HDR_*; cleared per call (propose_kernel / zero_kernel)
     uint32_t* digest;        // total_nodes x 8
     uint8_t* nstat;          // total_nodes: NS_* of the node, written by the lane that hashed it
@@ -720,120 +719,78 @@ __global__ void __launch_bounds__(256) heads_kernel(const Args a) {
     list_append<0>(a, cls, j, p, s_cnt, s_base);
 }
 
-// wave = a chunk of CHUNK consecutive positions, its S levels one after the other; see the head of this section.
-// One stream of S x 64 node loads per wave, RING of them in flight and never drained: while the last steps of a level are compared,
-// the first nodes of the next level are already on their way (their offsets were requested when the level began).  No barrier, no
-// LDS: a wave runs on its own, whatever its neighbours do.
-constexpr uint32_t RING = 8;
-static_assert(64u % RING == 0u, "a level is a whole number of ring turns");
-// `per_wave`: levels a wave takes (groups = ceil(S / per_wave) waves per chunk): more waves in flight against fewer set-ups
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) compare_kernel(const Args a, const uint32_t chunks, const uint32_t per_wave,
-                                                                                               const uint32_t groups) {
+// wave = (chunk, level); see the head of this section
+__global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const Args a, const uint32_t chunks) {
+    __shared__ uint32_t s_cnt[4][N_LIST];
+    __shared__ uint32_t s_base[N_LIST];
     beside_the_hashing();
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const uint32_t chunk = unit / groups;
-    if (chunk >= chunks) return;
-    const uint32_t S = a.shallow, i1 = chunk * CHUNK;
-    const uint32_t d_from = (unit - chunk * groups) * per_wave, d_to = d_from + per_wave < S ? d_from + per_wave : S;
-    // the lane's position; lane 0 carries, level by level, the node position i1's run continues (if i1 does not open one itself)
-    const uint32_t i = i1 + (lane ? lane - 1u : 0u);
-    const bool real = lane >= 1u && i < a.v.n;
-    enum : uint32_t { M_LEN = 0xffffu, M_PART = 1u << 16, M_HEAD = 1u << 17, M_ACT = 1u << 18 };
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (tid < 4u * N_LIST) (&s_cnt[0][0])[tid] = 0u;
+    const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (tid >> 6));
+    const uint32_t chunk = unit / a.shallow, d = unit - chunk * a.shallow;
+    // the lane's position; lane 0 looks at lane 1's: it carries the node that position's run continues, if it is not a head itself
+    const uint32_t i = chunk * CHUNK + (lane ? lane - 1u : 0u);
 
-    // ---- the position's record, boiled down: first node; info = levels that open a run | reachable levels << 16 | root index usable << 24 ----
-    enum : uint32_t { I_END_SHIFT = 16, I_ROOT_OK = 1u << 24 };
-    uint32_t first = 0, info = 0;
-    if (real) {
+    // ---- what the lane's position is: meta = len (<= 768) | takes part | opens a run ----
+    enum : uint32_t { M_LEN = 0xffffu, M_PART = 1u << 16, M_HEAD = 1u << 17 };
+    uint32_t meta = 0, j = 0, p = 0, len = 0;
+    uint64_t b = 0;
+    bool real = false, act = false;
+    if (chunk < chunks && i < a.v.n) {
         const PosInfo me = load_pos_info(a.pos + i), prev = load_pos_info(a.pos + (i ? i - 1u : 0u));
-        first = me.first;
-        if (me.end == POS_BROKEN) a.hdr[HDR_PFN_BROKEN] = 1u;  // (node ranges of other proofs may overlap: the walk trusts nothing then)
-        else info = (me.end < S ? me.end : S) << I_END_SHIFT;
-        if (me.root < a.v.n_roots) info |= I_ROOT_OK;
-        for (uint32_t d = 0; d < S; ++d)
-            if (key_head(a, i, d, me, prev)) info |= 1u << d;
-    }
-    // ---- lane d < S: the key head of position i1's group at level d, through the bucket table (h_meta = 0: none) ----
-    uint32_t h_meta = 0, h_j = 0;
-    uint64_t h_b = 0;
-    if (lane >= d_from && lane < d_to && a.bstart && i1 < a.v.n && 4u * lane <= a.bucket_bits && !(a.dbg & 2u)) {
-        const uint32_t d = lane;
-        const PosInfo one = load_pos_info(a.pos + i1), oprev = load_pos_info(a.pos + (i1 ? i1 - 1u : 0u));
-        if (!key_head(a, i1, d, one, oprev)) {
-            const uint32_t sh = a.bucket_bits - 4u * d;
-            const uint32_t gs = a.bstart[(bucket_of(kb_of(one), a.bucket_bits) >> sh) << sh];
-            if (gs < i1) {  // (in front of this chunk: a head inside it is met on the way)
-                const PosInfo h = load_pos_info(a.pos + gs), hprev = load_pos_info(a.pos + (gs ? gs - 1u : 0u));
-                const ShallowLane H = ordered_node(a, h, d);
-                // usable only if it is what heads_kernel lists: a node that takes part, of this group, opening its run
-                if (takes_part(H) && same_key_group(H.root, H.kb, one.root, kb_of(one), d) && key_head(a, gs, d, h, hprev)) {
-                    h_meta = M_PART | M_HEAD | H.len;
-                    h_j = H.j;
-                    h_b = a.v.node_off[H.j];
+        const ShallowLane L = ordered_node(a, me, d);
+        p = me.p;
+        j = L.j;
+        len = L.len;
+        if (key_head(a, i, d, me, prev)) meta |= M_HEAD;
+        if (takes_part(L)) {
+            meta |= M_PART | L.len;
+            b = a.v.node_off[j];
+        }
+        if (lane >= 1u) {
+            real = true;
+            act = L.act;
+            if (L.broken) a.hdr[HDR_PFN_BROKEN] = 1u;  // (node ranges of other proofs may overlap: the walk trusts nothing then)
+            if (L.act && !L.valid) a.nstat[j] = 0u;     // never hashed: says so (nobody else writes this node's state)
+        } else {
+            // the key head of position 1's group, through the bucket table
+            const bool wanted = a.bstart && (meta & M_PART) && !(meta & M_HEAD) && 4u * d <= a.bucket_bits;
+            meta = 0;
+            if (wanted) {
+                const uint32_t sh = a.bucket_bits - 4u * d;
+                const uint32_t gs = a.bstart[(bucket_of(L.kb, a.bucket_bits) >> sh) << sh];
+                if (gs < i) {  // (in front of this chunk: a head inside it is met on the way)
+                    const PosInfo h = load_pos_info(a.pos + gs), hprev = load_pos_info(a.pos + (gs ? gs - 1u : 0u));
+                    const ShallowLane H = ordered_node(a, h, d);
+                    // usable only if it is what heads_kernel lists: a node that takes part, of this group, opening its run
+                    if (takes_part(H) && same_key_group(H.root, H.kb, L.root, L.kb, d) && key_head(a, gs, d, h, hprev)) {
+                        meta = M_PART | M_HEAD | H.len;
+                        j = H.j;
+                        b = a.v.node_off[j];
+                    }
                 }
             }
         }
     }
-    const uint32_t hb_lo = (uint32_t)h_b, hb_hi = (uint32_t)(h_b >> 32);
 
-    // the lane's node of level d from its two offsets (e = node_off[first + d + 1], b = node_off[first + d]); lane 0: the level's head
-    auto describe = [&](uint32_t d, uint64_t e, uint64_t b, uint32_t& meta, uint32_t& b_lo, uint32_t& b_hi) __attribute__((always_inline)) {
-        meta = 0;
-        b_lo = (uint32_t)b;
-        b_hi = (uint32_t)(b >> 32);
-        if (d < (info >> I_END_SHIFT & 0xffu)) {  // (lane 0 and the lanes behind the batch's end: 0 levels)
-            meta = M_ACT;
-            if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
-                const uint32_t len = (uint32_t)(e - b);
-                if ((info & I_ROOT_OK) && len >= RATE && len <= CMP_MAX_LEN) meta |= M_PART | len;
-            } else {
-                a.nstat[first + d] = 0u;  // never hashed: says so (nobody else writes this node's state)
-            }
-        }
-        if (info >> d & 1u) meta |= M_HEAD;
-        // (wave-uniform lane index d: the level's head travels from lane d to lane 0)
-        const uint32_t m0 = lane_u32(h_meta, d), l0 = lane_u32(hb_lo, d), u0 = lane_u32(hb_hi, d);
-        if (lane == 0u) {
-            meta = m0;
-            b_lo = l0;
-            b_hi = u0;
-        }
-    };
-    auto offsets = [&](uint32_t d, uint64_t& e, uint64_t& b) __attribute__((always_inline)) {
-        e = b = 0;
-        if (d < (info >> I_END_SHIFT & 0xffu)) {
-            b = a.v.node_off[first + d];
-            e = a.v.node_off[first + d + 1u];
-        }
-    };
-
+    // ---- the stream: node by node, 12 bytes per lane, two trips of four loads in flight ----
+    const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32);
     const uint32_t off12 = 12u * lane;
-    uint32_t meta, b_lo, b_hi;  // this level
-    {
-        uint64_t e, b;
-        offsets(d_from, e, b);
-        describe(d_from, e, b, meta, b_lo, b_hi);
-    }
-    // a node that takes no part is "read" as the blob's first 12 bytes: readable whenever some node takes part (>= 136 bytes)
-    auto fetch = [&](uint32_t l, uint32_t fm, uint32_t flo, uint32_t fhi) __attribute__((always_inline)) -> U32x3 {
-        const uint32_t m = lane_u32(fm, l);
-        const bool part = (m & M_PART) != 0u;
-        const uint32_t ln = part ? (m & M_LEN) : 12u;
-        const uint64_t base = part ? lane_u64(flo, fhi, l) : 0ull;
-        const uint32_t o = off12 < ln - 12u ? off12 : ln - 12u;  // (lanes behind the node's end repeat its last 12 bytes)
-        return *reinterpret_cast<const U32x3*>(a.v.nodes + base + o);
-    };
-    const bool readable = a.v.nodes_len >= 12u && !(a.dbg & 1u);
-    U32x3 ring[RING];
-#pragma unroll
-    for (uint32_t u = 0; u < RING; ++u) ring[u] = readable ? fetch(u, meta, b_lo, b_hi) : U32x3{0u, 0u, 0u};
-
-    for (uint32_t d = d_from; d < d_to; ++d) {
-        const bool more = d + 1u < d_to;
+    uint32_t my_ref = 64u;  // the lane whose node this lane's node is a copy of (64: none)
+    bool late = false;      // differs from its run's reference (or found none): to be hashed, says this kernel
+    const unsigned long long parts = __ballot((meta & M_PART) != 0u);
+    if (parts) {
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(parts);  // (nothing to do behind the last node that takes part)
         U32x3 ref{0u, 0u, 0u};
         uint32_t ref_len = 0, ref_lane = 64u;
-        uint32_t my_ref = 64u;  // the lane whose node this lane's node is a copy of (64: none)
-        bool late = false;      // differs from its run's reference (or found none): to be hashed, says this kernel
+        auto fetch = [&](uint32_t l) __attribute__((always_inline)) -> U32x3 {
+            const uint32_t m = lane_u32(meta, l);
+            const bool part = (m & M_PART) != 0u;
+            const uint32_t ln = part ? (m & M_LEN) : 12u;                 // (a node that takes no part: the blob's first bytes,
+            const uint64_t base = part ? lane_u64(b_lo, b_hi, l) : 0ull;  //  readable because some node of >= 136 bytes exists)
+            const uint32_t o = off12 < ln - 12u ? off12 : ln - 12u;       // (lanes behind the node's end repeat its last 12 bytes)
+            return *reinterpret_cast<const U32x3*>(a.v.nodes + base + o);
+        };
         auto step = [&](uint32_t l, const U32x3& cur) __attribute__((always_inline)) {
             const uint32_t m = lane_u32(meta, l);
             if (m & M_HEAD) ref_lane = 64u;  // a run ends here, whatever this node is
@@ -855,45 +812,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 ref_lane = l;
             }
         };
-        auto turns = [&](uint32_t from, uint32_t to) __attribute__((always_inline)) {
-            for (uint32_t t = from; t < to; t += RING) {
+        constexpr uint32_t U = 4;
+        U32x3 A[U], B[U];
 #pragma unroll
-                for (uint32_t u = 0; u < RING; ++u) {
-                    step(t + u, ring[u]);
-                    ring[u] = fetch(t + RING + u, meta, b_lo, b_hi);
-                }
-            }
-        };
-        // The next level's offsets are requested when this level begins and turned into its description half way through (they
-        // have long arrived: no wait), so that the level's last ring turn can fetch ahead into the next level.
-        uint32_t nmeta = 0, nb_lo = 0, nb_hi = 0;
-        {
-            uint64_t ne = 0, nb = 0;
-            if (more) offsets(d + 1u, ne, nb);
-            if (readable) turns(0u, 32u);
-            if (more) describe(d + 1u, ne, nb, nmeta, nb_lo, nb_hi);
-        }
-        if (readable) {
-            turns(32u, 64u - RING);
+        for (uint32_t u = 0; u < U; ++u) A[u] = fetch(u);
+        for (uint32_t t = 0; t <= last; t += 2u * U) {
 #pragma unroll
-            for (uint32_t u = 0; u < RING; ++u) {
-                step(64u - RING + u, ring[u]);
-                if (more) ring[u] = fetch(u, nmeta, nb_lo, nb_hi);
-            }
+            for (uint32_t u = 0; u < U; ++u) B[u] = fetch((t + U + u) & 63u);
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) step(t + u, A[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) A[u] = fetch((t + 2u * U + u) & 63u);
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) step(t + U + u, B[u]);
         }
-        // ---- the level's results: the representative of every node, and what is left to hash ----
-        const uint32_t hj = lane_u32(h_j, d);
-        const uint32_t j = lane ? first + d : hj;
-        const uint32_t rj = (uint32_t)__shfl((int)j, (int)(my_ref & 63u), 64);
-        if (meta & M_ACT) a.rep[j] = my_ref < 64u ? rj : j;  // (M_ACT: a real position's existing node -- never lane 0)
-        if (late && !(a.dbg & 4u)) {  // (rare: damaged copies and their successors -- a reservation each)
-            const uint32_t cls = node_list(meta & M_LEN), stripe = chunk % STRIPES;
-            a.ent2[ent2_index(a, cls, stripe, atomicAdd(&a.hdr[cursor_word(cls, stripe, 1u)], 1u))] = make_uint2(j, a.pos[i].p);
-        }
-        meta = nmeta;
-        b_lo = nb_lo;
-        b_hi = nb_hi;
     }
+    // ---- results: the representative of every node, and what is left to hash ----
+    const uint32_t rj = (uint32_t)__shfl((int)j, (int)(my_ref & 63u), 64);
+    if (real && act) a.rep[j] = my_ref < 64u ? rj : j;
+    list_append<1>(a, (real && late) ? node_list(len) : CLASS_NONE, j, p, s_cnt, s_base);
 }
 
 // ---------------------------------------------------------------- canonical full branch, per rate block
@@ -974,18 +911,18 @@ PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
 // single-wave speed.  With the ladder a wave that is behind outranks the ones ahead: they advance block by block
 // together and finish together (profiles/EXPERIMENTS.md: ladders measured).
 template <bool LADDER>
-PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p, const bool ladder = true /* EXPLORATION */) {
+PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
     sponge_zero(s);
-    if (LADDER && ladder) __builtin_amdgcn_s_setprio(2);
+    if (LADDER) __builtin_amdgcn_s_setprio(2);
     uint32_t bad = absorb_b532_block<0, 34>(s, p);
     keccak_f1600(s);
-    if (LADDER && ladder) __builtin_amdgcn_s_setprio(1);
+    if (LADDER) __builtin_amdgcn_s_setprio(1);
     bad |= absorb_b532_block<1, 34>(s, p + RATE);
     keccak_f1600(s);
-    if (LADDER && ladder) __builtin_amdgcn_s_setprio(1);
+    if (LADDER) __builtin_amdgcn_s_setprio(1);
     bad |= absorb_b532_block<2, 34>(s, p + 2u * RATE);
     keccak_f1600(s);
-    if (LADDER && ladder) __builtin_amdgcn_s_setprio(0);
+    if (LADDER) __builtin_amdgcn_s_setprio(0);
     bad |= absorb_b532_block<3, 31>(s, p + 3u * RATE);
     keccak_f1600(s);
     return bad;
@@ -1137,7 +1074,7 @@ PHANT_DEV bool list_role(const Args& a, uint32_t q, const uint32_t lane) {
     uint32_t bad;
     const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
     if (cls == LIST_B532) {
-        bad = hash_b532<true>(s, p, !(a.dbg & 64u));
+        bad = hash_b532<true>(s, p);
     } else if (cls == 0u && __ballot(len != len0 || p + RATE > safe_end) == 0ull) {
         hash_short_uniform(s, p, len0);  // one length below the rate for the whole chunk
         bad = 1u;
@@ -1223,7 +1160,7 @@ PHANT_DEV void deep_role(const Args& a, const uint32_t w, const uint32_t lane, c
         const bool is532 = active && len == BRANCH_LEN;
         if (roomy && __ballot(is532) != 0ull) {
             // the lanes with a 532-byte node (the others run along on a readable address: the blob's first bytes)
-            const uint32_t bad = hash_b532<true>(s, (is532 && !(a.dbg & 8u)) ? ptr : a.v.nodes, !(a.dbg & 64u));
+            const uint32_t bad = hash_b532<true>(s, is532 ? ptr : a.v.nodes);
             if (is532 && bad == 0u) flags |= F_CANON;
         }
         const bool rest = active && !(roomy && is532);
@@ -2147,9 +2084,9 @@ static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries,
     Layout l;
     const uint64_t wgs = (lanes + 255u) / 256u;
     l.stripe_cap = (uint32_t)((wgs + STRIPES - 1u) / STRIPES * 256u);
-    // (list set 1: a comparison wave -- one per chunk of positions -- appends at most CHUNK x levels entries to ITS stripe's lists;
-    // `units` = chunks x levels)
-    l.stripe_cap2 = (uint32_t)((units + STRIPES - 1u) / STRIPES * CHUNK + (uint64_t)CHUNK * MAX_SHALLOW);
+    // (list set 1: the comparison's workgroups -- four (chunk, level) waves each -- append there, one reservation per workgroup)
+    const uint64_t wgs2 = (units + 3u) / 4u;
+    l.stripe_cap2 = (uint32_t)((wgs2 + STRIPES - 1u) / STRIPES * 256u);
     size_t p = HEADER_BYTES;
     l.nstat = p;  p += rnd256(tn + 16);
     l.dtab = p;   p += rnd256((size_t)direct_entries * 4);
@@ -2197,7 +2134,6 @@ static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
     a.pos = nullptr;
     a.bstart = nullptr;
     a.bucket_bits = 0;
-    a.dbg = std::getenv("PHANT_VERIFY_DBG") ? (uint32_t)std::atoi(std::getenv("PHANT_VERIFY_DBG")) : 0u;
 }
 
 }  // namespace v3
@@ -2290,7 +2226,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
             if (three && (e = hipStreamWaitEvent(side->stream2, side->fork, 0)) != hipSuccess) return e;
         }
         if (tune.diag & 1u) {
-            const uint32_t lds = (tune.diag == 3u || std::getenv("PHANT_DIAG_CAP")) ? hash_lds : 0u;  // (capped only where something memory-bound runs beside it)
+            const uint32_t lds = tune.diag == 3u ? hash_lds : 0u;  // (capped only where something memory-bound runs beside it)
             hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), lds, hs, a, wpl, deep_levels);
             hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), lds ? lds + 8192u : 0u, st, a);
             if (ordered) hipLaunchKernelGGL(hash_late_kernel, dim3(list_wgs < 256u ? list_wgs : 256u), dim3(256), 0, st, a);
@@ -2332,10 +2268,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         mark(3);  // (no heads_kernel and nothing hashed ahead of the comparison in this form: stages 2 and 3 are empty)
         mark(4);
         if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
-        {
-            static const uint32_t dedup_lds = std::getenv("PHANT_DEDUP_LDS_KB") ? (uint32_t)std::atoi(std::getenv("PHANT_DEDUP_LDS_KB")) * 1024u : 0u;  // EXPLORATION
-            hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), two ? dedup_lds : 0u, st, a);
-        }
+        hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), 0, st, a);
         mark(5);
         hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, st, a);
         mark(6);
@@ -2393,9 +2326,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     mark(4);
     if (three && (e = hipEventRecord(side->join2, side->stream2)) != hipSuccess) return e;
     const uint32_t n_chunks = (uint32_t)((v.n + CHUNK - 1u) / CHUNK);
-    static const uint32_t cmp_levels = std::getenv("PHANT_CMP_LEVELS") ? (uint32_t)std::atoi(std::getenv("PHANT_CMP_LEVELS")) : 1u;  // EXPLORATION
-    const uint32_t per_wave = cmp_levels ? cmp_levels : 1u, groups = (a.shallow + per_wave - 1u) / per_wave;
-    hipLaunchKernelGGL(compare_kernel, dim3((uint32_t)(((uint64_t)n_chunks * groups + 3u) / 4u)), dim3(256), 0, st, a, n_chunks, per_wave, groups);
+    hipLaunchKernelGGL(compare_kernel, dim3((uint32_t)((units + 3u) / 4u)), dim3(256), 0, st, a, n_chunks);
     mark(5);
     // what the comparison left: a thin list (damaged copies and their successors) -- a bounded grid that strides over it
     const uint32_t late_wgs = list_wgs < 256u ? list_wgs : 256u;

@@ -19,6 +19,9 @@ except Exception as e:
 PY
 }
 b config3 --cpu-seconds 8
+PHANT_VERIFY_ORDERED=1 b config3_ordered_form --no-cpu-baseline --no-strong
+PHANT_VERIFY_KEY_ORDERED=1 b config3_sorted_keys_callers_order --no-cpu-baseline --no-strong --proof-order sorted
+b config3_sorted_keys_table_form --no-cpu-baseline --no-strong --proof-order sorted
 b config3_nodedup --no-cpu-baseline --no-strong --verify-mode nodedup
 b config3_fused --no-cpu-baseline --no-strong --verify-mode fused --steps 5
 b config3_1M --no-cpu-baseline --no-strong --proofs 1000000 --steps 5 --inner 4
@@ -61,12 +64,18 @@ python tools/probe_walk_report.py /tmp/prof_t head_kernel | tail -1 | tr ' ' '\n
 bash tools/gpu_prof.sh "${1:-evidence}/state_root_prof" state_offsets_check_kernel python $R/tools/bench_state.py --accounts 200000 --slots 5 > /dev/null 2>&1
 [ -x tools/ubench/overlap ] && timeout 60 tools/ubench/overlap > "$OUT/overlap_ubench.txt" 2>&1; grep -c overlap "$OUT/overlap_ubench.txt"
 timeout 200 python tools/probe_power.py --seconds 2 --out "$OUT/power_and_clock_per_phase.jsonl" > "$OUT/probe_power.log" 2>&1
+timeout 200 python tools/probe_bound_power.py 5000 > "$OUT/bound_experiment_power.txt" 2>&1
+for w in 2048 256; do PHANT_DIAG_STREAM_WGS=$w timeout 100 python tools/probe_bound.py 2>/dev/null | tail -2 | sed "s/^/stream workgroups $w: /"; done > "$OUT/bound_experiment.txt"
+for mb in 128 16 2; do PHANT_DIAG_STREAM_MB=$mb timeout 100 python tools/probe_bound.py 2>/dev/null | tail -2 | sed "s/^/stream region $mb MB: /"; done >> "$OUT/bound_experiment.txt"
+PHANT_VERIFY_ORDERED=1 timeout 100 python tools/probe_stages.py 2 > "$OUT/stages_ordered_form.txt" 2>&1; timeout 100 python tools/probe_stages.py 2 > "$OUT/stages_table_form.txt" 2>&1
+rm -rf /tmp/pwo; ( cd /tmp && timeout 200 env PHANT_VERIFY_ORDERED=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/pwo -o p -- python $R/tools/probe_walk.py > "$OUT/probe_ordered.log" 2>&1 )
+python tools/probe_walk_report.py /tmp/pwo > "$OUT/timeline_ordered_form.txt"
 rm -rf /tmp/pw; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pw -o p -- python $R/tools/probe_walk.py > "$OUT/probe.log" 2>&1 )
 python tools/probe_walk_report.py /tmp/pw | tee "$OUT/timeline.txt" | cut -c1-260 | tail -6
 # ---- PMC passes: counters in their own runs, kernel trace only
-pmc() {  # name, counters, mode
-  name=$1; ctr=$2; mode=$3
-  ( cd /tmp && rm -rf /tmp/pmc_$name && timeout 300 env PHANT_VERIFY_SERIAL=1 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --inner 1 --no-strong --no-cpu-baseline --streams 1 --verify-mode $mode > "$OUT/pmc_$name.log" 2>&1 )
+pmc() {  # name, counters, mode, [ENV=VAL]
+  name=$1; ctr=$2; mode=$3; extra=${4:-PHANT_X=0}
+  ( cd /tmp && rm -rf /tmp/pmc_$name && timeout 300 env PHANT_VERIFY_SERIAL=1 $extra rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --inner 1 --no-strong --no-cpu-baseline --streams 1 --verify-mode $mode > "$OUT/pmc_$name.log" 2>&1 )
   for f in $(find /tmp/pmc_$name -name '*counter_collection.csv'); do (head -1 "$f"; grep -E 'phant::' "$f") > "$OUT/$name.csv"; done
 }
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -74,6 +83,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   for f in $(find /tmp/ub_$c -name '*counter_collection.csv'); do cp "$f" "$OUT/ubench_$c.csv"; done
   pmc flat_$c $c flat
   pmc nodedup_$c $c nodedup
+  pmc ordered_$c $c flat PHANT_VERIFY_ORDERED=1
 done
 pmc flat_SQ1 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" flat
 pmc flat_SQ2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE" flat
