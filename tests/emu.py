@@ -226,6 +226,11 @@ def mirror_context(lib, mode="flat"):
             assert rc == 0, rc
             self._h, self._lib = h, lib
 
+        def keccak_rate(self, waves_per_simd=6, perms=100):
+            # the emulated device's permutation rate means nothing; one wave per SIMD and two permutations exercise the
+            # same kernel and the same entry point in a second instead of half a minute
+            return super().keccak_rate(1, min(perms, 2))
+
     return EmuContext()
 
 
@@ -240,6 +245,8 @@ def emulated_backend(lib=None):
             import pytest
             pytest.skip(str(e))
     saved_lib, saved_ctx = L._lib, dict(Cx._default)
+    from tests import suite
+    suite.EMULATED = True
     L._lib = lib
     Cx._default.clear()
     Cx._default[0] = mirror_context(lib)
@@ -247,6 +254,7 @@ def emulated_backend(lib=None):
     try:
         yield
     finally:
+        suite.EMULATED = False
         undo()
         for c in Cx._default.values():
             c.close()

@@ -95,6 +95,7 @@ static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline void __threadfence() {}
+static inline void __threadfence_system() {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
 // (workgroups run one after the other here: a scoped atomic load / store is the plain one, the device's 100 MHz clock a counter)
 #define __HIP_MEMORY_SCOPE_AGENT 4
@@ -588,6 +589,7 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
 static inline hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithFlags(s, 0); }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }  // (a launch has run when it returns)
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event(); return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }

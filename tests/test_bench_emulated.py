@@ -11,7 +11,7 @@ import sys
 
 import pytest
 
-from tests import emu
+from tests import emu, suite
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -119,7 +119,8 @@ def _check_contract(line, steps, warmup):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
 
 
-@pytest.mark.parametrize("mode,streams,inner", [("flat", 3, 2), ("flat", 1, 1), ("fused", 2, 1), ("nodedup", 2, 1)])
+@pytest.mark.parametrize("mode,streams,inner", [("flat", 3, 2), ("flat", 1, 1), ("fused", 2, 1), ("nodedup", 2, 1)] if suite.FULL else
+                         [("flat", 3, 2), ("fused", 2, 1)])
 def test_config3_dry_run(mode, streams, inner):
     line = _bench(["--proofs", "300", "--steps", "3", "--warmup", "1", "--verify-mode", mode, "--streams",
                    str(streams), "--cpu-seconds", "0.2", "--inner", str(inner), "--block-scale", "0.01"])
@@ -230,14 +231,19 @@ def _rank_main(rank, world, port, argv, q):
         backend.close()
 
 
-@pytest.mark.parametrize("argv", [
-    ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "3", "--inner", "2", "--block-scale", "0.01"],
-    ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4", "--inner", "1", "--no-strong"],
-    ["--gpus", "2", "--workload", "config4", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--streams", "2",
-     "--inner", "1"],
-    ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "2", "--inner", "3", "--allreduce-every", "2",
-     "--block-scale", "0.01"],
-], ids=["config3", "config3-fewer-steps-than-slots", "config4", "config3-verdicts-every-2-passes"])
+_TWO_RANK_RUNS = {
+    "config3": ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "3", "--inner", "2", "--block-scale", "0.01"],
+    "config3-verdicts-every-2-passes": ["--gpus", "2", "--proofs", "200", "--steps", "2", "--warmup", "1", "--streams", "2", "--inner", "3",
+                                        "--allreduce-every", "2", "--block-scale", "0.01"],
+    "config3-fewer-steps-than-slots": ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--streams", "4", "--inner", "1",
+                                       "--no-strong"],
+    "config4": ["--gpus", "2", "--workload", "config4", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--streams", "2",
+                "--inner", "1"],
+}
+_TWO_RANK_IDS = list(_TWO_RANK_RUNS) if suite.FULL else ["config3-verdicts-every-2-passes", "config4"]
+
+
+@pytest.mark.parametrize("argv", [_TWO_RANK_RUNS[k] for k in _TWO_RANK_IDS], ids=_TWO_RANK_IDS)
 def test_two_ranks_dry_run(argv):
     """The N > 1 path the driver launches with torchrun (never run on real GPUs this round): both ranks build their
     shard, agree on the state root, verify, all-reduce the verdict; rank 0 prints the one line."""

@@ -18,7 +18,10 @@ def _emulated_backend():
     yield from emu.emulated_backend()
 
 
-@pytest.fixture(params=[1, 2, 3, 8])
+from tests import suite  # noqa: E402
+
+
+@pytest.fixture(params=[1, 2, 3, 8] if suite.FULL else [2, 8])
 def comm(request):
     import phant_amd
     os.environ["HIPEMU_DEVICES"] = str(request.param)

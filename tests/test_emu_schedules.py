@@ -22,14 +22,23 @@ def test_results_do_not_depend_on_the_execution_order():
         pytest.skip(str(e))
     runs = []
     # (seed, what fresh "device" memory holds, ...): a result must not depend on uninitialised workspace either
-    for seed, fill, modules, expr in (
+    from tests import suite
+    if suite.FULL:
+        plan = (
             (3, "0x00", ["tests/test_emu_verify.py"],
              "(flat or levels3 or levels16) and (random_tries or mutation or hostile_index_arrays_match or synthetic_block)"),
             (11, "0xff", ["tests/test_emu_verify.py"],
-             "(levels1 or nodedup or fused) and (random_tries or mutation or non_monotone)"),
+             "(levels1 or nodedup or fused or ordered or caller) and (random_tries or mutation or non_monotone)"),
             (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py",
                          "tests/test_emu_witness.py"],
-             "not 20000 and not fixture_state")):
+             "not 20000 and not fixture_state"))
+    else:  # (the default CPU suite: tests/suite.py)
+        plan = (
+            (3, "0x00", ["tests/test_emu_verify.py"], "(flat or levels3) and (random_tries or mutation)"),
+            (11, "0xff", ["tests/test_emu_verify.py"], "(fused or ordered or caller) and (random_tries or mutation or non_monotone)"),
+            (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py", "tests/test_emu_witness.py"],
+             "not 20000 and not fixture_state and not sharded and not orders_its_leaves and not state_trie_leaves and not device_form"))
+    for seed, fill, modules, expr in plan:
         cmd = [sys.executable, "-m", "pytest", *modules, "-x", "-q", "-p", "no:cacheprovider"]
         if expr:
             cmd += ["-k", expr]

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests import emu
+from tests import emu, suite
 
 @pytest.fixture(scope="module", autouse=True)
 def _emulated_backend():
@@ -17,8 +17,13 @@ def _emulated_backend():
 
 # levelsN = the two-tier pipeline with its tier split forced (tests/emu.py): 1 = only root nodes deduplicated, 16 = every
 # level (nothing left for the in-place tier); "flat" chooses it from the batch size
-@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+ordered", "levels16+ordered",
-                                        "levels3+caller", "levels16+caller"])
+# (the default CPU suite: one mode of every kind -- the form a small batch takes, a forced tier split through the tables, the two
+# ordered forms, the one-lane-per-proof kernel; PHANT_CPU_SUITE=full: all ten, as the -m gpu module runs them)
+_MODES = ["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+ordered", "levels16+ordered", "levels3+caller",
+          "levels16+caller"] if suite.FULL else ["flat", "levels3", "fused", "levels16+ordered", "levels3+caller"]
+
+
+@pytest.fixture(scope="module", params=_MODES)
 def M(request):
     import phant_amd
     from tests.test_gpu_verify import _Mode
@@ -31,7 +36,7 @@ from tests.test_gpu_verify import (  # noqa: E402,F401
     test_reference_vector_tries, test_random_tries, test_embedded_nodes_and_branch_values,
     test_mutation_fuzz_matches_oracle, test_garbage_committed_roots, test_bad_offsets_are_flagged,
     test_host_form_on_both_sides_of_the_staging_limit, test_which_nodes_get_hashed_per_tier_split,
-    test_empty_trie_proves_absence, test_one_byte_off_in_a_duplicate_node,
+    test_empty_trie_proves_absence, test_one_byte_off_in_a_duplicate_node, test_bound_experiment_runs_on_a_two_tier_launch,
     test_non_monotone_proof_first_node_matches_oracle, test_synthetic_depth8_small_vs_oracle,
     test_synthetic_other_depths, test_block_witness_accounts_and_storage)
 from tests.test_gpu_x_verify_more import (  # noqa: E402,F401
@@ -98,7 +103,7 @@ def test_hostile_index_arrays_match_the_checked_oracle(M, oracle):
     k = np.frombuffer(b"".join(keys), np.uint8)
     ridx = ridx.astype(np.uint32)
     seen = set()
-    for _ in range(14 if os.environ.get("PHANT_EMU_SANITIZE") == "1" else 40):  # (the ASan build is ~8 x slower)
+    for _ in range(suite.scale(40, 8) if os.environ.get("PHANT_EMU_SANITIZE") != "1" else suite.scale(14, 5)):  # (the ASan build is ~8 x slower)
         no, pf, ri = _hostile(rng, node_off, pfn, ridx, nodes.size, len(roots))
         got = M.verify_batch(r, ri, k, 32, nodes, no, pf)
         want = oracle.mpt_verify_batch_checked(r, ri, k, 32, nodes, no, pf)
@@ -122,7 +127,7 @@ def test_hostile_index_arrays_device_form(M, oracle):
     k = np.frombuffer(b"".join(keys), np.uint8).copy()
     ridx = ridx.astype(np.uint32)
     dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731  (a dword-rounded "device" copy under the emulator)
-    for it in range(9 if os.environ.get("PHANT_EMU_SANITIZE") == "1" else 25):
+    for it in range(suite.scale(25, 7) if os.environ.get("PHANT_EMU_SANITIZE") != "1" else suite.scale(9, 4)):
         no, pf, ri = _hostile(rng, node_off, pfn, ridx, nodes.size, len(roots))
         if it % 3 == 0:
             pf[-1] = int(rng.choice([0, 5, len(node_off) + 3, 2 ** 31, 2 ** 32 - 1]))

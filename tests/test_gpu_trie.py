@@ -222,16 +222,18 @@ def test_receipt_trie_shaped_items(P, oracle):
 
 
 def test_fixture_state_roots(P):
+    from tests import suite
     fx = golden.fixtures()
     n = 0
-    for c in fx["cases"]:
+    step = suite.scale(1, 4)  # (every case on the GPU; the default CPU suite's emulated run: every fourth, tests/suite.py)
+    for c in fx["cases"][::step]:
         acc = golden.accounts_of(c["pre"], fx["codes"])
         assert P.state.state_root(acc).hex() == c["genesis_state_root"], c["name"]
         if "post" in c:
             acc = golden.accounts_of(c["post"], fx["codes"])
             assert P.state.state_root(acc).hex() == c["post_state_root"], c["name"]
         n += 1
-    assert n == 84
+    assert n == (84 + step - 1) // step
 
 
 def test_state_root_random_vs_oracle(P, oracle):
@@ -266,7 +268,8 @@ def test_state_root_orders_its_leaves_on_the_gpu(P, oracle, monkeypatch):
     against the oracle; and the same state with the device sort reduced to 8 / 16 key bits and no repair of ties, where nearly
     every neighbour ties, the order check raises its flag and the host orders the batch (the path an unrepairable collision takes)."""
     rng = np.random.default_rng(77)
-    acc = _random_accounts(rng, 40, 700) + _random_accounts(rng, 2500, 3)
+    from tests import suite
+    acc = _random_accounts(rng, *suite.scale((40, 700), (12, 300))) + _random_accounts(rng, *suite.scale((2500, 3), (600, 3)))
     want = oracle.state_root(acc)
     monkeypatch.setenv("PHANT_SORT_NO_FALLBACK", "1")   # (test knob: fail instead of ordering on the host)
     assert P.state.state_root(acc) == want              # ... so this order is the device's

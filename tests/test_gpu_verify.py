@@ -276,6 +276,28 @@ def test_synthetic_depth8_small_vs_oracle(M, oracle):
     assert int(fails.item()) == w.n_invalid == 75
 
 
+def test_bound_experiment_runs_on_a_two_tier_launch(M):
+    """phant_verify_bound_experiment (diagnostics: the launch's hashing alone, a clean read of the witness alone, both): three positive
+    times on a batch that takes a two-tier form, a refusal on one that is hashed whole; the statuses of the verification it starts
+    with are the expected ones and a normal call on the same ctx afterwards still is."""
+    import phant_amd
+    from phant_amd import _lib as L
+    if M.mode in ("fused",):
+        pytest.skip("the one-lane-per-proof kernel has no tiers")
+    w = phant_amd.witness.account_witness(1500, depth=8, seed=21, corrupt_frac=0.02)
+    two_tier = M.mode.startswith("levels")
+    if two_tier:
+        res = M._ctx.verify_bound_experiment(w.batch, 2)
+        assert set(res) == {"hash_only_ms", "stream_only_ms", "together_ms"} and all(v > 0 for v in res.values())
+        assert M._ctx.verify_form() in ("table", "ordered", "ordered_by_caller")
+    else:
+        with pytest.raises(L.PhantError):
+            M._ctx.verify_bound_experiment(w.batch, 2)
+    st = M.verify_batch_dev(w.batch)
+    torch.cuda.synchronize()
+    assert torch.equal(st, w.expected)
+
+
 def test_one_byte_off_in_a_duplicate_node(M, oracle):
     """Copies of an upper-level branch are compared with their group's representative instead of being hashed: one byte
     changed anywhere in a copy -- first byte, the seams of the compare's lane layout (bytes 15/16, 511/512), the range its

@@ -42,7 +42,9 @@ def test_sharded_state_root_matches_the_fixture_roots(P):
     from phant_amd import shard
     fx = golden.fixtures()
     cases = sorted(fx["cases"], key=lambda c: -len(c.get("post", c["pre"])))
-    picked = cases[:6] + cases[-6:]                                   # the largest states (401 accounts) and the smallest
+    from tests import suite
+    k = suite.scale(6, 2)
+    picked = cases[:k] + cases[-k:]                                   # the largest states (401 accounts) and the smallest
     for c in picked:
         for which, want in (("pre", c["genesis_state_root"]), ("post", c.get("post_state_root"))):
             if want is None:

@@ -8,8 +8,9 @@ import phant_amd
 from phant_amd import mpt as M
 dev = torch.device("cuda", 0)
 ctx = phant_amd.Context(0)
-wa = phant_amd.witness.account_witness(100_000, depth=8, seed=2, device=dev, ctx=ctx)
-wb = phant_amd.witness.account_witness(100_000, depth=8, seed=3, device=dev, ctx=ctx)
+N = int(os.environ.get("PROOFS", "100000"))
+wa = phant_amd.witness.account_witness(N, depth=8, seed=2, device=dev, ctx=ctx)
+wb = phant_amd.witness.account_witness(N, depth=8, seed=3, device=dev, ctx=ctx)
 st = torch.empty(wa.batch.n, dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
 for k in range(8):
