@@ -73,10 +73,12 @@ struct Workspaces {
     }
     // A few pinned, device-visible words for what a pass reads back in the middle of a call (the trie builder's counters): a
     // copy into pageable memory costs ~25 us, a kernel that stores its flags here costs nothing beyond the synchronisation.
+    // Coherent (fine-grained) whatever HIP_HOST_COHERENT says: the trie builder's host side reads what a kernel stored here
+    // WHILE that kernel runs (order_kernel).
     static constexpr size_t MAILBOX_WORDS = 2048;
     uint32_t* mailbox = nullptr;
     hipError_t ensure_mailbox() {
-        return mailbox ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&mailbox), MAILBOX_WORDS * 4, hipHostMallocDefault);
+        return mailbox ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&mailbox), MAILBOX_WORDS * 4, hipHostMallocCoherent);
     }
     // a helper stream + events for the trie builder's deepest bins, which run next to the bulk of the leaves
     hipStream_t side = nullptr;

@@ -44,6 +44,13 @@ constexpr int INF_LCP = 0x7fffffff;
 constexpr uint32_t FAN = 16;      // fan-out of the min-tree: a group of children is one 64-byte line
 constexpr int MAX_LEVELS = 8;      // 16^8 boundaries
 constexpr uint32_t N_COUNTERS = 8u + 2u * (uint32_t)MAX_DEPTH_BINS;
+constexpr uint32_t SIDE_MAX_NODES = 65536;         // nodes in the bins that run beside the leaves (one generation of four-block workgroups)
+constexpr uint32_t CROWDED_BIN = 4u * 256u * 64u;  // nodes: above it a bin in four-block slots (one wave per SIMD) no longer fits the chip at once
+// The pinned mailbox (arena.h) as order_kernel's first workgroup fills it: the counters at [0, N_COUNTERS), then the depth from which
+// the bins run beside the leaves (or -1), then the word the host waits for.
+constexpr uint32_t MAILBOX_DEEP_FROM = N_COUNTERS, MAILBOX_READY = N_COUNTERS + 1u, MAILBOX_ORDERED = N_COUNTERS + 2u, MAILBOX_DONE = N_COUNTERS + 3u;
+static_assert(MAILBOX_DONE < Workspaces::MAILBOX_WORDS, "the counters and their trailers fit the pinned mailbox");
+constexpr uint32_t CNT_DEEP_FROM = 4;  // counters[4]: order_kernel's deep_from for the kernels behind it
 
 struct TrieDev {
     const uint8_t* keys;
@@ -73,17 +80,19 @@ struct TrieDev {
     // scratch blob for encodings
     uint8_t* scratch;
     unsigned long long* cursor;
-    // counters[0] = n_rep, [1] = error flags, [2] = scratch overflow, [3] = some leaf may reach a rate block, branch nodes per depth
+    // counters[0] = n_rep, [1] = error flags, [2] = scratch overflow, [3] = some leaf may reach a rate block, [4]: CNT_DEEP_FROM, branch nodes per depth
     // at [8..8+512), their children (leaves and nodes) per depth at [8+512..8+1024)
     uint32_t* counters;
     uint32_t* order;      // rep boundaries grouped by depth
     uint32_t* order2;     // per depth bin, from its start: the nodes that did not fit the slot class the bin was run in
     uint32_t* misfit;     // 512: how many of those
     // the keys whose leaves hang under a node of depth >= deep_from (and how many): hashed FIRST, so that the few nodes of the deepest
-    // bins can be hashed next to the bulk of the leaves (forest_device); deep_from < 0: no such split
+    // bins can be hashed next to the bulk of the leaves (forest_device); deep_from (order_kernel) < 0: no such split
     uint32_t* deep_leaves;
     uint32_t* deep_count;
-    int32_t deep_from;
+    uint32_t side_ok;        // (order_kernel works the depth out itself -- if this says it may -- and tells the host and, through counters[CNT_DEEP_FROM], leaf_kernel)
+    uint32_t* mailbox;       // pinned host memory, device-visible
+    uint32_t mailbox_tag;    // what MAILBOX_READY holds once this call's counters are in the mailbox
     uint32_t* depth_cursor;  // 512
     uint8_t* roots;       // n_tries x 32
     uint8_t* root_enc;    // optional: n_tries x root_enc_cap, the RLP of every trie's root node
@@ -405,18 +414,34 @@ __global__ void __launch_bounds__(COUNT_BLOCK) identify_kernel(TrieDev t) {
 
 // Also: where a depth's bin starts (the exclusive prefix sum of identify_kernel's histogram: every workgroup forms it again in LDS
 // -- 512 counters, nine steps -- instead of the host sending it over), and the slot lengths cleared (16 bytes per node).
+//
+// It is launched straight behind identify_kernel, BEFORE the host has seen the counters (a copy, a synchronisation and the host's
+// way back into the stream were 31 us of idle chip per call): its first workgroup puts the counters into the pinned mailbox and
+// raises MAILBOX_READY there, the host picks them up while this kernel runs and has the leaves and the bins queued behind it by
+// the time it ends.  What the host used to decide in between is therefore decided here: nothing happens on keys lcp_kernel refused
+// (counters[1]), and the depth from which the bins run beside the leaves (forest_device, "the deepest bins") is worked out by
+// every workgroup from the histogram -- the host takes the value from the mailbox, so there is one rule, not two.
 __global__ void __launch_bounds__(COUNT_BLOCK) order_kernel(TrieDev t) {
     __shared__ uint32_t s_cnt[MAX_DEPTH_BINS];
     __shared__ uint32_t s_base[MAX_DEPTH_BINS];
     __shared__ uint32_t s_begin[2][MAX_DEPTH_BINS];
+    __shared__ int32_t s_stop, s_from;
+    __shared__ uint32_t s_bins;
     static_assert(COUNT_BLOCK >= MAX_DEPTH_BINS, "one lane per depth bin");
     const uint32_t i = blockIdx.x * COUNT_BLOCK + threadIdx.x;
     const uint32_t tid = threadIdx.x;
+    const bool refused = t.counters[1] != 0u;  // (the same word for every lane: the branch below is taken by whole workgroups)
+    const uint32_t mine = tid < (uint32_t)MAX_DEPTH_BINS ? t.counters[8 + tid] : 0u;
     if (tid < (uint32_t)MAX_DEPTH_BINS) {
         s_cnt[tid] = 0u;
-        s_begin[0][tid] = t.counters[8 + tid];
+        s_begin[0][tid] = mine;
     }
-    if (i < t.counters[0]) reinterpret_cast<uint4*>(t.slot_len)[i] = make_uint4(0u, 0u, 0u, 0u);  // (n_rep <= n lanes)
+    if (tid == 0) {
+        s_stop = -1;
+        s_from = MAX_DEPTH_BINS;
+        s_bins = 0u;
+    }
+    if (!refused && i < t.counters[0]) reinterpret_cast<uint4*>(t.slot_len)[i] = make_uint4(0u, 0u, 0u, 0u);  // (n_rep <= n lanes)
     __syncthreads();
     uint32_t cur = 0;
     for (uint32_t o = 1; o < (uint32_t)MAX_DEPTH_BINS; o <<= 1) {  // inclusive scan, two buffers
@@ -424,6 +449,31 @@ __global__ void __launch_bounds__(COUNT_BLOCK) order_kernel(TrieDev t) {
         cur ^= 1u;
         __syncthreads();
     }
+    // The bins that run beside the leaves: from the deepest one up while a bin is not crowded and they hold no more than
+    // SIDE_MAX_NODES nodes together -- the first bin that breaks the rule ends the run; two bins at least, never the root's.
+    int32_t deep_from = -1;
+    if (t.side_ok && !refused && t.counters[3] == 0u) {
+        const uint32_t at_and_below = s_begin[cur][MAX_DEPTH_BINS - 1] - (tid < (uint32_t)MAX_DEPTH_BINS ? s_begin[cur][tid] : 0u) + mine;
+        if (mine && (mine >= CROWDED_BIN || at_and_below > SIDE_MAX_NODES)) atomicMax(&s_stop, (int32_t)tid);
+        __syncthreads();
+        if (mine && (int32_t)tid > s_stop) {
+            atomicMin(&s_from, (int32_t)tid);
+            atomicAdd(&s_bins, 1u);
+        }
+        __syncthreads();
+        if (s_bins >= 2u && s_from > 0) deep_from = s_from;
+    }
+    if (blockIdx.x == 0 && t.mailbox) {
+        for (uint32_t k = tid; k < N_COUNTERS; k += COUNT_BLOCK) t.mailbox[k] = t.counters[k];
+        if (tid == 0) {
+            t.mailbox[MAILBOX_DEEP_FROM] = (uint32_t)deep_from;
+            t.counters[CNT_DEEP_FROM] = (uint32_t)deep_from;  // (for leaf_kernel, which may be in the stream before the host has read the mailbox)
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) *reinterpret_cast<volatile uint32_t*>(t.mailbox + MAILBOX_READY) = t.mailbox_tag;
+    }
+    if (refused) return;
     const bool live = i < t.n && i != 0 && t.dense[i] != NONE;
     if (live) resolve_parent(t, i);
     const uint32_t d = live ? (uint32_t)t.lcp[i] : 0u;
@@ -436,13 +486,13 @@ __global__ void __launch_bounds__(COUNT_BLOCK) order_kernel(TrieDev t) {
     __syncthreads();
     if (live) t.order[(d ? s_begin[cur][d - 1u] : 0u) + s_base[d] + local] = i;
     // the keys under the deepest nodes, as a list (one reservation per workgroup)
-    if (t.deep_from >= 0) {
+    if (deep_from >= 0) {
         __shared__ uint32_t s_deep[COUNT_BLOCK / 64u + 1u];
         const uint32_t lane = tid & 63u, wave = tid >> 6;
         bool deep = false;
         if (i < t.n) {
             const uint32_t ps = t.leaf_ps[i];
-            deep = ps != BRANCH_VALUE && t.leaf_parent[i] != NONE && (int32_t)ps - 1 >= t.deep_from;
+            deep = ps != BRANCH_VALUE && t.leaf_parent[i] != NONE && (int32_t)ps - 1 >= deep_from;
         }
         const unsigned long long m = __ballot(deep);
         if (lane == 0) s_deep[wave] = (uint32_t)__popcll(m);
@@ -721,12 +771,22 @@ constexpr uint32_t LEAF_BIG_MAX = BRANCH_STAGE_BYTES_;  // 4 x 136: the padding 
 // bins are hashed next to the other leaves; that pass (no list) then skips them (t.deep_from).
 __global__ void __launch_bounds__(256) leaf_kernel(TrieDev t, const uint32_t* list, const uint32_t* dev_count) {
     __shared__ uint32_t s_stage[256 * LEAF_STAGE_DW];
+    if (t.counters[1] != 0u) return;  // (keys lcp_kernel refused: this launch may have been queued before the host knew)
+    const int32_t deep_from = (int32_t)t.counters[CNT_DEEP_FROM];
+    // The pass over all keys sits in the stream right behind order_kernel: that it has started says that order_kernel is through,
+    // with everything it wrote in memory.  The host waits for this word before it starts, by hand, the leaves under the deepest
+    // bins and those bins on the helper stream -- no event in the main stream (a marker between order_kernel and this kernel held
+    // this kernel up by 7-10 us).
+    if (!list && t.mailbox && blockIdx.x == 0 && threadIdx.x == 0) {
+        *reinterpret_cast<volatile uint32_t*>(t.mailbox + MAILBOX_ORDERED) = t.mailbox_tag;
+        __threadfence_system();
+    }
     const uint32_t count = list ? *dev_count : t.n;
     for (uint32_t first = blockIdx.x * 256u; first < count; first += gridDim.x * 256u) {
         const uint32_t q = first + threadIdx.x;
         const uint32_t i = list ? (q < count ? list[q] : t.n) : q;
         LeafPlan p = leaf_plan(t, i);
-        if (!list && t.deep_from >= 0 && p.live && (int32_t)p.ps - 1 >= t.deep_from && t.leaf_parent[i] != NONE) p.live = false;
+        if (!list && deep_from >= 0 && p.live && (int32_t)p.ps - 1 >= deep_from && t.leaf_parent[i] != NONE) p.live = false;
         const bool staged = p.live && p.total < RATE;
         const bool scratch = p.live && p.total >= LEAF_BIG_MAX;
         const unsigned long long at = wave_alloc(t.cursor, scratch ? ((p.total + 3u) & ~3u) : 0u);
@@ -1231,6 +1291,12 @@ __global__ void __launch_bounds__(BRANCH_LANES) leaf_big_kernel(TrieDev t) {
     if (p.live && p.total >= RATE && p.total < LEAF_BIG_MAX) leaf_emit_staged<BRANCH_STAGE_DW>(t, i, p, s_stage + threadIdx.x * BRANCH_STAGE_DW);
 }
 
+// the end of a call: the first counters (the scratch overflow flag among them) into the mailbox, then the word the host waits for
+__global__ void __launch_bounds__(64) finish_kernel(TrieDev t) {
+    if (threadIdx.x < 3u) t.mailbox[threadIdx.x] = t.counters[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile uint32_t*>(t.mailbox + MAILBOX_DONE) = t.mailbox_tag;
+}
 __global__ void __launch_bounds__(256) fill_empty_roots_kernel(uint8_t* roots, uint32_t n_tries) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n_tries) store_empty_root(roots + 32ull * i);
@@ -1250,12 +1316,13 @@ inline uint32_t blocks(uint64_t n) { return (uint32_t)((n + 255u) / 256u); }
 
 }  // namespace
 
+// Up to this many keys the slot tables and the scratch blob are sized for the worst case (a branch node per key: 1.3 KB per key against
+// ~0.45 KB for uniformly spread keys -- 10.6 GB at the limit) so that the leaves need not wait for the host to learn the node count.
+constexpr uint64_t LEAVES_AHEAD_MAX_KEYS = 8u << 20;
 constexpr uint32_t SIDE_MIN_KEYS = 400000;    // below it the leaves are too few to hide the deepest bins behind (200 000 keys: 0.497 vs 0.491 ms without)
-constexpr uint32_t SIDE_MAX_NODES = 65536;    // nodes in the bins that run beside the leaves (one generation of four-block workgroups)
 constexpr uint32_t SIDE_LEAF_LDS = 20480;     // bytes of unused dynamic LDS per leaf workgroup meanwhile: TWO of them per CU instead of four (with three,
                                               // 5 or 6 KB, the bins beside them still starved: 146-162 us for a bin of 116 nodes)
 constexpr uint32_t FALLBACK_GRID = 1024;           // workgroups of a bin's fallback pass (its count is on the device)
-constexpr uint32_t CROWDED_BIN = 4u * 256u * 64u;  // nodes: above it a bin in four-block slots (one wave per SIMD) no longer fits the chip at once
 
 // Device-side forest build; all pointers device memory, except roots_host.
 static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off,
@@ -1304,7 +1371,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     {
         const size_t n1 = (size_t)n + 1;
         const size_t total = DevArena::round(n1) + DevArena::round(n1 * 4 + 64) * 7 + DevArena::round(tree_ints * 4 + 64) +
-                             DevArena::round((size_t)n * 4) * 5 + DevArena::round(N_COUNTERS * 4) + 256 +
+                             DevArena::round((size_t)n * 4) * 5 + DevArena::round((size_t)n * 16) + DevArena::round(N_COUNTERS * 4) + 256 +
                              DevArena::round(MAX_DEPTH_BINS * 4) * 3 + 256 + 4096;
         TB_TRY(ws.t1.reset(total));
         t.first_flag = ws.t1.take<uint8_t>(n1);
@@ -1323,7 +1390,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         t.misfit = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
         t.deep_leaves = ws.t1.take<uint32_t>(n);
         t.deep_count = ws.t1.take<uint32_t>(1);
-        t.deep_from = -1;
+        t.slot_len = ws.t1.take<uint8_t>((size_t)n * 16);  // (n_rep <= n: sized before the host has seen n_rep)
         t.counters = ws.t1.take<uint32_t>(N_COUNTERS);
         t.depth_cursor = ws.t1.take<uint32_t>(MAX_DEPTH_BINS);
         t.cursor = ws.t1.take<unsigned long long>(1);
@@ -1351,12 +1418,67 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         hipLaunchKernelGGL(tree_levels_kernel, dim3(g), dim3(256), 0, st, t, base);
     }
     hipLaunchKernelGGL(identify_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
+    // order_kernel goes straight behind it and hands the counters over through the mailbox while it runs (see there); the host
+    // watches the word it raises -- a look at the stream now and then, so that a launch that failed cannot keep it waiting
+    {
+        static const bool no_side = std::getenv("PHANT_TRIE_NO_SIDE") != nullptr;  // (A/B)
+        static const uint32_t side_min = std::getenv("PHANT_TRIE_SIDE_MIN_KEYS") ? (uint32_t)std::atoi(std::getenv("PHANT_TRIE_SIDE_MIN_KEYS")) : SIDE_MIN_KEYS;  // (test knob)
+        t.side_ok = (!no_side && n >= side_min) ? 1u : 0u;
+    }
+    // The slot tables and the scratch blob: sized for n_rep = n (a node has two children at least) when that is affordable, so that
+    // the bulk of the leaves can be queued behind order_kernel at once -- else from the n_rep the mailbox brings, the leaves after it.
+    // leaves: list hdr (<=9) + HP (<= 3 + key bytes + 1) + value (<= 9 + len), 4-byte rounded;
+    // branches: <= 3 + 16*33 + value; extensions <= 48 + key bytes / 2
+    auto size_tables = [&](uint64_t reps) -> int32_t {
+        const uint64_t max_key = 255;
+        const uint64_t cap = total_val_bytes + total_key_bytes + (uint64_t)n * 32 + reps * (3 + 16 * 33 + 16 + 48 + max_key / 2 + 16) + 4096;
+        TB_TRY(ws.t2.reset(DevArena::round((size_t)reps * 16 * 32) + DevArena::round(cap) + 1024));
+        t.slot_bytes = ws.t2.take<uint8_t>((size_t)reps * 16 * 32);
+        t.scratch = ws.t2.take<uint8_t>(cap);
+        t.scratch_cap = cap;
+        if (ws.t2.overflowed || !t.scratch) {
+            err = "trie slot tables sized too small (internal)";
+            return PHANT_E_DEVICE;
+        }
+        return PHANT_OK;
+    };
+    static const uint64_t ahead_max_keys = std::getenv("PHANT_TRIE_AHEAD_MAX_KEYS") ? (uint64_t)std::max(0ll, std::atoll(std::getenv("PHANT_TRIE_AHEAD_MAX_KEYS"))) : LEAVES_AHEAD_MAX_KEYS;  // (test knob)
+    const bool ahead = n <= ahead_max_keys;
+    // (a leaf workgroup's static LDS + this must stay within the 64 KiB a launch gets without opting in)
+    static const uint32_t side_lds_knob = std::getenv("PHANT_TRIE_SIDE_LDS") ? (uint32_t)std::min(std::max(std::atoi(std::getenv("PHANT_TRIE_SIDE_LDS")), 0), 65536 - 4 * 256 * (int)LEAF_STAGE_DW) : SIDE_LEAF_LDS;
+    if (t.side_ok) TB_TRY(ws.ensure_side());
+    if (ahead) {
+        const int32_t rc = size_tables(n);
+        if (rc) return rc;
+    }
+    volatile uint32_t* const mbox = ws.mailbox;
+    t.mailbox = ws.mailbox;
+    t.mailbox_tag = mbox[MAILBOX_READY] + 1u;  // (the previous call ended with a synchronisation: nothing else writes the word)
+    if (t.mailbox_tag == 0u) t.mailbox_tag = 1u;
+    hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
+    // (the bulk of the leaves: with room for the bins beside them wherever order_kernel MAY decide for such bins)
+    if (ahead) hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), t.side_ok ? side_lds_knob : 0u, st, t, nullptr, nullptr);
     TB_TRY(hipGetLastError());
-
-    static_assert(N_COUNTERS <= Workspaces::MAILBOX_WORDS, "the counters fit the pinned mailbox");
-    TB_TRY(hipMemcpyAsync(ws.mailbox, t.counters, N_COUNTERS * 4, hipMemcpyDeviceToHost, st));
-    TB_TRY(hipStreamSynchronize(st));
+    auto wait_for = [&](uint32_t word) -> int32_t {
+        for (uint32_t spins = 1; mbox[word] != t.mailbox_tag; ++spins) {
+            if (spins % 4096u) continue;
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipErrorNotReady) continue;
+            TB_TRY(q);
+            if (mbox[word] != t.mailbox_tag) {  // (the stream is through and the word is not there)
+                err = "the trie builder's counters did not reach the mailbox (internal)";
+                return PHANT_E_DEVICE;
+            }
+        }
+        return PHANT_OK;
+    };
+    {
+        const int32_t rc = wait_for(MAILBOX_READY);
+        if (rc) return rc;
+    }
     const std::vector<uint32_t> cnt(ws.mailbox, ws.mailbox + N_COUNTERS);
+    const int deep_from = (int32_t)ws.mailbox[MAILBOX_DEEP_FROM];
+    if (cnt[1]) (void)hipStreamSynchronize(st);  // (order_kernel and the leaves, which do nothing on such keys, are through before the arenas are anyone else's)
     if (cnt[1] & ERR_KEY_RANGE) {
         err = "key longer than 255 bytes, or key offsets not monotone";
         return PHANT_E_INVALID_ARG;
@@ -1373,22 +1495,11 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         acc += cnt[8 + d];
     }
 
-    // leaves: list hdr (<=9) + HP (<= 3 + key bytes + 1) + value (<= 9 + len), 4-byte rounded;
-    // branches: <= 3 + 16*33 + value; extensions <= 48 + key bytes / 2
-    const uint64_t max_key = 255;
-    const uint64_t cap = total_val_bytes + total_key_bytes + (uint64_t)n * 32 +
-                         (uint64_t)n_rep * (3 + 16 * 33 + 16 + 48 + max_key / 2 + 16) + 4096;
-    TB_TRY(ws.t2.reset(DevArena::round((size_t)n_rep * 16 * 32) + DevArena::round((size_t)n_rep * 16) +
-                       DevArena::round(cap) + 1024));
-    t.slot_bytes = ws.t2.take<uint8_t>((size_t)n_rep * 16 * 32);
-    t.slot_len = ws.t2.take<uint8_t>((size_t)n_rep * 16);
-    t.scratch = ws.t2.take<uint8_t>(cap);
-    t.scratch_cap = cap;
-    if (ws.t2.overflowed || !t.scratch) {
-        err = "trie slot tables sized too small (internal)";
-        return PHANT_E_DEVICE;
+    if (!ahead) {
+        const int32_t rc = size_tables(n_rep);
+        if (rc) return rc;
     }
-    // (order_kernel also clears the slot lengths and forms the bins' starts from the histogram it finds in t.counters)
+    // (order_kernel has cleared the slot lengths and formed the bins' starts from the histogram it found in t.counters)
     // A bin's slot class (branch_kernel): four blocks unless the bin is crowded (more workgroups than the chip holds at once) and
     // its mean fan-out says that most of its nodes fit less; what does not fit is run through the four-block class behind it.
     static const uint32_t fallback_grid = std::getenv("PHANT_TRIE_FALLBACK_GRID") ? (uint32_t)std::max(1, std::atoi(std::getenv("PHANT_TRIE_FALLBACK_GRID"))) : FALLBACK_GRID;  // (test knob)
@@ -1425,26 +1536,6 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     // round trips, the Keccak-f) -- time in which the chip does nothing else.  They only need the leaves that hang under THEM: so
     // those leaves go first (order_kernel lists them), and then the deepest bins run on a stream of their own NEXT TO the bulk of
     // the leaves, which keeps a workgroup's worth of LDS per CU free for them.
-    int deep_from = -1;
-    {
-        static const bool no_side = std::getenv("PHANT_TRIE_NO_SIDE") != nullptr;  // (A/B)
-        static const uint32_t side_min = std::getenv("PHANT_TRIE_SIDE_MIN_KEYS") ? (uint32_t)std::atoi(std::getenv("PHANT_TRIE_SIDE_MIN_KEYS")) : SIDE_MIN_KEYS;  // (test knob)
-        if (!no_side && !cnt[3] && n >= side_min) {
-            uint64_t nodes = 0;
-            int bins = 0, from = -1;
-            for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) {
-                const uint32_t c = cnt[8 + d];
-                if (!c) continue;
-                if (c >= CROWDED_BIN || nodes + c > SIDE_MAX_NODES) break;
-                nodes += c;
-                ++bins;
-                from = d;
-            }
-            if (bins >= 2 && from > 0) deep_from = from;
-        }
-    }
-    t.deep_from = deep_from;
-    if (n_rep) hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
     // (whatever fails behind the fork: the helper stream is waited for before the arenas can be handed to another call)
     struct SideGuard {
         hipStream_t s = nullptr;
@@ -1453,29 +1544,51 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         }
     } side_guard;
     if (deep_from >= 0) {
-        TB_TRY(ws.ensure_side());
-        // (a leaf workgroup's static LDS + this must stay within the 64 KiB a launch gets without opting in)
-        static const uint32_t side_lds = std::getenv("PHANT_TRIE_SIDE_LDS") ? (uint32_t)std::min(std::max(std::atoi(std::getenv("PHANT_TRIE_SIDE_LDS")), 0), 65536 - 4 * 256 * (int)LEAF_STAGE_DW) : SIDE_LEAF_LDS;
-        hipLaunchKernelGGL(leaf_kernel, dim3(std::min(blocks(n), 256u)), dim3(256), 0, st, t, t.deep_leaves, t.deep_count);
-        TB_TRY(hipEventRecord(ws.side_fork, st));
-        TB_TRY(hipStreamWaitEvent(ws.side, ws.side_fork, 0));
         side_guard.s = ws.side;
+        if (ahead) {
+            // the leaves under the deepest bins, then those bins, on the helper stream next to the bulk of the leaves -- started
+            // by hand once the kernel behind order_kernel says that it has started (MAILBOX_ORDERED), no event in the main stream
+            const int32_t rc = wait_for(MAILBOX_ORDERED);
+            if (rc) return rc;
+            hipLaunchKernelGGL(leaf_kernel, dim3(std::min(blocks(n), 256u)), dim3(256), 0, ws.side, t, t.deep_leaves, t.deep_count);
+        } else {
+            hipLaunchKernelGGL(leaf_kernel, dim3(std::min(blocks(n), 256u)), dim3(256), 0, st, t, t.deep_leaves, t.deep_count);
+            TB_TRY(hipEventRecord(ws.side_fork, st));
+            hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), side_lds_knob, st, t, nullptr, nullptr);
+            TB_TRY(hipStreamWaitEvent(ws.side, ws.side_fork, 0));
+        }
         for (int d = MAX_DEPTH_BINS - 1; d >= deep_from; --d) launch_bin(d, ws.side);
         TB_TRY(hipEventRecord(ws.side_join, ws.side));
-        hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), side_lds, st, t, nullptr, nullptr);
-        TB_TRY(hipStreamWaitEvent(st, ws.side_join, 0));
+        // The bins above them need these bins AND all leaves.  The helper stream is normally through well before the leaves are: the
+        // host watches its event and queues the rest behind the leaves by hand -- a wait for the event IN the main stream stood
+        // between the leaves and the next bin for 11 us even when the event had long been reached.
+        static const bool join_in_stream = std::getenv("PHANT_TRIE_JOIN_IN_STREAM") != nullptr;  // (A/B)
+        if (join_in_stream) {
+            TB_TRY(hipStreamWaitEvent(st, ws.side_join, 0));
+        } else {
+            hipError_t q;
+            while ((q = hipEventQuery(ws.side_join)) == hipErrorNotReady) {
+            }
+            TB_TRY(q);
+        }
         for (int d = deep_from - 1; d >= 0; --d) launch_bin(d, st);
     } else {
-        hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t, nullptr, nullptr);
+        if (!ahead) hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), 0, st, t, nullptr, nullptr);
         // (leaves of 136 .. 543 bytes: identify_kernel said whether there can be any -- a grid of lanes that only find out that
         // their leaf is small was 24 us per million keys)
         if (cnt[3])
             hipLaunchKernelGGL(leaf_big_kernel, dim3((n + BRANCH_LANES - 1u) / BRANCH_LANES), dim3(BRANCH_LANES), 0, st, t);
         for (int d = MAX_DEPTH_BINS - 1; d >= 0; --d) launch_bin(d, st);
     }
+    // The end of the call the same way: finish_kernel, last in the stream, puts the overflow flag into the mailbox and raises
+    // MAILBOX_DONE; the host watches that word instead of sleeping on the stream behind a 12-byte copy (10 000 keys: 0.237 against
+    // 0.248 ms per call; a million: the same).  Everything this call queued has run when the word is there.
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, st, t);
     TB_TRY(hipGetLastError());
-    TB_TRY(hipMemcpyAsync(ws.mailbox, t.counters, 3 * 4, hipMemcpyDeviceToHost, st));
-    TB_TRY(hipStreamSynchronize(st));
+    {
+        const int32_t rc = wait_for(MAILBOX_DONE);
+        if (rc) return rc;
+    }
     if (ws.mailbox[2]) {
         err = "trie scratch overflow (internal bound too small)";
         return PHANT_E_DEVICE;

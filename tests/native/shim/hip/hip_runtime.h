@@ -483,7 +483,7 @@ struct hipemu_event {
 };
 typedef hipemu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocCoherent = 0x40000000 };
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 struct hipDeviceProp_t {
     char name[256];

@@ -2,8 +2,10 @@
 deepest bins run beside the bulk of the leaves from 65 536 keys on -- which only a big trie on the GPU reaches.  Here every bin of
 small tries runs in the one- / two-block class (what does not fit takes the fallback list), with a fallback grid of ONE
 workgroup (the grid-stride loop); and tries of a few hundred keys split their leaves (the keys under the deepest nodes first, listed
-by order_kernel, then the deepest bins on the helper stream next to the rest); and with the node-per-half-wave kernel off, which
-otherwise takes every bin of a small trie.  Against the oracle: the test bodies of
+by order_kernel, then the deepest bins on the helper stream next to the rest) -- in both orders of launching: the bulk of the leaves
+queued behind order_kernel with worst-case tables (the default up to 8 M keys), and after the host has read the node count
+(PHANT_TRIE_AHEAD_MAX_KEYS=0: what tries beyond that get); and with the node-per-half-wave kernel off, which otherwise takes every
+bin of a small trie.  Against the oracle: the test bodies of
 tests/test_gpu_trie.py over the emulated kernels (tests/emu.py), each setting in a process of its own (the knobs are read once)."""
 import os
 import subprocess
@@ -18,8 +20,10 @@ SUBSET = "random_vs_oracle or variable_length or state_root_random or block_root
 @pytest.mark.parametrize("env", [{"PHANT_TRIE_SLOT_BLOCKS": "1", "PHANT_TRIE_FALLBACK_GRID": "1"},
                                  {"PHANT_TRIE_SLOT_BLOCKS": "2", "PHANT_TRIE_FALLBACK_GRID": "1"},
                                  {"PHANT_TRIE_SIDE_MIN_KEYS": "257"},
+                                 {"PHANT_TRIE_SIDE_MIN_KEYS": "257", "PHANT_TRIE_AHEAD_MAX_KEYS": "0"},
                                  {"PHANT_TRIE_NO_COOP": "1"}],
-                         ids=["one_block_slots", "two_block_slots", "deepest_bins_beside_the_leaves", "lane_per_node_bins_only"])
+                         ids=["one_block_slots", "two_block_slots", "deepest_bins_beside_the_leaves", "leaves_behind_the_node_count",
+                              "lane_per_node_bins_only"])
 def test_slot_classes_and_fallback_lists(env):
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_emu_trie.py", "-x", "-q", "-p", "no:cacheprovider", "-k", SUBSET],
                        cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)

@@ -19,7 +19,7 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e)
 P
 }
-for round in 1 2 3; do
+for round in 1 2; do
   for so in old new; do one ${so}_1M_$round $so 1000000; one ${so}_100k_$round $so 100000; one ${so}_10k_$round $so 10000; done
 done
 cp tools/_ab/new.so phant_amd/libphant_gpu.so
