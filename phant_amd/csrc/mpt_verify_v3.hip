@@ -1299,7 +1299,7 @@ PHANT_DEV void coop_node(const Args& a, const CoopLane& c, const uint32_t l, con
 
 __global__ void __launch_bounds__(256) hash_coop_kernel(const Args a, const uint32_t levels) {
     const uint32_t tid = threadIdx.x, l = tid & 31u, base = tid & 32u;
-    const uint32_t h = blockIdx.x * 8u + (tid >> 5);
+    const uint32_t h = blockIdx.x * (blockDim.x >> 5) + (tid >> 5);  // (workgroups of four waves, or of one: see the launch)
     const uint32_t p = h / levels, level = h % levels;
     uint32_t first = 0, count = 0, root = 0;
     if (p < a.v.n) {
@@ -1310,7 +1310,7 @@ __global__ void __launch_bounds__(256) hash_coop_kernel(const Args a, const uint
         if (a.v.root_idx) root = a.v.root_idx[p];
     }
     const uint32_t stat_word = HDR_STAT + HDR_STAT_WORDS * (a.hdr[HDR_PARITY] & 1u) + N_CLASS * (h % HDR_STAT_STRIPES);
-    const CoopLane c = coop_lane(l, base);
+    const CoopLane c = coop_lane(l, base, gridDim.x * (blockDim.x >> 6) <= 1024u);  // (a wave per SIMD at most)
     for (uint32_t d = level;; d += levels) {
         if (__ballot(d < count) == 0ull) break;
         coop_node(a, c, l, base, d < count, p, first + d, d, root, stat_word);
@@ -1352,7 +1352,8 @@ __global__ void __launch_bounds__(256) hash_late_kernel(const Args a) {
         return;
     }
     const uint32_t l = tid & 31u, base = tid & 32u;
-    const CoopLane c = coop_lane(l, base);
+    static_assert(COOP_MAX_NODES <= 2048u, "a wave per SIMD at most on this path");
+    const CoopLane c = coop_lane(l, base, true);
     for (uint32_t h0 = (blockIdx.x * 4u + (tid >> 6)) * 2u;; h0 += gridDim.x * 8u) {  // (h0: the wave's first half's entry)
         if (h0 >= total) break;
         const uint32_t e = h0 + (base >> 5);
@@ -2188,7 +2189,10 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         // about as long as the levels walked (a batch of many empty or short proofs would be mostly idle half waves)
         const uint64_t halves = (uint64_t)v.n * deep_levels;
         if (total_nodes && total_nodes <= tune.coop_max && !tune.no_coop && halves <= 4ull * COOP_MAX_NODES)
-            hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);
+            // (the sponge's fetches share the CU's LDS pipeline: with one wave on a CU a permutation takes 4.9 us, with four 5.7 --
+            // up to two waves per CU the workgroups are single waves, which the dispatcher spreads over the CUs)
+            if (halves <= 1024u) hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 1u) / 2u)), dim3(64), 0, st, a, deep_levels);
+            else hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);
         else if (total_nodes)
             hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, wpl, deep_levels);
         hipLaunchKernelGGL((walk_kernel<true, false>), dim3(pg), dim3(256), 0, st, a);

@@ -1167,7 +1167,7 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
     // half's -- with the other half's surplus predicated off.  A wave is as long as its longer half anyway.)
     __shared__ uint32_t s_node[8][BRANCH_STAGE_DW];
     const uint32_t tid = threadIdx.x, hw = tid >> 5, l = tid & 31u, base = tid & 32u;  // (base: the half's first lane in its wave)
-    const uint32_t q = blockIdx.x * 8u + hw;
+    const uint32_t q = blockIdx.x * (blockDim.x >> 5) + hw;  // (workgroups of four waves, or of one: see the launch)
     const bool live = q < count;
     const uint32_t node = live ? t.order[begin + q] : 0u;
     uint32_t dn = 0, parent = NONE, lkey = 0, ext_len = 0, vk = NONE;
@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
         for (uint32_t k = 0; k < total; ++k) t.slot_bytes[slot * 32u + k] = b[k];
         t.slot_len[slot] = (uint8_t)total;
     }
-    const CoopLane c = coop_lane(l, base);
+    const CoopLane c = coop_lane(l, base, count <= 2048u);  // (two nodes a wave: a wave per SIMD at most)
     uint32_t lo = 0, hi = 0;
     PHANT_WAVE_LDS_SYNC();  // (lane 0's padding bytes and the embedded node's copy-out are through)
     coop_keccak256(c, buf, nb, coop_wave_max(nb, base), lo, hi);
@@ -1510,7 +1510,10 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         static const bool no_coop = std::getenv("PHANT_TRIE_NO_COOP") != nullptr;  // (A/B)
         static const uint32_t coop_max = std::getenv("PHANT_TRIE_COOP_MAX") ? (uint32_t)std::min(std::max(std::atoi(std::getenv("PHANT_TRIE_COOP_MAX")), 0), 1 << 20) : COOP_MAX_NODES;  // (A/B)
         if (c <= coop_max && !no_coop && !force_blocks) {
-            hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 7u) / 8u), dim3(256), 0, on, t, depth_begin[d], c);
+            // (the sponge's fetches share the CU's LDS pipeline: with one wave on a CU a permutation takes 4.9 us, with four 5.7 --
+            // up to two waves per CU the workgroups are single waves, which the dispatcher spreads over the CUs)
+            if (c <= 1024u) hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 1u) / 2u), dim3(64), 0, on, t, depth_begin[d], c);
+            else hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 7u) / 8u), dim3(256), 0, on, t, depth_begin[d], c);
             return;
         }
         const uint64_t children = cnt[8 + MAX_DEPTH_BINS + d];

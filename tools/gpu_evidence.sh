@@ -63,6 +63,8 @@ f=$(find /tmp/prof_t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && (head 
 python tools/probe_walk_report.py /tmp/prof_t head_kernel | tail -1 | tr ' ' '\n' | grep -v '^$' > "$OUT/mptize_timeline.txt"
 bash tools/gpu_prof.sh "${1:-evidence}/state_root_prof" state_offsets_check_kernel python $R/tools/bench_state.py --accounts 200000 --slots 5 > /dev/null 2>&1
 [ -x tools/ubench/overlap ] && timeout 60 tools/ubench/overlap > "$OUT/overlap_ubench.txt" 2>&1; grep -c overlap "$OUT/overlap_ubench.txt"
+[ -x tools/ubench/coop_sponge ] && timeout 60 tools/ubench/coop_sponge > "$OUT/coop_sponge_ubench.txt" 2>&1; grep -c "waves/SIMD" "$OUT/coop_sponge_ubench.txt"
+for n in 100 256; do rm -rf /tmp/pws; ( cd /tmp && PROOFS=$n timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pws -o p -- python $R/tools/probe_walk.py > /dev/null 2>&1 ); echo "$n proofs: $(python tools/probe_walk_report.py /tmp/pws | tail -1 | cut -c1-110)"; done > "$OUT/timeline_small_witness.txt"
 timeout 200 python tools/probe_power.py --seconds 2 --out "$OUT/power_and_clock_per_phase.jsonl" > "$OUT/probe_power.log" 2>&1
 timeout 200 python tools/probe_bound_power.py 5000 > "$OUT/bound_experiment_power.txt" 2>&1
 for w in 2048 256; do PHANT_DIAG_STREAM_WGS=$w timeout 100 python tools/probe_bound.py 2>/dev/null | tail -2 | sed "s/^/stream workgroups $w: /"; done > "$OUT/bound_experiment.txt"

@@ -65,6 +65,81 @@ __global__ void __launch_bounds__(64) coop_kernel(const uint64_t* __restrict__ i
     if (live) out[st] = ((uint64_t)hi << 32) | lo;
 }
 
+// Variants of the round with fewer DEPENDENT trips through the crossbar (the same lane layout):
+//   V = 1  theta's column in one trip (four independent fetches), D from C's neighbours (second trip), pi and chi's neighbours in ONE
+//          trip (B[x + k, y] fetched from the pre-pi lanes directly): 18 fetches, 3 trips
+//   V = 3  theta as in the product (two trips for the column, one for D), pi + chi in one trip: 16 fetches, 4 trips
+//   V = 2  D straight from A (ten words: columns x - 1 and x + 1), pi + chi in one trip: 26 fetches, 2 trips
+template <int V>
+__global__ void __launch_bounds__(64) coop_kernel_v(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int perms) {
+    const uint32_t lane = threadIdx.x & 63u, g = lane >> 5, l = lane & 31u;
+    const bool live = l < 25u;
+    const uint32_t ll = live ? l : 0u, x = ll % 5u, y = ll / 5u, base = 32u * g;
+    const uint32_t up5 = base + (ll + 5u) % 25u, up10 = base + (ll + 10u) % 25u, up15 = base + (ll + 15u) % 25u, up20 = base + (ll + 20u) % 25u;
+    const uint32_t xm1 = base + (x + 4u) % 5u + 5u * y, xp1 = base + (x + 1u) % 5u + 5u * y;
+    uint32_t pis[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        const uint32_t xx = (x + k) % 5u;
+        pis[k] = base + (xx + 3u * y) % 5u + 5u * xx;  // the lane (x', y') takes from ((x' + 3 y') mod 5, x')
+    }
+    uint32_t cm[5], cp[5];  // columns x - 1 and x + 1, every row
+#pragma unroll
+    for (uint32_t k = 0; k < 5u; ++k) {
+        cm[k] = base + (x + 4u) % 5u + 5u * k;
+        cp[k] = base + (x + 1u) % 5u + 5u * k;
+    }
+    uint32_t rho = 0;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) rho = ll == (uint32_t)i ? (uint32_t)RHO[i] : rho;
+    const bool swap = rho >= 32u, norot = (rho & 31u) == 0u;
+    const uint32_t sh = 32u - (rho & 31u);
+    const size_t st = ((size_t)blockIdx.x * 2u + g) * 25u + ll;
+    uint64_t a64 = in[st];
+    uint32_t lo = (uint32_t)a64, hi = (uint32_t)(a64 >> 32);
+    for (int p = 0; p < perms; ++p) {
+        for (int r = 0; r < 24; ++r) {
+            if (V == 1) {
+                const uint32_t al = fetch(lo, up5), ah = fetch(hi, up5), bl_ = fetch(lo, up10), bh_ = fetch(hi, up10);
+                const uint32_t dl = fetch(lo, up15), dh = fetch(hi, up15), el = fetch(lo, up20), eh = fetch(hi, up20);
+                const uint32_t cl = xor3(xor3(lo, al, bl_), dl, el), ch = xor3(xor3(hi, ah, bh_), dh, eh);
+                const uint32_t ml = fetch(cl, xm1), mh = fetch(ch, xm1), pl = fetch(cl, xp1), ph = fetch(ch, xp1);
+                lo = xor3(lo, ml, alignbit(pl, ph, 31));
+                hi = xor3(hi, mh, alignbit(ph, pl, 31));
+            } else if (V == 3) {
+                const uint32_t tl = lo ^ fetch(lo, up5), th = hi ^ fetch(hi, up5);
+                const uint32_t fl = fetch(lo, up20), fh = fetch(hi, up20);
+                const uint32_t cl = xor3(tl, fetch(tl, up10), fl), ch = xor3(th, fetch(th, up10), fh);
+                const uint32_t ml = fetch(cl, xm1), mh = fetch(ch, xm1), pl = fetch(cl, xp1), ph = fetch(ch, xp1);
+                lo = xor3(lo, ml, alignbit(pl, ph, 31));
+                hi = xor3(hi, mh, alignbit(ph, pl, 31));
+            } else {
+                uint32_t ml = 0, mh = 0, pl = 0, ph = 0;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    ml ^= fetch(lo, cm[k]);
+                    mh ^= fetch(hi, cm[k]);
+                    pl ^= fetch(lo, cp[k]);
+                    ph ^= fetch(hi, cp[k]);
+                }
+                lo = xor3(lo, ml, alignbit(pl, ph, 31));
+                hi = xor3(hi, mh, alignbit(ph, pl, 31));
+            }
+            const uint32_t sl = swap ? hi : lo, shh = swap ? lo : hi;
+            const uint32_t rl = norot ? sl : alignbit(sl, shh, sh), rh = norot ? shh : alignbit(shh, sl, sh);
+            const uint32_t b0l = fetch(rl, pis[0]), b1l = fetch(rl, pis[1]), b2l = fetch(rl, pis[2]);
+            const uint32_t b0h = fetch(rh, pis[0]), b1h = fetch(rh, pis[1]), b2h = fetch(rh, pis[2]);
+            lo = chi(b0l, b1l, b2l);
+            hi = chi(b0h, b1h, b2h);
+            if (ll == 0u) {
+                lo ^= KECCAK_RC[r][0];
+                hi ^= KECCAK_RC[r][1];
+            }
+        }
+    }
+    if (live) out[st] = ((uint64_t)hi << 32) | lo;
+}
+
 // the product's form: a state per lane
 __global__ void __launch_bounds__(64) lane_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int perms) {
     const size_t st = ((size_t)blockIdx.x * 64u + threadIdx.x) * 25u;
@@ -120,6 +195,17 @@ int main() {
     size_t bad = 0;
     for (size_t i = 0; i < r1.size(); ++i) bad += r1[i] != r2[i];
     printf("cooperative vs lane-per-state, 128 states x 3 permutations: %zu words differ\n", bad);
+    for (int v = 1; v <= 3; ++v) {
+        if (v == 1) hipLaunchKernelGGL(coop_kernel_v<1>, dim3(64), dim3(64), 0, 0, in, o2, 3);
+        else if (v == 2) hipLaunchKernelGGL(coop_kernel_v<2>, dim3(64), dim3(64), 0, 0, in, o2, 3);
+        else hipLaunchKernelGGL(coop_kernel_v<3>, dim3(64), dim3(64), 0, 0, in, o2, 3);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r2.data(), o2, r2.size() * 8, hipMemcpyDeviceToHost));
+        size_t b = 0;
+        for (size_t i = 0; i < r1.size(); ++i) b += r1[i] != r2[i];
+        printf("variant %d (fewer dependent trips) vs lane-per-state: %zu words differ\n", v, b);
+        bad += b;
+    }
     const int perms = 64;
     printf("%u SIMDs; %d permutations per wave, HIP events\n", simds, perms);
     printf("%-44s %10s %14s %16s\n", "form, waves", "ms", "us / perm", "M states x perm / s");
@@ -128,6 +214,11 @@ int main() {
         const double t1 = time_ms(lane_kernel, waves, in, o1, perms), t2 = time_ms(coop_kernel, waves, in, o2, perms);
         printf("lane per state (64 / wave), %5.2f waves/SIMD %10.3f %14.2f %16.1f\n", occ, t1, t1 * 1e3 / perms, 64.0 * waves * perms / (t1 * 1e-3) / 1e6);
         printf("25 lanes per state (2 / wave), %5.2f waves/SIMD %7.3f %14.2f %16.1f\n", occ, t2, t2 * 1e3 / perms, 2.0 * waves * perms / (t2 * 1e-3) / 1e6);
+        const double t3 = time_ms(coop_kernel_v<1>, waves, in, o2, perms), t4 = time_ms(coop_kernel_v<2>, waves, in, o2, perms);
+        printf("  ... 3 trips / 18 fetches a round, %5.2f waves/SIMD %5.3f %11.2f %16.1f\n", occ, t3, t3 * 1e3 / perms, 2.0 * waves * perms / (t3 * 1e-3) / 1e6);
+        printf("  ... 2 trips / 26 fetches a round, %5.2f waves/SIMD %5.3f %11.2f %16.1f\n", occ, t4, t4 * 1e3 / perms, 2.0 * waves * perms / (t4 * 1e-3) / 1e6);
+        const double t5 = time_ms(coop_kernel_v<3>, waves, in, o2, perms);
+        printf("  ... 4 trips / 16 fetches a round, %5.2f waves/SIMD %5.3f %11.2f %16.1f\n", occ, t5, t5 * 1e3 / perms, 2.0 * waves * perms / (t5 * 1e-3) / 1e6);
     }
     return bad ? 1 : 0;
 }
