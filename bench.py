@@ -1157,7 +1157,7 @@ def main():
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
                                 "node-set pipeline = classify_kernel (class lists) + hash_set_kernel + "
                                 "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
-                                "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + per depth bin branch_kernel<1|2|4> or, for a thin bin, branch_coop_kernel (first start to last end)"
+                                "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + per depth bin branch_kernel<1|2|4> or, for a thin bin, branch_coop_kernel, finish_kernel (first start to last end)"
                                 if args.workload == "mptize" else
                                 "mpt_verify_fused_kernel" if args.verify_mode == "fused" else pipeline),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
