@@ -1455,6 +1455,15 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     t.mailbox = ws.mailbox;
     t.mailbox_tag = mbox[MAILBOX_READY] + 1u;  // (the previous call ended with a synchronisation: nothing else writes the word)
     if (t.mailbox_tag == 0u) t.mailbox_tag = 1u;
+    // (from here on kernels of this call may be in the stream when something fails: whatever the way out, the stream is waited for
+    // before the arenas can be handed to another call -- the good way out ends on MAILBOX_DONE and has nothing left to wait for)
+    struct MainGuard {
+        hipStream_t s;
+        bool armed = true;
+        ~MainGuard() {
+            if (armed) (void)hipStreamSynchronize(s);
+        }
+    } main_guard{st};
     hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
     // (the bulk of the leaves: with room for the bins beside them wherever order_kernel MAY decide for such bins)
     if (ahead) hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), t.side_ok ? side_lds_knob : 0u, st, t, nullptr, nullptr);
@@ -1478,7 +1487,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     }
     const std::vector<uint32_t> cnt(ws.mailbox, ws.mailbox + N_COUNTERS);
     const int deep_from = (int32_t)ws.mailbox[MAILBOX_DEEP_FROM];
-    if (cnt[1]) (void)hipStreamSynchronize(st);  // (order_kernel and the leaves, which do nothing on such keys, are through before the arenas are anyone else's)
+    // (keys lcp_kernel refused: order_kernel and the leaves do nothing on them; main_guard waits for both on the way out)
     if (cnt[1] & ERR_KEY_RANGE) {
         err = "key longer than 255 bytes, or key offsets not monotone";
         return PHANT_E_INVALID_ARG;
@@ -1596,6 +1605,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         err = "trie scratch overflow (internal bound too small)";
         return PHANT_E_DEVICE;
     }
+    main_guard.armed = false;
     return PHANT_OK;
 }
 
