@@ -196,6 +196,7 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     if (const char* t = std::getenv("PHANT_VERIFY_KEY_ORDERED")) c->tune.key_ordered = t[0] == '1';
     // the S = 0 form's node-per-half-wave kernel (A/B): never / up to this many nodes
     c->tune.no_coop = std::getenv("PHANT_VERIFY_NO_COOP") != nullptr;
+    c->tune.no_wave = std::getenv("PHANT_VERIFY_NO_WAVE") != nullptr;
     if (const char* t = std::getenv("PHANT_VERIFY_COOP_MAX")) {
         const long v = std::strtol(t, nullptr, 10);
         c->tune.coop_max = (uint32_t)(v < 0 ? 0 : v > (1 << 20) ? (1 << 20) : v);

@@ -11,6 +11,8 @@
 // for launches of a few thousand nodes at most -- the thin depth bins of the trie hasher (trie_build.hip), the witness of an
 // ordinary block (mpt_verify_v3.hip).
 #pragma once
+#include <phant_platform.h>
+
 #include "keccak_f1600.hip.h"
 
 namespace phant {
@@ -75,6 +77,66 @@ PHANT_DEV void coop_permute(const CoopLane& c, uint32_t& lo, uint32_t& hi) {
         lo = xor3(lo, ml, alignbit(pl, ph, 31));
         hi = xor3(hi, mh, alignbit(ph, pl, 31));
         const uint32_t s0 = c.swap ? hi : lo, s1 = c.swap ? lo : hi;  // rho: rotl64 by the lane's amount
+        const uint32_t rl = c.norot ? s0 : alignbit(s0, s1, c.sh), rh = c.norot ? s1 : alignbit(s1, s0, c.sh);
+        lo = chi(coop_fetch(rl, c.pis0), coop_fetch(rl, c.pis1), coop_fetch(rl, c.pis2));  // pi and chi
+        hi = chi(coop_fetch(rh, c.pis0), coop_fetch(rh, c.pis1), coop_fetch(rh, c.pis2));
+        lo ^= (uint32_t)__builtin_amdgcn_readlane((int)c.rcl, r) & c.iota;  // iota
+        hi ^= (uint32_t)__builtin_amdgcn_readlane((int)c.rch, r) & c.iota;
+    }
+}
+
+// ---- ONE state per wave, theta without the crossbar ----
+// lane = x + 8 y (y = 0 .. 4: lanes 0 .. 39; lanes 5 .. 7 of every eight hold COPIES of columns 0, 1 and 4, so that a column's
+// x - 1 / x + 1 neighbours are one row rotation / shift away; lanes 40 .. 63 hold zero).  The column parity: y and y + 1 share a
+// 16-lane row (a DPP rotation by 8), then "mine XOR the lane 16 away", "... 32 away" (v_permlane16_swap / v_permlane32_swap of a
+// value with itself): every lane of a column, copies included, ends with its parity.  D by two DPP moves per half.  rho local.  pi
+// and chi's neighbours in ONE trip through the LDS crossbar, six fetches: every lane, the copies too, fetches its own three words
+// from the real lanes, so the copies are exact again after every round.  3.8 us per permutation at a quarter wave per SIMD, 4.0 at
+// one, 5.2 at two, 8.6 at four (the half-wave form: 4.9 / 5.7 / 8.4 / 16.5 -- at half as many waves per node:
+// tools/ubench/coop_sponge.hip).  `lane`: the lane's index in its wave; the digest: the words of lanes 0 .. 3.
+struct WaveLane {
+    uint32_t lane, word, pis0, pis1, pis2, sh, rcl, rch, iota;  // word: x + 5 y, or 25 in the lanes that hold none
+    bool used, real, swap, norot;                                 // used: lane < 40; real: not a copy
+};
+PHANT_DEV WaveLane wave_lane(uint32_t lane) {
+    constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5 y]
+    WaveLane c;
+    c.lane = lane;
+    c.used = lane < 40u;
+    const uint32_t col = lane & 7u;
+    c.real = c.used && col < 5u;
+    const uint32_t x = col < 5u ? col : (col == 5u ? 0u : (col == 6u ? 1u : 4u)), y = c.used ? lane >> 3 : 0u;
+    c.word = c.used ? x + 5u * y : 25u;
+    const uint32_t x1 = (x + 1u) % 5u, x2 = (x + 2u) % 5u;
+    c.pis0 = 8u * x + (x + 3u * y) % 5u;  // pi: the lane (x', y') takes from ((x' + 3 y') mod 5, x'); chi wants x', x' + 1, x' + 2
+    c.pis1 = 8u * x1 + (x1 + 3u * y) % 5u;
+    c.pis2 = 8u * x2 + (x2 + 3u * y) % 5u;
+    uint32_t rho = 0;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) rho = (x + 5u * y) == (uint32_t)i ? (uint32_t)RHO[i] : rho;
+    c.swap = rho >= 32u;
+    c.norot = (rho & 31u) == 0u;
+    c.sh = 32u - (rho & 31u);
+    c.rcl = lane < 24u ? KECCAK_RC[lane][0] : 0u;
+    c.rch = lane < 24u ? KECCAK_RC[lane][1] : 0u;
+    c.iota = (c.used && x == 0u && y == 0u) ? 0xffffffffu : 0u;
+    return c;
+}
+PHANT_DEV uint32_t wave_column_parity(uint32_t v, uint32_t lane) {  // (lanes 40 .. 63 hold zero)
+    const uint32_t s = v ^ PHANT_ROW_ROR8_ROWS012(v, lane);
+    const uint32_t t = PHANT_XOR_LANE16(s, lane);
+    return PHANT_XOR_LANE32(t, lane);
+}
+PHANT_DEV void wave_permute(const WaveLane& c, uint32_t& lo, uint32_t& hi) {
+    for (int r = 0; r < 24; ++r) {
+        lo = c.used ? lo : 0u;
+        hi = c.used ? hi : 0u;
+        const uint32_t cl = wave_column_parity(lo, c.lane), ch = wave_column_parity(hi, c.lane);  // theta
+        const uint32_t ml = PHANT_ROW_ROR1(cl, c.lane), mh = PHANT_ROW_ROR1(ch, c.lane);  // column x - 1 (a row's first lane: the copy of column 4 in its last)
+        const uint32_t pl = PHANT_ROW_SHL1(cl, c.lane), ph = PHANT_ROW_SHL1(ch, c.lane);  // column x + 1 (column 4: the copy of column 0 next to it)
+        lo = xor3(lo, ml, alignbit(pl, ph, 31));
+        hi = xor3(hi, mh, alignbit(ph, pl, 31));
+        const uint32_t s0 = c.swap ? hi : lo, s1 = c.swap ? lo : hi;  // rho
         const uint32_t rl = c.norot ? s0 : alignbit(s0, s1, c.sh), rh = c.norot ? s1 : alignbit(s1, s0, c.sh);
         lo = chi(coop_fetch(rl, c.pis0), coop_fetch(rl, c.pis1), coop_fetch(rl, c.pis2));  // pi and chi
         hi = chi(coop_fetch(rh, c.pis0), coop_fetch(rh, c.pis1), coop_fetch(rh, c.pis2));

@@ -82,6 +82,7 @@ struct VerifyTune {
     bool key_ordered = false;
     uint32_t coop_max = 2048;      // S = 0 form: batches of up to this many nodes take the node-per-half-wave hash kernel
     bool no_coop = false;
+    bool no_wave = false;  // (A/B: small S = 0 launches through the half-wave kernel, not the wave-per-node one)
     uint32_t* last_form = nullptr; // diagnostics: 0 = S = 0, 1 = table form, 2 = ordered (own order), 3 = ordered (caller's order)
     // diagnostics (phant_verify_bound_experiment), on a workspace a complete launch over the same witness has just left: 1 = only
     // the hashing of that launch (deep tier + everything listed, next to each other), 2 = only a coalesced read of the witness's

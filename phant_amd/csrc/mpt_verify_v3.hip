@@ -1214,6 +1214,7 @@ __global__ void __launch_bounds__(256, 4) hash_deep_kernel(const Args a, const u
 // canonical-branch markers checked on exactly those bytes), 25 lanes hold a word of the sponge each (coop_sponge.hip.h: ~6 us
 // per permutation).  Same node states, digests and statistics as deep_role<true>; up to COOP_MAX_NODES nodes per batch.
 constexpr uint32_t COOP_MAX_NODES = 2048;  // (one wave per SIMD: beyond it the shared sponge is no faster than a lane's)
+constexpr uint32_t WAVE_MAX_NODES = 2048;  // (proof, level) pairs up to which the S = 0 form gives a node a whole wave (hash_wave_kernel)
 // One node per half wave (the halves of a wave together: as many rate blocks as the longer node needs, the other half's surplus
 // predicated off -- every cross-lane operation runs with the whole wave).  `present`: this half has a node -- node j, index d in
 // proof p against root `root`.  stat_word: where the half's first lane counts the node (the in-place forms' statistics), or none.
@@ -1315,6 +1316,89 @@ __global__ void __launch_bounds__(256) hash_coop_kernel(const Args a, const uint
         if (__ballot(d < count) == 0ull) break;
         coop_node(a, c, l, base, d < count, p, first + d, d, root, stat_word);
     }
+}
+
+// The same with a WAVE per node and the sponge of coop_sponge.hip.h's second form (theta on DPP and row swaps: 3.8-4.2 us per
+// permutation up to a wave per SIMD against the half wave's 4.9-5.7 at the same node count): the witness of an ordinary block.
+// Everything but the lanes' roles is wave-uniform here.  `present`: node j exists, index d in proof p against root `root`.
+PHANT_DEV void wave_node(const Args& a, const WaveLane& c, const uint32_t l, const uint32_t p, const uint32_t j, const uint32_t d, const uint32_t root,
+                         const uint32_t stat_word) {
+    struct __attribute__((packed, aligned(1))) U64 { unsigned long long v; };
+    const uint32_t nn = 2u * a.v.key_len;
+    const uint64_t e = a.v.node_off[j + 1], b = a.v.node_off[j];
+    const bool active = e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull;
+    if (!active) {
+        if (l == 0) a.nstat[j] = 0u;
+        return;
+    }
+    const uint32_t len = (uint32_t)(e - b);
+    const uint8_t* const ptr = a.v.nodes + b;
+    const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * p;
+    const uint8_t* const refp = ref_location(a, j, d, root, (d >= 1u && d - 1u < nn) ? key_nibble(key, d - 1u) : 16u, b);
+    const uint32_t nb = len / RATE + 1u;
+    const bool branch = len == BRANCH_LEN;
+    uint32_t lo = 0, hi = 0, bad = 0;
+    for (uint32_t k = 0; k < nb; ++k) {
+        if (c.word < 17u) {  // (a copy absorbs what its column's lane absorbs)
+            const uint32_t off = k * RATE + 8u * c.word;
+            unsigned long long w = 0;
+            if (off + 8u <= len) {
+                w = reinterpret_cast<const U64*>(ptr + off)->v;
+            } else {
+#pragma unroll
+                for (uint32_t t = 0; t < 8u; ++t) {
+                    const uint32_t q = off + t;
+                    if (q < len) w |= (unsigned long long)ptr[q] << (8u * t);
+                    else if (q == len) w |= 0x01ull << (8u * t);  // Keccak-256's domain byte
+                }
+            }
+            if (k + 1u == nb && c.word == 16u) w |= 0x80ull << 56;  // the end of pad10*1: the rate's last byte
+            if (branch) {  // f9 02 11 | 16 x (a0 | 32 bytes) | 80: the markers among this lane's bytes
+#pragma unroll
+                for (uint32_t t = 0; t < 8u; ++t) {
+                    const uint32_t q = off + t;
+                    const uint32_t byte = (uint32_t)(w >> (8u * t)) & 0xffu;
+                    const int want = q == 0u ? 0xf9 : q == 1u ? 0x02 : q == 2u ? 0x11 : q == BRANCH_LEN - 1u ? 0x80 : (q < BRANCH_LEN && (q - 3u) % 33u == 0u) ? 0xa0 : -1;
+                    if (want >= 0 && byte != (uint32_t)want) bad = 1u;
+                }
+            }
+            lo ^= (uint32_t)w;
+            hi ^= (uint32_t)(w >> 32);
+        }
+        wave_permute(c, lo, hi);
+    }
+    bool ne = false;
+    if (refp && l < 4u) {
+        const unsigned long long r = reinterpret_cast<const U64*>(refp + 8u * l)->v;
+        ne = (uint32_t)r != lo || (uint32_t)(r >> 32) != hi;
+    }
+    const bool any_bad = __ballot(bad != 0u) != 0ull, any_ne = __ballot(ne) != 0ull;
+    uint32_t ns = NS_HASHED | ((branch && !any_bad) ? NS_CANON : 0u);
+    if (refp) ns |= NS_LINK_CHECKED | (!any_ne ? NS_LINK_OK : 0u);
+    if (l < 4u) {
+        a.digest[8ull * j + 2u * l] = lo;
+        a.digest[8ull * j + 2u * l + 1u] = hi;
+    }
+    if (l == 0) {
+        a.nstat[j] = (uint8_t)ns;
+        const uint32_t cls = len / RATE < N_CLASS ? len / RATE : N_CLASS - 1u;  // (reporting only, as deep_role)
+        if (stat_word != NO_STAT) atomicAdd(&a.hdr[stat_word + cls], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) hash_wave_kernel(const Args a, const uint32_t levels) {
+    const uint32_t tid = threadIdx.x, l = tid & 63u;
+    const uint32_t h = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);  // (workgroups of four waves, or of one: see the launch)
+    const uint32_t p = h / levels, level = h % levels;
+    if (p >= a.v.n) return;
+    const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
+    uint32_t count = 0;
+    if (last >= first && last <= a.total_nodes) count = last - first;
+    if (last < first && l == 0) a.hdr[HDR_PFN_BROKEN] = 1u;  // (no shallow tier in this form: see deep_role<true>)
+    const uint32_t root = a.v.root_idx ? a.v.root_idx[p] : 0u;
+    const uint32_t stat_word = HDR_STAT + HDR_STAT_WORDS * (a.hdr[HDR_PARITY] & 1u) + N_CLASS * (h % HDR_STAT_STRIPES);
+    const WaveLane c = wave_lane(l);
+    for (uint32_t d = level; d < count; d += levels) wave_node(a, c, l, p, first + d, d, root, stat_word);
 }
 
 // SET: which of the two list sets (the ordered form hashes its group heads -- set 0 -- next to the comparison and what the
@@ -2189,10 +2273,16 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         // about as long as the levels walked (a batch of many empty or short proofs would be mostly idle half waves)
         const uint64_t halves = (uint64_t)v.n * deep_levels;
         if (total_nodes && total_nodes <= tune.coop_max && !tune.no_coop && halves <= 4ull * COOP_MAX_NODES)
-            // (the sponge's fetches share the CU's LDS pipeline: with one wave on a CU a permutation takes 4.9 us, with four 5.7 --
-            // up to two waves per CU the workgroups are single waves, which the dispatcher spreads over the CUs)
-            if (halves <= 1024u) hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 1u) / 2u)), dim3(64), 0, st, a, deep_levels);
-            else hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);
+            // (the sponge's fetches share the CU's LDS pipeline: up to two waves per CU the workgroups are single waves, which the
+            // dispatcher spreads over the CUs)
+            if (halves <= WAVE_MAX_NODES && !tune.no_wave) {  // a wave per node
+                if (halves <= 512u) hipLaunchKernelGGL(hash_wave_kernel, dim3((uint32_t)halves), dim3(64), 0, st, a, deep_levels);
+                else hipLaunchKernelGGL(hash_wave_kernel, dim3((uint32_t)((halves + 3u) / 4u)), dim3(256), 0, st, a, deep_levels);
+            } else if (halves <= 1024u) {
+                hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 1u) / 2u)), dim3(64), 0, st, a, deep_levels);
+            } else {
+                hipLaunchKernelGGL(hash_coop_kernel, dim3((uint32_t)((halves + 7u) / 8u)), dim3(256), 0, st, a, deep_levels);
+            }
         else if (total_nodes)
             hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, wpl, deep_levels);
         hipLaunchKernelGGL((walk_kernel<true, false>), dim3(pg), dim3(256), 0, st, a);

@@ -43,3 +43,14 @@
 // LDS whose size the LAUNCH names (the compiler must not know it: a kernel's register budget follows from its launch bounds, not
 // from how many workgroups its LDS lets a CU hold)
 #define PHANT_DYNAMIC_LDS(type, name) extern __shared__ type name[]
+
+// Row operations of a wave64 (a row = 16 lanes) for the one-state-per-wave sponge (coop_sponge.hip.h): DPP shifts and rotations
+// inside a row, and "mine XOR the lane 16 / 32 away" -- v_permlane16_swap / v_permlane32_swap of a value with itself, the two
+// results XORed.  No LDS crossbar in any of them.  `lane` = the lane's index in its wave (the host build's forms need it).
+#define PHANT_ROW_SHL1(v, lane) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x101, 0xf, 0xf, false))      /* lane i: lane i + 1 of its row (the last: 0) */
+#define PHANT_ROW_ROR1(v, lane) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x121, 0xf, 0xf, false))      /* lane i: lane i - 1 of its row, the first: the last */
+#define PHANT_ROW_ROR8_ROWS012(v, lane) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x128, 0x7, 0xf, false)) /* rows 0-2: the lane 8 away in the row; row 3: 0 */
+#define PHANT_XOR_LANE16(v, lane) /* v ^ (v of lane ^ 16) */ \
+    ({ const auto r_ = __builtin_amdgcn_permlane16_swap((unsigned int)(v), (unsigned int)(v), false, false); (uint32_t)(r_[0] ^ r_[1]); })
+#define PHANT_XOR_LANE32(v, lane) /* v ^ (v of lane ^ 32) */ \
+    ({ const auto r_ = __builtin_amdgcn_permlane32_swap((unsigned int)(v), (unsigned int)(v), false, false); (uint32_t)(r_[0] ^ r_[1]); })

@@ -1283,6 +1283,123 @@ __global__ void __launch_bounds__(256) branch_coop_kernel(TrieDev t, uint32_t be
     if (hashed && l == 0 && !is_root) t.slot_len[slot] = 32;
 }
 
+// The same with a WAVE per node and the sponge of coop_sponge.hip.h's second form (lane = x + 8 y, theta on DPP and row swaps: 3.8-5.2
+// us per permutation up to two waves per SIMD against the half wave's 4.9-8.4 at the same node count): bins of up to WAVE_MAX_NODES
+// nodes.  Everything but the lanes' roles is wave-uniform here.
+constexpr uint32_t WAVE_MAX_NODES = 2048;
+PHANT_DEV void wave_keccak256(const WaveLane& c, const uint32_t* buf, uint32_t nb, uint32_t& lo, uint32_t& hi) {
+    lo = hi = 0u;
+    for (uint32_t k = 0; k < nb; ++k) {
+        if (c.word < 17u) {  // (a copy absorbs what its column's lane absorbs)
+            lo ^= buf[k * RATE_DWORDS + 2u * c.word];
+            hi ^= buf[k * RATE_DWORDS + 2u * c.word + 1u];
+        }
+        wave_permute(c, lo, hi);
+    }
+}
+__global__ void __launch_bounds__(256) branch_wave_kernel(TrieDev t, uint32_t begin, uint32_t count) {
+    __shared__ uint32_t s_node[4][BRANCH_STAGE_DW];
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, l = tid & 63u;
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + wv;  // (workgroups of four waves, or of one: see the launch)
+    if (q >= count) return;  // (the whole wave; no workgroup barrier below)
+    const uint32_t node = t.order[begin + q];
+    const uint32_t dn = t.dense[node], parent = t.nd_parent[node], lkey = t.nd_l[node], vk = t.value_key[node];
+    const int32_t d = t.lcp[node], pd = t.nd_pd[node];
+    const uint32_t ext_len = (uint32_t)(d - (pd + 1));
+    const bool is_root = parent == NONE;
+    uint32_t* const buf = s_node[wv];
+    uint8_t* const b = reinterpret_cast<uint8_t*>(buf);
+    // ---- the 17-item list (mpt.zig:216-231), sixteen lanes a child each ----
+    for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 64u) buf[k] = 0u;
+    PHANT_WAVE_LDS_SYNC();  // (the buffer is clear before any lane's bytes go in)
+    const uint32_t sl = l < 16u ? t.slot_len[(uint64_t)dn * 16u + l] : 0u;
+    const uint32_t mine = l < 16u ? (sl == 0u ? 1u : (sl == 32u ? 33u : sl)) : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t o = 1; o < 16u; o <<= 1) {
+        const uint32_t up = __shfl(incl, (int)((l - o) & 63u), 64);
+        if (l >= o) incl += up;  // (lanes 16.. add zeros)
+    }
+    const uint32_t children = __shfl(incl, 15, 64);
+    const uint32_t payload = children + 1u;  // (+ the empty value slot)
+    const uint32_t hdr = rlp_list_hdr_size(payload), total = hdr + payload;
+    // A value in the branch, a root whose bytes the caller wants, an extension over a branch too short to be hashed, an extension
+    // longer than the buffer: the general way, on the wave's first lane.
+    const bool plain = vk == NONE && !(is_root && t.root_enc) && (ext_len == 0u || (total >= 32u && 44u + ext_len / 2u < BRANCH_STAGE_BYTES));
+    if (!plain) {
+        if (l == 0) {
+            const BranchPlan p = branch_plan(t, t.order, begin + q, true);
+            branch_emit<BRANCH_STAGE_DW>(t, p, buf, p.need ? atomicAdd(t.cursor, (unsigned long long)p.need) : 0ull);
+        }
+        return;
+    }
+    if (l == 16u) {
+        (void)put_hdr(b, payload, 0xc0u, 0xf7u);
+        b[hdr + children] = 0x80;
+    }
+    if (l < 16u) {
+        uint8_t* w = b + hdr + (incl - mine);
+        if (sl == 0u) {
+            w[0] = 0x80;
+        } else {
+            const uint4* const src = reinterpret_cast<const uint4*>(t.slot_bytes + ((uint64_t)dn * 16u + l) * 32u);
+            const uint4 q0 = src[0], q1 = src[1];
+            const uint32_t qq[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            if (sl == 32u) *w++ = 0xa0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if ((uint32_t)k < sl) w[k] = (uint8_t)(qq[k >> 2] >> (8 * (k & 3)));
+        }
+    }
+    const bool embedded = total < 32u && !is_root;  // (mpt.zig:104,:112; no extension above it: see `plain`)
+    const bool hashed = !embedded;
+    PHANT_WAVE_LDS_SYNC();  // (every lane's bytes are in the buffer)
+    const uint32_t nb = hashed ? blocks_of(total) : 0u;
+    if (hashed && l == 0) {
+        b[total] = 0x01;  // Keccak-256's domain byte and the end of pad10*1
+        b[nb * RATE - 1u] |= 0x80;
+    }
+    const uint64_t slot = !is_root ? (uint64_t)t.dense[parent] * 16u + nib_at(t, lkey, (uint32_t)pd) : 0ull;
+    if (embedded && l == 0) {
+        for (uint32_t k = 0; k < total; ++k) t.slot_bytes[slot * 32u + k] = b[k];
+        t.slot_len[slot] = (uint8_t)total;
+    }
+    if (!hashed) return;
+    const WaveLane c = wave_lane(l);
+    uint32_t lo = 0, hi = 0;
+    PHANT_WAVE_LDS_SYNC();  // (lane 0's padding bytes are through)
+    wave_keccak256(c, buf, nb, lo, hi);
+    // ---- the ExtensionNode above it (mpt.zig:187-193): [HP(path), digest], built by the first lane, hashed by all ----
+    if (ext_len != 0u) {
+        Sponge s;
+        sponge_zero(s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s.lo[k] = __shfl(lo, k, 64);
+            s.hi[k] = __shfl(hi, k, 64);
+        }
+        PHANT_WAVE_LDS_SYNC();  // (every lane has absorbed the branch's last block out of the buffer)
+        for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 64u) buf[k] = 0u;
+        PHANT_WAVE_LDS_SYNC();  // (the buffer is clear)
+        uint32_t out_len = 0;
+        if (l == 0) {
+            out_len = put_extension(b, t, lkey, (uint32_t)(pd + 1), (uint32_t)d, true, s, nullptr, 0u);
+            b[out_len] = 0x01;
+            b[blocks_of(out_len) * RATE - 1u] |= 0x80;
+        }
+        PHANT_WAVE_LDS_SYNC();  // (the extension's bytes and padding are in the buffer)
+        out_len = __shfl(out_len, 0, 64);
+        wave_keccak256(c, buf, blocks_of(out_len), lo, hi);
+    }
+    // ---- the digest: words 0 .. 3 ----
+    if (l < 4u) {
+        uint32_t* const dst = reinterpret_cast<uint32_t*>(is_root ? t.roots + 32ull * trie_of(t, lkey) : t.slot_bytes + slot * 32u);
+        dst[2u * l] = lo;
+        dst[2u * l + 1u] = hi;
+    }
+    if (l == 0 && !is_root) t.slot_len[slot] = 32;
+}
+
 static_assert(BRANCH_STAGE_BYTES_ == BRANCH_STAGE_BYTES && BRANCH_STAGE_DW_ == BRANCH_STAGE_DW, "one slot size for big leaves and branches");
 __global__ void __launch_bounds__(BRANCH_LANES) leaf_big_kernel(TrieDev t) {
     __shared__ uint32_t s_stage[BRANCH_LANES * BRANCH_STAGE_DW];
@@ -1521,8 +1638,15 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         if (c <= coop_max && !no_coop && !force_blocks) {
             // (the sponge's fetches share the CU's LDS pipeline: with one wave on a CU a permutation takes 4.9 us, with four 5.7 --
             // up to two waves per CU the workgroups are single waves, which the dispatcher spreads over the CUs)
-            if (c <= 1024u) hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 1u) / 2u), dim3(64), 0, on, t, depth_begin[d], c);
-            else hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 7u) / 8u), dim3(256), 0, on, t, depth_begin[d], c);
+            static const bool no_wave = std::getenv("PHANT_TRIE_NO_WAVE") != nullptr;  // (A/B: the half-wave kernel for every thin bin)
+            if (c <= WAVE_MAX_NODES && !no_wave) {  // a wave per node
+                if (c <= 512u) hipLaunchKernelGGL(branch_wave_kernel, dim3(c), dim3(64), 0, on, t, depth_begin[d], c);
+                else hipLaunchKernelGGL(branch_wave_kernel, dim3((c + 3u) / 4u), dim3(256), 0, on, t, depth_begin[d], c);
+            } else if (c <= 1024u) {
+                hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 1u) / 2u), dim3(64), 0, on, t, depth_begin[d], c);
+            } else {
+                hipLaunchKernelGGL(branch_coop_kernel, dim3((c + 7u) / 8u), dim3(256), 0, on, t, depth_begin[d], c);
+            }
             return;
         }
         const uint64_t children = cnt[8 + MAX_DEPTH_BINS + d];

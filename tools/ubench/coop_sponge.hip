@@ -140,6 +140,60 @@ __global__ void __launch_bounds__(64) coop_kernel_v(const uint64_t* __restrict__
     if (live) out[st] = ((uint64_t)hi << 32) | lo;
 }
 
+// V = DPP: ONE state per wave, lane = x + 8 y (lanes 5..7 of every eight: copies of columns 0, 1 and 4, so that a column's x - 1 / x + 1
+// neighbours are a row rotation / shift away), theta without the LDS crossbar: the column parity by a row rotation (y and y + 1 share a
+// 16-lane row) and the two row-swap instructions (v_permlane16_swap / v_permlane32_swap), D by DPP shifts; rho local; pi and chi's
+// neighbours in one trip of six fetches (every lane, the copies too, fetches its own three words from the real lanes).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ uint32_t column_parity(uint32_t v) {  // (lanes 40.. hold zero)
+    const uint32_t s = v ^ dpp_mov<0x128, 0x7>(v);                      // row_ror:8 in rows 0-2: y ^ (y + 1) in both halves of a row
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(s, s, false, false);  // rows (0, 1) and (2, 3) exchanged
+    const uint32_t t = a.x ^ a.y;
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(t, t, false, false);  // the wave's halves exchanged
+    return b.x ^ b.y;
+}
+__global__ void __launch_bounds__(64) dpp_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int perms) {
+    const uint32_t L = threadIdx.x & 63u, c = L & 7u;
+    const bool used = L < 40u;
+    const uint32_t x = c < 5u ? c : (c == 5u ? 0u : (c == 6u ? 1u : 4u)), y = used ? (L >> 3) : 0u;
+    uint32_t pis[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        const uint32_t xx = (x + k) % 5u;
+        pis[k] = 8u * xx + (xx + 3u * y) % 5u;  // the lane (x', y') takes from ((x' + 3 y') mod 5, x')
+    }
+    uint32_t rho = 0;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) rho = (x + 5u * y) == (uint32_t)i ? (uint32_t)RHO[i] : rho;
+    const bool swap = rho >= 32u, norot = (rho & 31u) == 0u;
+    const uint32_t sh = 32u - (rho & 31u);
+    const uint32_t iota = (x == 0u && y == 0u && used) ? 0xffffffffu : 0u;
+    const uint32_t rcl = L < 24u ? KECCAK_RC[L][0] : 0u, rch = L < 24u ? KECCAK_RC[L][1] : 0u;
+    const size_t st = (size_t)blockIdx.x * 25u + x + 5u * y;
+    const uint64_t a64 = used ? in[st] : 0ull;
+    uint32_t lo = (uint32_t)a64, hi = (uint32_t)(a64 >> 32);
+    for (int p = 0; p < perms; ++p) {
+        for (int r = 0; r < 24; ++r) {
+            lo = used ? lo : 0u;
+            hi = used ? hi : 0u;
+            const uint32_t cl = column_parity(lo), ch = column_parity(hi);
+            const uint32_t ml = dpp_mov<0x121, 0xf>(cl), mh = dpp_mov<0x121, 0xf>(ch);  // row_ror:1: column x - 1 (lane 0 of a row: the copy of column 4 in lane 15)
+            const uint32_t pl = dpp_mov<0x101, 0xf>(cl), ph = dpp_mov<0x101, 0xf>(ch);  // row_shl:1: column x + 1 (column 4: the copy of column 0 next to it)
+            lo = xor3(lo, ml, alignbit(pl, ph, 31));
+            hi = xor3(hi, mh, alignbit(ph, pl, 31));
+            const uint32_t sl = swap ? hi : lo, shh = swap ? lo : hi;
+            const uint32_t rl = norot ? sl : alignbit(sl, shh, sh), rh = norot ? shh : alignbit(shh, sl, sh);
+            lo = chi(fetch(rl, pis[0]), fetch(rl, pis[1]), fetch(rl, pis[2]));
+            hi = chi(fetch(rh, pis[0]), fetch(rh, pis[1]), fetch(rh, pis[2]));
+            lo ^= (uint32_t)__builtin_amdgcn_readlane((int)rcl, r) & iota;
+            hi ^= (uint32_t)__builtin_amdgcn_readlane((int)rch, r) & iota;
+        }
+    }
+    if (used && c < 5u) out[st] = ((uint64_t)hi << 32) | lo;
+}
+
 // the product's form: a state per lane
 __global__ void __launch_bounds__(64) lane_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int perms) {
     const size_t st = ((size_t)blockIdx.x * 64u + threadIdx.x) * 25u;
@@ -206,6 +260,15 @@ int main() {
         printf("variant %d (fewer dependent trips) vs lane-per-state: %zu words differ\n", v, b);
         bad += b;
     }
+    {   // one state per wave: 128 states = 128 waves
+        hipLaunchKernelGGL(dpp_kernel, dim3(128), dim3(64), 0, 0, in, o2, 3);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(r2.data(), o2, r2.size() * 8, hipMemcpyDeviceToHost));
+        size_t b = 0;
+        for (size_t i = 0; i < r1.size(); ++i) b += r1[i] != r2[i];
+        printf("DPP form (one state per wave) vs lane-per-state: %zu words differ\n", b);
+        bad += b;
+    }
     const int perms = 64;
     printf("%u SIMDs; %d permutations per wave, HIP events\n", simds, perms);
     printf("%-44s %10s %14s %16s\n", "form, waves", "ms", "us / perm", "M states x perm / s");
@@ -218,6 +281,8 @@ int main() {
         printf("  ... 3 trips / 18 fetches a round, %5.2f waves/SIMD %5.3f %11.2f %16.1f\n", occ, t3, t3 * 1e3 / perms, 2.0 * waves * perms / (t3 * 1e-3) / 1e6);
         printf("  ... 2 trips / 26 fetches a round, %5.2f waves/SIMD %5.3f %11.2f %16.1f\n", occ, t4, t4 * 1e3 / perms, 2.0 * waves * perms / (t4 * 1e-3) / 1e6);
         const double t5 = time_ms(coop_kernel_v<3>, waves, in, o2, perms);
+        const double t6 = time_ms(dpp_kernel, waves, in, o2, perms);
+        printf("  ... DPP theta, 1 trip / 6 fetches (1 / wave), %5.2f waves/SIMD %5.3f %8.2f %16.1f\n", occ, t6, t6 * 1e3 / perms, 1.0 * waves * perms / (t6 * 1e-3) / 1e6);
         printf("  ... 4 trips / 16 fetches a round, %5.2f waves/SIMD %5.3f %11.2f %16.1f\n", occ, t5, t5 * 1e3 / perms, 2.0 * waves * perms / (t5 * 1e-3) / 1e6);
     }
     return bad ? 1 : 0;
