@@ -16,7 +16,7 @@ def pytest_configure(config):
 def pytest_cmdline_main(config):
     """`-m "not gpu"` with no -n of the caller's: the suite's time is the kernel sources running on the host (tests/emu.py), one
     core at a time -- its MODULES are spread over a few pytest-xdist workers (a module stays in one process: the emulated
-    library, its contexts and the environment knobs are module-scoped).  22 minutes become 7 on eight cores.
+    library, its contexts and the environment knobs are module-scoped).  Half an hour becomes 7 minutes on eight cores.
     PHANT_CPU_SUITE_WORKERS=0 keeps everything in this process; `-m gpu` is never touched (one GPU, one process)."""
     opt = config.option
     if (getattr(opt, "markexpr", "") or "").strip() != "not gpu" or getattr(opt, "numprocesses", None) is not None:
@@ -26,7 +26,7 @@ def pytest_cmdline_main(config):
     if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):  # (a worker runs this hook too)
         return None
     try:
-        workers = int(os.environ.get("PHANT_CPU_SUITE_WORKERS", min(4, (os.cpu_count() or 1) // 2)))
+        workers = int(os.environ.get("PHANT_CPU_SUITE_WORKERS", min(6, (os.cpu_count() or 1) - 2)))
     except ValueError:
         workers = 0
     if workers < 2:
