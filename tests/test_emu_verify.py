@@ -38,6 +38,7 @@ from tests.test_gpu_verify import (  # noqa: E402,F401
     test_host_form_on_both_sides_of_the_staging_limit, test_which_nodes_get_hashed_per_tier_split,
     test_empty_trie_proves_absence, test_one_byte_off_in_a_duplicate_node, test_bound_experiment_runs_on_a_two_tier_launch,
     test_non_monotone_proof_first_node_matches_oracle, test_synthetic_depth8_small_vs_oracle,
+    test_small_witnesses_on_both_sides_of_every_kernel_choice,
     test_synthetic_other_depths, test_block_witness_accounts_and_storage)
 from tests.test_gpu_x_verify_more import (  # noqa: E402,F401
     test_keys_longer_than_the_lds_staging, test_synthetic_block_witness_vs_oracle)

@@ -35,6 +35,7 @@ def test_mptize_rejects_unsorted(P):
 @pytest.mark.parametrize("n,key_len,shared,vmax", [(1, 32, 0, 40), (2, 32, 0, 40), (3, 1, 0, 5), (16, 1, 0, 3),
                                                      (256, 1, 0, 40), (1000, 32, 0, 120), (1000, 32, 10, 40),
                                                      (5000, 3, 0, 10), (2000, 32, 62, 33), (300, 4, 0, 700),
+                                                     (5000, 32, 0, 60), (9000, 32, 0, 60),  # depth 3: ~1 400 / ~2 600 nodes (a wave / a half wave per node)
                                                      (20000, 32, 0, 90)])
 def test_mptize_random_vs_oracle(P, oracle, n, key_len, shared, vmax):
     rng = np.random.default_rng(n + key_len * 31 + shared)

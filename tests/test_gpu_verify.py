@@ -276,6 +276,28 @@ def test_synthetic_depth8_small_vs_oracle(M, oracle):
     assert int(fails.item()) == w.n_invalid == 75
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 128, 255, 256, 257, 300, 512, 513])
+def test_small_witnesses_on_both_sides_of_every_kernel_choice(M, oracle, n):
+    """The S = 0 form picks its hash kernel from the batch: a wave per node up to 2 048 (proof, level) pairs (single-wave workgroups
+    up to 512 pairs = 64 depth-8 proofs, four-wave ones beyond), a node per half wave while the batch has at most 2 048 nodes, a
+    lane per node after that -- 256 depth-8 proofs are the last wave-per-node batch, 257 the first lane-per-node one.  Statuses and
+    the verdict against the oracle on both sides of each edge, a tenth of the proofs damaged."""
+    import phant_amd
+    from tests import suite
+    if suite.EMULATED and not suite.FULL and n not in (1, 64, 65, 256, 257):
+        pytest.skip("the default CPU suite runs the edges only (tests/suite.py)")
+    w = phant_amd.witness.account_witness(n, depth=8, seed=100 + n, corrupt_frac=0.1)
+    st = M.verify_batch_dev(w.batch)
+    torch.cuda.synchronize()
+    assert torch.equal(st, w.expected)
+    b = w.batch
+    want = oracle.mpt_verify_batch(b.roots.cpu().numpy(), None, b.keys.cpu().numpy(), 32, b.nodes.cpu().numpy(),
+                                   b.node_off.cpu().numpy().astype(np.uint64),
+                                   b.proof_first_node.cpu().numpy().astype(np.uint32))
+    assert np.array_equal(st.cpu().numpy(), want[0])
+    assert int(M.verdict_dev(st, None, 1).item()) == w.n_invalid
+
+
 def test_bound_experiment_runs_on_a_two_tier_launch(M):
     """phant_verify_bound_experiment (diagnostics: the launch's hashing alone, a clean read of the witness alone, both): three positive
     times on a batch that takes a two-tier form, a refusal on one that is hashed whole; the statuses of the verification it starts
