@@ -244,6 +244,16 @@ PHANT_API int32_t phant_mpt_verify_nodeset_dev(phant_ctx *ctx, const uint8_t *d_
                                                uint64_t nodes_len, const uint64_t *d_node_off,
                                                uint32_t total_nodes, uint32_t n, uint8_t *d_status,
                                                uint64_t *d_value_off, uint32_t *d_value_len);
+/* ... with the per-root verdict of phant_mpt_verify_verdict_dev from the same launch: d_fail_count[r] (n_roots x u32,
+ * overwritten) = keys against root r whose status is not PRESENT / ABSENT; a key whose root index is out of range
+ * counts against root 0. */
+PHANT_API int32_t phant_mpt_verify_nodeset_verdict_dev(phant_ctx *ctx, const uint8_t *d_roots, uint32_t n_roots,
+                                                       const uint32_t *d_root_idx, const uint8_t *d_keys,
+                                                       uint32_t key_len, const uint8_t *d_nodes,
+                                                       uint64_t nodes_len, const uint64_t *d_node_off,
+                                                       uint32_t total_nodes, uint32_t n, uint8_t *d_status,
+                                                       uint64_t *d_value_off, uint32_t *d_value_len,
+                                                       uint32_t *d_fail_count);
 
 /* ------------------------------------------------------------------ streaming
  * BASELINE config 5 (consecutive block witnesses, H2D overlapped with verification): up to
@@ -262,6 +272,15 @@ PHANT_API int32_t phant_mpt_verify_submit(phant_ctx *ctx, uint32_t slot, const u
                                           uint64_t nodes_len, const uint64_t *node_off,
                                           const uint32_t *proof_first_node, uint32_t n,
                                           uint8_t *status, uint64_t *value_off, uint32_t *value_len);
+/* The same for a node-set witness (arguments of phant_mpt_verify_nodeset): the form a block's execution witness arrives in
+ * (src/engine_api/execution_payload.zig:121) -- every node crosses the bus once.  Shares the slots with
+ * phant_mpt_verify_submit (a slot holds one submission of either kind until phant_wait). */
+PHANT_API int32_t phant_mpt_verify_nodeset_submit(phant_ctx *ctx, uint32_t slot, const uint8_t *roots,
+                                                  uint32_t n_roots, const uint32_t *root_idx,
+                                                  const uint8_t *keys, uint32_t key_len, const uint8_t *nodes,
+                                                  uint64_t nodes_len, const uint64_t *node_off,
+                                                  uint32_t total_nodes, uint32_t n, uint8_t *status,
+                                                  uint64_t *value_off, uint32_t *value_len);
 PHANT_API int32_t phant_wait(phant_ctx *ctx, uint32_t slot);
 
 /* ------------------------------------------------------------ several GPUs, one process
@@ -514,6 +533,12 @@ PHANT_API int32_t phant_verify_bound_experiment(phant_ctx *ctx, const uint8_t *d
  * ctx stream (synchronises it).  *perms_per_s = permutations per second over the whole chip: the VALU ceiling every hash
  * kernel of this library is measured against (bench.py: roofline.valu.peak). */
 PHANT_API int32_t phant_keccak_rate(phant_ctx *ctx, uint32_t waves_per_simd, uint32_t perms, double *perms_per_s);
+/* Diagnostics (A/B of the node-set pipeline's hash kernel, tools/): ladder = the four-block hash waves lower their issue
+ * priority block by block (default 1); order = 0: class lists by falling rate-block count (default), 1: rising; hash_lds_bytes
+ * = idle dynamic LDS per hash workgroup (caps the hash waves per SIMD; default 0); resident_wgs = the hash grid's cap, its
+ * waves striding over the chunk queue (default 4 x CUs; 0 = a wave per chunk). */
+PHANT_API int32_t phant_nodeset_tune(phant_ctx *ctx, int32_t ladder, uint32_t order, uint32_t hash_lds_bytes,
+                                     uint32_t resident_wgs);
 
 #ifdef __cplusplus
 }

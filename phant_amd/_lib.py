@@ -62,6 +62,10 @@ SYMBOLS = {
     "phant_mpt_verdict_dev": (_i32, [_vp, _vp, _vp, _u32, _u32, _vp]),
     "phant_mpt_verify_nodeset": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
     "phant_mpt_verify_nodeset_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "phant_mpt_verify_nodeset_verdict_dev": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _u32, _vp, _vp, _vp,
+                                                    _vp]),
+    "phant_mpt_verify_nodeset_submit": (_i32, [_vp, _u32, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _u32, _vp, _vp,
+                                               _vp]),
     "phant_host_alloc": (_i32, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "phant_host_free": (_i32, [_vp, _vp]),
     "phant_mpt_verify_submit": (_i32, [_vp, _u32, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp]),
@@ -85,6 +89,7 @@ SYMBOLS = {
     "phant_timing": (_i32, [_vp, _i32]),
     "phant_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "phant_keccak_rate": (_i32, [_vp, _u32, _u32, C.POINTER(C.c_double)]),
+    "phant_nodeset_tune": (_i32, [_vp, _i32, _u32, _u32, _u32]),
     "phant_verify_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float * 7)]),
     "phant_verify_form": (_i32, [_vp, C.POINTER(C.c_uint32)]),
     "phant_verify_bound_experiment": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp, _u32,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(_HERE, "libphant_gpu.so")
-SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v3.hip", "trie_build.hip", "state_root.hip", "radix_sort.hip", "capi.hip", "comm.hip",
+SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v3.hip", "mpt_verify_nodeset.hip", "trie_build.hip", "state_root.hip", "radix_sort.hip", "capi.hip", "comm.hip",
            "witness_json.cpp", "host_rlp.cpp"]
 # (host exceptions ON: the generated extern "C" wrappers -- csrc/capi_guard_*.inc -- turn a std::bad_alloc into PHANT_E_OOM)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,15 @@ struct phant_witness {
     phant::Witness w;
 };
 
+// The workspace of the node-set pipeline (mpt_verify_nodeset.hip): zeroed when it is allocated, never cleared afterwards -- every
+// launch on it carries an epoch greater than all before it.
+struct NodesetSpace {
+    phant::DevArena dv;
+    uint32_t cap_nodes = 0;  // what `dv` is laid out for (grow-only, a power of two: the layout never changes under a live claim word)
+    uint32_t epoch = 0;
+    bool dirty = true;  // to be zeroed before the next launch (fresh memory, a failed launch, the epoch about to wrap)
+};
+
 struct phant_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -32,6 +42,10 @@ struct phant_ctx {
     // grow-only device arenas for the host-form calls
     phant::Workspaces ws;
     phant::DevArena dv;  // workspace of the device-form verify pipeline
+    NodesetSpace ns;     // ... of the node-set pipeline
+    uint32_t ns_salt[2] = {0, 0};  // key of its record table's slot function
+    phant::NodesetTune ns_tune;
+    bool last_was_nodeset = false;  // which pipeline phant_verify_stats reports on
     bool verify_fused = false;
     phant::VerifyTune tune;
     int32_t dedup_levels = -1;  // trie levels deduplicated by the two-tier pipeline: < 0 = from the batch size, 0 = none
@@ -41,6 +55,7 @@ struct phant_ctx {
     struct Slot {
         hipStream_t stream = nullptr;
         phant::DevArena io, dv;
+        NodesetSpace ns;
         bool busy = false;
     } slots[PHANT_MAX_SLOTS];
     uint32_t last_shallow = 0;  // trie levels the last two-tier launch deduplicated (diagnostics)
@@ -179,6 +194,11 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         }
     } holder{c};
     c->device = dev;
+    {
+        std::random_device rd;
+        c->ns_salt[0] = (uint32_t)rd();
+        c->ns_salt[1] = (uint32_t)rd();
+    }
     c->verify_fused = fused;
     c->dedup_levels = dedup_levels;
     // diagnostics / A/B, read once per ctx (tools/sweep_verify.py): the deep tier's occupancy cap, serial tiers
@@ -230,6 +250,7 @@ void phant_ctx_destroy(phant_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     c->ws.release();
     c->dv.release();
+    c->ns.dv.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->kev)
@@ -241,6 +262,7 @@ void phant_ctx_destroy(phant_ctx* c) {
         }
         sl.io.release();
         sl.dv.release();
+        sl.ns.dv.release();
     }
     if (c->side.stream) (void)hipStreamSynchronize(c->side.stream);
     if (c->side.stream2) (void)hipStreamSynchronize(c->side.stream2);
@@ -285,11 +307,20 @@ int32_t phant_timing(phant_ctx* c, int32_t enable) {
 int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
     if (!c || !hashed) return PHANT_E_INVALID_ARG;
     for (int i = 0; i < 8; ++i) hashed[i] = 0;
+    if (c->last_was_nodeset) {
+        if (!c->ns.dv.base) return PHANT_OK;
+        DeviceGuard g(c->device);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint32_t hdr[phant::VERIFY_HEADER_WORDS];
+        HIP_TRY(c, hipMemcpy(hdr, c->ns.dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
+        phant::verify_nodeset_stats_from_header(hdr, c->ns.epoch, hashed, nullptr);
+        return PHANT_OK;
+    }
     if (c->verify_fused || !c->dv.base) return PHANT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->side.stream) HIP_TRY(c, hipStreamSynchronize(c->side.stream));
-    // list counts and the deep tier's striped counters, in the header of the verify workspace (mpt_verify_v2.hip)
+    // list counts and the deep tier's striped counters, in the header of the verify workspace (mpt_verify_v3.hip)
     uint32_t hdr[phant::VERIFY_HEADER_WORDS];
     HIP_TRY(c, hipMemcpy(hdr, c->dv.base, sizeof(hdr), hipMemcpyDeviceToHost));
     phant::verify_stats_from_header(hdr, hashed);
@@ -353,6 +384,15 @@ int32_t phant_last_kernel_ms(phant_ctx* c, float* ms) {
     DeviceGuard g(c->device);
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PHANT_OK;
+}
+
+int32_t phant_nodeset_tune(phant_ctx* c, int32_t ladder, uint32_t order, uint32_t hash_lds_bytes, uint32_t resident_wgs) {
+    if (!c || ladder < 0 || ladder > 2 || order > 1u || hash_lds_bytes > 56u * 1024u) return PHANT_E_INVALID_ARG;
+    c->ns_tune.form = (uint32_t)ladder;
+    c->ns_tune.order = order;
+    c->ns_tune.hash_lds = hash_lds_bytes;
+    c->ns_tune.resident_wgs = resident_wgs;
     return PHANT_OK;
 }
 
@@ -571,6 +611,7 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
         // correctness; it keeps the first launch on fresh memory deterministic)
         HIP_TRY(c, hipMemsetAsync(dv.base, 0, dv.cap, st));
     }
+    if (&dv == &c->dv) c->last_was_nodeset = false;
     auto launch = [&]() { return phant::launch_mpt_verify(a, total_nodes, dv.base, c->dedup_levels, st, side, c->tune); };
     if (timed) {
         TimedRegion t(c);
@@ -813,25 +854,110 @@ int32_t phant_mpt_verify_batch(phant_ctx* c, const uint8_t* roots, uint32_t n_ro
 
 /* -------------------------------------------------------------- node-set witnesses */
 
+// Runs the node-set pipeline on device-resident arguments on stream `st` with the workspace `sp` (a.fail_count given: the verdict).
+static int32_t nodeset_resident_on(phant_ctx* c, const phant::VerifyArgs& a, uint32_t total_nodes, hipStream_t st, NodesetSpace& sp,
+                                   bool timed) {
+    if (total_nodes > sp.cap_nodes || !sp.dv.base) {
+        const uint32_t cap = phant::verify_nodeset_capacity(total_nodes);
+        HIP_TRY(c, hipStreamSynchronize(st));
+        sp.cap_nodes = 0;
+        hipError_t e = sp.dv.reset(phant::verify_nodeset_workspace_bytes(cap));
+        if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(node-set workspace)", e);
+        sp.cap_nodes = cap;
+        sp.dirty = true;
+    }
+    if (sp.dirty || sp.epoch >= 0xfffffff0u) {
+        HIP_TRY(c, hipMemsetAsync(sp.dv.base, 0, sp.dv.cap, st));
+        sp.epoch = 0;
+        sp.dirty = false;
+    }
+    ++sp.epoch;
+    if (&sp == &c->ns) c->last_was_nodeset = true;
+    hipError_t e;
+    if (timed) {
+        TimedRegion t(c);
+        e = phant::launch_mpt_verify_nodeset(a, total_nodes, sp.cap_nodes, sp.dv.base, sp.epoch, c->ns_salt, st, c->ns_tune);
+    } else {
+        e = phant::launch_mpt_verify_nodeset(a, total_nodes, sp.cap_nodes, sp.dv.base, sp.epoch, c->ns_salt, st, c->ns_tune);
+    }
+    if (e != hipSuccess) {
+        sp.dirty = true;  // (whatever part of the launch ran: the next one starts from zeroed memory)
+        return fail(c, PHANT_E_DEVICE, "launch_mpt_verify_nodeset", e);
+    }
+    return PHANT_OK;
+}
+
+static bool nodeset_args_ok(const uint8_t* roots, uint32_t n_roots, const uint8_t* keys, uint32_t key_len, const uint64_t* node_off,
+                            const uint8_t* status) {
+    return roots && n_roots != 0 && node_off && status && (!key_len || keys) && key_len <= 0x3fffffffu;
+}
+
+int32_t phant_mpt_verify_nodeset_verdict_dev(phant_ctx* c, const uint8_t* d_roots, uint32_t n_roots, const uint32_t* d_root_idx,
+                                             const uint8_t* d_keys, uint32_t key_len, const uint8_t* d_nodes, uint64_t nodes_len,
+                                             const uint64_t* d_node_off, uint32_t total_nodes, uint32_t n, uint8_t* d_status,
+                                             uint64_t* d_value_off, uint32_t* d_value_len, uint32_t* d_fail_count) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    if (n == 0) {
+        if (d_fail_count && n_roots) HIP_TRY(c, hipMemsetAsync(d_fail_count, 0, sizeof(uint32_t) * (size_t)n_roots, c->stream));
+        return PHANT_OK;
+    }
+    if (!nodeset_args_ok(d_roots, n_roots, d_keys, key_len, d_node_off, d_status))
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset_dev: bad argument");
+    phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len, d_node_off, nullptr, n,
+                        d_status, d_value_off, d_value_len};
+    a.fail_count = d_fail_count;
+    return nodeset_resident_on(c, a, total_nodes, c->stream, c->ns, true);
+}
+
 int32_t phant_mpt_verify_nodeset_dev(phant_ctx* c, const uint8_t* d_roots, uint32_t n_roots, const uint32_t* d_root_idx,
                                      const uint8_t* d_keys, uint32_t key_len, const uint8_t* d_nodes, uint64_t nodes_len,
                                      const uint64_t* d_node_off, uint32_t total_nodes, uint32_t n, uint8_t* d_status,
                                      uint64_t* d_value_off, uint32_t* d_value_len) {
-    if (!c) return PHANT_E_INVALID_ARG;
-    if (n == 0) return PHANT_OK;
-    if (!d_roots || n_roots == 0 || !d_node_off || !d_status || (key_len && !d_keys) || key_len > 0x3fffffffu)
-        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset_dev: bad argument");
-    DeviceGuard g(c->device);
-    const size_t need = phant::verify_nodeset_workspace_bytes(total_nodes);
-    if (need > c->dv.cap) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        hipError_t e = c->dv.reset(need);
-        if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(verify workspace)", e);
+    return phant_impl::phant_mpt_verify_nodeset_verdict_dev(c, d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len,
+                                                            d_node_off, total_nodes, n, d_status, d_value_off, d_value_len, nullptr);
+}
+
+// Stage a host node set into `io` on stream `s`, run the pipeline there with the workspace `sp` and queue the copies of the results
+// back into the caller's buffers.  Does NOT wait.  d_fail_out (may be null): where the per-root verdict is left on the device.
+static int32_t nodeset_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& io, NodesetSpace& sp, bool timed, const uint8_t* roots,
+                                  uint32_t n_roots, const uint32_t* root_idx, const uint8_t* keys, uint32_t key_len,
+                                  const uint8_t* nodes, uint64_t nodes_len, const uint64_t* node_off, uint32_t total_nodes, uint32_t n,
+                                  uint8_t* status, uint64_t* value_off, uint32_t* value_len, uint32_t** d_fail_out) {
+    const size_t need = ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) + ws_round((size_t)n * key_len + 4) +
+                        ws_round((size_t)nodes_len + 16) + ws_round(((size_t)total_nodes + 1) * 8) + ws_round(n) +
+                        ws_round((size_t)n * 8) + ws_round((size_t)n * 4) + ws_round((size_t)n_roots * 4);
+    if (need > io.cap) HIP_TRY(c, hipStreamSynchronize(s));
+    {
+        hipError_t e = io.reset(need);
+        if (e != hipSuccess) return fail(c, PHANT_E_OOM, "hipMalloc(workspace)", e);
     }
-    phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len, d_node_off, nullptr, n,
-                        d_status, d_value_off, d_value_len};
-    TimedRegion t(c);
-    HIP_TRY(c, phant::launch_mpt_verify_nodeset(a, total_nodes, c->dv.base, c->stream));
+    uint8_t* d_roots = io.take<uint8_t>((size_t)n_roots * 32);
+    uint32_t* d_ridx = io.take<uint32_t>(n);
+    uint8_t* d_keys = io.take<uint8_t>((size_t)n * key_len + 4);
+    uint8_t* d_nodes = io.take<uint8_t>((size_t)nodes_len + 16);
+    uint64_t* d_noff = io.take<uint64_t>((size_t)total_nodes + 1);
+    uint8_t* d_status = io.take<uint8_t>(n);
+    uint64_t* d_voff = io.take<uint64_t>(n);
+    uint32_t* d_vlen = io.take<uint32_t>(n);
+    uint32_t* d_fail = io.take<uint32_t>(n_roots);
+    if (io.overflowed) return fail(c, PHANT_E_DEVICE, "node-set staging arena undersized");
+    HIP_TRY(c, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 32, hipMemcpyHostToDevice, s));
+    if (root_idx) HIP_TRY(c, hipMemcpyAsync(d_ridx, root_idx, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
+    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nodes_len, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_noff, node_off, ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
+    phant::VerifyArgs a{d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len, d_noff, nullptr, n,
+                        d_status, d_voff, d_vlen};
+    if (d_fail_out) {
+        a.fail_count = d_fail;
+        *d_fail_out = d_fail;
+    }
+    const int32_t rc = nodeset_resident_on(c, a, total_nodes, s, sp, timed);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
+    if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (value_len) HIP_TRY(c, hipMemcpyAsync(value_len, d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     return PHANT_OK;
 }
 
@@ -841,35 +967,16 @@ int32_t phant_mpt_verify_nodeset(phant_ctx* c, const uint8_t* roots, uint32_t n_
                                  uint64_t* value_off, uint32_t* value_len) {
     if (!c) return PHANT_E_INVALID_ARG;
     if (n == 0) return PHANT_OK;
-    if (!roots || n_roots == 0 || !node_off || !status || (key_len && !keys) || (nodes_len && !nodes) || key_len > 0x3fffffffu)
+    if (!nodeset_args_ok(roots, n_roots, keys, key_len, node_off, status) || (nodes_len && !nodes))
         return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset: null pointer");
     DeviceGuard g(c->device);
-    hipStream_t s = c->stream;
-    const size_t need = ws_round((size_t)n_roots * 32) + ws_round((size_t)n * 4) + ws_round((size_t)n * key_len + 4) +
-                        ws_round((size_t)nodes_len + 16) + ws_round(((size_t)total_nodes + 1) * 8) + ws_round(n) +
-                        ws_round((size_t)n * 8) + ws_round((size_t)n * 4);
-    int32_t rc = ws_reset(c, need);
-    if (rc) return rc;
-    uint8_t* d_roots = ws_take<uint8_t>(c, (size_t)n_roots * 32);
-    uint32_t* d_ridx = ws_take<uint32_t>(c, n);
-    uint8_t* d_keys = ws_take<uint8_t>(c, (size_t)n * key_len + 4);
-    uint8_t* d_nodes = ws_take<uint8_t>(c, (size_t)nodes_len + 16);
-    uint64_t* d_noff = ws_take<uint64_t>(c, (size_t)total_nodes + 1);
-    uint8_t* d_status = ws_take<uint8_t>(c, n);
-    uint64_t* d_voff = ws_take<uint64_t>(c, n);
-    uint32_t* d_vlen = ws_take<uint32_t>(c, n);
-    HIP_TRY(c, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 32, hipMemcpyHostToDevice, s));
-    if (root_idx) HIP_TRY(c, hipMemcpyAsync(d_ridx, root_idx, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (key_len) HIP_TRY(c, hipMemcpyAsync(d_keys, keys, (size_t)n * key_len, hipMemcpyHostToDevice, s));
-    if (nodes_len) HIP_TRY(c, hipMemcpyAsync(d_nodes, nodes, (size_t)nodes_len, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(d_noff, node_off, ((size_t)total_nodes + 1) * 8, hipMemcpyHostToDevice, s));
-    rc = phant_impl::phant_mpt_verify_nodeset_dev(c, d_roots, n_roots, root_idx ? d_ridx : nullptr, d_keys, key_len, d_nodes, nodes_len,
-                                      d_noff, total_nodes, n, d_status, d_voff, d_vlen);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(status, d_status, n, hipMemcpyDeviceToHost, s));
-    if (value_off) HIP_TRY(c, hipMemcpyAsync(value_off, d_voff, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    if (value_len) HIP_TRY(c, hipMemcpyAsync(value_len, d_vlen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    const int32_t rc = nodeset_host_async(c, c->stream, c->ws.io, c->ns, true, roots, n_roots, root_idx, keys, key_len, nodes, nodes_len,
+                                          node_off, total_nodes, n, status, value_off, value_len, nullptr);
+    if (rc) {
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return PHANT_OK;
 }
 
@@ -909,6 +1016,28 @@ int32_t phant_mpt_verify_submit(phant_ctx* c, uint32_t slot, const uint8_t* root
     const int32_t rc = verify_host_async(c, sl.stream, sl.io, sl.dv, nullptr, false, roots, n_roots, root_idx, keys,
                                          key_len, nodes, nodes_len, node_off, proof_first_node, n, status, value_off,
                                          value_len);
+    if (rc) {
+        (void)hipStreamSynchronize(sl.stream);  // nothing of a failed submission stays in flight
+        return rc;
+    }
+    sl.busy = true;
+    return PHANT_OK;
+}
+
+int32_t phant_mpt_verify_nodeset_submit(phant_ctx* c, uint32_t slot, const uint8_t* roots, uint32_t n_roots, const uint32_t* root_idx,
+                                        const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
+                                        const uint64_t* node_off, uint32_t total_nodes, uint32_t n, uint8_t* status,
+                                        uint64_t* value_off, uint32_t* value_len) {
+    if (!c || slot >= PHANT_MAX_SLOTS) return PHANT_E_INVALID_ARG;
+    phant_ctx::Slot& sl = c->slots[slot];
+    if (sl.busy) return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset_submit: slot still in flight (phant_wait it first)");
+    if (n == 0) return PHANT_OK;
+    if (!nodeset_args_ok(roots, n_roots, keys, key_len, node_off, status) || (nodes_len && !nodes))
+        return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset_submit: bad argument");
+    DeviceGuard g(c->device);
+    if (!sl.stream) HIP_TRY(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    const int32_t rc = nodeset_host_async(c, sl.stream, sl.io, sl.ns, false, roots, n_roots, root_idx, keys, key_len, nodes, nodes_len,
+                                          node_off, total_nodes, n, status, value_off, value_len, nullptr);
     if (rc) {
         (void)hipStreamSynchronize(sl.stream);  // nothing of a failed submission stays in flight
         return rc;

@@ -106,9 +106,31 @@ void verify_tier_stats_from_header(const uint32_t* hdr, uint32_t out[4]);
 // out[0] = proofs the walk could not settle from the tables (verified from scratch by their lane), out[1] = nodes
 // decoded by walks that had to decode more than one
 void verify_paths_from_header(const uint32_t* hdr, uint32_t out[2]);
-// node-SET witnesses (every node shipped once, any order; references resolved by hash)
-size_t verify_nodeset_workspace_bytes(uint32_t total_nodes);
-hipError_t launch_mpt_verify_nodeset(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, hipStream_t st);
+// node-SET witnesses (every node shipped once, any order; references resolved by hash): mpt_verify_nodeset.hip.
+// The workspace is sized for a CAPACITY in nodes (verify_nodeset_capacity(total_nodes), verify_nodeset_workspace_bytes(capacity)),
+// zeroed when it is allocated and never cleared afterwards: every launch on it names the same capacity (the layout follows from it)
+// and carries an `epoch` greater than every earlier launch's on the same memory (the owner counts; a failed launch -> zero it again).
+// salt: the key of the record table's slot function (per ctx, random).  a.fail_count (may be null): the per-root verdict.
+struct NodesetTune {
+    uint32_t form = 1;      // how a wave hashes 532-byte nodes: 0 plain, 1 its issue priority falls block by block (hash_b532<true>),
+                            // 2 every rate block requested a permutation ahead, into registers (hash_b532_ahead: 3 waves per SIMD)
+    uint32_t order = 0;     // chunk queue: 0 = lists by falling rate-block count, 1 = rising (A/B)
+    uint32_t hash_lds = 40u * 1024u;  // idle dynamic LDS per hash workgroup (not an occupancy cap at this size: four workgroups a CU
+                                      // either way): measured, one launch of BASELINE's node set 189 us without, 183 / 180 / 177 at
+                                      // 8 / 32 / 40 KiB -- the dispatcher hands out workgroups with LDS more slowly, the waves of a
+                                      // SIMD start apart and do not all wait for their rate blocks at once (profiles/r6_explore/NOTES.md)
+    uint32_t resident_wgs = 0;  // 0 = a wave per chunk.  Otherwise the hash grid is capped at this many workgroups and its waves stride
+                                // over the chunk queue (A/B: one generation of waves, every wave a four-permutation chunk and then
+                                // maybe a one-permutation one -- measured SLOWER, 199 against 190 us: the lockstep it creates costs
+                                // more than the thin second generation it avoids)
+};
+uint32_t verify_nodeset_capacity(uint32_t total_nodes);
+size_t verify_nodeset_workspace_bytes(uint32_t cap_nodes);
+hipError_t launch_mpt_verify_nodeset(const VerifyArgs& a, uint32_t total_nodes, uint32_t cap_nodes, uint8_t* ws, uint32_t epoch,
+                                     const uint32_t salt[2], hipStream_t st, const NodesetTune& tune);
+// nodes hashed per rate-block class by the launch of `epoch`, from a host copy of the workspace's first VERIFY_HEADER_WORDS
+// words; *overflow (may be null): nodes that went through the second table
+void verify_nodeset_stats_from_header(const uint32_t* hdr, uint32_t epoch, uint32_t hashed[8], uint32_t* overflow);
 hipError_t launch_mpt_verdict(const uint8_t* d_status, const uint32_t* d_root_idx, uint32_t n,
                               uint32_t n_roots, uint32_t* d_fail_count, hipStream_t st);
 

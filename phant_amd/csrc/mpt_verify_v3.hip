@@ -58,20 +58,11 @@
 #include "launch.h"
 #include "mpt_verify_one.hip.h"
 #include "coop_sponge.hip.h"
+#include "verify_hash.hip.h"
 
 namespace phant {
 namespace v3 {
-
-constexpr uint32_t N_CLASS = 8;        // class c = (c+1) rate blocks; last class = 8 or more
-constexpr uint32_t LIST_B532 = 8;      // list of the nodes that are exactly 532 bytes long
-constexpr uint32_t N_LIST = 9;
-constexpr uint32_t CLASS_NONE = 0xffu;
-constexpr uint32_t STRIPES = 8;        // every class list is kept as STRIPES sub-lists (workgroup b appends to b mod STRIPES):
-                                       // returning atomics on ONE address are served one at a time, ~11.6 ns each
-                                       // (tools/ubench/atomic_rate.hip) -- thousands of workgroups on one cursor are tens of us
-constexpr uint32_t MAX_SHALLOW = 16;   // key prefix of <= 16 nibbles fits 64 bits
-constexpr uint32_t STATUS_NEEDS_SLOW = 0xffu;
-constexpr uint32_t BRANCH_LEN = 532u;  // f9 02 11 | 16 x (a0 + 32 bytes) | 80
+using namespace vh;
 
 // header words of the workspace (zeroed per call)
 constexpr uint32_t HDR_PFN_BROKEN = 9;   // some proof has last < first
@@ -97,30 +88,7 @@ static_assert(HDR_STAT_END <= VERIFY_HEADER_WORDS && 4u * VERIFY_HEADER_WORDS <=
 
 PHANT_DEV uint32_t cursor_word(uint32_t cls, uint32_t stripe, uint32_t set = 0u) { return HDR_CUR + 256u * set + 32u * stripe + cls; }
 
-// nstat[] bits
-constexpr uint32_t NS_HASHED = 1u, NS_CANON = 2u, NS_LINK_CHECKED = 4u, NS_LINK_OK = 8u;
 
-PHANT_DEV uint32_t node_list(uint32_t len) {
-    if (len == BRANCH_LEN) return LIST_B532;
-    const uint32_t nb = len / RATE + 1u;
-    return (nb > N_CLASS ? N_CLASS : nb) - 1u;
-}
-
-struct __attribute__((packed, aligned(1))) U32x4 { uint32_t x, y, z, w; };
-struct __attribute__((packed, aligned(1))) U32x3 { uint32_t x, y, z; };
-struct __attribute__((packed, aligned(1))) U32x2 { uint32_t x, y; };
-struct __attribute__((packed, aligned(1))) U32x1 { uint32_t x; };
-PHANT_DEV uint4 load16u(const uint8_t* p) {  // unaligned 16-byte global load
-    const U32x4 v = *reinterpret_cast<const U32x4*>(p);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-PHANT_DEV uint32_t load4u(const uint8_t* p) { return reinterpret_cast<const U32x1*>(p)->x; }
-// value of `v` in lane `i` (wave-uniform i).  The builtin returns int: without the cast a 64-bit
-// offset assembled from two halves gets its low half sign-extended (wrong for blobs > 2 GiB).
-PHANT_DEV uint32_t lane_u32(uint32_t v, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane(v, i); }
-PHANT_DEV uint64_t lane_u64(uint32_t lo, uint32_t hi, uint32_t i) {
-    return ((uint64_t)lane_u32(hi, i) << 32) | (uint64_t)lane_u32(lo, i);
-}
 
 // first 8 key bytes, big-endian (zero padded): the nibble prefix of depth d is its top 4d bits
 PHANT_DEV uint64_t key_prefix64(const uint8_t* __restrict__ key, uint32_t key_len) {
@@ -833,142 +801,6 @@ __global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const A
     list_append<1>(a, (real && late) ? node_list(len) : CLASS_NONE, j, p, s_cnt, s_base);
 }
 
-// ---------------------------------------------------------------- canonical full branch, per rate block
-// f9 02 11 | 16 x (a0 + 32 bytes) | 80 = 532 bytes: what the marker bytes of rate block K (bytes
-// [136 K, 136 K + 136) of the node, as 34 little-endian dwords) must be.  The hash waves hold exactly
-// these dwords in registers when they absorb the block, so checking the form of a node there costs ~10
-// VALU operations per block and no memory traffic.
-struct BranchMask {
-    uint32_t m[4][RATE_DWORDS];
-    uint32_t v[4][RATE_DWORDS];
-};
-constexpr BranchMask make_branch_mask() {
-    BranchMask r{};
-    for (uint32_t q = 0; q < BRANCH_LEN; ++q) {
-        int want = -1;
-        if (q == 0) want = 0xf9;
-        else if (q == 1) want = 0x02;
-        else if (q == 2) want = 0x11;
-        else if (q == BRANCH_LEN - 1u) want = 0x80;
-        else if ((q - 3u) % 33u == 0u) want = 0xa0;
-        if (want >= 0) {
-            const uint32_t k = q / RATE, i = (q % RATE) / 4u, sh = 8u * (q % 4u);
-            r.m[k][i] |= 0xffu << sh;
-            r.v[k][i] |= (uint32_t)want << sh;
-        }
-    }
-    return r;
-}
-constexpr BranchMask BRANCH_MASK = make_branch_mask();
-
-template <int K, int NDW>
-PHANT_DEV uint32_t branch_block_bad_k(const uint32_t (&d)[RATE_DWORDS]) {
-    uint32_t bad = 0;
-#pragma unroll
-    for (int i = 0; i < NDW; ++i) {
-        if (BRANCH_MASK.m[K][i] != 0u) bad |= (d[i] ^ BRANCH_MASK.v[K][i]) & BRANCH_MASK.m[K][i];
-    }
-    return bad;
-}
-
-// One rate block of a 532-byte node into the sponge: K = which block (0..3), NDW = its message dwords (34, or 31 for
-// the last block: 124 message bytes, then the padding -- two constants, nothing masked per lane, nothing read beyond
-// the node's last byte).  Returns nonzero iff the block contradicts the canonical full branch.
-template <int K, int NDW>
-PHANT_DEV uint32_t absorb_b532_block(Sponge& s, const uint8_t* __restrict__ p) {
-    uint32_t d[RATE_DWORDS];
-    if constexpr (NDW == 34) {
-        load_block_wide(d, p);
-    } else {
-        static_assert(NDW == 31, "last block of a 532-byte node: 124 message bytes");
-#pragma unroll
-        for (int c = 0; c < 7; ++c) {
-            const uint4 v = load16u(p + 16 * c);
-            d[4 * c] = v.x;
-            d[4 * c + 1] = v.y;
-            d[4 * c + 2] = v.z;
-            d[4 * c + 3] = v.w;
-        }
-        const U32x3 t = *reinterpret_cast<const U32x3*>(p + 112);
-        d[28] = t.x;
-        d[29] = t.y;
-        d[30] = t.z;
-        d[31] = 0x00000001u;  // pad 0x01 right behind the 124 message bytes
-        d[32] = 0u;
-        d[33] = 0x80000000u;  // ... 0x80 in the last byte of the rate
-    }
-    const uint32_t bad = branch_block_bad_k<K, NDW>(d);
-    xor_block(s, d);
-    return bad;
-}
-
-// Keccak-256 of a node that is exactly 532 bytes long, for every lane of the wave (wave-uniform: all active lanes
-// have such a node; inactive lanes hash whatever `ptr` points at -- the launcher gives them a readable one).  Returns
-// nonzero iff the node is NOT the canonical full branch.
-// LADDER: the wave's issue priority falls as it gets on (2, 1, 1, 0 over the four blocks: below the memory-bound kernels' 3
-// throughout).  VALU issue on a SIMD is arbitrated by priority, then age -- left alone, the oldest of four co-resident
-// hash waves takes ~60 % of the slots, finishes first, and the youngest ends up running its last permutations alone at
-// single-wave speed.  With the ladder a wave that is behind outranks the ones ahead: they advance block by block
-// together and finish together (profiles/EXPERIMENTS.md: ladders measured).
-template <bool LADDER>
-PHANT_DEV uint32_t hash_b532(Sponge& s, const uint8_t* __restrict__ p) {
-    sponge_zero(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(2);
-    uint32_t bad = absorb_b532_block<0, 34>(s, p);
-    keccak_f1600(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(1);
-    bad |= absorb_b532_block<1, 34>(s, p + RATE);
-    keccak_f1600(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(1);
-    bad |= absorb_b532_block<2, 34>(s, p + 2u * RATE);
-    keccak_f1600(s);
-    if (LADDER) __builtin_amdgcn_s_setprio(0);
-    bad |= absorb_b532_block<3, 31>(s, p + 3u * RATE);
-    keccak_f1600(s);
-    return bad;
-}
-
-// Keccak-256 of one node per lane, any lengths (exec-masked loop: the wave runs as many permutations as its longest
-// node needs).  `safe_end`: one past the last byte of the node blob.
-PHANT_DEV void hash_any(Sponge& s, const uint8_t* __restrict__ p, uint32_t len, const uint8_t* __restrict__ safe_end) {
-    sponge_zero(s);
-    uint32_t left = len;
-    while (left >= RATE) {
-        absorb_full_block_wide(s, p);
-        keccak_f1600(s);
-        p += RATE;
-        left -= RATE;
-    }
-    if (p + RATE <= safe_end) {
-        uint32_t d[RATE_DWORDS];
-        load_block_wide(d, p);  // the whole window; bytes past the node are masked off
-        absorb_loaded_final(s, d, left);
-    } else {  // last node of the blob: narrow loads that never leave the message
-        const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
-        absorb_final_block(s, reinterpret_cast<const uint32_t*>(p - sh), sh, left);
-    }
-    keccak_f1600(s);
-}
-
-// Keccak-256 of one node per lane where every lane's node has the SAME length `len` < 136 (wave-uniform): the
-// padding masks are scalars.
-PHANT_DEV void hash_short_uniform(Sponge& s, const uint8_t* __restrict__ p, uint32_t len /* wave-uniform */) {
-    sponge_zero(s);
-    uint32_t d[RATE_DWORDS];
-    load_block_wide(d, p);
-#pragma unroll
-    for (int i = 0; i < (int)RATE_DWORDS; ++i) {
-        const int m = (int)len - 4 * i;  // message bytes inside this dword (scalar)
-        const uint32_t t = 1u << ((m & 3) * 8);
-        const uint32_t keep = m >= 4 ? 0xffffffffu : (m <= 0 ? 0u : t - 1u);
-        uint32_t pad = (m >= 0 && m < 4) ? t : 0u;
-        if (i == (int)RATE_DWORDS - 1) pad ^= 0x80000000u;
-        const uint32_t v = (d[i] & keep) ^ pad;
-        if (i & 1) s.hi[i >> 1] = v;
-        else s.lo[i >> 1] = v;
-    }
-    keccak_f1600(s);
-}
 
 // Where the 32 bytes node j must hash to are (nullptr: not known without decoding the parent).  `d`: index of the
 // node in its proof, `root`: the proof's root index, `nib_parent`: the key nibble at depth d - 1 (or >= 16: none),
@@ -1005,22 +837,6 @@ PHANT_DEV void store_node_digest(const Args& a, uint32_t j, const Sponge& s) {
 }
 
 // ---------------------------------------------------------------- hash: the list role
-// Wave q hashes chunk q (64 nodes of one list) and exits; the grid covers the worst case and the dispatcher keeps every
-// SIMD full.  A short last chunk repeats its last node (same results stored twice) so that no lane is ever idle-masked.
-// The chunk queue is the concatenation of the lists in this order: classes by falling rate-block count -- 8+ blocks, 7, 6,
-// 5, [532-byte list], 4 (others), 3, 2, 1 --, inside a class the stripes.
-constexpr uint32_t N_QUEUE = N_LIST * STRIPES;  // 72
-PHANT_DEV uint32_t queue_class(uint32_t li) {
-    const uint32_t o = li / STRIPES;
-    return o < 4u ? 7u - o : (o == 4u ? LIST_B532 : 8u - o);
-}
-PHANT_DEV uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
-    for (uint32_t o = 1; o < 64u; o <<= 1) {
-        const uint32_t up = __shfl_up(v, o, 64);
-        if (lane >= o) v += up;
-    }
-    return v;
-}
 
 // -> false: no chunk q (the queue is shorter)
 template <uint32_t SET>
@@ -1474,43 +1290,6 @@ __global__ void __launch_bounds__(256) hash_late_kernel(const Args a) {
     }
 }
 
-// node-set witnesses: every node listed (classify_kernel), no owners, no references
-__global__ void __launch_bounds__(256, 4) hash_set_kernel(const Args a) {
-    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t N = a.total_nodes;
-    uint32_t cls = N_LIST, idx = 0;
-#pragma unroll
-    for (int o = 0; o < (int)N_LIST; ++o) {
-        const int c = o < 4 ? 7 - o : (o == 4 ? (int)LIST_B532 : 8 - o);
-        const uint32_t cnt = a.hdr[c];
-        const uint32_t chunks = (cnt + 63u) / 64u;
-        if (cls == N_LIST) {
-            if (q < chunks) {
-                cls = (uint32_t)c;
-                idx = q * 64u + lane;
-                idx = idx < cnt ? idx : cnt - 1u;
-            } else {
-                q -= chunks;
-            }
-        }
-    }
-    if (cls == N_LIST) return;
-    const uint32_t j = a.ent[(uint64_t)cls * N + idx].x;
-    const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
-    const uint64_t b = a.v.node_off[j];
-    const uint32_t len = (uint32_t)(a.v.node_off[j + 1] - b);
-    const uint8_t* const p = a.v.nodes + b;
-    Sponge s;
-    uint32_t bad = 1u;
-    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane(len);
-    if (cls == LIST_B532) bad = hash_b532<false>(s, p);
-    else if (cls == 0u && __ballot(len != len0 || p + RATE > safe_end) == 0ull) hash_short_uniform(s, p, len0);
-    else hash_any(s, p, len, safe_end);
-    a.nstat[j] = (uint8_t)(NS_HASHED | (bad == 0u ? NS_CANON : 0u));
-    store_node_digest(a, j, s);
-}
-
 // ---------------------------------------------------------------- walk
 //   LINK_FAST     hash matches, node is a canonical full branch and the key has a nibble for it: step over
 //   LINK_HASH_OK  hash matches, node must be decoded (BASELINE: the account leaf)
@@ -1526,13 +1305,6 @@ PHANT_DEV uint32_t code_of(uint32_t ns, bool has_nibble) {
     return (has_nibble && (ns & NS_CANON)) ? LINK_FAST : LINK_HASH_OK;
 }
 
-// Nodes the generic decoder opens (for BASELINE's proofs: the 112-byte account leaf) are first copied
-// into a per-lane LDS slot with 16-byte loads, together with the key: the RLP decoder and the path
-// comparison read single bytes one after the other, and from HBM/L2 every one of those ~100 dependent
-// reads cost a full cache round trip (the per-CU L1 does not hold 256 lanes' nodes).
-constexpr uint32_t WALK_STAGE_BYTES = 192;  // nodes up to this size are staged; longer ones are read in place
-constexpr uint32_t WALK_KEY_BYTES = 32;
-constexpr uint32_t WALK_SLOT_DW = (WALK_STAGE_BYTES + WALK_KEY_BYTES) / 4 + 1;  // odd stride: no bank pile-up
 
 // ---- the leaf, decoded ahead of time ----
 // What a proof's walk does once the hashes are known is all but fixed for a well-formed witness: step over the full branches, decode
@@ -1911,189 +1683,6 @@ __global__ void __launch_bounds__(256) stream_read_kernel(const uint4* __restric
     if (x == 0x9e3779b9u && sink) sink[blockIdx.x & 255u] = x;  // (never, in effect: the result only has to be wanted)
 }
 
-// ---------------------------------------------------------------- node-set witnesses
-// A witness that ships every node ONCE, in any order (what a block builder that deduplicates its proofs
-// sends): references are resolved by hash.  Hash every node (classify_kernel + hash_set_kernel, nothing to
-// deduplicate, no links), put digest -> node into an open-addressing table, then one lane per key walks from its
-// root.  Semantics: DESIGN.md section 3 with "the node a 32-byte reference points to" = the node of the set with
-// that digest (none: MISSING_NODE; BAD_HASH / EXTRA_NODES / INVALID_EMPTY cannot occur).
-constexpr uint32_t SET_EMPTY = 0xffffffffu;
-
-// one lane per node: sort the well-formed nodes into the rate-block class lists
-__global__ void __launch_bounds__(256) classify_kernel(const Args a) {
-    constexpr uint32_t WAVES = 4;
-    __shared__ uint32_t s_cnt[WAVES][N_LIST];
-    __shared__ uint32_t s_base[N_LIST];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t NT = a.total_nodes;
-    const uint32_t j = blockIdx.x * 256u + tid;
-    uint32_t cls = CLASS_NONE;
-    if (j < NT) {
-        const uint64_t e = a.v.node_off[j + 1], b = a.v.node_off[j];
-        if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) cls = node_list((uint32_t)(e - b));
-    }
-    uint32_t my_rank = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < N_LIST; ++c) {
-        const unsigned long long m = __ballot(cls == c);
-        if (lane == 0) s_cnt[wave][c] = (uint32_t)__popcll(m);
-        if (cls == c) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    }
-    __syncthreads();
-    if (tid < N_LIST) {
-        uint32_t tot = 0;
-        for (uint32_t w = 0; w < WAVES; ++w) tot += s_cnt[w][tid];
-        s_base[tid] = tot ? atomicAdd(&a.hdr[tid], tot) : 0u;
-    }
-    __syncthreads();
-    if (cls != CLASS_NONE) {
-        uint32_t at = s_base[cls] + my_rank;
-        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
-        a.ent[(uint64_t)cls * NT + at] = make_uint2(j, 0u);
-    }
-}
-
-__global__ void __launch_bounds__(256) nodeset_insert_kernel(const Args a, uint32_t* tab, uint32_t tab_mask) {
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= a.total_nodes) return;
-    const uint64_t b = a.v.node_off[j], e = a.v.node_off[j + 1];
-    if (!(e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull)) return;  // never hashed: not in the set
-    uint32_t slot = a.digest[8ull * j] & tab_mask;
-    for (;;) {  // the table has >= 2 x total_nodes slots: terminates
-        const uint32_t prev = atomicCAS(&tab[slot], SET_EMPTY, j);
-        if (prev == SET_EMPTY) return;
-        // an identical node already there: one of them is enough (same digest => same bytes, up to Keccak)
-        const uint4* x = reinterpret_cast<const uint4*>(a.digest + 8ull * prev);
-        const uint4* y = reinterpret_cast<const uint4*>(a.digest + 8ull * j);
-        const uint4 x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
-        if (((x0.x ^ y0.x) | (x0.y ^ y0.y) | (x0.z ^ y0.z) | (x0.w ^ y0.w) | (x1.x ^ y1.x) | (x1.y ^ y1.y) | (x1.z ^ y1.z) |
-             (x1.w ^ y1.w)) == 0u)
-            return;
-        slot = (slot + 1u) & tab_mask;
-    }
-}
-
-// the node of the set whose digest is want[], or SET_EMPTY
-PHANT_DEV uint32_t nodeset_find(const Args& a, const uint32_t* __restrict__ tab, uint32_t tab_mask,
-                                const uint32_t (&want)[8]) {
-    uint32_t slot = want[0] & tab_mask;
-    for (;;) {
-        const uint32_t j = tab[slot];
-        if (j == SET_EMPTY) return SET_EMPTY;
-        const uint4* x = reinterpret_cast<const uint4*>(a.digest + 8ull * j);
-        const uint4 x0 = x[0], x1 = x[1];
-        if (((x0.x ^ want[0]) | (x0.y ^ want[1]) | (x0.z ^ want[2]) | (x0.w ^ want[3]) | (x1.x ^ want[4]) | (x1.y ^ want[5]) |
-             (x1.z ^ want[6]) | (x1.w ^ want[7])) == 0u)
-            return j;
-        slot = (slot + 1u) & tab_mask;
-    }
-}
-
-__global__ void __launch_bounds__(256) nodeset_walk_kernel(const Args a, const uint32_t* tab, uint32_t tab_mask) {
-    __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.v.n) return;
-    uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
-    const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
-    const uint8_t* const nodes_end = a.v.nodes + a.v.nodes_len;
-    uint64_t voff = 0;
-    uint32_t vlen = 0, status = 0xffffffffu;
-    const uint32_t r = a.v.root_idx ? a.v.root_idx[i] : 0u;
-    if (r >= a.v.n_roots) {
-        status = PHANT_PROOF_BAD_INPUT;
-    } else {
-        const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * i;
-        const uint32_t nn = 2u * a.v.key_len;
-        const uint8_t* const slot_key = reinterpret_cast<const uint8_t*>(slot + WALK_STAGE_BYTES / 4);
-        const bool key_in_lds = a.v.key_len <= WALK_KEY_BYTES;
-        if (key_in_lds) {
-            uint8_t* kdst = reinterpret_cast<uint8_t*>(slot + WALK_STAGE_BYTES / 4);
-            for (uint32_t t = 0; t < a.v.key_len; ++t) kdst[t] = key[t];
-        }
-        uint32_t want[8];
-        {
-            GlobalBytes rb{a.v.roots + 32ull * r};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) want[k] = rb.u32(4 * k);
-        }
-        WalkState w;
-        w.pos = 0;
-        w.status = PHANT_PROOF_BAD_INPUT;
-        w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
-        bool by_hash = true, at_root = true;
-        const uint8_t* cur = nullptr;
-        uint32_t cur_len = 0;
-        const uint8_t* staged_from = nullptr;
-        for (;;) {
-            if (by_hash) {
-                const uint32_t j = nodeset_find(a, tab, tab_mask, want);
-                if (j == SET_EMPTY) {  // (the root of an empty trie needs no node)
-                    status = (at_root && is_empty_root(want)) ? PHANT_PROOF_ABSENT : PHANT_PROOF_MISSING_NODE;
-                    break;
-                }
-                at_root = false;
-                const uint64_t b = a.v.node_off[j];
-                cur = a.v.nodes + b;
-                cur_len = (uint32_t)(a.v.node_off[j + 1] - b);
-                // a canonical full branch (checked by the wave that hashed it): the next reference is slot
-                // nib of the node, no decoding
-                if ((a.nstat[j] & NS_CANON) && w.pos < nn) {
-                    const uint32_t nib = key_in_lds ? key_nibble(slot_key, w.pos) : key_nibble(key, w.pos);
-                    const uint8_t* rb = cur + (4u + 33u * nib);
-                    const uint4 r0 = load16u(rb), r1 = load16u(rb + 16);
-                    want[0] = r0.x; want[1] = r0.y; want[2] = r0.z; want[3] = r0.w;
-                    want[4] = r1.x; want[5] = r1.y; want[6] = r1.z; want[7] = r1.w;
-                    w.pos += 1;
-                    continue;
-                }
-                staged_from = nullptr;
-                const uint32_t padded = (cur_len + 15u) & ~15u;
-                if (cur_len <= WALK_STAGE_BYTES && cur + padded <= nodes_end) {
-                    for (uint32_t o = 0; o < padded; o += 16u) {
-                        const uint4 q = load16u(cur + o);
-                        slot[o / 4u] = q.x;
-                        slot[o / 4u + 1u] = q.y;
-                        slot[o / 4u + 2u] = q.z;
-                        slot[o / 4u + 3u] = q.w;
-                    }
-                    staged_from = cur;
-                }
-            }
-            auto step_from = [&](const uint8_t* nb, const uint8_t* kp) __attribute__((always_inline)) -> uint32_t {
-                GlobalBytes nd{nb};
-                const uint32_t st = walk_node(nd, cur_len, kp, nn, w);
-                if (st == STEP_HASH) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) want[k] = nd.u32(w.ref_pay + 4 * k);
-                }
-                return st;
-            };
-            uint32_t step;
-            if (!key_in_lds) step = step_from(cur, key);
-            else if (staged_from) step = step_from(slot_node + (cur - staged_from), slot_key);
-            else step = step_from(cur, slot_key);
-            if (step == STEP_DONE) break;
-            if (step == STEP_HASH) {
-                by_hash = true;
-            } else {
-                cur = cur + w.ref_pay;
-                cur_len = w.ref_total;
-                by_hash = false;
-            }
-        }
-        if (status == 0xffffffffu) {
-            status = w.status;
-            if (status == PHANT_PROOF_PRESENT) {
-                voff = (uint64_t)(cur - a.v.nodes) + w.value_pay;
-                vlen = w.value_len;
-            }
-        }
-    }
-    a.v.status[i] = (uint8_t)status;
-    if (a.v.value_off) a.v.value_off[i] = voff;
-    if (a.v.value_len) a.v.value_len[i] = vlen;
-}
-
 // ---------------------------------------------------------------- host side
 static size_t rnd256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -2177,9 +1766,7 @@ static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries,
     l.dtab = p;   p += rnd256((size_t)direct_entries * 4);
     l.table = p;  p += rnd256((size_t)te * 8);
     l.rep = p;    p += rnd256(tn * 4 + 64);
-    // the two-tier form's striped lists, or the node-set form's N_LIST x total_nodes
-    const size_t striped = (size_t)N_LIST * STRIPES * l.stripe_cap * 8u;
-    l.ent = p;    p += rnd256(striped > tn * 8 * N_LIST ? striped : tn * 8 * N_LIST);
+    l.ent = p;    p += rnd256((size_t)N_LIST * STRIPES * l.stripe_cap * 8u);
     l.digest = p; p += rnd256(tn * 32);
     const size_t buckets = ord_n ? (size_t)1 << ORDER_MAX_BITS : 0;
     l.pos = p;    p += rnd256((size_t)ord_n * sizeof(PosInfo));
@@ -2435,49 +2022,12 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     return hipGetLastError();
 }
 
-static uint32_t nodeset_table_entries(uint32_t total_nodes) {
-    uint32_t t = 1024;
-    while (t < 2u * total_nodes && t < (1u << 31)) t <<= 1;
-    return t;
-}
-
-size_t verify_nodeset_workspace_bytes(uint32_t total_nodes) {
-    return v3::workspace_bytes(total_nodes) + v3::rnd256((size_t)nodeset_table_entries(total_nodes) * 4);
-}
-
-hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, uint8_t* ws, hipStream_t st) {
-    using namespace v3;
-    if (v.n == 0) return hipSuccess;
-    Args a;
-    a.v = v;
-    a.total_nodes = total_nodes;
-    a.shallow = 0;
-    a.direct = 0;
-    const uint32_t te = 1024;
-    const Layout l = layout(total_nodes, te, 0, 0, 0, 0);
-    bind(a, ws, l, te);
-    uint32_t* tab = reinterpret_cast<uint32_t*>(ws + workspace_bytes(total_nodes));
-    const uint32_t tab_entries = nodeset_table_entries(total_nodes);
-    hipError_t e = hipMemsetAsync(ws, 0, l.dtab, st);  // header + node states
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(tab, 0xff, (size_t)tab_entries * 4, st);
-    if (e != hipSuccess) return e;
-    if (total_nodes) {
-        const uint32_t ng = (total_nodes + 255u) / 256u;
-        hipLaunchKernelGGL(classify_kernel, dim3(ng), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(hash_set_kernel, dim3(ng + (N_LIST + 3u) / 4u), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(nodeset_insert_kernel, dim3(ng), dim3(256), 0, st, a, tab, tab_entries - 1u);
-    }
-    hipLaunchKernelGGL(nodeset_walk_kernel, dim3((v.n + 255u) / 256u), dim3(256), 0, st, a, tab, tab_entries - 1u);
-    return hipGetLastError();
-}
-
 // nodes hashed per rate-block class by the last launch on this workspace (host copy of the header)
 void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]) {
     using namespace v3;
     uint32_t lists[N_LIST];
     for (uint32_t c = 0; c < N_LIST; ++c) {
-        lists[c] = hdr[c];  // (the node-set form's single cursors)
+        lists[c] = 0;
         for (uint32_t t = 0; t < LIST_SETS; ++t)
             for (uint32_t s = 0; s < STRIPES; ++s) lists[c] += hdr[HDR_CUR + 256u * t + 32u * s + c];
     }
@@ -2492,7 +2042,7 @@ void verify_tier_stats_from_header(const uint32_t* hdr, uint32_t out[4]) {
     using namespace v3;
     out[0] = out[1] = out[2] = out[3] = 0;
     for (uint32_t c = 0; c < N_LIST; ++c) {
-        uint32_t cnt = hdr[c];  // (the node-set form's single cursors)
+        uint32_t cnt = 0;
         for (uint32_t t = 0; t < LIST_SETS; ++t)
             for (uint32_t s = 0; s < STRIPES; ++s) cnt += hdr[HDR_CUR + 256u * t + 32u * s + c];
         out[0] += cnt;

@@ -326,16 +326,99 @@ def verify_nodeset(roots, root_idx, keys, key_len, nodes, node_off, ctx: Context
 
 def verify_nodeset_dev(roots: torch.Tensor, root_idx: torch.Tensor | None, keys: torch.Tensor, nodes: torch.Tensor,
                        node_off: torch.Tensor, status: torch.Tensor | None = None, ctx: Context | None = None,
-                       value_off: torch.Tensor | None = None, value_len: torch.Tensor | None = None) -> torch.Tensor:
+                       value_off: torch.Tensor | None = None, value_len: torch.Tensor | None = None,
+                       fail_count: torch.Tensor | None = None) -> torch.Tensor:
     """Device form, asynchronous on the ctx stream.  keys (n, key_len) u8, node_off (m + 1,) i64; value_off (n,) i64 and
-    value_len (n,) i32 (optional outputs): where in `nodes` the proven value of a PRESENT key lies."""
+    value_len (n,) i32 (optional outputs): where in `nodes` the proven value of a PRESENT key lies.  With `fail_count`
+    (int32[n_roots], device) the per-root verdict comes out of the same launch (phant_mpt_verify_nodeset_verdict_dev)."""
     ctx = ctx or default_context(nodes.device.index)
     n = keys.shape[0]
     if status is None:
         status = torch.empty(n, dtype=torch.uint8, device=nodes.device)
-    ctx.check(ctx._lib.phant_mpt_verify_nodeset_dev(
-        ctx.handle, roots.data_ptr(), roots.numel() // 32, None if root_idx is None else root_idx.data_ptr(),
-        keys.data_ptr(), keys.shape[1], nodes.data_ptr(), nodes.numel(), node_off.data_ptr(), node_off.numel() - 1, n,
-        status.data_ptr(), None if value_off is None else value_off.data_ptr(),
-        None if value_len is None else value_len.data_ptr()))
+    args = (ctx.handle, roots.data_ptr(), roots.numel() // 32, None if root_idx is None else root_idx.data_ptr(),
+            keys.data_ptr(), keys.shape[1], nodes.data_ptr(), nodes.numel(), node_off.data_ptr(), node_off.numel() - 1, n,
+            status.data_ptr(), None if value_off is None else value_off.data_ptr(),
+            None if value_len is None else value_len.data_ptr())
+    if fail_count is None:
+        ctx.check(ctx._lib.phant_mpt_verify_nodeset_dev(*args))
+    else:
+        assert fail_count.dtype == torch.int32 and fail_count.numel() >= roots.numel() // 32
+        ctx.check(ctx._lib.phant_mpt_verify_nodeset_verdict_dev(*args, fail_count.data_ptr()))
     return status
+
+
+@dataclass
+class NodeSet:
+    """A node-set witness resident in HBM: what a block's execution witness is (src/engine_api/execution_payload.zig:121) --
+    every trie node once, in any order, next to the keys it proves.
+
+    roots (n_roots, 32) u8 | root_idx (n,) i32 or None | keys (n, key_len) u8 | nodes (nodes_len,) u8 | node_off (m + 1,) i64
+    """
+    roots: torch.Tensor
+    root_idx: torch.Tensor | None
+    keys: torch.Tensor
+    nodes: torch.Tensor
+    node_off: torch.Tensor
+
+    @property
+    def n(self) -> int:
+        return self.keys.shape[0]
+
+    @property
+    def n_roots(self) -> int:
+        return self.roots.numel() // 32
+
+    @property
+    def total_nodes(self) -> int:
+        return self.node_off.numel() - 1
+
+    def algorithmic_bytes(self) -> int:
+        """node bytes + key bytes read, 1 status byte written per key"""
+        return int(self.nodes.numel() + self.keys.numel() + self.n)
+
+
+@dataclass
+class HostNodeSet:
+    """A NodeSet in pinned host memory, plus pinned result buffers (phant_mpt_verify_nodeset_submit)."""
+    roots: torch.Tensor
+    root_idx: torch.Tensor | None
+    keys: torch.Tensor
+    nodes: torch.Tensor
+    node_off: torch.Tensor
+    status: torch.Tensor
+    value_off: torch.Tensor
+    value_len: torch.Tensor
+
+    @property
+    def n(self) -> int:
+        return self.keys.shape[0]
+
+    def h2d_bytes(self) -> int:
+        t = [self.roots, self.keys, self.nodes, self.node_off]
+        if self.root_idx is not None:
+            t.append(self.root_idx)
+        return int(sum(x.numel() * x.element_size() for x in t))
+
+
+def nodeset_to_host(s: NodeSet) -> HostNodeSet:
+    def pin(t):
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t)
+        return h
+
+    n = s.n
+    return HostNodeSet(pin(s.roots), None if s.root_idx is None else pin(s.root_idx), pin(s.keys), pin(s.nodes), pin(s.node_off),
+                       torch.empty(n, dtype=torch.uint8, pin_memory=True), torch.empty(n, dtype=torch.int64, pin_memory=True),
+                       torch.empty(n, dtype=torch.int32, pin_memory=True))
+
+
+def verify_nodeset_submit(hw: HostNodeSet, slot: int, ctx: Context | None = None) -> None:
+    """phant_mpt_verify_nodeset_submit: queue copy-in, verification and copy-out of the node set on slot `slot`; returns at
+    once.  hw.status / value_off / value_len are valid after wait(slot)."""
+    ctx = ctx or default_context()
+    key_len = hw.keys.shape[1] if hw.keys.dim() == 2 else 0
+    ctx.check(ctx._lib.phant_mpt_verify_nodeset_submit(
+        ctx.handle, slot, hw.roots.data_ptr(), hw.roots.numel() // 32,
+        None if hw.root_idx is None else hw.root_idx.data_ptr(), hw.keys.data_ptr(), key_len, hw.nodes.data_ptr(),
+        hw.nodes.numel(), hw.node_off.data_ptr(), hw.node_off.numel() - 1, hw.n, hw.status.data_ptr(),
+        hw.value_off.data_ptr(), hw.value_len.data_ptr()))

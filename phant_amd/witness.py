@@ -21,7 +21,7 @@ from dataclasses import dataclass
 import torch
 
 from .crypto.hasher import keccak256_fixed_dev
-from .mpt import ProofBatch, PROOF_PRESENT, PROOF_ABSENT, PROOF_BAD_HASH
+from .mpt import NodeSet, ProofBatch, PROOF_PRESENT, PROOF_ABSENT, PROOF_BAD_HASH, PROOF_MISSING_NODE
 
 EMPTY_ROOT = bytes.fromhex("56e81f171bcc55a6ff8345e692c0f86e5b48e01b996cadc001622fb5e363b421")
 EMPTY_CODE_HASH = bytes.fromhex("c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470")
@@ -53,6 +53,10 @@ class Witness:
     bytes_per_proof: int    # node bytes + key bytes
     perms_per_proof: int
     seed: int
+    # the status every key must get when the same witness is shipped as a node SET (node_set()): a damaged copy is just another
+    # node nobody refers to, so its proof still verifies when an intact copy of that node came with another proof -- and the
+    # node is MISSING when the damaged copy was the only one
+    expected_nodeset: torch.Tensor | None = None
 
 
 def _rand_u8(shape, gen, device):
@@ -189,6 +193,7 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
 
     # ---- 1 % slice: corrupted nodes (-> BAD_HASH) and exclusion proofs (-> ABSENT) ----
     expected = torch.full((n,), PROOF_PRESENT, dtype=torch.uint8, device=device)
+    expected_set = expected.clone()
     n_bad = int(n * corrupt_frac / 2)
     n_invalid = 0
     if n_bad:
@@ -199,12 +204,24 @@ def account_witness(n: int, depth: int = 8, seed: int = 2, device=None, corrupt_
         expected[bad] = PROOF_BAD_HASH
         keys[excl, 31] ^= 0x01  # same path down to the leaf, different tail: proven absent
         expected[excl] = PROOF_ABSENT
+        expected_set[excl] = PROOF_ABSENT
         n_invalid = n_bad
+        # as a node set: is there an intact copy of the damaged node among the other proofs?
+        lvl = torch.clamp(pos // BRANCH_LEN, max=L)
+        expected_set[bad[lvl == L]] = PROOF_MISSING_NODE  # (a leaf belongs to one proof)
+        for l in range(L):
+            sel = bad[lvl == l]
+            if sel.numel():
+                node = level_index[l][sel]
+                U = int(level_index[l].max().item()) + 1
+                copies = torch.bincount(level_index[l], minlength=U)[node]
+                damaged = torch.bincount(node, minlength=U)[node]
+                expected_set[sel[copies - damaged < 1]] = PROOF_MISSING_NODE
     batch = ProofBatch(roots=root, root_idx=root_idx, keys=keys.contiguous(), nodes=nodes.reshape(-1),
                        node_off=node_off.contiguous(), proof_first_node=pfn.contiguous())
     perms = L * ((BRANCH_LEN + 1 + 135) // 136) + (leaf_len + 1 + 135) // 136
     return Witness(batch=batch, expected=expected, n_invalid=n_invalid, nodes_per_proof=depth,
-                   bytes_per_proof=proof_bytes + 32, perms_per_proof=perms, seed=seed)
+                   bytes_per_proof=proof_bytes + 32, perms_per_proof=perms, seed=seed, expected_nodeset=expected_set)
 
 
 # BASELINE config 4: the witness of one 10 000-transaction block.  phant has no witness type yet (DESIGN.md
@@ -268,7 +285,8 @@ def block_witness(shape: dict | None = None, seed: int = 4, device=None, corrupt
     total_perms = sum(w.perms_per_proof * w.batch.n for w in parts)
     return Witness(batch=batch, expected=torch.cat([w.expected for w in parts]),
                    n_invalid=sum(w.n_invalid for w in parts), nodes_per_proof=total_nodes / n,
-                   bytes_per_proof=(int(batch.nodes.numel()) + 32 * n) / n, perms_per_proof=total_perms / n, seed=seed)
+                   bytes_per_proof=(int(batch.nodes.numel()) + 32 * n) / n, perms_per_proof=total_perms / n, seed=seed,
+                   expected_nodeset=torch.cat([w.expected_nodeset for w in parts]))
 
 
 def as_node_set(batch: ProofBatch, ctx=None):
@@ -290,3 +308,21 @@ def as_node_set(batch: ProofBatch, ctx=None):
     off[1:] = torch.cumsum(lens, 0)
     idx = torch.repeat_interleave(batch.node_off[keep] - off[:-1], lens) + torch.arange(int(off[-1]), device=d.device)
     return batch.nodes[idx].contiguous(), off
+
+
+def node_set(w: Witness, ctx=None, shuffle_seed: int | None = None) -> NodeSet:
+    """The witness as a node SET -- the form a block's execution witness has (src/engine_api/execution_payload.zig:121): its
+    keys and roots as they are, every distinct node once.  shuffle_seed: the nodes in a random order (a set has none)."""
+    b = w.batch
+    nodes, off = as_node_set(b, ctx=ctx)
+    if shuffle_seed is not None:
+        g = torch.Generator(device=nodes.device)
+        g.manual_seed(shuffle_seed)
+        m = off.numel() - 1
+        perm = torch.randperm(m, device=nodes.device, generator=g)
+        lens = (off[1:] - off[:-1])[perm]
+        noff = torch.zeros(m + 1, dtype=torch.int64, device=nodes.device)
+        noff[1:] = torch.cumsum(lens, 0)
+        idx = torch.repeat_interleave(off[:-1][perm] - noff[:-1], lens) + torch.arange(int(noff[-1]), device=nodes.device)
+        nodes, off = nodes[idx].contiguous(), noff
+    return NodeSet(roots=b.roots, root_idx=b.root_idx, keys=b.keys, nodes=nodes, node_off=off)

@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "phant_amd", "csrc")
-SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v3.hip", "trie_build.hip", "state_root.hip", "radix_sort.hip",
+SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v3.hip", "mpt_verify_nodeset.hip", "trie_build.hip", "state_root.hip", "radix_sort.hip",
            "capi.hip", "comm.hip", "witness_json.cpp", "host_rlp.cpp"]
 OUT_DIR = os.path.join(ROOT, "tests", "native", "_build")
 
@@ -273,7 +273,7 @@ def _device_is_host_memory(ctx0):
     from phant_amd import mpt, witness
     from phant_amd.crypto import hasher
     saved = (witness.account_witness, witness.keccak256_fixed_dev, torch.Tensor.cuda, torch.cuda.synchronize,
-             mpt.to_host, hasher.keccak256_fixed_dev, hasher.keccak256_batch_dev)
+             mpt.to_host, hasher.keccak256_fixed_dev, hasher.keccak256_batch_dev, mpt.nodeset_to_host)
     real_account_witness = witness.account_witness
 
     def fixed_dev(blob, msg_len, n, stride=None, out=None, ctx=None):
@@ -291,6 +291,13 @@ def _device_is_host_memory(ctx0):
         n = b.n
         c = lambda t: None if t is None else t.clone()  # noqa: E731
         return mpt.HostWitness(c(b.roots), c(b.root_idx), c(b.keys), c(b.nodes), c(b.node_off), c(b.proof_first_node),
+                               torch.empty(n, dtype=torch.uint8), torch.empty(n, dtype=torch.int64),
+                               torch.empty(n, dtype=torch.int32))
+
+    def nodeset_to_host(s_):
+        n = s_.n
+        c = lambda t: None if t is None else t.clone()  # noqa: E731
+        return mpt.HostNodeSet(c(s_.roots), c(s_.root_idx), c(s_.keys), c(s_.nodes), c(s_.node_off),
                                torch.empty(n, dtype=torch.uint8), torch.empty(n, dtype=torch.int64),
                                torch.empty(n, dtype=torch.int32))
 
@@ -318,9 +325,10 @@ def _device_is_host_memory(ctx0):
     torch.Tensor.cuda = to_device
     torch.cuda.synchronize = lambda *a, **k: None
     mpt.to_host = to_host
+    mpt.nodeset_to_host = nodeset_to_host
 
     def undo():
         (witness.account_witness, witness.keccak256_fixed_dev, torch.Tensor.cuda, torch.cuda.synchronize,
-         mpt.to_host, hasher.keccak256_fixed_dev, hasher.keccak256_batch_dev) = saved
+         mpt.to_host, hasher.keccak256_fixed_dev, hasher.keccak256_batch_dev, mpt.nodeset_to_host) = saved
         phant_amd.witness.account_witness = saved[0]
     return undo

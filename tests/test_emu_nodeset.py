@@ -20,7 +20,8 @@ def M():
 
 
 from tests.test_gpu_nodeset import (  # noqa: E402,F401
-    test_random_tries, test_damaged_and_missing_nodes, test_garbage_committed_roots, test_block_witness_as_a_node_set)
+    test_random_tries, test_damaged_and_missing_nodes, test_garbage_committed_roots, test_block_witness_as_a_node_set,
+    test_duplicate_nodes_and_floods, test_device_form_verdict_and_generator_expectation, test_streaming_submit_wait_node_sets)
 
 
 def test_hostile_index_arrays_match_the_checked_oracle(M, oracle):

@@ -147,3 +147,98 @@ def test_depth8_node_set_full_size(M, oracle):
                                       new_off.cpu().numpy().astype(np.uint64))
     assert np.array_equal(st2.cpu().numpy(), want2[0])
     assert (st2[absent] == M.PROOF_ABSENT).all() and (st2[~absent] == M.PROOF_PRESENT).all()
+
+
+def test_duplicate_nodes_and_floods(M, oracle):
+    """A set is supposed to hold every node once; a witness that repeats nodes -- a few copies of everything, thousands of
+    copies of one node -- is verified all the same (which copy a value range points into is the verifier's choice: the bytes
+    are compared), and the flood costs no probe chain of its own copies (mpt_verify_nodeset.hip: tag -> overflow list -> the
+    second table)."""
+    rng = np.random.default_rng(99)
+    keys, vals = random_kv(rng, 300, 32, 1, 90)
+    t = oracle.Trie(keys, vals)
+    q = list(keys) + [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(40)]
+    proofs = [t.prove(k) for k in q]
+    uniq = list(dict.fromkeys(nd for p in proofs for nd in p))
+    for copies, flood in ((3, 0), (1, 5000), (2, 700)):
+        nodes = [nd for nd in uniq for _ in range(copies)] + [uniq[0]] * flood + [uniq[-1]] * (flood // 2)
+        order = rng.permutation(len(nodes))
+        nodes = [nodes[i] for i in order]
+        off = np.zeros(len(nodes) + 1, np.uint64)
+        off[1:] = np.cumsum([len(x) for x in nodes])
+        blob = np.frombuffer(b"".join(nodes), np.uint8).copy()
+        r = np.frombuffer(t.root(), np.uint8)
+        karr = np.frombuffer(b"".join(q), np.uint8)
+        got = M.verify_nodeset(r, None, karr, 32, blob, off)
+        want = oracle.mpt_verify_nodeset(r, None, karr, 32, blob, off)
+        assert np.array_equal(got[0], want[0])
+        assert np.array_equal(got[2], want[2])
+        assert (got[0][:300] == M.PROOF_PRESENT).all() and (got[0][300:] == M.PROOF_ABSENT).all()
+        for i in range(300):
+            assert blob[int(got[1][i]):int(got[1][i]) + int(got[2][i])].tobytes() == vals[i]
+
+
+def test_device_form_verdict_and_generator_expectation(M, oracle):
+    """phant_mpt_verify_nodeset_verdict_dev on a synthetic depth-8 witness shipped as a set, 10 % of the proofs damaged or
+    exclusion proofs: statuses = the oracle's = what the generator says they must be (expected_nodeset: a damaged copy only
+    costs its key the proof when no intact copy of that node came with another key); the verdict counts them; a dirty counter
+    buffer is overwritten; the same call again (the next epoch on the same workspace) gives the same answer."""
+    import phant_amd
+    for n, depth, seed in ((3000, 8, 5), (2000, 5, 6)):
+        w = phant_amd.witness.account_witness(n, depth=depth, seed=seed, corrupt_frac=0.1)
+        s = phant_amd.witness.node_set(w, shuffle_seed=seed)
+        want = oracle.mpt_verify_nodeset(s.roots.cpu().numpy(), None, s.keys.cpu().numpy(), 32, s.nodes.cpu().numpy(),
+                                         s.node_off.cpu().numpy().astype(np.uint64))
+        assert np.array_equal(want[0], w.expected_nodeset.cpu().numpy())
+        assert {M.PROOF_PRESENT, M.PROOF_ABSENT, M.PROOF_MISSING_NODE} <= set(want[0].tolist())
+        for _ in range(3):
+            fc = torch.full((1,), 777, dtype=torch.int32, device=s.nodes.device)
+            vo = torch.empty(n, dtype=torch.int64, device=s.nodes.device)
+            vl = torch.empty(n, dtype=torch.int32, device=s.nodes.device)
+            st = M.verify_nodeset_dev(s.roots, None, s.keys, s.nodes, s.node_off, value_off=vo, value_len=vl, fail_count=fc)
+            torch.cuda.synchronize()
+            assert np.array_equal(st.cpu().numpy(), want[0])
+            assert np.array_equal(vo.cpu().numpy().view(np.uint64), want[1]) and np.array_equal(vl.cpu().numpy().view(np.uint32), want[2])
+            assert int(fc.item()) == int((want[0] == M.PROOF_MISSING_NODE).sum())
+
+
+def test_streaming_submit_wait_node_sets(M, oracle):
+    """phant_mpt_verify_nodeset_submit / phant_wait: node sets of different sizes in flight on one ctx (a slot's workspace is laid
+    out for the largest it has seen), pinned buffers, slots shared with the per-proof form; results = the oracle's."""
+    import phant_amd
+    from phant_amd import mpt
+    from phant_amd.context import default_context
+    ctx = default_context()
+    ws = [phant_amd.witness.account_witness(n, depth=d, seed=60 + k, corrupt_frac=0.1)
+          for k, (n, d) in enumerate(((700, 8), (1300, 6), (64, 8), (2000, 7), (900, 4)))]
+    sets = [phant_amd.witness.node_set(w, shuffle_seed=k) for k, w in enumerate(ws)]
+    hosts = [mpt.nodeset_to_host(s) for s in sets]
+    want = [oracle.mpt_verify_nodeset(h.roots.numpy(), None, h.keys.numpy(), 32, h.nodes.numpy(), h.node_off.numpy().astype(np.uint64))
+            for h in hosts]
+    proof_host = mpt.to_host(ws[0].batch)
+    for round_ in range(2):  # (the second round meets warm arenas and later epochs)
+        for h in hosts:
+            h.status.fill_(0x55)
+        pending = []
+        for k, h in enumerate(hosts):
+            slot = k % 3
+            if len(pending) == 3:
+                mpt.wait(pending.pop(0), ctx)
+            mpt.verify_nodeset_submit(h, slot, ctx)
+            pending.append(slot)
+        for s_ in pending:
+            mpt.wait(s_, ctx)
+        for w, h, (st, vo, vl) in zip(ws, hosts, want):
+            assert np.array_equal(h.status.numpy(), st) and np.array_equal(st, w.expected_nodeset.cpu().numpy())
+            assert np.array_equal(h.value_off.numpy().view(np.uint64), vo) and np.array_equal(h.value_len.numpy().view(np.uint32), vl)
+        # a slot takes either kind of witness, one after the other
+        mpt.verify_submit(proof_host, 1, ctx)
+        mpt.wait(1, ctx)
+        assert torch.equal(proof_host.status, ws[0].expected.cpu())
+    mpt.verify_nodeset_submit(hosts[0], 0, ctx)
+    with pytest.raises(Exception):
+        mpt.verify_nodeset_submit(hosts[1], 0, ctx)
+    with pytest.raises(Exception):
+        mpt.verify_submit(proof_host, 0, ctx)
+    mpt.wait(0, ctx)
+    assert np.array_equal(hosts[0].status.numpy(), want[0][0])

@@ -39,7 +39,19 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters, uint32_t sb, 
     if constexpr (OP == 16) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));           \
     if constexpr (OP == 17) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]));                 \
     if constexpr (OP == 18) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); \
-    if constexpr (OP == 19) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+    if constexpr (OP == 19) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(b));        \
+    if constexpr (OP == 20) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); \
+    if constexpr (OP == 21) asm volatile("v_alignbit_b32 %0, %1, %2, 7" : "=v"(a[i]) : "v"(a[(i + 1) & 15]), "v"(b)); \
+    if constexpr (OP == 22) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(a[i]) : "v"(c));        \
+    if constexpr (OP == 23) asm volatile("v_alignbit_b32 %0, %0, %0, %1" : "+v"(a[i]) : "v"(c));    \
+    if constexpr (OP == 24) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));         \
+    if constexpr (OP == 25) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); \
+    if constexpr (OP == 26) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));     \
+    if constexpr (OP == 27) asm volatile("v_bfe_u32 %0, %0, 3, 20" : "+v"(a[i]));                   \
+    if constexpr (OP == 28) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));             \
+    if constexpr (OP == 29) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[i]));                   \
+    if constexpr (OP == 30) asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(a[i]) : "v"(a[(i + 1) & 15]), "v"(b), "v"(c)); \
+    if constexpr (OP == 31) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
             REP16(STEP)
 #undef STEP
         }
@@ -103,7 +115,10 @@ int main() {
     const char* names[] = {"v_xor_b32(e32)", "v_bitop3_b32 vvv", "v_alignbit_b32 vv,imm", "v_fma_f32", "v_and_or_b32",
                            "v_perm_b32", "v_add_u32", "v_mov_b32", "v_bitop3 v,v,s", "v_xor_b32 s,v",
                            "v_alignbit v,v(same),imm", "v_bfi_b32", "v_lshl_or_b32", "v_alignbyte_b32", "v_or3_b32",
-                           "v_xad_u32", "v_and_b32", "v_lshlrev_b32", "v_add3_u32", "v_xor_b32_e64"};
+                           "v_xad_u32", "v_and_b32", "v_lshlrev_b32", "v_add3_u32", "v_xor_b32_e64",
+                           "v_alignbit v,v,v(shift)", "v_alignbit dst!=src0,imm", "v_lshlrev_b32 v,v", "v_alignbit v,v(same),v",
+                           "v_mul_u32_u24", "v_mad_u32_u24", "v_lshl_add_u32", "v_bfe_u32", "v_mul_f32", "v_lshrrev_b32 imm",
+                           "v_bitop3 dst!=src0", "v_mul_lo_u32"};
     for (int wps = 1; wps <= 8; wps *= 2) {
         const int blocks = cus * wps;  // 256 threads = 4 waves = one per SIMD
         printf("--- %d wave(s) per SIMD ---\n", wps);
@@ -116,7 +131,8 @@ int main() {
                ghz * 1e9 / per_simd_per_s, ghz, 64.0 * per_simd_per_s / (ghz * 1e9));              \
     }
         RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14)
-        RUN(15) RUN(16) RUN(17) RUN(18) RUN(19)
+        RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29)
+        RUN(30) RUN(31)
         const char* n64[] = {"v_lshlrev_b64", "v_pk_fma_f32", "v_pk_mov_b32"};
 #define RUN64(OP)                                                                                 \
     {                                                                                             \
