@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--stream-proofs", type=int, default=0,
                     help="config5: stream account witnesses of this many depth-8 proofs instead of block witnesses (A/B)")
     ap.add_argument("--stream-slots", type=int, default=2, help="witnesses in flight (config5)")
+    ap.add_argument("--nodeset", action="store_true",
+                    help="config5: stream the block witnesses as node SETS (every distinct node once: the form an execution witness has, "
+                         "src/engine_api/execution_payload.zig:121) through phant_mpt_verify_nodeset_submit / phant_wait")
     ap.add_argument("--verify-mode", default="flat", choices=["flat", "nodedup", "fused"],
                     help="flat = the two-tier pipeline (default: shallow trie levels deduplicated, deep ones hashed "
                          "in place); nodedup = every shipped node hashed (A/B); fused = one lane per proof (A/B)")
@@ -257,6 +260,33 @@ def cpu_baseline_block(w, target_seconds):
             "sample": f"{cnt} evenly strided proofs of the {hb.n}-proof block witness, oracle/verify.c single-threaded, "
                       f"{dt:.1f} s", "host_cpus": os.cpu_count(),
             "statuses_match_gpu_expected": bool((st == exp[idx]).all())}
+
+
+def cpu_baseline_nodeset(sset, target_seconds, gpu_status=None):
+    """oracle/verify.c's node-set verifier (hash every node, order the digests, walk every key), 1 core, over the WHOLE witness --
+    it is seconds of CPU work --, repeated until the sample is long enough; its statuses against the timed GPU launches'."""
+    import numpy as np
+    from oracle import oracle as O
+
+    roots = sset.roots.cpu().numpy()
+    ri = None if sset.root_idx is None else sset.root_idx.cpu().numpy().astype(np.uint32)
+    keys = sset.keys.cpu().numpy()
+    nodes = sset.nodes.cpu().numpy()
+    off = sset.node_off.cpu().numpy().astype(np.uint64)
+    dt, passes, st = 0.0, 0, None
+    while passes == 0 or (dt < target_seconds and passes < 8):
+        t0 = time.perf_counter()
+        st_k, _, _ = O.mpt_verify_nodeset(roots, ri, keys, 32, nodes, off)
+        dt += time.perf_counter() - t0
+        passes += 1
+        assert st is None or np.array_equal(st, st_k)
+        st = st_k
+    gpu_ok = None if gpu_status is None else bool(np.array_equal(st, gpu_status))
+    return {"value": sset.n * passes / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": f"the whole node set ({sset.total_nodes} nodes, {sset.n} keys) x {passes} pass(es), oracle/verify.c "
+                      f"(oracle_mpt_verify_nodeset) single-threaded, {dt:.1f} s",
+            "host_cpus": os.cpu_count(), "oracle_checked": gpu_ok is not None, "oracle_matches_timed_gpu_statuses": gpu_ok,
+            "oracle_checked_proofs": sset.n if gpu_ok is not None else 0}
 
 
 def cpu_baseline_config2(blob, n, target_seconds):
@@ -765,7 +795,11 @@ def extra_legs(args):
     import subprocess
     legs = [("config2", ["--workload", "config2", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
             ("mptize_1M_keys", ["--workload", "mptize", "--keys", "1000000", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
-            ("config5_16_blocks", ["--workload", "config5", "--steps", "4", "--warmup", "2", "--cpu-seconds", "3"])]
+            ("nodeset_config3", ["--workload", "nodeset", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
+            # BASELINE config 5 at its stated length: 256 consecutive block witnesses (4 distinct ones in rotation), and the same
+            # witnesses as node sets -- the form an execution witness has
+            ("config5_256_blocks", ["--workload", "config5", "--steps", "64", "--warmup", "2", "--cpu-seconds", "3"]),
+            ("config5_nodeset_256_blocks", ["--workload", "config5", "--nodeset", "--steps", "64", "--warmup", "2", "--cpu-seconds", "3"])]
     out, t_end = {}, time.time() + args.extra_seconds
     for name, argv in legs:
         left = t_end - time.time()
@@ -946,27 +980,42 @@ def main():
             strong["predicted"] = strong_predicted(total_proofs, world, strong["value"])
             del r4
     elif args.workload == "nodeset":
-        w = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2, device=dev, rank=rank,
-                                              world=world, ctx=ctx, corrupt_frac=0.0)
+        # config 3's trie as a node SET: S launch sequences in flight (slot k: own ctx, torch stream, witness of seed 2 + k), every
+        # pass = phant_mpt_verify_nodeset_verdict_dev (statuses + the per-root verdict out of one launch) + the verdict's all-reduce
+        S = max(1, min(args.streams, 4))
+        ns_slots = []
+        for k in range(S):
+            stream_k = torch.cuda.current_stream(dev) if k == 0 else torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream_k):
+                c_k = ctx if k == 0 else mk_ctx(args, local_rank)
+                w_k = phant_amd.witness.account_witness(args.proofs, depth=args.depth, seed=2 + k, device=dev, rank=rank, world=world,
+                                                        ctx=c_k, corrupt_frac=0.01)
+                s_k = phant_amd.witness.node_set(w_k, ctx=c_k, shuffle_seed=7 + k)
+            ns_slots.append((stream_k, c_k, w_k, s_k, torch.empty(s_k.n, dtype=torch.uint8, device=dev),
+                             torch.zeros(1, dtype=torch.int32, device=dev)))
+        torch.cuda.synchronize()
+        w, sset = ns_slots[0][2], ns_slots[0][3]
         b = w.batch
-        set_nodes, set_off = phant_amd.witness.as_node_set(b, ctx=ctx)
-        n_units = b.n
-        alg_bytes = int(set_nodes.numel() + b.keys.numel() + n_units)
-        status = torch.empty(n_units, dtype=torch.uint8, device=dev)
-        fails = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_units = sset.n
+        alg_bytes = sset.algorithmic_bytes()
+        ns_turn = {"k": 0}
 
         def kernel_only():
-            M.verify_nodeset_dev(b.roots, None, b.keys, set_nodes, set_off, status=status, ctx=ctx)
+            M.verify_nodeset_dev(sset.roots, None, sset.keys, sset.nodes, sset.node_off, status=ns_slots[0][4], ctx=ctx)
 
         def step():
-            kernel_only()
-            M.verdict_dev(status, None, 1, out=fails, ctx=ctx)
-            if world > 1:
-                dist.all_reduce(fails)
+            st_, c_, _, s_, status_, fails_ = ns_slots[ns_turn["k"] % S]
+            ns_turn["k"] += 1
+            with torch.cuda.stream(st_):
+                M.verify_nodeset_dev(s_.roots, None, s_.keys, s_.nodes, s_.node_off, status=status_, ctx=c_, fail_count=fails_)
+                if world > 1:
+                    dist.all_reduce(fails_)
 
         metric, unit = "mpt_keys_verified_per_sec_depth%d_nodeset" % args.depth, "proofs/s"
         workload = (f"nodeset: {args.proofs} depth-{args.depth} keys per GPU against one state root, witness = the "
-                    f"{set_off.numel() - 1} distinct nodes shipped once ({set_nodes.numel()} B)")
+                    f"{sset.total_nodes} distinct nodes shipped once, in random order ({sset.nodes.numel()} B; 1% of the source "
+                    f"proofs damaged / exclusion proofs: a damaged copy is a node nobody refers to), {S} launch sequence(s) in "
+                    f"flight, each over its own witness")
     elif args.workload == "mptize":
         # the state-trie hasher: n sorted distinct random 32-byte keys (hashed addresses), 78-byte values (account RLP)
         n_units = args.keys
@@ -1010,13 +1059,18 @@ def main():
         else:  # BASELINE config 5: block witnesses (config 4's shape; this rank's share of each)
             wl = [phant_amd.witness.block_witness(scale=args.block_scale, seed=40 + k, device=dev, rank=rank, world=world,
                                                   ctx=ctx) for k in range(4)]
-        hosts = [MM.to_host(x.batch) for x in wl]
+        if args.nodeset:  # the same witnesses as node SETS: every distinct node crosses the bus once
+            sets = [phant_amd.witness.node_set(x, ctx=ctx, shuffle_seed=70 + k) for k, x in enumerate(wl)]
+            hosts = [MM.nodeset_to_host(x) for x in sets]
+            sset = sets[0]
+        else:
+            hosts = [MM.to_host(x.batch) for x in wl]
         w = wl[0]
         b = w.batch
         n_units = b.n
         for x in wl:
             assert x.batch.n == n_units
-        alg_bytes = wl[0].batch.algorithmic_bytes()
+        alg_bytes = sets[0].algorithmic_bytes() if args.nodeset else wl[0].batch.algorithmic_bytes()
         slots = max(1, min(args.stream_slots, 4))
         state = {"k": 0, "pending": []}
 
@@ -1024,7 +1078,10 @@ def main():
             k = state["k"]
             if len(state["pending"]) == slots:
                 MM.wait(state["pending"].pop(0), ctx)
-            MM.verify_submit(hosts[k % 4], k % slots, ctx)
+            if args.nodeset:
+                MM.verify_nodeset_submit(hosts[k % 4], k % slots, ctx)
+            else:
+                MM.verify_submit(hosts[k % 4], k % slots, ctx)
             state["pending"].append(k % slots)
             state["k"] = k + 1
 
@@ -1042,6 +1099,11 @@ def main():
                     f"{b.n_roots} roots on this rank each; 4 distinct ones in rotation)")
         workload = (f"config5: consecutive {what} streamed from pinned host memory, {slots} in flight per GPU "
                     f"(H2D {hosts[0].h2d_bytes()} B per witness)")
+        if args.nodeset:
+            metric += "_nodeset"
+            workload += (f"; every witness shipped as a node SET ({sets[0].total_nodes} distinct nodes of the "
+                         f"{int(b.node_off.numel() - 1)} the per-proof form ships, random order: the form an execution witness has) "
+                         f"through phant_mpt_verify_nodeset_submit")
     else:
         n_units = args.messages
         g = torch.Generator(device=dev)
@@ -1086,17 +1148,30 @@ def main():
         ms_per_step = ms_per_pass * inner
 
         # correctness of what was timed
+        cpu_check_status = None
         if args.workload == "nodeset":
-            assert bool((status == 1).all()) and int(fails.item()) == 0, "node-set statuses differ from the expectation"
+            cpu_check_status = ns_slots[0][4].cpu().numpy().copy()  # slot 0's last timed pass over its witness
+            for _, _, w_, _, status_, fails_ in ns_slots:
+                assert torch.equal(status_, w_.expected_nodeset), "node-set statuses differ from the constructed expectation"
+                want_f = torch.tensor([int((w_.expected_nodeset >= 16).sum().item())], dtype=torch.int32, device=dev)
+                if world > 1:
+                    dist.all_reduce(want_f)
+                assert int(fails_.item()) == int(want_f.item()), (int(fails_.item()), int(want_f.item()))
         if streamed:
             for x, h in zip(wl, hosts):
-                assert torch.equal(h.status, x.expected.cpu()), "streamed statuses differ from the expectation"
+                assert torch.equal(h.status, (x.expected_nodeset if args.nodeset else x.expected).cpu()), \
+                    "streamed statuses differ from the expectation"
             # the kernels of one witness, device-resident, for the roofline object (the streamed rate itself is
             # bounded by PCIe: see the pcie object)
             dstatus = torch.empty(n_units, dtype=torch.uint8, device=dev)
+            if args.nodeset:
+                cpu_check_status = hosts[0].status.numpy().copy()
 
-            def kernel_only():
-                M.verify_batch_dev(wl[0].batch, status=dstatus, ctx=ctx)
+                def kernel_only():
+                    M.verify_nodeset_dev(sset.roots, sset.root_idx, sset.keys, sset.nodes, sset.node_off, status=dstatus, ctx=ctx)
+            else:
+                def kernel_only():
+                    M.verify_batch_dev(wl[0].batch, status=dstatus, ctx=ctx)
 
         # device time of one launch of the path (all kernels of the verify pipeline / the sponge kernel),
         # HIP events on the launch stream (phant_timing)
@@ -1107,9 +1182,43 @@ def main():
             kms.append(ctx.last_kernel_ms())
         ctx.timing(False)
         k_avg_ms = sum(kms) / len(kms)
+        if args.workload == "nodeset":
+            # one launch: HIP events on the launch stream around a run of back-to-back launches (alternating witnesses), as for
+            # the per-proof line; the per-launch pairs above (a host synchronisation after each) stay as kernel_synced_avg_ms
+            n_timed = max(10, min(args.steps * inner, 120))
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st0 = ns_slots[0][0]
+            sets = [x[3] for x in ns_slots]
+            with torch.cuda.stream(st0):
+                for k in range(4):
+                    M.verify_nodeset_dev(sets[k % S].roots, None, sets[k % S].keys, sets[k % S].nodes, sets[k % S].node_off,
+                                         status=ns_slots[0][4], ctx=ctx)
+                ev0.record(st0)
+                for k in range(n_timed):
+                    M.verify_nodeset_dev(sets[k % S].roots, None, sets[k % S].keys, sets[k % S].nodes, sets[k % S].node_off,
+                                         status=ns_slots[0][4], ctx=ctx)
+                ev1.record(st0)
+            torch.cuda.synchronize()
+            synced = k_avg_ms
+            k_avg_ms = ev0.elapsed_time(ev1) / n_timed
+            kernel_only()  # (the statistics are the last launch's: slot 0's witness)
+            hashed = ctx.verify_stats()
+            kf = int(sum((c + 1) * h for c, h in enumerate(hashed)))
+            peak6 = ctx.keccak_rate(6, 200) / 1e9
+            peak4 = ctx.keccak_rate(4, 200) / 1e9
+            vpeak = max(peak6, peak4)
+            extra = {"kernel_synced_avg_ms": synced, "nodes_shipped": int(sset.total_nodes), "nodes_hashed": int(sum(hashed)),
+                     "keccak_f_run": kf,
+                     "valu": {"bound": "valu", "achieved": kf / (k_avg_ms * 1e-3) / 1e9, "peak": vpeak, "unit": "G Keccak-f/s",
+                              "frac": kf / (k_avg_ms * 1e-3) / 1e9 / vpeak,
+                              "throughput_frac": value / world / n_units * kf / 1e9 / vpeak,
+                              "peak_source": "phant_keccak_rate on this device, this run: permutations only, the better of 4 and 6 "
+                                             "waves per SIMD",
+                              "note": "every node of the set is hashed exactly once: permutations run / whole-pipeline time of one "
+                                      "launch (frac) and / the rate with the launch sequences in flight (throughput_frac)"}}
         if streamed and args.verify_mode != "fused":
             hashed = ctx.verify_stats()
-            extra = {"nodes_shipped": int(b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed))}
+            extra = {"nodes_shipped": int(sset.total_nodes if args.nodeset else b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed))}
         if args.workload == "mptize":
             # the roofline that bounds a trie hasher: every node is hashed once, Keccak-f is integer-VALU-bound (110 MB of keys and
             # values are 1.6 % of HBM's rate at these times: the wrong ceiling).  Peak as for the verify line: measured in this run
@@ -1155,11 +1264,15 @@ def main():
                      "traffic_source": (tr.get("source") or tr.get("stale")) if tr else None,
                      "traffic_detail": tr,
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
-                                "node-set pipeline = classify_kernel (class lists) + hash_set_kernel + "
-                                "nodeset_insert_kernel + nodeset_walk_kernel" if args.workload == "nodeset" else
+                                "node-set pipeline = set_classify_kernel (class lists) + set_hash_kernel (every node hashed once and put "
+                                "into the record table by the lane that hashed it) + set_late_kernel (empty on a set of distinct nodes) "
+                                "+ set_walk_kernel (one launch of the path, first kernel start to last kernel end; the hash kernel is "
+                                "integer-VALU-bound, see roofline.valu)" if args.workload == "nodeset" else
                                 "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + per depth bin branch_kernel<1|2|4> or, for a thin bin, branch_coop_kernel, finish_kernel (first start to last end)"
                                 if args.workload == "mptize" else
-                                "mpt_verify_fused_kernel" if args.verify_mode == "fused" else pipeline),
+                                "mpt_verify_fused_kernel" if args.verify_mode == "fused" else
+                                "node-set pipeline = set_classify_kernel + set_hash_kernel + set_late_kernel + set_walk_kernel"
+                                if (streamed and args.nodeset) else pipeline),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
     if single is not None:
@@ -1175,11 +1288,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.workload == "mptize":
             line["cpu_baseline"] = cpu_baseline_mptize(keys_t, vals_t, n_units, root, args.cpu_seconds)
+        elif args.workload == "nodeset" or (args.workload == "config5" and args.nodeset):
+            line["cpu_baseline"] = cpu_baseline_nodeset(sset, args.cpu_seconds, cpu_check_status)
         elif args.workload == "config4":
             line["cpu_baseline"] = cpu_baseline_block(w, args.cpu_seconds)
         elif args.workload == "config5" and not args.stream_proofs:
             line["cpu_baseline"] = cpu_baseline_block(w, args.cpu_seconds)
-        elif args.workload in ("config3", "config5", "nodeset"):
+        elif args.workload in ("config3", "config5"):
             line["cpu_baseline"] = cpu_baseline_config3(w, args.cpu_seconds, timed_status0 if args.workload == "config3" else None)
         else:
             line["cpu_baseline"] = cpu_baseline_config2(blob, n_units, args.cpu_seconds)

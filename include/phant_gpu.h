@@ -309,6 +309,21 @@ PHANT_API int32_t phant_mpt_verify_sharded(phant_comm *comm, const uint8_t *root
                                            const uint8_t *nodes, uint64_t nodes_len, const uint64_t *node_off,
                                            const uint32_t *proof_first_node, uint32_t n, uint8_t *status,
                                            uint64_t *value_off, uint32_t *value_len, uint32_t *fail_count);
+/* The same for a node-set witness (arguments of phant_mpt_verify_nodeset).  A flat set cannot be cut without knowing where
+ * its nodes sit in their tries -- which only hashing them tells --, so the cut is the caller's: node_group[j] (total_nodes
+ * bytes, or NULL) = the top nibble 0..15 of the keys node j lies under (a node at depth >= 1 of its trie: what a witness
+ * producer that walks the tries knows for free), PHANT_NODE_SHARED for a node above that (the tries' root nodes) or of
+ * unknown place.  Node j goes to device node_group[j] mod N, a shared one to every device; NULL = every node to every
+ * device (correct, no byte saved: the devices then only split the keys).  The hints decide placement and nothing else: a
+ * key whose nodes were sent elsewhere gets PHANT_PROOF_MISSING_NODE, as with any incomplete witness -- never a pass it
+ * should not get. */
+#define PHANT_NODE_SHARED 0xffu
+PHANT_API int32_t phant_mpt_verify_nodeset_sharded(phant_comm *comm, const uint8_t *roots, uint32_t n_roots,
+                                                   const uint32_t *root_idx, const uint8_t *keys, uint32_t key_len,
+                                                   const uint8_t *nodes, uint64_t nodes_len, const uint64_t *node_off,
+                                                   uint32_t total_nodes, const uint8_t *node_group, uint32_t n,
+                                                   uint8_t *status, uint64_t *value_off, uint32_t *value_len,
+                                                   uint32_t *fail_count);
 /* Device form of the exchange for callers that keep their shards resident (phant_mpt_verify_verdict_dev on every
  * phant_comm_ctx): d_fail_count[rank] = that device's n_roots counters; summed in place on every device, on the
  * ranks' own streams (not waited for). */

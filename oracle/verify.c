@@ -1,3 +1,4 @@
+#define _GNU_SOURCE /* qsort_r */
 /*
  * oracle/verify.c -- TEST INFRASTRUCTURE (see phant_oracle.h).
  *
@@ -303,10 +304,10 @@ uint8_t oracle_mpt_verify(const uint8_t root[32], const uint8_t *key, uint32_t k
     return verify_core(root, key, key_len, nodes, node_off, n_nodes, NULL, ~(uint64_t)0, value_off, value_len);
 }
 
-static const uint8_t *g_sort_digests; /* qsort has no context argument; the oracle is single-threaded here */
-static int cmp_digest_idx(const void *a, const void *b) {
-    return memcmp(g_sort_digests + 32 * (size_t)*(const uint32_t *)a,
-                  g_sort_digests + 32 * (size_t)*(const uint32_t *)b, 32);
+/* (glibc's qsort_r: the digests travel as the comparator's context, so that several threads may each verify a node set) */
+static int cmp_digest_idx(const void *a, const void *b, void *digests) {
+    return memcmp((const uint8_t *)digests + 32 * (size_t)*(const uint32_t *)a,
+                  (const uint8_t *)digests + 32 * (size_t)*(const uint32_t *)b, 32);
 }
 
 /* nodes_len == ~0 and n_roots == 0: offsets and root indices are trusted (oracle_mpt_verify_nodeset).  Otherwise
@@ -330,8 +331,7 @@ static int nodeset_verify(const uint8_t *roots, uint32_t n_roots, const uint32_t
         oracle_keccak256(nodes + b, (size_t)(e - b), dig + 32 * (size_t)i);
         order[members++] = i;
     }
-    g_sort_digests = dig;
-    qsort(order, members, sizeof(uint32_t), cmp_digest_idx);
+    qsort_r(order, members, sizeof(uint32_t), cmp_digest_idx, dig);
     nodeset set = {dig, order, members};
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t r = root_idx ? root_idx[i] : 0;

@@ -105,6 +105,8 @@ SYMBOLS = {
     "phant_comm_last_error": (C.c_char_p, [_vp]),
     "phant_comm_owner": (_u32, [_vp, _vp, _u32]),
     "phant_mpt_verify_sharded": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    "phant_mpt_verify_nodeset_sharded": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp, _vp, _vp,
+                                                _vp]),
     "phant_mpt_root_sharded": (_i32, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "phant_state_root_sharded": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "phant_comm_allreduce_verdict": (_i32, [_vp, _vp, _u32]),

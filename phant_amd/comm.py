@@ -81,6 +81,34 @@ class Comm:
             raise L.PhantError(rc, self._lib.phant_comm_last_error(self._h).decode())
         return status[:n], voff[:n], vlen[:n], fails[:n_roots]
 
+    def verify_nodeset_sharded(self, roots, root_idx, keys, key_len, nodes, node_off, node_group=None):
+        """Host form of a node-set witness over the comm's devices (phant_mpt_verify_nodeset_sharded): the keys by their top
+        nibble, node j to device node_group[j] mod N (a hint of the witness producer: the top nibble of the keys the node lies
+        under, 0xff = every device; None = every node to every device) -> (status, value_off, value_len, fail_count[n_roots])."""
+        roots = np.ascontiguousarray(roots, np.uint8)
+        keys = np.ascontiguousarray(keys, np.uint8)
+        nodes = np.ascontiguousarray(nodes, np.uint8)
+        node_off = np.ascontiguousarray(node_off, np.uint64)
+        ri = None if root_idx is None else np.ascontiguousarray(root_idx, np.uint32)
+        grp = None if node_group is None else np.ascontiguousarray(node_group, np.uint8)
+        n = len(ri) if ri is not None else (keys.size // key_len if key_len else 0)
+        n_roots = roots.size // 32
+        total_nodes = len(node_off) - 1
+        assert grp is None or grp.size == total_nodes
+        nodes_len = nodes.size
+        if nodes.size == 0:
+            nodes = np.zeros(1, np.uint8)
+        status = np.zeros(max(n, 1), np.uint8)
+        voff = np.zeros(max(n, 1), np.uint64)
+        vlen = np.zeros(max(n, 1), np.uint32)
+        fails = np.zeros(max(n_roots, 1), np.uint32)
+        rc = self._lib.phant_mpt_verify_nodeset_sharded(self._h, _p(roots), n_roots, _p(ri), _p(keys), key_len, _p(nodes), nodes_len,
+                                                        _p(node_off), total_nodes, _p(grp), n, _p(status), _p(voff), _p(vlen),
+                                                        _p(fails))
+        if rc != L.OK:
+            raise L.PhantError(rc, self._lib.phant_comm_last_error(self._h).decode())
+        return status[:n], voff[:n], vlen[:n], fails[:n_roots]
+
     def mptize(self, keys: list[bytes], vals: list[bytes]) -> bytes:
         """mptize (mpt.zig:38-45) of sorted distinct keys (>= 1 byte each), the sub-tries of the sixteen top nibbles dealt
         out to the comm's devices (phant_mpt_root_sharded)."""

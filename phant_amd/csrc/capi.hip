@@ -1075,6 +1075,15 @@ int32_t ctx_verify_host_async_verdict(phant_ctx* c, const uint8_t* roots, uint32
     return phant_impl::verify_host_async(c, c->stream, c->ws.io, c->dv, &c->side, false, roots, n_roots, root_idx, keys, key_len, nodes,
                              nodes_len, node_off, proof_first_node, n, status, value_off, value_len, d_fail);
 }
+// the same for a node-set witness
+int32_t ctx_nodeset_host_async_verdict(phant_ctx* c, const uint8_t* roots, uint32_t n_roots, const uint32_t* root_idx,
+                                       const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
+                                       const uint64_t* node_off, uint32_t total_nodes, uint32_t n, uint8_t* status,
+                                       uint64_t* value_off, uint32_t* value_len, uint32_t** d_fail) {
+    DeviceGuard g(c->device);
+    return phant_impl::nodeset_host_async(c, c->stream, c->ws.io, c->ns, false, roots, n_roots, root_idx, keys, key_len, nodes,
+                                          nodes_len, node_off, total_nodes, n, status, value_off, value_len, d_fail);
+}
 // a device array of n_roots zeroed counters owned by the ctx (a rank without proofs still takes part in the reduction)
 int32_t ctx_zero_verdict(phant_ctx* c, uint32_t n_roots, uint32_t** d_fail) {
     DeviceGuard g(c->device);

@@ -36,6 +36,10 @@ int32_t ctx_verify_host_async_verdict(phant_ctx* c, const uint8_t* roots, uint32
                                       const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
                                       const uint64_t* node_off, const uint32_t* proof_first_node, uint32_t n,
                                       uint8_t* status, uint64_t* value_off, uint32_t* value_len, uint32_t** d_fail);
+int32_t ctx_nodeset_host_async_verdict(phant_ctx* c, const uint8_t* roots, uint32_t n_roots, const uint32_t* root_idx,
+                                       const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
+                                       const uint64_t* node_off, uint32_t total_nodes, uint32_t n, uint8_t* status,
+                                       uint64_t* value_off, uint32_t* value_len, uint32_t** d_fail);
 int32_t ctx_zero_verdict(phant_ctx* c, uint32_t n_roots, uint32_t** d_fail);
 hipStream_t ctx_stream(phant_ctx* c);
 int ctx_device(const phant_ctx* c);
@@ -53,6 +57,7 @@ struct Shard {
     std::vector<uint8_t> keys, nodes, status;
     std::vector<uint32_t> root_idx, pfn, value_len;
     std::vector<uint64_t> node_off, value_off;
+    std::vector<uint32_t> members;  // node-set form: which of the caller's nodes this device was given
     uint32_t* d_fail = nullptr;
     int32_t rc = PHANT_OK;
 };
@@ -457,6 +462,129 @@ int32_t phant_mpt_verify_sharded(phant_comm* c, const uint8_t* roots, uint32_t n
                     uint32_t j = 0;
                     while (j + 1 < l - f && s.node_off[sf + j + 1] <= s.value_off[k]) ++j;
                     vo = s.value_off[k] - s.node_off[sf + j] + node_off[f + j];
+                }
+                value_off[i] = vo;
+            }
+        }
+    }
+    return PHANT_OK;
+}
+
+// The node-set form over the comm's devices.  A flat set cannot be cut without knowing where its nodes sit in their tries --
+// which is what hashing them finds out --, so the cut is the caller's: node_group[j] says under which top key nibble node j lies
+// (what a witness producer that walks the tries knows for free), PHANT_NODE_SHARED for the nodes above that level.  The hints
+// are not trusted for anything but placement: a node sent to the wrong device is a node that device's keys cannot find --
+// MISSING_NODE, the verdict an incomplete witness gets --, never an accepted key that should have failed.
+int32_t phant_mpt_verify_nodeset_sharded(phant_comm* c, const uint8_t* roots, uint32_t n_roots, const uint32_t* root_idx,
+                                         const uint8_t* keys, uint32_t key_len, const uint8_t* nodes, uint64_t nodes_len,
+                                         const uint64_t* node_off, uint32_t total_nodes, const uint8_t* node_group, uint32_t n,
+                                         uint8_t* status, uint64_t* value_off, uint32_t* value_len, uint32_t* fail_count) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    if (fail_count)
+        for (uint32_t r = 0; r < n_roots; ++r) fail_count[r] = 0;
+    if (n == 0) return PHANT_OK;
+    if (!roots || n_roots == 0 || !node_off || !status || (key_len && !keys) || (nodes_len && !nodes) || key_len > 0x3fffffffu)
+        return cfail(c, PHANT_E_INVALID_ARG, "mpt_verify_nodeset_sharded: bad argument");
+    const uint32_t W = (uint32_t)c->ctx.size();
+    for (Shard& s : c->shards) {
+        s.proofs.clear();
+        s.members.clear();
+        s.d_fail = nullptr;
+        s.rc = PHANT_OK;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        c->shards[phant_impl::phant_comm_owner(c, keys ? keys + (size_t)key_len * i : nullptr, key_len)].proofs.push_back(i);
+    // (an entry of node_off that goes backwards, ends beyond the blob or is absurdly long is not a member of the set -- as on one
+    // device --: it is simply not shipped)
+    for (uint32_t j = 0; j < total_nodes; ++j) {
+        const uint64_t b = node_off[j], e = node_off[j + 1];
+        if (e < b || e > nodes_len || e - b > 0x7fffffffull) continue;
+        const uint32_t g = node_group ? node_group[j] : PHANT_NODE_SHARED;
+        if (g < 16u && W > 1u) {
+            c->shards[g % W].members.push_back(j);
+        } else {
+            for (Shard& s : c->shards) s.members.push_back(j);
+        }
+    }
+    auto work = [&](uint32_t r) {
+        Shard& s = c->shards[r];
+        const uint32_t m = (uint32_t)s.proofs.size();
+        if (m == 0) {
+            s.rc = phant::ctx_zero_verdict(c->ctx[r], n_roots, &s.d_fail);
+            return;
+        }
+        s.keys.resize((size_t)m * key_len);
+        s.root_idx.resize(root_idx ? m : 0);
+        s.status.assign(m, 0);
+        s.value_off.assign(m, 0);
+        s.value_len.assign(m, 0);
+        for (uint32_t k = 0; k < m; ++k) {
+            const uint32_t i = s.proofs[k];
+            if (key_len) std::memcpy(s.keys.data() + (size_t)k * key_len, keys + (size_t)i * key_len, key_len);
+            if (root_idx) s.root_idx[k] = root_idx[i];
+        }
+        size_t bytes = 0;
+        for (uint32_t j : s.members) bytes += (size_t)(node_off[j + 1] - node_off[j]);
+        s.nodes.resize(bytes);
+        s.node_off.resize(s.members.size() + 1);
+        size_t at = 0;
+        for (size_t k = 0; k < s.members.size(); ++k) {
+            const uint32_t j = s.members[k];
+            const size_t len = (size_t)(node_off[j + 1] - node_off[j]);
+            s.node_off[k] = at;
+            if (len) std::memcpy(s.nodes.data() + at, nodes + node_off[j], len);
+            at += len;
+        }
+        s.node_off[s.members.size()] = at;
+        s.rc = phant::ctx_nodeset_host_async_verdict(c->ctx[r], roots, n_roots, root_idx ? s.root_idx.data() : nullptr, s.keys.data(),
+                                                     key_len, s.nodes.data(), s.nodes.size(), s.node_off.data(),
+                                                     (uint32_t)s.members.size(), m, s.status.data(), s.value_off.data(),
+                                                     s.value_len.data(), &s.d_fail);
+    };
+    for_each_device(W, work);
+    for (uint32_t r = 0; r < W; ++r)
+        if (c->shards[r].rc != PHANT_OK) {
+            for (phant_ctx* x : c->ctx) (void)phant_stream_sync(x);  // nothing of a failed call stays in flight
+            return cfail(c, c->shards[r].rc, std::string("mpt_verify_nodeset_sharded: device ") + std::to_string(c->devices[r]) + ": " +
+                                                 phant_last_error(c->ctx[r]));
+        }
+    // ---- the one exchange: per-root failure counts, summed over the devices (RCCL over xGMI) ----
+    std::vector<uint32_t*> bufs(W);
+    for (uint32_t r = 0; r < W; ++r) bufs[r] = c->shards[r].d_fail;
+    int32_t rc = all_reduce_u32(c, bufs, n_roots);
+    if (rc == PHANT_OK && fail_count) {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        hipError_t e = hipSetDevice(c->devices[0]);
+        if (e == hipSuccess) e = hipMemcpyAsync(fail_count, bufs[0], (size_t)n_roots * 4, hipMemcpyDeviceToHost, phant::ctx_stream(c->ctx[0]));
+        if (prev >= 0) (void)hipSetDevice(prev);
+        if (e != hipSuccess) rc = cfail(c, PHANT_E_DEVICE, "mpt_verify_nodeset_sharded: copying the verdict back");
+    }
+    for (phant_ctx* x : c->ctx) {
+        const int32_t src = phant_stream_sync(x);
+        if (rc == PHANT_OK && src != PHANT_OK) rc = cfail(c, src, std::string("mpt_verify_nodeset_sharded: ") + phant_last_error(x));
+    }
+    if (rc != PHANT_OK) return rc;
+    // ---- results back into the caller's order; value offsets back into the caller's node blob ----
+    for (uint32_t r = 0; r < W; ++r) {
+        const Shard& s = c->shards[r];
+        for (uint32_t k = 0; k < (uint32_t)s.proofs.size(); ++k) {
+            const uint32_t i = s.proofs[k];
+            status[i] = s.status[k];
+            if (value_len) value_len[i] = s.value_len[k];
+            if (value_off) {
+                uint64_t vo = 0;
+                if (s.status[k] == PHANT_PROOF_PRESENT && !s.members.empty()) {
+                    // the shard node the value lies in: the last one that starts at or before it
+                    size_t lo = 0, hi = s.members.size();
+                    while (hi - lo > 1) {
+                        const size_t mid = lo + (hi - lo) / 2;
+                        if (s.node_off[mid] <= s.value_off[k]) lo = mid;
+                        else hi = mid;
+                    }
+                    // (empty nodes share their start with the next one: step to the node that really holds the byte)
+                    while (lo + 1 < s.members.size() && s.node_off[lo + 1] <= s.value_off[k]) ++lo;
+                    vo = s.value_off[k] - s.node_off[lo] + node_off[s.members[lo]];
                 }
                 value_off[i] = vo;
             }

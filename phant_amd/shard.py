@@ -121,6 +121,78 @@ def verify_sharded(b: HostBatch, rank: int, world: int, verify=gpu_verify, group
 
 
 # ------------------------------------------------------------------------------------------------------
+# Node-set witnesses (the form a block's execution witness has: every node once, in any order).
+@dataclass
+class HostNodeSet:
+    """A node-set witness in caller (host) memory, the argument list of phant_mpt_verify_nodeset; `node_group` (optional) is
+    the placement hint of phant_mpt_verify_nodeset_sharded: the top nibble of the keys a node lies under, 0xff = shared."""
+    roots: np.ndarray             # (n_roots, 32) u8
+    root_idx: np.ndarray | None   # (n,) u32 or None (= all 0)
+    keys: np.ndarray              # (n, key_len) u8
+    nodes: np.ndarray             # (nodes_len,) u8
+    node_off: np.ndarray          # (total_nodes + 1,) u64
+    node_group: np.ndarray | None = None  # (total_nodes,) u8
+
+    @property
+    def n(self) -> int:
+        return len(self.keys)
+
+    @property
+    def n_roots(self) -> int:
+        return self.roots.size // 32
+
+
+def take_node_set(s: HostNodeSet, rank: int, world: int) -> tuple[np.ndarray, HostNodeSet]:
+    """This rank's share of a node set: the keys whose top nibble it owns and the nodes its hints place here (a shared node
+    everywhere; without hints every node) -> (owned key indices, the sub-witness, node blob re-packed)."""
+    mine = np.nonzero(shard_of_key(s.keys, world) == rank)[0]
+    noff = s.node_off.astype(np.int64)
+    m = len(noff) - 1
+    lens = noff[1:] - noff[:-1]
+    ok = (lens >= 0) & (noff[1:] <= s.nodes.size) & (lens <= 0x7FFFFFFF)  # (a nonsense entry is not a member: not shipped)
+    if s.node_group is None or world == 1:
+        member = ok
+    else:
+        g = np.asarray(s.node_group, np.int64)
+        member = ok & ((g >= 16) | (g % world == rank))
+    ids = np.nonzero(member)[0]
+    l = lens[ids]
+    new_off = np.zeros(len(ids) + 1, np.int64)
+    np.cumsum(l, out=new_off[1:])
+    nbytes = int(new_off[-1])
+    src = np.repeat(noff[ids] - new_off[:-1], l) + np.arange(nbytes, dtype=np.int64)
+    nodes = s.nodes[src] if nbytes else np.zeros(0, np.uint8)
+    del m
+    return mine, HostNodeSet(roots=s.roots, root_idx=None if s.root_idx is None else s.root_idx[mine], keys=s.keys[mine],
+                             nodes=np.ascontiguousarray(nodes), node_off=new_off.astype(np.uint64))
+
+
+def gpu_verify_nodeset(s: HostNodeSet):
+    """Product verifier: the C-ABI host form on this rank's GPU."""
+    from . import mpt
+
+    st, _, _ = mpt.verify_nodeset(s.roots, s.root_idx if s.root_idx is not None else np.zeros(s.n, np.uint32), s.keys,
+                                  s.keys.shape[1] if s.keys.ndim == 2 else 0, s.nodes, s.node_off)
+    return st
+
+
+def verify_nodeset_sharded(s: HostNodeSet, rank: int, world: int, verify=gpu_verify_nodeset, group=None, device=None):
+    """Verify this rank's share of the node set; returns (owned key indices, their statuses, GLOBAL fail count per root).
+    The single collective is the all-reduce of n_roots int32, as for per-proof witnesses."""
+    import torch
+    import torch.distributed as dist
+
+    mine, sub = take_node_set(s, rank, world)
+    status = np.asarray(verify(sub), np.uint8) if sub.n else np.zeros(0, np.uint8)
+    fc = torch.from_numpy(fail_counts(status, sub.root_idx, s.n_roots).astype(np.int32))
+    if device is not None:
+        fc = fc.to(device)
+    if world > 1:
+        dist.all_reduce(fc, op=dist.ReduceOp.SUM, group=group)
+    return mine, status, fc.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------------
 # Trie roots across GPUs (SURVEY.md section 8e, second bullet): mptize sharded by the top key nibble.
 #
 # Rank r owns the top nibbles x with x % world == r.  For each of them it builds the sub-trie of the keys

@@ -189,6 +189,14 @@ def test_config2_dry_run():
 def test_nodeset_and_config5_dry_run():
     line = _bench(["--workload", "nodeset", "--proofs", "300", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2", "--inner", "1"])
     _check_contract(line, 2, 1)
+    assert line["cpu_baseline"]["oracle_matches_timed_gpu_statuses"] is True and line["roofline"]["valu"]["frac"] > 0
+    assert line["roofline"]["nodes_hashed"] == line["roofline"]["nodes_shipped"] > 300
+    # config 5 with every block witness shipped as a node set (phant_mpt_verify_nodeset_submit)
+    line = _bench(["--workload", "config5", "--nodeset", "--block-scale", "0.01", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.2"])
+    _check_contract(line, 2, 1)
+    assert line["metric"] == "mpt_proofs_verified_per_sec_block_witness_streamed_nodeset" and "pcie" in line
+    assert line["cpu_baseline"]["oracle_matches_timed_gpu_statuses"] is True
+    assert line["roofline"]["nodes_hashed"] == line["roofline"]["nodes_shipped"]
     line = _bench(["--workload", "config5", "--stream-proofs", "150", "--steps", "5", "--warmup", "1",
                    "--cpu-seconds", "0.2"])
     _check_contract(line, 5, 1)

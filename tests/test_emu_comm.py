@@ -34,7 +34,11 @@ def comm(request):
 
 from tests.test_gpu_comm import (  # noqa: E402,F401
     body_sharded_matches_oracle_and_single_ctx, body_block_witness_per_root_verdict, body_rejects_inconsistent_index_arrays,
-    body_sharded_mptize_matches_the_oracle, body_sharded_state_root)
+    body_sharded_mptize_matches_the_oracle, body_sharded_state_root, body_nodeset_sharded)
+
+
+def test_nodeset_sharded(comm, oracle):
+    body_nodeset_sharded(comm, oracle)
 
 
 def test_sharded_matches_oracle_and_single_ctx(comm, oracle):

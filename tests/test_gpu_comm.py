@@ -63,6 +63,56 @@ def body_block_witness_per_root_verdict(comm, oracle):
     assert np.array_equal(fails, np.bincount(ri[bad], minlength=len(roots)).astype(np.uint32))
 
 
+def body_nodeset_sharded(comm, oracle):
+    """phant_mpt_verify_nodeset_sharded: the block witness as ONE node set, its nodes placed by the producer's hints (a node to the
+    device of the top nibble it lies under, the tries' root nodes to all).  Statuses, value ranges (in the CALLER's blob) and
+    the all-reduced verdict equal the oracle's over the whole set -- with the hints, without them (every node everywhere), and,
+    with hints that send nodes to the wrong place, the oracle's over what each device was given: the keys that lost a node are
+    MISSING_NODE, nobody passes who should not."""
+    from tests.witness_util import node_set_with_groups
+    rng = np.random.default_rng(47)
+    roots, root_idx, keys, proofs = block_witness(oracle, rng, n_accounts=150, n_contracts=8, max_slots=50,
+                                                  n_account_proofs=70, n_storage_proofs=160)
+    blob, off, grp = node_set_with_groups(proofs, keys, rng)
+    r = np.frombuffer(b"".join(roots), np.uint8)
+    karr = np.frombuffer(b"".join(keys), np.uint8)
+    ri = np.asarray(root_idx, np.uint32)
+    want = oracle.mpt_verify_nodeset(r, ri, karr, 32, blob, off)
+    bad = (want[0] != 1) & (want[0] != 2)
+    for hint in (grp, None):
+        st, vo, vl, fails = comm.verify_nodeset_sharded(r, ri, karr, 32, blob, off, hint)
+        assert np.array_equal(st, want[0]) and np.array_equal(vl, want[2])
+        present = st == 1
+        assert np.array_equal(vo[present], want[1][present])
+        assert np.array_equal(fails, np.bincount(ri[bad], minlength=len(roots)).astype(np.uint32))
+    assert (want[0] == 1).sum() > 50 and (grp != 0xFF).sum() > 100
+    # hostile hints: every grouped node one device further on
+    W = comm.size
+    wrong = np.where(grp == 0xFF, grp, (grp + 1) % 16).astype(np.uint8)
+    st, vo, vl, fails = comm.verify_nodeset_sharded(r, ri, karr, 32, blob, off, wrong)
+    lens = np.diff(off.astype(np.int64))
+    for d in range(W):
+        mine = np.array([i for i, k in enumerate(keys) if (k[0] >> 4) % W == d], np.int64)
+        if mine.size == 0:
+            continue
+        member = (wrong == 0xFF) | ((wrong % W) == d) if W > 1 else np.ones(len(wrong), bool)
+        sub_off = np.zeros(int(member.sum()) + 1, np.uint64)
+        sub_off[1:] = np.cumsum(lens[member])
+        sub_blob = np.concatenate([blob[int(off[j]):int(off[j + 1])] for j in np.flatnonzero(member)] or [np.zeros(0, np.uint8)])
+        sub = oracle.mpt_verify_nodeset(r, ri[mine], karr.reshape(-1, 32)[mine].reshape(-1), 32,
+                                        sub_blob if sub_blob.size else np.zeros(1, np.uint8), sub_off)
+        assert np.array_equal(st[mine], sub[0])
+        assert not ((st[mine] == 1) & (want[0][mine] != 1)).any()
+    if W > 1:
+        assert (st == 20).sum() > (want[0] == 20).sum()  # (PHANT_PROOF_MISSING_NODE)
+    # index arrays of an untrusted witness: a node whose offsets are nonsense is not a member, here as on one device
+    off2 = off.copy()
+    off2[3] = off2[2] - 1 if off2[2] else off2[3]
+    st2, _, _, _ = comm.verify_nodeset_sharded(r, ri, karr, 32, blob, off2, grp)
+    want2 = oracle.mpt_verify_nodeset_checked(r, ri, karr, 32, blob, off2)
+    assert np.array_equal(st2, want2[0])
+
+
 def body_sharded_mptize_matches_the_oracle(comm, oracle):
     """phant_mpt_root_sharded: the sub-tries of the sixteen top nibbles on the comm's devices, root branch formed on the
     host -- same root as the oracle's mptize and as the single-ctx call, for every shape of the top of the trie (full
@@ -145,6 +195,10 @@ def test_one_device_comm_block_witness(comm1, oracle):
 
 
 @pytest.mark.gpu
+def test_one_device_comm_nodeset(comm1, oracle):
+    body_nodeset_sharded(comm1, oracle)
+
+
 def test_one_device_comm_state_root(comm1, oracle):
     body_sharded_state_root(comm1, oracle)
 
@@ -189,6 +243,7 @@ def test_all_devices_comm_verify_sharded(comm_all, oracle):
     body_sharded_matches_oracle_and_single_ctx(comm_all, oracle)
     body_block_witness_per_root_verdict(comm_all, oracle)
     body_rejects_inconsistent_index_arrays(comm_all, oracle)
+    body_nodeset_sharded(comm_all, oracle)
 
 
 @pytest.mark.gpu

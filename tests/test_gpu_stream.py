@@ -140,3 +140,93 @@ def test_streamed_block_witnesses_vs_oracle(oracle):
     finally:
         pin.free()
         ctx.close()
+
+
+def test_streamed_block_witnesses_as_node_sets_vs_oracle(oracle):
+    """The same stream with every block witness shipped as a node SET -- the form the hook at
+    /root/reference/src/engine_api/execution_payload.zig:121,175-181 would be handed (`executionWitness`: every trie node once,
+    in any order): 16 consecutive witnesses of 80 000 keys against 2 001 roots through phant_mpt_verify_nodeset_submit /
+    phant_wait, three slots in flight, every slot reused; every status byte, value range and per-root verdict must equal
+    oracle/verify.c's node-set verifier on the same arrays (and the generator's expectation: a damaged copy only costs its
+    key the proof when no intact copy of that node came with another key)."""
+    import phant_amd
+    from phant_amd import mpt as M
+
+    ctx = phant_amd.Context()
+    pin = _Pinned(ctx)
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    try:
+        blocks, want, shipped = [], [], []
+        for k in range(BLOCKS):
+            w = phant_amd.witness.block_witness(scale=1.0, seed=700 + k, corrupt_frac=0.01, ctx=ctx)
+            s = phant_amd.witness.node_set(w, ctx=ctx, shuffle_seed=k)
+            hb = {"roots": s.roots.cpu().numpy().reshape(-1), "root_idx": s.root_idx.cpu().numpy().astype(np.uint32),
+                  "keys": s.keys.cpu().numpy(), "nodes": s.nodes.cpu().numpy(),
+                  "node_off": s.node_off.cpu().numpy().astype(np.uint64)}
+            n, n_roots = hb["keys"].shape[0], hb["roots"].size // 32
+            assert n >= 79_000 and n_roots == 2001
+            shipped.append((int(w.batch.nodes.numel()), hb["nodes"].size))
+            expected = w.expected_nodeset.cpu().numpy()
+            del w, s
+            blocks.append({"in": {k2: pin.like(v) for k2, v in hb.items()}, "n": n, "n_roots": n_roots, "expected": expected,
+                           "status": pin.array((n,), np.uint8), "voff": pin.array((n,), np.uint64),
+                           "vlen": pin.array((n,), np.uint32)})
+        torch.cuda.synchronize()
+
+        # the oracle hashes and orders a block's ~300 000 nodes single-threaded: the blocks side by side
+        def check(k):
+            i = blocks[k]["in"]
+            return oracle.mpt_verify_nodeset(i["roots"], i["root_idx"], i["keys"], 32, i["nodes"], i["node_off"])
+
+        with ThreadPoolExecutor(threads) as ex:
+            want = list(ex.map(check, range(BLOCKS)))
+        for k in range(BLOCKS):
+            assert np.array_equal(want[k][0], blocks[k]["expected"])  # (the generator: a second opinion on the oracle)
+
+        def submit(k, slot):
+            x = blocks[k]
+            i = x["in"]
+            x["status"][:] = 0x55
+            ctx.check(ctx._lib.phant_mpt_verify_nodeset_submit(
+                ctx.handle, slot, i["roots"].ctypes.data, x["n_roots"], i["root_idx"].ctypes.data, i["keys"].ctypes.data, 32,
+                i["nodes"].ctypes.data, i["nodes"].size, i["node_off"].ctypes.data, i["node_off"].size - 1, x["n"],
+                x["status"].ctypes.data, x["voff"].ctypes.data, x["vlen"].ctypes.data))
+
+        for round_ in range(2):
+            pending = []
+            for k in range(BLOCKS):
+                slot = k % SLOTS
+                if len(pending) == SLOTS:
+                    ctx.check(ctx._lib.phant_wait(ctx.handle, pending.pop(0)))
+                submit(k, slot)
+                pending.append(slot)
+            for s_ in pending:
+                ctx.check(ctx._lib.phant_wait(ctx.handle, s_))
+            for k in range(BLOCKS):
+                x = blocks[k]
+                st, vo, vl = want[k]
+                assert np.array_equal(x["status"], st), (k, np.flatnonzero(x["status"] != st)[:10])
+                present = st == M.PROOF_PRESENT
+                assert np.array_equal(x["voff"][present], vo[present]) and np.array_equal(x["vlen"][present], vl[present])
+                assert (st == M.PROOF_MISSING_NODE).sum() > 0 and (st == M.PROOF_ABSENT).sum() > 0
+        # a node set is what crosses the bus: well under the per-proof form's bytes
+        assert all(ns < 0.7 * pp for pp, ns in shipped), shipped[:3]
+
+        # the per-root verdict as the device form computes it (the walk kernel), on the same witnesses resident
+        for k in (0, BLOCKS - 1):
+            i = blocks[k]["in"]
+            dev = torch.device("cuda", torch.cuda.current_device())
+            fails = torch.empty(blocks[k]["n_roots"], dtype=torch.int32, device=dev)
+            st_dev = M.verify_nodeset_dev(torch.from_numpy(i["roots"].reshape(-1, 32).copy()).to(dev),
+                                          torch.from_numpy(i["root_idx"].astype(np.int32)).to(dev),
+                                          torch.from_numpy(i["keys"].copy()).to(dev), torch.from_numpy(i["nodes"].copy()).to(dev),
+                                          torch.from_numpy(i["node_off"].astype(np.int64)).to(dev), ctx=ctx, fail_count=fails)
+            torch.cuda.synchronize()
+            st = want[k][0]
+            assert np.array_equal(st_dev.cpu().numpy(), st)
+            bad = ~((st == M.PROOF_PRESENT) | (st == M.PROOF_ABSENT))
+            assert np.array_equal(fails.cpu().numpy().astype(np.uint32),
+                                  np.bincount(i["root_idx"][bad], minlength=blocks[k]["n_roots"]).astype(np.uint32))
+    finally:
+        pin.free()
+        ctx.close()

@@ -152,6 +152,108 @@ def test_world2_gloo_matches_single_process(oracle, emulated):
     assert np.array_equal(seen, full)                         # disjoint cover, identical statuses
 
 
+def _two_root_node_set(oracle, seed=5):
+    """The same witness as ONE node set with the producer's placement hints, as a HostNodeSet."""
+    from phant_amd.shard import HostNodeSet
+    from tests.witness_util import random_kv, node_set_with_groups
+
+    rng = np.random.default_rng(seed)
+    proofs, keys, ridx, roots = [], [], [], []
+    for r, n in enumerate((120, 60)):
+        ks, vs = random_kv(rng, n, 32, 1, 70)
+        t = oracle.Trie(ks, vs)
+        roots.append(t.root())
+        for k in list(ks) + [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n // 4)]:
+            proofs.append(t.prove(k))
+            keys.append(k)
+            ridx.append(r)
+    for i in range(0, len(proofs), 9):  # damage every 9th proof's last node: as a set, that node is simply another node
+        nd = bytearray(proofs[i][-1])
+        nd[len(nd) // 2] ^= 0x10
+        proofs[i] = proofs[i][:-1] + [bytes(nd)]
+    blob, off, grp = node_set_with_groups(proofs, keys, rng)
+    return HostNodeSet(roots=np.frombuffer(b"".join(roots), np.uint8).reshape(-1, 32).copy(), root_idx=np.asarray(ridx, np.uint32),
+                       keys=np.frombuffer(b"".join(keys), np.uint8).reshape(-1, 32).copy(), nodes=blob, node_off=off,
+                       node_group=grp)
+
+
+def _oracle_verify_nodeset(oracle):
+    def f(s):
+        st, _, _ = oracle.mpt_verify_nodeset(s.roots, s.root_idx, s.keys, 32, s.nodes if s.nodes.size else np.zeros(1, np.uint8),
+                                             s.node_off)
+        return st
+    return f
+
+
+def _nodeset_worker(rank, world, port, q, emulated):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from phant_amd import shard
+
+    O.build()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = _two_root_node_set(O)
+        if emulated:
+            from tests import emu
+            backend = emu.emulated_backend(emu.load_mirror_lib())
+            next(backend)
+            mine, status, fc = shard.verify_nodeset_sharded(s, rank, world)
+            backend.close()
+        else:
+            mine, status, fc = shard.verify_nodeset_sharded(s, rank, world, verify=_oracle_verify_nodeset(O))
+        _, sub = shard.take_node_set(s, rank, world)
+        q.put((rank, mine.tolist(), status.tolist(), fc.tolist(), int(sub.nodes.size)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("emulated", [False, True], ids=["oracle-per-rank", "emulated-kernels-per-rank"])
+def test_world2_gloo_node_set(oracle, emulated):
+    """A node-set witness over two ranks: keys by their top nibble, nodes by the producer's hints (the tries' root nodes on both
+    ranks) -- every rank ships less than the whole set, the statuses are the unsharded ones, the verdict the global one."""
+    import torch.multiprocessing as mp
+
+    if emulated:
+        from tests import emu
+        try:
+            emu.build()
+        except RuntimeError as e:
+            pytest.skip(str(e))
+    from phant_amd import shard
+
+    s = _two_root_node_set(oracle)
+    full = _oracle_verify_nodeset(oracle)(s)
+    want_fc = shard.fail_counts(full, s.root_idx, s.n_roots)
+    assert want_fc.sum() > 0 and (full == oracle.PROOF_ABSENT).any() and (full == oracle.PROOF_PRESENT).any()
+    for world in (1, 2, 4):  # the cut: keys a disjoint cover; every grouped node on exactly one rank, a shared one on all
+        placed = np.zeros(len(s.node_group), np.int64)
+        for r in range(world):
+            g = s.node_group.astype(np.int64)
+            placed += ((g >= 16) | (g % world == r)) if world > 1 else 1
+        assert ((placed == 1) | ((s.node_group == 0xFF) & (placed == world))).all()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nodeset_worker, args=(r, 2, port, q, emulated)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seen = np.full(s.n, 255, np.uint8)
+    for rank, mine, status, fc, shipped in got:
+        assert fc == want_fc.tolist(), (rank, fc, want_fc)
+        assert shipped < 0.75 * s.nodes.size  # (about half of the set, plus the shared nodes)
+        seen[np.asarray(mine, np.int64)] = np.asarray(status, np.uint8)
+    assert np.array_equal(seen, full)
+
+
 def _block_worker(rank, world, port, q):
     """bench.py's config-4 step on every rank: build this rank's share of the block witness (the state root is
     agreed on with one all-reduce inside the generator), verify it with the verdict fused in, all-reduce the

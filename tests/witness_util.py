@@ -190,6 +190,27 @@ def node_set(proofs, rng=None):
     return blob, off
 
 
+def node_set_with_groups(proofs, keys, rng=None):
+    """node_set() plus the placement hint of phant_mpt_verify_nodeset_sharded, as a witness producer that walks the tries would
+    emit it: group[j] = the top nibble of the keys node j lies under (a node at depth >= 1 of some proof), 0xff for a node that
+    heads a proof (a trie's root node) or that turned up under two different nibbles (the same bytes in two tries).
+    -> (nodes u8[], node_off u64[m+1], group u8[m])"""
+    grp = {}
+    for p, k in zip(proofs, keys):
+        nib = k[0] >> 4
+        for d, nd in enumerate(p):
+            g = 0xFF if d == 0 else nib
+            grp[nd] = g if nd not in grp or grp[nd] == g else 0xFF
+    uniq = list(grp)
+    if rng is not None:
+        uniq = [uniq[i] for i in rng.permutation(len(uniq))]
+    off = np.zeros(len(uniq) + 1, np.uint64)
+    if uniq:
+        off[1:] = np.cumsum([len(x) for x in uniq])
+    blob = np.frombuffer(b"".join(uniq), np.uint8).copy() if uniq else np.zeros(0, np.uint8)
+    return blob, off, np.array([grp[x] for x in uniq], np.uint8)
+
+
 def damage_node(rng, node: bytes) -> bytes:
     nd = bytearray(node)
     kind = int(rng.integers(0, 7))
