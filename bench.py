@@ -112,9 +112,11 @@ def parse():
     ap.add_argument("--nodeset", action="store_true",
                     help="config5: stream the block witnesses as node SETS (every distinct node once: the form an execution witness has, "
                          "src/engine_api/execution_payload.zig:121) through phant_mpt_verify_nodeset_submit / phant_wait")
-    ap.add_argument("--verify-mode", default="flat", choices=["flat", "nodedup", "fused"],
-                    help="flat = the two-tier pipeline (default: shallow trie levels deduplicated, deep ones hashed "
-                         "in place); nodedup = every shipped node hashed (A/B); fused = one lane per proof (A/B)")
+    ap.add_argument("--verify-mode", default="flat", choices=["flat", "nodedup"],
+                    help="flat = the verify pipeline as the library sizes it (shallow trie levels deduplicated, deep ones hashed "
+                         "in place); nodedup = every shipped node hashed (= --dedup-levels 0: A/B)")
+    ap.add_argument("--diag", default="", help="per-ctx switches of include/phant_gpu_diag.h for every ctx of the run: "
+                                               "knob=value,knob=value (phant_amd.Context.DIAG; e.g. verify_serial=1 for the PMC passes)")
     ap.add_argument("--dedup-levels", type=int, default=None,
                     help="flat: trie levels deduplicated (default: chosen from the batch size)")
     ap.add_argument("--inner", type=int, default=30,
@@ -517,8 +519,8 @@ def per_kernel_roofline(kernel_ms, tiers, n, w, valu_peak, form):
     shallow = n * min(S, w.nodes_per_proof)  # nodes of the shallow tier
     copies = shallow - tiers["list_nodes"]
     node_b, key_b = 532, 32
-    out = {"note": "tiers serialised (PHANT_VERIFY_SERIAL=1): HIP events around each stage, alone on the chip; in one launch the deep "
-                   "tier, the hashing of the group heads and the comparison run next to each other", "dedup_levels": S, "form": form}
+    out = {"note": "tiers serialised (phant_diag_set: verify_serial): HIP events around each stage, alone on the chip; in one launch the "
+                   "deep tier runs next to the shallow tier's propose -> dedup -> hash_list chain", "dedup_levels": S, "form": form}
 
     def hbm(ms, nbytes, what):
         g = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -531,24 +533,11 @@ def per_kernel_roofline(kernel_ms, tiers, n, w, valu_peak, form):
                 "frac": g / valu_peak}
 
     out["hash_deep_kernel"] = valu(kernel_ms["hash_deep"], tiers["deep_keccak_f"])
-    if form == "table":
-        out["hash_list_kernel"] = valu(kernel_ms["hash_late"], tiers["list_keccak_f"])
-        out["dedup_kernel"] = hbm(kernel_ms["compare"], copies * node_b + shallow * 16 + n * (key_b + 8),
-                                  "the copies' own bytes once (their representatives are cache hits) + offsets + keys")
-        out["propose_kernel"] = hbm(kernel_ms["order"], shallow * 16 + n * (key_b + 8) + tiers["list_nodes"] * 4,
-                                    "offsets + keys + table stores")
-    else:
-        # (the two hash_list launches share one statistic: the heads' share of the Keccak-f is what the late launch did not run --
-        # the late list is short, its time is latency)
-        out["hash_list_kernel<heads>"] = valu(kernel_ms["hash_heads"], tiers["list_keccak_f"])
-        out["hash_list_kernel<late>"] = {"ms": kernel_ms["hash_late"], "bound": "latency",
-                                          "note": "the copies that differ: a few chunks of four sequential Keccak-f"}
-        out["compare_kernel"] = hbm(kernel_ms["compare"], shallow * node_b + shallow * 16 + n * (key_b + 8),
-                                    "every shallow node once + offsets + keys")
-        out["heads_kernel"] = hbm(kernel_ms["heads"], shallow * 16 + n * (key_b + 8) + tiers["list_nodes"] * 8,
-                                  "offsets + keys + list entries")
-        out["order_pass"] = hbm(kernel_ms["order"], n * (2 * key_b + 12) + 3 * 4 * 65536,
-                                "keys twice + counters + the order (order_hist + order_scan + order_scatter, or clear_kernel)")
+    out["hash_list_kernel"] = valu(kernel_ms["hash_list"], tiers["list_keccak_f"])
+    out["dedup_kernel"] = hbm(kernel_ms["dedup"], copies * node_b + shallow * 16 + n * (key_b + 8),
+                              "the copies' own bytes once (their representatives are cache hits) + offsets + keys")
+    out["propose_kernel"] = hbm(kernel_ms["propose"], shallow * 16 + n * (key_b + 8) + tiers["list_nodes"] * 4,
+                                "offsets + keys + table stores")
     out["walk_kernel"] = hbm(kernel_ms["walk"], n * (112 + key_b + 8 + 9) + w.nodes_per_proof * n * (1 + 4 * S // 8),
                              "the leaf, the key, node states and representatives, one status byte")
     return out
@@ -556,9 +545,12 @@ def per_kernel_roofline(kernel_ms, tiers, n, w, valu_peak, form):
 
 def mk_ctx(args, local_rank, use_torch_stream=True):
     import phant_amd
-    return phant_amd.Context(local_rank, use_torch_stream=use_torch_stream, verify_fused=(args.verify_mode == "fused"),
-                             verify_nodedup=(args.verify_mode == "nodedup"),
-                             dedup_levels=(args.dedup_levels if args.verify_mode == "flat" else None))
+    c = phant_amd.Context(local_rank, use_torch_stream=use_torch_stream, verify_nodedup=(args.verify_mode == "nodedup"),
+                          dedup_levels=(args.dedup_levels if args.verify_mode == "flat" else None))
+    for item in filter(None, (x.strip() for x in args.diag.split(","))):
+        k, _, v = item.partition("=")
+        c.diag_set(k.strip(), int(v or "1"))
+    return c
 
 
 _SLOT_STREAMS = []
@@ -722,23 +714,16 @@ def run_proof_bench(args, make_witness, S, steps, warmup, inner, dev, local_rank
         M.verify_batch_dev(wits[k % n_wit].batch, status=dstatus, ctx=ctx)
         kms.append(ctx.last_kernel_ms())
     ctx.timing(False)
-    hashed = ctx.verify_stats() if args.verify_mode != "fused" else None
-    # every kernel of the pipeline alone on the chip: a second ctx with the tiers serialised (PHANT_VERIFY_SERIAL is read at
-    # ctx creation), HIP events around each kernel (phant_verify_kernel_ms), averaged over a few launches
+    hashed = ctx.verify_stats()
+    # every kernel of the pipeline alone on the chip: a second ctx with the tiers serialised (phant_diag_set: verify_serial), HIP
+    # events around each kernel (phant_verify_kernel_ms), averaged over a few launches
     kernels = tiers = bound = None
     if args.verify_mode == "flat":
         tiers = ctx.verify_tier_stats()
         if tiers["dedup_levels"]:
-            saved = os.environ.get("PHANT_VERIFY_SERIAL")
-            os.environ["PHANT_VERIFY_SERIAL"] = "1"
-            try:
-                with torch.cuda.stream(st0):
-                    cs = mk_ctx(args, local_rank)
-            finally:
-                if saved is None:
-                    os.environ.pop("PHANT_VERIFY_SERIAL", None)
-                else:
-                    os.environ["PHANT_VERIFY_SERIAL"] = saved
+            with torch.cuda.stream(st0):
+                cs = mk_ctx(args, local_rank)
+            cs.diag_set("verify_serial", 1)
             acc, reps = {}, 8
             with torch.cuda.stream(st0):
                 for k in range(reps + 2):
@@ -955,7 +940,7 @@ def main():
                               "(0.121 ms) is out of reach for this hashing next to ANY stream on this chip -- what is left between one "
                               "launch and together_ms is all the shallow tier's own shape can still give")
                 extra["bound_experiment"] = be
-        if args.workload == "config3" and not args.no_strong and args.verify_mode != "fused":
+        if args.workload == "config3" and not args.no_strong:
             # BASELINE config 4 next to it: ONE block witness split over the same N GPUs (strong scaling): accounts by
             # top key nibble, contracts dealt out whole, one all-reduce of the per-root verdicts per pass
             del r
@@ -1216,7 +1201,7 @@ def main():
                                              "waves per SIMD",
                               "note": "every node of the set is hashed exactly once: permutations run / whole-pipeline time of one "
                                       "launch (frac) and / the rate with the launch sequences in flight (throughput_frac)"}}
-        if streamed and args.verify_mode != "fused":
+        if streamed:
             hashed = ctx.verify_stats()
             extra = {"nodes_shipped": int(sset.total_nodes if args.nodeset else b.node_off.numel() - 1), "nodes_hashed": int(sum(hashed))}
         if args.workload == "mptize":
@@ -1235,10 +1220,10 @@ def main():
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
 
     pipeline = ("two-tier verify pipeline = hash_deep_kernel (in-place hashing of the deep levels, helper stream) next to the "
-                "shallow tier (one root: order_hist / order_scan / order_scatter kernels, then heads_kernel + hash_list_kernel<0> on "
-                "a second helper stream next to compare_kernel + hash_list_kernel<1>; several roots: propose_kernel + dedup_kernel + "
-                "hash_list_kernel), then walk_kernel (one launch of the path, first kernel start to last kernel end; the hash "
-                "kernels are integer-VALU-bound, see roofline.valu)")
+                "shallow tier (propose_kernel + dedup_kernel + hash_list_kernel: the copies of the upper trie levels are byte-compared "
+                "with one representative per group instead of hashed), then walk_kernel (one launch of the path, first kernel start "
+                "to last kernel end; the hash kernels are integer-VALU-bound, see roofline.valu); a batch of less than 72 MB of nodes: "
+                "zero_kernel + hash_deep / hash_coop / hash_wave_kernel over every node + walk_kernel")
     line = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "ms_per_pass": ms_per_pass, "higher_is_better": True,
@@ -1270,11 +1255,21 @@ def main():
                                 "integer-VALU-bound, see roofline.valu)" if args.workload == "nodeset" else
                                 "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + per depth bin branch_kernel<1|2|4> or, for a thin bin, branch_coop_kernel, finish_kernel (first start to last end)"
                                 if args.workload == "mptize" else
-                                "mpt_verify_fused_kernel" if args.verify_mode == "fused" else
                                 "node-set pipeline = set_classify_kernel + set_hash_kernel + set_late_kernel + set_walk_kernel"
                                 if (streamed and args.nodeset) else pipeline),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }
+    # the scalars a reader of the compacted line needs next to `frac` ("report VALU utilisation next to the
+    # HBM fraction"): the hashing is integer-VALU-bound, so the HBM fraction a launch could reach at most is the one it would have
+    # if it took exactly as long as its permutations take at the chip's measured Keccak-f rate
+    rf = line["roofline"]
+    if isinstance(rf.get("valu"), dict) and rf["valu"].get("peak"):
+        rf["valu_frac"] = rf["valu"]["frac"]
+        t_valu_ms = rf["keccak_f_run"] / (rf["valu"]["peak"] * 1e9) * 1e3
+        rf["valu_bound_frac_of_hbm"] = alg_bytes / (t_valu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        rf["valu_bound_ms"] = t_valu_ms
+    if isinstance(rf.get("bound_experiment"), dict) and "ceiling_frac" in rf["bound_experiment"]:
+        rf["ceiling_frac"] = rf["bound_experiment"]["ceiling_frac"]
     if single is not None:
         line["single_stream"] = single
     if strong is not None:

@@ -78,23 +78,11 @@ extern "C" {
 typedef struct phant_ctx phant_ctx;
 
 #define PHANT_CTX_OWN_STREAM 1u   /* flags: ignore `stream`, create a private non-blocking stream */
-#define PHANT_CTX_VERIFY_FUSED 2u /* flags: verify with the one-lane-per-proof kernel instead of the
-                                     two-tier pipeline (A/B and debugging) */
-#define PHANT_CTX_VERIFY_NODEDUP 4u /* flags: two-tier pipeline, but hash every shipped node even when the
-                                       batch carries byte-identical copies (A/B; = PHANT_CTX_DEDUP_LEVELS(0)) */
 /* flags: how many trie levels, counted from the root, the verify pipeline deduplicates across the proofs of a
  * batch (byte-compares copies instead of hashing them); deeper nodes are hashed in place.  Default (field 0):
  * chosen from the batch -- none for batches of less than 72 MB of nodes (the chip hashes those whole in a few rounds
- * of waves), otherwise the levels with fewer groups than proofs.  Correctness does not depend on it. */
-#define PHANT_CTX_VERIFY_KEY_ORDERED 8u /* flags (A/B): the caller's word that every batch lists its proofs in (root index, key)
-                                          order -- as a witness producer that walks the tries emits them.  The two-tier pipeline
-                                          then finds the byte-identical copies of the upper trie levels among NEIGHBOURS (the
-                                          "ordered form": every copy read once, the group heads hashed next to the comparison)
-                                          instead of through its group tables.  Nothing is trusted: an unordered batch is
-                                          verified just the same, with less deduplication (more hashing).  Measured on MI355X:
-                                          slower than the tables at every batch size (profiles/r5_explore/NOTES.md), hence A/B */
-#define PHANT_CTX_VERIFY_ORDERED 16u   /* flags (A/B): the ordered form for batches against ONE root, on the library's own order
-                                          (a counting sort on the top key bits in front of the comparison) */
+ * of waves), otherwise the levels with fewer groups than proofs; PHANT_CTX_DEDUP_LEVELS(0): every shipped node is
+ * hashed, whatever the batch.  A sizing hint of the one pipeline: correctness does not depend on it. */
 #define PHANT_CTX_DEDUP_LEVELS_SHIFT 8
 #define PHANT_CTX_DEDUP_LEVELS_MASK 0x1f00u
 #define PHANT_CTX_DEDUP_LEVELS(n) ((((uint32_t)(n) + 1u) << PHANT_CTX_DEDUP_LEVELS_SHIFT) & PHANT_CTX_DEDUP_LEVELS_MASK)
@@ -503,57 +491,6 @@ PHANT_API int32_t phant_state_trie_leaves(phant_ctx *ctx, const uint8_t *addrs, 
                                           const uint64_t *code_off, const uint8_t *slot_keys,
                                           const uint8_t *slot_vals, const uint32_t *slot_first, uint32_t n,
                                           uint8_t *keys, uint8_t *vals, uint64_t vals_cap, uint64_t *val_off);
-
-/* -------------------------------------------------------------- measurement
- * Device time of the last *_dev call -- every kernel it launched, first to
- * last -- measured with HIP events recorded on the ctx stream around the
- * launches (bench.py uses this for `roofline.achieved`).  Enable with
- * phant_timing(ctx, 1). */
-PHANT_API int32_t phant_timing(phant_ctx *ctx, int32_t enable);
-/* After a node-parallel verify call on this ctx: hashed[c] = number of nodes
- * of (c+1) rate blocks (c = 7: 8 or more) that were actually hashed, i.e.
- * distinct nodes; synchronises the ctx stream.  All zero after a fused call. */
-PHANT_API int32_t phant_verify_stats(phant_ctx *ctx, uint32_t hashed[8]);
-/* After a two-tier verify call on this ctx: out[0] = proofs the walk could not settle from the pipeline's tables and
- * verified from scratch, out[1] = nodes decoded by walks that had to decode more than one node (both 0 for a witness
- * of full-branch paths ending in a leaf); synchronises the ctx stream.  Diagnostics, not part of a result. */
-PHANT_API int32_t phant_verify_path_stats(phant_ctx *ctx, uint32_t out[2]);
-/* The two tiers of the last verify call on this ctx: out[0] = trie levels deduplicated (0: every shipped node hashed in
- * place), out[1] = nodes hashed from the class lists (representatives, nodes without a group, copies that differed) and
- * out[2] = their Keccak-f, out[3] = nodes hashed in place by the deep tier and out[4] = their Keccak-f.  Diagnostics. */
-PHANT_API int32_t phant_verify_tier_stats(phant_ctx *ctx, uint32_t out[5]);
-PHANT_API int32_t phant_last_kernel_ms(phant_ctx *ctx, float *ms);
-/* Diagnostics, for a ctx created with PHANT_VERIFY_SERIAL=1 in the environment (the pipeline's tiers then run one after the
- * other on the ctx stream): device time of each stage of the last two-tier verify launch, alone on the chip -- ms[0..6] =
- * the order pass (order_hist + order_scan + order_scatter kernels; table form: propose_kernel), hash_deep_kernel, heads_kernel,
- * the hashing of the group heads (hash_list_kernel, set 0), compare_kernel (table form: dedup_kernel), the hashing of what
- * the comparison left (hash_list_kernel, set 1; table form: of everything listed), walk_kernel.  Stages a form does not have
- * read 0.  form (may be NULL): 1 = table form, 2 = ordered form on the library's own order, 3 = on the caller's.
- * Synchronises the ctx stream. */
-#define PHANT_VERIFY_KERNEL_STAGES 7
-PHANT_API int32_t phant_verify_kernel_ms(phant_ctx *ctx, float ms[PHANT_VERIFY_KERNEL_STAGES]);
-PHANT_API int32_t phant_verify_form(phant_ctx *ctx, uint32_t *form);
-/* Diagnostics: what the chip can overlap at best on THIS witness (arguments of phant_mpt_verify_batch_dev).  One complete
- * verification first; then, `reps` times each on the ctx's streams, out_ms[0] = only the hashing that launch did (the deep tier
- * and everything listed, next to each other: the integer-VALU side), out_ms[1] = only a coalesced read of the node bytes (the
- * memory side, a clean stream), out_ms[2] = both next to each other.  A verify launch cannot be shorter than out_ms[2]; how
- * far it is above it is what its own kernels' shape costs.  bench.py: roofline.bound_experiment.  Synchronises. */
-PHANT_API int32_t phant_verify_bound_experiment(phant_ctx *ctx, const uint8_t *d_roots, uint32_t n_roots,
-                                                const uint32_t *d_root_idx, const uint8_t *d_keys, uint32_t key_len,
-                                                const uint8_t *d_nodes, uint64_t nodes_len, const uint64_t *d_node_off,
-                                                uint32_t total_nodes, const uint32_t *d_proof_first_node, uint32_t n,
-                                                uint8_t *d_status, uint32_t reps, float out_ms[3]);
-/* Diagnostics: the Keccak-f[1600] rate of the device when it does nothing else -- waves_per_simd (1..8) waves per SIMD,
- * every lane `perms` permutations of a register-resident state with the product's round function, timed with events on the
- * ctx stream (synchronises it).  *perms_per_s = permutations per second over the whole chip: the VALU ceiling every hash
- * kernel of this library is measured against (bench.py: roofline.valu.peak). */
-PHANT_API int32_t phant_keccak_rate(phant_ctx *ctx, uint32_t waves_per_simd, uint32_t perms, double *perms_per_s);
-/* Diagnostics (A/B of the node-set pipeline's hash kernel, tools/): ladder = the four-block hash waves lower their issue
- * priority block by block (default 1); order = 0: class lists by falling rate-block count (default), 1: rising; hash_lds_bytes
- * = idle dynamic LDS per hash workgroup (caps the hash waves per SIMD; default 0); resident_wgs = the hash grid's cap, its
- * waves striding over the chunk queue (default 4 x CUs; 0 = a wave per chunk). */
-PHANT_API int32_t phant_nodeset_tune(phant_ctx *ctx, int32_t ladder, uint32_t order, uint32_t hash_lds_bytes,
-                                     uint32_t resident_wgs);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,8 @@ SYMBOLS = {
     "phant_last_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "phant_keccak_rate": (_i32, [_vp, _u32, _u32, C.POINTER(C.c_double)]),
     "phant_nodeset_tune": (_i32, [_vp, _i32, _u32, _u32, _u32]),
-    "phant_verify_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float * 7)]),
+    "phant_diag_set": (_i32, [_vp, _u32, C.c_int64]),
+    "phant_verify_kernel_ms": (_i32, [_vp, C.POINTER(C.c_float * 5)]),
     "phant_verify_form": (_i32, [_vp, C.POINTER(C.c_uint32)]),
     "phant_verify_bound_experiment": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _u32, _vp, _u32, _vp, _u32,
                                             C.POINTER(C.c_float * 3)]),

@@ -33,7 +33,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "phant_gpu.h"),
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "phant_gpu.h"), os.path.join(INCLUDE, "phant_gpu_diag.h"),
                                                                  os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 

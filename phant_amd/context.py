@@ -16,16 +16,15 @@ def _np_ptr(a: np.ndarray):
 class Context:
     """Owns a phant_ctx.  Externally synchronised, like the C object."""
 
-    def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_fused: bool = False,
-                 verify_nodedup: bool = False, dedup_levels: int | None = None, key_ordered: bool = False, verify_ordered: bool = False):
+    def __init__(self, device: int | None = None, use_torch_stream: bool = True, verify_nodedup: bool = False,
+                 dedup_levels: int | None = None):
         """use_torch_stream: the ctx works on torch's current stream of the device (its launches are ordered with the torch
         operations around them: the default, and what every mirror function that takes or returns a tensor assumes).  False:
         a private stream -- device-form calls are then asynchronous on THAT stream and not ordered with torch's; the caller
         fences both ways (`torch.cuda.current_stream().synchronize()` before handing over tensors torch is still producing,
         `ctx.sync()` before torch reads a result).
-        verify_fused / verify_nodedup: the A/B forms of the verify pipeline (one lane per proof; every shipped
-        node hashed).  dedup_levels: how many trie levels from the root the two-tier pipeline deduplicates
-        (None = chosen from the batch size; PHANT_CTX_DEDUP_LEVELS)."""
+        dedup_levels: how many trie levels from the root the verify pipeline deduplicates (None = chosen from the batch
+        size; PHANT_CTX_DEDUP_LEVELS); verify_nodedup = dedup_levels 0: every shipped node hashed."""
         lib = L.lib()
         if not torch.cuda.is_available():
             raise L.PhantError(L.E_NO_DEVICE, "no GPU visible (phant_amd has no CPU fallback)")
@@ -36,14 +35,8 @@ class Context:
         stream, flags = None, 1  # PHANT_CTX_OWN_STREAM
         if use_torch_stream:
             stream, flags = torch.cuda.current_stream(self.device).cuda_stream or None, 0
-        if verify_fused:
-            flags |= 2  # PHANT_CTX_VERIFY_FUSED
         if verify_nodedup:
-            flags |= 4  # PHANT_CTX_VERIFY_NODEDUP
-        if verify_ordered:
-            flags |= 16  # PHANT_CTX_VERIFY_ORDERED (A/B: one root: the ordered form on the library's own order)
-        if key_ordered:
-            flags |= 8  # PHANT_CTX_VERIFY_KEY_ORDERED: every batch lists its proofs in (root index, key) order
+            dedup_levels = 0
         if dedup_levels is not None:
             flags |= ((int(dedup_levels) + 1) << 8) & 0x1F00  # PHANT_CTX_DEDUP_LEVELS(n)
         opts = L.PhantOpts(C.sizeof(L.PhantOpts), self.device, stream, flags)
@@ -88,15 +81,26 @@ class Context:
         self.check(self._lib.phant_keccak_rate(self._h, waves_per_simd, perms, C.byref(out)))
         return out.value
 
-    VERIFY_STAGES = ("order", "hash_deep", "heads", "hash_heads", "compare", "hash_late", "walk")
-    VERIFY_FORMS = {0: "hash_everything", 1: "table", 2: "ordered", 3: "ordered_by_caller"}
+    VERIFY_STAGES = ("propose", "hash_deep", "dedup", "hash_list", "walk")
+    VERIFY_FORMS = {0: "hash_everything", 1: "two_tiers"}
+    # include/phant_gpu_diag.h: the knobs of phant_diag_set
+    DIAG = {name: k + 1 for k, name in enumerate((
+        "verify_serial", "verify_hash_lds_kb", "verify_no_coop", "verify_no_wave", "verify_coop_max", "stream_wgs", "stream_mb",
+        "trie_no_side", "trie_side_min_keys", "trie_ahead_max_keys", "trie_side_lds", "trie_fallback_grid", "trie_slot_blocks",
+        "trie_no_coop", "trie_coop_max", "trie_no_wave", "trie_join_in_stream", "sort_no_fallback", "sort_prefix_bits",
+        "sort_repair_bits"))}
+
+    def diag_set(self, knob: str, value: int):
+        """phant_diag_set: a per-ctx switch of a measured alternative or a test hook (the library reads no environment)."""
+        self.check(self._lib.phant_diag_set(self._h, self.DIAG[knob], int(value)))
+
+    def nodeset_tune(self, form: int = 1, order: int = 0, hash_lds: int = 40 * 1024, resident_wgs: int = 0):
+        self.check(self._lib.phant_nodeset_tune(self._h, form, order, hash_lds, resident_wgs))
 
     def verify_kernel_ms(self) -> dict[str, float]:
-        """Device time of each stage of the last two-tier verify launch, tiers serialised (a ctx created while
-        PHANT_VERIFY_SERIAL=1 is in the environment): the order pass (table form: propose_kernel), hash_deep_kernel,
-        heads_kernel, the hashing of the group heads, compare_kernel (table form: dedup_kernel), the hashing of what the
-        comparison left (table form: of everything listed), walk_kernel."""
-        out = (C.c_float * 7)()
+        """Device time of each stage of the last two-tier verify launch with the tiers serialised (diag_set("verify_serial", 1)):
+        propose_kernel, hash_deep_kernel, dedup_kernel, hash_list_kernel, walk_kernel."""
+        out = (C.c_float * 5)()
         self.check(self._lib.phant_verify_kernel_ms(self._h, C.byref(out)))
         return dict(zip(self.VERIFY_STAGES, [float(x) for x in out]))
 

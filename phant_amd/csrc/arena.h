@@ -57,8 +57,27 @@ struct DevArena {
     }
 };
 
+// Switches of the trie hasher and of the state root's key sort (per ctx; set through include/phant_gpu_diag.h's phant_diag_set by
+// tests and tools, never read from the environment).  -1 / 0 / false = the library's own choice (the constants in trie_build.hip).
+struct TrieTune {
+    bool no_side = false;            // never run the deepest bins on the helper stream beside the leaves (A/B)
+    int64_t side_min_keys = -1;      // ... from this many keys on (tests)
+    int64_t ahead_max_keys = -1;     // the leaves are queued ahead of the host's sizing up to this many keys (tests)
+    int64_t side_lds = -1;           // idle dynamic LDS of the bulk leaf kernel while bins run beside it
+    int64_t fallback_grid = -1;      // workgroups of a bin's fallback pass (tests)
+    int32_t slot_blocks = 0;         // != 0: every bin in slots of this many rate blocks (A/B)
+    bool no_coop = false;            // never the node-per-half-wave / node-per-wave kernels for thin bins (A/B)
+    int64_t coop_max = -1;           // ... up to this many nodes
+    bool no_wave = false;            // the half-wave kernel for every thin bin (A/B)
+    bool join_in_stream = false;     // the helper stream joined by an event in the main stream instead of by hand (A/B)
+    bool sort_no_fallback = false;   // state root: an undecided device sort is an error instead of a host sort (tests)
+    int64_t sort_prefix_bits = -1;   // state root: the device sort on this many key bits, ties left undecided (tests)
+    int64_t sort_repair_bits = -1;   // ... ties repaired (tests)
+};
+
 // The arenas a ctx lends to the host-form entry points.
 struct Workspaces {
+    TrieTune tune;
     DevArena io;  // staged inputs / outputs of the current call
     DevArena t1;  // trie builder: per-key / per-boundary arrays
     DevArena t2;  // trie builder: slot tables + encoding scratch

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/phant_gpu.h"
+#include "../../include/phant_gpu_diag.h"
 #include "arena.h"
 #include "launch.h"
 #include "trie_build.h"
@@ -46,7 +47,6 @@ struct phant_ctx {
     uint32_t ns_salt[2] = {0, 0};  // key of its record table's slot function
     phant::NodesetTune ns_tune;
     bool last_was_nodeset = false;  // which pipeline phant_verify_stats reports on
-    bool verify_fused = false;
     phant::VerifyTune tune;
     int32_t dedup_levels = -1;  // trie levels deduplicated by the two-tier pipeline: < 0 = from the batch size, 0 = none
     // helper stream of the two-tier pipeline: its deep tier runs there, next to the shallow tier (created on first use)
@@ -60,7 +60,7 @@ struct phant_ctx {
     } slots[PHANT_MAX_SLOTS];
     uint32_t last_shallow = 0;  // trie levels the last two-tier launch deduplicated (diagnostics)
     uint32_t last_form = 0;     // the shallow tier's form in the last launch (VerifyTune::last_form)
-    hipEvent_t kev[phant::VERIFY_KERNEL_STAGES + 1] = {};  // PHANT_VERIFY_SERIAL: events around the stages of a launch
+    hipEvent_t kev[phant::VERIFY_KERNEL_STAGES + 1] = {};  // diagnostics (PHANT_DIAG_VERIFY_SERIAL): events around the stages of a launch
     bool kev_valid = false;
     // stream-side timing of the last device-form call
     bool timing = false;
@@ -171,15 +171,9 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         stream = opts->stream;
         own = (opts->flags & PHANT_CTX_OWN_STREAM) != 0;
     }
-    bool fused = opts && (opts->flags & PHANT_CTX_VERIFY_FUSED);
     int32_t dedup_levels = -1;
     if (opts && (opts->flags & PHANT_CTX_DEDUP_LEVELS_MASK))
         dedup_levels = (int32_t)((opts->flags & PHANT_CTX_DEDUP_LEVELS_MASK) >> PHANT_CTX_DEDUP_LEVELS_SHIFT) - 1;
-    if (opts && (opts->flags & PHANT_CTX_VERIFY_NODEDUP)) dedup_levels = 0;
-    if (const char* m = std::getenv("PHANT_VERIFY_MODE")) {  // overrides the flags (A/B without touching callers)
-        fused = std::strcmp(m, "fused") == 0;
-        if (std::strcmp(m, "nodedup") == 0) dedup_levels = 0;
-    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || dev < 0 || dev >= n) return PHANT_E_NO_DEVICE;
     hipDeviceProp_t prop;
@@ -199,28 +193,7 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
         c->ns_salt[0] = (uint32_t)rd();
         c->ns_salt[1] = (uint32_t)rd();
     }
-    c->verify_fused = fused;
     c->dedup_levels = dedup_levels;
-    // diagnostics / A/B, read once per ctx (tools/sweep_verify.py): the deep tier's occupancy cap, serial tiers
-    if (const char* t = std::getenv("PHANT_HASH_LDS_KB")) {
-        const long kb = std::strtol(t, nullptr, 10);
-        // (on top of the hash kernels' 8 KiB of static LDS, and the list kernel is launched with 8 KiB more: the sum must stay
-        // within the 64 KiB a launch gets without opting in)
-        c->tune.hash_lds = (uint32_t)(kb < 0 ? 0 : kb > 47 ? 47 : kb) * 1024u;
-    }
-    if (const char* t = std::getenv("PHANT_VERIFY_SERIAL")) c->tune.serial = t[0] == '1';
-    // the shallow tier's form (A/B): one of the ordered forms instead of the group tables
-    c->tune.own_order = opts && (opts->flags & PHANT_CTX_VERIFY_ORDERED);
-    if (const char* t = std::getenv("PHANT_VERIFY_ORDERED")) c->tune.own_order = t[0] == '1';
-    c->tune.key_ordered = opts && (opts->flags & PHANT_CTX_VERIFY_KEY_ORDERED);
-    if (const char* t = std::getenv("PHANT_VERIFY_KEY_ORDERED")) c->tune.key_ordered = t[0] == '1';
-    // the S = 0 form's node-per-half-wave kernel (A/B): never / up to this many nodes
-    c->tune.no_coop = std::getenv("PHANT_VERIFY_NO_COOP") != nullptr;
-    c->tune.no_wave = std::getenv("PHANT_VERIFY_NO_WAVE") != nullptr;
-    if (const char* t = std::getenv("PHANT_VERIFY_COOP_MAX")) {
-        const long v = std::strtol(t, nullptr, 10);
-        c->tune.coop_max = (uint32_t)(v < 0 ? 0 : v > (1 << 20) ? (1 << 20) : v);
-    }
     DeviceGuard g(dev);
     if (!own) {
         c->stream = (hipStream_t)stream;  // nullptr = the default stream
@@ -234,11 +207,6 @@ int32_t phant_ctx_create(const phant_opts* opts, phant_ctx** out) {
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return PHANT_E_DEVICE;
     c->tune.last_shallow = &c->last_shallow;
     c->tune.last_form = &c->last_form;
-    if (c->tune.serial) {  // diagnostics: events around every kernel of a two-tier launch (phant_verify_kernel_ms)
-        for (hipEvent_t& e : c->kev)
-            if (hipEventCreate(&e) != hipSuccess) return PHANT_E_DEVICE;
-        c->tune.kernel_ev = c->kev;
-    }
     holder.c = nullptr;
     *out = c;
     return PHANT_OK;
@@ -268,7 +236,6 @@ void phant_ctx_destroy(phant_ctx* c) {
     if (c->side.stream2) (void)hipStreamSynchronize(c->side.stream2);
     if (c->side.fork) (void)hipEventDestroy(c->side.fork);
     if (c->side.join) (void)hipEventDestroy(c->side.join);
-    if (c->side.sorted) (void)hipEventDestroy(c->side.sorted);
     if (c->side.join2) (void)hipEventDestroy(c->side.join2);
     if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
     if (c->side.stream2) (void)hipStreamDestroy(c->side.stream2);
@@ -316,7 +283,7 @@ int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
         phant::verify_nodeset_stats_from_header(hdr, c->ns.epoch, hashed, nullptr);
         return PHANT_OK;
     }
-    if (c->verify_fused || !c->dv.base) return PHANT_OK;
+    if (!c->dv.base) return PHANT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->side.stream) HIP_TRY(c, hipStreamSynchronize(c->side.stream));
@@ -330,7 +297,7 @@ int32_t phant_verify_stats(phant_ctx* c, uint32_t hashed[8]) {
 int32_t phant_verify_tier_stats(phant_ctx* c, uint32_t out[5]) {
     if (!c || !out) return PHANT_E_INVALID_ARG;
     for (int i = 0; i < 5; ++i) out[i] = 0;
-    if (c->verify_fused || !c->dv.base) return PHANT_OK;
+    if (!c->dv.base) return PHANT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->side.stream) HIP_TRY(c, hipStreamSynchronize(c->side.stream));
@@ -343,14 +310,14 @@ int32_t phant_verify_tier_stats(phant_ctx* c, uint32_t out[5]) {
 
 int32_t phant_verify_form(phant_ctx* c, uint32_t* form) {
     if (!c || !form) return PHANT_E_INVALID_ARG;
-    *form = c->verify_fused ? 0u : c->last_form;
+    *form = c->last_form;
     return PHANT_OK;
 }
 
 int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
     if (!c || !out) return PHANT_E_INVALID_ARG;
     out[0] = out[1] = 0;
-    if (c->verify_fused || !c->dv.base) return PHANT_OK;
+    if (!c->dv.base) return PHANT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->side.stream) HIP_TRY(c, hipStreamSynchronize(c->side.stream));
@@ -362,7 +329,7 @@ int32_t phant_verify_path_stats(phant_ctx* c, uint32_t out[2]) {
 
 int32_t phant_verify_kernel_ms(phant_ctx* c, float ms[PHANT_VERIFY_KERNEL_STAGES]) {
     if (!c || !ms) return PHANT_E_INVALID_ARG;
-    if (!c->tune.kernel_ev) return fail(c, PHANT_E_UNSUPPORTED, "verify_kernel_ms: the ctx was not created under PHANT_VERIFY_SERIAL=1");
+    if (!c->tune.kernel_ev) return fail(c, PHANT_E_UNSUPPORTED, "verify_kernel_ms: the tiers are not serialised on this ctx (phant_diag_set: the verify-serial knob)");
     // (the events hold the LAST launch that recorded them: if the latest verify took the S = 0 form they are an earlier one's)
     if (!c->kev_valid) return fail(c, PHANT_E_INVALID_ARG, "verify_kernel_ms: the last verify launch on this ctx was not a two-tier one");
     DeviceGuard g(c->device);
@@ -385,6 +352,47 @@ int32_t phant_last_kernel_ms(phant_ctx* c, float* ms) {
     HIP_TRY(c, hipEventSynchronize(c->ev1));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     return PHANT_OK;
+}
+
+int32_t phant_diag_set(phant_ctx* c, uint32_t knob, int64_t value) {
+    if (!c) return PHANT_E_INVALID_ARG;
+    DeviceGuard g(c->device);
+    phant::TrieTune& t = c->ws.tune;
+    switch (knob) {
+        case PHANT_DIAG_VERIFY_SERIAL:
+            if (value && !c->tune.kernel_ev) {  // events around every stage of a two-tier launch (phant_verify_kernel_ms)
+                for (hipEvent_t& e : c->kev)
+                    if (!e) HIP_TRY(c, hipEventCreate(&e));
+                c->tune.kernel_ev = c->kev;
+            }
+            c->tune.serial = value != 0;
+            c->kev_valid = false;
+            return PHANT_OK;
+        case PHANT_DIAG_VERIFY_HASH_LDS_KB:
+            // (on top of the hash kernels' 8 KiB of static LDS, and the list kernel is launched with 8 KiB more: the sum must stay
+            // within the 64 KiB a launch gets without opting in)
+            c->tune.hash_lds = (uint32_t)(value < 0 ? 0 : value > 47 ? 47 : value) * 1024u;
+            return PHANT_OK;
+        case PHANT_DIAG_VERIFY_NO_COOP: c->tune.no_coop = value != 0; return PHANT_OK;
+        case PHANT_DIAG_VERIFY_NO_WAVE: c->tune.no_wave = value != 0; return PHANT_OK;
+        case PHANT_DIAG_VERIFY_COOP_MAX: c->tune.coop_max = (uint32_t)(value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : value); return PHANT_OK;
+        case PHANT_DIAG_STREAM_WGS: c->tune.diag_stream_wgs = (uint32_t)(value < 0 ? 0 : value > 65536 ? 65536 : value); return PHANT_OK;
+        case PHANT_DIAG_STREAM_MB: c->tune.diag_stream_mb = (uint32_t)(value < 0 ? 0 : value > 65536 ? 65536 : value); return PHANT_OK;
+        case PHANT_DIAG_TRIE_NO_SIDE: t.no_side = value != 0; return PHANT_OK;
+        case PHANT_DIAG_TRIE_SIDE_MIN_KEYS: t.side_min_keys = value; return PHANT_OK;
+        case PHANT_DIAG_TRIE_AHEAD_MAX_KEYS: t.ahead_max_keys = value; return PHANT_OK;
+        case PHANT_DIAG_TRIE_SIDE_LDS: t.side_lds = value; return PHANT_OK;
+        case PHANT_DIAG_TRIE_FALLBACK_GRID: t.fallback_grid = value; return PHANT_OK;
+        case PHANT_DIAG_TRIE_SLOT_BLOCKS: t.slot_blocks = (int32_t)value; return PHANT_OK;
+        case PHANT_DIAG_TRIE_NO_COOP: t.no_coop = value != 0; return PHANT_OK;
+        case PHANT_DIAG_TRIE_COOP_MAX: t.coop_max = value; return PHANT_OK;
+        case PHANT_DIAG_TRIE_NO_WAVE: t.no_wave = value != 0; return PHANT_OK;
+        case PHANT_DIAG_TRIE_JOIN_IN_STREAM: t.join_in_stream = value != 0; return PHANT_OK;
+        case PHANT_DIAG_SORT_NO_FALLBACK: t.sort_no_fallback = value != 0; return PHANT_OK;
+        case PHANT_DIAG_SORT_PREFIX_BITS: t.sort_prefix_bits = value; return PHANT_OK;
+        case PHANT_DIAG_SORT_REPAIR_BITS: t.sort_repair_bits = value; return PHANT_OK;
+        default: return fail(c, PHANT_E_INVALID_ARG, "diag_set: no such knob");
+    }
 }
 
 int32_t phant_nodeset_tune(phant_ctx* c, int32_t ladder, uint32_t order, uint32_t hash_lds_bytes, uint32_t resident_wgs) {
@@ -575,14 +583,13 @@ int32_t phant_sender_addresses(phant_ctx* c, const uint8_t* pubkeys, uint64_t st
 
 // helper stream + events of the two-tier pipeline (created on first use)
 static int32_t ensure_side(phant_ctx* c) {
-    const bool need = !c->verify_fused && c->dedup_levels != 0;
+    const bool need = c->dedup_levels != 0;
     if (!need || c->side.stream) return PHANT_OK;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming));
-    // (the ordered form: the group heads are hashed on a helper stream of their own, next to the comparison)
+    // (diagnostics, phant_verify_bound_experiment: the clean read stream runs on a helper stream of its own)
     HIP_TRY(c, hipStreamCreateWithFlags(&c->side.stream2, hipStreamNonBlocking));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->side.sorted, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->side.join2, hipEventDisableTiming));
     return PHANT_OK;
 }
@@ -593,15 +600,6 @@ static int32_t verify_resident_on(phant_ctx* c, const phant::VerifyArgs& a_in, u
                                   phant::DevArena& dv, const phant::FlatSide* side, bool timed) {
     phant::VerifyArgs a = a_in;
     a.total_nodes = total_nodes;
-    if (c->verify_fused) {
-        if (timed) {
-            TimedRegion t(c);
-            HIP_TRY(c, phant::launch_mpt_verify_fused(a, st));
-        } else {
-            HIP_TRY(c, phant::launch_mpt_verify_fused(a, st));
-        }
-        return PHANT_OK;
-    }
     const size_t need = phant::verify_workspace_bytes(total_nodes);
     if (need > dv.cap) {
         HIP_TRY(c, hipStreamSynchronize(st));
@@ -710,16 +708,9 @@ static int32_t verify_host_async(phant_ctx* c, hipStream_t s, phant::DevArena& i
     }
     if (d_fail_out) {
         *d_fail_out = d_fail;
-        if (c->verify_fused) {  // the one-lane-per-proof A/B kernel has no tail kernel to carry the verdict
-            const int32_t frc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
-            if (frc) return frc;
-            HIP_TRY(c, phant::launch_mpt_verdict(d_status, a.root_idx, n, n_roots, d_fail, s));
-        } else {
-            a.fail_count = d_fail;
-            const int32_t frc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
-            if (frc) return frc;
-        }
-    } else {
+        a.fail_count = d_fail;
+    }
+    {
         const int32_t vrc = verify_resident_on(c, a, total_nodes, s, dv, side, timed);
         if (vrc) return vrc;
     }
@@ -758,7 +749,7 @@ int32_t phant_verify_bound_experiment(phant_ctx* c, const uint8_t* d_roots, uint
                                       uint32_t n, uint8_t* d_status, uint32_t reps, float out_ms[3]) {
     if (!c || !out_ms || reps == 0) return PHANT_E_INVALID_ARG;
     out_ms[0] = out_ms[1] = out_ms[2] = 0.f;
-    if (c->verify_fused || c->tune.serial) return fail(c, PHANT_E_UNSUPPORTED, "bound_experiment: needs the two-tier pipeline with its tiers next to each other");
+    if (c->tune.serial) return fail(c, PHANT_E_UNSUPPORTED, "bound_experiment: needs the two tiers next to each other");
     if (((uintptr_t)d_nodes & 15u) != 0) return fail(c, PHANT_E_INVALID_ARG, "bound_experiment: the node blob must be 16-byte aligned");
     // one complete launch: its lists and counts are what the hashing-only launches below work from
     int32_t rc = phant_impl::phant_mpt_verify_batch_dev(c, d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len, d_node_off,
@@ -807,12 +798,6 @@ int32_t phant_mpt_verify_verdict_dev(phant_ctx* c, const uint8_t* d_roots, uint3
         return fail(c, PHANT_E_INVALID_ARG, "mpt_verify_verdict_dev: bad argument");
     phant::VerifyArgs a{d_roots, n_roots, d_root_idx, d_keys, key_len, d_nodes, nodes_len,
                         d_node_off, d_proof_first_node, n, d_status, d_value_off, d_value_len};
-    if (c->verify_fused) {  // the one-lane-per-proof A/B kernel has no tail kernel to carry the verdict
-        const int32_t rc = verify_resident(c, a, total_nodes);
-        if (rc) return rc;
-        HIP_TRY(c, phant::launch_mpt_verdict(d_status, d_root_idx, n, n_roots, d_fail_count, c->stream));
-        return PHANT_OK;
-    }
     a.fail_count = d_fail_count;
     return verify_resident(c, a, total_nodes);
 }

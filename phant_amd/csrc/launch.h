@@ -48,21 +48,21 @@ struct VerifyArgs {
                                      // beyond it is BAD_INPUT before node_off is touched (set by the launchers'
                                      // caller, capi.hip::verify_resident_on)
 };
-hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st);
 // Two-tier pipeline (mpt_verify_v3.hip): the trie levels that repeat across proofs are deduplicated (propose ->
-// dedup/compare -> class-sorted hashing of the distinct nodes), the deeper ones hashed in place next to that, then walk.
+// dedup -> class-sorted hashing of the distinct nodes), the deeper ones hashed in place next to that, then walk.
 // ws = verify_workspace_bytes().  dedup_levels: how many levels from the root are deduplicated; < 0 = chosen from the
-// batch size, 0 = hash every shipped node (A/B).  `side` (may be null): helper stream + events owned by the ctx; with
+// batch size, 0 = hash every shipped node.  `side` (may be null): helper stream + events owned by the ctx; with
 // it the deep tier runs NEXT TO the shallow tier (VALU-bound hashing beside a memory stream), without it in front.
 struct FlatSide {
     hipStream_t stream;       // non-blocking helper stream owned by the ctx: the deep tier
     hipEvent_t fork, join;    // timing-disabled events
-    // the ordered form's second helper stream: the group heads' hashing next to the comparison (null: on the ctx stream)
+    // diagnostics (phant_verify_bound_experiment): a second helper stream for the clean read stream
     hipStream_t stream2 = nullptr;
-    hipEvent_t sorted = nullptr, join2 = nullptr;
+    hipEvent_t join2 = nullptr;
 };
 size_t verify_workspace_bytes(uint32_t total_nodes);
-// The deep tier's occupancy cap and a diagnostics switch (fixed per ctx).
+// The deep tier's occupancy cap and the diagnostics switches (per ctx; set through include/phant_gpu_diag.h, never from the
+// environment).
 struct VerifyTune {
     // An otherwise unused dynamic LDS allocation per workgroup of the deep tier caps how many of them a CU holds
     // (160 KiB / (8 KiB + it)) WHILE the shallow tier's memory-bound kernels run next to it: 40 KiB -> 3 workgroups = 3 hash
@@ -73,27 +73,21 @@ struct VerifyTune {
     uint32_t* last_shallow = nullptr; // diagnostics: where the launcher notes the tier split it chose (phant_verify_tier_stats)
     hipEvent_t* kernel_ev = nullptr;  // diagnostics, with `serial`: VERIFY_KERNEL_STAGES + 1 events recorded around the stages of a
                                       // two-tier launch (phant_verify_kernel_ms)
-    // The shallow tier's form: the group tables, unless one of the ORDERED forms (key-bucketed neighbour comparison,
-    // mpt_verify_v3.hip) is asked for -- A/B, measured slower on this chip at every batch size (profiles/r5_explore/NOTES.md):
-    // own_order (PHANT_CTX_VERIFY_ORDERED): a batch against ONE root is ordered by the library's own counting sort;
-    // key_ordered (PHANT_CTX_VERIFY_KEY_ORDERED: the caller says the proofs are in (root index, key) order): any batch, on the
-    // caller's order as it is.
-    bool own_order = false;
-    bool key_ordered = false;
     uint32_t coop_max = 2048;      // S = 0 form: batches of up to this many nodes take the node-per-half-wave hash kernel
     bool no_coop = false;
     bool no_wave = false;  // (A/B: small S = 0 launches through the half-wave kernel, not the wave-per-node one)
-    uint32_t* last_form = nullptr; // diagnostics: 0 = S = 0, 1 = table form, 2 = ordered (own order), 3 = ordered (caller's order)
+    uint32_t* last_form = nullptr; // diagnostics: 0 = S = 0 (every shipped node hashed in place), 1 = two tiers
     // diagnostics (phant_verify_bound_experiment), on a workspace a complete launch over the same witness has just left: 1 = only
     // the hashing of that launch (deep tier + everything listed, next to each other), 2 = only a coalesced read of the witness's
     // bytes (a clean stream with next to no VALU), 3 = both next to each other -- what the chip can overlap at best
     uint32_t diag = 0;
     uint32_t* diag_sink = nullptr;  // device words the read stream leaves its checksum in (so that the loads are not dead)
+    uint32_t diag_stream_wgs = 0;   // the read stream's workgroups (0 = 2 048) and, != 0, the region in MB its index wraps in
+    uint32_t diag_stream_mb = 0;
 };
-// stages of a two-tier launch, in the order of phant_verify_kernel_ms: the order pass (table form: propose_kernel), hash_deep,
-// heads_kernel (table form: nothing), the hashing of list set 0 (the group heads; table form: everything listed), the
-// comparison (table form: dedup_kernel), the hashing of list set 1 (table form: nothing), the walk
-constexpr int VERIFY_KERNEL_STAGES = 7;
+// stages of a two-tier launch, in the order of phant_verify_kernel_ms: propose_kernel, hash_deep_kernel, dedup_kernel,
+// hash_list_kernel, walk_kernel
+constexpr int VERIFY_KERNEL_STAGES = 5;
 hipError_t launch_mpt_verify(const VerifyArgs& a, uint32_t total_nodes, uint8_t* ws, int32_t dedup_levels,
                              hipStream_t st, const FlatSide* side, const VerifyTune& tune);
 // nodes hashed per rate-block class by the last launch, from a host copy of the workspace's first

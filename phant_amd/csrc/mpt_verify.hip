@@ -1,25 +1,9 @@
-// mpt_verify.hip -- batched Merkle-Patricia proof verification.
-//
-// Kernel `mpt_verify_fused_kernel`: one lane per proof.  The lane hashes each
-// proof node with its sponge in registers (Keccak-256, hasher.zig:4-8), checks
-// the digest against the reference taken from the parent (or the state root),
-// decodes the node and follows the key -- the walk of DESIGN.md section 3.  No
-// intermediate digests go to HBM: per proof the kernel reads its nodes + key
-// once and writes one status byte (+ value location).
+// mpt_verify.hip -- the per-root verdict over a status array (phant_mpt_verdict_dev).  (The lane-per-proof verifier that used to
+// live here as an A/B form is gone from the product; its per-proof routine, mpt_verify_one.hip.h, is what the two-tier walk
+// falls back to for a proof whose node range overlaps another's.)
 #include "mpt_verify_one.hip.h"
 
 namespace phant {
-
-__global__ void __launch_bounds__(256) mpt_verify_fused_kernel(const VerifyArgs a) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.n) return;
-    uint64_t voff;
-    uint32_t vlen;
-    const uint32_t st = verify_one(a, i, voff, vlen);
-    a.status[i] = (uint8_t)st;
-    if (a.value_off) a.value_off[i] = voff;
-    if (a.value_len) a.value_len[i] = vlen;
-}
 
 // fail_count[r] += #proofs against root r that are not PRESENT/ABSENT.
 // Per-wave ballot first, then one atomic per (wave, root) -- with a single
@@ -39,13 +23,6 @@ mpt_verdict_kernel(const uint8_t* __restrict__ status, const uint32_t* __restric
         const uint32_t r = root_idx[i];
         atomicAdd(&fail_count[r < n_roots ? r : 0u], 1u);
     }
-}
-
-hipError_t launch_mpt_verify_fused(const VerifyArgs& a, hipStream_t st) {
-    if (a.n == 0) return hipSuccess;
-    const uint32_t grid = (a.n + 255u) / 256u;
-    hipLaunchKernelGGL(mpt_verify_fused_kernel, dim3(grid), dim3(256), 0, st, a);
-    return hipGetLastError();
 }
 
 hipError_t launch_mpt_verdict(const uint8_t* d_status, const uint32_t* d_root_idx, uint32_t n,

@@ -51,8 +51,6 @@
 //
 // What it computes: the verifier missing at src/engine_api/execution_payload.zig:177-178, over the node encodings of
 // src/mpt/mpt.zig:187-193,216-231,254-261,285-314.
-#include <cstdlib>
-
 #include <phant_platform.h>
 
 #include "launch.h"
@@ -78,15 +76,13 @@ constexpr uint32_t HDR_STAT = 1024;      // + 128 x buffer + 8 x stripe + class:
 constexpr uint32_t HDR_STAT_STRIPES = 16;
 constexpr uint32_t HDR_STAT_WORDS = HDR_STAT_STRIPES * N_CLASS;            // per buffer
 constexpr uint32_t HDR_STAT_END = HDR_STAT + 2u * HDR_STAT_WORDS;          // 1280
-constexpr uint32_t HDR_CUR = 256;        // + 256 x list set + 32 x stripe + class: the lists' counts (a 128-byte line per stripe)
-constexpr uint32_t LIST_SETS = 2;        // set 0: what the table form lists / the ordered form's group heads (known from the keys:
-                                         // hashed early); set 1: the ordered form's copies that differ (known after the comparison)
+constexpr uint32_t HDR_CUR = 256;        // + 32 x stripe + class: the lists' counts (a 128-byte line per stripe)
 constexpr uint32_t HDR_WORDS = 768;      // flags and cursors; the statistics behind them
 constexpr size_t HEADER_BYTES = 8192;
 static_assert(HDR_STAT_END <= VERIFY_HEADER_WORDS && 4u * VERIFY_HEADER_WORDS <= HEADER_BYTES,
               "capi.hip copies VERIFY_HEADER_WORDS words back for the statistics");
 
-PHANT_DEV uint32_t cursor_word(uint32_t cls, uint32_t stripe, uint32_t set = 0u) { return HDR_CUR + 256u * set + 32u * stripe + cls; }
+PHANT_DEV uint32_t cursor_word(uint32_t cls, uint32_t stripe) { return HDR_CUR + 32u * stripe + cls; }
 
 
 
@@ -142,15 +138,6 @@ struct Args {
     uint32_t* rep;           // total_nodes; written for the shallow tier's nodes
     uint2* ent;              // N_LIST x STRIPES x stripe_cap: {node, owner proof} to hash, per list and stripe
     uint32_t stripe_cap;     // entries per (class, stripe) = lanes of the workgroups that append there
-    // the ordered form (key-bucketed neighbour comparison instead of the group tables)
-    uint2* ent2;             // list set 1, N_LIST x STRIPES x stripe_cap2
-    uint32_t stripe_cap2;
-    const struct PosInfo* pos;  // n records: what the ordered form needs to know about the proof at position i of the order
-    const uint32_t* bstart;  // buckets + 1: first position of bucket b (ord given)
-    uint32_t bucket_bits;    // a proof's bucket = the top bucket_bits bits of its key (ord given)
-    uint4* leafres;          // total_nodes: for the LAST node j of a proof {status or LEAF_NONE, value_len, value_off lo, hi}: what the
-                             // walk ends in if every node in front of j turns out to be a canonical full branch whose hash matches
-                             // (leaf_kernel; read by walk_kernel<.., true>)
     uint32_t* hdr;           // header: HDR_*; cleared per call (propose_kernel / zero_kernel)
     uint32_t* digest;        // total_nodes x 8
     uint8_t* nstat;          // total_nodes: NS_* of the node, written by the lane that hashed it
@@ -269,9 +256,6 @@ PHANT_DEV bool entry_matches(const Args& a, uint64_t en, const ShallowLane& L, u
 // where entry `at` of list (class, stripe) lives
 PHANT_DEV uint64_t ent_index(const Args& a, uint32_t cls, uint32_t stripe, uint32_t at) {
     return ((uint64_t)cls * STRIPES + stripe) * a.stripe_cap + at;
-}
-PHANT_DEV uint64_t ent2_index(const Args& a, uint32_t cls, uint32_t stripe, uint32_t at) {
-    return ((uint64_t)cls * STRIPES + stripe) * a.stripe_cap2 + at;
 }
 
 // all 64 lanes: are the `len` bytes at x and y equal?  16 bytes per lane per step.
@@ -426,382 +410,6 @@ __global__ void __launch_bounds__(256) PHANT_NUM_VGPR(48) dedup_kernel(const Arg
 }
 
 
-// ================================================================ the shallow tier, ORDERED form
-// The table form above finds a group's representative through a table slot and reads every representative a second time.
-// When the proofs are visited in the order of their (root, key prefix), the members of a group are NEIGHBOURS: a copy is
-// compared with the node the wave has just streamed, every copy passes through the memory path once, and which nodes head a
-// group -- and will have to be hashed whatever the comparison says -- is known from the keys alone, before a single node byte
-// is read: their hashing starts at once (list set 0, hash_list_kernel on a helper stream) NEXT TO the comparison, and what is
-// left behind the comparison are the copies that differ (list set 1: damaged nodes and their successors).
-//
-//   one root (the state trie): the library orders the proofs itself -- a counting sort on the top 4 (S - 1) key bits:
-//        order_hist_kernel (also the launch's clearing kernel) -> order_scan_kernel -> order_scatter_kernel
-//   several roots: only when the caller says the batch IS in (root, key) order (PHANT_CTX_VERIFY_KEY_ORDERED); otherwise the
-//        table form.  Nothing is trusted about that claim: an unordered batch only loses deduplication.
-//   heads_kernel     lane = (position, level): lists what the keys alone say must be hashed -- nodes that take no part in the
-//                    deduplication (single-block nodes, oversized ones) and KEY HEADS: the first position of a run of equal
-//                    (root, level, key prefix); without an order of the library's own also the first position of every chunk.
-//   compare_kernel   wave = (chunk of 63 consecutive positions, level).  Lane l >= 1 fetches what describes position
-//                    63 chunk + l - 1 (proof, node offsets, key prefix); lane 0 the node the chunk's first run continues: the
-//                    key head of its group, found through the bucket table.  Then the wave streams the 64 nodes one after the
-//                    other, 12 bytes per lane: a node that does not open a run is compared with the run's REFERENCE (in
-//                    registers: the key head, or the last copy that differed); equal => rep[] = the reference's node, never
-//                    hashed; different => listed (set 1) and the new reference: a damaged head costs its group one extra hash
-//                    per chunk, a damaged copy two.
-// Soundness is the table form's: rep[j] = r != j only if r is a node of j's group (same root, level and key prefix, checked
-// on the keys, not taken from the order) and bytes(j) == bytes(r), compared byte for byte; every r is listed -- by
-// heads_kernel when it is a key head (the same rule, evaluated on the same keys), by compare_kernel itself otherwise.
-constexpr uint32_t CHUNK = 63;            // positions per comparison wave (lane 0 carries the first run's reference)
-constexpr uint32_t CMP_MAX_LEN = 768;     // 64 lanes x 12 bytes: longer nodes take no part (a branch is at most 532 + its value)
-constexpr uint32_t ORDER_MAX_BITS = 16;   // buckets <= 65 536: the scan is one launch (levels beyond 4 nibbles: see the launcher)
-constexpr uint32_t SCAN_TILE = 2048;
-
-PHANT_DEV uint32_t bucket_of(uint64_t kb, uint32_t bits) { return bits ? (uint32_t)(kb >> (64u - bits)) : 0u; }
-
-// What the kernels of the ordered form need to know about the proof at a position, in ONE 32-byte record per position: written
-// once by a lane that reads its proof's entries of the caller's arrays coalesced, read by consecutive lanes for consecutive
-// positions -- instead of every (position, level) lane of two kernels gathering the same five arrays through the order.
-struct PosInfo {
-    uint32_t p;      // the proof
-    uint32_t first;  // its first node
-    uint32_t end;    // its nodes a walk can reach (d < end: node first + d exists and is reachable); POS_BROKEN: the node range goes backwards
-    uint32_t root;   // its root index
-    uint32_t kb_lo, kb_hi;  // its first 8 key bytes, big-endian
-    uint32_t pad[2];
-};
-static_assert(sizeof(PosInfo) == 32, "two 16-byte loads");
-constexpr uint32_t POS_BROKEN = 0xffffffffu;
-PHANT_DEV PosInfo pos_info_of(const Args& a, uint32_t p, uint64_t kb) {
-    PosInfo r;
-    r.p = p;
-    r.first = 0;
-    r.end = 0;
-    r.root = a.v.root_idx ? a.v.root_idx[p] : 0u;
-    r.kb_lo = (uint32_t)kb;
-    r.kb_hi = (uint32_t)(kb >> 32);
-    r.pad[0] = r.pad[1] = 0u;
-    const uint32_t first = a.v.proof_first_node[p], last = a.v.proof_first_node[p + 1];
-    if (last < first) {
-        r.end = POS_BROKEN;
-    } else if (last <= a.total_nodes) {  // (beyond: BAD_INPUT, the walk reports it)
-        const uint32_t nn = 2u * a.v.key_len, cnt = last - first;
-        r.first = first;
-        r.end = cnt <= nn ? cnt : nn + 1u;  // (a walk consumes >= one nibble per hashed node)
-    }
-    return r;
-}
-PHANT_DEV void store_pos_info(PosInfo* dst, const PosInfo& r) {
-    uint4* o = reinterpret_cast<uint4*>(dst);
-    o[0] = make_uint4(r.p, r.first, r.end, r.root);
-    o[1] = make_uint4(r.kb_lo, r.kb_hi, 0u, 0u);
-}
-PHANT_DEV PosInfo load_pos_info(const PosInfo* src) {
-    const uint4* i = reinterpret_cast<const uint4*>(src);
-    const uint4 x = i[0], y = i[1];
-    PosInfo r;
-    r.p = x.x; r.first = x.y; r.end = x.z; r.root = x.w;
-    r.kb_lo = y.x; r.kb_hi = y.y;
-    r.pad[0] = r.pad[1] = 0u;
-    return r;
-}
-PHANT_DEV uint64_t kb_of(const PosInfo& r) { return ((uint64_t)r.kb_hi << 32) | r.kb_lo; }
-
-// one lane per proof: how many proofs per bucket (bcnt zeroed by the launcher); the launch's clearing kernel
-__global__ void __launch_bounds__(256) order_hist_kernel(const Args a, uint32_t* bcnt) {
-    beside_the_hashing();
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    clear_launch_state(a, p, (size_t)gridDim.x * 256u);
-    if (p >= a.v.n) return;
-    atomicAdd(&bcnt[bucket_of(key_prefix64_wide(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len), a.bucket_bits)], 1u);
-}
-
-// bstart[b] = bcur[b] = proofs in buckets < b; bstart[buckets] = n.  Two launches: the tiles' sums (2 048 buckets per
-// workgroup), then every tile's own scan on top of the sums in front of it (<= 32 of them: one load, one wave sum).
-__global__ void __launch_bounds__(256) order_sums_kernel(const uint32_t* __restrict__ bcnt, uint32_t* __restrict__ sums, uint32_t buckets) {
-    __shared__ uint32_t s_wave[4];
-    beside_the_hashing();
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t at = blockIdx.x * SCAN_TILE + 8u * tid;
-    uint32_t mine = 0;
-    if (at + 8u <= buckets) {
-        const uint4 x = *reinterpret_cast<const uint4*>(bcnt + at), y = *reinterpret_cast<const uint4*>(bcnt + at + 4u);
-        mine = x.x + x.y + x.z + x.w + y.x + y.y + y.z + y.w;
-    } else {
-        for (uint32_t k = 0; k < 8u; ++k) mine += at + k < buckets ? bcnt[at + k] : 0u;
-    }
-    for (uint32_t o = 1; o < 64u; o <<= 1) {
-        const uint32_t up = __shfl_up(mine, o, 64);
-        if (lane >= o) mine += up;
-    }
-    if (lane == 63u) s_wave[wave] = mine;
-    __syncthreads();
-    if (tid == 0) sums[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-}
-__global__ void __launch_bounds__(256) order_scan_kernel(const uint32_t* __restrict__ bcnt, const uint32_t* __restrict__ sums,
-                                                         uint32_t* __restrict__ bstart, uint32_t* __restrict__ bcur, uint32_t buckets, uint32_t n) {
-    __shared__ uint32_t s_wave[4];
-    beside_the_hashing();
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    static_assert((1u << ORDER_MAX_BITS) / SCAN_TILE <= 64u, "the tiles in front of one fit a wave");
-    uint32_t before = lane < blockIdx.x ? sums[lane] : 0u;  // (every wave: no barrier for it)
-    for (uint32_t o = 1; o < 64u; o <<= 1) {
-        const uint32_t up = __shfl_up(before, o, 64);
-        if (lane >= o) before += up;
-    }
-    before = (uint32_t)__shfl((int)before, 63, 64);
-    uint32_t v[8];
-    const uint32_t at = blockIdx.x * SCAN_TILE + 8u * tid;
-    if (at + 8u <= buckets) {
-        const uint4 x = *reinterpret_cast<const uint4*>(bcnt + at), y = *reinterpret_cast<const uint4*>(bcnt + at + 4u);
-        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-    } else {
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) v[k] = at + k < buckets ? bcnt[at + k] : 0u;
-    }
-    uint32_t mine = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k) mine += v[k];
-    uint32_t inc = mine;
-    for (uint32_t o = 1; o < 64u; o <<= 1) {
-        const uint32_t up = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += up;
-    }
-    if (lane == 63u) s_wave[wave] = inc;
-    __syncthreads();
-    uint32_t run = before + inc - mine;
-    for (uint32_t w = 0; w < wave; ++w) run += s_wave[w];
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k) {
-        if (at + k < buckets) {
-            bstart[at + k] = run;
-            bcur[at + k] = run;
-        }
-        run += v[k];
-    }
-    if (blockIdx.x == 0 && tid == 0) bstart[buckets] = n;
-}
-
-// one lane per proof: its position in the order, and the position's record
-__global__ void __launch_bounds__(256) order_scatter_kernel(const Args a, uint32_t* bcur, PosInfo* pos) {
-    beside_the_hashing();
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= a.v.n) return;
-    const uint64_t kb = key_prefix64_wide(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len);
-    const PosInfo r = pos_info_of(a, p, kb);
-    store_pos_info(pos + atomicAdd(&bcur[bucket_of(kb, a.bucket_bits)], 1u), r);
-}
-
-// the caller's order taken as it is (no order pass): position = proof.  Also the launch's clearing kernel.
-__global__ void __launch_bounds__(256) order_identity_kernel(const Args a, PosInfo* pos) {
-    beside_the_hashing();
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    clear_launch_state(a, p, (size_t)gridDim.x * 256u);
-    if (p >= a.v.n) return;
-    store_pos_info(pos + p, pos_info_of(a, p, key_prefix64_wide(a.v.keys + (uint64_t)a.v.key_len * p, a.v.key_len)));
-}
-
-// (root, first d key nibbles) of two proofs equal?  (the key prefixes zero-padded: key_len is one per batch)
-PHANT_DEV bool same_key_group(uint32_t root_x, uint64_t kb_x, uint32_t root_y, uint64_t kb_y, uint32_t d) {
-    return root_x == root_y && same_prefix(kb_x, kb_y, d);
-}
-// Does position i open a run at level d?  The rule both kernels of the ordered form evaluate, on the keys alone.
-// `me`, `prev`: the records of positions i and i - 1 (prev: anything for i = 0).
-PHANT_DEV bool key_head(const Args& a, uint32_t i, uint32_t d, const PosInfo& me, const PosInfo& prev) {
-    if (i == 0u) return true;
-    if (!a.bstart && i % CHUNK == 0u) return true;  // (no bucket table to find a run's head through: every chunk opens its own)
-    return !same_key_group(prev.root, kb_of(prev), me.root, kb_of(me), d);
-}
-// the node of level d of the proof at a position, as shallow_node() describes it
-PHANT_DEV ShallowLane ordered_node(const Args& a, const PosInfo& r, uint32_t d) {
-    ShallowLane L;
-    L.p = r.p;
-    L.d = d;
-    L.j = 0;
-    L.root = r.root;
-    L.len = 0;
-    L.kb = kb_of(r);
-    L.act = L.valid = L.group = false;
-    L.broken = r.end == POS_BROKEN && d == 0u;
-    if (r.end == POS_BROKEN || d >= r.end) return L;
-    L.act = true;
-    L.j = r.first + d;
-    const uint64_t e = a.v.node_off[L.j + 1], b = a.v.node_off[L.j];
-    if (e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull) {
-        L.valid = true;
-        L.len = (uint32_t)(e - b);
-    }
-    L.group = L.valid && L.len >= RATE && L.root < a.v.n_roots;
-    return L;
-}
-
-// appends the lanes' nodes (cls != CLASS_NONE) to the class lists of `set`, compacted over the workgroup: one reservation per
-// workgroup and class on the cursor of the workgroup's stripe
-template <uint32_t SET>
-PHANT_DEV void list_append(const Args& a, uint32_t cls, uint32_t j, uint32_t owner, uint32_t (&s_cnt)[4][N_LIST], uint32_t (&s_base)[N_LIST]) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t my_rank = 0;
-    __syncthreads();  // (s_cnt cleared by the caller at the kernel's head)
-    unsigned long long todo = __ballot(cls != CLASS_NONE);
-    while (todo) {
-        const uint32_t c0 = lane_u32(cls, (uint32_t)__builtin_ctzll(todo));
-        const unsigned long long m = __ballot(cls == c0);
-        if (lane == 0) s_cnt[wave][c0] = (uint32_t)__popcll(m);
-        if (cls == c0) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        todo &= ~m;
-    }
-    __syncthreads();
-    const uint32_t stripe = blockIdx.x % STRIPES;
-    if (tid < N_LIST) {
-        uint32_t tot = 0;
-        for (uint32_t w = 0; w < 4u; ++w) tot += s_cnt[w][tid];
-        s_base[tid] = tot ? atomicAdd(&a.hdr[cursor_word(tid, stripe, SET)], tot) : 0u;
-    }
-    __syncthreads();
-    if (cls != CLASS_NONE) {
-        uint32_t at = s_base[cls] + my_rank;
-        for (uint32_t w = 0; w < wave; ++w) at += s_cnt[w][cls];
-        if (SET == 0u) a.ent[ent_index(a, cls, stripe, at)] = make_uint2(j, owner);
-        else a.ent2[ent2_index(a, cls, stripe, at)] = make_uint2(j, owner);
-    }
-}
-
-PHANT_DEV bool takes_part(const ShallowLane& L) { return L.group && L.len <= CMP_MAX_LEN; }
-
-// lane = (position, level), as the table form's lanes: consecutive lanes = consecutive nodes of one proof
-__global__ void __launch_bounds__(256) heads_kernel(const Args a) {
-    __shared__ uint32_t s_cnt[4][N_LIST];
-    __shared__ uint32_t s_base[N_LIST];
-    beside_the_hashing();
-    const uint32_t tid = threadIdx.x;
-    if (tid < 4u * N_LIST) (&s_cnt[0][0])[tid] = 0u;
-    const uint32_t g = blockIdx.x * 256u + tid;
-    const uint32_t i = g / a.shallow, d = g - i * a.shallow;
-    uint32_t cls = CLASS_NONE, j = 0, p = 0;
-    if (i < a.v.n) {
-        const PosInfo me = load_pos_info(a.pos + i), prev = load_pos_info(a.pos + (i ? i - 1u : 0u));
-        p = me.p;
-        const ShallowLane L = ordered_node(a, me, d);
-        j = L.j;
-        if (L.act && L.valid && (!takes_part(L) || key_head(a, i, d, me, prev))) cls = node_list(L.len);
-    }
-    list_append<0>(a, cls, j, p, s_cnt, s_base);
-}
-
-// wave = (chunk, level); see the head of this section
-__global__ void __launch_bounds__(256) PHANT_NUM_VGPR(64) compare_kernel(const Args a, const uint32_t chunks) {
-    __shared__ uint32_t s_cnt[4][N_LIST];
-    __shared__ uint32_t s_base[N_LIST];
-    beside_the_hashing();
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    if (tid < 4u * N_LIST) (&s_cnt[0][0])[tid] = 0u;
-    const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (tid >> 6));
-    const uint32_t chunk = unit / a.shallow, d = unit - chunk * a.shallow;
-    // the lane's position; lane 0 looks at lane 1's: it carries the node that position's run continues, if it is not a head itself
-    const uint32_t i = chunk * CHUNK + (lane ? lane - 1u : 0u);
-
-    // ---- what the lane's position is: meta = len (<= 768) | takes part | opens a run ----
-    enum : uint32_t { M_LEN = 0xffffu, M_PART = 1u << 16, M_HEAD = 1u << 17 };
-    uint32_t meta = 0, j = 0, p = 0, len = 0;
-    uint64_t b = 0;
-    bool real = false, act = false;
-    if (chunk < chunks && i < a.v.n) {
-        const PosInfo me = load_pos_info(a.pos + i), prev = load_pos_info(a.pos + (i ? i - 1u : 0u));
-        const ShallowLane L = ordered_node(a, me, d);
-        p = me.p;
-        j = L.j;
-        len = L.len;
-        if (key_head(a, i, d, me, prev)) meta |= M_HEAD;
-        if (takes_part(L)) {
-            meta |= M_PART | L.len;
-            b = a.v.node_off[j];
-        }
-        if (lane >= 1u) {
-            real = true;
-            act = L.act;
-            if (L.broken) a.hdr[HDR_PFN_BROKEN] = 1u;  // (node ranges of other proofs may overlap: the walk trusts nothing then)
-            if (L.act && !L.valid) a.nstat[j] = 0u;     // never hashed: says so (nobody else writes this node's state)
-        } else {
-            // the key head of position 1's group, through the bucket table
-            const bool wanted = a.bstart && (meta & M_PART) && !(meta & M_HEAD) && 4u * d <= a.bucket_bits;
-            meta = 0;
-            if (wanted) {
-                const uint32_t sh = a.bucket_bits - 4u * d;
-                const uint32_t gs = a.bstart[(bucket_of(L.kb, a.bucket_bits) >> sh) << sh];
-                if (gs < i) {  // (in front of this chunk: a head inside it is met on the way)
-                    const PosInfo h = load_pos_info(a.pos + gs), hprev = load_pos_info(a.pos + (gs ? gs - 1u : 0u));
-                    const ShallowLane H = ordered_node(a, h, d);
-                    // usable only if it is what heads_kernel lists: a node that takes part, of this group, opening its run
-                    if (takes_part(H) && same_key_group(H.root, H.kb, L.root, L.kb, d) && key_head(a, gs, d, h, hprev)) {
-                        meta = M_PART | M_HEAD | H.len;
-                        j = H.j;
-                        b = a.v.node_off[j];
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- the stream: node by node, 12 bytes per lane, two trips of four loads in flight ----
-    const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32);
-    const uint32_t off12 = 12u * lane;
-    uint32_t my_ref = 64u;  // the lane whose node this lane's node is a copy of (64: none)
-    bool late = false;      // differs from its run's reference (or found none): to be hashed, says this kernel
-    const unsigned long long parts = __ballot((meta & M_PART) != 0u);
-    if (parts) {
-        const uint32_t last = 63u - (uint32_t)__builtin_clzll(parts);  // (nothing to do behind the last node that takes part)
-        U32x3 ref{0u, 0u, 0u};
-        uint32_t ref_len = 0, ref_lane = 64u;
-        auto fetch = [&](uint32_t l) __attribute__((always_inline)) -> U32x3 {
-            const uint32_t m = lane_u32(meta, l);
-            const bool part = (m & M_PART) != 0u;
-            const uint32_t ln = part ? (m & M_LEN) : 12u;                 // (a node that takes no part: the blob's first bytes,
-            const uint64_t base = part ? lane_u64(b_lo, b_hi, l) : 0ull;  //  readable because some node of >= 136 bytes exists)
-            const uint32_t o = off12 < ln - 12u ? off12 : ln - 12u;       // (lanes behind the node's end repeat its last 12 bytes)
-            return *reinterpret_cast<const U32x3*>(a.v.nodes + base + o);
-        };
-        auto step = [&](uint32_t l, const U32x3& cur) __attribute__((always_inline)) {
-            const uint32_t m = lane_u32(meta, l);
-            if (m & M_HEAD) ref_lane = 64u;  // a run ends here, whatever this node is
-            if (!(m & M_PART)) return;
-            const uint32_t ln = m & M_LEN;
-            bool same = false;
-            if (ref_lane < 64u && ln == ref_len) {
-                uint32_t diff = cur.x ^ ref.x;
-                diff = __builtin_amdgcn_bitop3_b32(cur.y, ref.y, diff, 0xBE);  // acc | (x ^ y)
-                diff = __builtin_amdgcn_bitop3_b32(cur.z, ref.z, diff, 0xBE);
-                same = __ballot(diff != 0u) == 0ull;
-            }
-            if (same) {
-                if (lane == l) my_ref = ref_lane;
-            } else {
-                if (!(m & M_HEAD) && lane == l) late = true;
-                ref = cur;
-                ref_len = ln;
-                ref_lane = l;
-            }
-        };
-        constexpr uint32_t U = 4;
-        U32x3 A[U], B[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) A[u] = fetch(u);
-        for (uint32_t t = 0; t <= last; t += 2u * U) {
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) B[u] = fetch((t + U + u) & 63u);
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) step(t + u, A[u]);
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) A[u] = fetch((t + 2u * U + u) & 63u);
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) step(t + U + u, B[u]);
-        }
-    }
-    // ---- results: the representative of every node, and what is left to hash ----
-    const uint32_t rj = (uint32_t)__shfl((int)j, (int)(my_ref & 63u), 64);
-    if (real && act) a.rep[j] = my_ref < 64u ? rj : j;
-    list_append<1>(a, (real && late) ? node_list(len) : CLASS_NONE, j, p, s_cnt, s_base);
-}
-
-
 // Where the 32 bytes node j must hash to are (nullptr: not known without decoding the parent).  `d`: index of the
 // node in its proof, `root`: the proof's root index, `nib_parent`: the key nibble at depth d - 1 (or >= 16: none),
 // `b`: byte offset of node j.  The parent of node j is node j - 1 = bytes [node_off[j-1], b); if that is 532 bytes
@@ -839,13 +447,12 @@ PHANT_DEV void store_node_digest(const Args& a, uint32_t j, const Sponge& s) {
 // ---------------------------------------------------------------- hash: the list role
 
 // -> false: no chunk q (the queue is shorter)
-template <uint32_t SET>
 PHANT_DEV bool list_role(const Args& a, uint32_t q, const uint32_t lane) {
     // which list chunk q is in: every lane reads the count of a list (two: there are 72), one prefix sum over the wave
     // (72 dependent scalar loads per wave cost 12 us -- every wave of the grid, the real ones included)
     static_assert(N_QUEUE > 64u && N_QUEUE <= 128u, "two lists per lane");
-    const uint32_t cnt_a = a.hdr[cursor_word(queue_class(lane), lane % STRIPES, SET)];
-    const uint32_t cnt_b = lane + 64u < N_QUEUE ? a.hdr[cursor_word(queue_class(lane + 64u), (lane + 64u) % STRIPES, SET)] : 0u;
+    const uint32_t cnt_a = a.hdr[cursor_word(queue_class(lane), lane % STRIPES)];
+    const uint32_t cnt_b = lane + 64u < N_QUEUE ? a.hdr[cursor_word(queue_class(lane + 64u), (lane + 64u) % STRIPES)] : 0u;
     const uint32_t ch_a = (cnt_a + 63u) / 64u, ch_b = (cnt_b + 63u) / 64u;
     const uint32_t incl_a = wave_inclusive_scan(ch_a, lane);
     uint32_t li, before, cnt;
@@ -867,7 +474,7 @@ PHANT_DEV bool list_role(const Args& a, uint32_t q, const uint32_t lane) {
     const uint32_t cls = queue_class(li), stripe = li % STRIPES;
     uint32_t idx = (q - before) * 64u + lane;
     idx = idx < cnt ? idx : cnt - 1u;
-    const uint2 en = SET == 0u ? a.ent[ent_index(a, cls, stripe, idx)] : a.ent2[ent2_index(a, cls, stripe, idx)];
+    const uint2 en = a.ent[ent_index(a, cls, stripe, idx)];
     const uint32_t j = en.x;
     const uint8_t* const safe_end = a.v.nodes + a.v.nodes_len;
     const uint64_t b = a.v.node_off[j];
@@ -1217,77 +824,12 @@ __global__ void __launch_bounds__(256) hash_wave_kernel(const Args a, const uint
     for (uint32_t d = level; d < count; d += levels) wave_node(a, c, l, p, first + d, d, root, stat_word);
 }
 
-// SET: which of the two list sets (the ordered form hashes its group heads -- set 0 -- next to the comparison and what the
-// comparison leaves -- set 1 -- behind it)
-template <uint32_t SET>
 __global__ void __launch_bounds__(256, 4) hash_list_kernel(const Args a) {
     // On the critical path (propose -> dedup -> this -> walk) with fewer waves than the chip has SIMDs, four permutations in
     // a row each, while the deep tier's waves, which are many and in nobody's way, compete for the same issue slots: go first.
     __builtin_amdgcn_s_setprio(2);
-    uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (SET == 0u) {
-        (void)list_role<SET>(a, q, threadIdx.x & 63u);  // (the grid covers the worst case, the dispatcher keeps every SIMD full)
-    } else {
-        // set 1 is short (the copies that differ): a bounded grid whose waves stride over the queue
-        while (list_role<SET>(a, q, threadIdx.x & 63u)) q += gridDim.x * 4u;
-    }
-}
-
-// What the comparison of the ordered form left (list set 1: copies that differ, and their successors).  Few: a node per HALF
-// WAVE then (four sequential permutations at the shared sponge's ~6 us instead of a lane's ~9-11: this kernel sits between the
-// comparison and the walk, on the launch's critical chain); a witness with much damage is hashed a lane per node as any list.
-__global__ void __launch_bounds__(256) hash_late_kernel(const Args a) {
-    __builtin_amdgcn_s_setprio(2);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    // the 72 lists' counts, as list_role reads them; entry e of the queue = entry (e - before) of its list
-    static_assert(N_QUEUE > 64u && N_QUEUE <= 128u, "two lists per lane");
-    const uint32_t cnt_a = a.hdr[cursor_word(queue_class(lane), lane % STRIPES, 1u)];
-    const uint32_t cnt_b = lane + 64u < N_QUEUE ? a.hdr[cursor_word(queue_class(lane + 64u), (lane + 64u) % STRIPES, 1u)] : 0u;
-    const uint32_t incl_a = wave_inclusive_scan(cnt_a, lane);
-    const uint32_t incl_b = lane_u32(incl_a, 63u) + wave_inclusive_scan(cnt_b, lane);
-    const uint32_t total = lane_u32(incl_b, 63u);
-    if (total > COOP_MAX_NODES) {
-        uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (tid >> 6));
-        while (list_role<1>(a, q, lane)) q += gridDim.x * 4u;
-        return;
-    }
-    const uint32_t l = tid & 31u, base = tid & 32u;
-    static_assert(COOP_MAX_NODES <= 2048u, "a wave per SIMD at most on this path");
-    const CoopLane c = coop_lane(l, base, true);
-    for (uint32_t h0 = (blockIdx.x * 4u + (tid >> 6)) * 2u;; h0 += gridDim.x * 8u) {  // (h0: the wave's first half's entry)
-        if (h0 >= total) break;
-        const uint32_t e = h0 + (base >> 5);
-        // which list: the first one whose inclusive count exceeds e (wave-wide search, each half for its own entry)
-        const uint32_t e0 = h0, e1 = h0 + 1u;
-        const unsigned long long a0 = __ballot(e0 < incl_a), b0 = __ballot(e0 < incl_b);
-        const unsigned long long a1 = __ballot(e1 < incl_a), b1 = __ballot(e1 < incl_b);
-        const unsigned long long ma = base ? a1 : a0, mb = base ? b1 : b0;
-        const bool present = e < total;
-        uint32_t li = 0, before = 0;
-        {
-            // (readlane wants a wave-uniform index: both halves' candidates are fetched, each half keeps its own)
-            const uint32_t la0 = a0 ? (uint32_t)__builtin_ctzll(a0) : 0u, lb0 = b0 ? (uint32_t)__builtin_ctzll(b0) : 0u;
-            const uint32_t la1 = a1 ? (uint32_t)__builtin_ctzll(a1) : 0u, lb1 = b1 ? (uint32_t)__builtin_ctzll(b1) : 0u;
-            const uint32_t bef_a0 = lane_u32(incl_a, la0) - lane_u32(cnt_a, la0), bef_b0 = lane_u32(incl_b, lb0) - lane_u32(cnt_b, lb0);
-            const uint32_t bef_a1 = lane_u32(incl_a, la1) - lane_u32(cnt_a, la1), bef_b1 = lane_u32(incl_b, lb1) - lane_u32(cnt_b, lb1);
-            if (ma) {
-                li = base ? la1 : la0;
-                before = base ? bef_a1 : bef_a0;
-            } else if (mb) {
-                li = 64u + (base ? lb1 : lb0);
-                before = base ? bef_b1 : bef_b0;
-            }
-        }
-        uint32_t j = 0, owner = 0, d = 0, root = 0;
-        if (present) {
-            const uint2 en = a.ent2[ent2_index(a, queue_class(li), li % STRIPES, e - before)];
-            j = en.x;
-            owner = en.y;
-            d = j - a.v.proof_first_node[owner];
-            root = a.v.root_idx ? a.v.root_idx[owner] : 0u;
-        }
-        coop_node(a, c, l, base, present, owner, j, d, root, NO_STAT);
-    }
+    const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    (void)list_role(a, q, threadIdx.x & 63u);  // (the grid covers the worst case, the dispatcher keeps every SIMD full)
 }
 
 // ---------------------------------------------------------------- walk
@@ -1306,69 +848,8 @@ PHANT_DEV uint32_t code_of(uint32_t ns, bool has_nibble) {
 }
 
 
-// ---- the leaf, decoded ahead of time ----
-// What a proof's walk does once the hashes are known is all but fixed for a well-formed witness: step over the full branches, decode
-// the LAST node -- ~100 dependent byte reads of RLP and hex-prefix -- and compare the rest of the key.  That decoding needs nothing the
-// pipeline computes: leaf_kernel does it when the launch starts, next to everything else, for the case that every node in front of
-// the last one is stepped over (pos = nodes - 1 nibbles consumed), and the walk, at the end of the launch's critical chain, only looks
-// at node states and takes the prepared result -- or does it all itself when the proof turns out to be anything else.
-constexpr uint32_t LEAF_NONE = 0xffu;
-constexpr uint32_t LEAF_LANES = 256;
-__global__ void __launch_bounds__(LEAF_LANES) leaf_kernel(const Args a) {
-    __shared__ uint32_t s_stage[LEAF_LANES * WALK_SLOT_DW];
-    beside_the_hashing();
-    const uint32_t i = blockIdx.x * LEAF_LANES + threadIdx.x;
-    if (i >= a.v.n) return;
-    const uint32_t first = a.v.proof_first_node[i], last = a.v.proof_first_node[i + 1];
-    if (last <= first || last > a.total_nodes) return;  // (nothing to prepare: the walk settles these itself)
-    const uint32_t j = last - 1u, cnt = last - first, nn = 2u * a.v.key_len;
-    uint32_t status = LEAF_NONE, vlen = 0;
-    uint64_t voff = 0;
-    const uint64_t b = a.v.node_off[j], e = a.v.node_off[j + 1];
-    const uint32_t padded = (uint32_t)((e - b + 15u) & ~15ull);
-    if (cnt - 1u <= nn && e >= b && e <= a.v.nodes_len && e - b <= WALK_STAGE_BYTES && b + padded <= a.v.nodes_len &&
-        a.v.key_len <= WALK_KEY_BYTES) {
-        uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
-        const uint8_t* const cur = a.v.nodes + b;
-        for (uint32_t o = 0; o < padded; o += 16u) {
-            const uint4 q = load16u(cur + o);
-            slot[o / 4u] = q.x;
-            slot[o / 4u + 1u] = q.y;
-            slot[o / 4u + 2u] = q.z;
-            slot[o / 4u + 3u] = q.w;
-        }
-        uint8_t* const kdst = reinterpret_cast<uint8_t*>(slot + WALK_STAGE_BYTES / 4);
-        const uint8_t* const key = a.v.keys + (uint64_t)a.v.key_len * i;
-        for (uint32_t t = 0; t < a.v.key_len; ++t) kdst[t] = key[t];
-        const uint8_t* const slot_node = reinterpret_cast<const uint8_t*>(slot);
-        const uint8_t* const slot_key = reinterpret_cast<const uint8_t*>(slot + WALK_STAGE_BYTES / 4);
-        WalkState w;
-        w.pos = cnt - 1u;
-        w.status = PHANT_PROOF_BAD_INPUT;
-        w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
-        uint32_t at = 0, len = (uint32_t)(e - b);  // the node being decoded: the last node, or a node embedded in it
-        for (;;) {
-            GlobalBytes nd{slot_node + at};
-            const uint32_t st = walk_node(nd, len, slot_key, nn, w);
-            if (st == STEP_DONE) {
-                status = w.status;
-                if (status == PHANT_PROOF_PRESENT) {
-                    voff = b + at + w.value_pay;
-                    vlen = w.value_len;
-                }
-                break;
-            }
-            if (st == STEP_HASH) break;  // (the proof goes on behind its last node: MISSING_NODE, the walk's business)
-            at += w.ref_pay;
-            len = w.ref_total;
-        }
-    }
-    a.leafres[j] = make_uint4(status, vlen, (uint32_t)voff, (uint32_t)(voff >> 32));
-}
-
 // DIRECT: the S = 0 form (no representatives: every node was hashed in place by a lane that knew the proof's key)
-// LEAF: leaf_kernel has run
-template <bool DIRECT, bool LEAF>
+template <bool DIRECT>
 __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
     __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
     // With several launches in flight this kernel runs next to OTHER launches' hash waves: a few instructions between memory
@@ -1420,9 +901,6 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
             w.value_pay = w.value_len = w.ref_pay = w.ref_total = 0;
             uint32_t used = first;
             status = 0xffffffffu;
-            // what leaf_kernel prepared for this proof's last node (requested now, looked at when the run gets there)
-            uint4 leaf = make_uint4(LEAF_NONE, 0u, 0u, 0u);
-            if constexpr (LEAF) leaf = a.leafres[last - 1u];
 
             // ---- the run of nodes the hash waves settled, eight at a time.  While every node so far was stepped over,
             // a node's index in the proof is the number of key nibbles consumed.  A deep node's state is its own; a shallow
@@ -1496,17 +974,6 @@ __global__ void __launch_bounds__(256) walk_kernel(const Args a) {
                         run = false;
                         if (c == LINK_BAD_HASH) status = PHANT_PROOF_BAD_HASH;
                         else hash_known = c == LINK_HASH_OK;
-                        if constexpr (LEAF) {
-                            // the last node, reached over full branches only, its hash as the parent commits to it: exactly the
-                            // case leaf_kernel decoded it for
-                            if (hash_known && used + 1u == last && leaf.x != LEAF_NONE) {
-                                status = leaf.x;
-                                if (status == PHANT_PROOF_PRESENT) {
-                                    voff = ((uint64_t)leaf.w << 32) | leaf.z;
-                                    vlen = leaf.y;
-                                }
-                            }
-                        }
                     }
                 }
             }
@@ -1746,21 +1213,15 @@ static uint32_t table_entries(uint32_t n, uint32_t n_roots, uint32_t direct, uin
 }
 
 struct Layout {
-    size_t nstat, dtab, table, rep, ent, digest, pos, bcnt, bstart, bcur, bsums, ent2, leafres, end;
-    uint32_t stripe_cap, stripe_cap2;
+    size_t nstat, dtab, table, rep, ent, digest, end;
+    uint32_t stripe_cap;
 };
-// lanes of the comparison kernel of the ordered form: a wave per (chunk of CHUNK positions, level)
-static uint64_t compare_units(uint64_t n, uint32_t shallow) { return (n + CHUNK - 1u) / CHUNK * shallow; }
-// `lanes`: the shallow tier's lanes (proofs x shallow levels; 0 for the forms without a shallow tier); `ord_n`, `units`: proofs
-// ordered and comparison waves of the ordered form (0: another form)
-static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries, uint64_t lanes, uint64_t ord_n, uint64_t units) {
+// `lanes`: the shallow tier's lanes (proofs x shallow levels; 0 for the S = 0 form)
+static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries, uint64_t lanes) {
     const size_t tn = total_nodes;
     Layout l;
     const uint64_t wgs = (lanes + 255u) / 256u;
     l.stripe_cap = (uint32_t)((wgs + STRIPES - 1u) / STRIPES * 256u);
-    // (list set 1: the comparison's workgroups -- four (chunk, level) waves each -- append there, one reservation per workgroup)
-    const uint64_t wgs2 = (units + 3u) / 4u;
-    l.stripe_cap2 = (uint32_t)((wgs2 + STRIPES - 1u) / STRIPES * 256u);
     size_t p = HEADER_BYTES;
     l.nstat = p;  p += rnd256(tn + 16);
     l.dtab = p;   p += rnd256((size_t)direct_entries * 4);
@@ -1768,14 +1229,6 @@ static Layout layout(uint32_t total_nodes, uint32_t te, uint64_t direct_entries,
     l.rep = p;    p += rnd256(tn * 4 + 64);
     l.ent = p;    p += rnd256((size_t)N_LIST * STRIPES * l.stripe_cap * 8u);
     l.digest = p; p += rnd256(tn * 32);
-    const size_t buckets = ord_n ? (size_t)1 << ORDER_MAX_BITS : 0;
-    l.pos = p;    p += rnd256((size_t)ord_n * sizeof(PosInfo));
-    l.bcnt = p;   p += rnd256(buckets * 4);
-    l.bstart = p; p += rnd256((buckets + 1) * 4);
-    l.bcur = p;   p += rnd256(buckets * 4);
-    l.bsums = p;  p += rnd256(ord_n ? 256 : 0);
-    l.ent2 = p;   p += rnd256((size_t)N_LIST * STRIPES * l.stripe_cap2 * 8u);
-    l.leafres = p; p += rnd256(lanes ? tn * 16 : 0);  // (the two-tier forms)
     l.end = p + 1024;
     return l;
 }
@@ -1786,8 +1239,7 @@ size_t workspace_bytes(uint32_t total_nodes) {
     uint32_t t = 1024;
     while (t < 4ull * total_nodes && t < (1u << 26)) t <<= 1;
     const uint64_t lanes = (uint64_t)total_nodes + 256u * STRIPES;
-    // (n x S <= lanes and S >= 1: at most `lanes` proofs are ordered, and ceil(n / CHUNK) S <= n S / CHUNK + S comparison waves)
-    return layout(total_nodes, t, DIRECT_MAX_ENTRIES, lanes, lanes, lanes / CHUNK + MAX_SHALLOW + 1u).end;
+    return layout(total_nodes, t, DIRECT_MAX_ENTRIES, lanes).end;
 }
 
 static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
@@ -1800,12 +1252,6 @@ static void bind(Args& a, uint8_t* ws, const Layout& l, uint32_t te) {
     a.ent = reinterpret_cast<uint2*>(ws + l.ent);
     a.stripe_cap = l.stripe_cap;
     a.digest = reinterpret_cast<uint32_t*>(ws + l.digest);
-    a.leafres = reinterpret_cast<uint4*>(ws + l.leafres);
-    a.ent2 = reinterpret_cast<uint2*>(ws + l.ent2);
-    a.stripe_cap2 = l.stripe_cap2;
-    a.pos = nullptr;
-    a.bstart = nullptr;
-    a.bucket_bits = 0;
 }
 
 }  // namespace v3
@@ -1822,12 +1268,6 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     a.v = v;
     a.total_nodes = total_nodes;
     a.shallow = shallow_levels(v.n, v.n_roots, v.nodes_len, dedup_levels);
-    // Which form the shallow tier takes: the group tables, or -- asked for -- an ordered one (VerifyTune).
-    const bool own_order = tune.own_order && !tune.key_ordered && v.n_roots == 1u;
-    const bool ordered = own_order || tune.key_ordered;
-    // (the counting sort is on <= ORDER_MAX_BITS key bits: levels beyond that many nibbles would find their groups scattered
-    // over a bucket -- sound, but nothing deduplicated: left to the deep tier unless the split is forced)
-    if (own_order && dedup_levels < 0 && a.shallow > ORDER_MAX_BITS / 4u + 1u) a.shallow = ORDER_MAX_BITS / 4u + 1u;
     // the shallow tier has a lane per (proof, level) and lists sized by them: a forced split deeper than the proofs are
     // long on average is cut back to what the workspace (sized from total_nodes) holds
     while (a.shallow && (uint64_t)v.n * a.shallow > (uint64_t)total_nodes + 256u * STRIPES) --a.shallow;
@@ -1836,8 +1276,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     a.direct = direct_levels(v.n_roots, a.shallow, direct_entries);
     const uint32_t te = table_entries(v.n, v.n_roots, a.direct, a.shallow, total_nodes);
     const uint64_t lanes = (uint64_t)v.n * a.shallow;
-    const uint64_t units = ordered ? compare_units(v.n, a.shallow) : 0u;
-    const Layout l = layout(total_nodes, te, direct_entries, lanes, ordered ? v.n : 0u, units);
+    const Layout l = layout(total_nodes, te, direct_entries, lanes);
     bind(a, ws, l, te);
     hipError_t e = hipSuccess;
     const uint32_t pg = (v.n + 255u) / 256u;
@@ -1849,7 +1288,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     const uint32_t deep_levels = avg_len + 1u <= a.shallow ? 1u
                                  : (uint32_t)(avg_len + 1u - a.shallow < DEEP_LEVELS ? avg_len + 1u - a.shallow : DEEP_LEVELS);
     const uint32_t deep_wgs = (wpl * deep_levels + 3u) / 4u;
-    if (tune.last_form) *tune.last_form = (a.shallow == 0u || total_nodes == 0u) ? 0u : !ordered ? 1u : own_order ? 2u : 3u;
+    if (tune.last_form) *tune.last_form = (a.shallow == 0u || total_nodes == 0u) ? 0u : 1u;
     if (a.shallow == 0u || total_nodes == 0u) {
         // S = 0: clear, hash every node in place, walk on the node states.  No lists, tables or helper stream.
         a.shallow = 0;
@@ -1872,7 +1311,7 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
             }
         else if (total_nodes)
             hipLaunchKernelGGL(hash_deep_kernel<true>, dim3(deep_wgs), dim3(256), 0, st, a, wpl, deep_levels);
-        hipLaunchKernelGGL((walk_kernel<true, false>), dim3(pg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(walk_kernel<true>, dim3(pg), dim3(256), 0, st, a);
         return hipGetLastError();
     }
     // ---- two tiers ----
@@ -1885,8 +1324,6 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     // An otherwise unused dynamic LDS allocation caps the hash workgroups per CU while the shallow tier's memory-bound
     // kernels run next to them (VerifyTune::hash_lds): a fourth hash wave per SIMD would take the registers they need
     const uint32_t hash_lds = two ? tune.hash_lds : 0u;
-    // An otherwise unused dynamic LDS allocation caps the hash workgroups per CU while the shallow tier's memory-bound
-    // kernels run next to them (VerifyTune::hash_lds): a fourth hash wave per SIMD would take the registers they need
     // the deep role: no inputs but the witness, so it starts at once -- on the helper stream, next to the shallow tier
     if (two) {
         if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;  // (behind the previous launch's walk)
@@ -1896,11 +1333,11 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
     auto mark = [&](int i) {
         if (kev && e == hipSuccess) e = hipEventRecord(kev[i], st);
     };
-    const bool three = two && side->stream2 && side->sorted && side->join2;
-    hipStream_t h2 = three ? side->stream2 : st;
     if (tune.diag) {
         // the workspace holds what a complete launch over this witness left (lists, counts): its hashing alone, a clean read of
         // its bytes alone, or both next to each other -- the deep tier uncapped when nothing memory-bound runs beside it
+        const bool three = two && side->stream2 && side->join2;
+        hipStream_t h2 = three ? side->stream2 : st;
         if (two) {
             if ((e = hipEventRecord(side->fork, st)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(side->stream, side->fork, 0)) != hipSuccess) return e;
@@ -1909,20 +1346,19 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         if (tune.diag & 1u) {
             const uint32_t lds = tune.diag == 3u ? hash_lds : 0u;  // (capped only where something memory-bound runs beside it)
             hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), lds, hs, a, wpl, deep_levels);
-            hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), lds ? lds + 8192u : 0u, st, a);
-            if (ordered) hipLaunchKernelGGL(hash_late_kernel, dim3(list_wgs < 256u ? list_wgs : 256u), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(hash_list_kernel, dim3(list_wgs), dim3(256), lds ? lds + 8192u : 0u, st, a);
         }
         if (tune.diag & 2u) {
-            // (PHANT_DIAG_STREAM_WGS: how much the stream keeps in flight -- 256 lanes x 8 loads x 16 bytes per workgroup)
-            static const uint32_t wgs = std::getenv("PHANT_DIAG_STREAM_WGS") ? (uint32_t)std::atoi(std::getenv("PHANT_DIAG_STREAM_WGS")) : 2048u;
-            static const uint32_t region_mb = std::getenv("PHANT_DIAG_STREAM_MB") ? (uint32_t)std::atoi(std::getenv("PHANT_DIAG_STREAM_MB")) : 0u;
+            // (diag_stream_wgs: how much the stream keeps in flight -- 256 lanes x 8 loads x 16 bytes per workgroup; diag_stream_mb:
+            // the same loads out of a region that stays in L2 / Infinity Cache)
+            const uint32_t wgs = tune.diag_stream_wgs ? tune.diag_stream_wgs : 2048u;
             size_t mask = ~(size_t)0;
-            if (region_mb) {
-                size_t r16 = (size_t)region_mb << 16;  // 16-byte elements
+            if (tune.diag_stream_mb) {
+                size_t r16 = (size_t)tune.diag_stream_mb << 16;  // 16-byte elements
                 while (r16 > v.nodes_len / 16u) r16 >>= 1;
                 mask = r16 ? r16 - 1u : 0u;
             }
-            hipLaunchKernelGGL(stream_read_kernel, dim3(wgs ? wgs : 1u), dim3(256), 0, h2, reinterpret_cast<const uint4*>(v.nodes),
+            hipLaunchKernelGGL(stream_read_kernel, dim3(wgs), dim3(256), 0, h2, reinterpret_cast<const uint4*>(v.nodes),
                                (size_t)(v.nodes_len / 16u), tune.diag_sink, mask);
         }
         if (two) {
@@ -1935,89 +1371,23 @@ hipError_t launch_mpt_verify(const VerifyArgs& v_in, uint32_t total_nodes, uint8
         }
         return hipGetLastError();
     }
-    // the ordered forms: the leaves, decoded ahead of the walk, on the deep tier's stream, behind it (the staging -- 58 KB of LDS per
-    // 256 lanes -- would wait for room next to the hash workgroups anyway; the hashing of the listed nodes outlasts the deep tier)
-    auto leaf_launch = [&](hipStream_t s) { hipLaunchKernelGGL(leaf_kernel, dim3((v.n + LEAF_LANES - 1u) / LEAF_LANES), dim3(LEAF_LANES), 0, s, a); };
-    if (!ordered) {
-        // (propose_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep
-        // role's waves fill every slot they are given the moment they start)
-        mark(0);
-        hipLaunchKernelGGL(propose_kernel, dim3(sg), dim3(256), 0, st, a);
-        mark(1);
-        hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
-        mark(2);
-        mark(3);  // (no heads_kernel and nothing hashed ahead of the comparison in this form: stages 2 and 3 are empty)
-        mark(4);
-        if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), 0, st, a);
-        mark(5);
-        hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, st, a);
-        mark(6);
-        if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
-        // (the walk decodes the leaves itself here: decoded ahead -- leaf_kernel, as in the ordered forms -- the walk is 8 us
-        // shorter and the launch no shorter, and the extra kernel costs 2.5 % of the throughput with two launches in flight:
-        // profiles/r5_explore/NOTES.md)
-        hipLaunchKernelGGL((walk_kernel<false, false>), dim3(pg), dim3(256), 0, st, a);
-        mark(7);
-        if (e != hipSuccess) return e;
-        return hipGetLastError();
-    }
-    // ---- ordered form ----
+    // (propose_kernel is handed to the device first: it heads the critical chain and is over in microseconds, the deep
+    // role's waves fill every slot they are given the moment they start)
     mark(0);
-    PosInfo* const pos = reinterpret_cast<PosInfo*>(ws + l.pos);
-    a.pos = pos;
-    if (own_order) {
-        a.bucket_bits = 4u * (a.shallow - 1u) < ORDER_MAX_BITS ? 4u * (a.shallow - 1u) : ORDER_MAX_BITS;
-        const uint32_t buckets = 1u << a.bucket_bits, tiles = (buckets + SCAN_TILE - 1u) / SCAN_TILE;
-        uint32_t* const bcnt = reinterpret_cast<uint32_t*>(ws + l.bcnt);
-        uint32_t* const bstart = reinterpret_cast<uint32_t*>(ws + l.bstart);
-        uint32_t* const bcur = reinterpret_cast<uint32_t*>(ws + l.bcur);
-        uint32_t* const bsums = reinterpret_cast<uint32_t*>(ws + l.bsums);
-        if ((e = hipMemsetAsync(bcnt, 0, (size_t)buckets * 4u, st)) != hipSuccess) return e;
-        // (the first kernel of the chain is handed to the device first, then the deep role, whose waves fill every slot they are
-        // given the moment they start; with the tiers serialised for per-stage times the deep role runs behind the order pass)
-        hipLaunchKernelGGL(order_hist_kernel, dim3(pg), dim3(256), 0, st, a, bcnt);
-        if (!kev) {
-            hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
-            if (two) leaf_launch(hs);
-        }
-        if (tiles > 1u) hipLaunchKernelGGL(order_sums_kernel, dim3(tiles), dim3(256), 0, st, bcnt, bsums, buckets);
-        hipLaunchKernelGGL(order_scan_kernel, dim3(tiles), dim3(256), 0, st, bcnt, bsums, bstart, bcur, buckets, v.n);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(pg), dim3(256), 0, st, a, bcur, pos);
-        a.bstart = bstart;
-    } else {
-        hipLaunchKernelGGL(order_identity_kernel, dim3(pg), dim3(256), 0, st, a, pos);
-        if (!kev) {
-            hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
-            if (two) leaf_launch(hs);
-        }
-    }
+    hipLaunchKernelGGL(propose_kernel, dim3(sg), dim3(256), 0, st, a);
     mark(1);
-    if (kev) hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
+    hipLaunchKernelGGL(hash_deep_kernel<false>, dim3(deep_wgs), dim3(256), hash_lds, hs, a, wpl, deep_levels);
     mark(2);
     if (two && (e = hipEventRecord(side->join, side->stream)) != hipSuccess) return e;
-    if (three) {
-        if ((e = hipEventRecord(side->sorted, st)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(side->stream2, side->sorted, 0)) != hipSuccess) return e;
-    }
-    // the group heads: listed from the keys alone and hashed NEXT TO the comparison
-    hipLaunchKernelGGL(heads_kernel, dim3(sg), dim3(256), 0, h2, a);
+    hipLaunchKernelGGL(dedup_kernel, dim3(sg), dim3(256), 0, st, a);
     mark(3);
-    hipLaunchKernelGGL(hash_list_kernel<0>, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, h2, a);
+    hipLaunchKernelGGL(hash_list_kernel, dim3(list_wgs), dim3(256), hash_lds ? hash_lds + 8192u : 0u, st, a);
     mark(4);
-    if (three && (e = hipEventRecord(side->join2, side->stream2)) != hipSuccess) return e;
-    const uint32_t n_chunks = (uint32_t)((v.n + CHUNK - 1u) / CHUNK);
-    hipLaunchKernelGGL(compare_kernel, dim3((uint32_t)((units + 3u) / 4u)), dim3(256), 0, st, a, n_chunks);
-    mark(5);
-    // what the comparison left: a thin list (damaged copies and their successors) -- a bounded grid that strides over it
-    const uint32_t late_wgs = list_wgs < 256u ? list_wgs : 256u;
-    hipLaunchKernelGGL(hash_late_kernel, dim3(late_wgs), dim3(256), 0, st, a);
-    mark(6);
     if (two && (e = hipStreamWaitEvent(st, side->join, 0)) != hipSuccess) return e;
-    if (three && (e = hipStreamWaitEvent(st, side->join2, 0)) != hipSuccess) return e;
-    if (!two) leaf_launch(st);
-    hipLaunchKernelGGL((walk_kernel<false, true>), dim3(pg), dim3(256), 0, st, a);
-    mark(7);
+    // (the walk decodes the leaves itself: decoded ahead by a kernel of their own the walk is 8 us shorter and the launch no
+    // shorter, and the extra kernel costs 2.5 % of the throughput with two launches in flight: profiles/r5_explore/NOTES.md)
+    hipLaunchKernelGGL(walk_kernel<false>, dim3(pg), dim3(256), 0, st, a);
+    mark(5);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
@@ -2028,8 +1398,7 @@ void verify_stats_from_header(const uint32_t* hdr, uint32_t hashed[8]) {
     uint32_t lists[N_LIST];
     for (uint32_t c = 0; c < N_LIST; ++c) {
         lists[c] = 0;
-        for (uint32_t t = 0; t < LIST_SETS; ++t)
-            for (uint32_t s = 0; s < STRIPES; ++s) lists[c] += hdr[HDR_CUR + 256u * t + 32u * s + c];
+        for (uint32_t s = 0; s < STRIPES; ++s) lists[c] += hdr[HDR_CUR + 32u * s + c];
     }
     const uint32_t buf = (hdr[HDR_PARITY] & 1u) ^ 1u;  // (the walk has flipped the word)
     for (uint32_t c = 0; c < N_CLASS; ++c) {
@@ -2043,8 +1412,7 @@ void verify_tier_stats_from_header(const uint32_t* hdr, uint32_t out[4]) {
     out[0] = out[1] = out[2] = out[3] = 0;
     for (uint32_t c = 0; c < N_LIST; ++c) {
         uint32_t cnt = 0;
-        for (uint32_t t = 0; t < LIST_SETS; ++t)
-            for (uint32_t s = 0; s < STRIPES; ++s) cnt += hdr[HDR_CUR + 256u * t + 32u * s + c];
+        for (uint32_t s = 0; s < STRIPES; ++s) cnt += hdr[HDR_CUR + 32u * s + c];
         out[0] += cnt;
         out[1] += cnt * (c == LIST_B532 ? BRANCH_LEN / RATE + 1u : c + 1u);
     }

@@ -199,8 +199,8 @@ __global__ void __launch_bounds__(256) account_write_kernel(const uint32_t* __re
 
 // ------------------------------------------------------------------ host side
 // the permutation radix_sort.hip left undecided (64-bit prefixes tie / keys repeat), made on the host instead
-int32_t order_on_host(hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t* d_order, std::string& err) {
-    if (std::getenv("PHANT_SORT_NO_FALLBACK")) {  // tests: prove which path ordered the batch
+int32_t order_on_host(const TrieTune& tune, hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t* d_order, std::string& err) {
+    if (tune.sort_no_fallback) {  // tests: prove which path ordered the batch
         err = "device sort undecided (64-bit key prefixes tie or keys repeat)";
         return PHANT_E_UNSUPPORTED;
     }
@@ -222,11 +222,11 @@ int32_t order_on_host(hipStream_t st, const uint8_t* d_digests, const uint32_t* 
 // digests (device) -> their order in device memory by the device sort, WITHOUT waiting for its verdict: the order is used at
 // once, *d_flag is read back by the caller together with whatever it reads back next anyway; a set flag (ties in the 64-bit
 // prefixes: never, unless someone ground keys for it) means order_on_host and the work since then again.
-int32_t order_digests_async(hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* d_sort_ws,
+int32_t order_digests_async(const TrieTune& tune, hipStream_t st, const uint8_t* d_digests, const uint32_t* d_seg_of, uint32_t n, uint32_t n_seg, uint8_t* d_sort_ws,
                             uint32_t** d_order, uint32_t** d_flag, std::string& err) {
     uint32_t prefix_bits = 0;  // (the sort's own choice; a number -- tests -- means that many bits and no repair of ties)
-    if (const char* t = std::getenv("PHANT_SORT_PREFIX_BITS")) prefix_bits = (uint32_t)std::strtoul(t, nullptr, 10);
-    if (const char* t = std::getenv("PHANT_SORT_REPAIR_BITS")) prefix_bits = (uint32_t)std::strtoul(t, nullptr, 10) | 0x80000000u;  // (tests: few bits, ties repaired)
+    if (tune.sort_prefix_bits >= 0) prefix_bits = (uint32_t)tune.sort_prefix_bits;
+    if (tune.sort_repair_bits >= 0) prefix_bits = (uint32_t)tune.sort_repair_bits | 0x80000000u;  // (tests: few bits, ties repaired)
     SR_TRY(launch_order_digests(d_digests, d_seg_of, n, n_seg, d_sort_ws, d_order, d_flag, prefix_bits, st));
     return PHANT_OK;
 }
@@ -326,7 +326,7 @@ int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, Dev
         SR_TRY(launch_keccak256_fixed(d_live_keys, 32, 32, L, d_hk, st));
         uint32_t* d_order = nullptr;
         uint32_t* d_flag = nullptr;
-        int32_t rc = order_digests_async(st, d_hk, d_seg_of, L, n, d_sort, &d_order, &d_flag, err);
+        int32_t rc = order_digests_async(ws.tune, st, d_hk, d_seg_of, L, n, d_sort, &d_order, &d_flag, err);
         if (rc) return rc;
         for (int pass = 0; pass < 2; ++pass) {  // (a second time only behind the host's ordering)
             hipLaunchKernelGGL(slot_leaf_len_kernel, dim3(blocks((uint64_t)L + 1)), dim3(256), 0, st, d_order, d_live_src, d_svals_in, L, d_len);
@@ -338,7 +338,7 @@ int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, Dev
             SR_TRY(hipStreamSynchronize(st));
             leaf_bytes = mb[0];
             if (pass || !mb[1]) break;
-            if ((rc = order_on_host(st, d_hk, d_seg_of, L, d_order, err)) != PHANT_OK) return rc;
+            if ((rc = order_on_host(ws.tune, st, d_hk, d_seg_of, L, d_order, err)) != PHANT_OK) return rc;
             SR_TRY(hipMemsetAsync(d_flag, 0, 4, st));
         }
     }
@@ -363,7 +363,7 @@ int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, Dev
     SR_TRY(launch_keccak256_var(d_code, d_code_off, n, d_hc, st));
     uint32_t* d_aorder = nullptr;
     uint32_t* d_aflag = nullptr;
-    rc = order_digests_async(st, d_ha, nullptr, n, 1, d_sort, &d_aorder, &d_aflag, err);
+    rc = order_digests_async(ws.tune, st, d_ha, nullptr, n, 1, d_sort, &d_aorder, &d_aflag, err);
     if (rc) return rc;
     const uint32_t seg[2] = {0u, n};
     SR_TRY(hipMemcpyAsync(out.seg, seg, sizeof seg, hipMemcpyHostToDevice, st));
@@ -377,7 +377,7 @@ int32_t state_leaves_core(Workspaces& ws, hipStream_t st, const StateIn& in, Dev
         SR_TRY(hipStreamSynchronize(st));  // (and `seg` may go)
         out.val_bytes = mb[0];
         if (pass || !mb[1]) break;
-        if ((rc = order_on_host(st, d_ha, nullptr, n, d_aorder, err)) != PHANT_OK) return rc;
+        if ((rc = order_on_host(ws.tune, st, d_ha, nullptr, n, d_aorder, err)) != PHANT_OK) return rc;
         SR_TRY(hipMemsetAsync(d_aflag, 0, 4, st));
     }
     SR_TRY(hipGetLastError());

@@ -1538,9 +1538,8 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     // order_kernel goes straight behind it and hands the counters over through the mailbox while it runs (see there); the host
     // watches the word it raises -- a look at the stream now and then, so that a launch that failed cannot keep it waiting
     {
-        static const bool no_side = std::getenv("PHANT_TRIE_NO_SIDE") != nullptr;  // (A/B)
-        static const uint32_t side_min = std::getenv("PHANT_TRIE_SIDE_MIN_KEYS") ? (uint32_t)std::atoi(std::getenv("PHANT_TRIE_SIDE_MIN_KEYS")) : SIDE_MIN_KEYS;  // (test knob)
-        t.side_ok = (!no_side && n >= side_min) ? 1u : 0u;
+        const uint32_t side_min = ws.tune.side_min_keys >= 0 ? (uint32_t)std::min<int64_t>(ws.tune.side_min_keys, 0xffffffffll) : SIDE_MIN_KEYS;
+        t.side_ok = (!ws.tune.no_side && n >= side_min) ? 1u : 0u;
     }
     // The slot tables and the scratch blob: sized for n_rep = n (a node has two children at least) when that is affordable, so that
     // the bulk of the leaves can be queued behind order_kernel at once -- else from the n_rep the mailbox brings, the leaves after it.
@@ -1559,10 +1558,10 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         }
         return PHANT_OK;
     };
-    static const uint64_t ahead_max_keys = std::getenv("PHANT_TRIE_AHEAD_MAX_KEYS") ? (uint64_t)std::max(0ll, std::atoll(std::getenv("PHANT_TRIE_AHEAD_MAX_KEYS"))) : LEAVES_AHEAD_MAX_KEYS;  // (test knob)
+    const uint64_t ahead_max_keys = ws.tune.ahead_max_keys >= 0 ? (uint64_t)ws.tune.ahead_max_keys : LEAVES_AHEAD_MAX_KEYS;
     const bool ahead = n <= ahead_max_keys;
     // (a leaf workgroup's static LDS + this must stay within the 64 KiB a launch gets without opting in)
-    static const uint32_t side_lds_knob = std::getenv("PHANT_TRIE_SIDE_LDS") ? (uint32_t)std::min(std::max(std::atoi(std::getenv("PHANT_TRIE_SIDE_LDS")), 0), 65536 - 4 * 256 * (int)LEAF_STAGE_DW) : SIDE_LEAF_LDS;
+    const uint32_t side_lds_knob = ws.tune.side_lds >= 0 ? (uint32_t)std::min<int64_t>(ws.tune.side_lds, 65536 - 4 * 256 * (int)LEAF_STAGE_DW) : SIDE_LEAF_LDS;
     if (t.side_ok) TB_TRY(ws.ensure_side());
     if (ahead) {
         const int32_t rc = size_tables(n);
@@ -1628,17 +1627,17 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     // (order_kernel has cleared the slot lengths and formed the bins' starts from the histogram it found in t.counters)
     // A bin's slot class (branch_kernel): four blocks unless the bin is crowded (more workgroups than the chip holds at once) and
     // its mean fan-out says that most of its nodes fit less; what does not fit is run through the four-block class behind it.
-    static const uint32_t fallback_grid = std::getenv("PHANT_TRIE_FALLBACK_GRID") ? (uint32_t)std::max(1, std::atoi(std::getenv("PHANT_TRIE_FALLBACK_GRID"))) : FALLBACK_GRID;  // (test knob)
-    static const int force_blocks = std::getenv("PHANT_TRIE_SLOT_BLOCKS") ? std::atoi(std::getenv("PHANT_TRIE_SLOT_BLOCKS")) : 0;  // (A/B)
+    const uint32_t fallback_grid = ws.tune.fallback_grid >= 1 ? (uint32_t)std::min<int64_t>(ws.tune.fallback_grid, 1 << 20) : FALLBACK_GRID;
+    const int force_blocks = ws.tune.slot_blocks;
     auto launch_bin = [&](int d, hipStream_t on) {
         const uint32_t c = cnt[8 + d];
         if (!c) return;
-        static const bool no_coop = std::getenv("PHANT_TRIE_NO_COOP") != nullptr;  // (A/B)
-        static const uint32_t coop_max = std::getenv("PHANT_TRIE_COOP_MAX") ? (uint32_t)std::min(std::max(std::atoi(std::getenv("PHANT_TRIE_COOP_MAX")), 0), 1 << 20) : COOP_MAX_NODES;  // (A/B)
+        const bool no_coop = ws.tune.no_coop;
+        const uint32_t coop_max = ws.tune.coop_max >= 0 ? (uint32_t)std::min<int64_t>(ws.tune.coop_max, 1 << 20) : COOP_MAX_NODES;
         if (c <= coop_max && !no_coop && !force_blocks) {
             // (the sponge's fetches share the CU's LDS pipeline: with one wave on a CU a permutation takes 4.9 us, with four 5.7 --
             // up to two waves per CU the workgroups are single waves, which the dispatcher spreads over the CUs)
-            static const bool no_wave = std::getenv("PHANT_TRIE_NO_WAVE") != nullptr;  // (A/B: the half-wave kernel for every thin bin)
+            const bool no_wave = ws.tune.no_wave;  // (A/B: the half-wave kernel for every thin bin)
             if (c <= WAVE_MAX_NODES && !no_wave) {  // a wave per node
                 if (c <= 512u) hipLaunchKernelGGL(branch_wave_kernel, dim3(c), dim3(64), 0, on, t, depth_begin[d], c);
                 else hipLaunchKernelGGL(branch_wave_kernel, dim3((c + 3u) / 4u), dim3(256), 0, on, t, depth_begin[d], c);
@@ -1698,7 +1697,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         // The bins above them need these bins AND all leaves.  The helper stream is normally through well before the leaves are: the
         // host watches its event and queues the rest behind the leaves by hand -- a wait for the event IN the main stream stood
         // between the leaves and the next bin for 11 us even when the event had long been reached.
-        static const bool join_in_stream = std::getenv("PHANT_TRIE_JOIN_IN_STREAM") != nullptr;  // (A/B)
+        const bool join_in_stream = ws.tune.join_in_stream;  // (A/B)
         if (join_in_stream) {
             TB_TRY(hipStreamWaitEvent(st, ws.side_join, 0));
         } else {

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("PHANT_TEST_DIAG"):  # (a child pytest of a test that runs a module under a per-ctx switch: tests/diag.py)
+        from tests import diag
+        diag.install()
 
 
 @pytest.hookimpl(tryfirst=True)

@@ -106,22 +106,13 @@ class Opts(C.Structure):
     _fields_ = [("struct_size", _u32), ("device", _i32), ("stream", _vp), ("flags", _u32)]
 
 
-FUSED, NODEDUP = 2, 4
-
-
-def LEVELS(n):  # PHANT_CTX_DEDUP_LEVELS(n): the two-tier pipeline with the first n trie levels deduplicated
+def LEVELS(n):  # PHANT_CTX_DEDUP_LEVELS(n): the verify pipeline with the first n trie levels deduplicated
     return ((n + 1) << 8) & 0x1F00
 
 
-# "flat" = the two-tier pipeline with its tier split chosen from the batch size; levelsN force the split (1: only the
-# root nodes are deduplicated, 16: every level, nothing left for the in-place tier)
-# "+ordered" / "+caller": the ordered forms of the shallow tier (A/B) -- on the library's own order (batches against one root; the
-# others take the tables) / on the caller's order as it is (PHANT_CTX_VERIFY_KEY_ORDERED), which the tests' batches are NOT in:
-# nothing may depend on the promise
-KEY_ORDERED, ORDERED = 8, 16
-MODES = {"flat": 0, "nodedup": NODEDUP, "fused": FUSED, "levels1": LEVELS(1), "levels3": LEVELS(3), "levels16": LEVELS(16),
-         "levels3+ordered": LEVELS(3) | ORDERED, "levels16+ordered": LEVELS(16) | ORDERED, "levels3+caller": LEVELS(3) | KEY_ORDERED,
-         "levels16+caller": LEVELS(16) | KEY_ORDERED}
+# "flat" = the pipeline with its tier split chosen from the batch size; levelsN force the split (0: every shipped node hashed in
+# place, 1: only the root nodes are deduplicated, 16: every level, nothing left for the in-place tier)
+MODES = {"flat": 0, "nodedup": LEVELS(0), "levels1": LEVELS(1), "levels3": LEVELS(3), "levels16": LEVELS(16)}
 
 
 def _p(a):
@@ -220,11 +211,13 @@ def mirror_context(lib, mode="flat"):
     class EmuContext(Context):
         def __init__(self):  # noqa: super().__init__ needs a GPU
             self.device = 0
-            opts = L.PhantOpts(C.sizeof(L.PhantOpts), 0, None, MODES[mode])
+            opts = L.PhantOpts(C.sizeof(L.PhantOpts), 0, None, MODES[mode] if mode in MODES else LEVELS(int(mode[len("levels"):])))
             h = C.c_void_p()
             rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))
             assert rc == 0, rc
             self._h, self._lib = h, lib
+            from tests import diag
+            diag.apply(self)
 
         def keccak_rate(self, waves_per_simd=6, perms=100):
             # the emulated device's permutation rate means nothing; one wave per SIMD and two permutations exercise the

@@ -19,11 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _emulated_backend():
     # (these runs are about bench.py's plumbing: the node-per-half-wave hash kernel that small batches take -- 32 emulated lanes
     # and ~400 cross-lane operations per permutation -- makes them four times as long; tests/test_emu_verify.py is where it is tested)
-    os.environ["PHANT_VERIFY_NO_COOP"] = "1"
+    os.environ["PHANT_TEST_DIAG"] = "verify_no_coop=1"  # (applied to every emulated Context: tests/diag.py)
     try:
         yield from emu.emulated_backend()
     finally:
-        os.environ.pop("PHANT_VERIFY_NO_COOP", None)
+        os.environ.pop("PHANT_TEST_DIAG", None)
 
 
 @contextlib.contextmanager
@@ -61,9 +61,8 @@ def _no_cuda():
         def elapsed_time(self, other):
             return (other.t - self.t) * 1e3
 
-    def context(device=None, use_torch_stream=True, verify_fused=False, verify_nodedup=False, dedup_levels=None):
-        mode = ("fused" if verify_fused else "nodedup" if verify_nodedup else
-                "levels%d" % dedup_levels if dedup_levels is not None else "flat")
+    def context(device=None, use_torch_stream=True, verify_nodedup=False, dedup_levels=None):
+        mode = ("nodedup" if verify_nodedup else "levels%d" % dedup_levels if dedup_levels is not None else "flat")
         return emu.mirror_context(emu.mirror_lib(), mode)
 
     class _Device:  # torch.device("cuda", i) -> the CPU; isinstance checks inside torch still see a real device
@@ -119,8 +118,8 @@ def _check_contract(line, steps, warmup):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
 
 
-@pytest.mark.parametrize("mode,streams,inner", [("flat", 3, 2), ("flat", 1, 1), ("fused", 2, 1), ("nodedup", 2, 1)] if suite.FULL else
-                         [("flat", 3, 2), ("fused", 2, 1)])
+@pytest.mark.parametrize("mode,streams,inner", [("flat", 3, 2), ("flat", 1, 1), ("nodedup", 2, 1)] if suite.FULL else
+                         [("flat", 3, 2), ("nodedup", 2, 1)])
 def test_config3_dry_run(mode, streams, inner):
     line = _bench(["--proofs", "300", "--steps", "3", "--warmup", "1", "--verify-mode", mode, "--streams",
                    str(streams), "--cpu-seconds", "0.2", "--inner", str(inner), "--block-scale", "0.01"])
@@ -133,17 +132,14 @@ def test_config3_dry_run(mode, streams, inner):
     cb = line["cpu_baseline"]
     assert cb["oracle_checked"] is True and cb["oracle_matches_timed_gpu_statuses"] is True and cb["oracle_checked_proofs"] == 300
     assert line["single_stream"]["value"] > 0
-    if mode != "fused":
-        assert 0 < line["roofline"]["nodes_hashed"] <= line["roofline"]["nodes_shipped"] == 300 * 8
-        # BASELINE config 4 (one block witness, strong scaling) rides on the config-3 line
-        st = line["strong"]
-        assert st["scaling"] == "strong" and st["value"] > 0 and st["proofs_on_rank0"] == 1080
-        assert 0 < st["nodes_hashed"] <= st["nodes_shipped"]
-        # the predicted ceiling a SCALE reader should hold `value` against sits next to it
-        pr = st["predicted"]
-        assert pr["n_gpus"] == 1 and pr["ceiling_proofs_per_s"] > 0 and abs(pr["value_over_ceiling"] - st["value"] / pr["ceiling_proofs_per_s"]) < 1e-9
-    else:
-        assert "strong" not in line
+    assert 0 < line["roofline"]["nodes_hashed"] <= line["roofline"]["nodes_shipped"] == 300 * 8
+    # BASELINE config 4 (one block witness, strong scaling) rides on the config-3 line
+    st = line["strong"]
+    assert st["scaling"] == "strong" and st["value"] > 0 and st["proofs_on_rank0"] == 1080
+    assert 0 < st["nodes_hashed"] <= st["nodes_shipped"]
+    # the predicted ceiling a SCALE reader should hold `value` against sits next to it
+    pr = st["predicted"]
+    assert pr["n_gpus"] == 1 and pr["ceiling_proofs_per_s"] > 0 and abs(pr["value_over_ceiling"] - st["value"] / pr["ceiling_proofs_per_s"]) < 1e-9
 
 
 def test_config3_forced_tier_split_dry_run():
@@ -155,7 +151,7 @@ def test_config3_forced_tier_split_dry_run():
     r = line["roofline"]
     assert r["valu"]["peak"] > 0 and "this run" in r["valu"]["peak_source"]
     k = r["kernels"]
-    assert k["form"] == "table"
+    assert k["form"] == "two_tiers" and r["valu_frac"] == r["valu"]["frac"] and 0 < r["valu_bound_frac_of_hbm"]
     assert k["dedup_levels"] == 3 and all(k[n]["ms"] > 0 for n in ("propose_kernel", "hash_deep_kernel", "dedup_kernel",
                                                                     "hash_list_kernel", "walk_kernel"))
     assert k["hash_deep_kernel"]["bound"] == "valu" and k["dedup_kernel"]["bound"] == "hbm"
@@ -391,7 +387,7 @@ def test_gpus_2_without_torchrun_relaunches_itself(tmp_path):
     entry = tmp_path / "bench_entry.py"
     entry.write_text(_ENTRY_SCRIPT.format(root=ROOT))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(PHANT_BENCH_BACKEND="gloo", PHANT_BENCH_ENTRY=str(entry), PHANT_VERIFY_NO_COOP="1")
+    env.update(PHANT_BENCH_BACKEND="gloo", PHANT_BENCH_ENTRY=str(entry), PHANT_TEST_DIAG="verify_no_coop=1")
     argv = ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--inner", "1", "--no-strong", "--no-cpu-baseline",
             "--max-seconds", "600"]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, cwd=ROOT, capture_output=True, text=True,

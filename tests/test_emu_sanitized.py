@@ -21,8 +21,8 @@ if suite.FULL:
         ("tests/test_emu_bulk.py", "bloom_edge or sender"),
         ("tests/test_emu_verify.py", "(flat or levels3) and (embedded or bad_offsets or non_monotone or longer_than or garbage "
                                      "or hostile_index_arrays_match)"),
-        ("tests/test_emu_verify.py", "fused and (embedded or longer_than or hostile_index_arrays_match)"),
-        ("tests/test_emu_verify.py", "(levels1 or levels16 or nodedup or ordered or caller) and hostile_index_arrays_device"),
+        ("tests/test_emu_verify.py", "nodedup and (embedded or longer_than or hostile_index_arrays_match)"),
+        ("tests/test_emu_verify.py", "(levels1 or levels16 or nodedup) and hostile_index_arrays_device"),
         ("tests/test_emu_nodeset.py", "damaged or garbage or hostile"),
         ("tests/test_emu_trie.py", "reference_vectors or variable_length or rejects"),
         ("tests/test_emu_witness.py", "clean_witness or non_hex"),
@@ -32,8 +32,8 @@ else:  # (the default CPU suite: tests/suite.py)
         ("tests/test_emu_keccak.py", "edge_lengths or nonzero_base or fixed_device_form or with_prefix"),
         ("tests/test_emu_bulk.py", "bloom_edge or sender"),
         ("tests/test_emu_verify.py", "(flat or levels3) and (embedded or bad_offsets or non_monotone or longer_than or garbage)"),
-        ("tests/test_emu_verify.py", "fused and (embedded or longer_than)"),
-        ("tests/test_emu_verify.py", "(ordered or caller) and (hostile_index_arrays_device or one_byte_off)"),
+        ("tests/test_emu_verify.py", "nodedup and (embedded or longer_than)"),
+        ("tests/test_emu_verify.py", "levels16 and (hostile_index_arrays_device or one_byte_off)"),
         ("tests/test_emu_nodeset.py", "damaged or garbage or hostile"),
         ("tests/test_emu_trie.py", "reference_vectors or variable_length or rejects"),
         ("tests/test_emu_witness.py", "clean_witness or non_hex"),

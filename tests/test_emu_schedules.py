@@ -28,14 +28,14 @@ def test_results_do_not_depend_on_the_execution_order():
             (3, "0x00", ["tests/test_emu_verify.py"],
              "(flat or levels3 or levels16) and (random_tries or mutation or hostile_index_arrays_match or synthetic_block)"),
             (11, "0xff", ["tests/test_emu_verify.py"],
-             "(levels1 or nodedup or fused or ordered or caller) and (random_tries or mutation or non_monotone)"),
+             "(levels1 or nodedup) and (random_tries or mutation or non_monotone)"),
             (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py",
                          "tests/test_emu_witness.py"],
              "not 20000 and not fixture_state"))
     else:  # (the default CPU suite: tests/suite.py)
         plan = (
             (3, "0x00", ["tests/test_emu_verify.py"], "(flat or levels3) and (random_tries or mutation)"),
-            (11, "0xff", ["tests/test_emu_verify.py"], "(fused or ordered or caller) and (random_tries or mutation or non_monotone)"),
+            (11, "0xff", ["tests/test_emu_verify.py"], "(nodedup or levels16) and (random_tries or mutation or non_monotone)"),
             (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py", "tests/test_emu_witness.py"],
              "not 20000 and not fixture_state and not sharded and not orders_its_leaves and not state_trie_leaves and not device_form"))
     for seed, fill, modules, expr in plan:
@@ -44,7 +44,7 @@ def test_results_do_not_depend_on_the_execution_order():
             cmd += ["-k", expr]
         env = dict(os.environ, HIPEMU_SCHEDULE=str(seed), HIPEMU_FILL=fill)
         if seed == 3:  # this child also takes the diagnostics form: the two tiers one after the other on one stream
-            env.update(PHANT_VERIFY_SERIAL="1")
+            env.update(PHANT_TEST_DIAG="verify_serial=1")
         runs.append((seed, subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                             text=True)))
     for seed, proc in runs:

@@ -4,9 +4,10 @@ small tries runs in the one- / two-block class (what does not fit takes the fall
 workgroup (the grid-stride loop); and tries of a few hundred keys split their leaves (the keys under the deepest nodes first, listed
 by order_kernel, then the deepest bins on the helper stream next to the rest) -- in both orders of launching: the bulk of the leaves
 queued behind order_kernel with worst-case tables (the default up to 8 M keys), and after the host has read the node count
-(PHANT_TRIE_AHEAD_MAX_KEYS=0: what tries beyond that get); and with the node-per-half-wave kernel off, which otherwise takes every
+(trie_ahead_max_keys = 0: what tries beyond that get); and with the node-per-half-wave kernel off, which otherwise takes every
 bin of a small trie.  Against the oracle: the test bodies of
-tests/test_gpu_trie.py over the emulated kernels (tests/emu.py), each setting in a process of its own (the knobs are read once)."""
+tests/test_gpu_trie.py over the emulated kernels (tests/emu.py), each setting in a process of its own (the switches are per ctx:
+include/phant_gpu_diag.h, applied to every Context of the child by tests/diag.py)."""
 import os
 import subprocess
 import sys
@@ -17,11 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUBSET = "random_vs_oracle or variable_length or state_root_random or block_roots or receipt_trie"
 
 
-@pytest.mark.parametrize("env", [{"PHANT_TRIE_SLOT_BLOCKS": "1", "PHANT_TRIE_FALLBACK_GRID": "1"},
-                                 {"PHANT_TRIE_SLOT_BLOCKS": "2", "PHANT_TRIE_FALLBACK_GRID": "1"},
-                                 {"PHANT_TRIE_SIDE_MIN_KEYS": "257"},
-                                 {"PHANT_TRIE_SIDE_MIN_KEYS": "257", "PHANT_TRIE_AHEAD_MAX_KEYS": "0"},
-                                 {"PHANT_TRIE_NO_COOP": "1"}],
+@pytest.mark.parametrize("env", [{"PHANT_TEST_DIAG": "trie_slot_blocks=1,trie_fallback_grid=1"},
+                                 {"PHANT_TEST_DIAG": "trie_slot_blocks=2,trie_fallback_grid=1"},
+                                 {"PHANT_TEST_DIAG": "trie_side_min_keys=257"},
+                                 {"PHANT_TEST_DIAG": "trie_side_min_keys=257,trie_ahead_max_keys=0"},
+                                 {"PHANT_TEST_DIAG": "trie_no_coop=1"}],
                          ids=["one_block_slots", "two_block_slots", "deepest_bins_beside_the_leaves", "leaves_behind_the_node_count",
                               "lane_per_node_bins_only"])
 def test_slot_classes_and_fallback_lists(env):

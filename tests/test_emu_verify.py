@@ -17,10 +17,9 @@ def _emulated_backend():
 
 # levelsN = the two-tier pipeline with its tier split forced (tests/emu.py): 1 = only root nodes deduplicated, 16 = every
 # level (nothing left for the in-place tier); "flat" chooses it from the batch size
-# (the default CPU suite: one mode of every kind -- the form a small batch takes, a forced tier split through the tables, the two
-# ordered forms, the one-lane-per-proof kernel; PHANT_CPU_SUITE=full: all ten, as the -m gpu module runs them)
-_MODES = ["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+ordered", "levels16+ordered", "levels3+caller",
-          "levels16+caller"] if suite.FULL else ["flat", "levels3", "fused", "levels16+ordered", "levels3+caller"]
+# (the default CPU suite: the form a small batch takes, two forced tier splits, every node hashed; PHANT_CPU_SUITE=full: all five, as
+# the -m gpu module runs them)
+_MODES = ["flat", "levels1", "levels3", "levels16", "nodedup"] if suite.FULL else ["flat", "levels3", "levels16", "nodedup"]
 
 
 @pytest.fixture(scope="module", params=_MODES)
@@ -48,7 +47,7 @@ from tests.test_gpu_verify import test_streaming_submit_wait as _streaming_submi
 
 
 def test_streaming_submit_wait(M):
-    if M.mode not in ("flat", "fused"):
+    if M.mode not in ("flat", "levels3"):
         pytest.skip("slot bookkeeping is host code shared by all modes: two of them suffice here")
     _streaming_submit_wait(M)
 

@@ -199,6 +199,7 @@ def test_one_device_comm_nodeset(comm1, oracle):
     body_nodeset_sharded(comm1, oracle)
 
 
+@pytest.mark.gpu
 def test_one_device_comm_state_root(comm1, oracle):
     body_sharded_state_root(comm1, oracle)
 

@@ -263,7 +263,7 @@ def _random_accounts(rng, n, max_slots):
     return acc
 
 
-def test_state_root_orders_its_leaves_on_the_gpu(P, oracle, monkeypatch):
+def test_state_root_orders_its_leaves_on_the_gpu(P, oracle):
     """phant_state_root sorts hashed addresses and hashed slot keys on the device (radix_sort.hip: 64-bit prefixes, then a
     regrouping by account): accounts with many slots (several sort tiles, every digit pass populated) and many accounts,
     against the oracle; and the same state with the device sort reduced to 8 / 16 key bits and no repair of ties, where nearly
@@ -272,26 +272,31 @@ def test_state_root_orders_its_leaves_on_the_gpu(P, oracle, monkeypatch):
     from tests import suite
     acc = _random_accounts(rng, *suite.scale((40, 700), (12, 300))) + _random_accounts(rng, *suite.scale((2500, 3), (600, 3)))
     want = oracle.state_root(acc)
-    monkeypatch.setenv("PHANT_SORT_NO_FALLBACK", "1")   # (test knob: fail instead of ordering on the host)
-    assert P.state.state_root(acc) == want              # ... so this order is the device's
-    monkeypatch.setenv("PHANT_SORT_PREFIX_BITS", "8")
-    with pytest.raises(Exception):
-        P.state.state_root(acc)
-    monkeypatch.delenv("PHANT_SORT_NO_FALLBACK")
-    for bits in ("8", "16"):
-        monkeypatch.setenv("PHANT_SORT_PREFIX_BITS", bits)
-        assert P.state.state_root(acc) == want
-    monkeypatch.delenv("PHANT_SORT_PREFIX_BITS")
-    # the product sorts on 32 prefix bits and repairs what ties (tie_fix_kernel): at 32 bits nothing in a test ever ties, so the
-    # repair is driven with 8 bits -- a few hundred slots per account and a few dozen accounts make runs of two to ten everywhere --
-    # and the device's order must still be the one that gives the oracle's root (no fallback allowed)
-    tied = _random_accounts(rng, 60, 300) + _random_accounts(rng, 40, 0)
-    monkeypatch.setenv("PHANT_SORT_NO_FALLBACK", "1")
-    monkeypatch.setenv("PHANT_SORT_REPAIR_BITS", "8")
-    assert P.state.state_root(tied) == oracle.state_root(tied)
-    monkeypatch.delenv("PHANT_SORT_NO_FALLBACK")
-    assert P.state.state_root(acc) == want                # runs longer than the repair takes on (2 540 accounts on 8 bits): fallback
-    monkeypatch.delenv("PHANT_SORT_REPAIR_BITS")
+    from phant_amd.context import default_context
+    knob = default_context().diag_set  # (include/phant_gpu_diag.h: per-ctx test hooks; P.state works on the default ctx)
+    try:
+        knob("sort_no_fallback", 1)   # fail instead of ordering on the host
+        assert P.state.state_root(acc) == want              # ... so this order is the device's
+        knob("sort_prefix_bits", 8)
+        with pytest.raises(Exception):
+            P.state.state_root(acc)
+        knob("sort_no_fallback", 0)
+        for bits in (8, 16):
+            knob("sort_prefix_bits", bits)
+            assert P.state.state_root(acc) == want
+        knob("sort_prefix_bits", -1)
+        # the product sorts on 32 prefix bits and repairs what ties (tie_fix_kernel): at 32 bits nothing in a test ever ties, so the
+        # repair is driven with 8 bits -- a few hundred slots per account and a few dozen accounts make runs of two to ten everywhere --
+        # and the device's order must still be the one that gives the oracle's root (no fallback allowed)
+        tied = _random_accounts(rng, 60, 300) + _random_accounts(rng, 40, 0)
+        knob("sort_no_fallback", 1)
+        knob("sort_repair_bits", 8)
+        assert P.state.state_root(tied) == oracle.state_root(tied)
+        knob("sort_no_fallback", 0)
+        assert P.state.state_root(acc) == want                # runs longer than the repair takes on (2 540 accounts on 8 bits): fallback
+    finally:
+        for k, v in (("sort_no_fallback", 0), ("sort_prefix_bits", -1), ("sort_repair_bits", -1)):
+            knob(k, v)
     one = _random_accounts(rng, 1, 5000)   # one account, one big storage trie
     assert P.state.state_root(one) == oracle.state_root(one)
 

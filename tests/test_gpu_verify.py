@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 class _Mode:
-    """phant_amd.mpt with every verify call bound to one ctx (two-tier pipeline with its tier split chosen or forced, without in-batch node dedup, or the one-lane-per-proof kernel)."""
+    """phant_amd.mpt with every verify call bound to one ctx (the verify pipeline with its tier split chosen or forced)."""
 
     def __init__(self, mod, ctx, mode=None):
         self._mod, self._ctx, self.mode = mod, ctx, mode
@@ -26,16 +26,12 @@ class _Mode:
         return self._mod.verify_batch_dev(*a, ctx=self._ctx, **k)
 
 
-# "+ordered" / "+caller": the ordered forms of the shallow tier (A/B) -- on the library's own order (one root) / on the caller's order
-# as it is (PHANT_CTX_VERIFY_KEY_ORDERED), which these batches are NOT in: nothing may depend on the promise
-@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup", "fused", "levels3+ordered", "levels16+ordered",
-                                        "levels3+caller", "levels16+caller"])
+# "flat": the tier split chosen from the batch; levelsN: forced (PHANT_CTX_DEDUP_LEVELS; "nodedup" = levels0: every shipped node hashed)
+@pytest.fixture(scope="module", params=["flat", "levels1", "levels3", "levels16", "nodedup"])
 def M(request):
     import phant_amd
-    mode, _, form = request.param.partition("+")
-    ctx = phant_amd.Context(verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"),
-                            dedup_levels=(int(mode[6:]) if mode.startswith("levels") else None),
-                            key_ordered=(form == "caller"), verify_ordered=(form == "ordered"))
+    mode = request.param
+    ctx = phant_amd.Context(verify_nodedup=(mode == "nodedup"), dedup_levels=(int(mode[6:]) if mode.startswith("levels") else None))
     yield _Mode(phant_amd.mpt, ctx, request.param)
     ctx.close()
 
@@ -230,8 +226,6 @@ def test_which_nodes_get_hashed_per_tier_split(M, oracle):
     """300 proofs through one 300-key trie share their upper nodes.  A small batch with the tier split chosen by the launcher is
     hashed whole (S = 0: every shipped node), as with deduplication switched off; with a forced split the copies of the levels
     above it are compared instead of hashed (phant_verify_stats)."""
-    if M.mode == "fused":
-        pytest.skip("the one-lane-per-proof kernel keeps no per-node statistics")
     rng = np.random.default_rng(5)
     keys, vals = random_kv(rng, 300, 32, 1, 60, 0)
     t = oracle.Trie(keys, vals)
@@ -242,8 +236,6 @@ def test_which_nodes_get_hashed_per_tier_split(M, oracle):
     hashed = sum(M._ctx.verify_stats())
     if M.mode in ("flat", "nodedup"):
         assert hashed == shipped
-    elif M.mode.endswith("+caller"):  # (the caller's order as it is: every chunk of 63 positions opens its own runs)
-        assert hashed <= shipped - 299 + 300 // 63, (M.mode, hashed, shipped)
     else:  # levels1 / levels3 / levels16: at least the 299 copies of the root node are not hashed
         assert hashed <= shipped - 299, (M.mode, hashed, shipped)
 
@@ -304,14 +296,12 @@ def test_bound_experiment_runs_on_a_two_tier_launch(M):
     with are the expected ones and a normal call on the same ctx afterwards still is."""
     import phant_amd
     from phant_amd import _lib as L
-    if M.mode in ("fused",):
-        pytest.skip("the one-lane-per-proof kernel has no tiers")
     w = phant_amd.witness.account_witness(1500, depth=8, seed=21, corrupt_frac=0.02)
     two_tier = M.mode.startswith("levels")
     if two_tier:
         res = M._ctx.verify_bound_experiment(w.batch, 2)
         assert set(res) == {"hash_only_ms", "stream_only_ms", "together_ms"} and all(v > 0 for v in res.values())
-        assert M._ctx.verify_form() in ("table", "ordered", "ordered_by_caller")
+        assert M._ctx.verify_form() == "two_tiers"
     else:
         with pytest.raises(L.PhantError):
             M._ctx.verify_bound_experiment(w.batch, 2)

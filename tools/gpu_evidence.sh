@@ -19,18 +19,17 @@ except Exception as e:
 PY
 }
 b config3 --cpu-seconds 8
-PHANT_VERIFY_ORDERED=1 b config3_ordered_form --no-cpu-baseline --no-strong
-PHANT_VERIFY_KEY_ORDERED=1 b config3_sorted_keys_callers_order --no-cpu-baseline --no-strong --proof-order sorted
-b config3_sorted_keys_table_form --no-cpu-baseline --no-strong --proof-order sorted
+b config3_sorted_keys --no-cpu-baseline --no-strong --proof-order sorted
 b config3_nodedup --no-cpu-baseline --no-strong --verify-mode nodedup
-b config3_fused --no-cpu-baseline --no-strong --verify-mode fused --steps 5
 b config3_1M --no-cpu-baseline --no-strong --proofs 1000000 --steps 5 --inner 4
 b config3_four_in_flight --no-cpu-baseline --no-strong --streams 4
 b config4 --workload config4 --cpu-seconds 5
 b config4_nodedup --workload config4 --no-cpu-baseline --verify-mode nodedup
 b config2 --workload config2 --cpu-seconds 3
-b nodeset --workload nodeset --no-cpu-baseline
+b nodeset --workload nodeset --cpu-seconds 3
+b nodeset_one_in_flight --workload nodeset --no-cpu-baseline --streams 1
 b config5 --workload config5 --steps 64 --cpu-seconds 3
+b config5_nodeset --workload config5 --nodeset --steps 64 --cpu-seconds 3
 b config5_20k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 20000
 b config5_100k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 100000
 b mptize --workload mptize --cpu-seconds 8 --steps 10
@@ -54,7 +53,7 @@ prof() {  # tag, env..., (BARGS)
   echo "== $tag"; cut -d, -f1-4 "$OUT/config3_kernel_stats_$tag.csv" | cut -c1-150
 }
 BARGS="--streams 1" prof concurrent X=1
-BARGS="--streams 1" prof serial PHANT_VERIFY_SERIAL=1
+BARGS="--streams 1 --diag verify_serial=1" prof serial X=1
 BARGS="--streams 2" prof streams2 X=1
 BARGS="--streams 4" prof streams4 X=1
 BARGS="--streams 1 --workload config4" prof config4 X=1
@@ -67,17 +66,17 @@ bash tools/gpu_prof.sh "${1:-evidence}/state_root_prof" state_offsets_check_kern
 for n in 100 256; do rm -rf /tmp/pws; ( cd /tmp && PROOFS=$n timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pws -o p -- python $R/tools/probe_walk.py > /dev/null 2>&1 ); echo "$n proofs: $(python tools/probe_walk_report.py /tmp/pws | tail -1 | cut -c1-110)"; done > "$OUT/timeline_small_witness.txt"
 timeout 200 python tools/probe_power.py --seconds 2 --out "$OUT/power_and_clock_per_phase.jsonl" > "$OUT/probe_power.log" 2>&1
 timeout 200 python tools/probe_bound_power.py 5000 > "$OUT/bound_experiment_power.txt" 2>&1
-for w in 2048 256; do PHANT_DIAG_STREAM_WGS=$w timeout 100 python tools/probe_bound.py 2>/dev/null | tail -2 | sed "s/^/stream workgroups $w: /"; done > "$OUT/bound_experiment.txt"
-for mb in 128 16 2; do PHANT_DIAG_STREAM_MB=$mb timeout 100 python tools/probe_bound.py 2>/dev/null | tail -2 | sed "s/^/stream region $mb MB: /"; done >> "$OUT/bound_experiment.txt"
-PHANT_VERIFY_ORDERED=1 timeout 100 python tools/probe_stages.py 2 > "$OUT/stages_ordered_form.txt" 2>&1; timeout 100 python tools/probe_stages.py 2 > "$OUT/stages_table_form.txt" 2>&1
-rm -rf /tmp/pwo; ( cd /tmp && timeout 200 env PHANT_VERIFY_ORDERED=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/pwo -o p -- python $R/tools/probe_walk.py > "$OUT/probe_ordered.log" 2>&1 )
-python tools/probe_walk_report.py /tmp/pwo > "$OUT/timeline_ordered_form.txt"
+for w in 2048 256; do STREAM_WGS=$w timeout 100 python tools/probe_bound.py 2>/dev/null | tail -2 | sed "s/^/stream workgroups $w: /"; done > "$OUT/bound_experiment.txt"
+for mb in 128 16 2; do STREAM_MB=$mb timeout 100 python tools/probe_bound.py 2>/dev/null | tail -2 | sed "s/^/stream region $mb MB: /"; done >> "$OUT/bound_experiment.txt"
+timeout 100 python tools/probe_stages.py 2 > "$OUT/stages.txt" 2>&1
+rm -rf /tmp/pns; ( cd /tmp && SPECS=1:0:40960:0 timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pns -o p -- python $R/tools/probe_nodeset2.py > "$OUT/probe_nodeset.log" 2>&1 )
+python tools/probe_walk_report.py /tmp/pns set_classify_kernel | tail -6 > "$OUT/timeline_nodeset.txt"
 rm -rf /tmp/pw; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/pw -o p -- python $R/tools/probe_walk.py > "$OUT/probe.log" 2>&1 )
 python tools/probe_walk_report.py /tmp/pw | tee "$OUT/timeline.txt" | cut -c1-260 | tail -6
 # ---- PMC passes: counters in their own runs, kernel trace only
 pmc() {  # name, counters, mode, [ENV=VAL]
-  name=$1; ctr=$2; mode=$3; extra=${4:-PHANT_X=0}
-  ( cd /tmp && rm -rf /tmp/pmc_$name && timeout 300 env PHANT_VERIFY_SERIAL=1 $extra rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --inner 1 --no-strong --no-cpu-baseline --streams 1 --verify-mode $mode > "$OUT/pmc_$name.log" 2>&1 )
+  name=$1; ctr=$2; mode=$3
+  ( cd /tmp && rm -rf /tmp/pmc_$name && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --inner 1 --no-strong --no-cpu-baseline --streams 1 --verify-mode $mode --diag verify_serial=1 > "$OUT/pmc_$name.log" 2>&1 )
   for f in $(find /tmp/pmc_$name -name '*counter_collection.csv'); do (head -1 "$f"; grep -E 'phant::' "$f") > "$OUT/$name.csv"; done
 }
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -85,7 +84,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   for f in $(find /tmp/ub_$c -name '*counter_collection.csv'); do cp "$f" "$OUT/ubench_$c.csv"; done
   pmc flat_$c $c flat
   pmc nodedup_$c $c nodedup
-  pmc ordered_$c $c flat PHANT_VERIFY_ORDERED=1
 done
 pmc flat_SQ1 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" flat
 pmc flat_SQ2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE" flat

@@ -15,7 +15,7 @@ correction factor used here is derived from a known byte count in the same acces
     uncalibrated -- a lower bound.
 The result carries a hash of the kernel sources it was measured on (`csrc_sha256`): bench.py quotes it only while
 phant_amd/csrc still hashes to that.
-The PMC passes run the pipeline's tiers one after the other (PHANT_VERIFY_SERIAL=1): counters are per dispatch.
+The PMC passes run the pipeline's tiers one after the other (bench.py --diag verify_serial=1): counters are per dispatch.
 """
 import collections
 import csv

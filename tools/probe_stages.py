@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Stage times of one verify launch, tiers serialised (every stage alone on the chip: phant_verify_kernel_ms), on BASELINE config 3;
-the form from the environment (PHANT_VERIFY_ORDERED=1 / PHANT_VERIFY_KEY_ORDERED=1; PROOF_ORDER=sorted).  python tools/probe_stages.py [repetitions]"""
+PROOF_ORDER=sorted: the proofs in ascending key order.  python tools/probe_stages.py [repetitions]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PHANT_VERIFY_SERIAL"] = "1"
 import torch
 import phant_amd
 from phant_amd import mpt as M
 dev = torch.device("cuda", 0)
 ctx = phant_amd.Context(0)
+ctx.diag_set("verify_serial", 1)
 order = os.environ.get("PROOF_ORDER", "random")
 wa = phant_amd.witness.account_witness(100_000, depth=8, seed=2, device=dev, ctx=ctx, key_order=order)
 st = torch.empty(wa.batch.n, dtype=torch.uint8, device=dev)

@@ -61,7 +61,7 @@ def main():
     from tests.witness_util import random_kv, pack_proofs, node_set
 
     modes = {"flat": {}, "levels1": {"dedup_levels": 1}, "levels3": {"dedup_levels": 3}, "levels16": {"dedup_levels": 16},
-             "nodedup": {"verify_nodedup": True}, "fused": {"verify_fused": True}}
+             "nodedup": {"verify_nodedup": True}}
     if args.emulated:
         from tests import emu
         backend = emu.emulated_backend()

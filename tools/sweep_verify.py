@@ -16,23 +16,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 COMBOS = [
-    # PHANT_HASH_LDS_KB caps the deep tier's workgroups per CU (= its waves per SIMD) while the shallow tier runs beside it
-    # (40 -> 4, 52 -> 3, 0 = no cap; default 40); PHANT_VERIFY_SERIAL=1: the tiers one after the other (diagnostics)
+    # (per-ctx switches of include/phant_gpu_diag.h) verify_hash_lds_kb caps the deep tier's workgroups per CU (= its waves per SIMD)
+    # while the shallow tier runs beside it (40 -> 3, 0 = no cap; default 40); verify_serial = 1: the tiers one after the other
     ("flat", None, {}),
-    ("flat", None, {"PHANT_HASH_LDS_KB": "0"}),
-    ("flat", None, {"PHANT_HASH_LDS_KB": "52"}),
-    ("flat", None, {"PHANT_VERIFY_SERIAL": "1"}),
+    ("flat", None, {"verify_hash_lds_kb": "0"}),
+    ("flat", None, {"verify_hash_lds_kb": "47"}),
+    ("flat", None, {"verify_serial": "1"}),
     ("flat", 4, {}),
     ("flat", 6, {}),
     ("flat", 8, {}),                                     # every level of a depth-8 proof deduplicated: no in-place tier
     ("nodedup", None, {}),
-    ("fused", None, {}),
 ]
-KNOBS = ("PHANT_HASH_LDS_KB", "PHANT_VERIFY_SERIAL")
 
 
 def grid(spec):
-    """--grid "PHANT_VERIFY_ORDER=0,1;PHANT_COMPARE_WGS=256,768;PHANT_HASH_LDS_KB=0,40": the cross product, mode flat"""
+    """--grid "verify_hash_lds_kb=0,40;verify_no_coop=0,1": the cross product of diag knobs, mode flat"""
     import itertools
     axes = []
     for part in spec.split(";"):
@@ -46,7 +44,7 @@ def main():
     ap.add_argument("--proofs", type=int, default=100_000)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--grid", default=None, help="cross product of environment knobs instead of the built-in list")
+    ap.add_argument("--grid", default=None, help="cross product of diag knobs instead of the built-in list")
     ap.add_argument("--corrupt", type=float, default=None, help="fraction of damaged / exclusion proofs in the witness")
     ap.add_argument("--levels", default=None, help="e.g. 4,5,4,5: the two-tier pipeline at these forced tier splits, in this order")
     args = ap.parse_args()
@@ -64,10 +62,9 @@ def main():
     status = torch.empty(b.n, dtype=torch.uint8, device=dev)
     lines = []
     for mode, levels, env in combos:
-        for k in KNOBS:
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        ctx = phant_amd.Context(0, verify_fused=(mode == "fused"), verify_nodedup=(mode == "nodedup"), dedup_levels=levels)
+        ctx = phant_amd.Context(0, verify_nodedup=(mode == "nodedup"), dedup_levels=levels)
+        for k, v in env.items():
+            ctx.diag_set(k, int(v))
         status.fill_(0x77)
         for _ in range(3):
             M.verify_batch_dev(b, status=status, ctx=ctx)
@@ -84,11 +81,11 @@ def main():
             M.verify_batch_dev(b, status=status, ctx=ctx)
             kms.append(ctx.last_kernel_ms())
         ctx.timing(False)
-        hashed = ctx.verify_stats() if mode != "fused" else []
-        paths = ctx.verify_path_stats() if mode != "fused" else (0, 0)
+        hashed = ctx.verify_stats()
+        paths = ctx.verify_path_stats()
         line = {"mode": mode, "dedup_levels": levels, "env": env, "ok": ok, "wall_ms": round(wall, 4), "event_ms": round(sum(kms) / len(kms), 4),
                 "event_min_ms": round(min(kms), 4), "proofs_per_s": round(b.n / (wall * 1e-3)),
-                "kernel_us": ({k: round(v * 1e3, 1) for k, v in ctx.verify_kernel_ms().items()} if env.get("PHANT_VERIFY_SERIAL") == "1" and mode == "flat" else None),
+                "kernel_us": ({k: round(v * 1e3, 1) for k, v in ctx.verify_kernel_ms().items()} if env.get("verify_serial") == "1" and mode == "flat" else None),
                 "nodes_hashed": int(sum(hashed)), "slow_proofs": paths[0], "walk_opened": paths[1], "keccak_f": int(sum((c + 1) * h for c, h in enumerate(hashed)))}
         print(json.dumps(line), flush=True)
         lines.append(line)
