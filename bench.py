@@ -130,6 +130,10 @@ def parse():
                          "(passes x roots) block on a stream of its own (default 1: a verdict per witness, what a validator needs; "
                          "rounds 1-3 of this repository batched --inner = 30 passes per exchange: their N > 1 figures are not "
                          "comparable)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="N > 1: every rank on device 0 (a one-GPU box: the process-per-GPU control flow -- shards, per-pass verdict "
+                         "all-reduce, the strong leg -- over the real kernels; with PHANT_BENCH_BACKEND=gloo the collectives are staged "
+                         "through host memory.  NOT a scaling measurement: the line says distinct_devices = 1)")
     ap.add_argument("--comm", action="store_true",
                     help="the in-process form of the multi-GPU path: ONE process, every visible device behind one phant_comm "
                          "(phant_comm_ctx + phant_mpt_verify_verdict_dev per device, one phant_comm_allreduce_verdict per pass); "
@@ -832,6 +836,8 @@ def main():
         return relaunch_under_torchrun(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.comm:
@@ -846,6 +852,26 @@ def main():
             backend = os.environ.get("PHANT_BENCH_BACKEND", "nccl")
             dist.init_process_group(backend, timeout=datetime.timedelta(seconds=args.rendezvous_seconds),
                                     **({"device_id": dev} if backend == "nccl" else {}))
+            if backend == "gloo" and getattr(dev, "type", "cpu") == "cuda":
+                # gloo on a GPU box (--one-device): device tensors go through host memory, in place
+                raw_reduce, raw_gather = dist.all_reduce, dist.all_gather
+
+                def all_reduce_staged(t, *a, **k):
+                    if not t.is_cuda:
+                        return raw_reduce(t, *a, **k)
+                    h = t.cpu()
+                    raw_reduce(h, *a, **k)
+                    t.copy_(h)
+
+                def all_gather_staged(out, t, *a, **k):
+                    if not t.is_cuda:
+                        return raw_gather(out, t, *a, **k)
+                    hs = [torch.empty_like(t, device="cpu") for _ in out]
+                    raw_gather(hs, t.cpu(), *a, **k)
+                    for o, h in zip(out, hs):
+                        o.copy_(h)
+
+                dist.all_reduce, dist.all_gather = all_reduce_staged, all_gather_staged
             # who is in the job: every rank's device, gathered over the same backend the verdicts will take -- N distinct
             # UUIDs = N GPUs really took part (the first collective: RCCL builds its communicator here)
             mine = device_id_bytes(dev)

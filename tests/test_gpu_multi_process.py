@@ -56,6 +56,36 @@ def test_torchrun_two_gpus_matches_one_gpu():
 
 
 @pytest.mark.gpu
+def test_two_ranks_one_device_gloo():
+    """What a ONE-GPU box can say about the process-per-GPU form: two ranks under torch.distributed.run, both on device 0, the
+    verdict all-reduce over gloo (staged through host memory) -- the shard slices, the per-pass verdict exchange on device
+    tensors, the `strong` leg and bench.py's own assertion that every verdict row equals the failures over BOTH ranks' shards,
+    over the HIP kernels instead of the emulator.  Not a scaling number, and the line says so."""
+    if _devices() < 1:
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PHANT_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--one-device", "--steps", "2",
+                        "--warmup", "1", "--proofs", "20000", "--no-cpu-baseline", "--max-seconds", "600"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    two = _line(p.stdout)
+    assert "error" not in two and two["n_gpus"] == 2 and two["value"] > 0
+    rw = two["rccl_world"]
+    assert rw["ranks"] == 2 and rw["backend"] == "gloo" and rw["distinct_devices"] == 1
+    assert two["roofline"]["verdict_exchange"]["allreduces_on_this_rank"] > 0
+    assert two["strong"]["predicted"]["n_gpus"] == 2 and two["strong"]["value"] > 0
+    # the same control flow for node-set witnesses
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--one-device", "--workload",
+                        "nodeset", "--steps", "2", "--warmup", "1", "--proofs", "20000", "--no-cpu-baseline", "--max-seconds", "600"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    ns = _line(p.stdout)
+    assert ns["n_gpus"] == 2 and ns["rccl_world"]["distinct_devices"] == 1 and ns["value"] > 0
+
+
+@pytest.mark.gpu
 def test_comm_form_two_gpus():
     if _devices() < 2:
         pytest.skip("one GPU visible")
