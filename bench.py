@@ -103,7 +103,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--proof-order", choices=("random", "sorted"), default="random",
                     help="config 3: order of the proofs in the batch (BASELINE: random; sorted = ascending keys, an A/B)")
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5", "nodeset", "mptize"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config4", "config5", "nodeset", "mptize", "block_roots"])
+    ap.add_argument("--items", type=int, default=100, help="block_roots: items per list (transactions / receipts / withdrawals)")
     ap.add_argument("--keys", type=int, default=1_000_000, help="mptize: sorted 32-byte keys (78-byte values) per GPU")
     ap.add_argument("--block-scale", type=float, default=1.0, help="config4: size of the block relative to 10k tx")
     ap.add_argument("--stream-proofs", type=int, default=0,
@@ -293,6 +294,20 @@ def cpu_baseline_nodeset(sset, target_seconds, gpu_status=None):
                       f"(oracle_mpt_verify_nodeset) single-threaded, {dt:.1f} s",
             "host_cpus": os.cpu_count(), "oracle_checked": gpu_ok is not None, "oracle_matches_timed_gpu_statuses": gpu_ok,
             "oracle_checked_proofs": sset.n if gpu_ok is not None else 0}
+
+
+def cpu_baseline_block_roots(lists, target_seconds):
+    """oracle/mpt.c (the restatement of mptize behind calculateMPTRoot, blockchain.zig:209-235), one core, the same three lists."""
+    from oracle import oracle as O
+    reps, t0 = 0, time.perf_counter()
+    while reps == 0 or time.perf_counter() - t0 < target_seconds:
+        for x in lists:
+            O.index_root_rlp(x)
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": 3 * reps / dt, "unit": "roots/s", "cores": 1, "kind": "port", "ms_per_call_of_three": dt / reps * 1e3,
+            "sample": f"{reps} x the same three lists, oracle/mpt.c (oracle_index_root_rlp) single-threaded, {dt:.1f} s",
+            "host_cpus": os.cpu_count()}
 
 
 def cpu_baseline_config2(blob, n, target_seconds):
@@ -784,6 +799,7 @@ def extra_legs(args):
     import subprocess
     legs = [("config2", ["--workload", "config2", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
             ("mptize_1M_keys", ["--workload", "mptize", "--keys", "1000000", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
+            ("block_roots_100_items", ["--workload", "block_roots", "--items", "100", "--steps", "20", "--warmup", "3", "--cpu-seconds", "2"]),
             ("nodeset_config3", ["--workload", "nodeset", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
             # BASELINE config 5 at its stated length: 256 consecutive block witnesses (4 distinct ones in rotation), and the same
             # witnesses as node sets -- the form an execution witness has
@@ -1061,6 +1077,34 @@ def main():
         metric, unit = "mpt_trie_keys_hashed_per_sec", "keys/s"
         workload = (f"mptize: root of the trie of {n_units} sorted random 32-byte keys with 78-byte values per GPU, arrays "
                     f"resident in HBM (phant_mpt_root_dev; {alg_bytes} B = keys + values + root)")
+    elif args.workload == "block_roots":
+        # what the reference's live callers of mptize compute per block (src/blockchain/blockchain.zig:198-204,209-235): the
+        # index-keyed roots of its transaction / receipt / withdrawal lists -- here as ONE phant_block_roots call, host form (the
+        # caller's bytes in, three roots out: copies included -- at this size the call is launch latency, not bandwidth)
+        import numpy as np
+        rngb = np.random.default_rng(3 + rank)
+        mkl = lambda lo, hi: [rngb.integers(0, 256, int(rngb.integers(lo, hi)), dtype=np.uint8).tobytes() for _ in range(args.items)]  # noqa: E731
+        lists = [mkl(100, 300), mkl(300, 700), mkl(40, 60)]
+        n_units = 3
+        alg_bytes = int(sum(len(x) for l_ in lists for x in l_) + 3 * 32)
+        roots_got = {}
+        # (packed once: a step is the C call, not Python's marshalling of 300 byte strings)
+        import ctypes as C
+        from phant_amd.mpt import _pack, _np_ptr
+        packed = [_pack(x, np.uint64) for x in lists]
+        item_p = (C.c_void_p * 3)(*[_np_ptr(b_).value for b_, _ in packed])
+        off_p = (C.c_void_p * 3)(*[_np_ptr(o_).value for _, o_ in packed])
+        cnt_p = (C.c_uint32 * 3)(*[len(x) for x in lists])
+        roots_out = np.zeros(96, np.uint8)
+
+        def step():
+            ctx.check(ctx._lib.phant_block_roots(ctx.handle, item_p, off_p, cnt_p, 3, _np_ptr(roots_out), None, None, None, 0, 0, None))
+            roots_got["r"] = [roots_out[32 * i:32 * i + 32].tobytes() for i in range(3)]
+
+        kernel_only = None
+        metric, unit = "mpt_block_index_roots_per_sec", "roots/s"
+        workload = (f"block_roots: the three index-keyed roots of a block (transactions / receipts / withdrawals, {args.items} items "
+                    f"each, {alg_bytes} B) in one phant_block_roots call, host form (copies in and out included)")
     elif args.workload == "config5":
         # 4 distinct witnesses in pinned host memory, submitted round-robin; results land in pinned buffers
         from phant_amd import mpt as MM
@@ -1137,7 +1181,7 @@ def main():
 
     if not proofs_like:
         # back-to-back repetitions per timed step (timed region of the order of 100 ms; figures are per single pass)
-        inner = {"config2": max(1, args.inner), "nodeset": max(1, args.inner), "config5": 4, "mptize": 4}[args.workload]
+        inner = {"config2": max(1, args.inner), "nodeset": max(1, args.inner), "config5": 4, "mptize": 4, "block_roots": 10}[args.workload]
         for _ in range(args.warmup):
             step()
         if streamed:
@@ -1186,13 +1230,20 @@ def main():
 
         # device time of one launch of the path (all kernels of the verify pipeline / the sponge kernel),
         # HIP events on the launch stream (phant_timing)
-        ctx.timing(True)
-        kms = []
-        for _ in range(max(5, min(args.steps, 50))):
-            kernel_only()
-            kms.append(ctx.last_kernel_ms())
-        ctx.timing(False)
-        k_avg_ms = sum(kms) / len(kms)
+        if args.workload == "block_roots":
+            # (a synchronous host-form call: its wall time IS the call; the trie's Keccak-f against the chip's rate says how far
+            # from any throughput bound a block-sized trie is -- it is a chain of launch and sponge latencies)
+            k_avg_ms = ms_per_pass
+            from oracle import oracle as O
+            assert roots_got["r"] == [O.index_root_rlp(x) for x in lists], "block roots differ from the oracle"
+        else:
+            ctx.timing(True)
+            kms = []
+            for _ in range(max(5, min(args.steps, 50))):
+                kernel_only()
+                kms.append(ctx.last_kernel_ms())
+            ctx.timing(False)
+            k_avg_ms = sum(kms) / len(kms)
         if args.workload == "nodeset":
             # one launch: HIP events on the launch stream around a run of back-to-back launches (alternating witnesses), as for
             # the per-proof line; the per-launch pairs above (a host synchronisation after each) stay as kernel_synced_avg_ms
@@ -1279,6 +1330,9 @@ def main():
                                 "into the record table by the lane that hashed it) + set_late_kernel (empty on a set of distinct nodes) "
                                 "+ set_walk_kernel (one launch of the path, first kernel start to last kernel end; the hash kernel is "
                                 "integer-VALU-bound, see roofline.valu)" if args.workload == "nodeset" else
+                                "trie hasher on three block-sized lists as one forest (head / lcp / min-tree / identify / order / leaf / a "
+                                "kernel per depth bin: branch_wave_kernel at this size; the call is a chain of launch and sponge latencies)"
+                                if args.workload == "block_roots" else
                                 "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + per depth bin branch_kernel<1|2|4> or, for a thin bin, branch_coop_kernel, finish_kernel (first start to last end)"
                                 if args.workload == "mptize" else
                                 "node-set pipeline = set_classify_kernel + set_hash_kernel + set_late_kernel + set_walk_kernel"
@@ -1309,6 +1363,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.workload == "mptize":
             line["cpu_baseline"] = cpu_baseline_mptize(keys_t, vals_t, n_units, root, args.cpu_seconds)
+        elif args.workload == "block_roots":
+            line["cpu_baseline"] = cpu_baseline_block_roots(lists, min(args.cpu_seconds, 3.0))
         elif args.workload == "nodeset" or (args.workload == "config5" and args.nodeset):
             line["cpu_baseline"] = cpu_baseline_nodeset(sset, args.cpu_seconds, cpu_check_status)
         elif args.workload == "config4":

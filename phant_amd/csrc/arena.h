@@ -97,7 +97,11 @@ struct Workspaces {
     static constexpr size_t MAILBOX_WORDS = 2048;
     uint32_t* mailbox = nullptr;
     hipError_t ensure_mailbox() {
-        return mailbox ? hipSuccess : hipHostMalloc(reinterpret_cast<void**>(&mailbox), MAILBOX_WORDS * 4, hipHostMallocCoherent);
+        if (mailbox) return hipSuccess;
+        const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&mailbox), MAILBOX_WORDS * 4, hipHostMallocCoherent);
+        if (e == hipSuccess)  // (the handshake words are compared with a tag counted up from what is found here: start from zero)
+            for (size_t i = 0; i < MAILBOX_WORDS; ++i) mailbox[i] = 0u;
+        return e;
     }
     // a helper stream + events for the trie builder's deepest bins, which run next to the bulk of the leaves
     hipStream_t side = nullptr;

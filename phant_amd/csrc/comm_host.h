@@ -30,6 +30,8 @@ const char* ncclGetErrorString(ncclResult_t result);
 #include <thread>
 #include <vector>
 
+#include "host_threads.h"
+
 namespace phant {
 
 // the six RCCL entry points comm.hip uses, with the signatures rccl.h declares
@@ -73,12 +75,11 @@ inline bool load_rccl(Rccl& r, std::string& err) {
 
 // work(d) for every device d < n: device 0 on the calling thread, the others on a host thread each (packing a shard and
 // staging it is host work; the devices' streams run independently anyway)
+// Nothing leaves a thread (host_threads.h): a shard that ran out of host memory comes back as std::bad_alloc on the calling thread,
+// after every device's thread has been joined.
 template <class F>
 inline void for_each_device(uint32_t n, F&& work) {
-    std::vector<std::thread> th;
-    for (uint32_t d = 1; d < n; ++d) th.emplace_back([&work, d] { work(d); });
-    if (n) work(0);
-    for (std::thread& t : th) t.join();
+    parallel_guarded(n, [&work](size_t d) { work((uint32_t)d); });
 }
 
 }  // namespace phant

@@ -25,6 +25,8 @@
 #include <utility>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1559,13 +1561,28 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         return PHANT_OK;
     };
     const uint64_t ahead_max_keys = ws.tune.ahead_max_keys >= 0 ? (uint64_t)ws.tune.ahead_max_keys : LEAVES_AHEAD_MAX_KEYS;
-    const bool ahead = n <= ahead_max_keys;
+    bool ahead = n <= ahead_max_keys;
     // (a leaf workgroup's static LDS + this must stay within the 64 KiB a launch gets without opting in)
     const uint32_t side_lds_knob = ws.tune.side_lds >= 0 ? (uint32_t)std::min<int64_t>(ws.tune.side_lds, 65536 - 4 * 256 * (int)LEAF_STAGE_DW) : SIDE_LEAF_LDS;
     if (t.side_ok) TB_TRY(ws.ensure_side());
     if (ahead) {
-        const int32_t rc = size_tables(n);
-        if (rc) return rc;
+        // The worst-case tables are ~3 x what the trie will need (1.3 KB against ~0.45 KB per key).  Where that much is not to be
+        // had -- torch sharing the device, several ctxs or slots -- the call falls back to what it did before the leaves went
+        // ahead: tables sized from the node count the mailbox brings, the leaves behind it.
+        size_t free_b = 0, total_b = 0;
+        const uint64_t worst = (uint64_t)n * (16 * 32 + 3 + 16 * 33 + 16 + 48 + 127 + 16 + 32) + total_val_bytes + total_key_bytes;
+        if (worst > ws.t2.cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && worst > (uint64_t)free_b + ws.t2.cap) {
+            ahead = false;
+        } else {
+            const int32_t rc = size_tables(n);
+            if (rc == PHANT_E_OOM) {
+                (void)hipGetLastError();  // (the failed hipMalloc's sticky error)
+                err.clear();
+                ahead = false;
+            } else if (rc) {
+                return rc;
+            }
+        }
     }
     volatile uint32_t* const mbox = ws.mailbox;
     t.mailbox = ws.mailbox;
@@ -1581,7 +1598,9 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         }
     } main_guard{st};
     hipLaunchKernelGGL(order_kernel, dim3((n + COUNT_BLOCK - 1u) / COUNT_BLOCK), dim3(COUNT_BLOCK), 0, st, t);
-    // (the bulk of the leaves: with room for the bins beside them wherever order_kernel MAY decide for such bins)
+    // (the bulk of the leaves: with room for the bins beside them wherever order_kernel MAY decide for such bins -- from SIDE_MIN_KEYS
+    // keys on the leaf workgroups carry the idle LDS, two of them a CU instead of four, also in the rare trie whose deepest bins
+    // turn out too crowded to run beside them: the leaf kernel is LDS- and latency-bound at either occupancy, measured +-1 %)
     if (ahead) hipLaunchKernelGGL(leaf_kernel, dim3(blocks(n)), dim3(256), t.side_ok ? side_lds_knob : 0u, st, t, nullptr, nullptr);
     TB_TRY(hipGetLastError());
     auto wait_for = [&](uint32_t word) -> int32_t {
@@ -1595,6 +1614,7 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
                 return PHANT_E_DEVICE;
             }
         }
+        std::atomic_thread_fence(std::memory_order_acquire);  // (the counters behind the word are read after it)
         return PHANT_OK;
     };
     {
@@ -1701,9 +1721,13 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
         if (join_in_stream) {
             TB_TRY(hipStreamWaitEvent(st, ws.side_join, 0));
         } else {
-            hipError_t q;
-            while ((q = hipEventQuery(ws.side_join)) == hipErrorNotReady) {
+            // (watched, not slept on: the event is normally reached ~30 us before the leaves end.  A bounded watch -- a helper
+            // stream that does not get there is handed to the runtime's own wait)
+            hipError_t q = hipErrorNotReady;
+            for (uint32_t spins = 0; spins < (1u << 22) && (q = hipEventQuery(ws.side_join)) == hipErrorNotReady; ++spins) {
+                if ((spins & 1023u) == 1023u) std::this_thread::yield();
             }
+            if (q == hipErrorNotReady) q = hipEventSynchronize(ws.side_join);
             TB_TRY(q);
         }
         for (int d = deep_from - 1; d >= 0; --d) launch_bin(d, st);

@@ -32,6 +32,7 @@
 #include <thread>
 #include <vector>
 
+#include "host_threads.h"
 #include "witness.h"
 
 namespace phant {
@@ -654,12 +655,7 @@ static bool parse_mt(const char* json, size_t len, unsigned threads, Witness& w,
             }
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
+    parallel_guarded(T, work);  // (nothing leaves a thread: host_threads.h)
     for (size_t t = 0; t < T; ++t)
         if (perr_at[t]) {  // the first failing thread holds the earliest error of the document
             err = perr[t];
@@ -725,12 +721,7 @@ static bool parse_mt(const char* json, size_t len, unsigned threads, Witness& w,
             w.slots[slot0[t] + i] = sl;
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (size_t t = 1; t < T; ++t) th.emplace_back(place, t);
-        place(0);
-        for (auto& x : th) x.join();
-    }
+    parallel_guarded(T, place);
     return true;
 }
 

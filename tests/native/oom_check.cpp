@@ -108,6 +108,49 @@ int main() {
         phant_witness_free(w);
     }
 
+    // the parser on SEVERAL threads (a document of a few accounts): an allocation that fails inside a worker thread must come back
+    // through the calling thread (csrc/host_threads.h), never std::terminate
+    {
+        std::string many = "{\"stateRoot\":\"0x" + std::string(64, '1') + "\",\"accounts\":[";
+        for (int a = 0; a < 6; ++a) {
+            char hx[8];
+            std::snprintf(hx, sizeof hx, "%02x", a + 3);
+            many += std::string(a ? "," : "") + "{\"address\":\"0x" + std::string(38, '2') + hx +
+                    "\",\"accountProof\":[\"0xcc8520010203048568656c6c6f\"],\"storageProof\":[{\"key\":\"0x1\",\"value\":\"0x2\","
+                    "\"proof\":[\"0xc0\",\"0x80\"]}]}";
+        }
+        many += "]}";
+        for (unsigned threads = 2; threads <= 3; ++threads)
+            for (int form = 0; form < 2; ++form) {
+                phant_witness* w = nullptr;
+                char err[128];
+                r = sweep(form ? "phant_witness_index_json (threads)" : "phant_witness_parse_json_mt", [&] {
+                    w = nullptr;
+                    const int32_t rc = form ? phant_witness_index_json(many.data(), many.size(), threads, &w, err, sizeof err)
+                                            : phant_witness_parse_json_mt(many.data(), many.size(), threads, &w, err, sizeof err);
+                    if (rc != PHANT_OK && w) return -99;
+                    return rc;
+                });
+                if (r < 0 || !w) return 1;
+                total += r;
+                phant_witness_free(w);
+            }
+    }
+    // a node-set witness: the one-leaf trie's node as a set of one, host form and streamed
+    {
+        uint8_t st1 = 0;
+        r = sweep("phant_mpt_verify_nodeset", [&] { return phant_mpt_verify_nodeset(ctx, root, 1, nullptr, key, 4, leaf, 13, node_off, 1, 1, &st1, &vo, &vl); });
+        if (r < 0 || st1 != PHANT_PROOF_PRESENT) return 1;
+        total += r;
+        r = sweep("phant_mpt_verify_nodeset_submit", [&] {
+            const int32_t rc = phant_mpt_verify_nodeset_submit(ctx, 1, root, 1, nullptr, key, 4, leaf, 13, node_off, 1, 1, &st1, &vo, &vl);
+            const int32_t wrc = phant_wait(ctx, 1);
+            return rc ? rc : wrc;
+        });
+        if (r < 0 || st1 != PHANT_PROOF_PRESENT) return 1;
+        total += r;
+    }
+
     // several devices of one process (HIPEMU_DEVICES): the sharded calls re-pack the witness per device in std::vectors
     phant_comm* comm = nullptr;
     r = sweep("phant_comm_create", [&] {
@@ -120,6 +163,19 @@ int main() {
     r = sweep("phant_mpt_verify_sharded", [&] { return phant_mpt_verify_sharded(comm, root, 1, nullptr, key, 4, leaf, 13, node_off, pfn, 1, &status, &vo, &vl, &fails); });
     if (r < 0 || status != PHANT_PROOF_PRESENT || fails != 0) return 1;
     total += r;
+    {
+        // two keys that belong to two different devices of a comm of >= 2: more than one non-empty shard
+        alignas(4) const uint8_t keys2[8] = {1, 2, 3, 4, 0x11, 2, 3, 4};
+        uint8_t st2[2] = {0, 0};
+        uint64_t vo2[2];
+        uint32_t vl2[2], fails2 = 9;
+        const uint8_t grp[1] = {PHANT_NODE_SHARED};
+        r = sweep("phant_mpt_verify_nodeset_sharded", [&] {
+            return phant_mpt_verify_nodeset_sharded(comm, root, 1, nullptr, keys2, 4, leaf, 13, node_off, 1, grp, 2, st2, vo2, vl2, &fails2);
+        });
+        if (r < 0 || st2[0] != PHANT_PROOF_PRESENT || st2[1] != PHANT_PROOF_ABSENT || fails2 != 0) return 1;
+        total += r;
+    }
     uint8_t root2[32];
     r = sweep("phant_mpt_root_sharded", [&] { return phant_mpt_root_sharded(comm, key, key_off, (const uint8_t*)"hello", val_off, 1, root2); });
     if (r < 0 || std::memcmp(root, root2, 32) != 0) return 1;

@@ -599,6 +599,13 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
     return hipSuccess;
 }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+// (the emulated device: as much memory as the host will give; HIPEMU_FREE_BYTES pretends less -- the trie builder's sizing)
+static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
+    const char* e = std::getenv("HIPEMU_FREE_BYTES");
+    *total_b = (size_t)1 << 40;
+    *free_b = e ? (size_t)std::strtoull(e, nullptr, 10) : *total_b;
+    return hipSuccess;
+}
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {

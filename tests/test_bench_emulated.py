@@ -204,6 +204,13 @@ def test_nodeset_and_config5_dry_run():
     assert line["config"]["units_per_gpu_per_step"] == 200 + 15 * 8 + 4 * 40 + 1 * 600
 
 
+def test_block_roots_dry_run():
+    line = _bench(["--workload", "block_roots", "--items", "20", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0.2"])
+    _check_contract(line, 1, 1)
+    assert line["metric"] == "mpt_block_index_roots_per_sec" and line["config"]["units_per_gpu_per_step"] == 3
+    assert line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["ms_per_call_of_three"] > 0
+
+
 def test_mptize_dry_run():
     line = _bench(["--workload", "mptize", "--keys", "3000", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0.2"])
     _check_contract(line, 1, 1)

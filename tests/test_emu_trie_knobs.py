@@ -5,7 +5,8 @@ workgroup (the grid-stride loop); and tries of a few hundred keys split their le
 by order_kernel, then the deepest bins on the helper stream next to the rest) -- in both orders of launching: the bulk of the leaves
 queued behind order_kernel with worst-case tables (the default up to 8 M keys), and after the host has read the node count
 (trie_ahead_max_keys = 0: what tries beyond that get); and with the node-per-half-wave kernel off, which otherwise takes every
-bin of a small trie.  Against the oracle: the test bodies of
+bin of a small trie; and on a device that reports too little free memory for the worst-case slot tables (the emulator's
+HIPEMU_FREE_BYTES: the call then sizes them from the node count, as beyond 8 M keys).  Against the oracle: the test bodies of
 tests/test_gpu_trie.py over the emulated kernels (tests/emu.py), each setting in a process of its own (the switches are per ctx:
 include/phant_gpu_diag.h, applied to every Context of the child by tests/diag.py)."""
 import os
@@ -22,9 +23,10 @@ SUBSET = "random_vs_oracle or variable_length or state_root_random or block_root
                                  {"PHANT_TEST_DIAG": "trie_slot_blocks=2,trie_fallback_grid=1"},
                                  {"PHANT_TEST_DIAG": "trie_side_min_keys=257"},
                                  {"PHANT_TEST_DIAG": "trie_side_min_keys=257,trie_ahead_max_keys=0"},
-                                 {"PHANT_TEST_DIAG": "trie_no_coop=1"}],
+                                 {"PHANT_TEST_DIAG": "trie_no_coop=1"},
+                                 {"HIPEMU_FREE_BYTES": "1000"}],
                          ids=["one_block_slots", "two_block_slots", "deepest_bins_beside_the_leaves", "leaves_behind_the_node_count",
-                              "lane_per_node_bins_only"])
+                              "lane_per_node_bins_only", "no_room_for_the_worst_case_tables"])
 def test_slot_classes_and_fallback_lists(env):
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_emu_trie.py", "-x", "-q", "-p", "no:cacheprovider", "-k", SUBSET],
                        cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Latency of the block's index-keyed roots on the GPU: three phant_index_root_rlp calls (one per list, what three
 calculateMPTRoot calls would become) against ONE phant_block_roots (the lists as one forest).  Host form: the items are the
-caller's bytes, every call includes its copies.
+caller's bytes, every call includes its copies.  Next to every line: oracle/mpt.c (the restatement of the reference's mptize,
+src/blockchain/blockchain.zig:209-235's calculateMPTRoot) on ONE core of this host over the same lists -- at the sizes the reference
+calls mptize with, that is the figure to hold the GPU's against.
 
     python tools/bench_block_roots.py [--items 400]
 """
@@ -22,6 +24,8 @@ def main():
     import torch
     import phant_amd
     from phant_amd import mpt as M
+    from oracle import oracle as O  # (the checker, timed as the CPU baseline: never part of what is measured as the GPU's)
+    O.build()
     rng = np.random.default_rng(3)
     for n in args.items:
         mk = lambda lo, hi: [rng.integers(0, 256, int(rng.integers(lo, hi)), dtype=np.uint8).tobytes() for _ in range(n)]  # noqa: E731
@@ -42,8 +46,23 @@ def main():
         one = t(lambda: M.index_root_rlp(lists[1]))
         three = t(lambda: [M.index_root_rlp(x) for x in lists])
         forest = t(lambda: M.block_roots(lists))
+        assert [O.index_root_rlp(x) for x in lists] == want
+
+        def tc(f, budget=0.5):
+            f()
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget:
+                f()
+                reps += 1
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        cpu_one = tc(lambda: O.index_root_rlp(lists[1]))
+        cpu_three = tc(lambda: [O.index_root_rlp(x) for x in lists])
         print(json.dumps({"items_per_list": n, "one_root_ms": round(one, 4), "three_calls_ms": round(three, 4),
-                          "block_roots_ms": round(forest, 4), "block_roots_over_one_root": round(forest / one, 3)}), flush=True)
+                          "block_roots_ms": round(forest, 4), "block_roots_over_one_root": round(forest / one, 3),
+                          "cpu_baseline": {"one_root_ms": round(cpu_one, 4), "three_roots_ms": round(cpu_three, 4), "cores": 1, "kind": "port",
+                                           "what": "oracle/mpt.c (oracle_index_root_rlp), one core, the same lists"},
+                          "gpu_over_cpu_three_roots": round(forest / cpu_three, 2)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -63,4 +63,25 @@ if hasattr(ctx._lib, "phant_state_root_dev"):
     line["device_form_seconds"] = round(best_dev, 4)
     line["device_form_leaves_per_s"] = round(n * (k + 1) / best_dev)
     line["device_form_root_matches"] = bytes(d_root.cpu().numpy().tobytes()) == out.tobytes()
+# the CPU baseline beside it: oracle/state.c (the restatement of a StateDB.root() over src/state/types.zig:13-20's fields), ONE core,
+# on a bounded sample of the same accounts (the first CPU_ACCOUNTS of them: a state root is one pass over its accounts)
+try:
+    from oracle import oracle as O  # noqa: E402
+    O.build()
+    import ctypes as C  # noqa: E402
+    m = min(n, int(os.environ.get("CPU_ACCOUNTS", "20000")))
+    co = np.zeros(m + 1, np.uint64)
+    fi = (np.arange(m + 1) * k).astype(np.uint32)
+    cout = np.zeros(32, np.uint8)
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)  # noqa: E731
+    t0 = time.perf_counter()
+    rc = O.lib().oracle_state_root(p(addrs[:m]), p(nonces[:m]), p(bal[:m]), p(code), p(co), p(sk[:m * k] if k else np.zeros((1, 32), np.uint8)),
+                                   p(sv[:m * k] if k else np.zeros((1, 32), np.uint8)), p(fi), m, p(cout))
+    dt = time.perf_counter() - t0
+    line["cpu_baseline"] = {"value": round(m * (k + 1) / dt), "unit": "leaves/s", "cores": 1, "kind": "port",
+                            "sample": f"the first {m} accounts x {k} slots, oracle/state.c single-threaded, {dt:.2f} s", "rc": rc}
+    if m == n:
+        line["cpu_baseline"]["root_matches_gpu"] = cout.tobytes() == out.tobytes()
+except Exception as e:  # (the GPU line stands without it)
+    line["cpu_baseline"] = {"error": repr(e)}
 print(json.dumps(line))
