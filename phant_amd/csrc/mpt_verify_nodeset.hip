@@ -19,12 +19,14 @@
 //                        its own (only atomics ever touch the claim words), the record = {digest, byte offset, length,
 //                        canonical-full-branch bit, epoch} in a 64-byte line of its own (plain stores: read by the next
 //                        kernel only).  A slot whose claim word carries an older epoch is free: no table is ever cleared.
-//   set_late_kernel      the nodes the record table did not take -- the slot's tag equalled theirs (an exact duplicate, or a
-//                        2^-32 coincidence), or PROBE_CAP slots were taken -- go, digest and all, to an overflow list and from
-//                        there into a second table that resolves duplicates exactly (compare-and-swap + a comparison of the
-//                        two digests, both written by the previous kernel).  On a witness of distinct nodes the list is
-//                        empty and the kernel returns at once.  (A witness of 350 000 copies of ONE node costs three atomics
-//                        on one address per copy -- milliseconds, linear --, never a probe chain of its own copies.)
+//                        A node the record table does not take -- the slot's tag equals its own (an exact duplicate, or a 2^-32
+//                        coincidence), or PROBE_CAP slots were taken -- goes, digest and all, to an overflow list and, by the same
+//                        lane, into a second table that resolves duplicates exactly (compare-and-swap, then a comparison with the
+//                        digest of the entry it met: written by that entry's lane BEFORE its compare-and-swap, read behind a
+//                        fence).  On a witness of distinct nodes nobody takes this way.  (A witness of 350 000 copies of ONE
+//                        node costs three atomics on one address per copy -- milliseconds, linear --, never a probe chain of its
+//                        own copies.  Until round 6 this was a kernel of its own between the hashing and the walk: 4-5 us of
+//                        every launch for a list that is empty.)
 //   set_walk_kernel      one lane per key, from its root: a reference costs ONE 48-byte record fetch (digest compared in
 //                        full, the node's place and form in the same line), a canonical full branch one 32-byte fetch of the
 //                        child reference for the key's nibble, anything else is staged into LDS and decoded (mpt_walk.hip.h,
@@ -148,6 +150,32 @@ __global__ void __launch_bounds__(256) set_classify_kernel(const Args a) {
 // one-permutation waves fill what is left); order 1: by rising count (A/B)
 PHANT_DEV uint32_t queue_class_o(uint32_t li, uint32_t order) { return queue_class(order ? (N_QUEUE - STRIPES) - (li / STRIPES) * STRIPES + li % STRIPES : li); }
 
+// An overflow node into the second table: an entry names an overflow node of THIS launch or is free; two nodes with the same
+// digest: one of them is enough.  The entry it meets may have been written by another wave of the same kernel: its digest is read
+// behind the compare-and-swap that returned the entry's index and a fence (the writer: digest, fence, compare-and-swap).
+PHANT_DEV bool same_digest(const uint4& x0, const uint4& x1, const uint4& y0, const uint4& y1) {
+    return ((x0.x ^ y0.x) | (x0.y ^ y0.y) | (x0.z ^ y0.z) | (x0.w ^ y0.w) | (x1.x ^ y1.x) | (x1.y ^ y1.y) | (x1.z ^ y1.z) | (x1.w ^ y1.w)) == 0u;
+}
+PHANT_DEV void thin_insert(const Args& a, uint32_t k, const uint4& d0, const uint4& d1, uint32_t h) {
+    const unsigned long long mine = ((unsigned long long)a.epoch << 32) | (unsigned long long)(k + 1u);
+    uint32_t slot = thin_home(h) & a.thin_mask;
+    for (;;) {  // the table has >= 2 x total_nodes slots: terminates
+        unsigned long long cur = atomicAdd(&a.thin[slot], 0ull);
+        if ((uint32_t)(cur >> 32) != a.epoch) {
+            const unsigned long long old = atomicCAS(&a.thin[slot], cur, mine);
+            if (old == cur) break;  // this node's
+            cur = old;
+            if ((uint32_t)(cur >> 32) != a.epoch) continue;  // (what was read was older than what is there: once more)
+        }
+        __threadfence();
+        const uint32_t k2 = (uint32_t)cur - 1u;
+        const uint4* const o = a.ov_dig + 2ull * k2;
+        const uint4 y0 = o[0], y1 = o[1];
+        if (same_digest(d0, d1, y0, y1)) break;
+        slot = (slot + 1u) & a.thin_mask;
+    }
+}
+
 // The record of the node the lane has just hashed.  Called by every lane of the wave (the overflow list takes one reservation
 // per wave); `real` = the lane has a node of its own to record.
 PHANT_DEV void insert_record(const Args& a, const Sponge& s, uint64_t b, uint32_t len_canon, uint32_t j, bool real) {
@@ -166,7 +194,7 @@ PHANT_DEV void insert_record(const Args& a, const Sponge& s, uint64_t b, uint32_
             placed = true;
             break;
         }
-        if ((uint32_t)old == tag) break;  // its own copy, as far as 32 more bits can tell: settled exactly by set_late_kernel
+        if ((uint32_t)old == tag) break;  // its own copy, as far as 32 more bits can tell: settled exactly in the second table (thin_insert)
         slot = (slot + 1u) & a.mask;
     }
     // the overflow list: one reservation per wave
@@ -176,12 +204,15 @@ PHANT_DEV void insert_record(const Args& a, const Sponge& s, uint64_t b, uint32_
         uint32_t base = 0;
         if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&a.hdr[HDR_OVF + 32u * (a.epoch & 1u)], (uint32_t)__popcll(m));
         base = lane_u32(base, (uint32_t)__builtin_ctzll(m));
+        const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint4 d0 = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]), d1 = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
         if (!placed) {
-            const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             a.ov_ent[k] = make_uint4((uint32_t)b, (uint32_t)(b >> 32), len_canon, j);
-            a.ov_dig[2ull * k] = make_uint4(s.lo[0], s.hi[0], s.lo[1], s.hi[1]);
-            a.ov_dig[2ull * k + 1u] = make_uint4(s.lo[2], s.hi[2], s.lo[3], s.hi[3]);
+            a.ov_dig[2ull * k] = d0;
+            a.ov_dig[2ull * k + 1u] = d1;
         }
+        __threadfence();  // the entry before the word that names it
+        if (!placed) thin_insert(a, k, d0, d1, h);
     }
 }
 
@@ -238,34 +269,6 @@ template <int FORM>
 __global__ void __launch_bounds__(256, FORM == 2 ? 3 : 4) set_hash_kernel(const Args a) {
     const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     hash_chunks<FORM>(a, q, gridDim.x * 4u, threadIdx.x & 63u);
-}
-
-// ---------------------------------------------------------------- the overflow list -> the second table
-PHANT_DEV bool same_digest(const uint4& x0, const uint4& x1, const uint4& y0, const uint4& y1) {
-    return ((x0.x ^ y0.x) | (x0.y ^ y0.y) | (x0.z ^ y0.z) | (x0.w ^ y0.w) | (x1.x ^ y1.x) | (x1.y ^ y1.y) | (x1.z ^ y1.z) | (x1.w ^ y1.w)) == 0u;
-}
-
-// A bounded grid strides over the overflow list (empty on a witness of distinct nodes).  An entry of the second table names an
-// overflow node of THIS launch or is free; two nodes with the same digest: one of them is enough.
-__global__ void __launch_bounds__(256) set_late_kernel(const Args a) {
-    const uint32_t ovf = a.hdr[HDR_OVF + 32u * (a.epoch & 1u)];
-    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < ovf; k += gridDim.x * 256u) {
-        const uint4 d0 = a.ov_dig[2ull * k], d1 = a.ov_dig[2ull * k + 1u];
-        const unsigned long long mine = ((unsigned long long)a.epoch << 32) | (unsigned long long)(k + 1u);
-        uint32_t slot = thin_home(home_hash(d0.x, d0.y, a.salt0, a.salt1)) & a.thin_mask;
-        for (;;) {  // the table has >= 2 x total_nodes slots: terminates
-            unsigned long long cur = a.thin[slot];
-            if ((uint32_t)(cur >> 32) != a.epoch) {
-                const unsigned long long old = atomicCAS(&a.thin[slot], cur, mine);
-                if (old == cur) break;  // this node's
-                cur = old;
-                if ((uint32_t)(cur >> 32) != a.epoch) continue;  // (what was read was older than what is there: once more)
-            }
-            const uint32_t k2 = (uint32_t)cur - 1u;
-            if (k2 < ovf && same_digest(d0, d1, a.ov_dig[2ull * k2], a.ov_dig[2ull * k2 + 1u])) break;
-            slot = (slot + 1u) & a.thin_mask;
-        }
-    }
 }
 
 // ---------------------------------------------------------------- walk
@@ -580,8 +583,6 @@ hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, 
         if (tune.form == 2u) hipLaunchKernelGGL(set_hash_kernel<2>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
         else if (tune.form == 1u) hipLaunchKernelGGL(set_hash_kernel<1>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
         else hipLaunchKernelGGL(set_hash_kernel<0>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
-        const uint32_t late = ng < 256u ? ng : 256u;
-        hipLaunchKernelGGL(set_late_kernel, dim3(late), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(set_walk_kernel, dim3((v.n + 255u) / 256u), dim3(256), 0, st, a);
     return hipGetLastError();
