@@ -73,6 +73,7 @@ struct TrieTune {
     bool sort_no_fallback = false;   // state root: an undecided device sort is an error instead of a host sort (tests)
     int64_t sort_prefix_bits = -1;   // state root: the device sort on this many key bits, ties left undecided (tests)
     int64_t sort_repair_bits = -1;   // ... ties repaired (tests)
+    int64_t small_max_keys = -1;     // up to this many keys a call takes the two-launch pass (trie_build.hip: small_head_kernel; 0: never)
 };
 
 // The arenas a ctx lends to the host-form entry points.
@@ -113,6 +114,15 @@ struct Workspaces {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&side_join, hipEventDisableTiming);
         return e;
     }
+    // the small pass's persistent words (trie_build.hip: the call's flags, a count of workgroups), zeroed when allocated and by
+    // every call's last workgroup
+    uint32_t* small_state = nullptr;
+    hipError_t ensure_small(size_t bytes) {
+        if (small_state) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&small_state), bytes);
+        if (e == hipSuccess) e = hipMemset(small_state, 0, bytes);
+        return e;
+    }
     // the pinned twin of a device address inside `io`
     template <class T>
     T* staged(T* d) const {
@@ -126,6 +136,8 @@ struct Workspaces {
         stage = nullptr;
         if (mailbox) (void)hipHostFree(mailbox);
         mailbox = nullptr;
+        if (small_state) (void)hipFree(small_state);
+        small_state = nullptr;
         if (side_fork) (void)hipEventDestroy(side_fork);
         if (side_join) (void)hipEventDestroy(side_join);
         if (side) (void)hipStreamDestroy(side);

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) first_flag_kernel(TrieDev t) {
 }
 
 // lcp + strict-order check (mpt.zig:39 asserts sorted; distinct keys assumed), element i <= n
-PHANT_DEV void lcp_element(const TrieDev& t, const uint32_t i) {
+PHANT_DEV void lcp_element(const TrieDev& t, const uint32_t i, const bool starts) {
     int32_t v = -1;
     // The device-resident form cannot look at the offsets on the host: a key longer than 255 bytes, or offsets that go
     // backwards (the difference wraps), would index the depth counters of the kernels behind this one out of bounds.  Such a
@@ -134,7 +134,7 @@ PHANT_DEV void lcp_element(const TrieDev& t, const uint32_t i) {
         }
         if (i > 0 && t.key_off[i] - t.key_off[i - 1] > MAX_KEY_BYTES) sane = false;
     }
-    const bool inner = i > 0 && i < t.n && !(t.first_flag && t.first_flag[i]);  // (first_flag null: ONE trie, no start but key 0)
+    const bool inner = i > 0 && i < t.n && !starts;
     if (inner && !sane) v = 0;
     if (inner && sane) {
         const uint32_t la = t.key_off[i] - t.key_off[i - 1], lb = t.key_off[i + 1] - t.key_off[i];
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) lcp_kernel(TrieDev t) {
     if (i <= t.n) {
         t.value_key[i] = NONE;
         t.dense[i] = NONE;
-        lcp_element(t, i);
+        lcp_element(t, i, t.first_flag && t.first_flag[i]);  // (first_flag null: ONE trie, no start but key 0)
     } else if (i < t.lvl_size[0]) {
         t.lcp[i] = INF_LCP;
     }
@@ -883,7 +883,7 @@ struct BranchPlan {
     const uint8_t* v;
     int32_t d, pd;
 };
-PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t* list, const uint32_t at, const bool live) {
+PHANT_DEV BranchPlan branch_plan_node(const TrieDev& t, const uint32_t node, const bool live) {
     BranchPlan p;
     p.live = live;
     p.i = p.dn = p.total = 0;
@@ -891,7 +891,7 @@ PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t* list, const u
     p.v = nullptr;
     p.full = false;
     if (live) {
-        p.i = list[at];
+        p.i = node;
         p.dn = t.dense[p.i];
         // the 16 slot lengths: one aligned 16-byte load
         const uint4 sl4 = *reinterpret_cast<const uint4*>(t.slot_len + (uint64_t)p.dn * 16u);
@@ -922,6 +922,9 @@ PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t* list, const u
     // the others reserve room in the scratch blob
     p.need = (live && !p.staged) ? (((p.total + 3u) & ~3u) + ((p.ext_cap + 3u) & ~3u)) : 0u;
     return p;
+}
+PHANT_DEV BranchPlan branch_plan(const TrieDev& t, const uint32_t* list, const uint32_t at, const bool live) {
+    return branch_plan_node(t, live ? list[at] : 0u, live);
 }
 // built in the lane's LDS slot (BRANCH_STAGE_DW dwords) / at byte `at` of the scratch blob, hashed, the extension above it
 // likewise, delivered to the parent's slot table
@@ -1299,17 +1302,14 @@ PHANT_DEV void wave_keccak256(const WaveLane& c, const uint32_t* buf, uint32_t n
         wave_permute(c, lo, hi);
     }
 }
-__global__ void __launch_bounds__(256) branch_wave_kernel(TrieDev t, uint32_t begin, uint32_t count) {
-    __shared__ uint32_t s_node[4][BRANCH_STAGE_DW];
-    const uint32_t tid = threadIdx.x, wv = tid >> 6, l = tid & 63u;
-    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + wv;  // (workgroups of four waves, or of one: see the launch)
-    if (q >= count) return;  // (the whole wave; no workgroup barrier below)
-    const uint32_t node = t.order[begin + q];
-    const uint32_t dn = t.dense[node], parent = t.nd_parent[node], lkey = t.nd_l[node], vk = t.value_key[node];
-    const int32_t d = t.lcp[node], pd = t.nd_pd[node];
+// the branch node whose representative boundary is `node` (of depth d), by the whole wave (l: the lane); buf: BRANCH_STAGE_DW
+// dwords of LDS of the wave's own
+PHANT_DEV void branch_wave_node(const TrieDev& t, const uint32_t node, const int32_t d, const uint32_t parent, uint32_t* const buf,
+                                 const uint32_t l) {
+    const uint32_t dn = t.dense[node], lkey = t.nd_l[node], vk = t.value_key[node];
+    const int32_t pd = t.nd_pd[node];
     const uint32_t ext_len = (uint32_t)(d - (pd + 1));
     const bool is_root = parent == NONE;
-    uint32_t* const buf = s_node[wv];
     uint8_t* const b = reinterpret_cast<uint8_t*>(buf);
     // ---- the 17-item list (mpt.zig:216-231), sixteen lanes a child each ----
     for (uint32_t k = l; k < BRANCH_STAGE_DW; k += 64u) buf[k] = 0u;
@@ -1330,7 +1330,7 @@ __global__ void __launch_bounds__(256) branch_wave_kernel(TrieDev t, uint32_t be
     const bool plain = vk == NONE && !(is_root && t.root_enc) && (ext_len == 0u || (total >= 32u && 44u + ext_len / 2u < BRANCH_STAGE_BYTES));
     if (!plain) {
         if (l == 0) {
-            const BranchPlan p = branch_plan(t, t.order, begin + q, true);
+            const BranchPlan p = branch_plan_node(t, node, true);
             branch_emit<BRANCH_STAGE_DW>(t, p, buf, p.need ? atomicAdd(t.cursor, (unsigned long long)p.need) : 0ull);
         }
         return;
@@ -1401,6 +1401,212 @@ __global__ void __launch_bounds__(256) branch_wave_kernel(TrieDev t, uint32_t be
     }
     if (l == 0 && !is_root) t.slot_len[slot] = 32;
 }
+__global__ void __launch_bounds__(256) branch_wave_kernel(TrieDev t, uint32_t begin, uint32_t count) {
+    __shared__ uint32_t s_node[4][BRANCH_STAGE_DW];
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, l = tid & 63u;
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + wv;  // (workgroups of four waves, or of one: see the launch)
+    if (q >= count) return;  // (the whole wave; no workgroup barrier below)
+    const uint32_t node = t.order[begin + q];
+    branch_wave_node(t, node, t.lcp[node], t.nd_parent[node], s_node[wv], l);
+}
+
+// ---- small tries: the whole pass in TWO launches ----
+// A block's transaction / receipt / withdrawal tries (src/blockchain/blockchain.zig:198-204,209-235: a few hundred items at most)
+// cost the pass above its chain of launches, not its work: ~12 kernels one behind the other, the host in between, a lane's 9-us
+// sponge per level -- 0.26 ms for 100 items, which one CPU core does in 0.1.  Up to SMALL_MAX_KEYS keys (all tries of the call
+// together):
+//
+//   small_head_kernel   ONE workgroup of 1 024 lanes.  A lane per boundary: lcp_element (a forest's trie starts by binary search: no
+//                flag array), the markers, the slot lengths, empty roots -- the lcp array stays in LDS as well and the min-tree is
+//                built over it THERE (<= 2 224 ints); then a lane per key asks identify_element's queries against LDS.  A node's
+//                dense id is its boundary (no ranking, no depth lists: `order` / `order2` hold the nodes' child counts here).
+//   small_climb_kernel  a WAVE per key: the leaf's bytes into the wave's LDS buffer -- header and hex-prefix path by the first lane,
+//                the value sixteen bytes per lane --, hashed from there by the one-state-per-wave sponge (coop_sponge.hip.h:
+//                3.8-5.2 us a permutation instead of a lane's 9), sixteen rate blocks at a time for as long as the leaf is (a
+//                30 KB transaction takes the same way as a 100-byte one); its reference into its parent's slot table, then ONE
+//                count on the parent: the wave that brings a node's LAST child goes on with that node (branch_wave_node), and so
+//                on up to the root.  No level waits for another: a call takes as long as its longest chain, not as the sum of
+//                every level's slowest node (six levels under a block's 400-item lists), and nothing in the kernel waits at all
+//                (what orders a child's reference before its parent's reader: the reference, a fence, the count; the count, a
+//                fence, the references).  How many children a node has: the boundaries of its depth inside its interval all
+//                have the node as their representative (identify_element's R) -- they count themselves there in the first kernel
+//                (+ 1, - 1 for a value in the branch).  The workgroup that leaves last hands the flags to the mailbox and clears
+//                the counters for the next call.
+//
+// (Measured on the way, profiles/r6_explore/NOTES.md section 3: the same phases inside ONE kernel with a barrier across the grid
+// between them -- 2 us faster than launches of their own up to ~100 workgroups, 40 us slower at 300, and a kernel that waits for
+// workgroups that may not be resident; and a launch per trie depth, which is what the general pass does.)
+constexpr uint32_t SMALL_MAX_KEYS = 2048;
+constexpr uint32_t SMALL_MAX_WGS = 512;
+constexpr uint32_t SMALL_HEAD_LANES = 1024;
+constexpr uint32_t SMALL_BUF_BLOCKS = 16;
+constexpr uint32_t SMALL_BUF_DW = SMALL_BUF_BLOCKS * RATE_DWORDS + 4u;  // (a multiple of four: a wave's buffer starts on a 16-byte boundary)
+constexpr uint32_t SMALL_PRE_BYTES = 288;  // list header (<= 9) + hex-prefix string (<= 3 + 256) + value header (<= 9), rounded
+constexpr uint32_t SMALL_LCP_INTS = (SMALL_MAX_KEYS + 1u + FAN - 1u) / FAN * FAN + 256u;  // level 0 + the levels above it (<= 144 + 16) + slack
+static_assert(SMALL_BUF_DW >= BRANCH_STAGE_DW, "a wave's buffer holds a branch node");
+// Workspaces::small_state, in words: the flags of the call (lcp_element's and the scratch blob's: t.counters points here) and the
+// count of workgroups that have left the second kernel -- zeroed when allocated and by every call's last workgroup
+constexpr uint32_t SS_EXITED = 1, SS_COUNTERS = 8, SS_WORDS = 64;
+
+// LeafNode (mpt.zig:54-56 / :254-261) of key i by a whole wave; buf: SMALL_BUF_DW dwords, pre: SMALL_PRE_BYTES bytes of the wave's own
+PHANT_DEV void leaf_wave_node(const TrieDev& t, const uint32_t i, uint32_t* const buf, uint8_t* const pre, const uint32_t l) {
+    const LeafPlan p = leaf_plan(t, i);
+    if (!p.live) return;
+    const uint32_t parent = t.leaf_parent[i];
+    const bool is_root = parent == NONE;
+    const bool hashed = p.total >= 32u || is_root;
+    uint8_t* const b = reinterpret_cast<uint8_t*>(buf);
+    const uint32_t total = p.total, off = total - (uint32_t)p.vlen;  // (what stands in front of the value's bytes)
+    if (l == 0) {
+        uint8_t* w = put_hdr(pre, p.payload, 0xc0u, 0xf7u);
+        w = put_hp(w, t, i, p.ps, p.nl, true);
+        if (!(p.vlen == 1 && p.v[0] < 0x80u)) (void)put_hdr(w, p.vlen, 0x80u, 0xb7u);
+    }
+    const uint32_t tr = is_root ? trie_of(t, i) : 0u;
+    const bool want_enc = is_root && t.root_enc;
+    if (want_enc && l == 0) t.root_enc_len[tr] = total;
+    const uint64_t slot = is_root ? 0ull : (uint64_t)t.dense[parent] * 16u + (p.ps ? nib_at(t, i, p.ps - 1u) : 0u);
+    const uint32_t nb = blocks_of(total);
+    const WaveLane c = wave_lane(l);
+    uint32_t lo = 0, hi = 0;
+    PHANT_WAVE_LDS_SYNC();  // (the first lane's bytes are in `pre`)
+    for (uint32_t first = 0; first < nb; first += SMALL_BUF_BLOCKS) {
+        const uint32_t nbc = nb - first < SMALL_BUF_BLOCKS ? nb - first : SMALL_BUF_BLOCKS;
+        const uint32_t b0 = first * RATE, b1 = b0 + nbc * RATE;
+        // bytes [b0, b1) of the padded message, sixteen per lane and trip: a piece that lies inside the value is ONE unaligned
+        // 16-byte load and one LDS store (a byte per lane and trip was 34 dependent loads per sixteen blocks); the pieces around
+        // it -- the header and path in front, the padding behind -- byte by byte
+        struct __attribute__((packed, aligned(1))) Piece { uint32_t x, y, z, w; };
+        for (uint32_t k0 = b0 + 16u * l; k0 < b1; k0 += 16u * 64u) {
+            uint4 q;
+            if (k0 >= off && k0 + 16u <= total) {
+                const Piece v = *reinterpret_cast<const Piece*>(p.v + (k0 - off));
+                q = make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                uint32_t d[4] = {0u, 0u, 0u, 0u};
+                for (uint32_t c = 0; c < 16u; ++c) {
+                    const uint32_t k = k0 + c;
+                    uint32_t v = k < off ? pre[k] : (k < total ? p.v[k - off] : (k == total ? 0x01u : 0u));
+                    if (k == nb * RATE - 1u) v |= 0x80u;
+                    d[c >> 2] |= v << (8u * (c & 3u));
+                }
+                q = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            *reinterpret_cast<uint4*>(b + (k0 - b0)) = q;
+            if (want_enc && k0 < total && total <= t.root_enc_cap) {
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                for (uint32_t c = 0; c < 16u && k0 + c < total; ++c) t.root_enc[(uint64_t)tr * t.root_enc_cap + k0 + c] = (uint8_t)(w[c >> 2] >> (8u * (c & 3u)));
+            }
+        }
+        PHANT_WAVE_LDS_SYNC();  // (every lane's bytes are in the buffer)
+        if (hashed) {
+            for (uint32_t k = 0; k < nbc; ++k) {
+                if (c.word < 17u) {  // (a copy absorbs what its column's lane absorbs)
+                    lo ^= buf[k * RATE_DWORDS + 2u * c.word];
+                    hi ^= buf[k * RATE_DWORDS + 2u * c.word + 1u];
+                }
+                wave_permute(c, lo, hi);
+            }
+        } else if (l == 0) {  // (shorter than 32 bytes: embedded, mpt.zig:104,:112 -- one chunk)
+            for (uint32_t k = 0; k < total; ++k) t.slot_bytes[slot * 32u + k] = b[k];
+            t.slot_len[slot] = (uint8_t)total;
+        }
+        PHANT_WAVE_LDS_SYNC();  // (every lane has read the buffer)
+    }
+    if (hashed && l < 4u) {
+        uint32_t* const dst = reinterpret_cast<uint32_t*>(is_root ? t.roots + 32ull * tr : t.slot_bytes + slot * 32u);
+        dst[2u * l] = lo;
+        dst[2u * l + 1u] = hi;
+    }
+    if (hashed && l == 0 && !is_root) t.slot_len[slot] = 32;
+}
+
+__global__ void __launch_bounds__(SMALL_HEAD_LANES) small_head_kernel(TrieDev t) {
+    __shared__ alignas(16) int32_t s_lcp[SMALL_LCP_INTS];  // (a group of the min-tree is one 16-byte-aligned 64-byte load)
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < t.lvl_size[0]; i += SMALL_HEAD_LANES) {
+        if (i <= t.n) {
+            t.value_key[i] = NONE;
+            t.dense[i] = NONE;
+            if (i < t.n) {
+                reinterpret_cast<uint4*>(t.slot_len)[i] = make_uint4(0u, 0u, 0u, 0u);
+                t.order[i] = 0u;   // boundaries of the node's depth inside its interval (its children - 1)
+                t.order2[i] = 0u;  // children that have delivered
+            }
+            const bool starts = i > 0 && i < t.n && t.n_tries > 1u && t.seg_first[trie_of(t, i)] == i;
+            lcp_element(t, i, starts);
+            s_lcp[i] = t.lcp[i];  // (what the lane has just stored)
+        } else {
+            s_lcp[i] = INF_LCP;
+        }
+    }
+    for (uint32_t r = tid; r < t.n_tries; r += SMALL_HEAD_LANES) store_empty_root(t.roots + 32ull * r);
+    if (tid == 0) *t.cursor = 0ull;
+    __syncthreads();
+    if (t.counters[1] != 0u) return;  // (keys lcp_element refused: the second kernel does nothing but end the call)
+    int32_t* const tree = s_lcp + t.lvl_size[0];
+    for (uint32_t k = 1; k < t.n_lvl; ++k) {
+        const int32_t* const src = k == 1u ? s_lcp : tree + t.lvl_off[k - 1u];
+        for (uint32_t q = tid; q < t.lvl_size[k]; q += SMALL_HEAD_LANES) tree[t.lvl_off[k] + q] = q * FAN < t.lvl_size[k - 1u] ? group_min(src + q * FAN) : INF_LCP;
+        __syncthreads();
+    }
+    TrieDev tl = t;
+    tl.lcp = s_lcp;
+    tl.tree = tree;
+    for (uint32_t i = tid; i < t.n; i += SMALL_HEAD_LANES) {
+        int32_t d, leaf_under, node_under;
+        if (identify_element(tl, i, d, leaf_under, node_under)) t.dense[i] = i;
+        const uint32_t rep = t.nd_rep[i];  // (what identify_element has just stored: NONE where boundary i is a trie's start)
+        if (rep != NONE) atomicAdd(&t.order[rep], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) small_climb_kernel(TrieDev t, uint32_t* state) {
+    __shared__ alignas(16) uint32_t s_buf[4][SMALL_BUF_DW];
+    __shared__ uint8_t s_pre[4][SMALL_PRE_BYTES];
+    __shared__ uint32_t s_last;
+    const uint32_t tid = threadIdx.x, l = tid & 63u, wv = tid >> 6;
+    const uint32_t gw = blockIdx.x * 4u + wv, waves = gridDim.x * 4u;
+    if (t.counters[1] == 0u) {
+        for (uint32_t i = gw; i < t.n; i += waves) {
+            if (t.leaf_ps[i] == BRANCH_VALUE) continue;  // (the value of a branch: that node carries it)
+            leaf_wave_node(t, i, s_buf[wv], s_pre[wv], l);
+            uint32_t node = t.leaf_parent[i];
+            while (node != NONE) {
+                __threadfence();  // (the reference before the count)
+                uint32_t arrived = 0;
+                if (l == 0) arrived = atomicAdd(&t.order2[node], 1u) + 1u;
+                arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+                const uint32_t need = t.order[node] + 1u - (t.value_key[node] != NONE ? 1u : 0u);
+                if (arrived != need) break;
+                __threadfence();  // (the count before the other children's references)
+                uint32_t parent = t.nd_parent[node];
+                if (parent != NONE && (parent & VIA)) parent = t.nd_rep[parent & ~VIA];  // (resolve_parent, in registers)
+                if (l == 0) t.nd_parent[node] = parent;                                   // (... and for the general way's reader, the same lane)
+                branch_wave_node(t, node, t.lcp[node], parent, s_buf[wv], l);
+                PHANT_WAVE_LDS_SYNC();  // (the buffer is the next node's)
+                node = parent;
+            }
+        }
+    }
+    // the workgroup that leaves last ends the call: the flags into the mailbox, the counters cleared for the next call, then the
+    // word the host waits for
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        s_last = atomicAdd(&state[SS_EXITED], 1u) == gridDim.x - 1u ? 1u : 0u;
+        __threadfence();
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < 3u) t.mailbox[tid] = state[SS_COUNTERS + tid];
+    __syncthreads();
+    if (tid < 8u) state[SS_COUNTERS + tid] = 0u;
+    if (tid == 0) state[SS_EXITED] = 0u;
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) *reinterpret_cast<volatile uint32_t*>(t.mailbox + MAILBOX_DONE) = t.mailbox_tag;
+}
 
 static_assert(BRANCH_STAGE_BYTES_ == BRANCH_STAGE_BYTES && BRANCH_STAGE_DW_ == BRANCH_STAGE_DW, "one slot size for big leaves and branches");
 __global__ void __launch_bounds__(BRANCH_LANES) leaf_big_kernel(TrieDev t) {
@@ -1442,6 +1648,74 @@ constexpr uint32_t SIDE_MIN_KEYS = 400000;    // below it the leaves are too few
 constexpr uint32_t SIDE_LEAF_LDS = 20480;     // bytes of unused dynamic LDS per leaf workgroup meanwhile: TWO of them per CU instead of four (with three,
                                               // 5 or 6 KB, the bins beside them still starved: 146-162 us for a bin of 116 nodes)
 constexpr uint32_t FALLBACK_GRID = 1024;           // workgroups of a bin's fallback pass (its count is on the device)
+
+// The small pass (small_head_kernel, small_climb_kernel): t holds the inputs, the outputs and the t1 arena's arrays.
+static int32_t small_forest(Workspaces& ws, hipStream_t st, TrieDev t, uint64_t total_key_bytes, uint64_t total_val_bytes, std::string& err) {
+    const uint32_t n = t.n;
+    TB_TRY(ws.ensure_small(SS_WORDS * 4u));
+    {   // slot tables by boundary (a node's dense id is its boundary: < n) + the scratch blob of the nodes that take the general way
+        const uint64_t cap = total_val_bytes + total_key_bytes + (uint64_t)n * (32 + 3 + 16 * 33 + 16 + 48 + 127 + 16) + 4096;
+        TB_TRY(ws.t2.reset(DevArena::round((size_t)n * 16 * 32) + DevArena::round(cap) + 1024));
+        t.slot_bytes = ws.t2.take<uint8_t>((size_t)n * 16 * 32);
+        t.scratch = ws.t2.take<uint8_t>(cap);
+        t.scratch_cap = cap;
+        if (ws.t2.overflowed || !t.scratch) {
+            err = "trie slot tables sized too small (internal)";
+            return PHANT_E_DEVICE;
+        }
+    }
+    uint32_t* const state = ws.small_state;
+    t.counters = state + SS_COUNTERS;
+    t.first_flag = nullptr;
+    volatile uint32_t* const mbox = ws.mailbox;
+    t.mailbox = ws.mailbox;
+    t.mailbox_tag = mbox[MAILBOX_READY] + 1u;
+    if (t.mailbox_tag == 0u) t.mailbox_tag = 1u;
+    mbox[MAILBOX_READY] = t.mailbox_tag;  // (the small pass has no use for this word but the next call counts on from it)
+    struct MainGuard {
+        hipStream_t s;
+        bool armed = true;
+        ~MainGuard() {
+            if (armed) (void)hipStreamSynchronize(s);
+        }
+    } main_guard{st};
+    auto wait_done = [&]() -> int32_t {
+        for (uint32_t spins = 1; mbox[MAILBOX_DONE] != t.mailbox_tag; ++spins) {
+            if (spins % 4096u) continue;
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipErrorNotReady) continue;
+            TB_TRY(q);
+            if (mbox[MAILBOX_DONE] != t.mailbox_tag) {
+                err = "the trie builder's flags did not reach the mailbox (internal)";
+                return PHANT_E_DEVICE;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return PHANT_OK;
+    };
+    const uint32_t G = std::max(1u, std::min(SMALL_MAX_WGS, (n + 3u) / 4u));
+    hipLaunchKernelGGL(small_head_kernel, dim3(1), dim3(SMALL_HEAD_LANES), 0, st, t);
+    hipLaunchKernelGGL(small_climb_kernel, dim3(G), dim3(256), 0, st, t, state);
+    TB_TRY(hipGetLastError());
+    {
+        const int32_t rc = wait_done();
+        if (rc) return rc;
+    }
+    main_guard.armed = false;
+    if (ws.mailbox[1] & ERR_KEY_RANGE) {
+        err = "key longer than 255 bytes, or key offsets not monotone";
+        return PHANT_E_INVALID_ARG;
+    }
+    if (ws.mailbox[1] & ERR_UNSORTED) {
+        err = "keys are not strictly increasing (mpt.zig:39)";
+        return PHANT_E_UNSORTED;
+    }
+    if (ws.mailbox[2]) {
+        err = "trie scratch overflow (internal bound too small)";
+        return PHANT_E_DEVICE;
+    }
+    return PHANT_OK;
+}
 
 // Device-side forest build; all pointers device memory, except roots_host.
 static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_keys, const uint32_t* d_key_off,
@@ -1521,6 +1795,10 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
 
     // head (roots, counters, a forest's start flags) -> [first_flag] -> lcp (+ markers, + the min-tree's padding): three or two
     // launches where there were five.  ONE trie has no start but key 0 and goes without the flags.
+    {
+        const uint64_t small_max = ws.tune.small_max_keys >= 0 ? (uint64_t)std::min<int64_t>(ws.tune.small_max_keys, SMALL_MAX_KEYS) : SMALL_MAX_KEYS;
+        if (n <= small_max) return small_forest(ws, st, t, total_key_bytes, total_val_bytes, err);
+    }
     if (n_tries == 1) t.first_flag = nullptr;
     {
         uint64_t lanes = N_COUNTERS;

@@ -108,13 +108,22 @@ def mptize_dev(keys: torch.Tensor, key_off: torch.Tensor, vals: torch.Tensor, va
     return out
 
 
+def pack_items(items):
+    """-> (blob u8[], off u64[n + 1]): a list's encoded items back to back, the form phant_index_root_rlp / phant_block_roots take
+    (and a compiled caller holds them in: src/blockchain/blockchain.zig:213-232 encodes every item into one buffer)."""
+    return _pack([bytes(x) for x in items], np.uint64)
+
+
+def index_root_rlp_packed(blob: np.ndarray, off: np.ndarray, ctx: Context | None = None) -> bytes:
+    ctx = ctx or default_context()
+    out = np.zeros(32, np.uint8)
+    ctx.check(ctx._lib.phant_index_root_rlp(ctx.handle, _np_ptr(blob), _np_ptr(off), len(off) - 1, _np_ptr(out)))
+    return out.tobytes()
+
+
 def index_root_rlp(items, ctx: Context | None = None) -> bytes:
     """calculateMPTRoot (blockchain.zig:209-235): item i under key rlp(i)."""
-    ctx = ctx or default_context()
-    blob, off = _pack([bytes(x) for x in items], np.uint64)
-    out = np.zeros(32, np.uint8)
-    ctx.check(ctx._lib.phant_index_root_rlp(ctx.handle, _np_ptr(blob), _np_ptr(off), len(items), _np_ptr(out)))
-    return out.tobytes()
+    return index_root_rlp_packed(*pack_items(items), ctx)
 
 
 def block_roots(lists, ctx: Context | None = None) -> list[bytes]:
@@ -122,12 +131,16 @@ def block_roots(lists, ctx: Context | None = None) -> list[bytes]:
     call: `lists` = the encoded items of every index-keyed trie of the block (key rlp(index), as index_root_rlp); all of
     them go through the trie hasher as one forest, so its level-by-level latency is paid once (phant_block_roots).
     -> one 32-byte root per list (empty_mpt_root for an empty one)."""
+    return block_roots_packed([pack_items(items) for items in lists], ctx)
+
+
+def block_roots_packed(packed, ctx: Context | None = None) -> list[bytes]:
+    """block_roots over lists that are packed already: [(blob, off), ...] as pack_items returns them."""
     ctx = ctx or default_context()
-    packed = [_pack([bytes(x) for x in items], np.uint64) for items in lists]
-    k = len(lists)
+    k = len(packed)
     item_p = (C.c_void_p * max(k, 1))(*[_np_ptr(b).value if b.size else None for b, _ in packed])
     off_p = (C.c_void_p * max(k, 1))(*[_np_ptr(o).value for _, o in packed])
-    n = (C.c_uint32 * max(k, 1))(*[len(x) for x in lists])
+    n = (C.c_uint32 * max(k, 1))(*[len(o) - 1 for _, o in packed])
     out = np.zeros(32 * max(k, 1), np.uint8)
     ctx.check(ctx._lib.phant_block_roots(ctx.handle, item_p, off_p, n, k, _np_ptr(out), None, None, None, 0, 0, None))
     return [out[32 * i:32 * i + 32].tobytes() for i in range(k)]

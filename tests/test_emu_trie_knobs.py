@@ -19,14 +19,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUBSET = "random_vs_oracle or variable_length or state_root_random or block_roots or receipt_trie"
 
 
-@pytest.mark.parametrize("env", [{"PHANT_TEST_DIAG": "trie_slot_blocks=1,trie_fallback_grid=1"},
-                                 {"PHANT_TEST_DIAG": "trie_slot_blocks=2,trie_fallback_grid=1"},
-                                 {"PHANT_TEST_DIAG": "trie_side_min_keys=257"},
-                                 {"PHANT_TEST_DIAG": "trie_side_min_keys=257,trie_ahead_max_keys=0"},
-                                 {"PHANT_TEST_DIAG": "trie_no_coop=1"},
-                                 {"HIPEMU_FREE_BYTES": "1000"}],
-                         ids=["one_block_slots", "two_block_slots", "deepest_bins_beside_the_leaves", "leaves_behind_the_node_count",
-                              "lane_per_node_bins_only", "no_room_for_the_worst_case_tables"])
+# (trie_small_max_keys=0: these tries are small enough for the one-launch pass of round 6, which has none of these choices: off)
+@pytest.mark.parametrize("env", [{"PHANT_TEST_DIAG": "trie_small_max_keys=0"},
+                                 {"PHANT_TEST_DIAG": "trie_small_max_keys=0,trie_slot_blocks=1,trie_fallback_grid=1"},
+                                 {"PHANT_TEST_DIAG": "trie_small_max_keys=0,trie_slot_blocks=2,trie_fallback_grid=1"},
+                                 {"PHANT_TEST_DIAG": "trie_small_max_keys=0,trie_side_min_keys=257"},
+                                 {"PHANT_TEST_DIAG": "trie_small_max_keys=0,trie_side_min_keys=257,trie_ahead_max_keys=0"},
+                                 {"PHANT_TEST_DIAG": "trie_small_max_keys=0,trie_no_coop=1"},
+                                 {"PHANT_TEST_DIAG": "trie_small_max_keys=0", "HIPEMU_FREE_BYTES": "1000"}],
+                         ids=["the_general_pass_for_small_tries", "one_block_slots", "two_block_slots", "deepest_bins_beside_the_leaves",
+                              "leaves_behind_the_node_count", "lane_per_node_bins_only", "no_room_for_the_worst_case_tables"])
 def test_slot_classes_and_fallback_lists(env):
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_emu_trie.py", "-x", "-q", "-p", "no:cacheprovider", "-k", SUBSET],
                        cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)

@@ -32,6 +32,10 @@ def main():
         lists = [mk(100, 300), mk(300, 700), mk(40, 60)]  # txs, receipts, withdrawals
         want = [M.index_root_rlp(x) for x in lists]
         assert M.block_roots(lists) == want
+        # what is timed: the C-ABI calls over lists that are packed already (blob + offsets: what a compiled caller holds), on
+        # both sides -- packing 1 200 Python byte strings per call costs more than the roots do
+        packed = [M.pack_items(x) for x in lists]
+        assert M.block_roots_packed(packed) == want
 
         def t(f, reps=30):
             for _ in range(3):
@@ -41,12 +45,18 @@ def main():
             for _ in range(reps):
                 f()
             torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / reps * 1e3
+            return (time.perf_counter() - t0) / reps * 1e3  # (the mean: a call that grows an arena is in it)
 
-        one = t(lambda: M.index_root_rlp(lists[1]))
-        three = t(lambda: [M.index_root_rlp(x) for x in lists])
-        forest = t(lambda: M.block_roots(lists))
+        one = t(lambda: M.index_root_rlp_packed(*packed[1]))
+        three = t(lambda: [M.index_root_rlp_packed(*x) for x in packed])
+        forest = t(lambda: M.block_roots_packed(packed))
         assert [O.index_root_rlp(x) for x in lists] == want
+        import ctypes as C
+        o_lib, o_out = O.lib(), np.zeros(32, np.uint8)
+        o_ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+
+        def o_root(blob, off):
+            assert o_lib.oracle_index_root_rlp(o_ptr(blob), o_ptr(off), len(off) - 1, o_ptr(o_out)) == 0
 
         def tc(f, budget=0.5):
             f()
@@ -56,8 +66,8 @@ def main():
                 reps += 1
             return (time.perf_counter() - t0) / reps * 1e3
 
-        cpu_one = tc(lambda: O.index_root_rlp(lists[1]))
-        cpu_three = tc(lambda: [O.index_root_rlp(x) for x in lists])
+        cpu_one = tc(lambda: o_root(*packed[1]))
+        cpu_three = tc(lambda: [o_root(*x) for x in packed])
         print(json.dumps({"items_per_list": n, "one_root_ms": round(one, 4), "three_calls_ms": round(three, 4),
                           "block_roots_ms": round(forest, 4), "block_roots_over_one_root": round(forest / one, 3),
                           "cpu_baseline": {"one_root_ms": round(cpu_one, 4), "three_roots_ms": round(cpu_three, 4), "cores": 1, "kind": "port",
