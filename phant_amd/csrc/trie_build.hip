@@ -1413,12 +1413,12 @@ __global__ void __launch_bounds__(256) branch_wave_kernel(TrieDev t, uint32_t be
 // ---- small tries: the whole pass in TWO launches ----
 // A block's transaction / receipt / withdrawal tries (src/blockchain/blockchain.zig:198-204,209-235: a few hundred items at most)
 // cost the pass above its chain of launches, not its work: ~12 kernels one behind the other, the host in between, a lane's 9-us
-// sponge per level -- 0.26 ms for 100 items, which one CPU core does in 0.1.  Up to SMALL_MAX_KEYS keys (all tries of the call
-// together):
+// sponge per level -- 0.26 ms for 100 items, which one CPU core does in 0.26 as well.  Up to SMALL_SURE_KEYS keys (all tries of the
+// call together; up to SMALL_MAX_KEYS where the values are long -- forest_device):
 //
 //   small_head_kernel   ONE workgroup of 1 024 lanes.  A lane per boundary: lcp_element (a forest's trie starts by binary search: no
 //                flag array), the markers, the slot lengths, empty roots -- the lcp array stays in LDS as well and the min-tree is
-//                built over it THERE (<= 2 224 ints); then a lane per key asks identify_element's queries against LDS.  A node's
+//                built over it THERE (<= 4 432 ints); then a lane per key asks identify_element's queries against LDS.  A node's
 //                dense id is its boundary (no ranking, no depth lists: `order` / `order2` hold the nodes' child counts here).
 //   small_climb_kernel  a WAVE per key: the leaf's bytes into the wave's LDS buffer -- header and hex-prefix path by the first lane,
 //                the value sixteen bytes per lane --, hashed from there by the one-state-per-wave sponge (coop_sponge.hip.h:
@@ -1436,13 +1436,14 @@ __global__ void __launch_bounds__(256) branch_wave_kernel(TrieDev t, uint32_t be
 // (Measured on the way, profiles/r6_explore/NOTES.md section 3: the same phases inside ONE kernel with a barrier across the grid
 // between them -- 2 us faster than launches of their own up to ~100 workgroups, 40 us slower at 300, and a kernel that waits for
 // workgroups that may not be resident; and a launch per trie depth, which is what the general pass does.)
-constexpr uint32_t SMALL_MAX_KEYS = 2048;
+constexpr uint32_t SMALL_MAX_KEYS = 4096;       // (what the first kernel's LDS holds)
+constexpr uint32_t SMALL_SURE_KEYS = 2048;      // up to here whatever the leaves are; beyond, where the mean value is a rate block or more
 constexpr uint32_t SMALL_MAX_WGS = 512;
 constexpr uint32_t SMALL_HEAD_LANES = 1024;
 constexpr uint32_t SMALL_BUF_BLOCKS = 16;
 constexpr uint32_t SMALL_BUF_DW = SMALL_BUF_BLOCKS * RATE_DWORDS + 4u;  // (a multiple of four: a wave's buffer starts on a 16-byte boundary)
 constexpr uint32_t SMALL_PRE_BYTES = 288;  // list header (<= 9) + hex-prefix string (<= 3 + 256) + value header (<= 9), rounded
-constexpr uint32_t SMALL_LCP_INTS = (SMALL_MAX_KEYS + 1u + FAN - 1u) / FAN * FAN + 256u;  // level 0 + the levels above it (<= 144 + 16) + slack
+constexpr uint32_t SMALL_LCP_INTS = (SMALL_MAX_KEYS + 1u + FAN - 1u) / FAN * FAN + 512u;  // level 0 + the levels above it (272 + 32 + 16 at the most) + slack
 static_assert(SMALL_BUF_DW >= BRANCH_STAGE_DW, "a wave's buffer holds a branch node");
 // Workspaces::small_state, in words: the flags of the call (lcp_element's and the scratch blob's: t.counters points here) and the
 // count of workgroups that have left the second kernel -- zeroed when allocated and by every call's last workgroup
@@ -1796,8 +1797,13 @@ static int32_t forest_device(Workspaces& ws, hipStream_t st, const uint8_t* d_ke
     // head (roots, counters, a forest's start flags) -> [first_flag] -> lcp (+ markers, + the min-tree's padding): three or two
     // launches where there were five.  ONE trie has no start but key 0 and goes without the flags.
     {
-        const uint64_t small_max = ws.tune.small_max_keys >= 0 ? (uint64_t)std::min<int64_t>(ws.tune.small_max_keys, SMALL_MAX_KEYS) : SMALL_MAX_KEYS;
-        if (n <= small_max) return small_forest(ws, st, t, total_key_bytes, total_val_bytes, err);
+        // Measured (profiles/r6_explore/NOTES.md section 3): one-block leaves (a state trie's) -- the two passes level at 2 048 keys, the
+        // general one ahead beyond (0.19 against 0.30 ms at 4 096); a block's lists (values of 50 .. 700 bytes: several permutations a
+        // leaf, which a wave's sponge runs at twice a lane's pace) -- ahead up to 3 x 1 000 items, level at 3 x 1 400.
+        const bool fits = n <= SMALL_MAX_KEYS && (size_t)t.lvl_size[0] + tree_ints + FAN <= SMALL_LCP_INTS;  // (the first kernel's LDS)
+        const bool by_default = fits && (n <= SMALL_SURE_KEYS || total_val_bytes >= (uint64_t)RATE * n);
+        const bool small = ws.tune.small_max_keys >= 0 ? fits && n <= (uint64_t)ws.tune.small_max_keys : by_default;
+        if (small) return small_forest(ws, st, t, total_key_bytes, total_val_bytes, err);
     }
     if (n_tries == 1) t.first_flag = nullptr;
     {

@@ -27,3 +27,12 @@ from tests.test_gpu_trie import (  # noqa: E402,F401
     test_sharded_mptize_matches_the_single_gpu_root)
 from tests.test_gpu_x_state_sharded import (  # noqa: E402,F401
     test_sharded_state_root_matches_the_fixture_roots, test_state_trie_leaves_and_random_states)
+
+
+def test_small_pass_beyond_its_sure_size(P, oracle):
+    """trie_build.hip's two-launch pass on 2 100 keys with values of a rate block and more (beyond 2 048 keys it is taken for long
+    values only; four levels of the min-tree in LDS): the -m gpu suite's test_mptize_small_pass_edges has the sizes up to 4 097."""
+    from tests.witness_util import random_kv
+    rng = np.random.default_rng(2100)
+    keys, vals = random_kv(rng, 2100, 4, 136, 200, 0)
+    assert P.mpt.mptize([P.mpt.KeyVal.init(k, v) for k, v in zip(keys, vals)]) == oracle.mptize(keys, vals)

@@ -45,6 +45,19 @@ def test_mptize_random_vs_oracle(P, oracle, n, key_len, shared, vmax):
     assert P.mpt.mptize(kvs) == oracle.mptize(keys, vals)
 
 
+@pytest.mark.parametrize("n,key_len,shared,vmax", [(2048, 32, 0, 60), (2049, 32, 0, 60), (3000, 32, 0, 400), (4096, 32, 0, 2600),
+                                                     (4097, 32, 0, 600), (40, 32, 0, 40000), (2100, 3, 0, 300), (600, 32, 60, 5000)])
+def test_mptize_small_pass_edges(P, oracle, n, key_len, shared, vmax):
+    """The two-launch pass for small tries (trie_build.hip: small_head_kernel, small_climb_kernel) where it begins and ends: its
+    last size with short values and the first beyond it; beyond 2 048 keys with long values (leaves of up to 20 rate blocks) up to
+    its very last size and the first beyond that; leaves of hundreds of rate blocks (sixteen at a time through the wave's buffer);
+    three-byte keys (a dense trie: full branches at every level) and keys that differ in their last two nibbles only (one long
+    extension over 600 leaves in two levels)."""
+    rng = np.random.default_rng(7 * n + vmax)
+    keys, vals = random_kv(rng, n, key_len, 1, vmax, shared)
+    assert P.mpt.mptize([P.mpt.KeyVal.init(k, v) for k, v in zip(keys, vals)]) == oracle.mptize(keys, vals)
+
+
 def test_mptize_device_form_matches_host_form_and_oracle(P, oracle):
     """phant_mpt_root_dev: the same trie from device-resident packed arrays -- reference vectors, random tries with
     fixed and variable-length keys, the empty trie; unsorted keys are refused."""
@@ -144,7 +157,8 @@ def test_block_roots_in_one_call(P, oracle):
     """phant_block_roots: every index-keyed trie of a block through the trie hasher as ONE forest (blockchain.zig:198-204).
     The reference's 87 transactionsTrie + 87 withdrawalsRoot fixture values, each block's pair from one call; then three
     lists per block with receipts-shaped items in the middle (the fixtures' receiptTrie needs the EVM: not a stand-alone
-    vector) against the oracle, lists of 0 / 1 / 127 / 128 / 129 / 400 items (the rlp(index) keys cross 0x80), no list at all."""
+    vector) against the oracle, lists of 0 / 1 / 127 / 128 / 129 / 400 items (the rlp(index) keys cross 0x80), a full block's 1 400 transactions and 1 300
+    receipts (the small tries' pass beyond 2 048 keys: long values), no list at all."""
     fx = golden.fixtures()
     n = 0
     for c in fx["cases"]:
@@ -161,7 +175,7 @@ def test_block_roots_in_one_call(P, oracle):
     assert n == 87
     rng = np.random.default_rng(11)
     mk = lambda k, lo, hi: [rng.integers(0, 256, int(rng.integers(lo, hi)), dtype=np.uint8).tobytes() for _ in range(k)]  # noqa: E731
-    for sizes in ((0, 0, 0), (1, 1, 0), (127, 127, 16), (128, 129, 1), (400, 400, 400), (3, 0, 129)):
+    for sizes in ((0, 0, 0), (1, 1, 0), (127, 127, 16), (128, 129, 1), (400, 400, 400), (3, 0, 129), (1400, 1300, 16)):
         lists = [mk(sizes[0], 100, 300), mk(sizes[1], 300, 700), mk(sizes[2], 40, 60)]
         got = P.mpt.block_roots(lists)
         assert got == [oracle.index_root_rlp(x) for x in lists], sizes

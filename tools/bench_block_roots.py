@@ -37,15 +37,17 @@ def main():
         packed = [M.pack_items(x) for x in lists]
         assert M.block_roots_packed(packed) == want
 
-        def t(f, reps=30):
+        def t(f, reps=40):  # (the median call: one call in a few hundred takes a millisecond or thirty -- a box's first seconds)
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            ts = []
             for _ in range(reps):
+                t0 = time.perf_counter()
                 f()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / reps * 1e3  # (the mean: a call that grows an arena is in it)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            return ts[len(ts) // 2] * 1e3
 
         one = t(lambda: M.index_root_rlp_packed(*packed[1]))
         three = t(lambda: [M.index_root_rlp_packed(*x) for x in packed])
