@@ -86,6 +86,7 @@ enum {
     PHANT_DIAG_SORT_NO_FALLBACK,      /* state root: != 0: an undecided device sort is an error, not a host sort (tests) */
     PHANT_DIAG_SORT_PREFIX_BITS,      /* state root: the device sort on this many key bits, ties left undecided (-1: its own choice) */
     PHANT_DIAG_SORT_REPAIR_BITS,      /* ... ties repaired (-1: its own choice) */
+    PHANT_DIAG_NODESET_WAVE_MAX,      /* node-set witnesses of up to this many nodes are hashed a node per wave (default 2 048; 0: never) */
     PHANT_DIAG_TRIE_SMALL_MAX_KEYS    /* trie hasher: up to this many keys a call takes the two-launch pass for small tries (-1: the default, 0: never) */
 };
 PHANT_API int32_t phant_diag_set(phant_ctx *ctx, uint32_t knob, int64_t value);

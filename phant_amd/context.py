@@ -88,7 +88,7 @@ class Context:
         "verify_serial", "verify_hash_lds_kb", "verify_no_coop", "verify_no_wave", "verify_coop_max", "stream_wgs", "stream_mb",
         "trie_no_side", "trie_side_min_keys", "trie_ahead_max_keys", "trie_side_lds", "trie_fallback_grid", "trie_slot_blocks",
         "trie_no_coop", "trie_coop_max", "trie_no_wave", "trie_join_in_stream", "sort_no_fallback", "sort_prefix_bits",
-        "sort_repair_bits", "trie_small_max_keys"))}
+        "sort_repair_bits", "nodeset_wave_max", "trie_small_max_keys"))}
 
     def diag_set(self, knob: str, value: int):
         """phant_diag_set: a per-ctx switch of a measured alternative or a test hook (the library reads no environment)."""

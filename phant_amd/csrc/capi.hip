@@ -391,6 +391,7 @@ int32_t phant_diag_set(phant_ctx* c, uint32_t knob, int64_t value) {
         case PHANT_DIAG_SORT_NO_FALLBACK: t.sort_no_fallback = value != 0; return PHANT_OK;
         case PHANT_DIAG_SORT_PREFIX_BITS: t.sort_prefix_bits = value; return PHANT_OK;
         case PHANT_DIAG_SORT_REPAIR_BITS: t.sort_repair_bits = value; return PHANT_OK;
+        case PHANT_DIAG_NODESET_WAVE_MAX: c->ns_tune.wave_max = (uint32_t)(value < 0 ? 0 : value > (1 << 20) ? (1 << 20) : value); return PHANT_OK;
         case PHANT_DIAG_TRIE_SMALL_MAX_KEYS: t.small_max_keys = value; return PHANT_OK;
         default: return fail(c, PHANT_E_INVALID_ARG, "diag_set: no such knob");
     }

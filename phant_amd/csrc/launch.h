@@ -113,6 +113,9 @@ struct NodesetTune {
                                       // either way): measured, one launch of BASELINE's node set 189 us without, 183 / 180 / 177 at
                                       // 8 / 32 / 40 KiB -- the dispatcher hands out workgroups with LDS more slowly, the waves of a
                                       // SIMD start apart and do not all wait for their rate blocks at once (profiles/r6_explore/NOTES.md)
+    uint32_t wave_max = 3500;   // sets of up to this many nodes: a WAVE per node (set_hash_wave_kernel), no class lists (0: never).  Measured,
+                                // one launch, wave per node against the lists: 309 nodes 44 / 65 us, 876: 54 / 93, 1 448: 61 / 78, 3 200: 77 / 82,
+                                // 5 137: 87-90 / 81, 9 800: 120 / 79
     uint32_t resident_wgs = 0;  // 0 = a wave per chunk.  Otherwise the hash grid is capped at this many workgroups and its waves stride
                                 // over the chunk queue (A/B: one generation of waves, every wave a four-permutation chunk and then
                                 // maybe a one-permutation one -- measured SLOWER, 199 against 190 us: the lockstep it creates costs

@@ -27,6 +27,10 @@
 //                        node costs three atomics on one address per copy -- milliseconds, linear --, never a probe chain of its
 //                        own copies.  Until round 6 this was a kernel of its own between the hashing and the walk: 4-5 us of
 //                        every launch for a list that is empty.)
+//   (set_hash_wave_kernel  the witness of an ordinary block -- up to NodesetTune::wave_max nodes -- instead of the two kernels above: a
+//                        WAVE per node, the sponge of coop_sponge.hip.h's one-state-per-wave form (3.8-5.2 us a permutation where a
+//                        lane takes 9: a set of a few hundred nodes is as long as ONE node's four permutations), no class lists;
+//                        the wave's first lane puts the node into the record table; the kernel also does the clearing.)
 //   set_walk_kernel      one lane per key, from its root: a reference costs ONE 48-byte record fetch (digest compared in
 //                        full, the node's place and form in the same line), a canonical full branch one 32-byte fetch of the
 //                        child reference for the key's nibble, anything else is staged into LDS and decoded (mpt_walk.hip.h,
@@ -42,6 +46,7 @@
 // found, never whether it matches.
 #include <phant_platform.h>
 
+#include "coop_sponge.hip.h"
 #include "launch.h"
 #include "mpt_walk.hip.h"
 #include "verify_hash.hip.h"
@@ -92,6 +97,16 @@ PHANT_DEV uint32_t home_hash(uint32_t d0, uint32_t d1, uint32_t salt0, uint32_t 
 PHANT_DEV uint32_t thin_home(uint32_t h) { return (h >> 16) | (h << 16); }
 
 // ---------------------------------------------------------------- classify
+// the next launch's cursors and overflow count, this launch's verdict (lane g of `lanes`)
+PHANT_DEV void clear_for_next(const Args& a, const size_t g, const size_t lanes) {
+    const uint32_t parity = a.epoch & 1u;
+    for (size_t i = g; i < 256u + 32u; i += lanes) {
+        if (i < 256u) a.hdr[HDR_CUR + 256u * (parity ^ 1u) + i] = 0u;
+        else a.hdr[HDR_OVF + 32u * (parity ^ 1u) + (i - 256u)] = 0u;
+    }
+    if (a.v.fail_count)
+        for (size_t r = g; r < a.v.n_roots; r += lanes) a.v.fail_count[r] = 0u;
+}
 __global__ void __launch_bounds__(256) set_classify_kernel(const Args a) {
     constexpr uint32_t WAVES = 4;
     __shared__ uint32_t s_cnt[WAVES][N_LIST];
@@ -100,15 +115,7 @@ __global__ void __launch_bounds__(256) set_classify_kernel(const Args a) {
     const uint32_t NT = a.total_nodes;
     const uint32_t j = blockIdx.x * 256u + tid;
     const uint32_t parity = a.epoch & 1u;
-    {   // the next launch's cursors and overflow count, this launch's verdict
-        const size_t g = j, lanes = (size_t)gridDim.x * 256u;
-        for (size_t i = g; i < 256u + 32u; i += lanes) {
-            if (i < 256u) a.hdr[HDR_CUR + 256u * (parity ^ 1u) + i] = 0u;
-            else a.hdr[HDR_OVF + 32u * (parity ^ 1u) + (i - 256u)] = 0u;
-        }
-        if (a.v.fail_count)
-            for (size_t r = g; r < a.v.n_roots; r += lanes) a.v.fail_count[r] = 0u;
-    }
+    clear_for_next(a, j, (size_t)gridDim.x * 256u);
     if (tid < WAVES * N_LIST) (&s_cnt[0][0])[tid] = 0u;
     uint32_t cls = CLASS_NONE, len = 0;
     uint64_t b = 0;
@@ -271,6 +278,65 @@ __global__ void __launch_bounds__(256, FORM == 2 ? 3 : 4) set_hash_kernel(const 
     hash_chunks<FORM>(a, q, gridDim.x * 4u, threadIdx.x & 63u);
 }
 
+// ---------------------------------------------------------------- a small set: a wave per node
+// Node j by the whole wave (mpt_verify_v3.hip's wave_node without a reference to compare with): lane `word` < 17 fetches eight
+// bytes of every rate block, the padding and the canonical-branch markers are settled on exactly those bytes.  The list cursors
+// only count here (verify_nodeset_stats_from_header reads them).
+__global__ void __launch_bounds__(256) set_hash_wave_kernel(const Args a) {
+    struct __attribute__((packed, aligned(1))) U64 { unsigned long long v; };
+    const uint32_t tid = threadIdx.x, l = tid & 63u;
+    clear_for_next(a, (size_t)blockIdx.x * blockDim.x + tid, (size_t)gridDim.x * blockDim.x);
+    const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);  // (workgroups of four waves, or of one: see the launch)
+    if (j >= a.total_nodes) return;
+    const uint64_t e = a.v.node_off[j + 1], b = a.v.node_off[j];
+    if (!(e >= b && e <= a.v.nodes_len && e - b <= 0x7fffffffull)) return;  // (not a member)
+    const uint32_t len = (uint32_t)(e - b);
+    const uint8_t* const ptr = a.v.nodes + b;
+    const uint32_t nb = len / RATE + 1u;
+    const bool branch = len == BRANCH_LEN;
+    const WaveLane c = wave_lane(l);
+    uint32_t lo = 0, hi = 0, bad = 0;
+    for (uint32_t k = 0; k < nb; ++k) {
+        if (c.word < 17u) {  // (a copy absorbs what its column's lane absorbs)
+            const uint32_t off = k * RATE + 8u * c.word;
+            unsigned long long w = 0;
+            if (off + 8u <= len) {
+                w = reinterpret_cast<const U64*>(ptr + off)->v;
+            } else {
+#pragma unroll
+                for (uint32_t t = 0; t < 8u; ++t) {
+                    const uint32_t q = off + t;
+                    if (q < len) w |= (unsigned long long)ptr[q] << (8u * t);
+                    else if (q == len) w |= 0x01ull << (8u * t);  // Keccak-256's domain byte
+                }
+            }
+            if (k + 1u == nb && c.word == 16u) w |= 0x80ull << 56;  // the end of pad10*1: the rate's last byte
+            if (branch) {  // f9 02 11 | 16 x (a0 | 32 bytes) | 80: the markers among this lane's bytes
+#pragma unroll
+                for (uint32_t t = 0; t < 8u; ++t) {
+                    const uint32_t q = off + t;
+                    const uint32_t byte = (uint32_t)(w >> (8u * t)) & 0xffu;
+                    const int want = q == 0u ? 0xf9 : q == 1u ? 0x02 : q == 2u ? 0x11 : q == BRANCH_LEN - 1u ? 0x80 : (q < BRANCH_LEN && (q - 3u) % 33u == 0u) ? 0xa0 : -1;
+                    if (want >= 0 && byte != (uint32_t)want) bad = 1u;
+                }
+            }
+            lo ^= (uint32_t)w;
+            hi ^= (uint32_t)(w >> 32);
+        }
+        wave_permute(c, lo, hi);
+    }
+    const bool canon = branch && __ballot(bad != 0u) == 0ull;
+    // the digest: the words of lanes 0 .. 3 -- to the first lane, which records the node
+    Sponge s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s.lo[k] = (uint32_t)__shfl((int)lo, k, 64);
+        s.hi[k] = (uint32_t)__shfl((int)hi, k, 64);
+    }
+    insert_record(a, s, b, len | (canon ? CANON_BIT : 0u), j, l == 0);
+    if (l == 0) atomicAdd(&a.hdr[cursor_word(a.epoch & 1u, node_list(len), j % STRIPES)], 1u);
+}
+
 // ---------------------------------------------------------------- walk
 struct Found {
     uint64_t off;
@@ -323,9 +389,12 @@ PHANT_DEV Found set_find(const Args& a, const uint32_t (&want)[8], uint32_t ovf)
 // loop, whatever its state; a wave makes as many trips as its SLOWEST LANE needs in total (~2 per level + that lane's extra
 // slots), not the sum over the levels of the slowest lane of each.  Everything that is not "record found, canonical full branch,
 // the key has a nibble for it" leaves the machine for the generic loop behind it.
-__global__ void __launch_bounds__(256) set_walk_kernel(const Args a) {
-    __shared__ uint32_t s_stage[256 * WALK_SLOT_DW];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+// (workgroups of ONE wave: 100 000 keys are 1 563 waves for 1 024 SIMDs -- in workgroups of four, 135 of the 256 CUs got eight of
+// them and the others four; 177.5 against 179.4 us per launch)
+constexpr uint32_t WALK_LANES = 64;
+__global__ void __launch_bounds__(WALK_LANES) set_walk_kernel(const Args a) {
+    __shared__ uint32_t s_stage[WALK_LANES * WALK_SLOT_DW];
+    const uint32_t i = blockIdx.x * WALK_LANES + threadIdx.x;
     const bool in = i < a.v.n;
     uint32_t status = PHANT_PROOF_PRESENT, r = 0;
     uint32_t* const slot = s_stage + threadIdx.x * WALK_SLOT_DW;
@@ -571,20 +640,27 @@ hipError_t launch_mpt_verify_nodeset(const VerifyArgs& v, uint32_t total_nodes, 
     a.ov_dig = reinterpret_cast<uint4*>(ws + l.ov_dig);
     a.thin = reinterpret_cast<unsigned long long*>(ws + l.thin);
     a.thin_mask = l.slots - 1u;
-    // (always: it is what clears the next launch's cursors and this launch's verdict)
     const uint32_t ng = total_nodes ? (total_nodes + 255u) / 256u : 1u;
-    hipLaunchKernelGGL(set_classify_kernel, dim3(ng), dim3(256), 0, st, a);
-    if (v.n == 0) return hipGetLastError();
-    if (total_nodes) {
-        // grid: every node listed (64-node chunks, four waves per workgroup) + a short chunk per list, or -- fewer -- as many
-        // workgroups as the chip holds at once (NodesetTune::resident_wgs), whose waves then stride over the queue
-        const uint32_t all = ng + (N_QUEUE + 3u) / 4u;
-        const uint32_t wgs = tune.resident_wgs && tune.resident_wgs < all ? tune.resident_wgs : all;
-        if (tune.form == 2u) hipLaunchKernelGGL(set_hash_kernel<2>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
-        else if (tune.form == 1u) hipLaunchKernelGGL(set_hash_kernel<1>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
-        else hipLaunchKernelGGL(set_hash_kernel<0>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
+    if (v.n != 0 && total_nodes != 0 && total_nodes <= tune.wave_max) {
+        // a wave per node (up to two waves per CU the workgroups are single waves, which the dispatcher spreads over the CUs:
+        // the sponge's fetches share a CU's LDS pipeline); the kernel clears what set_classify_kernel clears
+        if (total_nodes <= 512u) hipLaunchKernelGGL(set_hash_wave_kernel, dim3(total_nodes), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(set_hash_wave_kernel, dim3((total_nodes + 3u) / 4u), dim3(256), 0, st, a);
+    } else {
+        // (always: it is what clears the next launch's cursors and this launch's verdict)
+        hipLaunchKernelGGL(set_classify_kernel, dim3(ng), dim3(256), 0, st, a);
+        if (v.n == 0) return hipGetLastError();
+        if (total_nodes) {
+            // grid: every node listed (64-node chunks, four waves per workgroup) + a short chunk per list, or -- fewer -- as many
+            // workgroups as the chip holds at once (NodesetTune::resident_wgs), whose waves then stride over the queue
+            const uint32_t all = ng + (N_QUEUE + 3u) / 4u;
+            const uint32_t wgs = tune.resident_wgs && tune.resident_wgs < all ? tune.resident_wgs : all;
+            if (tune.form == 2u) hipLaunchKernelGGL(set_hash_kernel<2>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
+            else if (tune.form == 1u) hipLaunchKernelGGL(set_hash_kernel<1>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
+            else hipLaunchKernelGGL(set_hash_kernel<0>, dim3(wgs), dim3(256), tune.hash_lds, st, a);
+        }
     }
-    hipLaunchKernelGGL(set_walk_kernel, dim3((v.n + 255u) / 256u), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(set_walk_kernel, dim3((v.n + WALK_LANES - 1u) / WALK_LANES), dim3(WALK_LANES), 0, st, a);
     return hipGetLastError();
 }
 

@@ -57,3 +57,15 @@ def test_hostile_index_arrays_match_the_checked_oracle(M, oracle):
         assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
         seen |= set(got[0].tolist())
     assert {M.PROOF_PRESENT, M.PROOF_MISSING_NODE} <= seen
+
+
+def test_small_sets_through_the_class_lists_as_well():
+    """A set of up to 2 048 nodes takes the wave-per-node kernel (set_hash_wave_kernel), so most of this module's sets do; here
+    the same tests with it off (nodeset_wave_max = 0: classify + the lane-per-node hash kernel at every size), in a child pytest
+    (the switch is per ctx: tests/diag.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_emu_nodeset.py", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "not through_the_class_lists"], cwd=root, env=dict(os.environ, PHANT_TEST_DIAG="nodeset_wave_max=0"),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and " passed" in r.stdout and " failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
