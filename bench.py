@@ -1321,21 +1321,23 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS,
                      "throughput_GBps": value / world * alg_bytes / n_units / 1e9,  # algorithmic bytes x the measured
                      "throughput_frac": value / world * alg_bytes / n_units / 1e9 / HBM_PEAK_GBS,  # rate (launches overlap)
-                     "traffic": (tr["bytes"] if (tr := (pmc_traffic(args.verify_mode, args.proofs)
-                                                        if args.workload == "config3" else None)) else None),
+                     "traffic": (tr["bytes"] if (tr := (pmc_traffic(args.verify_mode, args.proofs) if args.workload == "config3" else
+                                                        pmc_traffic("nodeset", args.proofs) if args.workload == "nodeset" else None)) else None),
                      "traffic_source": (tr.get("source") or tr.get("stale")) if tr else None,
                      "traffic_detail": tr,
                      "kernel": ("keccak256_fixed_kernel" if args.workload == "config2" else
                                 "node-set pipeline = set_classify_kernel (class lists) + set_hash_kernel (every node hashed once and put "
-                                "into the record table by the lane that hashed it) + set_late_kernel (empty on a set of distinct nodes) "
+                                "into the record table by the lane that hashed it, duplicates into a second table by the same lane) "
                                 "+ set_walk_kernel (one launch of the path, first kernel start to last kernel end; the hash kernel is "
                                 "integer-VALU-bound, see roofline.valu)" if args.workload == "nodeset" else
-                                "trie hasher on three block-sized lists as one forest (head / lcp / min-tree / identify / order / leaf / a "
-                                "kernel per depth bin: branch_wave_kernel at this size; the call is a chain of launch and sponge latencies)"
+                                "trie hasher on three block-sized lists as one forest, the pass for small tries: small_head_kernel (one "
+                                "workgroup: lcp, min-tree in LDS, the nodes) + small_climb_kernel (a wave per key: the leaf, then every node "
+                                "whose last child the wave has just delivered); the call is as long as its longest chain of nodes + ~55 us of "
+                                "launches, copies and a wake-up"
                                 if args.workload == "block_roots" else
                                 "trie hasher = head_kernel + lcp_kernel + tree_levels_kernel x 2 + identify_kernel + order_kernel + leaf_kernel (the keys under the deepest nodes first; the deepest depth bins beside the rest) + per depth bin branch_kernel<1|2|4> or, for a thin bin, branch_coop_kernel, finish_kernel (first start to last end)"
                                 if args.workload == "mptize" else
-                                "node-set pipeline = set_classify_kernel + set_hash_kernel + set_late_kernel + set_walk_kernel"
+                                "node-set pipeline = set_classify_kernel + set_hash_kernel + set_walk_kernel"
                                 if (streamed and args.nodeset) else pipeline),
                      "kernel_avg_ms": k_avg_ms, "algorithmic_bytes_per_launch": alg_bytes, **extra},
     }

@@ -33,9 +33,15 @@ b config5_nodeset --workload config5 --nodeset --steps 64 --cpu-seconds 3
 b config5_20k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 20000
 b config5_100k_account_proofs --workload config5 --no-cpu-baseline --stream-proofs 100000
 b mptize --workload mptize --cpu-seconds 8 --steps 10
+b block_roots_100_items --workload block_roots --items 100 --cpu-seconds 2
+b block_roots_400_items --workload block_roots --items 400 --cpu-seconds 2
 timeout 300 python bench.py --comm --steps 10 --inner 10 2>&1 | grep '^{' | tail -1 > "$OUT/bench_comm_one_process.json"; python -c "
 import json; d=json.load(open('$OUT/bench_comm_one_process.json')); print('comm (one process)', d['n_gpus'], 'device(s)', round(d['value']/1e6,1), 'M proofs/s', round(d.get('ms_per_pass', d['ms_per_step']),4), 'ms')"
-timeout 300 python tools/bench_block_roots.py --items 1 10 100 400 > "$OUT/block_roots.jsonl" 2>&1; tail -4 "$OUT/block_roots.jsonl"
+timeout 300 python tools/bench_block_roots.py --items 1 10 100 400 1000 2>&1 | grep items > "$OUT/block_roots.jsonl"; cut -c1-200 "$OUT/block_roots.jsonl"
+timeout 300 python tools/probe_small_trie.py 2>&1 | grep "items\|mptize_dev" > "$OUT/small_tries_against_the_general_pass.txt"; tail -4 "$OUT/small_tries_against_the_general_pass.txt"
+timeout 300 python tools/probe_nodeset_small.py 2>&1 | grep proofs > "$OUT/nodeset_small_witness.txt"; cat "$OUT/nodeset_small_witness.txt"
+rm -rf /tmp/pst; ( cd /tmp && MODE=small REPS=5 ITEMS=100,400 KEYS= timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pst -o p -- python $R/tools/probe_small_trie.py > "$OUT/prof_small_tries.log" 2>&1 )
+python tools/probe_small_report.py /tmp/pst | awk 'NR%8==7' > "$OUT/timeline_small_tries.txt"; cat "$OUT/timeline_small_tries.txt"
 timeout 300 python tools/bench_state.py > "$OUT/state_root.jsonl" 2>&1; timeout 300 python tools/bench_state.py --accounts 1000000 --slots 0 >> "$OUT/state_root.jsonl" 2>&1; cut -c1-330 "$OUT/state_root.jsonl"
 timeout 300 python tools/sweep_verify.py --steps 40 --out "$OUT/sweep.jsonl" > "$OUT/sweep.log" 2>&1; python - <<PY
 import json
@@ -49,14 +55,18 @@ prof() {  # tag, env..., (BARGS)
   tag=$1; shift
   ( cd /tmp && rm -rf /tmp/prof_$tag && timeout 300 env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python $R/bench.py --no-cpu-baseline --steps 5 --inner 10 --no-strong $BARGS > "$OUT/prof_$tag.log" 2>&1 )
   f=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
-  [ -n "$f" ] && (head -1 "$f"; grep "phant" "$f") > "$OUT/config3_kernel_stats_$tag.csv"
-  echo "== $tag"; cut -d, -f1-4 "$OUT/config3_kernel_stats_$tag.csv" | cut -c1-150
+  pre=config3_; case $tag in nodeset*|block_roots*) pre="";; esac
+  [ -n "$f" ] && (head -1 "$f"; grep "phant" "$f") > "$OUT/${pre}kernel_stats_$tag.csv"
+  echo "== $tag"; cut -d, -f1-4 "$OUT/${pre}kernel_stats_$tag.csv" | cut -c1-150
 }
 BARGS="--streams 1" prof concurrent X=1
 BARGS="--streams 1 --diag verify_serial=1" prof serial X=1
 BARGS="--streams 2" prof streams2 X=1
 BARGS="--streams 4" prof streams4 X=1
 BARGS="--streams 1 --workload config4" prof config4 X=1
+BARGS="--streams 1 --workload nodeset" prof nodeset X=1
+BARGS="--streams 2 --workload nodeset" prof nodeset_streams2 X=1
+BARGS="--workload block_roots --items 100" prof block_roots_100_items X=1
 ( cd /tmp && rm -rf /tmp/prof_t && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -o p -- python $R/bench.py --workload mptize --no-cpu-baseline --steps 10 > "$OUT/prof_mptize.log" 2>&1 )
 f=$(find /tmp/prof_t -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && (head -1 "$f"; grep "phant" "$f") > "$OUT/mptize_kernel_stats.csv"
 python tools/probe_walk_report.py /tmp/prof_t head_kernel | tail -1 | tr ' ' '\n' | grep -v '^$' > "$OUT/mptize_timeline.txt"
@@ -85,7 +95,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc flat_$c $c flat
   pmc nodedup_$c $c nodedup
 done
+pmcns() {  # name, counters: the node-set launch
+  name=$1; ctr=$2
+  ( cd /tmp && rm -rf /tmp/pmc_$name && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$name -o pmc -- python $R/bench.py --workload nodeset --steps 2 --warmup 1 --inner 1 --no-cpu-baseline --streams 1 > "$OUT/pmc_$name.log" 2>&1 )
+  for f in $(find /tmp/pmc_$name -name '*counter_collection.csv'); do (head -1 "$f"; grep -E 'phant::' "$f") > "$OUT/$name.csv"; done
+}
+pmcns nodeset_FETCH_SIZE FETCH_SIZE
+pmcns nodeset_WRITE_SIZE WRITE_SIZE
+pmcns nodeset_SQ1 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"
 pmc flat_SQ1 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" flat
 pmc flat_SQ2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE" flat
 python tools/pmc_traffic.py "$OUT" > "$OUT/pmc_traffic.json" 2> "$OUT/pmc_traffic.err"; head -c 600 "$OUT/pmc_traffic.json"; tail -2 "$OUT/pmc_traffic.err"
+ls "$OUT" | wc -l
+T0=$(date +%s); timeout 1200 python bench.py > "$OUT/bench_default_as_the_driver_runs_it.json" 2> "$OUT/bench_default.err"; echo "default bench.py: $(( $(date +%s) - T0 )) s, rc $?"
 ls "$OUT" | wc -l

@@ -84,5 +84,22 @@ for mode in ("flat", "nodedup"):
         tot_r += r
         tot_w += w
     out[mode] = {"read": round(tot_r), "write": round(tot_w), "total": round(tot_r + tot_w), "kernels": per}
+# the node-set launch (bench.py --workload nodeset: 100 000 keys against config 3's trie as its distinct nodes), when its passes
+# are there: set_hash_kernel reads a node per lane like the hash kernels above (their factor), set_classify_kernel streams
+# node_off (the stream factor), set_walk_kernel's scattered fetches are left at 1.0 (a lower bound)
+ns_f, ns_w = os.path.join(d, "nodeset_FETCH_SIZE.csv"), os.path.join(d, "nodeset_WRITE_SIZE.csv")
+if os.path.exists(ns_f) and os.path.exists(ns_w):
+    fr, wr = mean_by_kernel(ns_f), mean_by_kernel(ns_w)
+    per = {}
+    tot_r = tot_w = 0.0
+    for k in fr:
+        if "ns::set_" not in k:
+            continue
+        fac = f_hash if "set_hash" in k else f_stream if "set_classify" in k else 1.0
+        r, w = fr[k] * fac, wr.get(k, 0.0) * f_write
+        per[k] = {"read": round(r), "write": round(w), "read_factor": round(fac, 3), "calibrated": "set_walk" not in k}
+        tot_r += r
+        tot_w += w
+    out["nodeset"] = {"read": round(tot_r), "write": round(tot_w), "total": round(tot_r + tot_w), "kernels": per}
 json.dump(out, sys.stdout, indent=1)
 print()

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--first-seed", type=int, default=2000)
     ap.add_argument("--emulated", action="store_true")
     ap.add_argument("--max-keys", type=int, default=4000)
+    ap.add_argument("--long-values", action="store_true", help="values of up to 300 .. 5 000 bytes (leaves of many rate blocks: the small tries' pass beyond 2 048 keys)")
     args = ap.parse_args()
     import phant_amd
     from oracle import oracle as O
@@ -41,7 +42,7 @@ def main():
         n = int(rng.integers(1, min(args.max_keys, 256 ** min(key_len, 3) // 2)))
         shared = int(rng.choice([0, 0, 2, 6, 2 * key_len - 4])) if key_len >= 4 else 0
         n = min(n, 256 ** ((2 * key_len - shared) // 2) // 2)  # (distinct keys must exist)
-        vmax = int(rng.choice([1, 3, 31, 32, 33, 60, 300]))
+        vmax = int(rng.choice([300, 700, 2200, 5000])) if args.long_values else int(rng.choice([1, 3, 31, 32, 33, 60, 300]))
         keys, vals = random_kv(rng, n, key_len, 1, vmax, shared)
         what = []
         if phant_amd.mpt.mptize([KV(k, v) for k, v in zip(keys, vals)]) != O.mptize(keys, vals):
