@@ -800,7 +800,8 @@ def extra_legs(args):
     legs = [("config2", ["--workload", "config2", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
             ("mptize_1M_keys", ["--workload", "mptize", "--keys", "1000000", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
             ("block_roots_100_items", ["--workload", "block_roots", "--items", "100", "--steps", "20", "--warmup", "3", "--cpu-seconds", "2"]),
-            ("nodeset_config3", ["--workload", "nodeset", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
+            # (three launch sequences in flight, each over its own node set: 572 / 602 / 644 / 642 M keys/s at 1 / 2 / 3 / 4)
+            ("nodeset_config3", ["--workload", "nodeset", "--streams", "3", "--steps", "10", "--warmup", "2", "--cpu-seconds", "3"]),
             # BASELINE config 5 at its stated length: 256 consecutive block witnesses (4 distinct ones in rotation), and the same
             # witnesses as node sets -- the form an execution witness has
             ("config5_256_blocks", ["--workload", "config5", "--steps", "64", "--warmup", "2", "--cpu-seconds", "3"]),
@@ -1313,7 +1314,7 @@ def main():
                       args.workload == "nodeset" else {}),
                    "verify_mode": args.verify_mode if proofs_like else None,
                    "dedup_levels": (args.dedup_levels if proofs_like else None),
-                   "streams": (S if proofs_like else 1), "passes_per_timed_step": inner,
+                   "streams": (S if (proofs_like or args.workload == "nodeset") else 1), "passes_per_timed_step": inner,
                    "timed_region_ms": ms_per_step * args.steps,
                    "step": f"a timed step = {inner} back-to-back pass(es) of the path over a resident batch; ms_per_step x steps = the "
                            "timed region, ms_per_pass = one pass (`value` = units per pass / ms_per_pass)"},
