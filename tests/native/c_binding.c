@@ -62,6 +62,36 @@ int main(void) {
     CHECK(phant_mpt_verify_batch(ctx, h, 1, NULL, key, 4, leaf, sizeof(leaf), node_off, proof_first_node, 1, &status,
                                  NULL, NULL) == PHANT_OK);
     CHECK(status == PHANT_PROOF_BAD_HASH);
+    h[0] ^= 1;
+    /* the same witness as a node SET (execution_payload.zig:121: the nodes once, in any order, no list per key), with an
+     * unrelated node in front; then through the streaming pair */
+    const uint8_t set[] = {0xc2, 0x01, 0x02, 0xcc, 0x85, 0x20, 1, 2, 3, 4, 0x85, 'h', 'e', 'l', 'l', 'o'};
+    const uint64_t set_off[3] = {0, 3, sizeof(set)};
+    status = 0xee;
+    CHECK(phant_mpt_verify_nodeset(ctx, h, 1, NULL, key, 4, set, sizeof(set), set_off, 2, 1, &status, &value_off, &value_len) ==
+          PHANT_OK);
+    CHECK(status == PHANT_PROOF_PRESENT && value_len == 5 && memcmp(set + value_off, "hello", 5) == 0);
+    CHECK(phant_mpt_verify_nodeset(ctx, h, 1, NULL, key, 4, set, 3, set_off, 1, 1, &status, NULL, NULL) == PHANT_OK);
+    CHECK(status == PHANT_PROOF_MISSING_NODE); /* (the set without the leaf) */
+    status = 0xee;
+    CHECK(phant_mpt_verify_nodeset_submit(ctx, 1, h, 1, NULL, other, 4, set, sizeof(set), set_off, 2, 1, &status, NULL, NULL) ==
+          PHANT_OK);
+    CHECK(phant_wait(ctx, 1) == PHANT_OK);
+    CHECK(status == PHANT_PROOF_ABSENT);
+    /* blockchain.zig:198-204: a block's index-keyed roots in one call -- a list of one item is the trie of the single pair
+     * (rlp(0) = 0x80, item), an empty list gives mpt.zig:10's empty_mpt_root */
+    const uint8_t item[] = {0xf8, 0x4e, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10};
+    const uint64_t item_off[2] = {0, sizeof(item)};
+    const uint8_t *lists[2] = {item, NULL};
+    const uint64_t *list_off[2] = {item_off, NULL};
+    const uint32_t list_n[2] = {1, 0};
+    uint8_t roots[64], want[32];
+    const uint8_t k80[1] = {0x80};
+    const uint32_t k80_off[2] = {0, 1};
+    CHECK(phant_block_roots(ctx, lists, list_off, list_n, 2, roots, NULL, NULL, NULL, 0, 0, NULL) == PHANT_OK);
+    CHECK(phant_mpt_root(ctx, k80, k80_off, item, item_off, 1, want) == PHANT_OK);
+    CHECK(memcmp(roots, want, 32) == 0);
+    CHECK(hex_eq(roots + 32, 32, "56e81f171bcc55a6ff8345e692c0f86e5b48e01b996cadc001622fb5e363b421"));
     phant_ctx_destroy(ctx);
     printf("c binding OK (%s)\n", phant_version());
     return 0;

@@ -453,3 +453,29 @@ def test_sharded_mptize_matches_the_single_gpu_root(oracle):
                 nz = np.nonzero(lens > 0)[0]
                 got = subs[int(nz[0])] if len(nz) else shard.EMPTY_MPT_ROOT
             assert got == want, (world, len(keys))
+
+
+def test_small_tries_from_two_threads(P, oracle):
+    """Two host threads, a ctx each, hashing blocks' lists at the same time (ctypes releases the GIL for the call): the small
+    tries' pass keeps its flags and counters in words of its ctx (Workspaces::small_state) and waits on its own mailbox --
+    every root of both threads against the oracle."""
+    import threading
+    rng = np.random.default_rng(314)
+    mk = lambda k, lo, hi: [rng.integers(0, 256, int(rng.integers(lo, hi)), dtype=np.uint8).tobytes() for _ in range(k)]  # noqa: E731
+    work = [[mk(int(rng.integers(0, 60)), 100, 300), mk(int(rng.integers(0, 60)), 300, 700), mk(int(rng.integers(0, 20)), 40, 60)]
+            for _ in range(24)]
+    want = [[oracle.index_root_rlp(x) for x in lists] for lists in work]
+    got = [[None] * len(work), [None] * len(work)]
+
+    def run(t):
+        ctx = P.Context(0)
+        for rep in range(4):
+            for i, lists in enumerate(work):
+                got[t][i] = P.mpt.block_roots(lists, ctx=ctx)
+
+    th = [threading.Thread(target=run, args=(t,)) for t in (0, 1)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert got[0] == want and got[1] == want
