@@ -344,7 +344,13 @@ PHANT_API int32_t phant_state_root_sharded(phant_comm *comm, const uint8_t *addr
  * the GPU (batched Keccak), verifies account proofs against stateRoot and storage proofs against each
  * account's storageHash in ONE batch, then checks on the host that every proven account leaf
  * rlp([nonce, balance, storageRoot, codeHash]) (src/state/types.zig:13-20) agrees with what the
- * witness declares.  status[i] per proof in document order (account proof, then its storage proofs). */
+ * witness declares.  status[i] per proof in document order (account proof, then its storage proofs).
+ * The node-SET form of the document -- what an execution witness is (execution_payload.zig:121): every trie node once, in any
+ * order, in a top-level "state" array, and NO "accountProof" / "proof" members --
+ *   { "stateRoot": "0x<32>", "state": ["0x<rlp node>", ...], "accounts": [ { "address", "storageHash", "codeHash", "nonce",
+ *     "balance", "storageProof": [ { "key", "value" } ] } ] }
+ * is taken by the same entry points (all three parsers); phant_witness_verify then resolves references by hash
+ * (phant_mpt_verify_nodeset: a reference nothing in the set hashes to is PHANT_PROOF_MISSING_NODE). */
 typedef struct phant_witness phant_witness;
 typedef struct phant_witness_info {
     uint32_t struct_size; /* = sizeof(phant_witness_info) */
@@ -357,7 +363,8 @@ typedef struct phant_witness_info {
     const uint32_t *preimage_off;     /* n_proofs + 1 */
     const uint8_t *nodes;
     const uint64_t *node_off;         /* total_nodes + 1 */
-    const uint32_t *proof_first_node; /* n_proofs + 1 */
+    const uint32_t *proof_first_node; /* n_proofs + 1 (node-set form: all zero) */
+    uint32_t node_set;                /* != 0: the document's nodes are a SET (its "state" array): `nodes` / `node_off` hold every node once */
 } phant_witness_info;
 /* err (optional, err_cap bytes) receives a message with the byte offset on PHANT_E_INVALID_ARG */
 PHANT_API int32_t phant_witness_parse_json(const char *json, uint64_t len, phant_witness **out,

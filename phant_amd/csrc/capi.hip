@@ -1140,7 +1140,9 @@ int32_t phant_witness_index_json(const char* json, uint64_t len, uint32_t thread
 void phant_witness_free(phant_witness* w) { delete w; }
 
 int32_t phant_witness_get(const phant_witness* pw, phant_witness_info* info) {
-    if (!pw || !info || info->struct_size < sizeof(phant_witness_info)) return PHANT_E_INVALID_ARG;
+    // (node_set is the struct's last member, added in round 6: a caller compiled against the shorter struct gets the rest)
+    if (!pw || !info || info->struct_size < offsetof(phant_witness_info, node_set)) return PHANT_E_INVALID_ARG;
+    if (info->struct_size >= sizeof(phant_witness_info)) info->node_set = pw->w.node_set ? 1u : 0u;
     const phant::Witness& w = pw->w;
     info->n_proofs = (uint32_t)w.root_idx.size();
     info->n_roots = (uint32_t)(w.roots.size() / 32);
@@ -1226,7 +1228,12 @@ int32_t phant_witness_verify(phant_ctx* c, const phant_witness* pw, const uint8_
         const int32_t src = ensure_side(c);
         if (src) return src;
     }
-    rc = verify_resident_on(c, a, total_nodes, s, c->dv, &c->side, true);
+    if (w.node_set) {  // the document's "state" array: every node once, references resolved by hash
+        a.proof_first_node = nullptr;
+        rc = nodeset_resident_on(c, a, total_nodes, s, c->ns, true);
+    } else {
+        rc = verify_resident_on(c, a, total_nodes, s, c->dv, &c->side, true);
+    }
     if (rc) return rc;
     std::vector<uint64_t> voff(n);
     std::vector<uint32_t> vlen(n);

@@ -56,7 +56,10 @@ struct Witness {
     std::vector<uint32_t> preimage_off;     // proofs + 1
     ByteBlob nodes;
     std::vector<uint64_t> node_off;         // total_nodes + 1
-    std::vector<uint32_t> proof_first_node; // proofs + 1
+    std::vector<uint32_t> proof_first_node; // proofs + 1 (node-set form: all zero)
+    // node-set form (the document has a top-level "state" array: every trie node once, in any order, and no node list per
+    // proof): `nodes` / `node_off` hold that SET, phant_witness_verify resolves references by hash (phant_mpt_verify_nodeset)
+    bool node_set = false;
     std::vector<WitnessAccount> accounts;
     std::vector<WitnessSlot> slots;
     // "index" form (witness_index_json): the proof nodes are NOT decoded on the host -- `nodes` stays empty,

@@ -12,6 +12,15 @@
 //                     "nonce": "0x..", "balance": "0x..", "codeHash": "0x<32>", "storageHash": "0x<32>",
 //                     "storageProof": [ { "key": "0x<slot>", "value": "0x..", "proof": ["0x<rlp node>", ...] } ] } ] }
 //
+// The node-SET form of the same document -- what an execution witness is (execution_payload.zig:121; go-ethereum's stateless
+// ExecutionWitness calls the member "state"): every trie node ONCE, in any order, in a top-level array, and no node list per proof --
+//
+//   { "stateRoot": "0x<32>", "state": ["0x<rlp node>", ...],
+//     "accounts": [ { "address", "nonce", "balance", "codeHash", "storageHash", "storageProof": [ { "key", "value" } ] } ] }
+//
+// A document with "state" must not carry "accountProof" / "proof" members (one form or the other); phant_witness_verify then
+// resolves every 32-byte reference by hash among the nodes of the set (phant_mpt_verify_nodeset).
+//
 // Hex follows phant's src/common/hexutils.zig:22-37: optional 0x prefix, "0x0" / "" = empty, odd length
 // otherwise an error (quantities "0x1" are accepted for nonce / balance / key / value, which hexutils'
 // prefixedHexToInt also takes).  Unknown members are skipped.
@@ -209,6 +218,7 @@ bool hex_padded(const char* b, const char* e, size_t width, uint8_t* dst) {
 
 struct Builder {
     Witness& w;
+    bool node_set = false;  // the document has a top-level "state" array: proofs carry no node lists
     explicit Builder(Witness& ww) : w(ww) {}
 
     void begin_proof(uint32_t root, uint32_t account, const uint8_t* pre, size_t pre_len) {
@@ -221,7 +231,7 @@ struct Builder {
         w.nodes.insert(w.nodes.end(), nd.begin(), nd.end());
         w.node_off.push_back((uint64_t)w.nodes.size());
     }
-    void end_proof() { w.proof_first_node.push_back((uint32_t)(w.node_off.size() - 1)); }
+    void end_proof() { w.proof_first_node.push_back(node_set ? 0u : (uint32_t)(w.node_off.size() - 1)); }  // (node-set form: no list per proof)
 };
 
 // two hex digits -> one byte in ONE lookup: index = the two characters as a little-endian u16, value < 0 for
@@ -269,15 +279,8 @@ __attribute__((target("avx2"))) size_t hex_decode_avx2(const char* b, size_t n, 
 const bool HAVE_AVX2 = __builtin_cpu_supports("avx2");
 #endif
 
-// hex data (hexutils.zig:22-37: optional 0x, "0x0" / "" empty, even digit count) appended to `out`
-bool hex_append(const char* b, const char* e, ByteBlob& out) {
-    if (e - b >= 2 && b[0] == '0' && (b[1] == 'x' || b[1] == 'X')) b += 2;
-    const size_t n = (size_t)(e - b);
-    if (n == 0 || (n == 1 && b[0] == '0')) return true;
-    if (n & 1) return false;
-    const size_t at = out.size();
-    out.resize(at + n / 2);
-    uint8_t* w = out.data() + at;
+// n (even) hex digits at b -> n / 2 bytes at w; false: some character is not a hex digit
+bool hex_decode_into(const char* b, size_t n, uint8_t* w) {
     int bad = 0;
     size_t done = 0;
 #if defined(__x86_64__)
@@ -291,7 +294,18 @@ bool hex_append(const char* b, const char* e, ByteBlob& out) {
         bad |= v;  // negative iff the pair is not two hex digits
         *w++ = (uint8_t)v;
     }
-    if (bad < 0) {
+    return bad >= 0;
+}
+
+// hex data (hexutils.zig:22-37: optional 0x, "0x0" / "" empty, even digit count) appended to `out`
+bool hex_append(const char* b, const char* e, ByteBlob& out) {
+    if (e - b >= 2 && b[0] == '0' && (b[1] == 'x' || b[1] == 'X')) b += 2;
+    const size_t n = (size_t)(e - b);
+    if (n == 0 || (n == 1 && b[0] == '0')) return true;
+    if (n & 1) return false;
+    const size_t at = out.size();
+    out.resize(at + n / 2);
+    if (!hex_decode_into(b, n, out.data() + at)) {
         out.resize(at);
         return false;
     }
@@ -356,6 +370,7 @@ bool parse_storage_entry(Parser& ps, Builder& b, uint32_t account) {
                     return ps.fail("storage value is not a hex quantity of at most 32 bytes");
                 slot.has_value = 1;
             } else if (name.is("proof")) {
+                if (b.node_set) return ps.fail("a witness with \"state\" carries no \"proof\" lists");
                 if (have_proof) return ps.fail("duplicate \"proof\"");
                 if (!parse_node_array(ps, b)) return false;
                 have_proof = true;
@@ -367,7 +382,7 @@ bool parse_storage_entry(Parser& ps, Builder& b, uint32_t account) {
             break;
         }
     }
-    if (!have_key || !have_proof) return ps.fail("storageProof entry needs \"key\" and \"proof\"");
+    if (!have_key || (!have_proof && !b.node_set)) return ps.fail(b.node_set ? "storageProof entry needs \"key\"" : "storageProof entry needs \"key\" and \"proof\"");
     b.end_proof();
     b.w.slots.push_back(slot);
     return true;
@@ -427,6 +442,7 @@ bool parse_account(Parser& ps, Builder& b) {
                     return ps.fail("balance is not a hex quantity of at most 32 bytes");
                 acc.has_balance = 1;
             } else if (name.is("accountProof")) {
+                if (b.node_set) return ps.fail("a witness with \"state\" carries no \"accountProof\" lists");
                 if (have_proof) return ps.fail("duplicate \"accountProof\"");
                 // the account proof comes first in the output; its nodes are decoded straight into the blob,
                 // the address is filled in when it is met
@@ -440,7 +456,15 @@ bool parse_account(Parser& ps, Builder& b) {
             } else if (name.is("storageProof")) {
                 if (have_storage) return ps.fail("duplicate \"storageProof\"");
                 have_storage = true;
-                if (have_proof) {
+                if (have_proof || b.node_set) {
+                    if (b.node_set && !have_proof) {  // (the account's own proof -- its key, no nodes -- goes in first, as in the other form)
+                        static const uint8_t zero20n[20] = {0};
+                        acc.proof = (uint32_t)b.w.root_idx.size();
+                        addr_at = b.w.preimages.size();
+                        b.begin_proof(0u, account, zero20n, 20);
+                        b.end_proof();
+                        have_proof = true;
+                    }
                     if (!parse_storage_array(ps, b, account)) return false;
                 } else {  // rare member order: remember where it is and come back after the account proof
                     ps.ws();
@@ -455,7 +479,15 @@ bool parse_account(Parser& ps, Builder& b) {
             break;
         }
     }
-    if (!have_addr || !have_proof) return ps.fail("account needs \"address\" and \"accountProof\"");
+    if (b.node_set && !have_proof) {
+        static const uint8_t zero20n[20] = {0};
+        acc.proof = (uint32_t)b.w.root_idx.size();
+        addr_at = b.w.preimages.size();
+        b.begin_proof(0u, account, zero20n, 20);
+        b.end_proof();
+        have_proof = true;
+    }
+    if (!have_addr || !have_proof) return ps.fail(b.node_set ? "account needs \"address\"" : "account needs \"address\" and \"accountProof\"");
     std::memcpy(b.w.preimages.data() + addr_at, acc.address, 20);
     b.w.accounts.push_back(acc);
     b.w.roots.insert(b.w.roots.end(), acc.storage_hash, acc.storage_hash + 32);  // root 1 + account
@@ -471,9 +503,53 @@ bool parse_account(Parser& ps, Builder& b) {
 
 }  // namespace
 
-static bool parse_single(const char* json, size_t len, Witness& w, std::string& err, bool deferred) {
+// Does the document have a top-level "state" member (the node-set form)?  A structural pass (a memchr per string) in front of
+// the parse: the two forms differ in what an account must and must not carry, and "state" may come behind "accounts".  A
+// document this pass cannot make sense of has none (the parse reports what is wrong with it).
+static bool top_level_has_state(const char* json, size_t len) {
+    Parser ps{json, json + len, std::string(), json};
+    if (!ps.expect('{') || ps.lit('}')) return false;
+    for (;;) {
+        Parser::View name;
+        if (!ps.view(name) || !ps.expect(':')) return false;
+        if (name.is("state")) return true;
+        if (!ps.skip_value()) return false;
+        if (!ps.lit(',')) return false;
+    }
+}
+
+// the strings of a node array as views, nothing decoded: node_off (and, index form, node_src) from their lengths
+struct NodeView {
+    const char *b, *e;  // the digits (behind an optional 0x)
+};
+static bool scan_node_array(Parser& ps, Witness& w, std::vector<NodeView>& views) {
+    if (!ps.expect('[')) return false;
+    if (ps.lit(']')) return true;
+    uint64_t at = w.node_off.back();
+    for (;;) {
+        const char *sb = nullptr, *se = nullptr;
+        bool esc = false;
+        if (!ps.str_view(sb, se, esc)) return false;
+        const char* h = sb;
+        if (se - h >= 2 && h[0] == '0' && (h[1] == 'x' || h[1] == 'X')) h += 2;
+        size_t n = (size_t)(se - h);
+        if (n == 1 && h[0] == '0') n = 0;  // "0x0" = empty (hexutils.zig:22-37)
+        if (esc || (n & 1)) return ps.fail("proof node is not hex data");
+        views.push_back(NodeView{h, h + n});
+        at += n / 2;
+        w.node_off.push_back(at);
+        if (ps.lit(',')) continue;
+        return ps.expect(']');
+    }
+}
+
+// state_views != nullptr: the nodes of a "state" array are NOT decoded here -- their views are handed back (parse_mt decodes them
+// on its threads); node_off is complete either way
+static bool parse_single(const char* json, size_t len, Witness& w, std::string& err, bool deferred,
+                         std::vector<NodeView>* state_views = nullptr) {
     w = Witness();
     w.deferred = deferred;
+    w.node_set = top_level_has_state(json, len);
     w.json = deferred ? json : nullptr;
     w.json_len = deferred ? len : 0;
     if (!deferred) w.nodes.reserve(len / 2);  // a witness is mostly hex: avoids regrowing the blob while it is filled
@@ -483,7 +559,8 @@ static bool parse_single(const char* json, size_t len, Witness& w, std::string& 
     w.roots.assign(32, 0);  // root 0 = stateRoot, filled below
     Parser ps{json, json + len, std::string(), json};
     Builder b(w);
-    bool have_root = false, have_accounts = false;
+    b.node_set = w.node_set;
+    bool have_root = false, have_accounts = false, have_state = false;
     bool ok = ps.expect('{');
     std::string name, s;
     if (ok && !ps.lit('}')) {
@@ -500,6 +577,17 @@ static bool parse_single(const char* json, size_t len, Witness& w, std::string& 
                     break;
                 }
                 have_root = true;
+            } else if (name == "state" && w.node_set) {
+                if (have_state) {
+                    ok = ps.fail("duplicate \"state\"");
+                    break;
+                }
+                have_state = true;
+                if (state_views && !deferred) {
+                    if (!(ok = scan_node_array(ps, w, *state_views))) break;
+                } else if (!(ok = parse_node_array(ps, b))) {
+                    break;
+                }
             } else if (name == "accounts") {
                 if (have_accounts) {
                     ok = ps.fail("duplicate \"accounts\"");
@@ -552,6 +640,34 @@ static bool parse_mt(const char* json, size_t len, unsigned threads, Witness& w,
         threads = std::thread::hardware_concurrency();
         if (threads == 0) threads = 1;
         if (threads > 32) threads = 32;
+    }
+    // ---- the node-set form: its accounts carry no nodes (a few dozen bytes each: parsed serially), its "state" array is the
+    // document -- one structural pass takes the strings' views, the threads decode contiguous runs of them into their place
+    if (top_level_has_state(json, len)) {
+        std::vector<NodeView> views;
+        if (!parse_single(json, len, w, err, deferred, &views)) return parse_single(json, len, w, err, deferred);  // (the serial parse's own message)
+        if (deferred) return true;
+        w.nodes.resize((size_t)w.node_off.back());
+        const size_t T = threads < 2 || len < (1u << 20) ? 1 : threads;
+        std::vector<size_t> bad_at(T, views.size());
+        auto decode = [&](size_t t) {
+            const size_t i0 = views.size() * t / T, i1 = views.size() * (t + 1) / T;
+            for (size_t i = i0; i < i1; ++i)
+                if (!hex_decode_into(views[i].b, (size_t)(views[i].e - views[i].b), w.nodes.data() + w.node_off[i])) {
+                    bad_at[t] = i;
+                    return;
+                }
+        };
+        parallel_guarded(T, decode);
+        for (size_t t = 0; t < T; ++t)
+            if (bad_at[t] < views.size()) {  // the earliest one of the document: what the serial parse stops at
+                Parser at{views[bad_at[t]].e + 1, json + len, std::string(), json};
+                at.fail("proof node is not hex data");
+                err = at.err;
+                w = Witness();
+                return false;
+            }
+        return true;
     }
     // ---- pass 1 (serial): top-level members, the span of every account object ----
     struct Span {

@@ -3,7 +3,9 @@
 the block witness as JSON -> packed arrays -> one batched verification on the GPU.
 
 Wire format: EIP-1186 `eth_getProof` result objects under a state root (include/phant_gpu.h, block
-witness section), hex per src/common/hexutils.zig:22-37.
+witness section), hex per src/common/hexutils.zig:22-37 -- or the node-SET form of the same document (a top-level
+"state" array with every trie node once, no "accountProof" / "proof" members: what an execution witness is), which
+verify() resolves by hash.
 
     w = ExecutionWitness.parse_json(text)                        # host-only (no GPU needed)
     status, n_failed = w.verify(ctx, expected_state_root=root)   # PHANT_PROOF_* per proof, document order; `root` = the
@@ -25,7 +27,7 @@ class WitnessInfo(C.Structure):
                 ("n_accounts", C.c_uint32), ("n_slots", C.c_uint32), ("total_nodes", C.c_uint32),
                 ("nodes_len", C.c_uint64), ("roots", C.c_void_p), ("root_idx", C.c_void_p),
                 ("account_of", C.c_void_p), ("preimages", C.c_void_p), ("preimage_off", C.c_void_p),
-                ("nodes", C.c_void_p), ("node_off", C.c_void_p), ("proof_first_node", C.c_void_p)]
+                ("nodes", C.c_void_p), ("node_off", C.c_void_p), ("proof_first_node", C.c_void_p), ("node_set", C.c_uint32)]
 
 
 class WitnessFormatError(ValueError):
@@ -88,7 +90,7 @@ class ExecutionWitness:
                 "preimages": _view(wi.preimages, int(pre_off[-1]) if n else 0, np.uint8), "preimage_off": pre_off,
                 "nodes": _view(wi.nodes, wi.nodes_len if wi.nodes else 0, np.uint8),
                 "node_off": _view(wi.node_off, wi.total_nodes + 1, np.uint64),
-                "proof_first_node": _view(wi.proof_first_node, n + 1, np.uint32)}
+                "proof_first_node": _view(wi.proof_first_node, n + 1, np.uint32), "node_set": bool(wi.node_set)}
 
     def verify(self, ctx: Context | None = None, expected_state_root: bytes | None = None):
         """-> (status u8[n_proofs], n_failed).  Needs a GPU (no CPU fallback).  expected_state_root: the 32-byte root the

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
             phant::Witness w2;
             std::string err2;
             const bool parsed2 = phant::witness_parse_json_mt(s.data(), s.size(), 3, w2, err2);
-            if (parsed != parsed2 || (parsed && (w.nodes != w2.nodes || w.node_off != w2.node_off || w.root_idx != w2.root_idx ||
+            if (parsed != parsed2 || (parsed && (w.node_set != w2.node_set || w.nodes != w2.nodes || w.node_off != w2.node_off || w.root_idx != w2.root_idx ||
                                                  w.proof_first_node != w2.proof_first_node || w.preimages != w2.preimages ||
                                                  w.roots != w2.roots))) {
                 std::fprintf(stderr, "threaded parser disagrees at edit %d\n", it);
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
                     }
                 }
                 if (parsed) {
-                    if (w3.node_off != w.node_off || w3.root_idx != w.root_idx || w3.proof_first_node != w.proof_first_node ||
+                    if (w3.node_set != w.node_set || w3.node_off != w.node_off || w3.root_idx != w.root_idx || w3.proof_first_node != w.proof_first_node ||
                         w3.preimages != w.preimages || w3.roots != w.roots) {
                         std::fprintf(stderr, "index form disagrees with the parser at edit %d\n", it);
                         return 10;
@@ -107,7 +107,8 @@ int main(int argc, char** argv) {
             ++ok;
             // a parsed witness must be internally consistent
             if (w.proof_first_node.size() != w.root_idx.size() + 1 || w.preimage_off.size() != w.root_idx.size() + 1 ||
-                w.node_off.back() != w.nodes.size() || w.proof_first_node.back() != w.node_off.size() - 1 ||
+                w.node_off.back() != w.nodes.size() ||
+                w.proof_first_node.back() != (w.node_set ? 0u : w.node_off.size() - 1) ||  // (node-set form: no list per proof)
                 w.roots.size() != 32 * (w.accounts.size() + 1)) {
                 std::fprintf(stderr, "inconsistent witness after edit %d\n", it);
                 return 4;

@@ -28,6 +28,7 @@ def built(oracle):
 from tests.test_gpu_witness import (  # noqa: E402,F401
     test_clean_witness, test_a_forged_state_root_is_rejected, test_declared_fields_must_match_the_proven_leaf,
     test_wrong_storage_hash_and_slot_value,
-    test_damaged_account_proof_unanchors_its_slots, test_keys_are_the_keccak_of_the_preimages)
+    test_damaged_account_proof_unanchors_its_slots, test_keys_are_the_keccak_of_the_preimages,
+    test_node_set_form_verifies_like_the_per_proof_form)
 from tests.test_gpu_x_witness_index import (  # noqa: E402,F401
     test_index_form_verifies_like_the_parsed_form, test_non_hex_digits_are_found_by_the_gpu)

@@ -156,3 +156,70 @@ def test_keys_are_the_keccak_of_the_preimages(EA, built, oracle):
     want, _, _ = oracle.mpt_verify_batch(info["roots"].reshape(-1), info["root_idx"], np.frombuffer(b"".join(keys), np.uint8), 32,
                                          info["nodes"], info["node_off"], info["proof_first_node"])
     assert st.tolist() == want.tolist()
+
+
+def test_node_set_form_verifies_like_the_per_proof_form(EA, built, oracle):
+    """The same witness with its nodes as a SET (a top-level "state" array: what an execution witness is,
+    src/engine_api/execution_payload.zig:121,175-181): every proof gets the status the per-proof form gives it (nothing in a
+    clean witness depends on which form ships the nodes), the same with the hex decoded on the GPU (index form), against the
+    oracle's node-set verifier over the parsed arrays, and through the engine hook.  Then what can go wrong with a set: a node
+    left out (the proofs through it: MISSING_NODE, the slots of an account that lost its leaf: MISMATCH -- nothing anchors
+    their root), a damaged node (it no longer hashes to what its parent commits to: a missing node), a declared field that
+    differs from the proven leaf (MISMATCH as in the other form), a forged state root."""
+    from tests.witness_util import block_witness_json, node_set_document
+    MISSING = 20
+    doc, expected, keys = built
+    sdoc = node_set_document(doc, np.random.default_rng(4))
+    assert "state" in sdoc and all("accountProof" not in a for a in sdoc["accounts"])
+    st, bad, info = _run(EA, sdoc)
+    assert info["node_set"] and st.tolist() == expected and bad == 0
+    want, _, _ = oracle.mpt_verify_nodeset(info["roots"].reshape(-1), info["root_idx"], np.frombuffer(b"".join(keys), np.uint8), 32,
+                                           info["nodes"], info["node_off"])
+    assert want.tolist() == expected
+    w = EA.ExecutionWitness.index_json(json.dumps(sdoc), threads=2)
+    st2, bad2 = w.verify()
+    w.close()
+    assert st2.tolist() == expected and bad2 == 0
+    trusted = bytes.fromhex(doc["stateRoot"][2:])
+    assert EA.new_payload_witness_ok(json.dumps(sdoc), trusted) and EA.new_payload_witness_ok(json.dumps(sdoc), trusted, on_gpu=True)
+    # a contract's account leaf left out of the set: its account proof ends in a missing node, its slots are unanchored
+    c = _first_contract(doc)
+    ia, n_s = _proof_index(doc, c), len(doc["accounts"][c]["storageProof"])
+    leaf = doc["accounts"][c]["accountProof"][-1]
+    cut = copy.deepcopy(sdoc)
+    cut["state"] = [x for x in cut["state"] if x != leaf]
+    st, bad, _ = _run(EA, cut)
+    want, i = list(expected), 0
+    for a in doc["accounts"]:  # (a contract may be touched twice: every proof that ends in this leaf)
+        if a["accountProof"][-1] == leaf:
+            want[i: i + 1 + len(a["storageProof"])] = [MISSING] + [MISMATCH] * len(a["storageProof"])
+        i += 1 + len(a["storageProof"])
+    n_bad = sum(x not in (PRESENT, ABSENT) for x in want)
+    assert want[ia] == MISSING and st.tolist() == want and bad == n_bad
+    # the same leaf damaged: a node nobody refers to + a reference nothing hashes to
+    dmg = copy.deepcopy(sdoc)
+    nd = bytearray(bytes.fromhex(leaf[2:]))
+    nd[len(nd) // 2] ^= 0x04
+    dmg["state"][dmg["state"].index(leaf)] = "0x" + nd.hex()
+    st, bad, _ = _run(EA, dmg)
+    assert st.tolist() == want and bad == n_bad
+    # a declared nonce that is not the leaf's
+    lie = copy.deepcopy(sdoc)
+    lie["accounts"][c]["nonce"] = hex(int(lie["accounts"][c]["nonce"], 16) + 1)
+    st, bad, _ = _run(EA, lie)
+    want = list(expected)
+    want[ia: ia + 1 + n_s] = [MISMATCH] * (1 + n_s)
+    assert st.tolist() == want and bad == 1 + n_s
+    # a self-consistent set under a root of the sender's choosing: consistent with itself, worthless against the trusted root
+    forged, fexp, _ = block_witness_json(oracle, np.random.default_rng(101), n_accounts=40, n_contracts=3, n_touched=10)
+    fset = node_set_document(forged, np.random.default_rng(6), state_first=True)
+    w = EA.ExecutionWitness.parse_json(json.dumps(fset))
+    st, bad = w.verify()
+    assert st.tolist() == fexp and bad == 0
+    st, bad = w.verify(expected_state_root=trusted)
+    w.close()
+    want = []
+    for a in forged["accounts"]:
+        want += [MISSING] + [MISMATCH] * len(a["storageProof"])  # (nothing in the set hashes to the trusted root)
+    assert st.tolist() == want and bad == len(want)
+    assert not EA.new_payload_witness_ok(json.dumps(fset), trusted)

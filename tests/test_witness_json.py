@@ -127,6 +127,18 @@ def test_parser_survives_damaged_documents_under_sanitizers(oracle, tmp_path):
     r = subprocess.run([str(exe), str(seed), "400"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     assert "variants parsed" in r.stdout
+    # the node-set form of both documents ("state" array, no proof lists): the small one damaged 10 000 times, the big one
+    # through the threaded decode of the array
+    from tests.witness_util import node_set_document
+    seed.write_text(json.dumps(node_set_document(doc, np.random.default_rng(1))))
+    r = subprocess.run([str(exe), str(seed), "10000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    big2, _, _ = block_witness_json(oracle, np.random.default_rng(7), n_accounts=6000, n_contracts=60, max_slots=200,
+                                    n_touched=2500, slots_per=8)
+    seed.write_text(json.dumps(node_set_document(big2, np.random.default_rng(2), state_first=True)))
+    assert seed.stat().st_size > (1 << 20)
+    r = subprocess.run([str(exe), str(seed), "400"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
 
 
 def test_member_order_does_not_matter(EA, oracle):
@@ -224,3 +236,65 @@ def test_index_form_agrees_with_the_full_parse(EA, oracle):
             EA.ExecutionWitness.index_json(bad)
     ok = EA.ExecutionWitness.index_json(text.replace('"accountProof": ["0xf', '"accountProof": ["0xg', 1))
     ok.close()  # (not hex, but that is for the GPU to say)
+
+
+def test_node_set_form_of_the_document(EA, oracle):
+    """The same witness with its nodes as a SET (a top-level "state" array, no "accountProof" / "proof" members: what an
+    execution witness is, src/engine_api/execution_payload.zig:121): proofs, roots, preimages as in the per-proof form, `nodes`
+    the array's strings in document order; "state" in front of or behind "accounts"; one thread, many, the index form -- one
+    result; the oracle's node-set verifier over the parsed arrays gives what the construction forces; a document that mixes
+    the forms is refused."""
+    from tests.witness_util import node_set_document
+    rng = np.random.default_rng(21)
+    doc, expected, keys = block_witness_json(oracle, rng)
+    wref = EA.ExecutionWitness.parse_json(json.dumps(doc))  # (kept: info() hands out views of its arrays)
+    ref = wref.info()
+    for state_first in (False, True):
+        sdoc = node_set_document(doc, np.random.default_rng(5), state_first=state_first)
+        text = json.dumps(sdoc, indent=(1 if state_first else None))
+        w = EA.ExecutionWitness.parse_json(text)
+        info = w.info()
+        assert info["node_set"] and not ref["node_set"]
+        for k in ("n_proofs", "n_roots", "n_accounts", "n_slots"):
+            assert info[k] == ref[k]
+        for k in ("roots", "root_idx", "account_of", "preimages", "preimage_off"):
+            assert np.array_equal(info[k], ref[k]), k
+        assert info["total_nodes"] == len(sdoc["state"]) and not info["proof_first_node"].any()
+        for j, nd in enumerate(sdoc["state"]):
+            b, e = int(info["node_off"][j]), int(info["node_off"][j + 1])
+            assert info["nodes"][b:e].tobytes().hex() == nd[2:]
+        st, _, _ = oracle.mpt_verify_nodeset(info["roots"].reshape(-1), info["root_idx"], np.frombuffer(b"".join(keys), np.uint8), 32,
+                                             info["nodes"], info["node_off"])
+        assert st.tolist() == expected
+        for threads in (0, 3):
+            w2 = EA.ExecutionWitness.parse_json(text, threads=threads)
+            i2 = w2.info()
+            assert all(np.array_equal(i2[k], info[k]) for k in info if hasattr(info[k], "shape")) and i2["node_set"]
+            w2.close()
+        w3 = EA.ExecutionWitness.index_json(text, threads=2)
+        i3 = w3.info()
+        assert i3["node_set"] and i3["nodes"].size == 0 and np.array_equal(i3["node_off"], info["node_off"])
+        w3.close()
+        w.close()
+    wref.close()
+    sdoc = node_set_document(doc, np.random.default_rng(5))
+    mixed = json.loads(json.dumps(sdoc))
+    mixed["accounts"][0]["accountProof"] = doc["accounts"][0]["accountProof"]
+    with pytest.raises(EA.WitnessFormatError, match="carries no"):
+        EA.ExecutionWitness.parse_json(json.dumps(mixed))
+    mixed = json.loads(json.dumps(sdoc))
+    mixed["accounts"][-1]["storageProof"][0]["proof"] = []
+    for threads in (1, 4):
+        with pytest.raises(EA.WitnessFormatError, match="carries no"):
+            EA.ExecutionWitness.parse_json(json.dumps(mixed), threads=threads)
+    bad = json.loads(json.dumps(sdoc))
+    bad["state"][len(bad["state"]) // 2] = "0x12zz"
+    errs = set()
+    for threads in (1, 4):
+        with pytest.raises(EA.WitnessFormatError, match="not hex data") as e:
+            EA.ExecutionWitness.parse_json(json.dumps(bad), threads=threads)
+        errs.add(str(e.value))
+    assert len(errs) == 1  # (the same message, byte offset included, whoever decodes the array)
+    dup = json.dumps(sdoc)[:-1] + ', "state": []}'
+    with pytest.raises(EA.WitnessFormatError, match="duplicate"):
+        EA.ExecutionWitness.parse_json(dup)

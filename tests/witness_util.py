@@ -178,6 +178,26 @@ def block_witness_json(oracle, rng, n_accounts=300, n_contracts=12, max_slots=12
     return doc, expected, keys
 
 
+def node_set_document(doc, rng=None, state_first=False):
+    """The node-SET form of an EIP-1186-shaped witness document (include/phant_gpu.h, block witness section): every node of its
+    "accountProof" / "proof" lists ONCE in a top-level "state" array (shuffled with `rng`), those members dropped."""
+    import copy
+    out = copy.deepcopy(doc)
+    nodes = []
+    for a in out["accounts"]:
+        nodes += a.pop("accountProof", [])
+        for sp in a.get("storageProof", []):
+            nodes += sp.pop("proof", [])
+    uniq = list(dict.fromkeys(nodes))
+    if rng is not None:
+        uniq = [uniq[i] for i in rng.permutation(len(uniq))]
+    if state_first:
+        out = {"state": uniq, **out}
+    else:
+        out["state"] = uniq
+    return out
+
+
 def node_set(proofs, rng=None):
     """Union of the nodes of `proofs`, each node once, shuffled: -> (nodes u8[], node_off u64[m+1])."""
     uniq = list(dict.fromkeys(nd for p in proofs for nd in p))
