@@ -298,3 +298,20 @@ def test_node_set_form_of_the_document(EA, oracle):
     dup = json.dumps(sdoc)[:-1] + ', "state": []}'
     with pytest.raises(EA.WitnessFormatError, match="duplicate"):
         EA.ExecutionWitness.parse_json(dup)
+
+
+def test_witness_info_of_a_caller_built_before_round_6(EA, oracle):
+    """phant_witness_info grew a member at its end (node_set): a caller compiled against the shorter struct passes the shorter
+    struct_size and gets everything but that member; anything shorter is refused."""
+    import ctypes as C
+    from phant_amd import _lib as L
+    doc, _, _ = block_witness_json(oracle, np.random.default_rng(3), n_accounts=30, n_contracts=2, n_touched=6)
+    w = EA.ExecutionWitness.parse_json(json.dumps(doc))
+    wi = EA.WitnessInfo()
+    wi.node_set = 0xdeadbeef
+    wi.struct_size = EA.WitnessInfo.node_set.offset  # the struct as it was
+    assert w._lib.phant_witness_get(w._h, C.byref(wi)) == L.OK
+    assert wi.n_proofs == w.info()["n_proofs"] and wi.node_set == 0xdeadbeef  # (not written)
+    wi.struct_size = EA.WitnessInfo.node_set.offset - 1
+    assert w._lib.phant_witness_get(w._h, C.byref(wi)) == L.E_INVALID_ARG
+    w.close()
