@@ -46,3 +46,24 @@ def public_kats():
     come from): a non-zero logs bloom and two address-from-key vectors, which the reference's own goldens lack."""
     with open(os.path.join(_G, "public_kats.json")) as f:
         return json.load(f)
+
+
+def one_transaction_receipts(block):
+    """A fixture block of ONE transaction whose header's logs bloom is zero: its receipt is known up to the status bit --
+    rlp([succeeded, cumulative_gas_used, bloom, logs]) (src/types/receipt.zig:13-35) with cumulative_gas_used = the header's
+    gasUsed, a zero bloom and no logs; behind the transaction's type byte for a typed transaction (EIP-2718: what the fixtures'
+    receiptTrie commits to -- the reference's Receipt.encode has no such prefix yet).  -> [receipt if it succeeded, receipt if
+    it failed], or None for any other block."""
+    if len(block["tx_values"]) != 1 or not block["bloom_is_zero"]:
+        return None
+    tx = bytes.fromhex(block["tx_values"][0])
+    prefix = tx[:1] if tx[0] < 0x80 else b""
+    gas = block["gas_used"]
+    g = gas.to_bytes((gas.bit_length() + 7) // 8, "big")
+    gas_rlp = g if len(g) == 1 and g[0] < 0x80 else bytes([0x80 + len(g)]) + g
+    out = []
+    for status in (b"\x01", b"\x80"):  # (the empty string encodes as 0x80)
+        payload = status + gas_rlp + b"\xb9\x01\x00" + bytes(256) + b"\xc0"
+        ll = (len(payload).bit_length() + 7) // 8
+        out.append(prefix + bytes([0xf7 + ll]) + len(payload).to_bytes(ll, "big") + payload)
+    return out

@@ -22,7 +22,8 @@ them.  Sources:
                         postState -> last blockHeader.stateRoot (cases
                         without expectException), per block the raw tx /
                         withdrawal encodings (decoded out of blocks[].rlp)
-                        -> blockHeader.transactionsTrie / withdrawalsRoot
+                        -> blockHeader.transactionsTrie / withdrawalsRoot; blockHeader.receiptTrie,
+                        gasUsed and whether blockHeader.bloom is zero
 """
 from __future__ import annotations
 
@@ -212,7 +213,13 @@ def make_fixture_roots():
                         continue
                     hdr = b["blockHeader"]
                     txs, wds = block_body(bytes.fromhex(h(b["rlp"])))
-                    blk = {"tx_values": [t.hex() for t in txs], "transactions_trie": h(hdr["transactionsTrie"])}
+                    blk = {"tx_values": [t.hex() for t in txs], "transactions_trie": h(hdr["transactionsTrie"]),
+                           # what the header says about the receipts (src/types/receipt.zig:13-35, blockchain.zig:201): their
+                           # trie's root, the block's gas and whether its logs bloom is all zero -- for a block of ONE
+                           # transaction without logs these ARE the receipt (cumulative gas = gasUsed, bloom = 0, logs = []) up
+                           # to its status bit: tests/test_oracle_golden.py::test_receipt_tries_of_one_transaction_blocks
+                           "receipt_trie": h(hdr["receiptTrie"]), "gas_used": int(hdr["gasUsed"], 16),
+                           "bloom_is_zero": int(h(hdr["bloom"]) or "0", 16) == 0}
                     counts["tx"] += 1
                     if wds is not None and "withdrawalsRoot" in hdr:
                         blk["withdrawal_values"] = [w.hex() for w in wds]

@@ -23,7 +23,7 @@ from tests.test_gpu_trie import (  # noqa: E402,F401
     test_mptize_reference_vectors, test_mptize_rejects_unsorted, test_mptize_random_vs_oracle,
     test_mptize_device_form_matches_host_form_and_oracle,
     test_mptize_variable_length_keys_and_branch_values, test_fixture_tx_and_withdrawal_roots, test_block_roots_in_one_call,
-    test_index_root_be32_vs_oracle, test_receipt_trie_shaped_items, test_fixture_state_roots, test_state_root_random_vs_oracle, test_state_root_orders_its_leaves_on_the_gpu, test_state_root_edge_cases, test_state_root_device_form_and_subtrie_nodes,
+    test_index_root_be32_vs_oracle, test_receipt_trie_shaped_items, test_fixture_receipt_tries_without_an_evm, test_fixture_state_roots, test_state_root_random_vs_oracle, test_state_root_orders_its_leaves_on_the_gpu, test_state_root_edge_cases, test_state_root_device_form_and_subtrie_nodes,
     test_sharded_mptize_matches_the_single_gpu_root)
 from tests.test_gpu_x_state_sharded import (  # noqa: E402,F401
     test_sharded_state_root_matches_the_fixture_roots, test_state_trie_leaves_and_random_states)

@@ -236,6 +236,28 @@ def test_receipt_trie_shaped_items(P, oracle):
         assert P.mpt.index_root_rlp(items) == oracle.index_root_rlp(items)
 
 
+def test_fixture_receipt_tries_without_an_evm(P):
+    """The fixtures' receiptTrie values that need no EVM (tests/golden.py: one_transaction_receipts -- 19 blocks without
+    transactions, 66 blocks of one transaction without logs, whose receipt the header determines up to its status bit): the
+    header's root is the GPU's root of exactly one of the two candidate receipts (calculateMPTRoot,
+    src/blockchain/blockchain.zig:201,209-235), one by one and all candidates of all blocks as ONE forest."""
+    lists, want = [], []
+    for c in golden.fixtures()["cases"]:
+        for b in c["blocks"]:
+            if not b["tx_values"]:
+                assert P.mpt.index_root_rlp([]).hex() == b["receipt_trie"]
+                continue
+            cand = golden.one_transaction_receipts(b)
+            if cand is None:
+                continue
+            roots = [P.mpt.index_root_rlp([r]).hex() for r in cand]
+            assert roots.count(b["receipt_trie"]) == 1, c["name"]
+            lists += [[r] for r in cand]
+            want += roots
+    assert len(want) == 2 * 66
+    assert [r.hex() for r in P.mpt.block_roots(lists)] == want
+
+
 def test_fixture_state_roots(P):
     from tests import suite
     fx = golden.fixtures()
