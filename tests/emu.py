@@ -15,6 +15,7 @@ CSRC = os.path.join(ROOT, "phant_amd", "csrc")
 SOURCES = ["keccak_batch.hip", "bulk_keccak.hip", "mpt_verify.hip", "mpt_verify_v3.hip", "mpt_verify_nodeset.hip", "trie_build.hip", "state_root.hip", "radix_sort.hip",
            "capi.hip", "comm.hip", "witness_json.cpp", "host_rlp.cpp"]
 OUT_DIR = os.path.join(ROOT, "tests", "native", "_build")
+EMU_SMALL_TRIE_KEYS, EMU_NODESET_WAVE_NODES = 300, 600  # (mirror_context: the default CPU suite's bounds of the wave-per-node kernels)
 
 
 
@@ -216,7 +217,15 @@ def mirror_context(lib, mode="flat"):
             rc = lib.phant_ctx_create(C.byref(opts), C.byref(h))
             assert rc == 0, rc
             self._h, self._lib = h, lib
-            from tests import diag
+            from tests import diag, suite
+            if not suite.FULL:
+                # The default CPU suite (tests/suite.py): the one-state-per-wave sponge is ~300 cross-lane operations a permutation,
+                # each a trip through the emulator's scheduler for 64 fibers -- the kernels that give a node a WAVE (the small tries'
+                # pass, node sets of up to 3 500 nodes) are taken up to a few hundred keys / nodes here; beyond that the other passes
+                # run, as they did before round 6.  tests/test_emu_trie.py::test_small_pass_beyond_its_sure_size and
+                # tests/test_emu_nodeset.py::test_a_wave_per_node_beyond_the_emulated_default set the library's own bounds again.
+                self.diag_set("trie_small_max_keys", EMU_SMALL_TRIE_KEYS)
+                self.diag_set("nodeset_wave_max", EMU_NODESET_WAVE_NODES)
             diag.apply(self)
 
         def keccak_rate(self, waves_per_simd=6, perms=100):

@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _emulated_backend():
     # (these runs are about bench.py's plumbing: the node-per-half-wave hash kernel that small batches take -- 32 emulated lanes
     # and ~400 cross-lane operations per permutation -- makes them four times as long; tests/test_emu_verify.py is where it is tested)
-    os.environ["PHANT_TEST_DIAG"] = "verify_no_coop=1"  # (applied to every emulated Context: tests/diag.py)
+    # (the same for node sets of up to 3 500 nodes, a wave per node: tests/test_emu_nodeset.py is where that kernel is tested)
+    os.environ["PHANT_TEST_DIAG"] = "verify_no_coop=1,nodeset_wave_max=0"  # (applied to every emulated Context: tests/diag.py)
     try:
         yield from emu.emulated_backend()
     finally:
@@ -394,7 +395,7 @@ def test_gpus_2_without_torchrun_relaunches_itself(tmp_path):
     entry = tmp_path / "bench_entry.py"
     entry.write_text(_ENTRY_SCRIPT.format(root=ROOT))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(PHANT_BENCH_BACKEND="gloo", PHANT_BENCH_ENTRY=str(entry), PHANT_TEST_DIAG="verify_no_coop=1")
+    env.update(PHANT_BENCH_BACKEND="gloo", PHANT_BENCH_ENTRY=str(entry), PHANT_TEST_DIAG="verify_no_coop=1,nodeset_wave_max=0")
     argv = ["--gpus", "2", "--proofs", "200", "--steps", "1", "--warmup", "0", "--inner", "1", "--no-strong", "--no-cpu-baseline",
             "--max-seconds", "600"]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, cwd=ROOT, capture_output=True, text=True,

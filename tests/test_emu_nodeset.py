@@ -69,3 +69,29 @@ def test_small_sets_through_the_class_lists_as_well():
                         "not through_the_class_lists"], cwd=root, env=dict(os.environ, PHANT_TEST_DIAG="nodeset_wave_max=0"),
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and " passed" in r.stdout and " failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_a_wave_per_node_beyond_the_emulated_default(M, oracle):
+    """set_hash_wave_kernel on a set of ~700 nodes (the emulated contexts of the default CPU suite give a node a wave up to 600
+    nodes only: tests/emu.py) -- with the library's own bound, against the oracle."""
+    from phant_amd.context import default_context
+    from tests.witness_util import random_kv
+    from tests import emu as E, suite
+    ctx = default_context()
+    ctx.diag_set("nodeset_wave_max", 3500)
+    try:
+        rng = np.random.default_rng(900)
+        keys, vals = random_kv(rng, 3000, 32, 40, 80, 0)
+        trie = oracle.Trie(keys, vals)
+        ask = [keys[int(i)] for i in rng.permutation(3000)[:420]] + [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(8)]
+        nodes = list(dict.fromkeys(nd for k in ask for nd in trie.prove(k)))
+        assert 600 < len(nodes) < 3500
+        nodes = [nodes[int(i)] for i in rng.permutation(len(nodes))]
+        blob = np.frombuffer(b"".join(nodes), np.uint8)
+        off = np.concatenate([[0], np.cumsum([len(x) for x in nodes])]).astype(np.uint64)
+        r, k = np.frombuffer(trie.root(), np.uint8), np.frombuffer(b"".join(ask), np.uint8)
+        got = M.verify_nodeset(r, None, k, 32, blob, off, ctx=ctx)
+        want = oracle.mpt_verify_nodeset(r, None, k, 32, blob, off)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want)) and set(got[0].tolist()) == {1, 2}
+    finally:
+        ctx.diag_set("nodeset_wave_max", 3500 if suite.FULL else E.EMU_NODESET_WAVE_NODES)

@@ -29,7 +29,7 @@ def test_results_do_not_depend_on_the_execution_order():
              "(flat or levels3 or levels16) and (random_tries or mutation or hostile_index_arrays_match or synthetic_block)"),
             (11, "0xff", ["tests/test_emu_verify.py"],
              "(levels1 or nodedup) and (random_tries or mutation or non_monotone)"),
-            (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py",
+            (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_state.py", "tests/test_emu_bulk.py",
                          "tests/test_emu_witness.py"],
              "not 20000 and not fixture_state"))
     else:  # (the default CPU suite: tests/suite.py)
@@ -37,7 +37,8 @@ def test_results_do_not_depend_on_the_execution_order():
             (3, "0x00", ["tests/test_emu_verify.py"], "(flat or levels3) and (random_tries or mutation)"),
             (11, "0xff", ["tests/test_emu_verify.py"], "(nodedup or levels16) and (random_tries or mutation or non_monotone)"),
             (5, "0x01", ["tests/test_emu_nodeset.py", "tests/test_emu_trie.py", "tests/test_emu_bulk.py", "tests/test_emu_witness.py"],
-             "not 20000 and not fixture_state and not sharded and not orders_its_leaves and not state_trie_leaves and not device_form"))
+             "not 20000 and not fixture_state and not sharded and not orders_its_leaves and not state_trie_leaves and not device_form "
+             "and not through_the_class_lists and not fixture_tx and not block_roots and not receipt_tries_without"))
     for seed, fill, modules, expr in plan:
         cmd = [sys.executable, "-m", "pytest", *modules, "-x", "-q", "-p", "no:cacheprovider"]
         if expr:

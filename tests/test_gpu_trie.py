@@ -175,7 +175,9 @@ def test_block_roots_in_one_call(P, oracle):
     assert n == 87
     rng = np.random.default_rng(11)
     mk = lambda k, lo, hi: [rng.integers(0, 256, int(rng.integers(lo, hi)), dtype=np.uint8).tobytes() for _ in range(k)]  # noqa: E731
-    for sizes in ((0, 0, 0), (1, 1, 0), (127, 127, 16), (128, 129, 1), (400, 400, 400), (3, 0, 129), (1400, 1300, 16)):
+    from tests import suite
+    # (a full block's lists: on the GPU and in the full CPU suite -- 2 700 waves of long leaves are minutes on the emulator)
+    for sizes in ((0, 0, 0), (1, 1, 0), (127, 127, 16), (128, 129, 1), (400, 400, 400), (3, 0, 129)) + suite.scale(((1400, 1300, 16),), ()):
         lists = [mk(sizes[0], 100, 300), mk(sizes[1], 300, 700), mk(sizes[2], 40, 60)]
         got = P.mpt.block_roots(lists)
         assert got == [oracle.index_root_rlp(x) for x in lists], sizes
@@ -416,7 +418,8 @@ def test_state_root_device_form_and_subtrie_nodes(P, oracle):
         assert bytes(got.cpu().numpy().tobytes()).hex() == c["genesis_state_root"], c["name"]
     rng = np.random.default_rng(77)
     acc = []
-    for _ in range(900):
+    from tests import suite
+    for _ in range(suite.scale(900, 250)):  # (the default CPU suite's emulated run: fewer accounts, tests/suite.py)
         st = {int(rng.integers(0, 2 ** 62)): int(rng.integers(0, 3)) * int(rng.integers(1, 2 ** 62)) for _ in range(int(rng.integers(0, 6)))}
         acc.append(dict(addr=rng.integers(0, 256, 20, dtype=np.uint8).tobytes(), nonce=int(rng.integers(0, 1000)),
                         balance=int(rng.integers(0, 2 ** 62)) ** 2,
@@ -501,3 +504,15 @@ def test_small_tries_from_two_threads(P, oracle):
     for x in th:
         x.join()
     assert got[0] == want and got[1] == want
+
+
+def test_packed_forms_of_the_index_roots(P, oracle):
+    """pack_items / index_root_rlp_packed / block_roots_packed (the C-ABI's own argument form: a blob + offsets per list, what a
+    compiled caller holds) against the list forms and the oracle, empty lists included."""
+    rng = np.random.default_rng(8)
+    mk = lambda k, lo, hi: [rng.integers(0, 256, int(rng.integers(lo, hi)), dtype=np.uint8).tobytes() for _ in range(k)]  # noqa: E731
+    lists = [mk(130, 100, 300), [], mk(7, 300, 700), mk(1, 40, 60)]
+    packed = [P.mpt.pack_items(x) for x in lists]
+    want = [oracle.index_root_rlp(x) for x in lists]
+    assert P.mpt.block_roots_packed(packed) == want == P.mpt.block_roots(lists)
+    assert [P.mpt.index_root_rlp_packed(*p) for p in packed] == want

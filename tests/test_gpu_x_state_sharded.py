@@ -56,9 +56,10 @@ def test_sharded_state_root_matches_the_fixture_roots(P):
 
 def test_state_trie_leaves_and_random_states(P, oracle):
     from phant_amd import shard
+    from tests import suite
     rng = np.random.default_rng(12)
     acc = []
-    for _ in range(700):
+    for _ in range(suite.scale(700, 200)):  # (the default CPU suite's emulated run: fewer accounts, tests/suite.py)
         st = {int(rng.integers(0, 2 ** 62)): int(rng.integers(0, 3)) * int(rng.integers(1, 2 ** 62))
               for _ in range(int(rng.integers(0, 5)))}
         acc.append(dict(addr=rng.integers(0, 256, 20, dtype=np.uint8).tobytes(), nonce=int(rng.integers(0, 1000)),
