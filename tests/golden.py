@@ -67,3 +67,31 @@ def one_transaction_receipts(block):
         ll = (len(payload).bit_length() + 7) // 8
         out.append(prefix + bytes([0xf7 + ll]) + len(payload).to_bytes(ll, "big") + payload)
     return out
+
+
+def _receipt(prefix, status, gas):
+    g = gas.to_bytes((gas.bit_length() + 7) // 8, "big")
+    gas_rlp = g if len(g) == 1 and g[0] < 0x80 else bytes([0x80 + len(g)]) + g
+    payload = status + gas_rlp + b"\xb9\x01\x00" + bytes(256) + b"\xc0"
+    ll = (len(payload).bit_length() + 7) // 8
+    return prefix + bytes([0xf7 + ll]) + len(payload).to_bytes(ll, "big") + payload
+
+
+def two_transaction_receipts(block, root_of):
+    """A fixture block of TWO transactions without logs: the second receipt's cumulative gas is the header's gasUsed, the first
+    one's is some g0 in [21 000, gasUsed - 21 000] (a transaction costs 21 000 at least) -- `root_of([r0, r1])` over every g0 and
+    the four status combinations must hit the header's receiptTrie exactly once.  -> the receipts that do (a search: ~180 000
+    roots of two-item tries, seconds with the C oracle), or None for any other block."""
+    if len(block["tx_values"]) != 2 or not block["bloom_is_zero"]:
+        return None
+    pre = [bytes.fromhex(t)[:1] if bytes.fromhex(t)[0] < 0x80 else b"" for t in block["tx_values"]]
+    want, total, hits = bytes.fromhex(block["receipt_trie"]), block["gas_used"], []
+    for g0 in range(21000, total - 21000 + 1):
+        for s0 in (b"\x01", b"\x80"):
+            r0 = _receipt(pre[0], s0, g0)
+            for s1 in (b"\x01", b"\x80"):
+                cand = [r0, _receipt(pre[1], s1, total)]
+                if root_of(cand) == want:
+                    hits.append(cand)
+    assert len(hits) == 1, len(hits)
+    return hits[0]

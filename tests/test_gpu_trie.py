@@ -239,10 +239,10 @@ def test_receipt_trie_shaped_items(P, oracle):
 
 
 def test_fixture_receipt_tries_without_an_evm(P):
-    """The fixtures' receiptTrie values that need no EVM (tests/golden.py: one_transaction_receipts -- 19 blocks without
-    transactions, 66 blocks of one transaction without logs, whose receipt the header determines up to its status bit): the
-    header's root is the GPU's root of exactly one of the two candidate receipts (calculateMPTRoot,
-    src/blockchain/blockchain.zig:201,209-235), one by one and all candidates of all blocks as ONE forest."""
+    """The fixtures' 87 receiptTrie values without an EVM (tests/golden.py: 19 blocks without transactions; 66 blocks of one
+    transaction without logs, whose receipt the header determines up to its status bit; 2 blocks of two, whose first receipt's gas
+    is searched for): the header's root is the GPU's root of exactly one of the candidate receipts (calculateMPTRoot,
+    src/blockchain/blockchain.zig:201,209-235), one by one and all one-transaction candidates as ONE forest."""
     lists, want = [], []
     for c in golden.fixtures()["cases"]:
         for b in c["blocks"]:
@@ -258,6 +258,18 @@ def test_fixture_receipt_tries_without_an_evm(P):
             want += roots
     assert len(want) == 2 * 66
     assert [r.hex() for r in P.mpt.block_roots(lists)] == want
+    # the two blocks of TWO transactions: which (gas, status, status) the header commits to is found with the oracle
+    # (tests/golden.py: two_transaction_receipts, a search), the GPU must give those two receipts the header's root
+    from oracle import oracle as O
+    found = {}
+    for c in golden.fixtures()["cases"]:
+        for b in c["blocks"]:
+            if len(b["tx_values"]) == 2:
+                key = (b["receipt_trie"], b["gas_used"])
+                if key not in found:
+                    found[key] = golden.two_transaction_receipts(b, O.index_root_rlp)
+                assert P.mpt.index_root_rlp(found[key]).hex() == b["receipt_trie"]
+    assert len(found) == 1
 
 
 def test_fixture_state_roots(P):

@@ -105,3 +105,22 @@ def test_receipt_tries_of_empty_and_one_transaction_blocks(oracle):
             assert roots.count(b["receipt_trie"]) == 1, c["name"]
             n1 += 1
     assert (n0, n1) == (19, 66)
+
+
+def test_receipt_tries_of_the_two_transaction_blocks(oracle):
+    """The other two of the 87: two transactions without logs -- the first receipt's cumulative gas is not in the header, so every
+    value it can have is tried (tests/golden.py: two_transaction_receipts); exactly one (gas, status, status) has the header's
+    root, and it is the plain one: both succeeded."""
+    n = 0
+    seen = {}
+    for c in golden.fixtures()["cases"]:
+        for b in c["blocks"]:
+            if len(b["tx_values"]) != 2:
+                continue
+            key = (b["receipt_trie"], b["gas_used"], tuple(b["tx_values"]))
+            if key not in seen:  # (the two blocks are the same block of two fixture files)
+                seen[key] = golden.two_transaction_receipts(b, oracle.index_root_rlp)
+            r0, r1 = seen[key]
+            assert r0[3:4] == b"\x01" and r1[3:4] == b"\x01"  # f9 01 LL | status ...
+            n += 1
+    assert n == 2
