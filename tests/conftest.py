@@ -19,7 +19,8 @@ def pytest_configure(config):
 def pytest_cmdline_main(config):
     """`-m "not gpu"` with no -n of the caller's: the suite's time is the kernel sources running on the host (tests/emu.py), one
     core at a time -- its MODULES are spread over a few pytest-xdist workers (a module stays in one process: the emulated
-    library, its contexts and the environment knobs are module-scoped).  Half an hour becomes 7 minutes on eight cores.
+    library, its contexts and the environment knobs are module-scoped).  Forty minutes become ~10 on eight cores
+    (round 6: the wave-per-node kernels cost the emulator 300 cross-lane operations a permutation; tests/emu.py bounds them).
     PHANT_CPU_SUITE_WORKERS=0 keeps everything in this process; `-m gpu` is never touched (one GPU, one process)."""
     opt = config.option
     if (getattr(opt, "markexpr", "") or "").strip() != "not gpu" or getattr(opt, "numprocesses", None) is not None:
